@@ -1,0 +1,244 @@
+"""Seeded synthetic inputs: an SMPL-X-*shaped* body model and 2-D keypoint frames.
+
+The licensed ``SMPLX_{NEUTRAL,MALE,FEMALE}.npz`` files cannot ship, so tests, the
+benchmark and the smoke run use a deterministic stand-in with exactly the keys and
+shapes ``smplx.SMPLX`` consumes (reference call site
+``smplifyx/main.py:109-127``): V=10475 vertices, F=20908 faces, 55 joints with the
+true SMPL-X parent table, 486 pose-blendshape rows, 10+10 shape/expression
+directions, 45x45 hand PCA bases, 51 static + 79x17 dynamic face landmarks.
+The geometry is a crude humanoid (vertices scattered around the bones of a T-pose
+skeleton, <=4 skinning weights per vertex) so that fits behave like fits of a body.
+
+Pure numpy (+scipy cKDTree); nothing here touches the GPU or the oracle.
+"""
+import numpy as np
+
+NUM_JOINTS = 55
+NUM_VERTS = 10475
+NUM_FACES = 20908
+NUM_POSE_BASIS = 9 * (NUM_JOINTS - 1)
+
+# SMPL-X kinematic tree (kintree_table row 0; parents[0] = -1)
+SMPLX_PARENTS = np.array(
+    [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19,
+     15, 15, 15, 20, 25, 26, 20, 28, 29, 20, 31, 32, 20, 34, 35, 20, 37, 38,
+     21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50, 21, 52, 53], dtype=np.int64)
+
+# Vertex picks appended as joints 55..75 by smplx.VertexJointSelector for the real
+# SMPL-X topology (nose, reye, leye, rear, lear, 6 feet, 5 left tips, 5 right tips)
+SMPLX_EXTRA_VERTEX_IDS = np.array(
+    [9120, 9929, 9448, 616, 6,
+     5770, 5780, 8846, 8463, 8474, 8635,
+     5361, 4933, 5058, 5169, 5286,
+     8079, 7669, 7794, 7905, 8022], dtype=np.int64)
+
+
+def _rest_skeleton():
+    """Approximate SMPL-X T-pose joint positions [55,3] (metres, y up, +x = left)."""
+    J = np.zeros((55, 3), np.float64)
+    J[0] = (0.0, 0.0, 0.0)
+    J[1] = (0.06, -0.09, 0.0);   J[2] = (-0.06, -0.09, 0.0)
+    J[3] = (0.0, 0.11, -0.02)
+    J[4] = (0.10, -0.47, 0.0);   J[5] = (-0.10, -0.47, 0.0)
+    J[6] = (0.0, 0.25, 0.0)
+    J[7] = (0.09, -0.87, -0.03); J[8] = (-0.09, -0.87, -0.03)
+    J[9] = (0.0, 0.30, 0.02)
+    J[10] = (0.12, -0.93, 0.09); J[11] = (-0.12, -0.93, 0.09)
+    J[12] = (0.0, 0.51, -0.02)
+    J[13] = (0.08, 0.42, -0.01); J[14] = (-0.08, 0.42, -0.01)
+    J[15] = (0.0, 0.58, 0.02)
+    J[16] = (0.19, 0.45, -0.02); J[17] = (-0.19, 0.45, -0.02)
+    J[18] = (0.45, 0.44, -0.03); J[19] = (-0.45, 0.44, -0.03)
+    J[20] = (0.70, 0.45, -0.03); J[21] = (-0.70, 0.45, -0.03)
+    J[22] = (0.0, 0.56, 0.05)
+    J[23] = (0.03, 0.63, 0.08);  J[24] = (-0.03, 0.63, 0.08)
+    # fingers: order index, middle, pinky, ring, thumb; 3 joints each
+    zf = [0.03, 0.01, -0.03, -0.01, 0.05]
+    for side, base, wrist in ((1.0, 25, 20), (-1.0, 40, 21)):
+        for f in range(5):
+            for k in range(3):
+                x = 0.09 + 0.03 * k if f < 4 else 0.03 + 0.025 * k
+                y = 0.0 if f < 4 else -0.02
+                J[base + 3 * f + k] = J[wrist] + (side * x, y, zf[f])
+    return J
+
+
+def _bone_radius(j):
+    if j in (0, 3, 6, 9):
+        return 0.10
+    if j in (12, 15, 22, 23, 24):
+        return 0.06
+    if j in (1, 2, 4, 5):
+        return 0.06
+    if j >= 25:
+        return 0.007
+    return 0.04
+
+
+def make_synthetic_model(seed=0, num_verts=NUM_VERTS, num_faces=NUM_FACES,
+                         dtype=np.float32):
+    """Return a dict with the key set of an SMPL-X ``.npz`` (appendix A.1) plus
+    ``extra_vertex_ids`` (the 21 vertex-joint picks valid for this geometry).
+    Deterministic in ``seed``."""
+    from scipy.spatial import cKDTree
+    rng = np.random.RandomState(seed)
+    V, F, J = num_verts, num_faces, NUM_JOINTS
+    parents = SMPLX_PARENTS
+    Jrest = _rest_skeleton()
+
+    # ---- vertices scattered around bones -------------------------------------------
+    share = np.ones(J)
+    share[[0, 3, 6, 9]] = 6.0      # torso
+    share[[12, 15]] = 4.0          # neck/head
+    share[[22, 23, 24]] = 2.0      # face
+    share[[1, 2, 4, 5, 7, 8]] = 3.0
+    share[[16, 17, 18, 19, 20, 21]] = 2.5
+    share[25:] = 0.6
+    bone_of = rng.choice(J, size=V, p=share / share.sum())
+    t = rng.uniform(0.0, 1.0, size=V)
+    v_template = np.zeros((V, 3))
+    weights = np.zeros((V, J))
+    for j in range(J):
+        idx = np.nonzero(bone_of == j)[0]
+        if idx.size == 0:
+            continue
+        p = parents[j]
+        a = Jrest[p] if p >= 0 else Jrest[j] + np.array([0.0, -0.08, 0.0])
+        b = Jrest[j]
+        tt = t[idx][:, None]
+        pts = a * (1 - tt) + b * tt + rng.normal(0, _bone_radius(j), (idx.size, 3))
+        v_template[idx] = pts
+        # <=4 nonzero skinning weights: bone owner (parent joint), this joint,
+        # grand-parent and one child-side neighbour, blended along the bone
+        own = p if p >= 0 else j
+        w_this = 0.15 + 0.7 * t[idx] ** 2
+        weights[idx, j] += w_this
+        weights[idx, own] += (1.0 - w_this) * 0.85
+        gp = parents[own] if own >= 0 and parents[own] >= 0 else own
+        weights[idx, gp] += (1.0 - w_this) * 0.15
+    weights /= weights.sum(axis=1, keepdims=True)
+
+    # ---- joint regressor: sparse, row-stochastic, local --------------------------------
+    tree = cKDTree(v_template)
+    J_regressor = np.zeros((J, V))
+    for j in range(J):
+        d, nn = tree.query(Jrest[j], k=24)
+        w = np.exp(-(d / (d.mean() + 1e-9)) ** 2)
+        J_regressor[j, nn] = w / w.sum()
+
+    # ---- blend shapes ---------------------------------------------------------------
+    shapedirs = 0.01 * rng.normal(size=(V, 3, 20))
+    # make the first three shape directions smooth (height / girth / limb length)
+    shapedirs[:, :, 0] += 0.03 * v_template * np.array([0.3, 1.0, 0.3])
+    shapedirs[:, :, 1] += 0.03 * v_template * np.array([1.0, 0.1, 1.0])
+    shapedirs[:, :, 2] += 0.02 * v_template * np.array([1.0, 0.0, 0.0])
+    posedirs = 0.001 * rng.normal(size=(V, 3, NUM_POSE_BASIS))
+
+    # ---- faces: each vertex + two of its near neighbours ------------------------------
+    _, nbr = tree.query(v_template, k=8)
+    fa = rng.randint(0, V, size=F)
+    pick = np.stack([rng.permutation(7)[:2] + 1 for _ in range(64)])
+    pk = pick[rng.randint(0, 64, size=F)]
+    faces = np.stack([fa, nbr[fa, pk[:, 0]], nbr[fa, pk[:, 1]]], axis=1)
+
+    # ---- hands PCA ------------------------------------------------------------------
+    ql, _ = np.linalg.qr(rng.normal(size=(45, 45)))
+    qr_, _ = np.linalg.qr(rng.normal(size=(45, 45)))
+    hands_meanl = 0.1 * rng.normal(size=45)
+    hands_meanr = 0.1 * rng.normal(size=45)
+
+    # ---- landmarks: faces whose first vertex lies in the head region -------------------
+    head_c = Jrest[15] + np.array([0.0, 0.04, 0.05])
+    dist_head = np.linalg.norm(v_template[faces[:, 0]] - head_c, axis=1)
+    head_faces = np.argsort(dist_head)[:600]
+    lmk_faces_idx = rng.choice(head_faces, size=51, replace=False)
+    lmk_bary = rng.dirichlet(np.ones(3), size=51)
+    dyn_faces = rng.choice(head_faces, size=(79, 17))
+    dyn_bary = rng.dirichlet(np.ones(3), size=(79, 17))
+
+    # ---- vertex joints (nose, eyes, ears, feet, finger tips) ---------------------------
+    targets = [
+        Jrest[15] + (0.0, 0.03, 0.13),                       # nose
+        Jrest[24] + (0.0, 0.0, 0.02), Jrest[23] + (0.0, 0.0, 0.02),   # reye, leye
+        Jrest[15] + (-0.08, 0.03, 0.0), Jrest[15] + (0.08, 0.03, 0.0),  # rear, lear
+        Jrest[10] + (0.02, -0.02, 0.06), Jrest[10] + (0.06, -0.02, 0.04),
+        Jrest[7] + (0.0, -0.06, -0.05),                      # LBigToe LSmallToe LHeel
+        Jrest[11] + (-0.02, -0.02, 0.06), Jrest[11] + (-0.06, -0.02, 0.04),
+        Jrest[8] + (0.0, -0.06, -0.05),                      # R toes, heel
+    ]
+    for base, side in ((25, 1.0), (40, -1.0)):               # tips: thumb,index,middle,ring,pinky
+        for f in (4, 0, 1, 3, 2):
+            targets.append(Jrest[base + 3 * f + 2] + (side * 0.025, 0.0, 0.0))
+    extra = []
+    used = set()
+    for tg in targets:
+        _, cand = tree.query(np.asarray(tg, np.float64), k=16)
+        pickv = next(int(c) for c in cand if int(c) not in used)
+        used.add(pickv)
+        extra.append(pickv)
+
+    model = dict(
+        v_template=v_template.astype(dtype),
+        f=faces.astype(np.uint32),
+        shapedirs=shapedirs.astype(dtype),
+        posedirs=posedirs.astype(dtype),
+        J_regressor=J_regressor.astype(dtype),
+        weights=weights.astype(dtype),
+        kintree_table=np.stack([parents, np.arange(J)]).astype(np.int64),
+        hands_componentsl=ql.T.astype(dtype), hands_componentsr=qr_.T.astype(dtype),
+        hands_meanl=hands_meanl.astype(dtype), hands_meanr=hands_meanr.astype(dtype),
+        lmk_faces_idx=lmk_faces_idx.astype(np.int64),
+        lmk_bary_coords=lmk_bary.astype(dtype),
+        dynamic_lmk_faces_idx=dyn_faces.astype(np.int64),
+        dynamic_lmk_bary_coords=dyn_bary.astype(dtype),
+        extra_vertex_ids=np.asarray(extra, np.int64),
+    )
+    model["kintree_table"][0, 0] = -1
+    return model
+
+
+def make_synthetic_vposer(seed=0, latent=32, hidden=512, dtype=np.float32):
+    """Random-init VPoser-v1 *decoder* weights (appendix A.3): fc1 32->512,
+    fc2 512->512, out 512->126, leaky_relu(0.2).  Scaled so decoded poses are O(0.3 rad)."""
+    rng = np.random.RandomState(1000 + seed)
+    def lin(i, o, s):
+        return (rng.normal(size=(o, i)) * s / np.sqrt(i)).astype(dtype), \
+               (0.01 * rng.normal(size=o)).astype(dtype)
+    w1, b1 = lin(latent, hidden, 1.0)
+    w2, b2 = lin(hidden, hidden, 1.0)
+    w3, b3 = lin(hidden, 126, 0.4)
+    # bias the 6-D output towards identity so z = 0 decodes near the rest pose
+    ident6 = np.tile(np.array([1, 0, 0, 1, 0, 0], dtype), 21)   # view(-1,3,2): cols (1,0,0),(0,1,0)
+    b3 = b3 + ident6
+    return dict(fc1_w=w1, fc1_b=b1, fc2_w=w2, fc2_b=b2, out_w=w3, out_b=b3)
+
+
+def rodrigues_np(theta):
+    """Plain (eps-free) Rodrigues for data generation, [..,3] -> [..,3,3]."""
+    theta = np.asarray(theta, np.float64)
+    ang = np.linalg.norm(theta, axis=-1, keepdims=True)
+    ax = theta / np.maximum(ang, 1e-12)
+    K = np.zeros(theta.shape[:-1] + (3, 3))
+    K[..., 0, 1] = -ax[..., 2]; K[..., 0, 2] = ax[..., 1]
+    K[..., 1, 0] = ax[..., 2];  K[..., 1, 2] = -ax[..., 0]
+    K[..., 2, 0] = -ax[..., 1]; K[..., 2, 1] = ax[..., 0]
+    s = np.sin(ang)[..., None]; c = np.cos(ang)[..., None]
+    return np.eye(3) + s * K + (1 - c) * (K @ K)
+
+
+def make_frame_truth(index, seed=0):
+    """Ground-truth parameters of synthetic frame ``index``: per-frame
+    RandomState(seed*1_000_003 + index) so any shard regenerates identical frames."""
+    rng = np.random.RandomState((seed * 1000003 + index) % (2 ** 31 - 1))
+    truth = dict(
+        body_pose=0.15 * rng.normal(size=63),
+        global_orient=0.2 * rng.normal(size=3),
+        betas=rng.normal(size=10),
+        cam_t=np.array([rng.uniform(-.2, .2), rng.uniform(-.2, .2), rng.uniform(12., 24.)]),
+        prior_noise=0.05 * rng.normal(size=63),
+        prior_noise_go=0.05 * rng.normal(size=3),
+        kp_noise=rng.normal(size=(144, 2)),
+        conf=rng.uniform(0.3, 1.0, size=144),
+        conf_drop=rng.uniform(size=144) < 0.10,
+    )
+    return truth

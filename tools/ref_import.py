@@ -1,0 +1,60 @@
+"""Import the reference's in-tree hot-path modules in THIS container (never on the GPU
+box: /root/reference does not exist there and nothing under tests/-m gpu, smoke() or
+bench.py imports this file).
+
+The reference imports visualisation-only packages that are not installed
+(open3d, trimesh, pyrender, cv2, plyfile, human_body_prior, configargparse, smplx):
+they are replaced by MagicMock stubs, except `smplx.lbs.transform_mat`, a 2-line pure
+function the camera needs (smplifyx/camera.py:27,102), which is supplied from the
+oracle restatement.  No reference source is copied; modules are imported from where
+they lie.
+"""
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+REF_ROOT = os.environ.get("SFX_REFERENCE_ROOT", "/root/reference")
+REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def available():
+    return os.path.isdir(os.path.join(REF_ROOT, "smplifyx"))
+
+
+def import_reference():
+    """Returns a namespace with the reference modules:
+    fitting, camera, prior, utils, lbfgs_ls, optim_factory, fit_single_frame."""
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REF_ROOT)
+    if REPO_ROOT not in sys.path:
+        sys.path.insert(0, REPO_ROOT)
+    from oracle.body_model import transform_mat
+    for name in ["open3d", "skimage", "skimage.io", "skimage.transform", "trimesh", "pyrender",
+                 "cv2", "plyfile", "human_body_prior", "human_body_prior.tools",
+                 "human_body_prior.tools.model_loader",
+                 "human_body_prior.tools.visualization_tools",
+                 "human_body_prior.body_model", "human_body_prior.body_model.body_model",
+                 "configargparse", "mesh_viewer"]:
+        if name not in sys.modules:
+            sys.modules[name] = MagicMock()
+    if "smplx" not in sys.modules or isinstance(sys.modules["smplx"], MagicMock):
+        smplx = types.ModuleType("smplx")
+        lbs = types.ModuleType("smplx.lbs")
+        lbs.transform_mat = transform_mat
+        smplx.lbs = lbs
+        sys.modules["smplx"] = smplx
+        sys.modules["smplx.lbs"] = lbs
+    ref_pkg = os.path.join(REF_ROOT, "smplifyx")
+    if ref_pkg not in sys.path:
+        sys.path.insert(0, ref_pkg)
+    import importlib
+    ns = types.SimpleNamespace()
+    ns.utils = importlib.import_module("utils")
+    ns.prior = importlib.import_module("prior")
+    ns.camera = importlib.import_module("camera")
+    ns.fitting = importlib.import_module("fitting")
+    ns.lbfgs_ls = importlib.import_module("optimizers.lbfgs_ls")
+    ns.optim_factory = importlib.import_module("optimizers.optim_factory")
+    ns.fit_single_frame = importlib.import_module("fit_single_frame")
+    return ns
