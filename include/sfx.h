@@ -1,0 +1,186 @@
+/* sfx.h -- C ABI of libsfx.so, the MI355X (gfx950) SMPL-X fitting engine.
+ *
+ * The reference (xiyichen/smplify-x-partial) has no FFI seam: its hot path is a chain of
+ * Python objects.  This header is the boundary the replacement defines
+ * UNDER that Python surface; each entry point names the reference interface it stands
+ * in for.  Plain pointers and sizes only -- no torch types.  Unless stated otherwise a
+ * `const float*` / `const int32_t*` argument is a HOST pointer read during the call; a
+ * `*_dev` argument is a DEVICE pointer (e.g. torch.Tensor.data_ptr()); `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  No ownership is transferred.
+ * One model/batch handle per GPU; handles are thread-compatible, not thread-safe.
+ * Every function returns 0 on success or a negative code; sfx_last_error() describes it.
+ */
+#ifndef SFX_H_
+#define SFX_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sfx_model sfx_model;   /* model constants resident in HBM            */
+typedef struct sfx_batch sfx_batch;   /* B frames: parameters, data, optimiser state */
+
+/* ---- model -------------------------------------------------------------------------
+ * Replaces smplx.create(...) / smplx.SMPLX.__init__ (reference call site
+ * smplifyx/main.py:109-127; file keys SURVEY.md appendix A.1).  Arrays use the .npz
+ * layouts; the library re-lays them out for the GPU (k-major blend-shape matrix for the
+ * dense MFMA GEMM, vertex-major copy for the needed-rows path, folded joint regressor). */
+typedef struct sfx_model_desc {
+    int32_t V, F, J;              /* 10475, 20908, 55                                  */
+    int32_t num_betas, num_expr;  /* 10, 10                                            */
+    int32_t num_pca;              /* hand PCA comps used (12); 0 = hands given as 45-D */
+    const float*   v_template;    /* [V][3]                                            */
+    const float*   shapedirs;     /* [V][3][num_betas+num_expr] (betas then expression)*/
+    const float*   posedirs;      /* [V][3][9*(J-1)]                                   */
+    const float*   J_regressor;   /* [J][V]                                            */
+    const float*   lbs_weights;   /* [V][J]                                            */
+    const int32_t* parents;       /* [J], parents[0] = -1                              */
+    const float*   hands_comp_l;  /* [num_pca][45]                                     */
+    const float*   hands_comp_r;  /* [num_pca][45]                                     */
+    const float*   pose_mean;     /* [3*J]                                             */
+    const int32_t* faces;         /* [F][3]                                            */
+    int32_t        n_extra;       /* 21 vertex joints (VertexJointSelector)            */
+    const int32_t* extra_vertex_ids;
+    int32_t        n_lmk;         /* 51 static landmarks                               */
+    const int32_t* lmk_faces_idx; /* [n_lmk]                                           */
+    const float*   lmk_bary;      /* [n_lmk][3]                                        */
+    int32_t        n_dyn_rows, n_dyn;  /* 79, 17 (0,0 = no face contour)               */
+    const int32_t* dyn_lmk_faces_idx;  /* [n_dyn_rows][n_dyn]                          */
+    const float*   dyn_lmk_bary;       /* [n_dyn_rows][n_dyn][3]                       */
+    int32_t        K;             /* joints after joint_mapper                         */
+    const int32_t* joint_map;     /* [K] indices into the 55+n_extra+n_lmk+n_dyn list
+                                     (utils.JointMapper, smplifyx/utils.py:68-81)      */
+} sfx_model_desc;
+
+int  sfx_model_create(const sfx_model_desc* desc, sfx_model** out);
+void sfx_model_destroy(sfx_model* m);
+
+/* VPoser-v1 decoder weights (human_body_prior cvpr19; reference call sites
+ * fit_single_frame.py:241-245, fitting.py:236-238): fc1 [H][L], fc2 [H][H], out [126][H]. */
+int  sfx_model_set_vposer(sfx_model* m, int32_t latent, int32_t hidden,
+                          const float* fc1_w, const float* fc1_b,
+                          const float* fc2_w, const float* fc2_b,
+                          const float* out_w, const float* out_b);
+
+/* ---- stand-alone LBS forward ----------------------------------------------------------
+ * Replaces body_model(return_verts=True, body_pose=..., return_full_pose=True)
+ * (fitting.py:82,248; fit_single_frame.py:611).  All pointers are DEVICE pointers to
+ * contiguous fp32; any output may be NULL.  `hands` are PCA coefficients [B][num_pca]. */
+int  sfx_lbs_forward(sfx_model* m, int32_t B,
+                     const float* global_orient_dev,   /* [B][3]  */
+                     const float* body_pose_dev,       /* [B][63] */
+                     const float* betas_dev,           /* [B][num_betas] */
+                     const float* expression_dev,      /* [B][num_expr]  */
+                     const float* jaw_dev, const float* leye_dev, const float* reye_dev, /* [B][3] */
+                     const float* lhand_dev, const float* rhand_dev,   /* [B][num_pca] */
+                     float* vertices_out_dev,          /* [B][V][3]  or NULL */
+                     float* joints_out_dev,            /* [B][K][3]  or NULL */
+                     float* full_pose_out_dev,         /* [B][3J]    or NULL */
+                     void* stream);
+
+/* ---- a batch of independent frames -------------------------------------------------------
+ * Replaces, for B frames at once, the objects fit_single_frame() wires together
+ * (fit_single_frame.py:413-445: create_loss('camera_init'), create_loss('smplify'),
+ * FittingMonitor, optim_factory.create_optimizer('lbfgsls')).                            */
+typedef struct sfx_stage_weights {      /* one entry of opt_weights (fit_single_frame.py:330-353) */
+    float body_pose_weight, shape_weight;
+    float hand_prior_weight, expr_prior_weight;
+    float jaw_prior_weight[3];
+    float hand_joint_weight, face_joint_weight;   /* joint_weights slices (:569-572)    */
+    float coll_loss_weight;                       /* carried; interpenetration not built */
+} sfx_stage_weights;
+
+typedef struct sfx_batch_cfg {
+    int32_t B;
+    int32_t n_stages;               /* body stages (3 or 5)                              */
+    int32_t use_vposer;             /* pose_embedding = VPoser latent [32]                */
+    int32_t use_hands, use_face;    /* SMPLifyLoss flags (fitting.py:331-339)             */
+    int32_t use_joints_conf;        /* weights = joint_weights * conf (fitting.py:380)    */
+    int32_t has_regression_pose;    /* pprior = |emb - regression_pose|^2 (:391-397)      */
+    int32_t use_conf_cam_init;      /* use_conf quirk of camera-init loss (:509-511)      */
+    int32_t num_body_joints;        /* 25 / 26 / 23: start of the hand keypoints          */
+    int32_t maxiters;               /* run_fitting steps AND LBFGS max_iter (cfg: 30)     */
+    double  ftol, gtol;             /* run_fitting tolerances (cfg: 1e-9, 1e-9)           */
+    float   lr;                     /* cfg: 1.0                                           */
+    float   rho;                    /* GMoF rho (cfg: 100)                                */
+    float   depth_loss_weight;      /* camera-init depth term (default 1e2)               */
+    int32_t lbs_mode;               /* 0: needed-rows LBS in the loop; 1: dense V-vertex
+                                       LBS every closure (what the reference evaluates)   */
+    int32_t reuse_entry_eval;       /* 1: serve LBFGS.step's entry evaluation from the
+                                       value already computed at the same point           */
+} sfx_batch_cfg;
+
+int  sfx_batch_create(sfx_model* m, const sfx_batch_cfg* cfg,
+                      const sfx_stage_weights* stages /* [n_stages] */, sfx_batch** out);
+void sfx_batch_destroy(sfx_batch* b);
+
+/* Per-frame inputs (HOST pointers, copied):
+ *  keypoints   [B][K][3]  x, y, confidence                (fit_single_frame.py:276-284)
+ *  joint_weights [B][K]   after joints_to_ign and low-confidence zeroing (:285-287,574)
+ *  cam_init_mask [B][K]   1 for the trimmed init_joints_idxs (:289-294)
+ *  camera      [B][6]     focal_x, focal_y, center_x, center_y, data_weight(=1000/H), est_tz
+ *  cam_rot     [B][9]     camera rotation (row-major; identity in the reference)
+ */
+int  sfx_batch_set_frames(sfx_batch* b, const float* keypoints, const float* joint_weights,
+                          const float* cam_init_mask, const float* camera, const float* cam_rot);
+
+/* Parameters (HOST pointers).  Names = the reference's result-pkl keys
+ * (fit_single_frame.py:644-657).  `pose_embedding` is [B][63] or [B][latent];
+ * `regression_pose` (may be NULL) is the clone taken at fit_single_frame.py:442.          */
+int  sfx_batch_set_params(sfx_batch* b, const float* cam_translation, const float* global_orient,
+                          const float* betas, const float* lhand, const float* rhand,
+                          const float* expression, const float* jaw, const float* leye,
+                          const float* reye, const float* pose_embedding,
+                          const float* regression_pose);
+int  sfx_batch_get_params(sfx_batch* b, float* cam_translation, float* global_orient,
+                          float* betas, float* lhand, float* rhand, float* expression,
+                          float* jaw, float* leye, float* reye, float* pose_embedding,
+                          float* body_pose /* [B][63] decoded body pose */);
+
+/* One closure evaluation for every frame at the CURRENT parameters (fitting.py:232-273:
+ * forward + loss + adjoint).  stage = -1: camera-init loss over [cam_t, global_orient]
+ * (N=6); stage >= 0: SMPLifyLoss with that stage's weights over the body variable vector
+ * (order of body_model.parameters() + pose_embedding, N = sfx_batch_num_vars).
+ * loss_out [B], grad_out [B][N]: HOST pointers (either may be NULL).                      */
+int  sfx_batch_num_vars(sfx_batch* b, int32_t stage);
+int  sfx_batch_closure(sfx_batch* b, int32_t stage, float* loss_out, float* grad_out, void* stream);
+
+/* Camera translation guess of fitting.guess_init (fitting.py:36-110) for every frame:
+ * one LBS forward, t_z = f * mean|d3D| / mean|d2D| over `n_pairs` keypoint pairs.
+ * Writes cam_translation = (0,0,t_z) and est_tz.                                           */
+int  sfx_batch_guess_init(sfx_batch* b, const int32_t* pairs /* [n_pairs][2] */, int32_t n_pairs,
+                          void* stream);
+
+/* The whole per-frame schedule of fit_single_frame.py:447-612 for all frames, on device:
+ * camera stage, then n_stages body stages, each = FittingMonitor.run_fitting
+ * (fitting.py:147-217) driving LBFGS.step with strong-Wolfe line search
+ * (optimizers/lbfgs_ls.py:39-167,256-445).  first_stage/last_stage select a sub-range
+ * (-1 = camera stage).  Blocks until done.                                                */
+int  sfx_batch_fit(sfx_batch* b, int32_t first_stage, int32_t last_stage, void* stream);
+
+/* Per-frame results of the last sfx_batch_fit (HOST pointers, any may be NULL):
+ *  stage_loss [B][1+n_stages]  value run_fitting returns per stage (camera first)
+ *  stage_evals [B][1+n_stages] closure evaluations performed per stage
+ *  stage_ref_evals             evaluations the reference would have performed            */
+int  sfx_batch_get_stats(sfx_batch* b, float* stage_loss, int32_t* stage_evals,
+                         int32_t* stage_ref_evals);
+
+/* Final meshes / joints at the current parameters (dense LBS; DEVICE pointers, may be NULL). */
+int  sfx_batch_forward(sfx_batch* b, float* vertices_out_dev /* [B][V][3] */,
+                       float* joints_out_dev /* [B][K][3] */, void* stream);
+
+/* Timing hooks for the roofline report: average duration (ms) of the named kernel since
+ * the last reset, measured with HIP events on the launch stream.  name: "lbs_dense",
+ * "closure", "lbfgs".  Returns launches counted.                                          */
+int  sfx_prof_enable(int32_t on);
+int  sfx_prof_get(const char* name, double* total_ms, int64_t* launches);
+void sfx_prof_reset(void);
+
+const char* sfx_last_error(void);
+const char* sfx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFX_H_ */

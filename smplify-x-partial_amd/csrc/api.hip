@@ -1,0 +1,600 @@
+// api.hip -- host layer of libsfx.so: the C ABI of include/sfx.h over the gfx950 kernels.
+// Owns HBM residency of the model constants and of every batch's state; the hot loop
+// (sfx_batch_fit) is a stream of kernel launches with no host arithmetic and one small
+// device->host poll every POLL ticks.
+#include "../../include/sfx.h"
+#include "sfx_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+static thread_local char g_err[1024] = "";
+void sfx_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* sfx_last_error(void) { return g_err; }
+extern "C" const char* sfx_version(void) { return "sfx 0.1.0 (gfx950)"; }
+
+// ---------------------------------------------------------------------------------------
+// profiling: HIP-event timing of named kernels on the launch stream
+struct ProfAcc { double ms = 0; int64_t n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pend; };
+static int g_prof = 0;
+static std::map<std::string, ProfAcc> g_acc;
+
+static void prof_flush(ProfAcc& a) {
+    for (auto& p : a.pend) {
+        hipEventSynchronize(p.second);
+        float ms = 0; hipEventElapsedTime(&ms, p.first, p.second);
+        a.ms += ms; a.n += 1;
+        hipEventDestroy(p.first); hipEventDestroy(p.second);
+    }
+    a.pend.clear();
+}
+struct ProfScope {
+    const char* name; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(const char* n, hipStream_t st) : name(n), s(st) {
+        if (g_prof) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s); }
+    }
+    ~ProfScope() {
+        if (g_prof) { hipEventRecord(e1, s); auto& a = g_acc[name]; a.pend.push_back({e0, e1});
+                      if (a.pend.size() > 512) prof_flush(a); }
+    }
+};
+extern "C" int sfx_prof_enable(int32_t on) { g_prof = on; return 0; }
+extern "C" void sfx_prof_reset(void) { for (auto& kv : g_acc) { prof_flush(kv.second); } g_acc.clear(); }
+extern "C" int sfx_prof_get(const char* name, double* total_ms, int64_t* launches) {
+    auto it = g_acc.find(name);
+    if (it == g_acc.end()) { if (total_ms) *total_ms = 0; if (launches) *launches = 0; return 0; }
+    prof_flush(it->second);
+    if (total_ms) *total_ms = it->second.ms;
+    if (launches) *launches = it->second.n;
+    return (int)std::min<int64_t>(it->second.n, 1 << 30);
+}
+
+// ---------------------------------------------------------------------------------------
+struct DevAlloc {
+    std::vector<void*> ptrs;
+    template <typename T> T* up(const std::vector<T>& h) {
+        T* d = nullptr;
+        size_t n = std::max<size_t>(h.size(), 1) * sizeof(T);
+        if (hipMalloc((void**)&d, n) != hipSuccess) return nullptr;
+        if (!h.empty()) hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+        ptrs.push_back(d);
+        return d;
+    }
+    template <typename T> T* zeros(size_t count) {
+        T* d = nullptr;
+        size_t n = std::max<size_t>(count, 1) * sizeof(T);
+        if (hipMalloc((void**)&d, n) != hipSuccess) return nullptr;
+        hipMemset(d, 0, n);
+        ptrs.push_back(d);
+        return d;
+    }
+    void free_all() { for (void* p : ptrs) hipFree(p); ptrs.clear(); }
+};
+
+struct sfx_model {
+    DevModel M{};
+    DevAlloc mem;
+    int NB = 0, NE = 0, NPCA = 0;
+    sfx_batch* fwd = nullptr;     // lazily created batch behind sfx_lbs_forward
+    int fwd_B = 0;
+};
+
+struct sfx_batch {
+    sfx_model* m = nullptr;
+    BatchDev D{};
+    DevAlloc mem;
+    VarList* vl_dev = nullptr;    // [2]: camera, body
+    StageW* sw_dev = nullptr;     // [n_stages]
+    VarList vl_host[2];
+    int* stage_host = nullptr;    // pinned
+    int K = 0;
+};
+
+extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
+    if (!d || !out) { sfx_set_error("null argument"); return -1; }
+    if (d->J != SFX_J) { sfx_set_error("only J=55 (SMPL-X) is supported, got %d", d->J); return -1; }
+    const int V = d->V, S = d->num_betas + d->num_expr, P = 9 * (d->J - 1), KD = S + P;
+    if (KD > SFX_KD_PAD || (KD & 1)) { sfx_set_error("blend-shape depth %d unsupported", KD); return -1; }
+    if (d->K > SFX_MAX_K) { sfx_set_error("K=%d > %d", d->K, SFX_MAX_K); return -1; }
+    int dev_count = 0;
+    if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count == 0) {
+        sfx_set_error("no HIP device: libsfx has no CPU fallback"); return -3;
+    }
+    sfx_model* m = new sfx_model();
+    DevModel& M = m->M;
+    m->NB = d->num_betas; m->NE = d->num_expr; m->NPCA = d->num_pca;
+    M.V = V; M.F = d->F; M.S = S; M.P = P; M.KD = KD; M.K = d->K;
+    M.n_extra = d->n_extra; M.n_lmk = d->n_lmk; M.n_dyn_rows = d->n_dyn_rows; M.n_dyn = d->n_dyn;
+    M.Vpad = ((V + 31) / 32) * 32;
+
+    std::vector<float> vt(d->v_template, d->v_template + (size_t)V * 3);
+    M.v_template = m->mem.up(vt);
+    // blend-shape matrix, k-major [KD][V][3] and vertex-major [V][3][KD_PAD]
+    {
+        std::vector<float> dirs((size_t)KD * V * 3), dirsT((size_t)V * 3 * SFX_KD_PAD, 0.f);
+        for (int v = 0; v < V; ++v)
+            for (int c = 0; c < 3; ++c) {
+                const float* sd = d->shapedirs + ((size_t)v * 3 + c) * S;
+                const float* pd = d->posedirs + ((size_t)v * 3 + c) * P;
+                float* row = &dirsT[((size_t)v * 3 + c) * SFX_KD_PAD];
+                for (int k = 0; k < S; ++k) { row[k] = sd[k]; dirs[((size_t)k * V + v) * 3 + c] = sd[k]; }
+                for (int k = 0; k < P; ++k) { row[S + k] = pd[k]; dirs[((size_t)(S + k) * V + v) * 3 + c] = pd[k]; }
+            }
+        M.dirs = m->mem.up(dirs);
+        M.dirsT = m->mem.up(dirsT);
+    }
+    {
+        std::vector<float> W(d->lbs_weights, d->lbs_weights + (size_t)V * SFX_J);
+        std::vector<float> WT((size_t)SFX_JPAD * M.Vpad, 0.f);
+        for (int v = 0; v < V; ++v)
+            for (int j = 0; j < SFX_J; ++j) WT[(size_t)j * M.Vpad + v] = W[(size_t)v * SFX_J + j];
+        M.W = m->mem.up(W);
+        M.WT = m->mem.up(WT);
+    }
+    // folded joint regressor: J = J_template + J_dirs . coeff   (J_regressor . v_shaped)
+    {
+        std::vector<float> Jt((size_t)SFX_J * 3), Jd((size_t)SFX_J * 3 * S);
+        for (int j = 0; j < SFX_J; ++j) {
+            std::vector<double> acc(3 + 3 * S, 0.0);
+            const float* jr = d->J_regressor + (size_t)j * V;
+            for (int v = 0; v < V; ++v) {
+                const double w = jr[v];
+                if (w == 0.0) continue;
+                for (int c = 0; c < 3; ++c) {
+                    acc[c] += w * d->v_template[(size_t)v * 3 + c];
+                    const float* sd = d->shapedirs + ((size_t)v * 3 + c) * S;
+                    for (int l = 0; l < S; ++l) acc[3 + c * S + l] += w * sd[l];
+                }
+            }
+            for (int c = 0; c < 3; ++c) {
+                Jt[j * 3 + c] = (float)acc[c];
+                for (int l = 0; l < S; ++l) Jd[((size_t)j * 3 + c) * S + l] = (float)acc[3 + c * S + l];
+            }
+        }
+        M.J_template = m->mem.up(Jt);
+        M.J_dirs = m->mem.up(Jd);
+    }
+    // kinematic tree: depth levels and child lists
+    {
+        std::vector<int> par(d->parents, d->parents + SFX_J), depth(SFX_J, 0);
+        par[0] = -1;
+        int maxd = 0;
+        for (int j = 1; j < SFX_J; ++j) {
+            if (par[j] < 0 || par[j] >= j) { sfx_set_error("parents must be topologically ordered"); delete m; return -1; }
+            depth[j] = depth[par[j]] + 1; maxd = std::max(maxd, depth[j]);
+        }
+        if (maxd + 1 > SFX_MAX_LEVELS) { sfx_set_error("tree too deep"); delete m; return -1; }
+        M.n_levels = maxd + 1;
+        std::vector<int> lj;
+        for (int l = 0; l <= maxd; ++l) {
+            M.level_start[l] = (int)lj.size();
+            for (int j = 0; j < SFX_J; ++j) if (depth[j] == l) lj.push_back(j);
+        }
+        M.level_start[maxd + 1] = (int)lj.size();
+        std::vector<int> cs(SFX_J + 1, 0), cl;
+        for (int j = 0; j < SFX_J; ++j) {
+            cs[j] = (int)cl.size();
+            for (int c = j + 1; c < SFX_J; ++c) if (par[c] == j) cl.push_back(c);
+        }
+        cs[SFX_J] = (int)cl.size();
+        M.parents = m->mem.up(par); M.level_joints = m->mem.up(lj);
+        M.child_start = m->mem.up(cs); M.child_list = m->mem.up(cl);
+    }
+    {
+        std::vector<float> cl(d->hands_comp_l, d->hands_comp_l + (size_t)d->num_pca * SFX_NHAND);
+        std::vector<float> cr(d->hands_comp_r, d->hands_comp_r + (size_t)d->num_pca * SFX_NHAND);
+        std::vector<float> pm(d->pose_mean, d->pose_mean + SFX_POSE);
+        M.comp_l = m->mem.up(cl); M.comp_r = m->mem.up(cr); M.pose_mean = m->mem.up(pm);
+    }
+    {
+        std::vector<int> faces(d->faces, d->faces + (size_t)d->F * 3);
+        M.faces = m->mem.up(faces);
+        std::vector<int> df; std::vector<float> db;
+        if (d->n_dyn > 0) {
+            df.assign(d->dyn_lmk_faces_idx, d->dyn_lmk_faces_idx + (size_t)d->n_dyn_rows * d->n_dyn);
+            db.assign(d->dyn_lmk_bary, d->dyn_lmk_bary + (size_t)d->n_dyn_rows * d->n_dyn * 3);
+        }
+        M.dyn_faces = m->mem.up(df); M.dyn_bary = m->mem.up(db);
+    }
+    // mapped joints -> kinematic joints / vertex items
+    {
+        const int K = d->K;
+        std::vector<int> jt(K), js(K, 0), ji0(K, 0), jn(K, 0), ivid, idyn, ik;
+        std::vector<float> iw;
+        std::vector<std::vector<int>> readers(SFX_J);
+        const int e0 = SFX_J, l0 = e0 + d->n_extra, d0 = l0 + d->n_lmk, end = d0 + d->n_dyn;
+        for (int k = 0; k < K; ++k) {
+            const int s = d->joint_map[k];
+            if (s < 0 || s >= end) { sfx_set_error("joint_map[%d]=%d out of range [0,%d)", k, s, end); delete m; return -1; }
+            if (s < e0) { jt[k] = 0; js[k] = s; readers[s].push_back(k); continue; }
+            jt[k] = 1; ji0[k] = (int)ivid.size();
+            if (s < l0) { ivid.push_back(d->extra_vertex_ids[s - e0]); iw.push_back(1.f); idyn.push_back(-1); ik.push_back(k); jn[k] = 1; }
+            else if (s < d0) {
+                const int l = s - l0, f = d->lmk_faces_idx[l];
+                for (int c = 0; c < 3; ++c) { ivid.push_back(d->faces[(size_t)f * 3 + c]); iw.push_back(d->lmk_bary[l * 3 + c]);
+                                              idyn.push_back(-1); ik.push_back(k); }
+                jn[k] = 3;
+            } else {
+                const int l = s - d0;
+                for (int c = 0; c < 3; ++c) { ivid.push_back(-1); iw.push_back(0.f); idyn.push_back(l * 3 + c); ik.push_back(k); }
+                jn[k] = 3;
+            }
+        }
+        if ((int)ivid.size() > SFX_MAX_ITEMS) { sfx_set_error("too many vertex items"); delete m; return -1; }
+        M.n_items = (int)ivid.size();
+        std::vector<int> sk0(SFX_J + 1, 0), skl;
+        for (int s = 0; s < SFX_J; ++s) { sk0[s] = (int)skl.size(); for (int k : readers[s]) skl.push_back(k); }
+        sk0[SFX_J] = (int)skl.size();
+        M.jk_type = m->mem.up(jt); M.jk_src = m->mem.up(js); M.jk_item0 = m->mem.up(ji0); M.jk_nitem = m->mem.up(jn);
+        M.item_vid = m->mem.up(ivid); M.item_w = m->mem.up(iw); M.item_dyn = m->mem.up(idyn); M.item_k = m->mem.up(ik);
+        M.src_k0 = m->mem.up(sk0); M.src_klist = m->mem.up(skl);
+    }
+    if (hipDeviceSynchronize() != hipSuccess) { sfx_set_error("model upload failed"); delete m; return -2; }
+    *out = m;
+    return 0;
+}
+
+extern "C" void sfx_batch_destroy(sfx_batch* b);
+extern "C" void sfx_model_destroy(sfx_model* m) {
+    if (!m) return;
+    if (m->fwd) sfx_batch_destroy(m->fwd);
+    m->mem.free_all();
+    delete m;
+}
+
+extern "C" int sfx_model_set_vposer(sfx_model* m, int32_t latent, int32_t hidden, const float* w1, const float* b1,
+                                    const float* w2, const float* b2, const float* w3, const float* b3) {
+    if (!m) { sfx_set_error("null model"); return -1; }
+    auto v = [](const float* p, size_t n) { return std::vector<float>(p, p + n); };
+    m->M.vp_latent = latent; m->M.vp_hidden = hidden;
+    m->M.vp_w1 = m->mem.up(v(w1, (size_t)hidden * latent)); m->M.vp_b1 = m->mem.up(v(b1, hidden));
+    m->M.vp_w2 = m->mem.up(v(w2, (size_t)hidden * hidden)); m->M.vp_b2 = m->mem.up(v(b2, hidden));
+    m->M.vp_w3 = m->mem.up(v(w3, (size_t)126 * hidden));    m->M.vp_b3 = m->mem.up(v(b3, 126));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+static void build_layout(ParLayout& L, int NB, int NE, int NPCA, int use_vposer, int latent) {
+    L.NB = NB; L.NE = NE; L.NPCA = NPCA;
+    L.cam_t = 0; L.go = 3; L.betas = 6; L.lh = L.betas + NB; L.rh = L.lh + NPCA; L.expr = L.rh + NPCA;
+    L.jaw = L.expr + NE; L.leye = L.jaw + 3; L.reye = L.leye + 3; L.bodyp = L.reye + 3;
+    L.has_bodyp = use_vposer ? 0 : 1;
+    L.emb = L.bodyp + (L.has_bodyp ? 63 : 0);
+    L.NEMB = use_vposer ? latent : 63;
+    L.npar = L.emb + L.NEMB;
+}
+
+static void add_group(VarList& v, int off, int len, int has) {
+    const int g = v.ngroups++;
+    v.g_off[g] = (short)v.n; v.g_len[g] = (short)len; v.g_has[g] = (short)has;
+    for (int i = 0; i < len; ++i) v.idx[v.n++] = (short)(off + i);
+}
+
+extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_stage_weights* st, sfx_batch** out) {
+    if (!m || !c || !out) { sfx_set_error("null argument"); return -1; }
+    if (c->n_stages < 0 || c->n_stages > SFX_MAX_STAGES) { sfx_set_error("n_stages=%d unsupported", c->n_stages); return -1; }
+    if (c->use_vposer && m->M.vp_latent == 0) { sfx_set_error("use_vposer without sfx_model_set_vposer"); return -1; }
+    sfx_batch* b = new sfx_batch();
+    b->m = m; b->K = m->M.K;
+    BatchDev& D = b->D;
+    const int B = c->B, K = m->M.K;
+    D.cfg.B = B; D.cfg.n_stages = c->n_stages; D.cfg.use_vposer = c->use_vposer; D.cfg.use_hands = c->use_hands;
+    D.cfg.use_face = c->use_face; D.cfg.use_conf = c->use_joints_conf; D.cfg.has_reg = c->has_regression_pose;
+    D.cfg.use_conf_cam = c->use_conf_cam_init; D.cfg.nbj = c->num_body_joints; D.cfg.maxiters = c->maxiters;
+    D.cfg.max_eval = c->maxiters * 5 / 4; D.cfg.ftol = c->ftol; D.cfg.gtol = c->gtol;
+    D.cfg.lr = c->lr; D.cfg.rho = c->rho; D.cfg.depth_w = c->depth_loss_weight; D.cfg.lbs_mode = c->lbs_mode;
+    D.cfg.reuse = c->reuse_entry_eval;
+    build_layout(D.L, m->NB, m->NE, m->NPCA, c->use_vposer, m->M.vp_latent);
+    if (D.L.npar > SFX_NPAR_MAX) { sfx_set_error("parameter block too large"); delete b; return -1; }
+    const ParLayout& L = D.L;
+    VarList cam{}, body{};
+    add_group(cam, L.cam_t, 3, 1); add_group(cam, L.go, 3, 1);
+    // order of smplx.SMPLX.parameters() then pose_embedding (fit_single_frame.py:554-559)
+    add_group(body, L.betas, L.NB, 1); add_group(body, L.go, 3, 1);
+    if (L.has_bodyp) add_group(body, L.bodyp, 63, 0);
+    add_group(body, L.lh, L.NPCA, 1); add_group(body, L.rh, L.NPCA, 1);
+    add_group(body, L.jaw, 3, 1); add_group(body, L.leye, 3, 1); add_group(body, L.reye, 3, 1);
+    add_group(body, L.expr, L.NE, 1); add_group(body, L.emb, L.NEMB, 1);
+    b->vl_host[0] = cam; b->vl_host[1] = body;
+    std::vector<VarList> vls = {cam, body};
+    b->vl_dev = b->mem.up(vls);
+    std::vector<StageW> sws(std::max(1, c->n_stages));
+    for (int i = 0; i < c->n_stages; ++i) {
+        StageW& w = sws[i];
+        w.bpw = st[i].body_pose_weight; w.sw = st[i].shape_weight;
+        w.bend = 3.17f * st[i].body_pose_weight;            // fit_single_frame.py:567-568 (fp32 product)
+        w.hpw = st[i].hand_prior_weight; w.epw = st[i].expr_prior_weight;
+        for (int q = 0; q < 3; ++q) w.jaw[q] = st[i].jaw_prior_weight[q];
+        w.hand_jw = st[i].hand_joint_weight; w.face_jw = st[i].face_joint_weight;
+    }
+    b->sw_dev = b->mem.up(sws);
+    D.Bpad = ((B + 31) / 32) * 32;
+    D.X = b->mem.zeros<float>((size_t)B * SFX_NPAR_MAX);
+    D.Xt = b->mem.zeros<float>((size_t)B * SFX_NPAR_MAX);
+    D.gt = b->mem.zeros<float>((size_t)B * K * 2);
+    D.conf = b->mem.zeros<float>((size_t)B * K);
+    D.jw = b->mem.zeros<float>((size_t)B * K);
+    D.cmask = b->mem.zeros<float>((size_t)B * K);
+    D.cam = b->mem.zeros<float>((size_t)B * 8);
+    D.camR = b->mem.zeros<float>((size_t)B * 9);
+    D.regpose = b->mem.zeros<float>((size_t)B * 63);
+    D.f = b->mem.zeros<float>(B);
+    D.g = b->mem.zeros<float>((size_t)B * SFX_NVAR_MAX);
+    D.bodypose = b->mem.zeros<float>((size_t)B * 63);
+    D.featT = b->mem.zeros<float>((size_t)SFX_KD_PAD * D.Bpad);
+    D.AT = b->mem.zeros<float>((size_t)12 * SFX_JPAD * D.Bpad);
+    D.verts = b->mem.zeros<float>((size_t)B * m->M.V * 3);
+    D.joints = b->mem.zeros<float>((size_t)B * K * 3);
+    D.fullpose = b->mem.zeros<float>((size_t)B * SFX_POSE);
+    D.stage = b->mem.zeros<int>(B);
+    D.opt = b->mem.zeros<char>((size_t)B * sfx_optstate_size());
+    D.vec = b->mem.zeros<float>((size_t)B * NVEC * SFX_NVAR_MAX);
+    D.hist = b->mem.zeros<float>((size_t)B * 2 * SFX_HIST * SFX_NVAR_MAX);
+    D.n_active = b->mem.zeros<int>(4);
+    D.stage_loss = b->mem.zeros<float>((size_t)B * (1 + SFX_MAX_STAGES));
+    D.stage_evals = b->mem.zeros<int>((size_t)B * (1 + SFX_MAX_STAGES));
+    D.stage_ref_evals = b->mem.zeros<int>((size_t)B * (1 + SFX_MAX_STAGES));
+    if (!D.hist || !D.verts) { sfx_set_error("out of device memory"); b->mem.free_all(); delete b; return -2; }
+    if (hipHostMalloc((void**)&b->stage_host, (size_t)B * sizeof(int)) != hipSuccess) b->stage_host = nullptr;
+    *out = b;
+    return 0;
+}
+
+extern "C" void sfx_batch_destroy(sfx_batch* b) {
+    if (!b) return;
+    b->mem.free_all();
+    if (b->stage_host) hipHostFree(b->stage_host);
+    delete b;
+}
+
+extern "C" int sfx_batch_set_frames(sfx_batch* b, const float* kp, const float* jw, const float* cmask,
+                                    const float* cam, const float* camR) {
+    if (!b) { sfx_set_error("null batch"); return -1; }
+    const int B = b->D.cfg.B, K = b->K;
+    if (kp) {
+        std::vector<float> gt((size_t)B * K * 2), cf((size_t)B * K);
+        for (size_t i = 0; i < (size_t)B * K; ++i) { gt[2 * i] = kp[3 * i]; gt[2 * i + 1] = kp[3 * i + 1]; cf[i] = kp[3 * i + 2]; }
+        SFX_CHECK(hipMemcpy(b->D.gt, gt.data(), gt.size() * 4, hipMemcpyHostToDevice));
+        SFX_CHECK(hipMemcpy(b->D.conf, cf.data(), cf.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (jw) SFX_CHECK(hipMemcpy(b->D.jw, jw, (size_t)B * K * 4, hipMemcpyHostToDevice));
+    if (cmask) SFX_CHECK(hipMemcpy(b->D.cmask, cmask, (size_t)B * K * 4, hipMemcpyHostToDevice));
+    if (cam) {
+        std::vector<float> c8((size_t)B * 8, 0.f);
+        for (int i = 0; i < B; ++i) for (int q = 0; q < 6; ++q) c8[(size_t)i * 8 + q] = cam[(size_t)i * 6 + q];
+        SFX_CHECK(hipMemcpy(b->D.cam, c8.data(), c8.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (camR) SFX_CHECK(hipMemcpy(b->D.camR, camR, (size_t)B * 9 * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static void put(std::vector<float>& X, int B, int off, int n, const float* src) {
+    if (!src) return;
+    for (int i = 0; i < B; ++i) for (int q = 0; q < n; ++q) X[(size_t)i * SFX_NPAR_MAX + off + q] = src[(size_t)i * n + q];
+}
+static void take(const std::vector<float>& X, int B, int off, int n, float* dst) {
+    if (!dst) return;
+    for (int i = 0; i < B; ++i) for (int q = 0; q < n; ++q) dst[(size_t)i * n + q] = X[(size_t)i * SFX_NPAR_MAX + off + q];
+}
+
+extern "C" int sfx_batch_set_params(sfx_batch* b, const float* cam_t, const float* go, const float* betas,
+                                    const float* lh, const float* rh, const float* expr, const float* jaw,
+                                    const float* leye, const float* reye, const float* emb, const float* reg) {
+    if (!b) { sfx_set_error("null batch"); return -1; }
+    const int B = b->D.cfg.B; const ParLayout& L = b->D.L;
+    std::vector<float> X((size_t)B * SFX_NPAR_MAX);
+    SFX_CHECK(hipMemcpy(X.data(), b->D.X, X.size() * 4, hipMemcpyDeviceToHost));
+    put(X, B, L.cam_t, 3, cam_t); put(X, B, L.go, 3, go); put(X, B, L.betas, L.NB, betas);
+    put(X, B, L.lh, L.NPCA, lh); put(X, B, L.rh, L.NPCA, rh); put(X, B, L.expr, L.NE, expr);
+    put(X, B, L.jaw, 3, jaw); put(X, B, L.leye, 3, leye); put(X, B, L.reye, 3, reye);
+    put(X, B, L.emb, L.NEMB, emb);
+    // body_model.reset_params(body_pose=pose_embedding) also fills the (dead) body_pose parameter
+    if (L.has_bodyp && emb) put(X, B, L.bodyp, 63, emb);
+    SFX_CHECK(hipMemcpy(b->D.X, X.data(), X.size() * 4, hipMemcpyHostToDevice));
+    SFX_CHECK(hipMemcpy(b->D.Xt, X.data(), X.size() * 4, hipMemcpyHostToDevice));
+    if (reg) {
+        std::vector<float> r((size_t)B * 63, 0.f);
+        for (int i = 0; i < B; ++i) for (int q = 0; q < L.NEMB; ++q) r[(size_t)i * 63 + q] = reg[(size_t)i * L.NEMB + q];
+        SFX_CHECK(hipMemcpy(b->D.regpose, r.data(), r.size() * 4, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+extern "C" int sfx_batch_get_params(sfx_batch* b, float* cam_t, float* go, float* betas, float* lh, float* rh,
+                                    float* expr, float* jaw, float* leye, float* reye, float* emb, float* body_pose) {
+    if (!b) { sfx_set_error("null batch"); return -1; }
+    const int B = b->D.cfg.B; const ParLayout& L = b->D.L;
+    std::vector<float> X((size_t)B * SFX_NPAR_MAX);
+    SFX_CHECK(hipMemcpy(X.data(), b->D.X, X.size() * 4, hipMemcpyDeviceToHost));
+    take(X, B, L.cam_t, 3, cam_t); take(X, B, L.go, 3, go); take(X, B, L.betas, L.NB, betas);
+    take(X, B, L.lh, L.NPCA, lh); take(X, B, L.rh, L.NPCA, rh); take(X, B, L.expr, L.NE, expr);
+    take(X, B, L.jaw, 3, jaw); take(X, B, L.leye, 3, leye); take(X, B, L.reye, 3, reye);
+    take(X, B, L.emb, L.NEMB, emb);
+    if (body_pose) {
+        if (b->D.cfg.use_vposer) SFX_CHECK(hipMemcpy(body_pose, b->D.bodypose, (size_t)B * 63 * 4, hipMemcpyDeviceToHost));
+        else take(X, B, L.emb, 63, body_pose);
+    }
+    return 0;
+}
+
+extern "C" int sfx_batch_num_vars(sfx_batch* b, int32_t stage) {
+    if (!b) return -1;
+    return b->vl_host[stage < 0 ? 0 : 1].n;
+}
+
+// one closure evaluation of every (active) frame; stage_override = -2 -> per-frame stage[]
+static void eval_closure(sfx_batch* b, int stage_override, int from_X, hipStream_t s) {
+    const DevModel& M = b->m->M; const BatchDev& D = b->D;
+    ClosureArgs a{};
+    a.stage_override = stage_override; a.from_X = from_X;
+    // the camera stage asks for return_verts=False (fit_single_frame.py:485): the reference
+    // still evaluates every vertex there, so dense mode does too.
+    if (D.cfg.lbs_mode == 1) {
+        ClosureArgs e = a; e.export_dense = 1; e.forward_only = 2;
+        { ProfScope p("export", s); launch_closure(M, D, b->vl_dev, b->sw_dev, e, s); }
+        { ProfScope p("lbs_dense", s); launch_lbs_dense(M, D, s); }
+        a.use_dense_verts = 1;
+    }
+    ProfScope p("closure", s);
+    launch_closure(M, D, b->vl_dev, b->sw_dev, a, s);
+}
+
+extern "C" int sfx_batch_closure(sfx_batch* b, int32_t stage, float* loss_out, float* grad_out, void* stream) {
+    if (!b) { sfx_set_error("null batch"); return -1; }
+    if (stage >= b->D.cfg.n_stages) { sfx_set_error("stage %d out of range", stage); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    eval_closure(b, stage < 0 ? -1 : stage, 1, s);
+    SFX_CHECK(hipStreamSynchronize(s));
+    SFX_CHECK(hipGetLastError());
+    const int B = b->D.cfg.B, N = b->vl_host[stage < 0 ? 0 : 1].n;
+    if (loss_out) SFX_CHECK(hipMemcpy(loss_out, b->D.f, (size_t)B * 4, hipMemcpyDeviceToHost));
+    if (grad_out) {
+        std::vector<float> g((size_t)B * SFX_NVAR_MAX);
+        SFX_CHECK(hipMemcpy(g.data(), b->D.g, g.size() * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < B; ++i) memcpy(grad_out + (size_t)i * N, &g[(size_t)i * SFX_NVAR_MAX], (size_t)N * 4);
+    }
+    return 0;
+}
+
+__global__ void k_guess_init(BatchDev D, int K, const int* pairs, int n_pairs) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= D.cfg.B) return;
+    const float* j3 = D.joints + (size_t)b * K * 3;
+    const float* j2 = D.gt + (size_t)b * K * 2;
+    float s3 = 0.f, s2 = 0.f;
+    for (int p = 0; p < n_pairs; ++p) {
+        const int a = pairs[2 * p], c = pairs[2 * p + 1];
+        const float dx = j3[a * 3] - j3[c * 3], dy = j3[a * 3 + 1] - j3[c * 3 + 1], dz = j3[a * 3 + 2] - j3[c * 3 + 2];
+        const float ex = j2[a * 2] - j2[c * 2], ey = j2[a * 2 + 1] - j2[c * 2 + 1];
+        s3 += sqrtf(dx * dx + dy * dy + dz * dz);
+        s2 += sqrtf(ex * ex + ey * ey);
+    }
+    const float est = D.cam[(size_t)b * 8 + 0] * ((s3 / n_pairs) / (s2 / n_pairs));
+    float* x = D.X + (size_t)b * SFX_NPAR_MAX + D.L.cam_t;
+    x[0] = 0.f; x[1] = 0.f; x[2] = est;
+    float* xt = D.Xt + (size_t)b * SFX_NPAR_MAX + D.L.cam_t;
+    xt[0] = 0.f; xt[1] = 0.f; xt[2] = est;
+    D.cam[(size_t)b * 8 + 5] = est;
+}
+
+extern "C" int sfx_batch_guess_init(sfx_batch* b, const int32_t* pairs, int32_t n_pairs, void* stream) {
+    if (!b) { sfx_set_error("null batch"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<int> pv(pairs, pairs + 2 * n_pairs);
+    int* pd = nullptr;
+    SFX_CHECK(hipMalloc((void**)&pd, pv.size() * sizeof(int)));
+    SFX_CHECK(hipMemcpyAsync(pd, pv.data(), pv.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    ClosureArgs a{}; a.stage_override = -1; a.forward_only = 1; a.from_X = 1;
+    launch_closure(b->m->M, b->D, b->vl_dev, b->sw_dev, a, s);
+    hipLaunchKernelGGL(k_guess_init, dim3((b->D.cfg.B + 63) / 64), dim3(64), 0, s, b->D, b->K, pd, n_pairs);
+    SFX_CHECK(hipStreamSynchronize(s));
+    hipFree(pd);
+    SFX_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sfx_batch_fit(sfx_batch* b, int32_t first_stage, int32_t last_stage, void* stream) {
+    if (!b) { sfx_set_error("null batch"); return -1; }
+    const BatchDev& D = b->D; const DevModel& M = b->m->M;
+    if (first_stage < -1 || last_stage >= D.cfg.n_stages || last_stage < first_stage) {
+        sfx_set_error("bad stage range [%d,%d]", first_stage, last_stage); return -1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int B = D.cfg.B;
+    const int POLL = (D.cfg.lbs_mode == 1) ? 8 : 32;
+    launch_lbfgs_tick(M, D, b->vl_dev, first_stage, last_stage, 1, s);
+    const long max_ticks = (long)(last_stage - first_stage + 1) * D.cfg.maxiters * 80 + 64;
+    std::vector<int> hs(B);
+    int* hp = b->stage_host ? b->stage_host : hs.data();
+    long tick = 0;
+    bool done = false;
+    while (!done && tick < max_ticks) {
+        for (int q = 0; q < POLL; ++q, ++tick) {
+            eval_closure(b, -2, 0, s);
+            ProfScope p("lbfgs", s);
+            launch_lbfgs_tick(M, D, b->vl_dev, first_stage, last_stage, 0, s);
+        }
+        SFX_CHECK(hipMemcpyAsync(hp, D.stage, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+        SFX_CHECK(hipStreamSynchronize(s));
+        done = true;
+        for (int i = 0; i < B; ++i) if (hp[i] <= last_stage) { done = false; break; }
+    }
+    SFX_CHECK(hipGetLastError());
+    if (!done) { sfx_set_error("fit did not finish within %ld ticks", max_ticks); return -4; }
+    return 0;
+}
+
+extern "C" int sfx_batch_get_stats(sfx_batch* b, float* stage_loss, int32_t* stage_evals, int32_t* stage_ref_evals) {
+    if (!b) { sfx_set_error("null batch"); return -1; }
+    const int B = b->D.cfg.B, NS = b->D.cfg.n_stages + 1;
+    std::vector<float> l((size_t)B * (1 + SFX_MAX_STAGES));
+    std::vector<int> e(l.size()), r(l.size());
+    SFX_CHECK(hipMemcpy(l.data(), b->D.stage_loss, l.size() * 4, hipMemcpyDeviceToHost));
+    SFX_CHECK(hipMemcpy(e.data(), b->D.stage_evals, e.size() * 4, hipMemcpyDeviceToHost));
+    SFX_CHECK(hipMemcpy(r.data(), b->D.stage_ref_evals, r.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < B; ++i)
+        for (int q = 0; q < NS; ++q) {
+            if (stage_loss) stage_loss[(size_t)i * NS + q] = l[(size_t)i * (1 + SFX_MAX_STAGES) + q];
+            if (stage_evals) stage_evals[(size_t)i * NS + q] = e[(size_t)i * (1 + SFX_MAX_STAGES) + q];
+            if (stage_ref_evals) stage_ref_evals[(size_t)i * NS + q] = r[(size_t)i * (1 + SFX_MAX_STAGES) + q];
+        }
+    return 0;
+}
+
+extern "C" int sfx_batch_forward(sfx_batch* b, float* verts_dev, float* joints_dev, void* stream) {
+    if (!b) { sfx_set_error("null batch"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    const DevModel& M = b->m->M; const BatchDev& D = b->D;
+    ClosureArgs e{}; e.stage_override = 0; e.export_dense = 1; e.forward_only = 2; e.from_X = 1;
+    launch_closure(M, D, b->vl_dev, b->sw_dev, e, s);
+    { ProfScope p("lbs_dense", s); launch_lbs_dense(M, D, s); }
+    ClosureArgs a{}; a.stage_override = 0; a.forward_only = 1; a.from_X = 1; a.use_dense_verts = 1;
+    launch_closure(M, D, b->vl_dev, b->sw_dev, a, s);
+    const size_t nv = (size_t)D.cfg.B * M.V * 3 * 4, nj = (size_t)D.cfg.B * M.K * 3 * 4;
+    if (verts_dev) SFX_CHECK(hipMemcpyAsync(verts_dev, D.verts, nv, hipMemcpyDeviceToDevice, s));
+    if (joints_dev) SFX_CHECK(hipMemcpyAsync(joints_dev, D.joints, nj, hipMemcpyDeviceToDevice, s));
+    SFX_CHECK(hipStreamSynchronize(s));
+    SFX_CHECK(hipGetLastError());
+    return 0;
+}
+
+__global__ void k_pack_params(BatchDev D, const float* go, const float* bp, const float* betas, const float* expr,
+                              const float* jaw, const float* leye, const float* reye, const float* lh, const float* rh) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const ParLayout& L = D.L;
+    float* x = D.X + (size_t)b * SFX_NPAR_MAX;
+    auto cp = [&](int off, int n, const float* src) { if (t < n) x[off + t] = src ? src[(size_t)b * n + t] : 0.f; };
+    cp(L.cam_t, 3, nullptr); cp(L.go, 3, go); cp(L.betas, L.NB, betas); cp(L.lh, L.NPCA, lh); cp(L.rh, L.NPCA, rh);
+    cp(L.expr, L.NE, expr); cp(L.jaw, 3, jaw); cp(L.leye, 3, leye); cp(L.reye, 3, reye); cp(L.emb, 63, bp);
+}
+
+extern "C" int sfx_lbs_forward(sfx_model* m, int32_t B, const float* go, const float* bp, const float* betas,
+                               const float* expr, const float* jaw, const float* leye, const float* reye,
+                               const float* lh, const float* rh, float* verts_out, float* joints_out,
+                               float* full_pose_out, void* stream) {
+    if (!m) { sfx_set_error("null model"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (!m->fwd || m->fwd_B != B) {
+        if (m->fwd) sfx_batch_destroy(m->fwd);
+        sfx_batch_cfg c{}; c.B = B; c.n_stages = 1; c.maxiters = 1; c.num_body_joints = m->M.K; c.lbs_mode = 1;
+        sfx_stage_weights w{};
+        int rc = sfx_batch_create(m, &c, &w, &m->fwd);
+        if (rc) return rc;
+        m->fwd_B = B;
+    }
+    sfx_batch* b = m->fwd;
+    hipLaunchKernelGGL(k_pack_params, dim3(B), dim3(64), 0, s, b->D, go, bp, betas, expr, jaw, leye, reye, lh, rh);
+    int rc = sfx_batch_forward(b, verts_out, joints_out, s);
+    if (rc) return rc;
+    if (full_pose_out) SFX_CHECK(hipMemcpyAsync(full_pose_out, b->D.fullpose, (size_t)B * SFX_POSE * 4, hipMemcpyDeviceToDevice, s));
+    SFX_CHECK(hipStreamSynchronize(s));
+    return 0;
+}

@@ -1,0 +1,144 @@
+// Internal structures shared by the host layer (api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SFX_J 55            // SMPL-X kinematic joints
+#define SFX_POSE (3 * SFX_J)
+#define SFX_NHAND 45
+#define SFX_MAX_K 144       // mapped joints
+#define SFX_MAX_ITEMS 240   // vertex items (21 + 68*3 = 225)
+#define SFX_KD_PAD 512      // padded blend-shape depth (20 + 486 = 506)
+#define SFX_JPAD 56         // joints padded to an even MFMA depth
+#define SFX_MAX_LEVELS 16
+#define SFX_HIST 100        // L-BFGS history (optim_factory 'lbfgsls' default)
+#define SFX_NVAR_MAX 192    // optimiser vector length (182 / 88 / 6), padded to 3*64
+#define SFX_NPAR_MAX 192    // canonical per-frame parameter block
+#define SFX_MAX_STAGES 8
+#define SFX_MAX_GROUPS 12
+
+// Canonical per-frame parameter block (floats).  cam_t | global_orient | betas | lhand |
+// rhand | expression | jaw | leye | reye | body_pose param (dead, iff !use_vposer) | embedding
+struct ParLayout {
+    int cam_t, go, betas, lh, rh, expr, jaw, leye, reye, bodyp, emb;
+    int NB, NE, NPCA, NEMB, has_bodyp, npar;
+};
+
+// Variable list of one optimisation stage kind: flat optimiser index -> canonical index.
+struct VarList {
+    int n;
+    int ngroups;
+    short idx[SFX_NVAR_MAX];
+    short g_off[SFX_MAX_GROUPS], g_len[SFX_MAX_GROUPS], g_has[SFX_MAX_GROUPS];
+};
+
+struct StageW {       // per body stage
+    float bpw, sw, bend, hpw, epw, jaw[3], hand_jw, face_jw;
+};
+
+struct DevModel {
+    int V, F, S, P, KD, K;            // S = NB+NE, P = 486, KD = S+P
+    int n_extra, n_lmk, n_dyn_rows, n_dyn;
+    int n_levels;
+    int level_start[SFX_MAX_LEVELS + 1];
+    // constants
+    const float* v_template;   // [V][3]
+    const float* dirs;         // [KD][V][3]    k-major (dense GEMM B operand)
+    const float* dirsT;        // [V][3][KD_PAD] vertex-major (needed-rows path)
+    const float* W;            // [V][J]
+    const float* WT;           // [JPAD][Vpad]   (dense skinning GEMM B operand)
+    const float* J_template;   // [J][3]
+    const float* J_dirs;       // [J][3][S]
+    const int*   parents;      // [J]
+    const int*   level_joints; // [J] joints ordered by tree depth
+    const int*   child_start;  // [J+1]
+    const int*   child_list;   // [J-1]
+    const float* comp_l;       // [NPCA][45]
+    const float* comp_r;
+    const float* pose_mean;    // [165]
+    const int*   faces;        // [F][3]
+    const int*   dyn_faces;    // [rows][n_dyn]
+    const float* dyn_bary;     // [rows][n_dyn][3]
+    // mapped-joint description
+    const int*   jk_type;      // [K] 0 = kinematic joint, 1 = vertex items
+    const int*   jk_src;       // [K] joint id (type 0)
+    const int*   jk_item0;     // [K] first item (type 1)
+    const int*   jk_nitem;     // [K]
+    int n_items, n_static_items;
+    const int*   item_vid;     // [n_items] static vertex id (dynamic items: -1)
+    const float* item_w;       // [n_items] static bary weight
+    const int*   item_dyn;     // [n_items] -1, or (landmark*3 + corner) of the dynamic LUT
+    const int*   item_k;       // [n_items] owning mapped joint
+    const int*   src_k0;       // [J+1] CSR: mapped joints that read kinematic joint s
+    const int*   src_klist;    // [..]
+    int Vpad;
+    // VPoser decoder
+    int vp_latent, vp_hidden;
+    const float *vp_w1, *vp_b1, *vp_w2, *vp_b2, *vp_w3, *vp_b3;
+};
+
+struct BatchCfgDev {
+    int B, n_stages;
+    int use_vposer, use_hands, use_face, use_conf, has_reg, use_conf_cam;
+    int nbj;
+    int maxiters, max_eval;
+    double ftol, gtol;
+    float lr, rho, depth_w;
+    int lbs_mode, reuse;
+};
+
+// Per-frame data pointers (all device).
+struct BatchDev {
+    BatchCfgDev cfg;
+    ParLayout L;
+    float* X;          // [B][NPAR_MAX] accepted parameters
+    float* Xt;         // [B][NPAR_MAX] trial parameters (what the closure evaluates)
+    float* gt;         // [B][K][2]
+    float* conf;       // [B][K]
+    float* jw;         // [B][K]
+    float* cmask;      // [B][K]
+    float* cam;        // [B][8] fx fy cx cy data_weight est_tz - -
+    float* camR;       // [B][9]
+    float* regpose;    // [B][63]  (or latent)
+    float* f;          // [B] loss at Xt
+    float* g;          // [B][NVAR_MAX] flat gradient at Xt
+    float* bodypose;   // [B][63] decoded body pose (VPoser) scratch
+    // dense path
+    float* featT;      // [KD_PAD][Bpad]
+    float* AT;         // [12][JPAD][Bpad]
+    float* verts;      // [B][V][3]
+    float* joints;     // [B][K][3] (export)
+    float* fullpose;   // [B][165]  (export)
+    int Bpad;
+    // optimiser state
+    int*   stage;      // [B] current stage (-1 camera, 0.. body, n_stages = done)
+    void*  opt;        // [B] OptState
+    float* vec;        // [B][NVEC][NVAR_MAX] optimiser vectors
+    float* hist;       // [B][2][HIST][NVAR_MAX]
+    int*   n_active;   // [1] frames not done
+    float* stage_loss; // [B][1+MAX_STAGES]
+    int*   stage_evals;     // [B][1+MAX_STAGES]
+    int*   stage_ref_evals; // [B][1+MAX_STAGES]
+};
+
+enum { VEC_XINIT = 0, VEC_D, VEC_G, VEC_PREVG, VEC_GPREV, VEC_BG0, VEC_BG1, VEC_LSG0, NVEC };
+
+#define SFX_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+    sfx_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); return -2; } } while (0)
+
+void sfx_set_error(const char* fmt, ...);
+
+// kernel launchers (defined in the .hip files)
+struct ClosureArgs {
+    int stage_override;     // -2: use per-frame stage[]; otherwise stage for all frames
+    int forward_only;       // 1: export joints / full_pose / featT / AT only
+    int use_dense_verts;    // 1: item vertices come from BatchDev.verts
+    int export_dense;       // 1: write featT / AT for the dense kernel
+    int from_X;             // 1: evaluate at X instead of Xt
+};
+void launch_closure(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
+                    const ClosureArgs& a, hipStream_t s);
+void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s);
+void launch_lbfgs_tick(const DevModel& M, const BatchDev& D, const VarList* vl_dev, int first_stage,
+                       int last_stage, int init, hipStream_t s);
+size_t sfx_optstate_size();

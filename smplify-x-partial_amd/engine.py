@@ -1,0 +1,300 @@
+"""Batched fitting engine: Python face of libsfx.so (the MI355X-native entry point).
+
+`DeviceModel` uploads an SMPL-X model once per GPU; `FrameBatch` holds B independent
+frames (the reference handles exactly one, fit_single_frame.py:119) and runs the
+reference's per-frame schedule for all of them on device.  The drop-in modules
+(`smplx`, `fitting`, `fit_single_frame`, ...) are thin adapters over these two classes.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from .synthetic import SMPLX_EXTRA_VERTEX_IDS
+
+NUM_BODY_JOINTS = {"coco25": 25, "halpe": 26, "coco_wholebody": 23}
+PARAM_NAMES = ("cam_translation", "global_orient", "betas", "left_hand_pose", "right_hand_pose",
+               "expression", "jaw_pose", "leye_pose", "reye_pose", "pose_embedding")
+
+
+def _jaw_weights(cfg, shape_weights):
+    jw = cfg.get("jaw_pose_prior_weights")
+    if jw is None:
+        return [[x] * 3 for x in shape_weights]
+    return [[float(v) for v in e.split(",")] if isinstance(e, str) else [float(v) for v in e] for e in jw]
+
+
+def stage_weights_from_cfg(cfg):
+    """Per-stage weights exactly as fit_single_frame.py:133-207,330-353 assembles them
+    (defaults, zip-truncation to the shortest list)."""
+    use_hands, use_face = cfg.get("use_hands", True), cfg.get("use_face", True)
+    bpw = cfg.get("body_pose_prior_weights") or [4.04 * 1e2, 4.04 * 1e2, 57.4, 4.78]
+    n = len(bpw)
+    lists = {"data": cfg.get("data_weights") or [1] * n, "bpw": bpw,
+             "shape": cfg.get("shape_weights") or [1e2, 5 * 1e1, 1e1, .5 * 1e1]}
+    if use_face:
+        lists["face"] = cfg.get("face_joints_weights") or [0.0, 0.0, 0.0, 1.0]
+        lists["expr"] = cfg.get("expr_weights") or [1e2, 5 * 1e1, 1e1, .5 * 1e1]
+        lists["jaw"] = _jaw_weights(cfg, lists["shape"])
+    if use_hands:
+        lists["hand"] = cfg.get("hand_joints_weights") or [0.0, 0.0, 0.0, 1.0]
+        lists["hprior"] = cfg.get("hand_pose_prior_weights") or [1e2, 5 * 1e1, 1e1, .5 * 1e1]
+    if cfg.get("interpenetration", False):
+        lists["coll"] = cfg.get("coll_loss_weights") or [0.0] * n
+    lists["go"] = cfg.get("global_orient_weights") or [20, 10, 7.5, 5, 5]
+    for k in ("shape", "face", "expr", "jaw", "hand", "hprior", "coll"):
+        if k in lists and len(lists[k]) != n:
+            raise AssertionError("Number of Body pose prior weights does not match the number of %s weights" % k)
+    ns = min(len(v) for v in lists.values())
+    out = []
+    for i in range(ns):
+        w = capi.StageWeights()
+        w.body_pose_weight = lists["bpw"][i]
+        w.shape_weight = lists["shape"][i]
+        w.hand_prior_weight = lists["hprior"][i] if use_hands else 0.0
+        w.expr_prior_weight = lists["expr"][i] if use_face else 0.0
+        jaw = lists["jaw"][i] if use_face else [0.0, 0.0, 0.0]
+        for q in range(3):
+            w.jaw_prior_weight[q] = jaw[q]
+        w.hand_joint_weight = lists["hand"][i] if use_hands else 0.0
+        w.face_joint_weight = lists["face"][i] if use_face else 0.0
+        w.coll_loss_weight = lists["coll"][i] if "coll" in lists else 0.0
+        out.append(w)
+    return out, n
+
+
+class DeviceModel(object):
+    """SMPL-X constants resident in HBM (sfx_model).  `model` is a dict with the .npz key
+    set of SURVEY.md appendix A.1 (a real SMPLX_*.npz loaded with numpy, or
+    synthetic.make_synthetic_model())."""
+
+    def __init__(self, model, joint_map=None, num_betas=10, num_expression_coeffs=10,
+                 num_pca_comps=12, flat_hand_mean=False, use_face_contour=True,
+                 extra_vertex_ids=None, vposer=None):
+        lib = capi.load()
+        sd = np.asarray(model["shapedirs"])
+        es = 300 if sd.shape[-1] >= 400 else 10
+        sdirs = np.concatenate([sd[:, :, :num_betas], sd[:, :, es:es + num_expression_coeffs]], -1)
+        V = int(np.asarray(model["v_template"]).shape[0])
+        faces = capi.i32(np.asarray(model["f"]).astype(np.int64))
+        parents = np.asarray(model["kintree_table"])[0].astype(np.int64).copy()
+        parents[0] = -1
+        lm = np.zeros(45) if flat_hand_mean else np.asarray(model["hands_meanl"])
+        rm = np.zeros(45) if flat_hand_mean else np.asarray(model["hands_meanr"])
+        pose_mean = np.concatenate([np.zeros(75), lm, rm])
+        if extra_vertex_ids is None:
+            extra_vertex_ids = model.get("extra_vertex_ids", SMPLX_EXTRA_VERTEX_IDS)
+        n_lmk = int(np.asarray(model["lmk_faces_idx"]).shape[0])
+        dyn_f = np.asarray(model["dynamic_lmk_faces_idx"])
+        n_dyn = int(dyn_f.shape[1]) if use_face_contour else 0
+        n_all = 55 + len(extra_vertex_ids) + n_lmk + n_dyn
+        if joint_map is None:
+            joint_map = np.arange(n_all)
+        self.joint_map = np.asarray(joint_map).astype(np.int64)
+        self.V, self.F, self.K = V, int(faces.shape[0]), int(len(self.joint_map))
+        self.num_betas, self.num_expr, self.num_pca = num_betas, num_expression_coeffs, num_pca_comps
+        self.faces = np.asarray(model["f"]).astype(np.int64)
+        keep = dict(
+            v_template=capi.f32(model["v_template"]), shapedirs=capi.f32(sdirs),
+            posedirs=capi.f32(model["posedirs"]), J_regressor=capi.f32(model["J_regressor"]),
+            lbs_weights=capi.f32(model["weights"]), parents=capi.i32(parents),
+            hands_comp_l=capi.f32(np.asarray(model["hands_componentsl"])[:num_pca_comps]),
+            hands_comp_r=capi.f32(np.asarray(model["hands_componentsr"])[:num_pca_comps]),
+            pose_mean=capi.f32(pose_mean), faces=faces,
+            extra=capi.i32(extra_vertex_ids), lmk_f=capi.i32(model["lmk_faces_idx"]),
+            lmk_b=capi.f32(model["lmk_bary_coords"]), dyn_f=capi.i32(dyn_f),
+            dyn_b=capi.f32(model["dynamic_lmk_bary_coords"]), jm=capi.i32(self.joint_map))
+        d = capi.ModelDesc()
+        d.V, d.F, d.J = V, self.F, 55
+        d.num_betas, d.num_expr, d.num_pca = num_betas, num_expression_coeffs, num_pca_comps
+        d.v_template = capi.fptr(keep["v_template"]); d.shapedirs = capi.fptr(keep["shapedirs"])
+        d.posedirs = capi.fptr(keep["posedirs"]); d.J_regressor = capi.fptr(keep["J_regressor"])
+        d.lbs_weights = capi.fptr(keep["lbs_weights"]); d.parents = capi.iptr(keep["parents"])
+        d.hands_comp_l = capi.fptr(keep["hands_comp_l"]); d.hands_comp_r = capi.fptr(keep["hands_comp_r"])
+        d.pose_mean = capi.fptr(keep["pose_mean"]); d.faces = capi.iptr(keep["faces"])
+        d.n_extra = len(extra_vertex_ids); d.extra_vertex_ids = capi.iptr(keep["extra"])
+        d.n_lmk = n_lmk; d.lmk_faces_idx = capi.iptr(keep["lmk_f"]); d.lmk_bary = capi.fptr(keep["lmk_b"])
+        d.n_dyn_rows = int(dyn_f.shape[0]) if n_dyn else 0; d.n_dyn = n_dyn
+        d.dyn_lmk_faces_idx = capi.iptr(keep["dyn_f"]); d.dyn_lmk_bary = capi.fptr(keep["dyn_b"])
+        d.K = self.K; d.joint_map = capi.iptr(keep["jm"])
+        h = C.c_void_p()
+        capi.check(lib.sfx_model_create(C.byref(d), C.byref(h)))
+        self._h = h
+        self._lib = lib
+        self.vposer_latent = 0
+        if vposer is not None:
+            self.set_vposer(vposer)
+
+    def set_vposer(self, w):
+        a = {k: capi.f32(v) for k, v in w.items()}
+        latent, hidden = a["fc1_w"].shape[1], a["fc1_w"].shape[0]
+        capi.check(self._lib.sfx_model_set_vposer(self._h, latent, hidden, capi.fptr(a["fc1_w"]), capi.fptr(a["fc1_b"]),
+                                                  capi.fptr(a["fc2_w"]), capi.fptr(a["fc2_b"]),
+                                                  capi.fptr(a["out_w"]), capi.fptr(a["out_b"])))
+        self.vposer_latent = latent
+
+    def lbs_forward(self, global_orient, body_pose, betas, expression, jaw_pose, leye_pose, reye_pose,
+                    left_hand_pose, right_hand_pose, return_verts=True, return_full_pose=True, stream=None):
+        """torch CUDA tensors in/out (containers only); one dense LBS launch sequence."""
+        import torch
+        B = global_orient.shape[0]
+        dev = global_orient.device
+        ptr = lambda t: C.c_void_p(t.contiguous().data_ptr()) if t is not None else None
+        ins = [t.contiguous().float() if t is not None else None for t in
+               (global_orient, body_pose, betas, expression, jaw_pose, leye_pose, reye_pose,
+                left_hand_pose, right_hand_pose)]
+        verts = torch.empty([B, self.V, 3], dtype=torch.float32, device=dev) if return_verts else None
+        joints = torch.empty([B, self.K, 3], dtype=torch.float32, device=dev)
+        fp = torch.empty([B, 165], dtype=torch.float32, device=dev) if return_full_pose else None
+        s = C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream)
+        capi.check(self._lib.sfx_lbs_forward(self._h, B, *[ptr(t) for t in ins], ptr(verts), ptr(joints), ptr(fp), s))
+        return verts, joints, fp
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sfx_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FrameBatch(object):
+    """B frames under one configuration (sfx_batch)."""
+
+    def __init__(self, model, B, cfg, lbs_mode="dense", reuse_entry_eval=True, has_regression_pose=True):
+        self.model, self.B, self.cfg = model, int(B), dict(cfg)
+        self._lib = model._lib
+        stages, _ = stage_weights_from_cfg(cfg)
+        self.n_stages = len(stages)
+        c = capi.BatchCfg()
+        c.B = self.B
+        c.n_stages = self.n_stages
+        c.use_vposer = int(bool(cfg.get("use_vposer", True)))
+        c.use_hands = int(bool(cfg.get("use_hands", True)))
+        c.use_face = int(bool(cfg.get("use_face", True)))
+        c.use_joints_conf = int(bool(cfg.get("use_joints_conf", False)))
+        c.has_regression_pose = int(bool(has_regression_pose))
+        c.use_conf_cam_init = int(bool(cfg.get("use_conf_for_camera_init", False)))
+        c.num_body_joints = NUM_BODY_JOINTS[cfg.get("format", "coco25")]
+        c.maxiters = int(cfg.get("maxiters", 30))
+        c.ftol = float(cfg.get("ftol", 1e-9)); c.gtol = float(cfg.get("gtol", 1e-9))
+        c.lr = float(cfg.get("lr", 1.0)); c.rho = float(cfg.get("rho", 100))
+        c.depth_loss_weight = float(cfg.get("depth_loss_weight", 1e2))
+        c.lbs_mode = {"rows": 0, "dense": 1}[lbs_mode]
+        c.reuse_entry_eval = int(bool(reuse_entry_eval))
+        self.use_vposer = bool(c.use_vposer)
+        self.nemb = model.vposer_latent if self.use_vposer else 63
+        arr = (capi.StageWeights * max(1, self.n_stages))(*stages)
+        h = C.c_void_p()
+        capi.check(self._lib.sfx_batch_create(model._h, C.byref(c), arr, C.byref(h)))
+        self._h = h
+        self.K = model.K
+
+    # ---- data ------------------------------------------------------------------------------
+    def set_frames(self, keypoints, joint_weights, cam_init_mask, focal, center, data_weight, est_tz=None,
+                   cam_rot=None):
+        B, K = self.B, self.K
+        kp = capi.f32(keypoints).reshape(B, K, 3)
+        jw = capi.f32(np.broadcast_to(np.asarray(joint_weights, np.float32), (B, K)))
+        cm = capi.f32(np.broadcast_to(np.asarray(cam_init_mask, np.float32), (B, K)))
+        cam = np.zeros((B, 6), np.float32)
+        cam[:, 0] = cam[:, 1] = np.asarray(focal, np.float32)
+        cam[:, 2:4] = np.asarray(center, np.float32).reshape(-1, 2)
+        cam[:, 4] = np.asarray(data_weight, np.float32)
+        if est_tz is not None:
+            cam[:, 5] = np.asarray(est_tz, np.float32)
+        R = np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (B, 1)) if cam_rot is None else \
+            capi.f32(cam_rot).reshape(B, 9)
+        capi.check(self._lib.sfx_batch_set_frames(self._h, capi.fptr(kp), capi.fptr(jw), capi.fptr(cm),
+                                                  capi.fptr(cam), capi.fptr(capi.f32(R))))
+
+    def set_params(self, regression_pose=None, **p):
+        B = self.B
+        sizes = dict(cam_translation=3, global_orient=3, betas=self.model.num_betas,
+                     left_hand_pose=self.model.num_pca, right_hand_pose=self.model.num_pca,
+                     expression=self.model.num_expr, jaw_pose=3, leye_pose=3, reye_pose=3,
+                     pose_embedding=self.nemb)
+        args = []
+        for n in PARAM_NAMES:
+            v = p.get(n)
+            a = None if v is None else capi.f32(np.broadcast_to(np.asarray(v, np.float32).reshape(-1, sizes[n]), (B, sizes[n])))
+            args.append(a)
+        reg = None if regression_pose is None else capi.f32(
+            np.broadcast_to(np.asarray(regression_pose, np.float32).reshape(-1, self.nemb), (B, self.nemb)))
+        capi.check(self._lib.sfx_batch_set_params(self._h, *[capi.fptr(a) for a in args], capi.fptr(reg)))
+
+    def get_params(self):
+        B = self.B
+        sizes = [3, 3, self.model.num_betas, self.model.num_pca, self.model.num_pca, self.model.num_expr,
+                 3, 3, 3, self.nemb, 63]
+        outs = [np.zeros((B, n), np.float32) for n in sizes]
+        capi.check(self._lib.sfx_batch_get_params(self._h, *[capi.fptr(a) for a in outs]))
+        d = dict(zip(PARAM_NAMES + ("body_pose",), outs))
+        return d
+
+    # ---- compute ---------------------------------------------------------------------------
+    def num_vars(self, stage):
+        return self._lib.sfx_batch_num_vars(self._h, stage)
+
+    def closure(self, stage):
+        """(loss[B], grad[B,N]) at the current parameters; stage -1 = camera-init loss."""
+        N = self.num_vars(stage)
+        loss = np.zeros(self.B, np.float32)
+        grad = np.zeros((self.B, N), np.float32)
+        capi.check(self._lib.sfx_batch_closure(self._h, stage, capi.fptr(loss), capi.fptr(grad), None))
+        return loss, grad
+
+    def guess_init(self, pairs):
+        p = capi.i32(np.asarray(pairs).reshape(-1, 2))
+        capi.check(self._lib.sfx_batch_guess_init(self._h, capi.iptr(p), p.shape[0], None))
+
+    def fit(self, first_stage=-1, last_stage=None, stream=None):
+        last = self.n_stages - 1 if last_stage is None else last_stage
+        capi.check(self._lib.sfx_batch_fit(self._h, first_stage, last, C.c_void_p(stream) if stream else None))
+
+    def stats(self):
+        ns = self.n_stages + 1
+        loss = np.zeros((self.B, ns), np.float32)
+        ev = np.zeros((self.B, ns), np.int32)
+        rev = np.zeros((self.B, ns), np.int32)
+        capi.check(self._lib.sfx_batch_get_stats(self._h, capi.fptr(loss), capi.iptr(ev), capi.iptr(rev)))
+        return dict(stage_loss=loss, stage_evals=ev, stage_ref_evals=rev)
+
+    def forward(self, want_verts=True):
+        """Final meshes/joints at the current parameters as torch CUDA tensors."""
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        verts = torch.empty([self.B, self.model.V, 3], dtype=torch.float32, device=dev) if want_verts else None
+        joints = torch.empty([self.B, self.K, 3], dtype=torch.float32, device=dev)
+        capi.check(self._lib.sfx_batch_forward(self._h, C.c_void_p(verts.data_ptr()) if want_verts else None,
+                                               C.c_void_p(joints.data_ptr()), None))
+        return verts, joints
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sfx_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def prof_enable(on=True):
+    capi.load().sfx_prof_enable(int(on))
+
+
+def prof_reset():
+    capi.load().sfx_prof_reset()
+
+
+def prof_get(name):
+    ms, n = C.c_double(), C.c_int64()
+    capi.load().sfx_prof_get(name.encode(), C.byref(ms), C.byref(n))
+    return ms.value, n.value

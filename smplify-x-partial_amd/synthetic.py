@@ -242,3 +242,36 @@ def make_frame_truth(index, seed=0):
         conf_drop=rng.uniform(size=144) < 0.10,
     )
     return truth
+
+
+def make_frames(n, joints_fn, K, start=0, seed=0, focal=5000.0, H=600, W=800):
+    """Synthetic 2-D keypoint frames `start .. start+n-1`.
+
+    joints_fn(params) -> [n,K,3] mapped model joints for dict `params` of [n,.] float32
+    arrays (global_orient, body_pose, betas; everything else zero) -- the caller supplies
+    the LBS forward (the HIP engine on the GPU box, the oracle in CPU tests).
+    Keypoints = perspective projection of the model's own joints + 1 px noise;
+    confidences U(0.3,1) with 10 % dropped to (0,0,0); "regression prior" = true pose +
+    0.05 rad noise pushed through the rotmat -> xyz-euler path of the reference.
+    """
+    from .utils import euler_xyz_from_matrix
+    tr = [make_frame_truth(start + i, seed) for i in range(n)]
+    P = dict(global_orient=np.stack([t["global_orient"] for t in tr]).astype(np.float32),
+             body_pose=np.stack([t["body_pose"] for t in tr]).astype(np.float32),
+             betas=np.stack([t["betas"] for t in tr]).astype(np.float32))
+    j3 = np.asarray(joints_fn(P), np.float64)                       # [n,K,3]
+    cam_t = np.stack([t["cam_t"] for t in tr])
+    pc = j3 + cam_t[:, None, :]
+    uv = focal * pc[..., :2] / pc[..., 2:3] + np.array([W * 0.5, H * 0.5])
+    noise = np.stack([t["kp_noise"][:K] for t in tr])
+    conf = np.stack([t["conf"][:K] for t in tr])
+    drop = np.stack([t["conf_drop"][:K] for t in tr])
+    kp = np.concatenate([uv + noise, conf[..., None]], -1)
+    kp[drop] = 0.0
+    reg_pose = np.stack([euler_xyz_from_matrix(rodrigues_np((t["body_pose"] + t["prior_noise"]).reshape(21, 3))).reshape(-1)
+                         for t in tr])
+    reg_glob = np.stack([euler_xyz_from_matrix(rodrigues_np(t["global_orient"] + t["prior_noise_go"]))
+                         for t in tr])
+    return dict(keypoints=kp.astype(np.float32), reg_pose=reg_pose.astype(np.float32),
+                reg_global=reg_glob.astype(np.float32), truth=P, cam_t=cam_t.astype(np.float32),
+                H=H, W=W, focal=float(focal))

@@ -1,0 +1,102 @@
+"""Shared builders for the parity tests (oracle side = checker, engine side = product)."""
+import os
+
+import numpy as np
+import torch
+
+from smplifyx_amd import cmd_parser, synthetic, utils as U
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG_DIR = os.path.join(ROOT, "cfg_files")
+
+
+def load_cfg(name, **over):
+    base = dict(visualize=False, interactive=False, interpenetration=False, save_vertices=False,
+                use_gender_classifier=False)
+    base.update(over)
+    return cmd_parser.load_config(os.path.join(CFG_DIR, name), base)
+
+
+def joint_map_for(cfg):
+    return U.smpl_to_annotation("smplx", use_hands=cfg["use_hands"], use_face=cfg["use_face"],
+                                use_face_contour=cfg["use_face_contour"], format=cfg["format"])
+
+
+def base_joint_weights(cfg, K):
+    """COCO25.get_joint_weights (smplifyx/data_parser.py:159-171)."""
+    w = np.ones(K, np.float32)
+    ign = cfg.get("joints_to_ign")
+    if ign is not None and -1 not in ign:
+        w[ign] = 0.0
+    return w
+
+
+def random_params(rng, B, scale=1.0, nb=10, ne=10, npca=12):
+    return dict(
+        global_orient=(0.4 * scale * rng.normal(size=(B, 3))).astype(np.float32),
+        pose_embedding=(0.3 * scale * rng.normal(size=(B, 63))).astype(np.float32),
+        betas=(scale * rng.normal(size=(B, nb))).astype(np.float32),
+        expression=(scale * rng.normal(size=(B, ne))).astype(np.float32),
+        jaw_pose=(0.2 * scale * rng.normal(size=(B, 3))).astype(np.float32),
+        leye_pose=(0.1 * scale * rng.normal(size=(B, 3))).astype(np.float32),
+        reye_pose=(0.1 * scale * rng.normal(size=(B, 3))).astype(np.float32),
+        left_hand_pose=(scale * rng.normal(size=(B, npca))).astype(np.float32),
+        right_hand_pose=(scale * rng.normal(size=(B, npca))).astype(np.float32),
+    )
+
+
+def oracle_model(model, cfg, dtype=torch.float32):
+    from oracle.body_model import SMPLXRef
+    return SMPLXRef(model, joint_map=joint_map_for(cfg), num_betas=cfg["num_betas"],
+                    num_expression_coeffs=cfg["num_expression_coeffs"], num_pca_comps=cfg["num_pca_comps"],
+                    use_face_contour=cfg["use_face_contour"], create_body_pose=not cfg["use_vposer"], dtype=dtype)
+
+
+def oracle_joints_fn(model, cfg):
+    bm = oracle_model(model, cfg, torch.float64)
+
+    def fn(P):
+        n = P["global_orient"].shape[0]
+        out = []
+        for i in range(n):
+            bm.reset_params(global_orient=P["global_orient"][i:i + 1], betas=P["betas"][i:i + 1])
+            with torch.no_grad():
+                o = bm(return_verts=False, body_pose=torch.tensor(P["body_pose"][i:i + 1], dtype=torch.float64))
+            out.append(o.joints[0].numpy())
+        return np.stack(out)
+    return fn
+
+
+def oracle_frame_fit(model, cfg, frames, i, dtype=torch.float32, **kw):
+    """oracle.fit_frame.FrameFit for synthetic frame i (regression prior = noisy truth)."""
+    from oracle.fit_frame import FrameFit
+    bm = oracle_model(model, cfg, dtype)
+    K = frames["keypoints"].shape[1]
+    return FrameFit(bm, frames["keypoints"][i:i + 1], frames["H"], frames["W"], frames["focal"], cfg,
+                    base_joint_weights(cfg, K), reg_pose=frames["reg_pose"][i], reg_global=frames["reg_global"][i],
+                    dtype=dtype, **kw)
+
+
+def engine_batch_from_frames(dm, cfg, frames, idx, lbs_mode="rows", reuse=False):
+    """FrameBatch prepared the way fit_single_frame.py:209-294,358-411 prepares one frame."""
+    from smplifyx_amd import engine
+    idx = list(idx)
+    B = len(idx)
+    kp = frames["keypoints"][idx]
+    K = kp.shape[1]
+    nb = engine.NUM_BODY_JOINTS[cfg["format"]]
+    thr = np.array([cfg.get("confidence_threshold", 0)] * nb + [0] * 110)[:K]
+    jw = np.tile(base_joint_weights(cfg, K), (B, 1))
+    low = kp[:, :, 2] < thr[None, :]
+    jw[low] = 0
+    cmask = np.zeros((B, K), np.float32)
+    for b in range(B):
+        for j in cfg["init_joints_idxs"]:
+            if kp[b, j, 0] != 0 and kp[b, j, 1] != 0 and not low[b, j]:
+                cmask[b, j] = 1
+    fb = engine.FrameBatch(dm, B, cfg, lbs_mode=lbs_mode, reuse_entry_eval=reuse, has_regression_pose=True)
+    H, W = frames["H"], frames["W"]
+    fb.set_frames(kp, jw, cmask, frames["focal"], np.tile([W * 0.5, H * 0.5], (B, 1)), 1000.0 / H)
+    fb.set_params(regression_pose=frames["reg_pose"][idx], global_orient=frames["reg_global"][idx],
+                  pose_embedding=frames["reg_pose"][idx], cam_translation=np.zeros((B, 3), np.float32))
+    return fb
