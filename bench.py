@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py -- fitted frames/s of the MI355X SMPL-X fitting engine (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): 256 synthetic frames per GPU, neutral SMPL-X-shaped
+synthetic model, body-only (K=25 coco25), the 5-stage L-BFGS schedule of
+cfg_files/fit_smplx_smplifyx.yaml with use_vposer=False + synthetic regression prior
+(SURVEY.md 8d), camera stage + 5 body stages per frame.  A "step" = one complete fit of
+the rank's 256 frames.  Frames are independent: rank r fits frames [r*256, (r+1)*256)
+(weak scaling), no collective in the data path, one all_gather of the fitted-parameter
+records at the end of every step (RCCL over xGMI when N > 1).
+
+    python bench.py --gpus N --steps K --warmup W [--lbs dense|rows] [--frames 256]
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel (k_lbs_dense): algorithmic flops / HIP-event duration
+  cpu_baseline  the oracle (port of the reference path) timed on the host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+PEAK_MFMA_F32 = 157.3e12      # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+PEAK_HBM = 8.0e12
+
+
+def build_cfg():
+    import helpers as H
+    cfg = H.load_cfg("fit_smplx_smplifyx.yaml", use_hands=False, use_face=False, use_vposer=False)
+    cfg["use_camera_prior"] = False
+    return cfg
+
+
+def lbs_flops_per_frame(V, KD=506, J=55):
+    return 2.0 * KD * 3 * V + 2.0 * J * 12 * V + 21.0 * V
+
+
+def lbs_bytes_per_launch(B, V, KD=506, J=55):
+    const = 4.0 * (KD * 3 * V + J * V + 3 * V)              # dirs + W + template
+    return const + B * (3.0 * V * 4 + (KD + 12 * J) * 4)    # vertices out + feat/A in
+
+
+def cpu_baseline(model, cfg, frames, ref_evals_per_frame, budget_s=25.0):
+    """Oracle (port of the reference's path, validated against the reference by
+    tests/golden) on the host: closure evaluations/s inside the real frame driver for
+    ~budget_s seconds, converted to frames/s with the evaluations one fitted frame takes."""
+    import helpers as H
+    threads = max(1, min(8, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    ff = H.oracle_frame_fit(model, cfg, frames, 0, dtype=torch.float32)
+
+    class _Stop(Exception):
+        pass
+    t0 = time.time()
+    n = [0]
+    orig = ff._make_closure
+
+    def mk(params, fn):
+        closure, groups = orig(params, fn)
+
+        def timed(x):
+            if time.time() - t0 > budget_s:
+                raise _Stop()
+            n[0] += 1
+            return closure(x)
+        return timed, groups
+    ff._make_closure = mk
+    try:
+        ff.run()
+    except _Stop:
+        pass
+    dt = time.time() - t0
+    evals_s = n[0] / dt
+    return {"value": evals_s / max(ref_evals_per_frame, 1.0), "unit": "frames/s", "cores": threads,
+            "kind": "port", "closure_evals_per_s": evals_s,
+            "sample": "oracle frame driver (torch fp32, %d threads) on frame 0 for %.0f s = %d closure "
+                      "evaluations (dense LBS fwd + autograd bwd each); frames/s = evals/s / %.0f "
+                      "reference-equivalent evaluations per fitted frame" % (threads, dt, n[0], ref_evals_per_frame)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU")
+    ap.add_argument("--lbs", default="dense", choices=["dense", "rows"])
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    import helpers as H
+    from smplifyx_amd import engine, synthetic
+    cfg = build_cfg()
+    model = synthetic.make_synthetic_model(0)
+    jm = H.joint_map_for(cfg)
+    dm = engine.DeviceModel(model, joint_map=jm, num_betas=cfg["num_betas"],
+                            num_expression_coeffs=cfg["num_expression_coeffs"],
+                            num_pca_comps=cfg["num_pca_comps"], use_face_contour=cfg["use_face_contour"])
+    B = args.frames
+    dev = torch.device("cuda", local_rank)
+
+    def joints_fn(P):
+        z = lambda n: torch.zeros([B, n], device=dev)
+        t = lambda a: torch.tensor(a, device=dev)
+        _, j, _ = dm.lbs_forward(t(P["global_orient"]), t(P["body_pose"]), t(P["betas"]), z(10), z(3), z(3), z(3),
+                                 z(12), z(12), return_verts=False, return_full_pose=False)
+        return j.cpu().numpy()
+    frames = synthetic.make_frames(B, joints_fn, len(jm), start=rank * B, focal=float(cfg["focal_length"]))
+
+    def one_fit():
+        fb = H.engine_batch_from_frames(dm, cfg, frames, range(B), lbs_mode=args.lbs, reuse=True)
+        fb.guess_init(cfg["body_tri_idxs"])
+        fb.fit()
+        p = fb.get_params()
+        st = fb.stats()
+        rec = np.concatenate([p["cam_translation"], p["global_orient"], p["betas"], p["pose_embedding"],
+                              st["stage_loss"][:, -1:], st["stage_evals"].sum(1, keepdims=True).astype(np.float32)], 1)
+        if dist is not None:
+            rt = torch.tensor(rec, device=dev)
+            out = [torch.empty_like(rt) for _ in range(world)]
+            dist.all_gather(out, rt)
+        fb.close()
+        return st, p
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_fit()
+    engine.prof_enable(True)
+    engine.prof_reset()
+    sync()
+    t0 = time.time()
+    for _ in range(args.steps):
+        st, p = one_fit()
+    sync()
+    dt = time.time() - t0
+    engine.prof_enable(False)
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ms_dense, n_dense = engine.prof_get("lbs_dense")
+        ms_clo, n_clo = engine.prof_get("closure")
+        ms_lb, n_lb = engine.prof_get("lbfgs")
+        evals = st["stage_evals"].sum(1)
+        ref_evals = st["stage_ref_evals"].sum(1)
+        out = {
+            "metric": "fitted frames/sec", "value": world * B * args.steps / dt, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d synthetic frames/GPU, neutral SMPL-X-shaped synthetic model, "
+                                   "body-only K=25, camera stage + 5-stage L-BFGS (fit_smplx_smplifyx.yaml weights, "
+                                   "use_vposer=False, synthetic regression prior)" % B,
+                       "frames_per_gpu": B, "lbs_mode": args.lbs, "parallelism": "frames sharded, dp%d" % world,
+                       "closure_evals_per_frame_mean": float(evals.mean()),
+                       "closure_evals_per_frame_max": int(evals.max()),
+                       "reference_equiv_evals_per_frame_mean": float(ref_evals.mean()),
+                       "final_loss_mean": float(np.nanmean(st["stage_loss"][:, -1]))},
+            "kernels_ms_avg": {"lbs_dense": ms_dense / max(n_dense, 1), "closure": ms_clo / max(n_clo, 1),
+                               "lbfgs": ms_lb / max(n_lb, 1), "ticks_per_step": n_clo / max(args.steps, 1)},
+        }
+        if args.lbs == "dense" and n_dense:
+            t_k = 1e-3 * ms_dense / n_dense
+            fl = B * lbs_flops_per_frame(dm.V)
+            by = lbs_bytes_per_launch(B, dm.V)
+            out["roofline"] = {"kernel": "k_lbs_dense", "bound": "mfma", "achieved": fl / t_k / 1e12,
+                               "peak": PEAK_MFMA_F32 / 1e12, "unit": "TFLOP/s", "frac": fl / t_k / PEAK_MFMA_F32,
+                               "traffic": None, "flops_per_launch": fl, "bytes_per_launch": by,
+                               "hbm_GBps": by / t_k / 1e9, "hbm_frac": by / t_k / PEAK_HBM,
+                               "avg_launch_us": 1e6 * t_k, "launches": n_dense, "frames_per_launch": B}
+        else:
+            t_k = 1e-3 * ms_clo / max(n_clo, 1)
+            rows = 11
+            by = B * rows * (3 * 512 + 55) * 4.0 * 2
+            out["roofline"] = {"kernel": "k_closure(rows)", "bound": "hbm", "achieved": by / t_k / 1e9,
+                               "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": by / t_k / PEAK_HBM, "traffic": None,
+                               "bytes_per_launch": by, "avg_launch_us": 1e6 * t_k, "launches": n_clo}
+        if not args.no_cpu:
+            try:
+                out["cpu_baseline"] = cpu_baseline(model, cfg, frames, float(ref_evals.mean()))
+            except Exception as e:      # the baseline is a report, never the product path
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
