@@ -102,7 +102,7 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
     if (!d || !out) { sfx_set_error("null argument"); return -1; }
     if (d->J != SFX_J) { sfx_set_error("only J=55 (SMPL-X) is supported, got %d", d->J); return -1; }
     const int V = d->V, S = d->num_betas + d->num_expr, P = 9 * (d->J - 1), KD = S + P;
-    if (KD > SFX_KD_PAD || (KD & 1)) { sfx_set_error("blend-shape depth %d unsupported", KD); return -1; }
+    if (KD > SFX_KD_PAD || (KD % 22)) { sfx_set_error("blend-shape depth %d unsupported", KD); return -1; }
     if (d->K > SFX_MAX_K) { sfx_set_error("K=%d > %d", d->K, SFX_MAX_K); return -1; }
     int dev_count = 0;
     if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count == 0) {
@@ -117,16 +117,17 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
 
     std::vector<float> vt(d->v_template, d->v_template + (size_t)V * 3);
     M.v_template = m->mem.up(vt);
-    // blend-shape matrix, k-major [KD][V][3] and vertex-major [V][3][KD_PAD]
+    // blend-shape matrix, k-major [KD][3*Vpad] and vertex-major [V][3][KD_PAD]
     {
-        std::vector<float> dirs((size_t)KD * V * 3), dirsT((size_t)V * 3 * SFX_KD_PAD, 0.f);
+        const size_t LD = (size_t)3 * M.Vpad;
+        std::vector<float> dirs((size_t)KD * LD, 0.f), dirsT((size_t)V * 3 * SFX_KD_PAD, 0.f);
         for (int v = 0; v < V; ++v)
             for (int c = 0; c < 3; ++c) {
                 const float* sd = d->shapedirs + ((size_t)v * 3 + c) * S;
                 const float* pd = d->posedirs + ((size_t)v * 3 + c) * P;
                 float* row = &dirsT[((size_t)v * 3 + c) * SFX_KD_PAD];
-                for (int k = 0; k < S; ++k) { row[k] = sd[k]; dirs[((size_t)k * V + v) * 3 + c] = sd[k]; }
-                for (int k = 0; k < P; ++k) { row[S + k] = pd[k]; dirs[((size_t)(S + k) * V + v) * 3 + c] = pd[k]; }
+                for (int k = 0; k < S; ++k) { row[k] = sd[k]; dirs[(size_t)k * LD + (size_t)v * 3 + c] = sd[k]; }
+                for (int k = 0; k < P; ++k) { row[S + k] = pd[k]; dirs[(size_t)(S + k) * LD + (size_t)v * 3 + c] = pd[k]; }
             }
         M.dirs = m->mem.up(dirs);
         M.dirsT = m->mem.up(dirsT);
@@ -316,7 +317,7 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
         w.hand_jw = st[i].hand_joint_weight; w.face_jw = st[i].face_joint_weight;
     }
     b->sw_dev = b->mem.up(sws);
-    D.Bpad = ((B + 31) / 32) * 32;
+    D.Bpad = ((B + 127) / 128) * 128;
     D.X = b->mem.zeros<float>((size_t)B * SFX_NPAR_MAX);
     D.Xt = b->mem.zeros<float>((size_t)B * SFX_NPAR_MAX);
     D.gt = b->mem.zeros<float>((size_t)B * K * 2);

@@ -64,7 +64,7 @@ struct OptScal {
     Sc t, t_prev, H_diag;
     Sc loss, prev_loss, orig_loss, f_prev, ls_f0;
     Sc gtd_prev, ls_gtd0, d_norm;
-    Sc br[2], bf[2], bgtd[2];
+    Sc br0, br1, bf0, bf1, bgtd0, bgtd1;
     double prev_loss_outer;
 };
 struct OptState {
@@ -140,7 +140,7 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
         s.t = P(0.0); s.t_prev = P(0.0); s.H_diag = P(1.0);
         s.loss = P(0.0); s.prev_loss = P(0.0); s.orig_loss = P(0.0); s.f_prev = P(0.0); s.ls_f0 = P(0.0);
         s.gtd_prev = P(0.0); s.ls_gtd0 = P(0.0); s.d_norm = P(0.0);
-        s.br[0] = s.br[1] = s.bf[0] = s.bf[1] = s.bgtd[0] = s.bgtd[1] = P(0.0);
+        s.br0 = s.br1 = s.bf0 = s.bf1 = s.bgtd0 = s.bgtd1 = P(0.0);
         s.prev_loss_outer = 0.0;
     };
     if (init) {
@@ -183,12 +183,12 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
     auto start_zoom = [&](Sc b0, Sc b1, Sc f0, Sc f1, int g0_vec, const Lane3* g0_reg, const Lane3& g1, Sc gd0, Sc gd1,
                           bool done) {
         // bracket gradients: slot 0 from a stored vector (or register), slot 1 = incoming
-        s.br[0] = b0; s.br[1] = b1; s.bf[0] = f0; s.bf[1] = f1; s.bgtd[0] = gd0; s.bgtd[1] = gd1;
+        s.br0 = b0; s.br1 = b1; s.bf0 = f0; s.bf1 = f1; s.bgtd0 = gd0; s.bgtd1 = gd1;
         if (g0_reg) st3(VEC(VEC_BG0), *g0_reg, lane, N);
         else { const Lane3 tmp = ld3(VEC(g0_vec), lane, N); st3(VEC(VEC_BG0), tmp, lane, N); }
         st3(VEC(VEC_BG1), g1, lane, N);
         s.ls_done = done ? 1 : 0; s.insuf = 0;
-        if (sc_le(s.bf[0], s.bf[1])) { s.low = 0; s.high = 1; } else { s.low = 1; s.high = 0; }
+        if (sc_le(s.bf0, s.bf1)) { s.low = 0; s.high = 1; } else { s.low = 1; s.high = 0; }
     };
 
     int act = A_NONE;
@@ -233,21 +233,21 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
         const Lane3 d = ld3(VEC(VEC_D), lane, N);
         const Sc gtd_new = T(dot3(g_in, d));
         const int lo = s.low, hi = s.high;
-        if (armijo_fail(f_in, t) || sc_ge(f_in, s.bf[lo])) {
-            s.br[hi] = t; s.bf[hi] = f_in; s.bgtd[hi] = gtd_new;
+        if (armijo_fail(f_in, t) || sc_ge(f_in, (lo ? s.bf1 : s.bf0))) {
+            { const Sc v_ = t; if (hi) s.br1 = v_; else s.br0 = v_; } { const Sc v_ = f_in; if (hi) s.bf1 = v_; else s.bf0 = v_; } { const Sc v_ = gtd_new; if (hi) s.bgtd1 = v_; else s.bgtd0 = v_; }
             st3(VEC(hi ? VEC_BG1 : VEC_BG0), g_in, lane, N);
-            if (sc_le(s.bf[0], s.bf[1])) { s.low = 0; s.high = 1; } else { s.low = 1; s.high = 0; }
+            if (sc_le(s.bf0, s.bf1)) { s.low = 0; s.high = 1; } else { s.low = 1; s.high = 0; }
         } else {
             if (curv_ok(gtd_new)) s.ls_done = 1;
-            else if (sc_ge(sc_mul(gtd_new, sc_sub(s.br[hi], s.br[lo])), P(0.0))) {
-                s.br[hi] = s.br[lo]; s.bf[hi] = s.bf[lo]; s.bgtd[hi] = s.bgtd[lo];
+            else if (sc_ge(sc_mul(gtd_new, sc_sub((hi ? s.br1 : s.br0), (lo ? s.br1 : s.br0))), P(0.0))) {
+                { const Sc v_ = (lo ? s.br1 : s.br0); if (hi) s.br1 = v_; else s.br0 = v_; } { const Sc v_ = (lo ? s.bf1 : s.bf0); if (hi) s.bf1 = v_; else s.bf0 = v_; } { const Sc v_ = (lo ? s.bgtd1 : s.bgtd0); if (hi) s.bgtd1 = v_; else s.bgtd0 = v_; }
                 const Lane3 tmp = ld3(VEC(lo ? VEC_BG1 : VEC_BG0), lane, N);
                 st3(VEC(hi ? VEC_BG1 : VEC_BG0), tmp, lane, N);
             }
-            s.br[lo] = t; s.bf[lo] = f_in; s.bgtd[lo] = gtd_new;
+            { const Sc v_ = t; if (lo) s.br1 = v_; else s.br0 = v_; } { const Sc v_ = f_in; if (lo) s.bf1 = v_; else s.bf0 = v_; } { const Sc v_ = gtd_new; if (lo) s.bgtd1 = v_; else s.bgtd0 = v_; }
             st3(VEC(lo ? VEC_BG1 : VEC_BG0), g_in, lane, N);
         }
-        if (sc_lt(sc_mul(sc_abs(sc_sub(s.br[1], s.br[0])), s.d_norm), P(tol_change))) act = A_FINISH_LS;
+        if (sc_lt(sc_mul(sc_abs(sc_sub(s.br1, s.br0)), s.d_norm), P(tol_change))) act = A_FINISH_LS;
         else act = A_ZOOM_NEXT;
     }
 
@@ -292,24 +292,51 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
                 __syncthreads();
                 Lane3 q;
                 for (int e = 0; e < NE3; ++e) q.v[e] = -g.v[e];
-                for (int i = s.hist_n - 1; i >= 0; --i) {
-                    const int ph = (s.hist_head + i) % SFX_HIST;
-                    const Lane3 Si = ld3(hS + (size_t)ph * SFX_NVAR_MAX, lane, N);
-                    const Lane3 Yi = ld3(hY + (size_t)ph * SFX_NVAR_MAX, lane, N);
-                    const float al = dot3(Si, q) * gst->ro[ph];
-                    if (lane == 0) s_al[i] = al;
-                    q = axpy3(q, -al, Yi);
+                // two-loop recursion; history rows are prefetched CH at a time so that the
+                // serial chain is dot/axpy latency only, not HBM latency
+                constexpr int CH = 8;
+                for (int i0 = s.hist_n - 1; i0 >= 0; i0 -= CH) {
+                    Lane3 Sb[CH], Yb[CH]; float rb[CH];
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int i = i0 - c;
+                        const int ph = (s.hist_head + (i >= 0 ? i : 0)) % SFX_HIST;
+                        Sb[c] = ld3(hS + (size_t)ph * SFX_NVAR_MAX, lane, N);
+                        Yb[c] = ld3(hY + (size_t)ph * SFX_NVAR_MAX, lane, N);
+                        rb[c] = gst->ro[ph];
+                    }
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int i = i0 - c;
+                        if (i >= 0) {
+                            const float al = dot3(Sb[c], q) * rb[c];
+                            if (lane == 0) s_al[i] = al;
+                            q = axpy3(q, -al, Yb[c]);
+                        }
+                    }
                 }
                 __syncthreads();
                 Lane3 r;
                 const float hd = (float)s.H_diag.v;
                 for (int e = 0; e < NE3; ++e) r.v[e] = q.v[e] * hd;
-                for (int i = 0; i < s.hist_n; ++i) {
-                    const int ph = (s.hist_head + i) % SFX_HIST;
-                    const Lane3 Si = ld3(hS + (size_t)ph * SFX_NVAR_MAX, lane, N);
-                    const Lane3 Yi = ld3(hY + (size_t)ph * SFX_NVAR_MAX, lane, N);
-                    const float be = dot3(Yi, r) * gst->ro[ph];
-                    r = axpy3(r, s_al[i] - be, Si);
+                for (int i0 = 0; i0 < s.hist_n; i0 += CH) {
+                    Lane3 Sb[CH], Yb[CH]; float rb[CH], ab[CH];
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int i = i0 + c;
+                        const int ph = (s.hist_head + (i < s.hist_n ? i : 0)) % SFX_HIST;
+                        Sb[c] = ld3(hS + (size_t)ph * SFX_NVAR_MAX, lane, N);
+                        Yb[c] = ld3(hY + (size_t)ph * SFX_NVAR_MAX, lane, N);
+                        rb[c] = gst->ro[ph];
+                        ab[c] = s_al[i < s.hist_n ? i : 0];
+                    }
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        if (i0 + c < s.hist_n) {
+                            const float be = dot3(Yb[c], r) * rb[c];
+                            r = axpy3(r, ab[c] - be, Sb[c]);
+                        }
+                    }
                 }
                 d = r;
             }
@@ -343,9 +370,9 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
         }
         case A_ZOOM_NEXT: {      // next zoom trial (lbfgs_ls.py:108-131)
             if (s.ls_done || !(s.ls_iter < max_iter)) { act = A_FINISH_LS; break; }
-            Sc t = cubic_interpolate(s.br[0], s.bf[0], s.bgtd[0], s.br[1], s.bf[1], s.bgtd[1], false, P(0), P(0));
-            const Sc bmax = sc_gt(s.br[1], s.br[0]) ? s.br[1] : s.br[0];
-            const Sc bmin = sc_lt(s.br[1], s.br[0]) ? s.br[1] : s.br[0];
+            Sc t = cubic_interpolate(s.br0, s.bf0, s.bgtd0, s.br1, s.bf1, s.bgtd1, false, P(0), P(0));
+            const Sc bmax = sc_gt(s.br1, s.br0) ? s.br1 : s.br0;
+            const Sc bmin = sc_lt(s.br1, s.br0) ? s.br1 : s.br0;
             const Sc eps = sc_mul(P(0.1), sc_sub(bmax, bmin));
             if (sc_lt(sc_pmin(sc_sub(bmax, t), sc_sub(t, bmin)), eps)) {
                 if (s.insuf || sc_ge(t, bmax) || sc_le(t, bmin)) {
@@ -362,8 +389,8 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
         }
         case A_FINISH_LS: {      // accept the lowest bracket end (lbfgs_ls.py:163-167,398-434)
             const int lo = s.low;
-            const Sc t = s.br[lo];
-            s.loss = s.bf[lo]; s.t = t;
+            const Sc t = (lo ? s.br1 : s.br0);
+            s.loss = (lo ? s.bf1 : s.bf0); s.t = t;
             const Lane3 g = ld3(VEC(lo ? VEC_BG1 : VEC_BG0), lane, N);
             st3(VEC(VEC_G), g, lane, N);
             const Lane3 xi = ld3(VEC(VEC_XINIT), lane, N), d = ld3(VEC(VEC_D), lane, N);

@@ -43,7 +43,7 @@ struct DevModel {
     int level_start[SFX_MAX_LEVELS + 1];
     // constants
     const float* v_template;   // [V][3]
-    const float* dirs;         // [KD][V][3]    k-major (dense GEMM B operand)
+    const float* dirs;         // [KD][3*Vpad]  k-major, coords interleaved (dense GEMM B operand)
     const float* dirsT;        // [V][3][KD_PAD] vertex-major (needed-rows path)
     const float* W;            // [V][J]
     const float* WT;           // [JPAD][Vpad]   (dense skinning GEMM B operand)
