@@ -83,6 +83,7 @@ struct sfx_model {
     DevModel M{};
     DevAlloc mem;
     int NB = 0, NE = 0, NPCA = 0;
+    std::vector<int> meta_host = std::vector<int>(SFX_META_N, 0);
     sfx_batch* fwd = nullptr;     // lazily created batch behind sfx_lbs_forward
     int fwd_B = 0;
 };
@@ -186,6 +187,9 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
             for (int c = j + 1; c < SFX_J; ++c) if (par[c] == j) cl.push_back(c);
         }
         cs[SFX_J] = (int)cl.size();
+        for (int j = 0; j < SFX_J; ++j) { m->meta_host[MO_PAR + j] = par[j]; m->meta_host[MO_LJ + j] = lj[j]; }
+        for (int j = 0; j <= SFX_J; ++j) m->meta_host[MO_CS + j] = cs[j];
+        for (size_t q = 0; q < cl.size(); ++q) m->meta_host[MO_CL + q] = cl[q];
         M.parents = m->mem.up(par); M.level_joints = m->mem.up(lj);
         M.child_start = m->mem.up(cs); M.child_list = m->mem.up(cl);
     }
@@ -234,10 +238,17 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
         std::vector<int> sk0(SFX_J + 1, 0), skl;
         for (int s = 0; s < SFX_J; ++s) { sk0[s] = (int)skl.size(); for (int k : readers[s]) skl.push_back(k); }
         sk0[SFX_J] = (int)skl.size();
+        for (int s2 = 0; s2 <= SFX_J; ++s2) m->meta_host[MO_SK0 + s2] = sk0[s2];
+        for (size_t q = 0; q < skl.size(); ++q) m->meta_host[MO_SKL + q] = skl[q];
+        for (int k = 0; k < K; ++k) { m->meta_host[MO_JT + k] = jt[k]; m->meta_host[MO_JS + k] = js[k];
+                                      m->meta_host[MO_JI0 + k] = ji0[k]; m->meta_host[MO_JN + k] = jn[k]; }
+        for (size_t q = 0; q < ik.size(); ++q) m->meta_host[MO_IK + q] = ik[q];
         M.jk_type = m->mem.up(jt); M.jk_src = m->mem.up(js); M.jk_item0 = m->mem.up(ji0); M.jk_nitem = m->mem.up(jn);
         M.item_vid = m->mem.up(ivid); M.item_w = m->mem.up(iw); M.item_dyn = m->mem.up(idyn); M.item_k = m->mem.up(ik);
         M.src_k0 = m->mem.up(sk0); M.src_klist = m->mem.up(skl);
     }
+    if (m->meta_host.size() != SFX_META_N) { sfx_set_error("internal: meta table"); delete m; return -1; }
+    M.meta = m->mem.up(m->meta_host);
     if (hipDeviceSynchronize() != hipSuccess) { sfx_set_error("model upload failed"); delete m; return -2; }
     *out = m;
     return 0;

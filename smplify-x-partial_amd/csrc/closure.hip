@@ -16,6 +16,7 @@
 //   loss                                         : one lane per keypoint, fixed-order reduce
 //   reverse sweep                                : gathers only (no atomics) -> deterministic
 #include "sfx_internal.h"
+#include "wave_ops.h"
 
 #define CT 256
 
@@ -45,29 +46,24 @@ struct __align__(16) FrameLDS {
     float dpose[168];
     float gc[SFX_NPAR_MAX];
     float red[CT];
-    float red2[CT * 3];
     float lh45[SFX_NHAND], rh45[SFX_NHAND];
     float scal[16];
     int   lut_row;
+    int   meta[SFX_META_N];     // tree / joint-map tables (one coalesced load instead of
+                                // dependent global loads inside every level of the chain)
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 
-// fixed-order block reduction of CT partials (result in all threads)
+// fixed-order block reduction: DPP sum per wavefront, then the CT/64 partials in order
+// (2 barriers instead of a 9-barrier LDS tree); result in all threads
 __device__ __forceinline__ float block_sum(float v, float* red) {
-    const int t = threadIdx.x;
+    const float w = wave_sum_dpp(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
     __syncthreads();
-    red[t] = v;
-    __syncthreads();
-    for (int s = CT / 2; s > 0; s >>= 1) {
-        if (t < s) red[t] += red[t + s];
-        __syncthreads();
-    }
     float r = red[0];
+#pragma unroll
+    for (int i = 1; i < CT / 64; ++i) r += red[i];
     __syncthreads();
     return r;
 }
@@ -152,6 +148,7 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
     // ------------------------------------------------------------------ load parameters
     const float* xsrc = (args.from_X ? D.X : D.Xt) + (size_t)b * SFX_NPAR_MAX;
     for (int i = t; i < L.npar; i += CT) S.x[i] = xsrc[i];
+    for (int i = t; i < SFX_META_N; i += CT) S.meta[i] = M.meta[i];
     for (int i = t; i < SFX_KD_PAD; i += CT) { S.feat[i] = 0.f; S.dfeat[i] = 0.f; }
     for (int i = t; i < SFX_NPAR_MAX; i += CT) S.gc[i] = 0.f;
     for (int i = t; i < 168; i += CT) S.dpose[i] = 0.f;
@@ -204,8 +201,8 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
     for (int lev = 0; lev < M.n_levels; ++lev) {
         const int i0 = M.level_start[lev], n = M.level_start[lev + 1] - i0;
         if (t < n) {
-            const int j = M.level_joints[i0 + t];
-            const int p = M.parents[j];
+            const int j = S.meta[MO_LJ + i0 + t];
+            const int p = S.meta[MO_PAR + j];
             const float* Rj = &S.R[j * 9];
             float* Gj = &S.G[j * 12];
             if (p < 0) {
@@ -293,15 +290,24 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
     {
         const float4* f4 = reinterpret_cast<const float4*>(S.feat);
         const float4 fa = f4[lane], fb = f4[64 + lane];
-        for (int w = wv; w < NI * 3; w += CT / 64) {
-            const int i = w / 3, c = w % 3;
-            const int v = S.ivid[i];
-            const float4* row = reinterpret_cast<const float4*>(M.dirsT + ((size_t)v * 3 + c) * SFX_KD_PAD);
-            const float4 da = row[lane], db = row[64 + lane];
-            float acc = fa.x * da.x + fa.y * da.y + fa.z * da.z + fa.w * da.w +
-                        fb.x * db.x + fb.y * db.y + fb.z * db.z + fb.w * db.w;
-            acc = wave_sum(acc);
-            if (lane == 0) S.vp[i * 3 + c] = M.v_template[v * 3 + c] + acc;
+        // 4 rows per wavefront per pass: 8 independent 1-KiB loads in flight before the reductions
+        for (int w0 = wv * 4; w0 < NI * 3; w0 += (CT / 64) * 4) {
+            float4 da[4], db[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int w = (w0 + u < NI * 3) ? w0 + u : w0;
+                const int v = S.ivid[w / 3];
+                const float4* row = reinterpret_cast<const float4*>(M.dirsT + ((size_t)v * 3 + w % 3) * SFX_KD_PAD);
+                da[u] = row[lane]; db[u] = row[64 + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int w = w0 + u;
+                float acc = fa.x * da[u].x + fa.y * da[u].y + fa.z * da[u].z + fa.w * da[u].w +
+                            fb.x * db[u].x + fb.y * db[u].y + fb.z * db[u].z + fb.w * db[u].w;
+                acc = wave_sum(acc);
+                if (lane == 0 && w < NI * 3) S.vp[w] = M.v_template[S.ivid[w / 3] * 3 + w % 3] + acc;
+            }
         }
     }
     // skinning transforms of the items
@@ -331,10 +337,10 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
     for (int w = t; w < K * 3; w += CT) {
         const int k = w / 3, r = w % 3;
         float v;
-        if (M.jk_type[k] == 0) v = S.G[M.jk_src[k] * 12 + r * 4 + 3];
+        if (S.meta[MO_JT + k] == 0) v = S.G[S.meta[MO_JS + k] * 12 + r * 4 + 3];
         else {
             v = 0.f;
-            const int i0 = M.jk_item0[k], n = M.jk_nitem[k];
+            const int i0 = S.meta[MO_JI0 + k], n = S.meta[MO_JN + k];
             if (n == 1 && S.iw[i0] == 1.f) v = S.vert[i0 * 3 + r];
             else for (int i = 0; i < n; ++i) v += S.vert[(i0 + i) * 3 + r] * S.iw[i0 + i];
         }
@@ -403,16 +409,7 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
     }
     float lsum = block_sum(lpart, S.red);
     // camera-translation gradient = sum_k dpc
-    {
-        __syncthreads();
-        S.red2[t] = dpc[0]; S.red2[CT + t] = dpc[1]; S.red2[2 * CT + t] = dpc[2];
-        __syncthreads();
-        for (int s = CT / 2; s > 0; s >>= 1) {
-            if (t < s) { S.red2[t] += S.red2[t + s]; S.red2[CT + t] += S.red2[CT + t + s];
-                         S.red2[2 * CT + t] += S.red2[2 * CT + t + s]; }
-            __syncthreads();
-        }
-    }
+    const float gct0 = block_sum(dpc[0], S.red), gct1 = block_sum(dpc[1], S.red), gct2 = block_sum(dpc[2], S.red);
     float total;
     if (cam_stage) {
         float joint = lsum;
@@ -423,7 +420,7 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
         if (C.depth_w > 0.f) depth = (C.depth_w * C.depth_w) * (dz * dz);
         total = joint + depth;
         if (t < 3) {
-            float g = S.red2[t * CT];
+            float g = (t == 0) ? gct0 : (t == 1) ? gct1 : gct2;
             if (t == 2 && C.depth_w > 0.f) g += (C.depth_w * C.depth_w) * 2.f * dz;
             S.gc[L.cam_t + t] = g;
         }
@@ -479,7 +476,7 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
         total = joint + pp + shp + ang;
         if (C.use_face) total = total + jwl + exl;
         if (C.use_hands) total = total + lhp + rhp;
-        if (t < 3) S.gc[L.cam_t + t] = S.red2[t * CT];
+        if (t < 3) S.gc[L.cam_t + t] = (t == 0) ? gct0 : (t == 1) ? gct1 : gct2;
     }
     __syncthreads();
 
@@ -487,7 +484,7 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
     // d joints -> items / kinematic joints
     for (int w = t; w < NI * 3; w += CT) {
         const int i = w / 3, r = w % 3;
-        S.dvert[w] = S.dj[M.item_k[i] * 3 + r] * S.iw[i];
+        S.dvert[w] = S.dj[S.meta[MO_IK + i] * 3 + r] * S.iw[i];
     }
     __syncthreads();
     for (int w = t; w < NI * 3; w += CT) {
@@ -524,15 +521,15 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
     for (int lev = M.n_levels - 1; lev >= 0; --lev) {
         const int i0 = M.level_start[lev], n = M.level_start[lev + 1] - i0;
         if (t < n) {
-            const int j = M.level_joints[i0 + t];
-            const int p = M.parents[j];
+            const int j = S.meta[MO_LJ + i0 + t];
+            const int p = S.meta[MO_PAR + j];
             const float* dAj = &S.dA[j * 12];
             const float* Jj = &S.Jr[j * 3];
             float dGj[12];
             // posed joint adjoint: every mapped joint reading kinematic joint j
             float dpj[3] = {0.f, 0.f, 0.f};
-            for (int q = M.src_k0[j]; q < M.src_k0[j + 1]; ++q) {
-                const int k = M.src_klist[q];
+            for (int q = S.meta[MO_SK0 + j]; q < S.meta[MO_SK0 + j + 1]; ++q) {
+                const int k = S.meta[MO_SKL + q];
                 dpj[0] += S.dj[k * 3]; dpj[1] += S.dj[k * 3 + 1]; dpj[2] += S.dj[k * 3 + 2];
             }
 #pragma unroll
@@ -547,8 +544,8 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
 #pragma unroll
             for (int c = 0; c < 3; ++c)
                 dJj[c] = -(S.G[j * 12 + 0 + c] * dAj[3] + S.G[j * 12 + 4 + c] * dAj[7] + S.G[j * 12 + 8 + c] * dAj[11]);
-            for (int q = M.child_start[j]; q < M.child_start[j + 1]; ++q) {
-                const int ch = M.child_list[q];
+            for (int q = S.meta[MO_CS + j]; q < S.meta[MO_CS + j + 1]; ++q) {
+                const int ch = S.meta[MO_CL + q];
                 const float* dGc = &S.dG[ch * 12];
                 const float* Rch = &S.R[ch * 9];
                 const float rel[3] = {S.Jr[ch * 3] - Jj[0], S.Jr[ch * 3 + 1] - Jj[1], S.Jr[ch * 3 + 2] - Jj[2]};

@@ -14,6 +14,7 @@
 // only fused multiply-adds are the explicit fmaf() of the axpy updates (ATen's
 // add_(alpha) vector path).
 #include "sfx_internal.h"
+#include "wave_ops.h"
 
 enum { PH_ENTRY = 0, PH_BRACKET = 1, PH_ZOOM = 2 };
 enum { A_NONE = 0, A_ENTRY, A_ITER_HEAD, A_ZOOM_NEXT, A_FINISH_LS, A_END_STEP, A_FINISH_STAGE };
@@ -36,7 +37,7 @@ __device__ __forceinline__ Sc sc_neg(Sc a) { a.v = -a.v; return a; }
 __device__ __forceinline__ Sc sc_sqrt(Sc a) { return a.t ? T(sqrtf((float)a.v)) : P(sqrt(a.v)); }
 
 // lbfgs_ls.py:11-36
-__device__ Sc cubic_interpolate(Sc x1, Sc f1, Sc g1, Sc x2, Sc f2, Sc g2, bool has_bounds, Sc lo, Sc hi) {
+__device__ __forceinline__ Sc cubic_interpolate(Sc x1, Sc f1, Sc g1, Sc x2, Sc f2, Sc g2, bool has_bounds, Sc lo, Sc hi) {
     if (!has_bounds) {
         if (sc_le(x1, x2)) { lo = x1; hi = x2; } else { lo = x2; hi = x1; }
     }
@@ -78,16 +79,8 @@ size_t sfx_optstate_size() { return sizeof(OptState); }
 
 struct Lane3 { float v[NE3]; };
 
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wmax(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ float wsum(float v) { return wave_sum_dpp(v); }
+__device__ __forceinline__ float wmax(float v) { return wave_max_dpp(v); }
 __device__ __forceinline__ Lane3 ld3(const float* p, int lane, int N) {
     Lane3 r;
 #pragma unroll
@@ -117,6 +110,20 @@ __device__ __forceinline__ Lane3 axpy3(const Lane3& x, float a, const Lane3& d) 
     return r;
 }
 
+__device__ __forceinline__ OptScal fresh_state() {
+    OptScal s;
+    s.phase = PH_ENTRY; s.outer = 0; s.n_iter = 0; s.n_iter_total = 0; s.cur_evals = 0; s.func_evals = 0;
+    s.ls_evals = 0; s.ls_iter = 0; s.ls_done = 0; s.insuf = 0; s.low = 0; s.high = 1;
+    s.hist_n = 0; s.hist_head = 0; s.cache_valid = 0; s.has_prev_outer = 0; s.evals = 0; s.ref_evals = 0;
+    s.pad0 = 0; s.pad1 = 0;
+    s.t = P(0.0); s.t_prev = P(0.0); s.H_diag = P(1.0);
+    s.loss = P(0.0); s.prev_loss = P(0.0); s.orig_loss = P(0.0); s.f_prev = P(0.0); s.ls_f0 = P(0.0);
+    s.gtd_prev = P(0.0); s.ls_gtd0 = P(0.0); s.d_norm = P(0.0);
+    s.br0 = s.br1 = s.bf0 = s.bf1 = s.bgtd0 = s.bgtd1 = P(0.0);
+    s.prev_loss_outer = 0.0;
+    return s;
+}
+
 __global__ __launch_bounds__(64)
 void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int first_stage, int last_stage,
                   int init) {
@@ -133,19 +140,8 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
 #define VEC(k) (vec + (k) * SFX_NVAR_MAX)
 
     // ---------------------------------------------------------------- (re)initialisation
-    auto reset_state = [&](OptScal& s) {
-        s.phase = PH_ENTRY; s.outer = 0; s.n_iter = 0; s.n_iter_total = 0; s.cur_evals = 0; s.func_evals = 0;
-        s.ls_evals = 0; s.ls_iter = 0; s.ls_done = 0; s.insuf = 0; s.low = 0; s.high = 1;
-        s.hist_n = 0; s.hist_head = 0; s.cache_valid = 0; s.has_prev_outer = 0; s.evals = 0; s.ref_evals = 0;
-        s.t = P(0.0); s.t_prev = P(0.0); s.H_diag = P(1.0);
-        s.loss = P(0.0); s.prev_loss = P(0.0); s.orig_loss = P(0.0); s.f_prev = P(0.0); s.ls_f0 = P(0.0);
-        s.gtd_prev = P(0.0); s.ls_gtd0 = P(0.0); s.d_norm = P(0.0);
-        s.br0 = s.br1 = s.bf0 = s.bf1 = s.bgtd0 = s.bgtd1 = P(0.0);
-        s.prev_loss_outer = 0.0;
-    };
     if (init) {
-        OptScal s;
-        reset_state(s);
+        const OptScal s = fresh_state();
         stage = first_stage;
         if (lane == 0) {
             D.stage[b] = stage;
@@ -156,7 +152,12 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
     }
     if (stage > last_stage) return;
 
-    OptScal s = gst->s;    // scalar state in registers (uniform across the wavefront)
+    // scalar state lives in LDS for the duration of the tick: every lane reads (broadcast) and
+    // writes (identical values) the same words, so the single wavefront stays uniform
+    __shared__ OptScal s_state;
+    if (lane == 0) s_state = gst->s;
+    __syncthreads();
+    OptScal& s = s_state;
     const VarList& vl = vls[stage < 0 ? 0 : 1];
     int N = vl.n;
     const double tol_change = 1e-9;
@@ -168,28 +169,23 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
     int glast_cached = 0;
     s.evals += 1; s.ref_evals += 1;
 
-    auto gather_x = [&]() { Lane3 r;
+    auto gather_x = [X, lane, N, &vl]() { Lane3 r;
         for (int e = 0; e < NE3; ++e) { const int i = lane + 64 * e; r.v[e] = (i < N) ? X[vl.idx[i]] : 0.f; } return r; };
-    auto write_trial = [&](Sc t) {
+    auto write_trial = [X, Xt, vec, lane, N, &vl](Sc t) {
         const Lane3 xi = ld3(VEC(VEC_XINIT), lane, N), d = ld3(VEC(VEC_D), lane, N);
         const Lane3 xt = axpy3(xi, (float)t.v, d);
         for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
         __syncthreads();
         for (int e = 0; e < NE3; ++e) { const int i = lane + 64 * e; if (i < N) Xt[vl.idx[i]] = xt.v[e]; }
     };
-    auto armijo_fail = [&](Sc f_new, Sc t) {
-        return sc_gt(f_new, sc_add(s.ls_f0, sc_mul(sc_mul(P(1e-4), t), s.ls_gtd0))); };
-    auto curv_ok = [&](Sc gtd_new) { return sc_le(sc_abs(gtd_new), sc_mul(P(-0.9), s.ls_gtd0)); };
-    auto start_zoom = [&](Sc b0, Sc b1, Sc f0, Sc f1, int g0_vec, const Lane3* g0_reg, const Lane3& g1, Sc gd0, Sc gd1,
-                          bool done) {
-        // bracket gradients: slot 0 from a stored vector (or register), slot 1 = incoming
-        s.br0 = b0; s.br1 = b1; s.bf0 = f0; s.bf1 = f1; s.bgtd0 = gd0; s.bgtd1 = gd1;
-        if (g0_reg) st3(VEC(VEC_BG0), *g0_reg, lane, N);
-        else { const Lane3 tmp = ld3(VEC(g0_vec), lane, N); st3(VEC(VEC_BG0), tmp, lane, N); }
-        st3(VEC(VEC_BG1), g1, lane, N);
-        s.ls_done = done ? 1 : 0; s.insuf = 0;
-        if (sc_le(s.bf0, s.bf1)) { s.low = 0; s.high = 1; } else { s.low = 1; s.high = 0; }
-    };
+#define armijo_fail(f_new, t) sc_gt((f_new), sc_add(s.ls_f0, sc_mul(sc_mul(P(1e-4), (t)), s.ls_gtd0)))
+#define curv_ok(gtd_new) sc_le(sc_abs(gtd_new), sc_mul(P(-0.9), s.ls_gtd0))
+    // bracket set-up: gradient slot 0 = G0 (a Lane3 value), slot 1 = the incoming gradient
+#define start_zoom(b0, b1, f0, f1, G0, gd0, gd1, done) do {                                              \
+        s.br0 = (b0); s.br1 = (b1); s.bf0 = (f0); s.bf1 = (f1); s.bgtd0 = (gd0); s.bgtd1 = (gd1);        \
+        st3(VEC(VEC_BG0), (G0), lane, N); st3(VEC(VEC_BG1), g_in, lane, N);                               \
+        s.ls_done = (done) ? 1 : 0; s.insuf = 0;                                                         \
+        if (sc_le(s.bf0, s.bf1)) { s.low = 0; s.high = 1; } else { s.low = 1; s.high = 0; } } while (0)
 
     int act = A_NONE;
     // ---------------------------------------------------------------- consume the evaluation
@@ -203,18 +199,18 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
         const Lane3 d = ld3(VEC(VEC_D), lane, N);
         const Sc gtd_new = T(dot3(g_in, d));
         if (s.ls_iter == max_ls) {
-            start_zoom(P(0.0), t, s.ls_f0, f_in, VEC_LSG0, nullptr, g_in, s.ls_gtd0, gtd_new, false);
+            start_zoom(P(0.0), t, s.ls_f0, f_in, ld3(VEC(VEC_LSG0), lane, N), s.ls_gtd0, gtd_new, false);
             act = A_ZOOM_NEXT;
         } else if (armijo_fail(f_in, t) || (s.ls_iter > 1 && sc_ge(f_in, s.f_prev))) {
-            start_zoom(s.t_prev, t, s.f_prev, f_in, VEC_GPREV, nullptr, g_in, s.gtd_prev, gtd_new, false);
+            start_zoom(s.t_prev, t, s.f_prev, f_in, ld3(VEC(VEC_GPREV), lane, N), s.gtd_prev, gtd_new, false);
             act = A_ZOOM_NEXT;
         } else if (curv_ok(gtd_new)) {
             // single-point bracket: the point itself is accepted
-            start_zoom(t, t, f_in, f_in, 0, &g_in, g_in, gtd_new, gtd_new, true);
+            start_zoom(t, t, f_in, f_in, g_in, gtd_new, gtd_new, true);
             s.low = 0; s.high = 1;
             act = A_ZOOM_NEXT;
         } else if (sc_ge(gtd_new, P(0.0))) {
-            start_zoom(s.t_prev, t, s.f_prev, f_in, VEC_GPREV, nullptr, g_in, s.gtd_prev, gtd_new, false);
+            start_zoom(s.t_prev, t, s.f_prev, f_in, ld3(VEC(VEC_GPREV), lane, N), s.gtd_prev, gtd_new, false);
             act = A_ZOOM_NEXT;
         } else {
             const Sc lo = sc_add(t, sc_mul(P(0.01), sc_sub(t, s.t_prev)));
@@ -462,7 +458,7 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
             }
             stage += 1;
             if (lane == 0) D.stage[b] = stage;
-            reset_state(s);
+            s = fresh_state();
             for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
             act = A_NONE;
             break;
@@ -470,7 +466,8 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
         default: act = A_NONE; break;
         }
     }
-    if (lane == 0) gst->s = s;     // ro[] is written in place
+    __syncthreads();
+    if (lane == 0) gst->s = s_state;     // ro[] is written in place
 #undef VEC
 }
 

@@ -16,6 +16,19 @@
 #define SFX_NPAR_MAX 192    // canonical per-frame parameter block
 #define SFX_MAX_STAGES 8
 #define SFX_MAX_GROUPS 12
+// packed integer tables of the closure kernel (DevModel.meta)
+#define MO_PAR 0
+#define MO_LJ 56
+#define MO_CS 112
+#define MO_CL 168
+#define MO_SK0 224
+#define MO_SKL 280
+#define MO_JT 424
+#define MO_JS 568
+#define MO_JI0 712
+#define MO_JN 856
+#define MO_IK 1000
+#define SFX_META_N 1240
 
 // Canonical per-frame parameter block (floats).  cam_t | global_orient | betas | lhand |
 // rhand | expression | jaw | leye | reye | body_pose param (dead, iff !use_vposer) | embedding
@@ -72,6 +85,7 @@ struct DevModel {
     const int*   src_k0;       // [J+1] CSR: mapped joints that read kinematic joint s
     const int*   src_klist;    // [..]
     int Vpad;
+    const int*   meta;         // [SFX_META_N] packed copy of the tables above
     // VPoser decoder
     int vp_latent, vp_hidden;
     const float *vp_w1, *vp_b1, *vp_w2, *vp_b2, *vp_w3, *vp_b3;
