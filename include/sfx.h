@@ -89,6 +89,7 @@ typedef struct sfx_stage_weights {      /* one entry of opt_weights (fit_single_
     float jaw_prior_weight[3];
     float hand_joint_weight, face_joint_weight;   /* joint_weights slices (:569-572)    */
     float coll_loss_weight;                       /* carried; interpenetration not built */
+    float bending_prior_weight;                   /* < 0: derive 3.17 * body_pose_weight (:567-568) */
 } sfx_stage_weights;
 
 typedef struct sfx_batch_cfg {
@@ -158,6 +159,12 @@ int  sfx_batch_guess_init(sfx_batch* b, const int32_t* pairs /* [n_pairs][2] */,
  * (optimizers/lbfgs_ls.py:39-167,256-445).  first_stage/last_stage select a sub-range
  * (-1 = camera stage).  Blocks until done.                                                */
 int  sfx_batch_fit(sfx_batch* b, int32_t first_stage, int32_t last_stage, void* stream);
+
+/* ONE optimizer.step(closure) of LBFGS('lbfgsls') for every frame (lbfgs_ls.py:256-445), for
+ * callers that drive run_fitting's outer loop themselves.  resume = 0 starts a fresh optimiser
+ * (new stage), 1 continues the previous one (history kept).  loss_out [B] (HOST) receives what
+ * step() returns: the loss at entry.                                                        */
+int  sfx_batch_step(sfx_batch* b, int32_t stage, int32_t resume, float* loss_out, void* stream);
 
 /* Per-frame results of the last sfx_batch_fit (HOST pointers, any may be NULL):
  *  stage_loss [B][1+n_stages]  value run_fitting returns per stage (camera first)

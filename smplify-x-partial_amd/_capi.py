@@ -37,7 +37,7 @@ class StageWeights(C.Structure):
         ("hand_prior_weight", C.c_float), ("expr_prior_weight", C.c_float),
         ("jaw_prior_weight", C.c_float * 3),
         ("hand_joint_weight", C.c_float), ("face_joint_weight", C.c_float),
-        ("coll_loss_weight", C.c_float),
+        ("coll_loss_weight", C.c_float), ("bending_prior_weight", C.c_float),
     ]
 
 
@@ -68,6 +68,7 @@ SYMBOLS = {
     "sfx_batch_closure": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_void_p]),
     "sfx_batch_guess_init": (C.c_int, [C.c_void_p, i32p, C.c_int32, C.c_void_p]),
     "sfx_batch_fit": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "sfx_batch_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, C.c_void_p]),
     "sfx_batch_get_stats": (C.c_int, [C.c_void_p, f32p, i32p, i32p]),
     "sfx_batch_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sfx_prof_enable": (C.c_int, [C.c_int32]),

@@ -322,7 +322,8 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     for (int i = 0; i < c->n_stages; ++i) {
         StageW& w = sws[i];
         w.bpw = st[i].body_pose_weight; w.sw = st[i].shape_weight;
-        w.bend = 3.17f * st[i].body_pose_weight;            // fit_single_frame.py:567-568 (fp32 product)
+        // fit_single_frame.py:567-568: bending = 3.17 * body_pose_weight (fp32 product) unless given
+        w.bend = (st[i].bending_prior_weight >= 0.f) ? st[i].bending_prior_weight : 3.17f * st[i].body_pose_weight;
         w.hpw = st[i].hand_prior_weight; w.epw = st[i].expr_prior_weight;
         for (int q = 0; q < 3; ++q) w.jaw[q] = st[i].jaw_prior_weight[q];
         w.hand_jw = st[i].hand_joint_weight; w.face_jw = st[i].face_joint_weight;
@@ -513,16 +514,12 @@ extern "C" int sfx_batch_guess_init(sfx_batch* b, const int32_t* pairs, int32_t 
     return 0;
 }
 
-extern "C" int sfx_batch_fit(sfx_batch* b, int32_t first_stage, int32_t last_stage, void* stream) {
-    if (!b) { sfx_set_error("null batch"); return -1; }
+// tick loop shared by sfx_batch_fit (whole run_fitting) and sfx_batch_step (one LBFGS.step)
+static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, int step_mode, hipStream_t s) {
     const BatchDev& D = b->D; const DevModel& M = b->m->M;
-    if (first_stage < -1 || last_stage >= D.cfg.n_stages || last_stage < first_stage) {
-        sfx_set_error("bad stage range [%d,%d]", first_stage, last_stage); return -1;
-    }
-    hipStream_t s = (hipStream_t)stream;
     const int B = D.cfg.B;
     const int POLL = (D.cfg.lbs_mode == 1) ? 8 : 32;
-    launch_lbfgs_tick(M, D, b->vl_dev, first_stage, last_stage, 1, s);
+    launch_lbfgs_tick(M, D, b->vl_dev, first_stage, last_stage, init, step_mode, s);
     const long max_ticks = (long)(last_stage - first_stage + 1) * D.cfg.maxiters * 80 + 64;
     std::vector<int> hs(B);
     int* hp = b->stage_host ? b->stage_host : hs.data();
@@ -532,7 +529,7 @@ extern "C" int sfx_batch_fit(sfx_batch* b, int32_t first_stage, int32_t last_sta
         for (int q = 0; q < POLL; ++q, ++tick) {
             eval_closure(b, -2, 0, s);
             ProfScope p("lbfgs", s);
-            launch_lbfgs_tick(M, D, b->vl_dev, first_stage, last_stage, 0, s);
+            launch_lbfgs_tick(M, D, b->vl_dev, first_stage, last_stage, 0, step_mode, s);
         }
         SFX_CHECK(hipMemcpyAsync(hp, D.stage, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
         SFX_CHECK(hipStreamSynchronize(s));
@@ -541,6 +538,28 @@ extern "C" int sfx_batch_fit(sfx_batch* b, int32_t first_stage, int32_t last_sta
     }
     SFX_CHECK(hipGetLastError());
     if (!done) { sfx_set_error("fit did not finish within %ld ticks", max_ticks); return -4; }
+    return 0;
+}
+
+extern "C" int sfx_batch_fit(sfx_batch* b, int32_t first_stage, int32_t last_stage, void* stream) {
+    if (!b) { sfx_set_error("null batch"); return -1; }
+    if (first_stage < -1 || last_stage >= b->D.cfg.n_stages || last_stage < first_stage) {
+        sfx_set_error("bad stage range [%d,%d]", first_stage, last_stage); return -1;
+    }
+    return run_ticks(b, first_stage, last_stage, 1, 0, (hipStream_t)stream);
+}
+
+extern "C" int sfx_batch_step(sfx_batch* b, int32_t stage, int32_t resume, float* loss_out, void* stream) {
+    if (!b) { sfx_set_error("null batch"); return -1; }
+    if (stage < -1 || stage >= b->D.cfg.n_stages) { sfx_set_error("stage %d out of range", stage); return -1; }
+    int rc = run_ticks(b, stage, stage, resume ? 2 : 1, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    if (loss_out) {
+        const int B = b->D.cfg.B;
+        std::vector<float> l((size_t)B * (1 + SFX_MAX_STAGES));
+        SFX_CHECK(hipMemcpy(l.data(), b->D.stage_loss, l.size() * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < B; ++i) loss_out[i] = l[(size_t)i * (1 + SFX_MAX_STAGES) + stage + 1];
+    }
     return 0;
 }
 

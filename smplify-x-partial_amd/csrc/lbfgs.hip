@@ -126,7 +126,7 @@ __device__ __forceinline__ OptScal fresh_state() {
 
 __global__ __launch_bounds__(64)
 void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int first_stage, int last_stage,
-                  int init) {
+                  int init, int step_mode) {
     __shared__ float s_al[SFX_HIST];
     const int b = blockIdx.x, lane = threadIdx.x;
     const BatchCfgDev& C = D.cfg;
@@ -147,6 +147,11 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
             D.stage[b] = stage;
             gst->s = s;            // ro[] needs no initialisation (guarded by hist_n)
         }
+        for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
+        return;
+    }
+    if (init == 2) {           // resume after a pause (optimizer.step granularity): keep the state
+        if (stage >= 1000 && lane == 0) D.stage[b] = stage - 1000;
         for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
         return;
     }
@@ -409,6 +414,16 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
         }
         case A_END_STEP: {       // run_fitting bookkeeping (fitting.py:175-217)
             const double loss = s.orig_loss.v;
+            if (step_mode) {         // one LBFGS.step per call: hand control back, keep the state
+                if (lane == 0) {
+                    D.stage_loss[(size_t)b * (1 + SFX_MAX_STAGES) + stage + 1] = (float)loss;
+                    D.stage[b] = stage + 1000;
+                }
+                s.phase = PH_ENTRY;
+                for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
+                act = A_NONE;
+                break;
+            }
             bool stop = false;
             if (isnan(loss) || isinf(loss)) stop = true;
             if (!stop && s.outer > 0 && s.has_prev_outer && C.ftol > 0.0) {
@@ -472,6 +487,7 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
 }
 
 void launch_lbfgs_tick(const DevModel& M, const BatchDev& D, const VarList* vl_dev, int first_stage,
-                       int last_stage, int init, hipStream_t s) {
-    hipLaunchKernelGGL(k_lbfgs_tick, dim3(D.cfg.B), dim3(64), 0, s, M, D, vl_dev, first_stage, last_stage, init);
+                       int last_stage, int init, int step_mode, hipStream_t s) {
+    hipLaunchKernelGGL(k_lbfgs_tick, dim3(D.cfg.B), dim3(64), 0, s, M, D, vl_dev, first_stage, last_stage, init,
+                       step_mode);
 }

@@ -154,5 +154,5 @@ void launch_closure(const DevModel& M, const BatchDev& D, const VarList* vl_dev,
                     const ClosureArgs& a, hipStream_t s);
 void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s);
 void launch_lbfgs_tick(const DevModel& M, const BatchDev& D, const VarList* vl_dev, int first_stage,
-                       int last_stage, int init, hipStream_t s);
+                       int last_stage, int init, int step_mode, hipStream_t s);
 size_t sfx_optstate_size();

@@ -1,0 +1,142 @@
+"""Batched frame driver: everything fit_single_frame() does around the hot loop
+(smplifyx/fit_single_frame.py:209-294 initialisation, :358-411 camera prior / guess_init,
+:447-612 camera stage + orientation x stage loop, :644-660 result dict) for MANY frames at
+once.  All floating-point work of the loop itself happens in libsfx.so; this file only
+prepares small per-frame arrays and collects results.
+"""
+import numpy as np
+
+from . import engine
+
+NUM_BODY_JOINTS = engine.NUM_BODY_JOINTS
+
+
+def _rotvec_to_mat(r):
+    r = np.asarray(r, np.float64).reshape(3)
+    a = np.linalg.norm(r)
+    if a < 1e-12:
+        return np.eye(3)
+    k = r / a
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * (K @ K)
+
+
+def _mat_to_rotvec(R):
+    """cv2.Rodrigues(3x3) semantics: axis * angle with angle in [0, pi]."""
+    R = np.asarray(R, np.float64)
+    c = np.clip((np.trace(R) - 1) / 2, -1, 1)
+    a = np.arccos(c)
+    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    s = np.linalg.norm(v) / 2
+    if s < 1e-10:
+        if c > 0:
+            return np.zeros(3)
+        d = np.sqrt(np.maximum((np.diag(R) + 1) / 2, 0))
+        if R[0, 1] < 0: d[1] = -d[1]
+        if R[0, 2] < 0: d[2] = -d[2]
+        return d / np.linalg.norm(d) * a
+    return v / (2 * s) * a
+
+
+def flipped_orientation(body_orient):
+    """The 180-degree-about-y candidate of fit_single_frame.py:528-535."""
+    return _mat_to_rotvec(_rotvec_to_mat(body_orient) @ _rotvec_to_mat([0.0, np.pi, 0.0]))
+
+
+def prepare_frames(cfg, keypoints, joint_weights, reg_pose=None, reg_global=None):
+    """Per-frame arrays of fit_single_frame.py:276-294: low-confidence zeroing of the joint
+    weights, trimmed camera-init joints, shoulder distance test.  keypoints [B,K,3]."""
+    kp = np.asarray(keypoints, np.float32)
+    B, K = kp.shape[:2]
+    nb = NUM_BODY_JOINTS[cfg.get("format", "coco25")]
+    thr = np.array([cfg.get("confidence_threshold", 0) or 0] * nb + [0] * 110, np.float64)[:K]
+    low = kp[:, :, 2] < thr[None]
+    jw = np.broadcast_to(np.asarray(joint_weights, np.float32).reshape(-1, K), (B, K)).copy()
+    jw[low] = 0
+    cmask = np.zeros((B, K), np.float32)
+    for j in cfg.get("init_joints_idxs", (9, 12, 2, 5)):
+        ok = (kp[:, j, 0] != 0) & (kp[:, j, 1] != 0) & ~low[:, j]
+        cmask[ok, j] = 1
+    ls, rs = cfg.get("left_shoulder_idx", 2), cfg.get("right_shoulder_idx", 5)
+    sd = np.linalg.norm(kp[:, ls, :2] - kp[:, rs, :2], axis=1)
+    both = sd < cfg.get("side_view_thsh", 25.)
+    return dict(keypoints=kp, jw=jw, cmask=cmask, try_both=both)
+
+
+def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, reg_global=None,
+               cam_prior_t=None, cam_prior_center=None, lbs_mode="dense", reuse_entry_eval=True,
+               want_vertices=False):
+    """Fit B frames.  Arrays are [B, ...]; H, W, focal scalars or [B].  Returns a dict of
+    [B, ...] arrays: the reference's result-pkl fields + per-stage losses / evaluation counts."""
+    prep = prepare_frames(cfg, keypoints, joint_weights)
+    kp = prep["keypoints"]
+    B, K = kp.shape[:2]
+    use_vposer = bool(cfg.get("use_vposer", True))
+    has_reg = reg_pose is not None
+    if not has_reg and not use_vposer:
+        raise ValueError("use_vposer=False needs a regression prior (the reference crashes here: "
+                         "fit_single_frame.py:252 with body_prior_type 'l2')")
+    Hh = np.broadcast_to(np.asarray(H, np.float32), (B,))
+    Ww = np.broadcast_to(np.asarray(W, np.float32), (B,))
+    f = np.broadcast_to(np.asarray(focal, np.float32), (B,))
+    fb = engine.FrameBatch(dm, B, cfg, lbs_mode=lbs_mode, reuse_entry_eval=reuse_entry_eval,
+                           has_regression_pose=has_reg)
+    nemb = fb.nemb
+    emb0 = np.asarray(reg_pose, np.float32).reshape(B, nemb) if has_reg else np.zeros((B, nemb), np.float32)
+    go0 = np.asarray(reg_global, np.float32).reshape(B, 3) if reg_global is not None else np.zeros((B, 3), np.float32)
+    use_cam_prior = bool(cfg.get("use_camera_prior")) and has_reg and cam_prior_t is not None
+    center = (np.asarray(cam_prior_center, np.float32).reshape(B, 2) if use_cam_prior
+              else np.stack([Ww * 0.5, Hh * 0.5], 1))
+    est = np.asarray(cam_prior_t, np.float32).reshape(B, 3)[:, 2] if use_cam_prior else None
+    fb.set_frames(kp, prep["jw"], prep["cmask"], f, center, 1000.0 / Hh, est_tz=est)
+    fb.set_params(regression_pose=emb0 if has_reg else None, global_orient=go0, pose_embedding=emb0,
+                  cam_translation=(np.asarray(cam_prior_t, np.float32).reshape(B, 3) if use_cam_prior
+                                   else np.zeros((B, 3), np.float32)))
+    if not use_cam_prior:
+        fb.guess_init(cfg.get("body_tri_idxs", [(5, 12), (2, 9)]))
+    # ---- camera stage, then the body stages from the camera-stage orientation -------------------
+    fb.fit(first_stage=-1, last_stage=-1)
+    go_cam = fb.get_params()["global_orient"].copy()
+    if fb.n_stages:
+        fb.fit(first_stage=0, last_stage=fb.n_stages - 1)
+    st = fb.stats()
+    out = dict(fb.get_params())
+    out.update(stage_loss=st["stage_loss"].copy(), stage_evals=st["stage_evals"].copy(),
+               stage_ref_evals=st["stage_ref_evals"].copy(), n_orient=np.ones(B, np.int32))
+    verts = joints = None
+    if want_vertices:
+        v, j = fb.forward()
+        verts, joints = v.cpu().numpy(), j.cpu().numpy()
+    # ---- second orientation for side views (fit_single_frame.py:527-538,546-551) --------------
+    idx = np.nonzero(prep["try_both"])[0]
+    if idx.size and fb.n_stages:
+        # the reference continues from the first pass: pose_embedding and camera translation keep
+        # their fitted values, global_orient = camera-stage orientation rotated by pi about y,
+        # every other body parameter is reset to zero (reset_params), new optimiser per stage
+        n2 = len(idx)
+        fb2 = engine.FrameBatch(dm, n2, cfg, lbs_mode=lbs_mode, reuse_entry_eval=reuse_entry_eval,
+                                has_regression_pose=has_reg)
+        fb2.set_frames(kp[idx], prep["jw"][idx], prep["cmask"][idx], f[idx], center[idx], 1000.0 / Hh[idx])
+        flip = np.stack([flipped_orientation(g) for g in go_cam[idx]]).astype(np.float32)
+        fb2.set_params(regression_pose=emb0[idx] if has_reg else None, global_orient=flip,
+                       pose_embedding=out["pose_embedding"][idx], cam_translation=out["cam_translation"][idx])
+        fb2.fit(first_stage=0, last_stage=fb2.n_stages - 1)
+        st2, p2 = fb2.stats(), fb2.get_params()
+        out["n_orient"][idx] = 2
+        out["stage_evals"][idx, 1:] += st2["stage_evals"][:, 1:]
+        out["stage_ref_evals"][idx, 1:] += st2["stage_ref_evals"][:, 1:]
+        l1, l2 = out["stage_loss"][idx, -1], st2["stage_loss"][:, -1]
+        take2 = ~(l1 < l2)                         # min_idx = 0 if results[0] < results[1] else 1 (:664-665)
+        sel = idx[take2]
+        for k in p2:
+            out[k][sel] = p2[k][take2]
+        out["stage_loss"][sel, 1:] = st2["stage_loss"][take2, 1:]
+        if want_vertices and sel.size:
+            v2, j2 = fb2.forward()
+            verts[sel], joints[sel] = v2.cpu().numpy()[take2], j2.cpu().numpy()[take2]
+        fb2.close()
+    out["final_loss"] = out["stage_loss"][:, -1].copy()
+    if want_vertices:
+        out["vertices"], out["joints"] = verts, joints
+    fb.close()
+    return out

@@ -59,6 +59,7 @@ def stage_weights_from_cfg(cfg):
         w.hand_joint_weight = lists["hand"][i] if use_hands else 0.0
         w.face_joint_weight = lists["face"][i] if use_face else 0.0
         w.coll_loss_weight = lists["coll"][i] if "coll" in lists else 0.0
+        w.bending_prior_weight = -1.0
         out.append(w)
     return out, n
 
@@ -165,10 +166,15 @@ class DeviceModel(object):
 class FrameBatch(object):
     """B frames under one configuration (sfx_batch)."""
 
-    def __init__(self, model, B, cfg, lbs_mode="dense", reuse_entry_eval=True, has_regression_pose=True):
+    def __init__(self, model, B, cfg, lbs_mode="dense", reuse_entry_eval=True, has_regression_pose=True,
+                 stages=None, num_body_joints=None):
+        """`cfg` uses the reference's key names (cmd_parser).  `stages` (list of
+        capi.StageWeights) overrides the schedule derived from cfg; `num_body_joints` overrides
+        where the per-stage hand/face joint weights start (K = never: weights passed verbatim)."""
         self.model, self.B, self.cfg = model, int(B), dict(cfg)
         self._lib = model._lib
-        stages, _ = stage_weights_from_cfg(cfg)
+        if stages is None:
+            stages, _ = stage_weights_from_cfg(cfg)
         self.n_stages = len(stages)
         c = capi.BatchCfg()
         c.B = self.B
@@ -179,7 +185,8 @@ class FrameBatch(object):
         c.use_joints_conf = int(bool(cfg.get("use_joints_conf", False)))
         c.has_regression_pose = int(bool(has_regression_pose))
         c.use_conf_cam_init = int(bool(cfg.get("use_conf_for_camera_init", False)))
-        c.num_body_joints = NUM_BODY_JOINTS[cfg.get("format", "coco25")]
+        c.num_body_joints = (NUM_BODY_JOINTS[cfg.get("format", "coco25")] if num_body_joints is None
+                             else int(num_body_joints))
         c.maxiters = int(cfg.get("maxiters", 30))
         c.ftol = float(cfg.get("ftol", 1e-9)); c.gtol = float(cfg.get("gtol", 1e-9))
         c.lr = float(cfg.get("lr", 1.0)); c.rho = float(cfg.get("rho", 100))
@@ -255,6 +262,12 @@ class FrameBatch(object):
     def fit(self, first_stage=-1, last_stage=None, stream=None):
         last = self.n_stages - 1 if last_stage is None else last_stage
         capi.check(self._lib.sfx_batch_fit(self._h, first_stage, last, C.c_void_p(stream) if stream else None))
+
+    def step(self, stage, resume):
+        """One LBFGS.step for every frame; returns the entry losses [B]."""
+        loss = np.zeros(self.B, np.float32)
+        capi.check(self._lib.sfx_batch_step(self._h, stage, int(bool(resume)), capi.fptr(loss), None))
+        return loss
 
     def stats(self):
         ns = self.n_stages + 1

@@ -1,0 +1,109 @@
+"""Drop-in for smplifyx/fit_single_frame.py:59-677 -- same signature, same result pickle
+(keys and order of :644-657, protocol 2), same optional vertices.ply -- with the whole
+optimisation executed by the MI355X engine (driver.fit_frames with a batch of one).
+Not reproduced: visualisation (`visualize=True`), interpenetration (BVH term),
+VPoser encode().sample() initialisation (random in the reference, :245).
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from . import driver
+from . import utils
+
+
+def _write_ply(path, vertices):
+    v = np.asarray(vertices, "<f4")
+    with open(path, "wb") as fh:
+        fh.write(("ply\nformat binary_little_endian 1.0\nelement vertices %d\nproperty float x\n"
+                  "property float y\nproperty float z\nend_header\n" % v.shape[0]).encode("ascii"))
+        fh.write(v.tobytes())
+
+
+def fit_single_frame(img, keypoints, body_model, camera, joint_weights, body_pose_prior, jaw_prior,
+                     left_hand_prior, right_hand_prior, shape_prior, expr_prior, angle_prior,
+                     result_fn="out.pkl", mesh_fn="out.obj", loss_type="smplify", use_cuda=True,
+                     init_joints_idxs=(9, 12, 2, 5), use_face=True, use_hands=True, data_weights=None,
+                     body_pose_prior_weights=None, hand_pose_prior_weights=None, jaw_pose_prior_weights=None,
+                     shape_weights=None, expr_weights=None, hand_joints_weights=None, face_joints_weights=None,
+                     global_orient_weights=None, depth_loss_weight=1e2, interpenetration=True, coll_loss_weights=None,
+                     df_cone_height=0.5, penalize_outside=True, max_collisions=8, point2plane=False, part_segm_fn="",
+                     focal_length=5000., side_view_thsh=25., rho=100, vposer_latent_dim=32, vposer_ckpt="",
+                     use_joints_conf=False, interactive=True, visualize=False, degrees=None, batch_size=1,
+                     dtype=torch.float32, ign_part_pairs=None, left_shoulder_idx=2, right_shoulder_idx=5,
+                     result_folder=".", img_name="", pixie_results=None, expose_results=None, pare_results=None,
+                     regression_prior=None, format="coco25", smplx_path="", curr_img_folder=".", **kwargs):
+    assert batch_size == 1, "fit_single_frame handles one frame; use driver.fit_frames for batches"
+    if visualize:
+        raise NotImplementedError("visualize=True is outside the fitting path")
+    if interpenetration:
+        raise NotImplementedError("interpenetration=True: the BVH penetration term is not built (SURVEY.md 8f-1)")
+    if not use_cuda:
+        raise RuntimeError("use_cuda=False: this engine has no CPU path")
+    H, W, _ = np.asarray(img).shape
+    use_vposer = kwargs.get("use_vposer", True)
+    cfg = dict(kwargs)
+    cfg.update(init_joints_idxs=list(init_joints_idxs), use_face=use_face, use_hands=use_hands,
+               data_weights=data_weights, body_pose_prior_weights=body_pose_prior_weights,
+               hand_pose_prior_weights=hand_pose_prior_weights, jaw_pose_prior_weights=jaw_pose_prior_weights,
+               shape_weights=shape_weights, expr_weights=expr_weights, hand_joints_weights=hand_joints_weights,
+               face_joints_weights=face_joints_weights, global_orient_weights=global_orient_weights,
+               depth_loss_weight=depth_loss_weight, interpenetration=False, coll_loss_weights=coll_loss_weights,
+               side_view_thsh=side_view_thsh, rho=rho, use_joints_conf=use_joints_conf, format=format,
+               left_shoulder_idx=left_shoulder_idx, right_shoulder_idx=right_shoulder_idx, use_vposer=use_vposer)
+    if not use_joints_conf:
+        raise NameError("name 'joints_conf' is not defined")   # the reference fails here (fit_single_frame.py:286)
+    reg_pose = reg_glob = cam_t = cam_c = None
+    if regression_prior:
+        reg_pose, reg_glob = utils.regression_prior_pose(regression_prior, expose=expose_results, pixie=pixie_results,
+                                                         pare=pare_results)
+        if use_vposer:
+            raise NotImplementedError("use_vposer with a regression prior needs VPoser encode().sample() "
+                                      "(random in the reference, SURVEY.md 8f-2)")
+        if kwargs.get("use_camera_prior"):
+            if regression_prior in ("ExPose", "combined"):
+                cam_c = np.asarray(expose_results["center"], np.float32)
+                cam_t = np.array(expose_results["transl"], np.float64)
+                cam_t[-1] /= (5000 / focal_length)
+            elif regression_prior == "PIXIE":
+                left, top, right, bottom = pixie_results["bbox"]
+                size = int(max(right - left, bottom - top) * 1.1)
+                ctr = np.array([right - (right - left) / 2.0, bottom - (bottom - top) / 2.0])
+                cam_c = np.array([ctr[0], ctr[1]], np.float32)
+                pc = pixie_results["body_cam"]
+                cam_t = np.array([pc[1], pc[2], 2 * focal_length / (pc[0] * size + 1e-9)])
+            elif regression_prior == "PARE":
+                cx, cy, bb, _ = pare_results["bboxes"][0]
+                pc = pare_results["pred_cam"][0]
+                cam_c = np.array([cx, cy], np.float32)
+                cam_t = np.array([pc[1], pc[2], (2 * focal_length) / (bb * pc[0])])
+    dm = body_model.device_model
+    kp = np.asarray(keypoints, np.float32).reshape(1, dm.K, 3)
+    jw = joint_weights.detach().cpu().numpy() if torch.is_tensor(joint_weights) else np.asarray(joint_weights)
+    want_v = bool(kwargs.get("save_vertices"))
+    res = driver.fit_frames(dm, cfg, kp, jw.reshape(1, -1), H, W, focal_length, reg_pose=reg_pose, reg_global=reg_glob,
+                            cam_prior_t=cam_t, cam_prior_center=cam_c, lbs_mode="dense", reuse_entry_eval=True,
+                            want_vertices=want_v)
+    # write the fitted values back into the caller's modules, as the reference leaves them
+    with torch.no_grad():
+        camera.translation[:] = torch.as_tensor(res["cam_translation"]).to(camera.translation)
+        if cam_c is not None:
+            camera.center[:] = torch.as_tensor(cam_c).to(camera.center)
+        else:
+            camera.center[:] = torch.tensor([W, H], dtype=camera.center.dtype, device=camera.center.device) * 0.5
+        for name, p in body_model.named_parameters():
+            if name in res:
+                p[:] = torch.as_tensor(res[name]).to(p)
+    result = {"camera_rotation": camera.rotation.detach().cpu().numpy(),
+              "camera_translation": res["cam_translation"], "camera_center": camera.center.detach().cpu().numpy(),
+              "H": H, "W": W, "focal_length": focal_length}
+    for name, p in body_model.named_parameters():
+        result[name] = res[name] if name in res else p.detach().cpu().numpy()
+    result["body_pose"] = res["body_pose"]
+    with open(result_fn, "wb") as fh:
+        pickle.dump(result, fh, protocol=2)
+    if want_v:
+        _write_ply(os.path.join(result_folder, "vertices.ply"), res["vertices"][0])
+    return result, float(res["final_loss"][0])

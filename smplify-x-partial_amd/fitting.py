@@ -1,0 +1,315 @@
+"""Drop-in for smplifyx/fitting.py: guess_init (:36-110), FittingMonitor (:113-275),
+create_loss / SMPLifyLoss / SMPLifyCameraInitLoss (:278-520).
+
+The objects keep the reference's constructor kwargs, attributes and call conventions, but the
+arithmetic of the closure (LBS, projection, losses, adjoint) and of the optimiser runs in
+libsfx.so: `create_fitting_closure` binds a one-frame `engine.FrameBatch` to the caller's
+tensors; the closure it returns evaluates loss + gradients on the GPU and stores them in the
+parameters' `.grad`; `run_fitting` executes the whole step loop on device.  There is no
+autograd graph and no CPU fallback.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _capi as capi
+from . import engine
+from . import utils
+
+
+@torch.no_grad()
+def guess_init(model, joints_2d, edge_idxs, focal_length=5000, pose_embedding=None, vposer=None,
+               use_vposer=True, dtype=torch.float32, model_type="smpl", **kwargs):
+    """Initial camera translation (0, 0, f * mean|d3D| / mean|d2D|) over limb pairs."""
+    if use_vposer:
+        body_pose = vposer.decode(pose_embedding, output_type="aa").view(1, -1)
+    else:
+        body_pose = pose_embedding
+    output = model(body_pose=body_pose, return_verts=False, return_full_pose=False)
+    j3 = output.joints
+    j2 = joints_2d.to(device=j3.device)
+    d3 = torch.stack([j3[:, e[0]] - j3[:, e[1]] for e in edge_idxs], dim=1)
+    d2 = torch.stack([j2[:, e[0]] - j2[:, e[1]] for e in edge_idxs], dim=1)
+    h2 = d2.pow(2).sum(dim=-1).sqrt().mean(dim=1)
+    h3 = d3.pow(2).sum(dim=-1).sqrt().mean(dim=1)
+    est_d = focal_length * (h3 / h2)
+    z = torch.zeros([j3.shape[0]], device=j3.device, dtype=dtype)
+    return torch.stack([z, z.clone(), est_d], dim=1)
+
+
+def create_loss(loss_type="smplify", **kwargs):
+    if loss_type == "smplify":
+        return SMPLifyLoss(**kwargs)
+    elif loss_type == "camera_init":
+        return SMPLifyCameraInitLoss(**kwargs)
+    raise ValueError("Unknown loss type: {}".format(loss_type))
+
+
+class SMPLifyLoss(nn.Module):
+    """Weights / flags of the body objective (fitting.py:287-373).  Evaluated by the engine."""
+
+    def __init__(self, search_tree=None, pen_distance=None, tri_filtering_module=None, rho=100,
+                 body_pose_prior=None, shape_prior=None, expr_prior=None, angle_prior=None, jaw_prior=None,
+                 use_joints_conf=True, use_face=True, use_hands=True, left_hand_prior=None, right_hand_prior=None,
+                 interpenetration=True, dtype=torch.float32, data_weight=1.0, body_pose_weight=0.0,
+                 shape_weight=0.0, bending_prior_weight=0.0, hand_prior_weight=0.0, expr_prior_weight=0.0,
+                 jaw_prior_weight=0.0, coll_loss_weight=0.0, reduction="sum", regression_pose=None, num_stages=3,
+                 **kwargs):
+        super().__init__()
+        self.use_joints_conf, self.rho = use_joints_conf, rho
+        self.angle_prior, self.body_pose_prior, self.shape_prior = angle_prior, body_pose_prior, shape_prior
+        self.interpenetration = interpenetration
+        self.use_hands = use_hands
+        if use_hands:
+            self.left_hand_prior, self.right_hand_prior = left_hand_prior, right_hand_prior
+        self.use_face = use_face
+        if use_face:
+            self.expr_prior, self.jaw_prior = expr_prior, jaw_prior
+        reg = lambda n, v: self.register_buffer(n, torch.tensor(v, dtype=dtype))
+        reg("data_weight", data_weight); reg("body_pose_weight", body_pose_weight); reg("shape_weight", shape_weight)
+        reg("bending_prior_weight", bending_prior_weight)
+        if use_hands:
+            reg("hand_prior_weight", hand_prior_weight)
+        if use_face:
+            reg("expr_prior_weight", expr_prior_weight); reg("jaw_prior_weight", jaw_prior_weight)
+        if interpenetration:
+            reg("coll_loss_weight", coll_loss_weight)
+        self.regression_pose = regression_pose
+        self.num_stages = num_stages
+
+    def reset_loss_weights(self, loss_weight_dict):
+        for key in loss_weight_dict:
+            if hasattr(self, key):
+                cur = getattr(self, key)
+                v = loss_weight_dict[key]
+                if torch.is_tensor(v):
+                    new = v.clone().detach()
+                else:
+                    new = torch.tensor(v, dtype=cur.dtype, device=cur.device)
+                setattr(self, key, new)
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError("SMPLifyLoss is evaluated inside the closure returned by "
+                           "FittingMonitor.create_fitting_closure (HIP path); it has no stand-alone CPU forward")
+
+
+class SMPLifyCameraInitLoss(nn.Module):
+    def __init__(self, init_joints_idxs, trans_estimation=None, reduction="sum", data_weight=1.0,
+                 depth_loss_weight=1e2, dtype=torch.float32, joints_conf=None, use_conf=False, **kwargs):
+        super().__init__()
+        self.dtype = dtype
+        if trans_estimation is not None:
+            te = trans_estimation.clone().detach() if torch.is_tensor(trans_estimation) else torch.tensor(trans_estimation, dtype=dtype)
+            self.register_buffer("trans_estimation", te.to(dtype))
+        else:
+            self.trans_estimation = trans_estimation
+        self.register_buffer("data_weight", torch.tensor(data_weight, dtype=dtype))
+        idx = init_joints_idxs.clone().detach().long() if torch.is_tensor(init_joints_idxs) else torch.tensor(init_joints_idxs, dtype=torch.long)
+        self.register_buffer("init_joints_idxs", idx)
+        self.register_buffer("depth_loss_weight", torch.tensor(depth_loss_weight, dtype=dtype))
+        self.joints_conf = joints_conf
+        self.use_conf = use_conf
+
+    def reset_loss_weights(self, loss_weight_dict):
+        for key in loss_weight_dict:
+            if hasattr(self, key):
+                cur = getattr(self, key)
+                setattr(self, key, torch.tensor(loss_weight_dict[key], dtype=cur.dtype, device=cur.device))
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError("SMPLifyCameraInitLoss is evaluated inside the fitting closure (HIP path)")
+
+
+def _np(t):
+    return t.detach().to("cpu", torch.float32).numpy()
+
+
+class EngineClosure(object):
+    """What create_fitting_closure returns: callable like the reference's `fitting_func`
+    (fitting.py:232-273) and the handle run_fitting / LBFGS.step use to reach the device engine."""
+
+    def __init__(self, monitor, optimizer, body_model, camera, gt_joints, loss, joints_conf, joint_weights,
+                 use_vposer, vposer, pose_embedding, return_verts):
+        self.monitor, self.optimizer, self.body_model, self.camera = monitor, optimizer, body_model, camera
+        self.gt_joints, self.loss, self.joints_conf, self.joint_weights = gt_joints, loss, joints_conf, joint_weights
+        self.use_vposer, self.vposer, self.pose_embedding = use_vposer, vposer, pose_embedding
+        self.is_camera = isinstance(loss, SMPLifyCameraInitLoss)
+        self.return_verts = return_verts
+        self._fb, self._fb_stage = None, None
+        self._stepped = False
+
+    # ---- engine batch bound to the caller's tensors ------------------------------------------
+    def _batch(self, stage):
+        if self._fb is not None and self._fb_stage == stage:
+            return self._fb
+        if self._fb is not None:
+            self._fb.close()
+        bm, loss, cam = self.body_model, self.loss, self.camera
+        dm = bm.device_model
+        K = dm.K
+        opt = self.optimizer
+        maxiters = getattr(opt, "max_iter", self.monitor.maxiters)
+        if maxiters != self.monitor.maxiters:
+            raise NotImplementedError("LBFGS max_iter != FittingMonitor maxiters (the reference passes one value to both)")
+        w = capi.StageWeights()
+        has_reg = False
+        use_hands = use_face = False
+        if not self.is_camera:
+            f = lambda n: float(getattr(loss, n)) if hasattr(loss, n) else 0.0
+            w.body_pose_weight, w.shape_weight = f("body_pose_weight"), f("shape_weight")
+            w.bending_prior_weight = f("bending_prior_weight")
+            use_hands = bool(loss.use_hands and loss.left_hand_prior is not None)
+            use_face = bool(loss.use_face)
+            w.hand_prior_weight = f("hand_prior_weight")
+            w.expr_prior_weight = f("expr_prior_weight")
+            jw = getattr(loss, "jaw_prior_weight", torch.zeros(3)).detach().cpu().reshape(-1)
+            jw = jw.expand(3) if jw.numel() == 1 else jw
+            for q in range(3):
+                w.jaw_prior_weight[q] = float(jw[q])
+            if getattr(loss, "interpenetration", False) and float(getattr(loss, "coll_loss_weight", 0.0)) > 0:
+                raise NotImplementedError("interpenetration term (coll_loss_weight > 0) is not built (SURVEY.md 8f-1)")
+            reg = loss.regression_pose
+            has_reg = reg is not None and (not self.use_vposer or stage + 1 == loss.num_stages)
+        cfg = dict(use_vposer=self.use_vposer, use_hands=use_hands, use_face=use_face,
+                   use_joints_conf=bool(getattr(loss, "use_joints_conf", False)),
+                   use_conf_for_camera_init=bool(getattr(loss, "use_conf", False)),
+                   maxiters=self.monitor.maxiters, ftol=self.monitor.ftol, gtol=self.monitor.gtol,
+                   lr=getattr(opt, "lr", 1.0), rho=getattr(loss, "rho", 100),
+                   depth_loss_weight=(float(getattr(loss, "depth_loss_weight", 0.0))
+                                      if getattr(loss, "trans_estimation", None) is not None else 0.0))
+        fb = engine.FrameBatch(dm, 1, cfg, lbs_mode="dense" if self.return_verts else "rows",
+                               reuse_entry_eval=False, has_regression_pose=has_reg, stages=[w], num_body_joints=K)
+        gt = _np(self.gt_joints).reshape(1, K, 2)
+        if self.is_camera:
+            conf = _np(loss.joints_conf).reshape(1, K) if loss.joints_conf is not None else np.ones((1, K), np.float32)
+            jwts = np.ones((1, K), np.float32)
+            cmask = np.zeros((1, K), np.float32)
+            cmask[0, _np(loss.init_joints_idxs).astype(np.int64)] = 1
+            est = _np(loss.trans_estimation)[:, 2] if loss.trans_estimation is not None else np.zeros(1, np.float32)
+        else:
+            conf = _np(self.joints_conf).reshape(1, K) if self.joints_conf is not None else np.ones((1, K), np.float32)
+            jwts = _np(self.joint_weights).reshape(1, K)
+            cmask = np.zeros((1, K), np.float32)
+            est = np.zeros(1, np.float32)
+        kp = np.concatenate([gt, conf[..., None]], -1)
+        fb.set_frames(kp, jwts, cmask, _np(cam.focal_length_x), _np(cam.center), float(loss.data_weight), est_tz=est,
+                      cam_rot=_np(cam.rotation).reshape(1, 9))
+        self._fb, self._fb_stage = fb, stage
+        self._stepped = False
+        return fb
+
+    def _push(self, fb):
+        bm = self.body_model
+        g = lambda n: _np(getattr(bm, n)) if hasattr(bm, n) else None
+        reg = None
+        if not self.is_camera and self.loss.regression_pose is not None:
+            reg = _np(self.loss.regression_pose)
+        fb.set_params(regression_pose=reg, cam_translation=_np(self.camera.translation), global_orient=g("global_orient"),
+                      betas=g("betas"), left_hand_pose=g("left_hand_pose"), right_hand_pose=g("right_hand_pose"),
+                      expression=g("expression"), jaw_pose=g("jaw_pose"), leye_pose=g("leye_pose"),
+                      reye_pose=g("reye_pose"), pose_embedding=_np(self.pose_embedding))
+
+    @torch.no_grad()
+    def _pull(self, fb):
+        p = fb.get_params()
+        bm = self.body_model
+        tgt = dict(global_orient=bm.global_orient)
+        if not self.is_camera:
+            for n in ("betas", "left_hand_pose", "right_hand_pose", "expression", "jaw_pose", "leye_pose", "reye_pose"):
+                if hasattr(bm, n):
+                    tgt[n] = getattr(bm, n)
+            self.pose_embedding.copy_(torch.as_tensor(p["pose_embedding"]).to(self.pose_embedding))
+        else:
+            self.camera.translation.copy_(torch.as_tensor(p["cam_translation"]).to(self.camera.translation))
+        for n, t in tgt.items():
+            t.copy_(torch.as_tensor(p[n]).to(t))
+
+    def _var_params(self):
+        """Tensors in the order of the engine's flat variable vector for this closure."""
+        bm = self.body_model
+        if self.is_camera:
+            return [self.camera.translation, bm.global_orient]
+        ps = [p for p in bm.parameters() if p.requires_grad] + [self.pose_embedding]
+        return ps
+
+    def _check_params(self, params):
+        want = self._var_params()
+        if len(params) != len(want) or any(a is not b for a, b in zip(params, want)):
+            raise NotImplementedError("the device engine optimises [camera.translation, global_orient] (camera stage) "
+                                      "or body_model.parameters() + [pose_embedding] (body stages); got another set")
+
+    # ---- the reference's fitting_func(stage=0, backward=True) ------------------------------------
+    def __call__(self, stage=0, backward=True):
+        fb = self._batch(stage)
+        self._push(fb)
+        loss, grad = fb.closure(-1 if self.is_camera else 0)
+        if backward:
+            o = 0
+            for p in self._var_params():
+                n = p.numel()
+                gsl = torch.as_tensor(grad[0, o:o + n]).reshape(p.shape).to(p)
+                p.grad = gsl if not (self._is_dead(p)) else None
+                o += n
+        self.monitor.steps += 1
+        dev = self.body_model.faces_tensor.device
+        return torch.tensor(float(loss[0]), dtype=torch.float32, device=dev)
+
+    def _is_dead(self, p):
+        return (not self.use_vposer) and hasattr(self.body_model, "body_pose") and p is self.body_model.body_pose
+
+    def run_stage(self, stage):
+        fb = self._batch(stage)
+        self._push(fb)
+        fb.fit(first_stage=-1 if self.is_camera else 0, last_stage=-1 if self.is_camera else 0)
+        self._pull(fb)
+        st = fb.stats()
+        slot = 0 if self.is_camera else 1
+        self.monitor.steps += int(st["stage_evals"][0, slot])
+        v = float(st["stage_loss"][0, slot])
+        return None if np.isnan(v) else v
+
+    def step(self, stage):
+        fb = self._batch(stage)
+        self._push(fb)
+        loss = fb.step(-1 if self.is_camera else 0, resume=self._stepped)
+        self._stepped = True
+        self._pull(fb)
+        dev = self.body_model.faces_tensor.device
+        return torch.tensor(float(loss[0]), dtype=torch.float32, device=dev)
+
+
+class FittingMonitor(object):
+    def __init__(self, summary_steps=1, visualize=False, maxiters=100, ftol=2e-09, gtol=1e-05,
+                 body_color=(1.0, 1.0, 0.9, 1.0), model_type="smpl", **kwargs):
+        self.maxiters, self.ftol, self.gtol = maxiters, ftol, gtol
+        self.visualize, self.summary_steps = visualize, summary_steps
+        self.body_color, self.model_type = body_color, model_type
+        if visualize:
+            raise NotImplementedError("visualize=True: the mesh viewer is outside the fitting path")
+
+    def __enter__(self):
+        self.steps = 0
+        return self
+
+    def __exit__(self, exception_type, exception_value, traceback):
+        pass
+
+    def run_fitting(self, optimizer, closure, params, body_model, stage, use_vposer=True, pose_embedding=None,
+                    vposer=None, **kwargs):
+        """The whole step loop (fitting.py:174-217) on device; returns the step-entry loss of the
+        last step, like the reference."""
+        if not isinstance(closure, EngineClosure):
+            raise TypeError("run_fitting needs the closure returned by create_fitting_closure")
+        closure._check_params(list(params))
+        return closure.run_stage(stage)
+
+    def create_fitting_closure(self, optimizer, body_model, camera=None, gt_joints=None, loss=None,
+                               joints_conf=None, joint_weights=None, return_verts=True, return_full_pose=False,
+                               use_vposer=False, vposer=None, pose_embedding=None, create_graph=False, **kwargs):
+        if not hasattr(self, "steps"):
+            self.steps = 0
+        c = EngineClosure(self, optimizer, body_model, camera, gt_joints, loss, joints_conf, joint_weights,
+                          use_vposer, vposer, pose_embedding, return_verts)
+        if optimizer is not None and hasattr(optimizer, "_bind"):
+            optimizer._bind(c)
+        return c

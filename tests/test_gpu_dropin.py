@@ -1,0 +1,186 @@
+"""GPU tests of the drop-in call surface: the reference's own call sequence
+-- smplx.create / create_camera / create_prior / create_loss / FittingMonitor /
+create_optimizer / create_fitting_closure / run_fitting / fit_single_frame -- executed against
+this package's modules, checked against goldens of the real reference."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _setup(synth_model, cfg):
+    from smplifyx_amd import smplx, utils
+    from smplifyx_amd.camera import create_camera
+    jm = utils.JointMapper(H.joint_map_for(cfg))
+    model_params = dict(model_path=synth_model, joint_mapper=jm, create_global_orient=True,
+                        create_body_pose=not cfg.get("use_vposer"), create_betas=True, create_left_hand_pose=True,
+                        create_right_hand_pose=True, create_expression=True, create_jaw_pose=True,
+                        create_leye_pose=True, create_reye_pose=True, create_transl=False, dtype=torch.float32)
+    args = {k: v for k, v in cfg.items() if k not in model_params and k != "gender"}
+    bm = smplx.create(gender="neutral", **model_params, **args).to("cuda")
+    cam = create_camera(focal_length_x=5000.0, focal_length_y=5000.0, dtype=torch.float32, **cfg).to("cuda")
+    cam.rotation.requires_grad = False
+    return bm, cam
+
+
+def test_reference_call_sequence_per_stage(synth_model):
+    """The body of fit_single_frame.py:413-612, written with this package's modules exactly
+    as the reference writes it, must reproduce the reference's per-stage losses."""
+    from smplifyx_amd import fitting, prior
+    from smplifyx_amd.optimizers import optim_factory
+    g = np.load(os.path.join(GOLD, "e2e_synth.npz"))
+    cfg = H.load_cfg("fit_smplx_combined_coco25.yaml", use_hands=False, use_face=False)
+    cfg["use_camera_prior"] = False
+    bm, camera = _setup(synth_model, cfg)
+    dev = torch.device("cuda")
+    i = 0
+    dtype = torch.float32
+    keypoints = g["keypoints"][i:i + 1]
+    pose_embedding = torch.tensor(g["reg_pose"][i:i + 1], device=dev, requires_grad=True)
+    global_pose = torch.tensor(g["reg_global"][i:i + 1], device=dev)
+    bm.reset_params(global_orient=global_pose, body_pose=pose_embedding)
+    kd = torch.tensor(keypoints, dtype=dtype, device=dev)
+    gt_joints, joints_conf = kd[:, :, :2], kd[:, :, 2].reshape(1, -1)
+    joint_weights = torch.tensor(H.base_joint_weights(cfg, 25), device=dev).unsqueeze(0)
+    low = [k for k in range(25) if float(joints_conf[0, k]) < cfg["confidence_threshold"]]
+    joint_weights[:, low] = 0
+    init_idxs = [k for k in cfg["init_joints_idxs"]
+                 if float(gt_joints[0, k, 0]) != 0 and float(gt_joints[0, k, 1]) != 0 and k not in low]
+    init_t = fitting.guess_init(bm, gt_joints, cfg["body_tri_idxs"], use_vposer=False, pose_embedding=pose_embedding,
+                                model_type="smplx", focal_length=5000.0, dtype=dtype).reshape(1, -1)
+    with torch.no_grad():
+        camera.translation[:] = init_t
+        camera.center[:] = torch.tensor([800, 600], dtype=dtype) * 0.5
+    mk = lambda t: prior.create_prior(prior_type=t, dtype=dtype)
+    camera_loss = fitting.create_loss("camera_init", joints_conf=joints_conf, use_conf=cfg["use_conf_for_camera_init"],
+                                      trans_estimation=init_t, init_joints_idxs=torch.tensor(init_idxs, device=dev),
+                                      depth_loss_weight=1e2, dtype=dtype).to(dev)
+    loss = fitting.create_loss(loss_type="smplify", joint_weights=joint_weights, rho=cfg["rho"], use_joints_conf=True,
+                               use_face=False, use_hands=False, body_pose_prior=mk("l2"), shape_prior=mk("l2"),
+                               angle_prior=mk("angle"), interpenetration=False, dtype=dtype,
+                               regression_pose=pose_embedding.clone().detach(), num_stages=3).to(dev)
+    losses = []
+    with fitting.FittingMonitor(**cfg) as monitor:
+        data_weight = 1000 / 600
+        camera_loss.reset_loss_weights({"data_weight": data_weight})
+        camera.translation.requires_grad = True
+        bm.global_orient.requires_grad = True
+        cam_params = [camera.translation, bm.global_orient]
+        opt, cg = optim_factory.create_optimizer(cam_params, **cfg)
+        fit_camera = monitor.create_fitting_closure(opt, bm, camera, gt_joints, camera_loss, create_graph=cg,
+                                                    use_vposer=False, pose_embedding=pose_embedding,
+                                                    return_full_pose=False, return_verts=False)
+        # the closure alone: loss value + .grad on the optimised tensors
+        l0 = fit_camera(stage=0)
+        assert camera.translation.grad is not None and bm.global_orient.grad is not None
+        assert torch.isfinite(l0)
+        losses.append(monitor.run_fitting(opt, fit_camera, cam_params, bm, stage=0, use_vposer=False,
+                                          pose_embedding=pose_embedding))
+        orient = bm.global_orient.detach().cpu().numpy()
+        bm.reset_params(global_orient=orient, body_pose=pose_embedding)
+        bpw, sw = cfg["body_pose_prior_weights"], cfg["shape_weights"]
+        for opt_idx in range(3):
+            final_params = [p for p in bm.parameters() if p.requires_grad] + [pose_embedding]
+            body_opt, cg = optim_factory.create_optimizer(final_params, **cfg)
+            body_opt.zero_grad()
+            w = {"data_weight": data_weight, "body_pose_weight": torch.tensor(bpw[opt_idx], device=dev),
+                 "shape_weight": torch.tensor(sw[opt_idx], device=dev)}
+            w["bending_prior_weight"] = 3.17 * w["body_pose_weight"]
+            loss.reset_loss_weights(w)
+            closure = monitor.create_fitting_closure(body_opt, bm, camera=camera, gt_joints=gt_joints,
+                                                     joints_conf=joints_conf, joint_weights=joint_weights, loss=loss,
+                                                     create_graph=cg, use_vposer=False, pose_embedding=pose_embedding,
+                                                     return_verts=True, return_full_pose=True)
+            losses.append(monitor.run_fitting(body_opt, closure, final_params, bm, opt_idx,
+                                              pose_embedding=pose_embedding, use_vposer=False))
+        out = bm(return_verts=True, body_pose=pose_embedding)
+        assert out.vertices.shape == (1, 10475, 3) and out.joints.shape == (1, 25, 3)
+    ref32, ref64 = g["f0_f32_losses"], g["f0_f64_losses"]
+    spread = np.abs(ref32 - ref64) / np.abs(ref64)
+    rel = np.abs(np.array(losses) - ref32) / np.abs(ref32)
+    assert rel[0] < 1e-4 and rel[1] < max(spread[1], 2e-3), (losses, ref32)
+    assert np.all(rel[2:] < np.maximum(3 * spread[2:], 5e-2)), (losses, ref32)
+
+
+def test_optimizer_step_matches_run_fitting(synth_model):
+    """Driving the outer loop by hand with optimizer.step(closure) (reference fitting.py:174-175)
+    walks the same trajectory as run_fitting on device."""
+    from smplifyx_amd import fitting
+    from smplifyx_amd.optimizers import optim_factory
+    g = np.load(os.path.join(GOLD, "e2e_synth.npz"))
+    cfg = H.load_cfg("fit_smplx_combined_coco25.yaml", use_hands=False, use_face=False)
+    dev = torch.device("cuda")
+    res = []
+    for manual in (False, True):
+        bm, camera = _setup(synth_model, cfg)
+        pose_embedding = torch.tensor(g["reg_pose"][:1], device=dev, requires_grad=True)
+        bm.reset_params(global_orient=torch.tensor(g["reg_global"][:1]), body_pose=pose_embedding)
+        kd = torch.tensor(g["keypoints"][:1], device=dev)
+        gt, conf = kd[:, :, :2], kd[:, :, 2].reshape(1, -1)
+        with torch.no_grad():
+            camera.translation[:] = torch.tensor([[0.0, 0.0, 18.0]]); camera.center[:] = torch.tensor([400.0, 300.0])
+        cl = fitting.create_loss("camera_init", joints_conf=conf, use_conf=True,
+                                 trans_estimation=torch.tensor([[0.0, 0.0, 18.0]]),
+                                 init_joints_idxs=torch.tensor([2, 5, 9, 12]), depth_loss_weight=1e2).to(dev)
+        cl.reset_loss_weights({"data_weight": 1000 / 600})
+        params = [camera.translation, bm.global_orient]
+        opt, _ = optim_factory.create_optimizer(params, **cfg)
+        with fitting.FittingMonitor(**cfg) as mon:
+            c = mon.create_fitting_closure(opt, bm, camera, gt, cl, use_vposer=False, pose_embedding=pose_embedding,
+                                           return_verts=False)
+            if manual:
+                prev = None
+                for n in range(cfg["maxiters"]):
+                    l = opt.step(lambda: c(stage=0))
+                    if n > 0 and prev is not None:
+                        from smplifyx_amd.utils import rel_change
+                        if rel_change(prev, l.item()) <= cfg["ftol"]:
+                            break
+                    prev = l.item()
+                res.append((prev, camera.translation.detach().cpu().numpy().copy()))
+            else:
+                v = mon.run_fitting(opt, c, params, bm, 0, use_vposer=False, pose_embedding=pose_embedding)
+                res.append((v, camera.translation.detach().cpu().numpy().copy()))
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0]), res
+    assert np.allclose(res[0][1], res[1][1], rtol=0, atol=1e-5)
+
+
+def test_fit_single_frame_writes_reference_pickle(synth_model, tmp_path):
+    from smplifyx_amd import prior
+    from smplifyx_amd.fit_single_frame import fit_single_frame
+    from scipy.spatial.transform import Rotation as Rot
+    g = np.load(os.path.join(GOLD, "e2e_synth.npz"))
+    cfg = H.load_cfg("fit_smplx_combined_coco25.yaml", use_hands=False, use_face=False)
+    cfg["use_camera_prior"] = False
+    cfg["regression_prior"] = "ExPose"
+    bm, camera = _setup(synth_model, cfg)
+    i = 1
+    expose = {"body_pose": Rot.from_euler("XYZ", g["reg_pose"][i].reshape(21, 3).astype(np.float64)).as_matrix().astype(np.float32),
+              "global_orient": Rot.from_euler("XYZ", g["reg_global"][i].astype(np.float64)[None]).as_matrix().astype(np.float32)}
+    a = dict(cfg); a["focal_length"] = 5000.0
+    for k in ("result_folder", "output_folder", "mesh_folder"):      # main.py pops these before the call
+        a.pop(k, None)
+    mk = lambda t: prior.create_prior(prior_type=t, dtype=torch.float32)
+    fn = str(tmp_path / "000.pkl")
+    jw = torch.tensor(H.base_joint_weights(cfg, 25)).unsqueeze(0)
+    result, final = fit_single_frame(np.zeros((600, 800, 3), np.float32), g["keypoints"][i:i + 1], body_model=bm,
+                                     camera=camera, joint_weights=jw, dtype=torch.float32, shape_prior=mk("l2"),
+                                     expr_prior=None, body_pose_prior=mk("l2"), left_hand_prior=None, right_hand_prior=None,
+                                     jaw_prior=None, angle_prior=mk("angle"), result_fn=fn, expose_results=expose,
+                                     result_folder=str(tmp_path), **a)
+    res = pickle.load(open(fn, "rb"))
+    assert list(res.keys()) == ["camera_rotation", "camera_translation", "camera_center", "H", "W", "focal_length",
+                                "betas", "global_orient", "body_pose", "left_hand_pose", "right_hand_pose",
+                                "jaw_pose", "leye_pose", "reye_pose", "expression"]
+    ref32, ref64 = g["f%d_f32_losses" % i], g["f%d_f64_losses" % i]
+    spread = abs(ref32[-1] - ref64[-1]) / ref64[-1]
+    assert abs(final - ref32[-1]) / ref32[-1] < max(3 * spread, 5e-2)
+    assert res["body_pose"].shape == (1, 63) and res["camera_translation"].shape == (1, 3)
+    assert np.abs(res["camera_translation"] - g["f%d_f32_camera_translation" % i]).max() < 5e-2

@@ -171,30 +171,70 @@ def synth_frames(model, cfg, n):
     return _FRAME_CACHE[key]
 
 
+def _golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+
+
 @pytest.mark.parametrize("mode,reuse", [("rows", False), ("rows", True), ("dense", True)])
-def test_fit_matches_oracle_on_wellposed_frames(gpu, synth_model, cfg_body, mode, reuse):
-    """Whole schedule (camera stage + 3 body stages) for 2 synthetic frames vs the oracle driver."""
+def test_fit_matches_reference_on_wellposed_frames(gpu, synth_model, cfg_body, mode, reuse):
+    """Whole schedule (camera stage + 3 body stages) for 2 synthetic frames against the REAL
+    reference's fit_single_frame (tests/golden/e2e_synth.npz, generated by tools/make_goldens.py).
+    The optimisation is chaotic beyond the camera stage: the golden file also holds the
+    reference's fp64 run, and |ref32 - ref64| is the yardstick for what 'equal' can mean."""
+    g = _golden("e2e_synth")
     cfg = dict(cfg_body); cfg["use_camera_prior"] = False
     dm = _dm(synth_model, cfg)
     B = 2
-    frames = synth_frames(synth_model, cfg, B)
+    frames = dict(keypoints=g["keypoints"], reg_pose=g["reg_pose"], reg_global=g["reg_global"], H=600, W=800, focal=5000.0)
     fb = H.engine_batch_from_frames(dm, cfg, frames, range(B), lbs_mode=mode, reuse=reuse)
     fb.guess_init(cfg["body_tri_idxs"])
     fb.fit()
     st = fb.stats()
     got = fb.get_params()
     for i in range(B):
-        ff = H.oracle_frame_fit(synth_model, cfg, frames, i, dtype=torch.float32)
-        ref = ff.run()
-        ref_losses = np.array([ref["cam_loss"]] + list(ref["stage_losses"]))
-        rel = np.abs(st["stage_loss"][i] - ref_losses) / np.maximum(np.abs(ref_losses), 1e-9)
-        assert rel[0] < 1e-3, (i, st["stage_loss"][i], ref_losses)
-        assert np.all(rel[1:] < 2e-3), (i, st["stage_loss"][i], ref_losses)
-        assert np.abs(got["pose_embedding"][i] - ref["result"]["body_pose"][0]).max() < 2e-2
-        assert np.abs(got["cam_translation"][i] - ref["result"]["camera_translation"][0]).max() < 5e-2
+        ref32, ref64 = g["f%d_f32_losses" % i], g["f%d_f64_losses" % i]
+        spread = np.abs(ref32 - ref64) / np.abs(ref64)
+        rel = np.abs(st["stage_loss"][i] - ref32) / np.abs(ref32)
+        assert rel[0] < 1e-4, (i, st["stage_loss"][i], ref32)             # camera stage: well conditioned
+        assert rel[1] < max(spread[1], 2e-3), (i, rel, spread)            # first body stage
+        assert np.all(rel[2:] < np.maximum(3 * spread[2:], 5e-2)), (i, rel, spread)   # chaotic tail
+        dpose = np.abs(got["pose_embedding"][i] - g["f%d_f32_body_pose" % i][0]).max()
+        spose = np.abs(g["f%d_f64_body_pose" % i] - g["f%d_f32_body_pose" % i]).max()
+        assert dpose < max(2 * spose, 2e-2), (dpose, spose)
         if not reuse:
-            # same number of closure evaluations as the oracle machine (+-10 %: fp32 chaos)
-            assert abs(st["stage_evals"][i].sum() - sum(ref["evals"])) <= 0.25 * sum(ref["evals"])
+            ev = g["f%d_f32_evals" % i]
+            assert abs(int(st["stage_evals"][i].sum()) - int(ev.sum())) <= 0.5 * ev.sum()
+            assert np.array_equal(st["stage_evals"][i], st["stage_ref_evals"][i])
+
+
+def test_demo_config1_matches_reference(gpu, synth_model, cfg_body):
+    """BASELINE config 1: the two demo/ frames (real blended keypoints + ExPose/PIXIE priors,
+    camera prior, body-only, cfg_files/fit_smplx_combined_coco25.yaml) on the synthetic model,
+    against the reference's own fit (tests/golden/demo_config1.npz, fp32).  The problem is
+    ill-posed (real keypoints vs synthetic geometry): SURVEY.md 0 measured +-5 % on the final
+    loss for the reference against itself; the camera stage is well conditioned."""
+    g = _golden("demo_config1"); e = _golden("euler")
+    from smplifyx_amd import engine
+    cfg = dict(cfg_body)
+    dm = _dm(synth_model, cfg)
+    for name in ("02_cropped", "18_cropped"):
+        kp = g[name + "_keypoints"]; Hh, Ww = [int(v) for v in g[name + "_HW"]]
+        focal = float(g[name + "_focal"])
+        frames = dict(keypoints=kp, reg_pose=e[name + "_combined_pose"][None], reg_global=e[name + "_global"][None],
+                      H=Hh, W=Ww, focal=focal)
+        fb = H.engine_batch_from_frames(dm, cfg, frames, [0], lbs_mode="dense", reuse=False)
+        est = np.array([g[name + "_cam_prior_t"][2]], np.float32)
+        fb.set_frames(kp, _jw(cfg, frames), _cmask(cfg, frames), focal, g[name + "_cam_prior_center"][None].astype(np.float32),
+                      1000.0 / Hh, est_tz=est)
+        fb.set_params(regression_pose=frames["reg_pose"], global_orient=frames["reg_global"],
+                      pose_embedding=frames["reg_pose"], cam_translation=g[name + "_cam_prior_t"][None].astype(np.float32))
+        fb.fit()
+        st = fb.stats()
+        ref = g[name + "_losses"]
+        rel = np.abs(st["stage_loss"][0] - ref) / np.abs(ref)
+        assert rel[0] < 1e-4, (name, st["stage_loss"][0], ref)
+        assert np.all(rel[1:] < 5e-2), (name, st["stage_loss"][0], ref)
 
 
 def test_shard_invariance_bitwise(gpu, synth_model, cfg_body):
