@@ -33,8 +33,11 @@ PEAK_HBM = 8.0e12
 
 
 def build_cfg():
-    import helpers as H
-    cfg = H.load_cfg("fit_smplx_smplifyx.yaml", use_hands=False, use_face=False, use_vposer=False)
+    from smplifyx_amd import cmd_parser
+    cfg = cmd_parser.load_config(os.path.join(ROOT, "cfg_files", "fit_smplx_smplifyx.yaml"),
+                                 dict(use_hands=False, use_face=False, use_vposer=False, interpenetration=False,
+                                      visualize=False, interactive=False, save_vertices=False,
+                                      use_gender_classifier=False))
     cfg["use_camera_prior"] = False
     return cfg
 
@@ -107,11 +110,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    import helpers as H
-    from smplifyx_amd import engine, synthetic
+    from smplifyx_amd import engine, synthetic, utils as U
     cfg = build_cfg()
     model = synthetic.make_synthetic_model(0)
-    jm = H.joint_map_for(cfg)
+    jm = U.smpl_to_annotation("smplx", use_hands=cfg["use_hands"], use_face=cfg["use_face"],
+                              use_face_contour=cfg["use_face_contour"], format=cfg["format"])
     dm = engine.DeviceModel(model, joint_map=jm, num_betas=cfg["num_betas"],
                             num_expression_coeffs=cfg["num_expression_coeffs"],
                             num_pca_comps=cfg["num_pca_comps"], use_face_contour=cfg["use_face_contour"])
@@ -126,20 +129,19 @@ def main():
         return j.cpu().numpy()
     frames = synthetic.make_frames(B, joints_fn, len(jm), start=rank * B, focal=float(cfg["focal_length"]))
 
+    from smplifyx_amd import driver, dist as sdist
+    jw = np.ones(len(jm), np.float32)
+    jw[cfg["joints_to_ign"]] = 0.0                 # COCO25.get_joint_weights (data_parser.py:159-171)
+    n_total = world * B
+
     def one_fit():
-        fb = H.engine_batch_from_frames(dm, cfg, frames, range(B), lbs_mode=args.lbs, reuse=True)
-        fb.guess_init(cfg["body_tri_idxs"])
-        fb.fit()
-        p = fb.get_params()
-        st = fb.stats()
-        rec = np.concatenate([p["cam_translation"], p["global_orient"], p["betas"], p["pose_embedding"],
-                              st["stage_loss"][:, -1:], st["stage_evals"].sum(1, keepdims=True).astype(np.float32)], 1)
-        if dist is not None:
-            rt = torch.tensor(rec, device=dev)
-            out = [torch.empty_like(rt) for _ in range(world)]
-            dist.all_gather(out, rt)
-        fb.close()
-        return st, p
+        res = driver.fit_frames(dm, cfg, frames["keypoints"], jw, frames["H"], frames["W"], frames["focal"],
+                                reg_pose=frames["reg_pose"], reg_global=frames["reg_global"], lbs_mode=args.lbs,
+                                reuse_entry_eval=True)
+        rec = sdist.pack_records(res, rank * B)
+        table = sdist.gather_records(rec, n_total, device=dev)      # the one collective (RCCL all_gather)
+        assert table.shape[0] == n_total
+        return res, table
 
     def sync():
         torch.cuda.synchronize()
@@ -154,7 +156,7 @@ def main():
     sync()
     t0 = time.time()
     for _ in range(args.steps):
-        st, p = one_fit()
+        st, table = one_fit()
     sync()
     dt = time.time() - t0
     engine.prof_enable(False)

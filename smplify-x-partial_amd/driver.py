@@ -95,10 +95,14 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
     if not use_cam_prior:
         fb.guess_init(cfg.get("body_tri_idxs", [(5, 12), (2, 9)]))
     # ---- camera stage, then the body stages from the camera-stage orientation -------------------
-    fb.fit(first_stage=-1, last_stage=-1)
-    go_cam = fb.get_params()["global_orient"].copy()
-    if fb.n_stages:
-        fb.fit(first_stage=0, last_stage=fb.n_stages - 1)
+    go_cam = None
+    if prep["try_both"].any() or not fb.n_stages:
+        fb.fit(first_stage=-1, last_stage=-1)
+        go_cam = fb.get_params()["global_orient"].copy()      # needed for the flipped candidate
+        if fb.n_stages:
+            fb.fit(first_stage=0, last_stage=fb.n_stages - 1)
+    else:
+        fb.fit(first_stage=-1, last_stage=fb.n_stages - 1)    # frames change stage independently
     st = fb.stats()
     out = dict(fb.get_params())
     out.update(stage_loss=st["stage_loss"].copy(), stage_evals=st["stage_evals"].copy(),
