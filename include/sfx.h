@@ -110,6 +110,11 @@ typedef struct sfx_batch_cfg {
                                        LBS every closure (what the reference evaluates)   */
     int32_t reuse_entry_eval;       /* 1: serve LBFGS.step's entry evaluation from the
                                        value already computed at the same point           */
+    float   side_view_thsh;         /* > 0: frames whose 2-D shoulder distance is below it are
+                                       fitted twice (orientation flipped by pi about y) and the
+                                       lower final loss kept (fit_single_frame.py:461-463,
+                                       527-551,662-667); needs a fit over stages -1..n-1     */
+    int32_t left_shoulder_idx, right_shoulder_idx;
 } sfx_batch_cfg;
 
 int  sfx_batch_create(sfx_model* m, const sfx_batch_cfg* cfg,
@@ -183,6 +188,9 @@ int  sfx_batch_forward(sfx_batch* b, float* vertices_out_dev /* [B][V][3] */,
 int  sfx_prof_enable(int32_t on);
 int  sfx_prof_get(const char* name, double* total_ms, int64_t* launches);
 void sfx_prof_reset(void);
+
+/* Debug: shader-clock stamps at the phase boundaries of one closure launch (block 0). */
+int  sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out /* [32] */);
 
 const char* sfx_last_error(void);
 const char* sfx_version(void);

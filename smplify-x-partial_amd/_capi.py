@@ -50,6 +50,7 @@ class BatchCfg(C.Structure):
         ("ftol", C.c_double), ("gtol", C.c_double),
         ("lr", C.c_float), ("rho", C.c_float), ("depth_loss_weight", C.c_float),
         ("lbs_mode", C.c_int32), ("reuse_entry_eval", C.c_int32),
+        ("side_view_thsh", C.c_float), ("left_shoulder_idx", C.c_int32), ("right_shoulder_idx", C.c_int32),
     ]
 
 
@@ -71,6 +72,7 @@ SYMBOLS = {
     "sfx_batch_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, C.c_void_p]),
     "sfx_batch_get_stats": (C.c_int, [C.c_void_p, f32p, i32p, i32p]),
     "sfx_batch_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sfx_debug_phase_clocks": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "sfx_prof_enable": (C.c_int, [C.c_int32]),
     "sfx_prof_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "sfx_prof_reset": (None, []),

@@ -138,6 +138,17 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
         std::vector<float> WT((size_t)SFX_JPAD * M.Vpad, 0.f);
         for (int v = 0; v < V; ++v)
             for (int j = 0; j < SFX_J; ++j) WT[(size_t)j * M.Vpad + v] = W[(size_t)v * SFX_J + j];
+        std::vector<int> wj((size_t)V * SFX_NW, 0); std::vector<float> ww((size_t)V * SFX_NW, 0.f);
+        for (int v = 0; v < V; ++v) {
+            int n = 0;
+            for (int j = 0; j < SFX_J; ++j) {
+                const float w = W[(size_t)v * SFX_J + j];
+                if (w == 0.f) continue;
+                if (n == SFX_NW) { sfx_set_error("vertex %d has more than %d skinning weights", v, SFX_NW); delete m; return -1; }
+                wj[(size_t)v * SFX_NW + n] = j; ww[(size_t)v * SFX_NW + n] = w; ++n;
+            }
+        }
+        M.Wsp_j = m->mem.up(wj); M.Wsp_w = m->mem.up(ww);
         M.W = m->mem.up(W);
         M.WT = m->mem.up(WT);
     }
@@ -243,6 +254,41 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
         for (int k = 0; k < K; ++k) { m->meta_host[MO_JT + k] = jt[k]; m->meta_host[MO_JS + k] = js[k];
                                       m->meta_host[MO_JI0 + k] = ji0[k]; m->meta_host[MO_JN + k] = jn[k]; }
         for (size_t q = 0; q < ik.size(); ++q) m->meta_host[MO_IK + q] = ik[q];
+        // by-joint adjoint lists
+        {
+            auto build = [&](const std::vector<int>& vids, const std::vector<int>& items, std::vector<int>& start,
+                             std::vector<int>& it, std::vector<float>& wv, int base) {
+                for (int j = 0; j < SFX_J; ++j) {
+                    start.push_back(base + (int)it.size());
+                    for (size_t q = 0; q < items.size(); ++q) {
+                        const float w = d->lbs_weights[(size_t)vids[q] * SFX_J + j];
+                        if (w != 0.f) { it.push_back(items[q]); wv.push_back(w); }
+                    }
+                }
+                start.push_back(base + (int)it.size());
+            };
+            std::vector<int> svid, sitem, dynitems;
+            for (int i = 0; i < (int)ivid.size(); ++i) { if (idyn[i] < 0) { svid.push_back(ivid[i]); sitem.push_back(i); } else dynitems.push_back(i); }
+            std::vector<int> ss, si; std::vector<float> sw2;
+            build(svid, sitem, ss, si, sw2, 0);
+            M.sj_start = m->mem.up(ss); M.sj_item = m->mem.up(si); M.sj_w = m->mem.up(sw2);
+            std::vector<int> ds, di; std::vector<float> dw;
+            M.n_dyn_items = (int)dynitems.size();
+            for (int row = 0; row < d->n_dyn_rows && !dynitems.empty(); ++row) {
+                std::vector<int> vids;
+                for (int i : dynitems) {
+                    const int l = idyn[i] / 3, c = idyn[i] % 3;
+                    const int f = d->dyn_lmk_faces_idx[(size_t)row * d->n_dyn + l];
+                    vids.push_back(d->faces[(size_t)f * 3 + c]);
+                }
+                std::vector<int> st;
+                build(vids, dynitems, st, di, dw, 0);
+                // offsets are absolute into di/dw: rebuild with the running base
+                ds.insert(ds.end(), st.begin(), st.end());
+            }
+            // 'build' used base 0 relative to the current size of di at call time -> already absolute
+            M.dj_start = m->mem.up(ds); M.dj_item = m->mem.up(di); M.dj_w = m->mem.up(dw);
+        }
         M.jk_type = m->mem.up(jt); M.jk_src = m->mem.up(js); M.jk_item0 = m->mem.up(ji0); M.jk_nitem = m->mem.up(jn);
         M.item_vid = m->mem.up(ivid); M.item_w = m->mem.up(iw); M.item_dyn = m->mem.up(idyn); M.item_k = m->mem.up(ik);
         M.src_k0 = m->mem.up(sk0); M.src_klist = m->mem.up(skl);
@@ -304,6 +350,9 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.cfg.max_eval = c->maxiters * 5 / 4; D.cfg.ftol = c->ftol; D.cfg.gtol = c->gtol;
     D.cfg.lr = c->lr; D.cfg.rho = c->rho; D.cfg.depth_w = c->depth_loss_weight; D.cfg.lbs_mode = c->lbs_mode;
     D.cfg.reuse = c->reuse_entry_eval;
+    D.cfg.side_thsh = c->side_view_thsh; D.cfg.lsh = c->left_shoulder_idx; D.cfg.rsh = c->right_shoulder_idx;
+    if (c->side_view_thsh > 0.f && (c->left_shoulder_idx < 0 || c->left_shoulder_idx >= K || c->right_shoulder_idx < 0 || c->right_shoulder_idx >= K)) {
+        sfx_set_error("shoulder indices out of range"); delete b; return -1; }
     build_layout(D.L, m->NB, m->NE, m->NPCA, c->use_vposer, m->M.vp_latent);
     if (D.L.npar > SFX_NPAR_MAX) { sfx_set_error("parameter block too large"); delete b; return -1; }
     const ParLayout& L = D.L;
@@ -355,6 +404,11 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.stage_loss = b->mem.zeros<float>((size_t)B * (1 + SFX_MAX_STAGES));
     D.stage_evals = b->mem.zeros<int>((size_t)B * (1 + SFX_MAX_STAGES));
     D.stage_ref_evals = b->mem.zeros<int>((size_t)B * (1 + SFX_MAX_STAGES));
+    D.X0 = b->mem.zeros<float>((size_t)B * SFX_NPAR_MAX);
+    D.gocam = b->mem.zeros<float>((size_t)B * 4);
+    D.stage_loss2 = b->mem.zeros<float>((size_t)B * (1 + SFX_MAX_STAGES));
+    D.try_both = b->mem.zeros<int>(B);
+    D.orient_pass = b->mem.zeros<int>(B);
     if (!D.hist || !D.verts) { sfx_set_error("out of device memory"); b->mem.free_all(); delete b; return -2; }
     if (hipHostMalloc((void**)&b->stage_host, (size_t)B * sizeof(int)) != hipSuccess) b->stage_host = nullptr;
     *out = b;
@@ -435,6 +489,24 @@ extern "C" int sfx_batch_get_params(sfx_batch* b, float* cam_t, float* go, float
         if (b->D.cfg.use_vposer) SFX_CHECK(hipMemcpy(body_pose, b->D.bodypose, (size_t)B * 63 * 4, hipMemcpyDeviceToHost));
         else take(X, B, L.emb, 63, body_pose);
     }
+    return 0;
+}
+
+extern "C" int sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out /* [32] */) {
+    if (!b) { sfx_set_error("null batch"); return -1; }
+    long long* d = nullptr;
+    SFX_CHECK(hipMalloc((void**)&d, 64 * sizeof(long long)));
+    SFX_CHECK(hipMemset(d, 0, 64 * sizeof(long long)));
+    b->D.dbg = d;
+    ClosureArgs a{}; a.stage_override = stage; a.from_X = 1;
+    launch_closure(b->m->M, b->D, b->vl_dev, b->sw_dev, a, 0);
+    launch_closure(b->m->M, b->D, b->vl_dev, b->sw_dev, a, 0);      // second launch: warm caches
+    SFX_CHECK(hipDeviceSynchronize());
+    b->D.dbg = nullptr;
+    long long h[64];
+    SFX_CHECK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+    hipFree(d);
+    for (int i = 0; i < 32; ++i) out[i] = h[i];
     return 0;
 }
 

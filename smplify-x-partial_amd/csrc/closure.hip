@@ -19,6 +19,16 @@
 #include "wave_ops.h"
 
 #define CT 256
+#define FD_GT 0
+#define FD_CONF (2 * SFX_MAX_K)
+#define FD_JW (3 * SFX_MAX_K)
+#define FD_CMASK (4 * SFX_MAX_K)
+#define FD_CAM (5 * SFX_MAX_K)
+#define FD_CAMR (FD_CAM + 8)
+#define FD_REG (FD_CAMR + 12)
+#define FD_N (FD_REG + 64)
+// debug timing: block 0 / thread 0 stores the shader clock at phase boundaries when D.dbg != NULL
+#define MARK(i) do { if (D.dbg && blockIdx.x == 0 && threadIdx.x == 0) D.dbg[i] = clock64(); } while (0)
 
 struct __align__(16) FrameLDS {
     float feat[SFX_KD_PAD];        // first: read as float4
@@ -35,11 +45,14 @@ struct __align__(16) FrameLDS {
     float dvp[SFX_MAX_ITEMS * 3];
     int   ivid[SFX_MAX_ITEMS];
     float iw[SFX_MAX_ITEMS];
+    int   wj[SFX_MAX_ITEMS * SFX_NW];      // sparse skinning weights of the items
+    float ww[SFX_MAX_ITEMS * SFX_NW];
     float joints[SFX_MAX_K * 3];
     float dj[SFX_MAX_K * 3];
     float dA[SFX_J * 12];
     float dG[SFX_J * 12];
     float drel[SFX_J * 3];
+    float dpj[SFX_J * 3];
     float dJ[SFX_J * 3];
     float dR[SFX_J * 9];
     float dfeat[SFX_KD_PAD];
@@ -49,6 +62,7 @@ struct __align__(16) FrameLDS {
     float lh45[SFX_NHAND], rh45[SFX_NHAND];
     float scal[16];
     int   lut_row;
+    float fd[FD_N];             // this frame's keypoints / weights / camera / regression pose
     int   meta[SFX_META_N];     // tree / joint-map tables (one coalesced load instead of
                                 // dependent global loads inside every level of the chain)
 };
@@ -145,16 +159,27 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
     if (stage >= C.n_stages && !args.forward_only) return;      // frame finished
     const bool cam_stage = (stage < 0);
 
+    MARK(0);
     // ------------------------------------------------------------------ load parameters
     const float* xsrc = (args.from_X ? D.X : D.Xt) + (size_t)b * SFX_NPAR_MAX;
     for (int i = t; i < L.npar; i += CT) S.x[i] = xsrc[i];
     for (int i = t; i < SFX_META_N; i += CT) S.meta[i] = M.meta[i];
+    {   // per-frame data -> LDS (one coalesced pass instead of dependent global loads later)
+        const int K_ = M.K;
+        for (int i = t; i < 2 * K_; i += CT) S.fd[FD_GT + i] = D.gt[(size_t)b * K_ * 2 + i];
+        for (int i = t; i < K_; i += CT) { S.fd[FD_CONF + i] = D.conf[(size_t)b * K_ + i]; S.fd[FD_JW + i] = D.jw[(size_t)b * K_ + i];
+                                           S.fd[FD_CMASK + i] = D.cmask[(size_t)b * K_ + i]; }
+        if (t < 8) S.fd[FD_CAM + t] = D.cam[(size_t)b * 8 + t];
+        if (t >= 64 && t < 73) S.fd[FD_CAMR + t - 64] = D.camR[(size_t)b * 9 + t - 64];
+        if (t >= 128 && t < 128 + 63) S.fd[FD_REG + t - 128] = D.regpose[(size_t)b * 63 + t - 128];
+    }
     for (int i = t; i < SFX_KD_PAD; i += CT) { S.feat[i] = 0.f; S.dfeat[i] = 0.f; }
     for (int i = t; i < SFX_NPAR_MAX; i += CT) S.gc[i] = 0.f;
     for (int i = t; i < 168; i += CT) S.dpose[i] = 0.f;
     __syncthreads();
     const float* bodypose = C.use_vposer ? (D.bodypose + (size_t)b * 63) : (S.x + L.emb);
 
+    MARK(1);
     // ------------------------------------------------------------------ pose assembly
     if (t < SFX_POSE) {
         float v;
@@ -177,6 +202,7 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
     if (t < M.S) S.feat[t] = (t < L.NB) ? S.x[L.betas + t] : S.x[L.expr + t - L.NB];
     __syncthreads();
 
+    MARK(2);
     // ------------------------------------------------------------------ Rodrigues, rest joints
     if (t < SFX_J) {
         float R[9];
@@ -197,34 +223,26 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
     }
     __syncthreads();
 
+    MARK(3);
     // ------------------------------------------------------------------ kinematic chain
+    // one lane per (joint of the level, matrix element): 12 lanes per joint, <=10 joints per level
     for (int lev = 0; lev < M.n_levels; ++lev) {
         const int i0 = M.level_start[lev], n = M.level_start[lev + 1] - i0;
-        if (t < n) {
-            const int j = S.meta[MO_LJ + i0 + t];
+        const int jn = t / 12, e = t % 12;
+        if (jn < n) {
+            const int j = S.meta[MO_LJ + i0 + jn];
             const int p = S.meta[MO_PAR + j];
+            const int r = e >> 2, c = e & 3;
             const float* Rj = &S.R[j * 9];
-            float* Gj = &S.G[j * 12];
-            if (p < 0) {
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    Gj[r * 4 + 0] = Rj[r * 3 + 0]; Gj[r * 4 + 1] = Rj[r * 3 + 1];
-                    Gj[r * 4 + 2] = Rj[r * 3 + 2]; Gj[r * 4 + 3] = S.Jr[j * 3 + r];
-                }
-            } else {
-                const float* Gp = &S.G[p * 12];
-                const float rel[3] = {S.Jr[j * 3] - S.Jr[p * 3], S.Jr[j * 3 + 1] - S.Jr[p * 3 + 1],
-                                      S.Jr[j * 3 + 2] - S.Jr[p * 3 + 2]};
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        Gj[r * 4 + c] = Gp[r * 4 + 0] * Rj[0 * 3 + c] + Gp[r * 4 + 1] * Rj[1 * 3 + c] +
-                                        Gp[r * 4 + 2] * Rj[2 * 3 + c];
-                    Gj[r * 4 + 3] = Gp[r * 4 + 0] * rel[0] + Gp[r * 4 + 1] * rel[1] + Gp[r * 4 + 2] * rel[2] +
-                                    Gp[r * 4 + 3];
-                }
+            float v;
+            if (p < 0) v = (c < 3) ? Rj[r * 3 + c] : S.Jr[j * 3 + r];
+            else {
+                const float* Gp = &S.G[p * 12 + r * 4];
+                if (c < 3) v = Gp[0] * Rj[c] + Gp[1] * Rj[3 + c] + Gp[2] * Rj[6 + c];
+                else v = Gp[0] * (S.Jr[j * 3] - S.Jr[p * 3]) + Gp[1] * (S.Jr[j * 3 + 1] - S.Jr[p * 3 + 1]) +
+                         Gp[2] * (S.Jr[j * 3 + 2] - S.Jr[p * 3 + 2]) + Gp[3];
             }
+            S.G[j * 12 + e] = v;
         }
         __syncthreads();
     }
@@ -263,6 +281,7 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
     }
     __syncthreads();
 
+    MARK(4);
     // ------------------------------------------------------------------ dense export
     if (args.export_dense) {
         for (int k = t; k < M.KD; k += CT) D.featT[(size_t)k * D.Bpad + b] = S.feat[k];
@@ -273,6 +292,7 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
         if (args.forward_only == 2) return;     // export pass only
     }
 
+    MARK(5);
     // ------------------------------------------------------------------ needed vertices
     const int NI = M.n_items;
     for (int i = t; i < NI; i += CT) {
@@ -310,14 +330,23 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
             }
         }
     }
+    MARK(6);
     // skinning transforms of the items
+    // (sparse rows of lbs_weights: <= SFX_NW nonzeros per vertex, ascending joint order, so the
+    //  sum visits the same nonzero terms in the same order as the dense product)
+    for (int w = t; w < NI * SFX_NW; w += CT) {
+        const int i = w / SFX_NW, q2 = w % SFX_NW;
+        S.wj[w] = M.Wsp_j[(size_t)S.ivid[i] * SFX_NW + q2];
+        S.ww[w] = M.Wsp_w[(size_t)S.ivid[i] * SFX_NW + q2];
+    }
+    __syncthreads();
     for (int w = t; w < NI * 12; w += CT) {
         const int i = w / 12, e = w % 12;
-        const float* Wr = M.W + (size_t)S.ivid[i] * SFX_J;
         float acc = 0.f;
-        for (int j = 0; j < SFX_J; ++j) {
-            const float wj = Wr[j];
-            if (wj != 0.f) acc += wj * S.A[j * 12 + e];
+#pragma unroll
+        for (int q2 = 0; q2 < SFX_NW; ++q2) {
+            const float wq = S.ww[i * SFX_NW + q2];
+            if (wq != 0.f) acc += wq * S.A[S.wj[i * SFX_NW + q2] * 12 + e];
         }
         S.T[w] = acc;
     }
@@ -332,6 +361,7 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
     }
     __syncthreads();
 
+    MARK(7);
     // ------------------------------------------------------------------ mapped joints
     const int K = M.K;
     for (int w = t; w < K * 3; w += CT) {
@@ -353,10 +383,14 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
         return;
     }
 
+    MARK(8);
     // ------------------------------------------------------------------ losses
-    const float* cam = D.cam + (size_t)b * 8;
-    const float fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3], dwt = cam[4], est_tz = cam[5];
-    const float* Rc = D.camR + (size_t)b * 9;
+    // per-frame data was prefetched into LDS (S.fd) at kernel entry; all sums of this section go
+    // through ONE fixed-order reduction (DPP per wavefront, then 4 partials): 2 barriers in total
+    const float* fd = S.fd;
+    const float fx = fd[FD_CAM + 0], fy = fd[FD_CAM + 1], cx = fd[FD_CAM + 2], cy = fd[FD_CAM + 3];
+    const float dwt = fd[FD_CAM + 4], est_tz = fd[FD_CAM + 5];
+    const float* Rc = fd + FD_CAMR;
     const float* ct = S.x + L.cam_t;
     const float dw2 = dwt * dwt;
     const float rho2 = C.rho * C.rho;
@@ -365,12 +399,13 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
     float csum = 1.f;
     if (cam_stage && C.use_conf_cam) {
         float p = 0.f;
-        if (t < K) { const float cm = D.cmask[(size_t)b * K + t]; const float cf = D.conf[(size_t)b * K + t];
-                     p = (cm != 0.f) ? cf * cf : 0.f; }
+        if (t < K) { const float cm = fd[FD_CMASK + t]; const float cf = fd[FD_CONF + t]; p = (cm != 0.f) ? cf * cf : 0.f; }
         csum = block_sum(p, S.red);
     }
-    float lpart = 0.f;
-    float dpc[3] = {0.f, 0.f, 0.f};
+    enum { Q_L = 0, Q_D0, Q_D1, Q_D2, Q_PP, Q_SH, Q_ANG, Q_LH, Q_RH, Q_EX, Q_JW, NQ };
+    float q[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) q[i] = 0.f;
     if (t < K) {
         const float* p = &S.joints[t * 3];
         const float pcx = Rc[0] * p[0] + Rc[1] * p[1] + Rc[2] * p[2] + ct[0];
@@ -378,41 +413,77 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
         const float pcz = Rc[6] * p[0] + Rc[7] * p[1] + Rc[8] * p[2] + ct[2];
         const float ix = pcx / pcz, iy = pcy / pcz;
         const float u = fx * ix + cx, v = fy * iy + cy;
-        const float gx = D.gt[((size_t)b * K + t) * 2], gy = D.gt[((size_t)b * K + t) * 2 + 1];
-        const float rx = gx - u, ry = gy - v;
+        const float rx = fd[FD_GT + 2 * t] - u, ry = fd[FD_GT + 2 * t + 1] - v;
         float du, dv;       // dL/du, dL/dv
         if (cam_stage) {
-            const float cm = D.cmask[(size_t)b * K + t];
-            if (cm != 0.f) {
-                lpart = rx * rx + ry * ry;
+            if (fd[FD_CMASK + t] != 0.f) {
+                q[Q_L] = rx * rx + ry * ry;
                 du = -2.f * rx * csum * dw2; dv = -2.f * ry * csum * dw2;
             } else { du = 0.f; dv = 0.f; }
         } else {
-            float w = D.jw[(size_t)b * K + t];
+            float w = fd[FD_JW + t];
             if (t >= C.nbj) w = (t < C.nbj + 42) ? ((w != 0.f) ? sw.hand_jw : 0.f) : ((w != 0.f) ? sw.face_jw : 0.f);
-            if (C.use_conf) w *= D.conf[(size_t)b * K + t];
+            if (C.use_conf) w *= fd[FD_CONF + t];
             const float w2 = w * w;
             if (w2 != 0.f) {
                 const float sx = rx * rx, sy = ry * ry;
                 const float gmx = rho2 * (sx / (sx + rho2)), gmy = rho2 * (sy / (sy + rho2));
-                lpart = w2 * gmx + w2 * gmy;
+                q[Q_L] = w2 * gmx + w2 * gmy;
                 du = -(w2 * dw2) * gmof_grad(rx, rho2);
                 dv = -(w2 * dw2) * gmof_grad(ry, rho2);
             } else { du = 0.f; dv = 0.f; }
         }
         const float dix = du * fx, diy = dv * fy;
-        dpc[0] = dix / pcz; dpc[1] = diy / pcz;
-        dpc[2] = -(dix * pcx + diy * pcy) / (pcz * pcz);
-        S.dj[t * 3 + 0] = Rc[0] * dpc[0] + Rc[3] * dpc[1] + Rc[6] * dpc[2];
-        S.dj[t * 3 + 1] = Rc[1] * dpc[0] + Rc[4] * dpc[1] + Rc[7] * dpc[2];
-        S.dj[t * 3 + 2] = Rc[2] * dpc[0] + Rc[5] * dpc[1] + Rc[8] * dpc[2];
+        const float d0 = dix / pcz, d1 = diy / pcz, d2 = -(dix * pcx + diy * pcy) / (pcz * pcz);
+        q[Q_D0] = d0; q[Q_D1] = d1; q[Q_D2] = d2;
+        S.dj[t * 3 + 0] = Rc[0] * d0 + Rc[3] * d1 + Rc[6] * d2;
+        S.dj[t * 3 + 1] = Rc[1] * d0 + Rc[4] * d1 + Rc[7] * d2;
+        S.dj[t * 3 + 2] = Rc[2] * d0 + Rc[5] * d1 + Rc[8] * d2;
     }
-    float lsum = block_sum(lpart, S.red);
-    // camera-translation gradient = sum_k dpc
-    const float gct0 = block_sum(dpc[0], S.red), gct1 = block_sum(dpc[1], S.red), gct2 = block_sum(dpc[2], S.red);
+    const float bpw2 = sw.bpw * sw.bpw, sw2 = sw.sw * sw.sw, h2 = sw.hpw * sw.hpw, e2 = sw.epw * sw.epw;
+    if (!cam_stage) {
+        const bool latent_reg = C.use_vposer ? (stage + 1 == C.n_stages && C.has_reg) : (C.has_reg != 0);
+        if (t < L.NEMB) {       // pose prior on the embedding (fitting.py:390-401)
+            const float e = S.x[L.emb + t];
+            const float dlt = latent_reg ? (e - fd[FD_REG + t]) : e;
+            q[Q_PP] = dlt * dlt;
+            S.gc[L.emb + t] = 2.f * dlt * bpw2;
+        }
+        if (t < L.NB) { const float bt = S.x[L.betas + t]; q[Q_SH] = bt * bt; S.gc[L.betas + t] = 2.f * bt * sw2; }
+        if (t < 4) {            // angle prior: exp(pose[idx]*sign)^2 * bending weight (prior.py:73-89)
+            const int idx = (t == 0) ? 52 : (t == 1) ? 55 : (t == 2) ? 9 : 12;
+            const float sg = (t == 0) ? 1.f : -1.f;
+            const float e = expf(S.full_pose[3 + idx] * sg);
+            q[Q_ANG] = e * e;
+            S.dpose[3 + idx] = 2.f * (e * e) * sg * sw.bend;
+        }
+        if (C.use_hands && t < SFX_NHAND) {
+            q[Q_LH] = S.lh45[t] * S.lh45[t]; q[Q_RH] = S.rh45[t] * S.rh45[t];
+            S.dpose[75 + t] = 2.f * S.lh45[t] * h2; S.dpose[120 + t] = 2.f * S.rh45[t] * h2;
+        }
+        if (C.use_face) {
+            if (t < L.NE) { const float ev = S.x[L.expr + t]; q[Q_EX] = ev * ev; S.gc[L.expr + t] = 2.f * ev * e2; }
+            if (t < 3) { const float jv = S.x[L.jaw + t] * sw.jaw[t]; q[Q_JW] = jv * jv; S.gc[L.jaw + t] = 2.f * jv * sw.jaw[t]; }
+        }
+    }
+    {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const float w = wave_sum_dpp(q[i]);
+            if (lane == 0) S.red[wv * NQ + i] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            float r = S.red[i];
+#pragma unroll
+            for (int w = 1; w < CT / 64; ++w) r += S.red[w * NQ + i];
+            q[i] = r;
+        }
+    }
     float total;
     if (cam_stage) {
-        float joint = lsum;
+        float joint = q[Q_L];
         if (C.use_conf_cam) joint *= csum;
         joint *= dw2;
         const float dz = ct[2] - est_tz;
@@ -420,66 +491,19 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
         if (C.depth_w > 0.f) depth = (C.depth_w * C.depth_w) * (dz * dz);
         total = joint + depth;
         if (t < 3) {
-            float g = (t == 0) ? gct0 : (t == 1) ? gct1 : gct2;
+            float g = (t == 0) ? q[Q_D0] : (t == 1) ? q[Q_D1] : q[Q_D2];
             if (t == 2 && C.depth_w > 0.f) g += (C.depth_w * C.depth_w) * 2.f * dz;
             S.gc[L.cam_t + t] = g;
         }
     } else {
-        const float joint = lsum * dw2;
-        // ---- priors (single wavefront 0; tiny) ----
-        float pp = 0.f, shp = 0.f, ang = 0.f, lhp = 0.f, rhp = 0.f, exl = 0.f, jwl = 0.f;
-        const float bpw2 = sw.bpw * sw.bpw;
-        const bool latent_reg = C.use_vposer ? (stage + 1 == C.n_stages && C.has_reg) : (C.has_reg != 0);
-        const float* reg = D.regpose + (size_t)b * 63;
-        {   // pose prior on the embedding (fitting.py:390-401)
-            float p = 0.f;
-            if (t < L.NEMB) {
-                const float e = S.x[L.emb + t];
-                const float dlt = latent_reg ? (e - reg[t]) : e;
-                p = dlt * dlt;
-                S.gc[L.emb + t] = 2.f * dlt * bpw2;
-            }
-            pp = block_sum(p, S.red) * bpw2;
-        }
-        {
-            float p = 0.f;
-            if (t < L.NB) { const float bt = S.x[L.betas + t]; p = bt * bt; S.gc[L.betas + t] = 2.f * bt * (sw.sw * sw.sw); }
-            shp = block_sum(p, S.red) * (sw.sw * sw.sw);
-        }
-        {   // angle prior: exp(pose[idx]*sign)^2 * bending weight (prior.py:73-89, fitting.py:407-408)
-            float p = 0.f;
-            if (t < 4) {
-                const int idx = (t == 0) ? 52 : (t == 1) ? 55 : (t == 2) ? 9 : 12;
-                const float sg = (t == 0) ? 1.f : -1.f;
-                const float e = expf(S.full_pose[3 + idx] * sg);
-                p = e * e;
-                S.dpose[3 + idx] = 2.f * p * sg * sw.bend;
-            }
-            ang = block_sum(p, S.red) * sw.bend;
-        }
-        if (C.use_hands) {
-            const float h2 = sw.hpw * sw.hpw;
-            float p = 0.f, q = 0.f;
-            if (t < SFX_NHAND) { p = S.lh45[t] * S.lh45[t]; q = S.rh45[t] * S.rh45[t];
-                                 S.dpose[75 + t] = 2.f * S.lh45[t] * h2; S.dpose[120 + t] = 2.f * S.rh45[t] * h2; }
-            lhp = block_sum(p, S.red) * h2;
-            rhp = block_sum(q, S.red) * h2;
-        }
-        if (C.use_face) {
-            const float e2 = sw.epw * sw.epw;
-            float p = 0.f, q = 0.f;
-            if (t < L.NE) { const float ev = S.x[L.expr + t]; p = ev * ev; S.gc[L.expr + t] = 2.f * ev * e2; }
-            if (t < 3) { const float jv = S.x[L.jaw + t] * sw.jaw[t]; q = jv * jv; S.gc[L.jaw + t] = 2.f * jv * sw.jaw[t]; }
-            exl = block_sum(p, S.red) * e2;
-            jwl = block_sum(q, S.red);
-        }
-        total = joint + pp + shp + ang;
-        if (C.use_face) total = total + jwl + exl;
-        if (C.use_hands) total = total + lhp + rhp;
-        if (t < 3) S.gc[L.cam_t + t] = (t == 0) ? gct0 : (t == 1) ? gct1 : gct2;
+        total = q[Q_L] * dw2 + q[Q_PP] * bpw2 + q[Q_SH] * sw2 + q[Q_ANG] * sw.bend;
+        if (C.use_face) total = total + q[Q_JW] + q[Q_EX] * e2;
+        if (C.use_hands) total = total + q[Q_LH] * h2 + q[Q_RH] * h2;
+        if (t < 3) S.gc[L.cam_t + t] = (t == 0) ? q[Q_D0] : (t == 1) ? q[Q_D1] : q[Q_D2];
     }
     __syncthreads();
 
+    MARK(9);
     // ------------------------------------------------------------------ reverse sweep
     // d joints -> items / kinematic joints
     for (int w = t; w < NI * 3; w += CT) {
@@ -493,18 +517,26 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
                    S.T[i * 12 + 8 + c] * S.dvert[i * 3 + 2];
     }
     __syncthreads();
-    // dA[j][e] = sum_items W[v][j] * dT[e]
+    MARK(10);
+    // dA[j][e] = sum_items W[v][j] * dT[e]: per-joint item lists (CSR built at model creation,
+    // one per dynamic-contour LUT row), visited in ascending item order -> deterministic
     for (int w = t; w < SFX_J * 12; w += CT) {
         const int j = w / 12, e = w % 12, r = e >> 2, c = e & 3;
         float acc = 0.f;
-        for (int i = 0; i < NI; ++i) {
-            const float dv = S.dvert[i * 3 + r];
-            if (dv == 0.f) continue;
-            const float wj = M.W[(size_t)S.ivid[i] * SFX_J + j];
-            if (wj != 0.f) acc += wj * (dv * (c < 3 ? S.vp[i * 3 + c] : 1.f));
+        for (int pass = 0; pass < 2; ++pass) {
+            const int* st = pass ? (M.dj_start + (size_t)S.lut_row * (SFX_J + 1)) : M.sj_start;
+            const int* it = pass ? M.dj_item : M.sj_item;
+            const float* wt = pass ? M.dj_w : M.sj_w;
+            if (pass && M.n_dyn_items == 0) break;
+            for (int q2 = st[j]; q2 < st[j + 1]; ++q2) {
+                const int i = it[q2];
+                const float dv = S.dvert[i * 3 + r];
+                if (dv != 0.f) acc += wt[q2] * (dv * (c < 3 ? S.vp[i * 3 + c] : 1.f));
+            }
         }
         S.dA[w] = acc;
     }
+    MARK(11);
     // dfeat[k] = sum_items sum_c dirsT[v][c][k] * dvp[c]
     for (int k = t; k < M.KD; k += CT) {
         float acc = 0.f;
@@ -517,76 +549,66 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
         S.dfeat[k] = acc;
     }
     __syncthreads();
-    // kinematic chain, deepest level first; parents gather from their children
+    MARK(12);
+    // kinematic chain, deepest level first; parents gather from their children (no atomics).
+    // pass 0: posed-joint adjoints; pass 1 (per level): dG, one lane per matrix element;
+    // pass 2 (all joints at once): dR, d(rel); pass 3: dJ.
+    for (int w = t; w < SFX_J * 3; w += CT) {
+        const int j = w / 3, r = w % 3;
+        float acc = 0.f;
+        for (int q2 = S.meta[MO_SK0 + j]; q2 < S.meta[MO_SK0 + j + 1]; ++q2) acc += S.dj[S.meta[MO_SKL + q2] * 3 + r];
+        S.dpj[w] = acc;
+    }
+    __syncthreads();
     for (int lev = M.n_levels - 1; lev >= 0; --lev) {
         const int i0 = M.level_start[lev], n = M.level_start[lev + 1] - i0;
-        if (t < n) {
-            const int j = S.meta[MO_LJ + i0 + t];
-            const int p = S.meta[MO_PAR + j];
-            const float* dAj = &S.dA[j * 12];
-            const float* Jj = &S.Jr[j * 3];
-            float dGj[12];
-            // posed joint adjoint: every mapped joint reading kinematic joint j
-            float dpj[3] = {0.f, 0.f, 0.f};
-            for (int q = S.meta[MO_SK0 + j]; q < S.meta[MO_SK0 + j + 1]; ++q) {
-                const int k = S.meta[MO_SKL + q];
-                dpj[0] += S.dj[k * 3]; dpj[1] += S.dj[k * 3 + 1]; dpj[2] += S.dj[k * 3 + 2];
+        const int jn = t / 12, e = t % 12;
+        if (jn < n) {
+            const int j = S.meta[MO_LJ + i0 + jn];
+            const int r = e >> 2, c = e & 3;
+            const float dat = S.dA[j * 12 + r * 4 + 3];
+            float v = (c < 3) ? (S.dA[j * 12 + e] - dat * S.Jr[j * 3 + c]) : (dat + S.dpj[j * 3 + r]);
+            for (int q2 = S.meta[MO_CS + j]; q2 < S.meta[MO_CS + j + 1]; ++q2) {
+                const int ch = S.meta[MO_CL + q2];
+                const float* dGc = &S.dG[ch * 12 + r * 4];
+                if (c < 3) {
+                    const float* Rch = &S.R[ch * 9 + c * 3];
+                    v += dGc[0] * Rch[0] + dGc[1] * Rch[1] + dGc[2] * Rch[2] + dGc[3] * (S.Jr[ch * 3 + c] - S.Jr[j * 3 + c]);
+                } else v += dGc[3];
             }
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const float dat = dAj[r * 4 + 3];
-                dGj[r * 4 + 0] = dAj[r * 4 + 0] - dat * Jj[0];
-                dGj[r * 4 + 1] = dAj[r * 4 + 1] - dat * Jj[1];
-                dGj[r * 4 + 2] = dAj[r * 4 + 2] - dat * Jj[2];
-                dGj[r * 4 + 3] = dat + dpj[r];
-            }
-            float dJj[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                dJj[c] = -(S.G[j * 12 + 0 + c] * dAj[3] + S.G[j * 12 + 4 + c] * dAj[7] + S.G[j * 12 + 8 + c] * dAj[11]);
-            for (int q = S.meta[MO_CS + j]; q < S.meta[MO_CS + j + 1]; ++q) {
-                const int ch = S.meta[MO_CL + q];
-                const float* dGc = &S.dG[ch * 12];
-                const float* Rch = &S.R[ch * 9];
-                const float rel[3] = {S.Jr[ch * 3] - Jj[0], S.Jr[ch * 3 + 1] - Jj[1], S.Jr[ch * 3 + 2] - Jj[2]};
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        dGj[r * 4 + c] += dGc[r * 4 + 0] * Rch[c * 3 + 0] + dGc[r * 4 + 1] * Rch[c * 3 + 1] +
-                                          dGc[r * 4 + 2] * Rch[c * 3 + 2] + dGc[r * 4 + 3] * rel[c];
-                    dGj[r * 4 + 3] += dGc[r * 4 + 3];
-                }
-                dJj[0] -= S.drel[ch * 3]; dJj[1] -= S.drel[ch * 3 + 1]; dJj[2] -= S.drel[ch * 3 + 2];
-            }
-#pragma unroll
-            for (int e = 0; e < 12; ++e) S.dG[j * 12 + e] = dGj[e];
-            float dRj[9], drl[3];
-            if (p < 0) {
-#pragma unroll
-                for (int r = 0; r < 3; ++r) { dRj[r * 3] = dGj[r * 4]; dRj[r * 3 + 1] = dGj[r * 4 + 1];
-                                              dRj[r * 3 + 2] = dGj[r * 4 + 2]; drl[r] = dGj[r * 4 + 3]; }
-            } else {
-                const float* Gp = &S.G[p * 12];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        dRj[r * 3 + c] = Gp[0 + r] * dGj[0 + c] + Gp[4 + r] * dGj[4 + c] + Gp[8 + r] * dGj[8 + c];
-                    drl[r] = Gp[0 + r] * dGj[3] + Gp[4 + r] * dGj[7] + Gp[8 + r] * dGj[11];
-                }
-            }
-            if (j > 0) {
-#pragma unroll
-                for (int e = 0; e < 9; ++e) dRj[e] += S.dfeat[M.S + 9 * (j - 1) + e];
-            }
-#pragma unroll
-            for (int e = 0; e < 9; ++e) S.dR[j * 9 + e] = dRj[e];
-            S.drel[j * 3] = drl[0]; S.drel[j * 3 + 1] = drl[1]; S.drel[j * 3 + 2] = drl[2];
-            S.dJ[j * 3] = dJj[0] + drl[0]; S.dJ[j * 3 + 1] = dJj[1] + drl[1]; S.dJ[j * 3 + 2] = dJj[2] + drl[2];
+            S.dG[j * 12 + e] = v;
         }
         __syncthreads();
     }
+    for (int w = t; w < SFX_J * 12; w += CT) {
+        const int j = w / 12, e = w % 12;
+        const int p = S.meta[MO_PAR + j];
+        const float* dGj = &S.dG[j * 12];
+        if (e < 9) {
+            const int r = e / 3, c = e % 3;
+            float v;
+            if (p < 0) v = dGj[r * 4 + c];
+            else { const float* Gp = &S.G[p * 12]; v = Gp[0 + r] * dGj[0 + c] + Gp[4 + r] * dGj[4 + c] + Gp[8 + r] * dGj[8 + c]; }
+            if (j > 0) v += S.dfeat[M.S + 9 * (j - 1) + e];
+            S.dR[j * 9 + e] = v;
+        } else {
+            const int r = e - 9;
+            float v;
+            if (p < 0) v = dGj[r * 4 + 3];
+            else { const float* Gp = &S.G[p * 12]; v = Gp[0 + r] * dGj[3] + Gp[4 + r] * dGj[7] + Gp[8 + r] * dGj[11]; }
+            S.drel[j * 3 + r] = v;
+        }
+    }
+    __syncthreads();
+    for (int w = t; w < SFX_J * 3; w += CT) {
+        const int j = w / 3, c = w % 3;
+        float v = -(S.G[j * 12 + 0 + c] * S.dA[j * 12 + 3] + S.G[j * 12 + 4 + c] * S.dA[j * 12 + 7] +
+                    S.G[j * 12 + 8 + c] * S.dA[j * 12 + 11]);
+        for (int q2 = S.meta[MO_CS + j]; q2 < S.meta[MO_CS + j + 1]; ++q2) v -= S.drel[S.meta[MO_CL + q2] * 3 + c];
+        S.dJ[w] = v + S.drel[w];
+    }
+    __syncthreads();
+    MARK(13);
     // Rodrigues adjoint -> dpose ; joint regression adjoint -> shape coefficients
     if (t < SFX_J) {
         float dth[3] = {0.f, 0.f, 0.f};
@@ -599,6 +621,7 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
         if (l < L.NB) S.gc[L.betas + l] += acc; else S.gc[L.expr + l - L.NB] += acc;
     }
     __syncthreads();
+    MARK(14);
     // dpose -> canonical parameters
     if (t < 3) { S.gc[L.go + t] += S.dpose[t]; S.gc[L.jaw + t] += S.dpose[66 + t];
                  S.gc[L.leye + t] += S.dpose[69 + t]; S.gc[L.reye + t] += S.dpose[72 + t]; }
@@ -612,11 +635,13 @@ void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const St
         S.gc[(left ? L.lh : L.rh) + i] += acc;
     }
     __syncthreads();
+    MARK(15);
     // TODO(vposer): body-pose adjoint through the VPoser decoder is applied by k_vposer_bwd.
     const VarList& vl = vls[cam_stage ? 0 : 1];
     float* gout = D.g + (size_t)b * SFX_NVAR_MAX;
     for (int i = t; i < vl.n; i += CT) gout[i] = S.gc[vl.idx[i]];
     if (t == 0) D.f[b] = total;
+    MARK(16);
 }
 
 void launch_closure(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,

@@ -57,6 +57,44 @@ __device__ __forceinline__ Sc cubic_interpolate(Sc x1, Sc f1, Sc g1, Sc x2, Sc f
     return sc_div(sc_add(lo, hi), P(2.0));
 }
 
+// cv2.Rodrigues semantics (fit_single_frame.py:528-535): rotvec -> R, R . R([0,pi,0]), -> rotvec
+__device__ void flipped_orientation(const float* go, float* out) {
+    const double r0 = go[0], r1 = go[1], r2 = go[2];
+    const double a = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (a >= 1e-12) {
+        const double k0 = r0 / a, k1 = r1 / a, k2 = r2 / a, s = sin(a), c = 1.0 - cos(a);
+        const double K[9] = {0, -k2, k1, k2, 0, -k0, -k1, k0, 0};
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            double kk = 0; for (int q = 0; q < 3; ++q) kk += K[i * 3 + q] * K[q * 3 + j];
+            R[i * 3 + j] = (i == j ? 1.0 : 0.0) + s * K[i * 3 + j] + c * kk;
+        }
+    }
+    // R . Ry(pi): Ry(pi) = diag(-1, 1, -1) up to rounding of sin(pi); use the exact Rodrigues value
+    const double sp = sin(3.14159265358979323846), cp = 1.0 - cos(3.14159265358979323846);
+    const double Y[9] = {1 - cp, 0, sp, 0, 1, 0, -sp, 0, 1 - cp};
+    double M_[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        double v = 0; for (int q = 0; q < 3; ++q) v += R[i * 3 + q] * Y[q * 3 + j];
+        M_[i * 3 + j] = v;
+    }
+    double cth = (M_[0] + M_[4] + M_[8] - 1.0) / 2.0;
+    cth = cth < -1.0 ? -1.0 : (cth > 1.0 ? 1.0 : cth);
+    const double ang = acos(cth);
+    const double v0 = M_[7] - M_[5], v1 = M_[2] - M_[6], v2 = M_[3] - M_[1];
+    const double sn = sqrt(v0 * v0 + v1 * v1 + v2 * v2) / 2.0;
+    if (sn < 1e-10) {
+        if (cth > 0) { out[0] = out[1] = out[2] = 0.f; return; }
+        double d0 = sqrt(fmax((M_[0] + 1) / 2, 0.0)), d1 = sqrt(fmax((M_[4] + 1) / 2, 0.0)), d2 = sqrt(fmax((M_[8] + 1) / 2, 0.0));
+        if (M_[1] < 0) d1 = -d1;
+        if (M_[2] < 0) d2 = -d2;
+        const double n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        out[0] = (float)(d0 / n * ang); out[1] = (float)(d1 / n * ang); out[2] = (float)(d2 / n * ang);
+        return;
+    }
+    out[0] = (float)(v0 / (2 * sn) * ang); out[1] = (float)(v1 / (2 * sn) * ang); out[2] = (float)(v2 / (2 * sn) * ang);
+}
+
 struct OptScal {
     int phase, outer, n_iter, n_iter_total, cur_evals, func_evals;
     int ls_evals, ls_iter, ls_done, insuf, low, high;
@@ -81,15 +119,20 @@ struct Lane3 { float v[NE3]; };
 
 __device__ __forceinline__ float wsum(float v) { return wave_sum_dpp(v); }
 __device__ __forceinline__ float wmax(float v) { return wave_max_dpp(v); }
+// lane l owns elements 3l, 3l+1, 3l+2 of a (<=192)-vector: one 12-byte load per lane, 768
+// contiguous bytes per wavefront instruction.  Rows are allocated NVAR_MAX long, so the wide
+// load is always in bounds; elements >= N are masked to zero.
 __device__ __forceinline__ Lane3 ld3(const float* p, int lane, int N) {
     Lane3 r;
-#pragma unroll
-    for (int e = 0; e < NE3; ++e) { const int i = lane + 64 * e; r.v[e] = (i < N) ? p[i] : 0.f; }
+    const float3 v = *reinterpret_cast<const float3*>(p + 3 * lane);
+    r.v[0] = (3 * lane + 0 < N) ? v.x : 0.f;
+    r.v[1] = (3 * lane + 1 < N) ? v.y : 0.f;
+    r.v[2] = (3 * lane + 2 < N) ? v.z : 0.f;
     return r;
 }
 __device__ __forceinline__ void st3(float* p, const Lane3& a, int lane, int N) {
 #pragma unroll
-    for (int e = 0; e < NE3; ++e) { const int i = lane + 64 * e; if (i < N) p[i] = a.v[e]; }
+    for (int e = 0; e < NE3; ++e) { const int i = 3 * lane + e; if (i < N) p[i] = a.v[e]; }
 }
 __device__ __forceinline__ float dot3(const Lane3& a, const Lane3& b) {
     float p = a.v[0] * b.v[0];
@@ -100,7 +143,7 @@ __device__ __forceinline__ float dot3(const Lane3& a, const Lane3& b) {
 __device__ __forceinline__ float absmax3(const Lane3& a, int lane, int N) {
     float m = 0.f;
 #pragma unroll
-    for (int e = 0; e < NE3; ++e) if (lane + 64 * e < N) m = fmaxf(m, fabsf(a.v[e]));
+    for (int e = 0; e < NE3; ++e) if (3 * lane + e < N) m = fmaxf(m, fabsf(a.v[e]));
     return wmax(m);
 }
 __device__ __forceinline__ Lane3 axpy3(const Lane3& x, float a, const Lane3& d) {
@@ -146,6 +189,20 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
         if (lane == 0) {
             D.stage[b] = stage;
             gst->s = s;            // ro[] needs no initialisation (guarded by hist_n)
+            D.orient_pass[b] = 0;
+            int both = 0;
+            if (C.side_thsh > 0.f) {     // torch.dist of the 2-D shoulders (fit_single_frame.py:461-463)
+                const float* g2 = D.gt + (size_t)b * M.K * 2;
+                const float dx = g2[2 * C.lsh] - g2[2 * C.rsh], dy = g2[2 * C.lsh + 1] - g2[2 * C.rsh + 1];
+                both = sqrtf(dx * dx + dy * dy) < C.side_thsh;
+            }
+            D.try_both[b] = both;
+        }
+        for (int q = lane; q < 1 + SFX_MAX_STAGES; q += 64) {
+            if (q >= first_stage + 1 && q <= last_stage + 1) {
+                D.stage_evals[(size_t)b * (1 + SFX_MAX_STAGES) + q] = 0;
+                D.stage_ref_evals[(size_t)b * (1 + SFX_MAX_STAGES) + q] = 0;
+            }
         }
         for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
         return;
@@ -175,13 +232,13 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
     s.evals += 1; s.ref_evals += 1;
 
     auto gather_x = [X, lane, N, &vl]() { Lane3 r;
-        for (int e = 0; e < NE3; ++e) { const int i = lane + 64 * e; r.v[e] = (i < N) ? X[vl.idx[i]] : 0.f; } return r; };
+        for (int e = 0; e < NE3; ++e) { const int i = 3 * lane + e; r.v[e] = (i < N) ? X[vl.idx[i]] : 0.f; } return r; };
     auto write_trial = [X, Xt, vec, lane, N, &vl](Sc t) {
         const Lane3 xi = ld3(VEC(VEC_XINIT), lane, N), d = ld3(VEC(VEC_D), lane, N);
         const Lane3 xt = axpy3(xi, (float)t.v, d);
         for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
         __syncthreads();
-        for (int e = 0; e < NE3; ++e) { const int i = lane + 64 * e; if (i < N) Xt[vl.idx[i]] = xt.v[e]; }
+        for (int e = 0; e < NE3; ++e) { const int i = 3 * lane + e; if (i < N) Xt[vl.idx[i]] = xt.v[e]; }
     };
 #define armijo_fail(f_new, t) sc_gt((f_new), sc_add(s.ls_f0, sc_mul(sc_mul(P(1e-4), (t)), s.ls_gtd0)))
 #define curv_ok(gtd_new) sc_le(sc_abs(gtd_new), sc_mul(P(-0.9), s.ls_gtd0))
@@ -295,7 +352,7 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
                 for (int e = 0; e < NE3; ++e) q.v[e] = -g.v[e];
                 // two-loop recursion; history rows are prefetched CH at a time so that the
                 // serial chain is dot/axpy latency only, not HBM latency
-                constexpr int CH = 8;
+                constexpr int CH = 16;
                 for (int i0 = s.hist_n - 1; i0 >= 0; i0 -= CH) {
                     Lane3 Sb[CH], Yb[CH]; float rb[CH];
 #pragma unroll
@@ -396,7 +453,7 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
             st3(VEC(VEC_G), g, lane, N);
             const Lane3 xi = ld3(VEC(VEC_XINIT), lane, N), d = ld3(VEC(VEC_D), lane, N);
             const Lane3 xn = axpy3(xi, (float)t.v, d);
-            for (int e = 0; e < NE3; ++e) { const int i = lane + 64 * e; if (i < N) X[vl.idx[i]] = xn.v[e]; }
+            for (int e = 0; e < NE3; ++e) { const int i = 3 * lane + e; if (i < N) X[vl.idx[i]] = xn.v[e]; }
             s.cache_valid = 1;
             const bool opt_cond = sc_le(T(absmax3(g, lane, N)), P((double)1e-5));
             s.cur_evals += s.ls_evals; s.func_evals += s.ls_evals;
@@ -438,7 +495,7 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
                     if (!vl.g_has[gi]) continue;
                     float m = -INFINITY;
                     for (int e = 0; e < NE3; ++e) {
-                        const int i = lane + 64 * e;
+                        const int i = 3 * lane + e;
                         if (i >= vl.g_off[gi] && i < vl.g_off[gi] + vl.g_len[gi]) m = fmaxf(m, gl.v[e]);
                     }
                     m = wmax(m);
@@ -465,13 +522,52 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
         }
         case A_FINISH_STAGE: {
             const int slot = stage + 1;     // camera stage -> 0
+            const size_t so = (size_t)b * (1 + SFX_MAX_STAGES);
+            const int pass = D.orient_pass[b];
+            const float res = s.has_prev_outer ? (float)s.prev_loss_outer : __int_as_float(0x7fc00000);
             if (lane == 0) {
-                D.stage_loss[(size_t)b * (1 + SFX_MAX_STAGES) + slot] =
-                    s.has_prev_outer ? (float)s.prev_loss_outer : __int_as_float(0x7fc00000);
-                D.stage_evals[(size_t)b * (1 + SFX_MAX_STAGES) + slot] = s.evals;
-                D.stage_ref_evals[(size_t)b * (1 + SFX_MAX_STAGES) + slot] = s.ref_evals;
+                (pass ? D.stage_loss2 : D.stage_loss)[so + slot] = res;
+                D.stage_evals[so + slot] += s.evals;
+                D.stage_ref_evals[so + slot] += s.ref_evals;
             }
+            // camera stage done: remember the orientation the flipped candidate is derived from
+            if (stage < 0 && lane < 3) D.gocam[(size_t)b * 4 + lane] = X[D.L.go + lane];
             stage += 1;
+            // side view (fit_single_frame.py:527-551): second fit from the orientation rotated by pi
+            // about y; pose embedding and camera translation continue from the first fit, every
+            // other body parameter is zeroed; the lower final loss wins (:662-667)
+            if (stage == C.n_stages && last_stage == C.n_stages - 1 && D.try_both[b]) {
+                float* X0 = D.X0 + (size_t)b * SFX_NPAR_MAX;
+                __syncthreads();
+                if (pass == 0) {
+                    for (int i = lane; i < SFX_NPAR_MAX; i += 64) X0[i] = X[i];
+                    __syncthreads();
+                    const ParLayout& L = D.L;
+                    for (int i = lane; i < L.npar; i += 64) {
+                        const bool keep = (i >= L.cam_t && i < L.cam_t + 3) || (i >= L.emb && i < L.emb + L.NEMB);
+                        if (!keep) X[i] = 0.f;
+                    }
+                    __syncthreads();
+                    if (lane == 0) {
+                        float fl[3];
+                        flipped_orientation(D.gocam + (size_t)b * 4, fl);
+                        X[L.go] = fl[0]; X[L.go + 1] = fl[1]; X[L.go + 2] = fl[2];
+                        D.orient_pass[b] = 1;
+                    }
+                    if (L.has_bodyp && lane < 63) X[L.bodyp + lane] = X[L.emb + lane];
+                    __syncthreads();
+                    stage = 0;
+                } else {
+                    const float l0 = D.stage_loss[so + C.n_stages], l1 = res;
+                    if (l0 < l1) {                       // first orientation wins: restore it
+                        for (int i = lane; i < SFX_NPAR_MAX; i += 64) X[i] = X0[i];
+                    } else if (lane == 0) {
+                        for (int q = 1; q <= C.n_stages; ++q) D.stage_loss[so + q] = D.stage_loss2[so + q];
+                    }
+                    if (lane == 0) D.orient_pass[b] = 2;
+                    __syncthreads();
+                }
+            }
             if (lane == 0) D.stage[b] = stage;
             s = fresh_state();
             for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];

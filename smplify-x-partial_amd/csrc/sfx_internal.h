@@ -16,6 +16,7 @@
 #define SFX_NPAR_MAX 192    // canonical per-frame parameter block
 #define SFX_MAX_STAGES 8
 #define SFX_MAX_GROUPS 12
+#define SFX_NW 8             // nonzero skinning weights kept per vertex (needed-rows path)
 // packed integer tables of the closure kernel (DevModel.meta)
 #define MO_PAR 0
 #define MO_LJ 56
@@ -60,6 +61,8 @@ struct DevModel {
     const float* dirsT;        // [V][3][KD_PAD] vertex-major (needed-rows path)
     const float* W;            // [V][J]
     const float* WT;           // [JPAD][Vpad]   (dense skinning GEMM B operand)
+    const int*   Wsp_j;        // [V][SFX_NW] joints of the nonzero weights (ascending), pad: j=0,w=0
+    const float* Wsp_w;        // [V][SFX_NW]
     const float* J_template;   // [J][3]
     const float* J_dirs;       // [J][3][S]
     const int*   parents;      // [J]
@@ -85,6 +88,10 @@ struct DevModel {
     const int*   src_k0;       // [J+1] CSR: mapped joints that read kinematic joint s
     const int*   src_klist;    // [..]
     int Vpad;
+    // per-joint lists of (item, skinning weight): static items, and dynamic items per LUT row
+    const int *sj_start, *sj_item; const float* sj_w;      // [J+1], [..]
+    const int *dj_start, *dj_item; const float* dj_w;      // [rows][J+1] (absolute offsets), [..]
+    int n_dyn_items;
     const int*   meta;         // [SFX_META_N] packed copy of the tables above
     // VPoser decoder
     int vp_latent, vp_hidden;
@@ -99,6 +106,7 @@ struct BatchCfgDev {
     double ftol, gtol;
     float lr, rho, depth_w;
     int lbs_mode, reuse;
+    float side_thsh; int lsh, rsh;     // side-view test: 2-D shoulder distance threshold, indices
 };
 
 // Per-frame data pointers (all device).
@@ -133,6 +141,12 @@ struct BatchDev {
     float* stage_loss; // [B][1+MAX_STAGES]
     int*   stage_evals;     // [B][1+MAX_STAGES]
     int*   stage_ref_evals; // [B][1+MAX_STAGES]
+    float* X0;         // [B][NPAR_MAX] first-orientation result (side-view second fit)
+    float* gocam;      // [B][4] global_orient at the end of the camera stage
+    float* stage_loss2;// [B][1+MAX_STAGES] second-orientation stage losses
+    int*   try_both;   // [B]
+    int*   orient_pass;// [B] 0 first fit, 1 second fit running, 2 done
+    long long* dbg;         // [64] phase timestamps of block 0 (NULL = off)
 };
 
 enum { VEC_XINIT = 0, VEC_D, VEC_G, VEC_PREVG, VEC_GPREV, VEC_BG0, VEC_BG1, VEC_LSG0, NVEC };

@@ -80,7 +80,7 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
     Ww = np.broadcast_to(np.asarray(W, np.float32), (B,))
     f = np.broadcast_to(np.asarray(focal, np.float32), (B,))
     fb = engine.FrameBatch(dm, B, cfg, lbs_mode=lbs_mode, reuse_entry_eval=reuse_entry_eval,
-                           has_regression_pose=has_reg)
+                           has_regression_pose=has_reg, side_view=True)
     nemb = fb.nemb
     emb0 = np.asarray(reg_pose, np.float32).reshape(B, nemb) if has_reg else np.zeros((B, nemb), np.float32)
     go0 = np.asarray(reg_global, np.float32).reshape(B, 3) if reg_global is not None else np.zeros((B, 3), np.float32)
@@ -94,51 +94,20 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
                                    else np.zeros((B, 3), np.float32)))
     if not use_cam_prior:
         fb.guess_init(cfg.get("body_tri_idxs", [(5, 12), (2, 9)]))
-    # ---- camera stage, then the body stages from the camera-stage orientation -------------------
-    go_cam = None
-    if prep["try_both"].any() or not fb.n_stages:
-        fb.fit(first_stage=-1, last_stage=-1)
-        go_cam = fb.get_params()["global_orient"].copy()      # needed for the flipped candidate
-        if fb.n_stages:
-            fb.fit(first_stage=0, last_stage=fb.n_stages - 1)
-    else:
-        fb.fit(first_stage=-1, last_stage=fb.n_stages - 1)    # frames change stage independently
+    # ---- camera stage + body stages; frames change stage independently on device.  Side views
+    #      (2-D shoulder distance < side_view_thsh, fit_single_frame.py:461-463) are fitted a second
+    #      time from the orientation flipped by pi about y and the lower final loss is kept
+    #      (:527-551,662-667) -- also on device, inside the same batch.
+    fb.fit(first_stage=-1, last_stage=fb.n_stages - 1)
     st = fb.stats()
     out = dict(fb.get_params())
     out.update(stage_loss=st["stage_loss"].copy(), stage_evals=st["stage_evals"].copy(),
-               stage_ref_evals=st["stage_ref_evals"].copy(), n_orient=np.ones(B, np.int32))
+               stage_ref_evals=st["stage_ref_evals"].copy(),
+               n_orient=np.where(prep["try_both"] & (fb.n_stages > 0), 2, 1).astype(np.int32))
     verts = joints = None
     if want_vertices:
         v, j = fb.forward()
         verts, joints = v.cpu().numpy(), j.cpu().numpy()
-    # ---- second orientation for side views (fit_single_frame.py:527-538,546-551) --------------
-    idx = np.nonzero(prep["try_both"])[0]
-    if idx.size and fb.n_stages:
-        # the reference continues from the first pass: pose_embedding and camera translation keep
-        # their fitted values, global_orient = camera-stage orientation rotated by pi about y,
-        # every other body parameter is reset to zero (reset_params), new optimiser per stage
-        n2 = len(idx)
-        fb2 = engine.FrameBatch(dm, n2, cfg, lbs_mode=lbs_mode, reuse_entry_eval=reuse_entry_eval,
-                                has_regression_pose=has_reg)
-        fb2.set_frames(kp[idx], prep["jw"][idx], prep["cmask"][idx], f[idx], center[idx], 1000.0 / Hh[idx])
-        flip = np.stack([flipped_orientation(g) for g in go_cam[idx]]).astype(np.float32)
-        fb2.set_params(regression_pose=emb0[idx] if has_reg else None, global_orient=flip,
-                       pose_embedding=out["pose_embedding"][idx], cam_translation=out["cam_translation"][idx])
-        fb2.fit(first_stage=0, last_stage=fb2.n_stages - 1)
-        st2, p2 = fb2.stats(), fb2.get_params()
-        out["n_orient"][idx] = 2
-        out["stage_evals"][idx, 1:] += st2["stage_evals"][:, 1:]
-        out["stage_ref_evals"][idx, 1:] += st2["stage_ref_evals"][:, 1:]
-        l1, l2 = out["stage_loss"][idx, -1], st2["stage_loss"][:, -1]
-        take2 = ~(l1 < l2)                         # min_idx = 0 if results[0] < results[1] else 1 (:664-665)
-        sel = idx[take2]
-        for k in p2:
-            out[k][sel] = p2[k][take2]
-        out["stage_loss"][sel, 1:] = st2["stage_loss"][take2, 1:]
-        if want_vertices and sel.size:
-            v2, j2 = fb2.forward()
-            verts[sel], joints[sel] = v2.cpu().numpy()[take2], j2.cpu().numpy()[take2]
-        fb2.close()
     out["final_loss"] = out["stage_loss"][:, -1].copy()
     if want_vertices:
         out["vertices"], out["joints"] = verts, joints

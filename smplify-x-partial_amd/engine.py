@@ -167,7 +167,7 @@ class FrameBatch(object):
     """B frames under one configuration (sfx_batch)."""
 
     def __init__(self, model, B, cfg, lbs_mode="dense", reuse_entry_eval=True, has_regression_pose=True,
-                 stages=None, num_body_joints=None):
+                 stages=None, num_body_joints=None, side_view=False):
         """`cfg` uses the reference's key names (cmd_parser).  `stages` (list of
         capi.StageWeights) overrides the schedule derived from cfg; `num_body_joints` overrides
         where the per-stage hand/face joint weights start (K = never: weights passed verbatim)."""
@@ -193,6 +193,9 @@ class FrameBatch(object):
         c.depth_loss_weight = float(cfg.get("depth_loss_weight", 1e2))
         c.lbs_mode = {"rows": 0, "dense": 1}[lbs_mode]
         c.reuse_entry_eval = int(bool(reuse_entry_eval))
+        c.side_view_thsh = float(cfg.get("side_view_thsh", 0.0) or 0.0) if side_view else 0.0
+        c.left_shoulder_idx = int(cfg.get("left_shoulder_idx", 2))
+        c.right_shoulder_idx = int(cfg.get("right_shoulder_idx", 5))
         self.use_vposer = bool(c.use_vposer)
         self.nemb = model.vposer_latent if self.use_vposer else 63
         arr = (capi.StageWeights * max(1, self.n_stages))(*stages)

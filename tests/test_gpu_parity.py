@@ -252,3 +252,38 @@ def test_shard_invariance_bitwise(gpu, synth_model, cfg_body):
     for idx, p, st in res[1:]:
         for k in p:
             assert np.array_equal(p[k][-1], p0[k][2]), k
+
+
+def test_side_view_second_orientation_on_device(gpu, synth_model, cfg_body):
+    """Frames whose 2-D shoulders coincide are fitted twice (flipped orientation) inside the
+    batch; the result equals running the two passes by hand (fit_single_frame.py:527-551,662-667)."""
+    from smplifyx_amd import driver, engine
+    g = _golden("e2e_synth")
+    cfg = dict(cfg_body); cfg["use_camera_prior"] = False
+    dm = _dm(synth_model, cfg)
+    kp = g["keypoints"].copy()
+    kp[1, 5, :2] = kp[1, 2, :2] + 3.0            # frame 1: shoulders 3 px apart -> side view
+    jw = H.base_joint_weights(cfg, 25)
+    res = driver.fit_frames(dm, cfg, kp, jw, 600, 800, 5000.0, reg_pose=g["reg_pose"], reg_global=g["reg_global"],
+                            lbs_mode="rows", reuse_entry_eval=True)
+    assert list(res["n_orient"]) == [1, 2]
+    # by hand: pass 0 on a batch without the side-view program, then pass 1 from the flipped orientation
+    frames = dict(keypoints=kp, reg_pose=g["reg_pose"], reg_global=g["reg_global"], H=600, W=800, focal=5000.0)
+    fb = H.engine_batch_from_frames(dm, cfg, frames, [1], lbs_mode="rows", reuse=True)
+    fb.guess_init(cfg["body_tri_idxs"])
+    fb.fit(first_stage=-1, last_stage=-1)
+    go_cam = fb.get_params()["global_orient"].copy()
+    fb.fit(first_stage=0, last_stage=fb.n_stages - 1)
+    p0, s0 = fb.get_params(), fb.stats()
+    fb2 = H.engine_batch_from_frames(dm, cfg, frames, [1], lbs_mode="rows", reuse=True)
+    flip = driver.flipped_orientation(go_cam[0]).astype(np.float32)[None]
+    fb2.set_params(regression_pose=g["reg_pose"][1:2], global_orient=flip, pose_embedding=p0["pose_embedding"],
+                   cam_translation=p0["cam_translation"])
+    fb2.fit(first_stage=0, last_stage=fb2.n_stages - 1)
+    p1, s1 = fb2.get_params(), fb2.stats()
+    l0, l1 = s0["stage_loss"][0, -1], s1["stage_loss"][0, -1]
+    want = p0 if l0 < l1 else p1
+    assert np.allclose(res["final_loss"][1], min(l0, l1), rtol=1e-6)
+    for k in ("global_orient", "pose_embedding", "betas", "cam_translation"):
+        assert np.allclose(res[k][1], want[k][0], rtol=0, atol=1e-6), k
+    assert res["stage_evals"][1, 1:].sum() == s0["stage_evals"][0, 1:].sum() + s1["stage_evals"][0, 1:].sum()
