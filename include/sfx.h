@@ -186,7 +186,7 @@ int  sfx_batch_forward(sfx_batch* b, float* vertices_out_dev /* [B][V][3] */,
  * the last reset, measured with HIP events on the launch stream.  name: "lbs_dense",
  * "closure", "lbfgs".  Returns launches counted.                                          */
 int  sfx_prof_enable(int32_t on);
-int  sfx_prof_get(const char* name, double* total_ms, int64_t* launches);
+int  sfx_prof_get(const char* name, double* total_ms, int64_t* launches, double* units /* frames processed */);
 void sfx_prof_reset(void);
 
 /* Debug: shader-clock stamps at the phase boundaries of one closure launch (block 0). */

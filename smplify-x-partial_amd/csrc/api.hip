@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,9 +24,11 @@ extern "C" const char* sfx_version(void) { return "sfx 0.1.0 (gfx950)"; }
 
 // ---------------------------------------------------------------------------------------
 // profiling: HIP-event timing of named kernels on the launch stream
-struct ProfAcc { double ms = 0; int64_t n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pend; };
+struct ProfAcc { double ms = 0; int64_t n = 0; double units = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pend; };
 static int g_prof = 0;
+static int g_unfused = 0;     // debug: run the fitting loop with the stand-alone kernels
 static std::map<std::string, ProfAcc> g_acc;
+static std::mutex g_prof_mu;     // batches may be driven from several host threads (one stream each)
 
 static void prof_flush(ProfAcc& a) {
     for (auto& p : a.pend) {
@@ -38,22 +41,26 @@ static void prof_flush(ProfAcc& a) {
 }
 struct ProfScope {
     const char* name; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
-    ProfScope(const char* n, hipStream_t st) : name(n), s(st) {
-        if (g_prof) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s); }
+    ProfScope(const char* n, hipStream_t st, double units = 0) : name(n), s(st) {
+        if (g_prof) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s);
+                      std::lock_guard<std::mutex> lk(g_prof_mu); g_acc[name].units += units; }
     }
     ~ProfScope() {
-        if (g_prof) { hipEventRecord(e1, s); auto& a = g_acc[name]; a.pend.push_back({e0, e1});
-                      if (a.pend.size() > 512) prof_flush(a); }
+        if (g_prof && e0) { hipEventRecord(e1, s); std::lock_guard<std::mutex> lk(g_prof_mu);
+                            auto& a = g_acc[name]; a.pend.push_back({e0, e1});
+                            if (a.pend.size() > 4096) prof_flush(a); }
     }
 };
-extern "C" int sfx_prof_enable(int32_t on) { g_prof = on; return 0; }
-extern "C" void sfx_prof_reset(void) { for (auto& kv : g_acc) { prof_flush(kv.second); } g_acc.clear(); }
-extern "C" int sfx_prof_get(const char* name, double* total_ms, int64_t* launches) {
+extern "C" int sfx_prof_enable(int32_t on) { g_prof = on & 1; g_unfused = (on >> 1) & 1; return 0; }
+extern "C" void sfx_prof_reset(void) { std::lock_guard<std::mutex> lk(g_prof_mu); for (auto& kv : g_acc) { prof_flush(kv.second); } g_acc.clear(); }
+extern "C" int sfx_prof_get(const char* name, double* total_ms, int64_t* launches, double* units) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     auto it = g_acc.find(name);
-    if (it == g_acc.end()) { if (total_ms) *total_ms = 0; if (launches) *launches = 0; return 0; }
+    if (it == g_acc.end()) { if (total_ms) *total_ms = 0; if (launches) *launches = 0; if (units) *units = 0; return 0; }
     prof_flush(it->second);
     if (total_ms) *total_ms = it->second.ms;
     if (launches) *launches = it->second.n;
+    if (units) *units = it->second.units;
     return (int)std::min<int64_t>(it->second.n, 1 << 30);
 }
 
@@ -96,6 +103,7 @@ struct sfx_batch {
     StageW* sw_dev = nullptr;     // [n_stages]
     VarList vl_host[2];
     int* stage_host = nullptr;    // pinned
+    std::vector<int> slot_host;
     int K = 0;
 };
 
@@ -397,6 +405,7 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.joints = b->mem.zeros<float>((size_t)B * K * 3);
     D.fullpose = b->mem.zeros<float>((size_t)B * SFX_POSE);
     D.stage = b->mem.zeros<int>(B);
+    { std::vector<int> id(B); for (int i = 0; i < B; ++i) id[i] = i; D.slot = b->mem.up(id); D.nact = B; }
     D.opt = b->mem.zeros<char>((size_t)B * sfx_optstate_size());
     D.vec = b->mem.zeros<float>((size_t)B * NVEC * SFX_NVAR_MAX);
     D.hist = b->mem.zeros<float>((size_t)B * 2 * SFX_HIST * SFX_NVAR_MAX);
@@ -525,7 +534,7 @@ static void eval_closure(sfx_batch* b, int stage_override, int from_X, hipStream
     if (D.cfg.lbs_mode == 1) {
         ClosureArgs e = a; e.export_dense = 1; e.forward_only = 2;
         { ProfScope p("export", s); launch_closure(M, D, b->vl_dev, b->sw_dev, e, s); }
-        { ProfScope p("lbs_dense", s); launch_lbs_dense(M, D, s); }
+        { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
         a.use_dense_verts = 1;
     }
     ProfScope p("closure", s);
@@ -588,27 +597,67 @@ extern "C" int sfx_batch_guess_init(sfx_batch* b, const int32_t* pairs, int32_t 
 
 // tick loop shared by sfx_batch_fit (whole run_fitting) and sfx_batch_step (one LBFGS.step)
 static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, int step_mode, hipStream_t s) {
-    const BatchDev& D = b->D; const DevModel& M = b->m->M;
+    BatchDev& D = b->D; const DevModel& M = b->m->M;
     const int B = D.cfg.B;
-    const int POLL = (D.cfg.lbs_mode == 1) ? 8 : 32;
+    const bool dense = D.cfg.lbs_mode == 1;
+    const bool fused = !step_mode && !g_unfused;
     launch_lbfgs_tick(M, D, b->vl_dev, first_stage, last_stage, init, step_mode, s);
-    const long max_ticks = (long)(last_stage - first_stage + 1) * D.cfg.maxiters * 80 + 64;
+    const long max_ticks = (long)(last_stage - first_stage + 1) * D.cfg.maxiters * 80 * 2 + 64;
     std::vector<int> hs(B);
     int* hp = b->stage_host ? b->stage_host : hs.data();
     long tick = 0;
     bool done = false;
+    if (fused && dense) { ProfScope p("tick", s); launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, s); }
     while (!done && tick < max_ticks) {
-        for (int q = 0; q < POLL; ++q, ++tick) {
-            eval_closure(b, -2, 0, s);
-            ProfScope p("lbfgs", s);
-            launch_lbfgs_tick(M, D, b->vl_dev, first_stage, last_stage, 0, step_mode, s);
+        if (fused && !dense) {
+            // persistent per-frame workgroups; the host only re-launches frames that need more ticks
+            const int chunk = 512;
+            { ProfScope p("fit_rows", s); launch_fit_rows(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, chunk, s); }
+            tick += chunk;
+        } else if (fused) {
+            for (int q = 0; q < 8; ++q, ++tick) {
+                { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
+                ProfScope p("tick", s);
+                launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 1, s);
+            }
+        } else {
+            const int POLL = dense ? 8 : 32;
+            for (int q = 0; q < POLL; ++q, ++tick) {
+                eval_closure(b, -2, 0, s);
+                ProfScope p("lbfgs", s);
+                launch_lbfgs_tick(M, D, b->vl_dev, first_stage, last_stage, 0, step_mode, s);
+            }
         }
         SFX_CHECK(hipMemcpyAsync(hp, D.stage, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
         SFX_CHECK(hipStreamSynchronize(s));
         done = true;
         for (int i = 0; i < B; ++i) if (hp[i] <= last_stage) { done = false; break; }
+        if (fused && dense && !done) {
+            // compaction: finished frames give up their GEMM columns.  The pending evaluation of
+            // every active frame lives in column slot[b] of featT/AT, so re-export after remapping.
+            int n = 0;
+            for (int i = 0; i < B; ++i) if (hp[i] <= last_stage) ++n;
+            if ((b->D.nact + 31) / 32 != (n + 31) / 32) {      // a 32-frame MFMA tile became free
+                std::vector<int>& sl = b->slot_host;
+                sl.assign(B, 0);
+                int q = 0;
+                for (int i = 0; i < B; ++i) sl[i] = (hp[i] <= last_stage) ? q++ : 0;
+                SFX_CHECK(hipMemcpyAsync(D.slot, sl.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
+                b->D.nact = n;
+                ProfScope p("tick", s);
+                launch_tick_dense(M, b->D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, s);   // re-export only
+            }
+        }
     }
     SFX_CHECK(hipGetLastError());
+    if (fused && dense) {       // restore the identity mapping for stand-alone calls
+        std::vector<int>& sl = b->slot_host;
+        sl.resize(B);
+        for (int i = 0; i < B; ++i) sl[i] = i;
+        SFX_CHECK(hipMemcpyAsync(D.slot, sl.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
+        SFX_CHECK(hipStreamSynchronize(s));
+        b->D.nact = B;
+    }
     if (!done) { sfx_set_error("fit did not finish within %ld ticks", max_ticks); return -4; }
     return 0;
 }
@@ -658,7 +707,7 @@ extern "C" int sfx_batch_forward(sfx_batch* b, float* verts_dev, float* joints_d
     const DevModel& M = b->m->M; const BatchDev& D = b->D;
     ClosureArgs e{}; e.stage_override = 0; e.export_dense = 1; e.forward_only = 2; e.from_X = 1;
     launch_closure(M, D, b->vl_dev, b->sw_dev, e, s);
-    { ProfScope p("lbs_dense", s); launch_lbs_dense(M, D, s); }
+    { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
     ClosureArgs a{}; a.stage_override = 0; a.forward_only = 1; a.from_X = 1; a.use_dense_verts = 1;
     launch_closure(M, D, b->vl_dev, b->sw_dev, a, s);
     const size_t nv = (size_t)D.cfg.B * M.V * 3 * 4, nj = (size_t)D.cfg.B * M.K * 3 * 4;

@@ -11,7 +11,8 @@ $HIPCC $FLAGS -c "$HERE/api.hip" -o "$HERE/obj/api.o" & pids+=($!)
 $HIPCC $FLAGS -c "$HERE/closure.hip" -o "$HERE/obj/closure.o" & pids+=($!)
 $HIPCC $FLAGS -c "$HERE/lbs_dense.hip" -o "$HERE/obj/lbs_dense.o" & pids+=($!)
 $HIPCC $FLAGS -ffp-contract=off -c "$HERE/lbfgs.hip" -o "$HERE/obj/lbfgs.o" & pids+=($!)
+$HIPCC $FLAGS -c "$HERE/fused.hip" -o "$HERE/obj/fused.o" & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsfx.so" "$HERE/obj/api.o" "$HERE/obj/closure.o" \
-    "$HERE/obj/lbs_dense.o" "$HERE/obj/lbfgs.o"
+    "$HERE/obj/lbs_dense.o" "$HERE/obj/lbfgs.o" "$HERE/obj/fused.o"
 echo "built $OUT/libsfx.so"

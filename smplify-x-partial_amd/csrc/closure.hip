@@ -1,647 +1,11 @@
-// closure.hip -- one workgroup per frame: SMPL-X forward on the needed rows, perspective
-// reprojection, GMoF / prior losses, and the hand-derived adjoint, all in LDS.
-//
-// Replaces one call of the reference's fitting closure (smplifyx/fitting.py:232-273):
-//   body_model(...)            external smplx.lbs.lbs         
-//   camera(joints)             smplifyx/camera.py:93-117
-//   SMPLifyLoss.forward        smplifyx/fitting.py:375-461
-//   SMPLifyCameraInitLoss      smplifyx/fitting.py:499-520
-//   total_loss.backward()      autograd -> explicit reverse sweep below
-//
-// Work decomposition (256 threads = 4 wavefronts of 64):
-//   pose assembly / Rodrigues / joint regression : one lane per output
-//   kinematic chain                              : one lane per joint, level by level
-//   needed vertices (<=225 "items")              : one wavefront per 506-long blend-shape
-//                                                  dot product, xor-shuffle reduction
-//   loss                                         : one lane per keypoint, fixed-order reduce
-//   reverse sweep                                : gathers only (no atomics) -> deterministic
-#include "sfx_internal.h"
-#include "wave_ops.h"
-
-#define CT 256
-#define FD_GT 0
-#define FD_CONF (2 * SFX_MAX_K)
-#define FD_JW (3 * SFX_MAX_K)
-#define FD_CMASK (4 * SFX_MAX_K)
-#define FD_CAM (5 * SFX_MAX_K)
-#define FD_CAMR (FD_CAM + 8)
-#define FD_REG (FD_CAMR + 12)
-#define FD_N (FD_REG + 64)
-// debug timing: block 0 / thread 0 stores the shader clock at phase boundaries when D.dbg != NULL
-#define MARK(i) do { if (D.dbg && blockIdx.x == 0 && threadIdx.x == 0) D.dbg[i] = clock64(); } while (0)
-
-struct __align__(16) FrameLDS {
-    float feat[SFX_KD_PAD];        // first: read as float4
-    float x[SFX_NPAR_MAX];
-    float full_pose[168];
-    float R[SFX_J * 9];
-    float Jr[SFX_J * 3];
-    float G[SFX_J * 12];
-    float A[SFX_J * 12];
-    float vp[SFX_MAX_ITEMS * 3];
-    float T[SFX_MAX_ITEMS * 12];
-    float vert[SFX_MAX_ITEMS * 3];
-    float dvert[SFX_MAX_ITEMS * 3];
-    float dvp[SFX_MAX_ITEMS * 3];
-    int   ivid[SFX_MAX_ITEMS];
-    float iw[SFX_MAX_ITEMS];
-    int   wj[SFX_MAX_ITEMS * SFX_NW];      // sparse skinning weights of the items
-    float ww[SFX_MAX_ITEMS * SFX_NW];
-    float joints[SFX_MAX_K * 3];
-    float dj[SFX_MAX_K * 3];
-    float dA[SFX_J * 12];
-    float dG[SFX_J * 12];
-    float drel[SFX_J * 3];
-    float dpj[SFX_J * 3];
-    float dJ[SFX_J * 3];
-    float dR[SFX_J * 9];
-    float dfeat[SFX_KD_PAD];
-    float dpose[168];
-    float gc[SFX_NPAR_MAX];
-    float red[CT];
-    float lh45[SFX_NHAND], rh45[SFX_NHAND];
-    float scal[16];
-    int   lut_row;
-    float fd[FD_N];             // this frame's keypoints / weights / camera / regression pose
-    int   meta[SFX_META_N];     // tree / joint-map tables (one coalesced load instead of
-                                // dependent global loads inside every level of the chain)
-};
-
-__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
-
-// fixed-order block reduction: DPP sum per wavefront, then the CT/64 partials in order
-// (2 barriers instead of a 9-barrier LDS tree); result in all threads
-__device__ __forceinline__ float block_sum(float v, float* red) {
-    const float w = wave_sum_dpp(v);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
-    __syncthreads();
-    float r = red[0];
-#pragma unroll
-    for (int i = 1; i < CT / 64; ++i) r += red[i];
-    __syncthreads();
-    return r;
-}
-
-// smplx.lbs.batch_rodrigues: angle = ||theta + 1e-8||, R = I + sin K + (1-cos) K K
-__device__ __forceinline__ void rodrigues_fwd(const float* th, float* R) {
-    const float ex = th[0] + 1e-8f, ey = th[1] + 1e-8f, ez = th[2] + 1e-8f;
-    const float a = sqrtf(ex * ex + ey * ey + ez * ez);
-    const float dx = th[0] / a, dy = th[1] / a, dz = th[2] / a;
-    const float s = sinf(a), c = cosf(a);
-    const float K[9] = {0.f, -dz, dy, dz, 0.f, -dx, -dy, dx, 0.f};
-    const float omc = 1.f - c;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            float kk = K[i * 3 + 0] * K[0 * 3 + j] + K[i * 3 + 1] * K[1 * 3 + j] + K[i * 3 + 2] * K[2 * 3 + j];
-            R[i * 3 + j] = ((i == j) ? 1.f : 0.f) + s * K[i * 3 + j] + omc * kk;
-        }
-}
-
-// reverse of rodrigues_fwd: dth += J^T dR
-__device__ __forceinline__ void rodrigues_bwd(const float* th, const float* dR, float* dth) {
-    const float ex = th[0] + 1e-8f, ey = th[1] + 1e-8f, ez = th[2] + 1e-8f;
-    const float a = sqrtf(ex * ex + ey * ey + ez * ez);
-    const float inv = 1.f / a;
-    const float d[3] = {th[0] * inv, th[1] * inv, th[2] * inv};
-    const float s = sinf(a), c = cosf(a), omc = 1.f - c;
-    const float K[9] = {0.f, -d[2], d[1], d[2], 0.f, -d[0], -d[1], d[0], 0.f};
-    float KK[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            KK[i * 3 + j] = K[i * 3 + 0] * K[j] + K[i * 3 + 1] * K[3 + j] + K[i * 3 + 2] * K[6 + j];
-    float dRK = 0.f, dRKK = 0.f;
-#pragma unroll
-    for (int e = 0; e < 9; ++e) { dRK += dR[e] * K[e]; dRKK += dR[e] * KK[e]; }
-    float da = c * dRK + s * dRKK;
-    // dK = s dR + (1-c) (dR K^T + K^T dR)
-    float dK[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                t1 += dR[i * 3 + k] * K[j * 3 + k];     // dR K^T
-                t2 += K[k * 3 + i] * dR[k * 3 + j];     // K^T dR
-            }
-            dK[i * 3 + j] = s * dR[i * 3 + j] + omc * (t1 + t2);
-        }
-    const float dd[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
-    const float ddth = dd[0] * th[0] + dd[1] * th[1] + dd[2] * th[2];
-    da -= ddth * inv * inv;
-    dth[0] += dd[0] * inv + da * ex * inv;
-    dth[1] += dd[1] * inv + da * ey * inv;
-    dth[2] += dd[2] * inv + da * ez * inv;
-}
-
-__device__ __forceinline__ float gmof_grad(float r, float rho2) {
-    // d/dr [ rho^2 r^2 / (r^2 + rho^2) ] = 2 r rho^4 / (r^2 + rho^2)^2
-    const float den = r * r + rho2;
-    return 2.f * r * (rho2 / den) * (rho2 / den);
-}
+// closure.hip -- stand-alone launch of the per-frame closure (see closure_body.h).
+#include "closure_body.h"
 
 __global__ __launch_bounds__(CT)
 void k_closure(DevModel M, BatchDev D, const VarList* __restrict__ vls, const StageW* __restrict__ sws,
                ClosureArgs args) {
     __shared__ FrameLDS S;
-    const int b = blockIdx.x;
-    const int t = threadIdx.x;
-    const int lane = t & 63, wv = t >> 6;
-    const ParLayout& L = D.L;
-    const BatchCfgDev& C = D.cfg;
-
-    int stage = (args.stage_override != -2) ? args.stage_override : D.stage[b];
-    if (stage >= C.n_stages && !args.forward_only) return;      // frame finished
-    const bool cam_stage = (stage < 0);
-
-    MARK(0);
-    // ------------------------------------------------------------------ load parameters
-    const float* xsrc = (args.from_X ? D.X : D.Xt) + (size_t)b * SFX_NPAR_MAX;
-    for (int i = t; i < L.npar; i += CT) S.x[i] = xsrc[i];
-    for (int i = t; i < SFX_META_N; i += CT) S.meta[i] = M.meta[i];
-    {   // per-frame data -> LDS (one coalesced pass instead of dependent global loads later)
-        const int K_ = M.K;
-        for (int i = t; i < 2 * K_; i += CT) S.fd[FD_GT + i] = D.gt[(size_t)b * K_ * 2 + i];
-        for (int i = t; i < K_; i += CT) { S.fd[FD_CONF + i] = D.conf[(size_t)b * K_ + i]; S.fd[FD_JW + i] = D.jw[(size_t)b * K_ + i];
-                                           S.fd[FD_CMASK + i] = D.cmask[(size_t)b * K_ + i]; }
-        if (t < 8) S.fd[FD_CAM + t] = D.cam[(size_t)b * 8 + t];
-        if (t >= 64 && t < 73) S.fd[FD_CAMR + t - 64] = D.camR[(size_t)b * 9 + t - 64];
-        if (t >= 128 && t < 128 + 63) S.fd[FD_REG + t - 128] = D.regpose[(size_t)b * 63 + t - 128];
-    }
-    for (int i = t; i < SFX_KD_PAD; i += CT) { S.feat[i] = 0.f; S.dfeat[i] = 0.f; }
-    for (int i = t; i < SFX_NPAR_MAX; i += CT) S.gc[i] = 0.f;
-    for (int i = t; i < 168; i += CT) S.dpose[i] = 0.f;
-    __syncthreads();
-    const float* bodypose = C.use_vposer ? (D.bodypose + (size_t)b * 63) : (S.x + L.emb);
-
-    MARK(1);
-    // ------------------------------------------------------------------ pose assembly
-    if (t < SFX_POSE) {
-        float v;
-        if (t < 3) v = S.x[L.go + t];
-        else if (t < 66) v = bodypose[t - 3];
-        else if (t < 69) v = S.x[L.jaw + t - 66];
-        else if (t < 72) v = S.x[L.leye + t - 69];
-        else if (t < 75) v = S.x[L.reye + t - 72];
-        else {
-            const bool left = t < 120;
-            const int c = left ? t - 75 : t - 120;
-            const float* comp = left ? M.comp_l : M.comp_r;
-            const float* pc = S.x + (left ? L.lh : L.rh);
-            v = 0.f;
-            for (int i = 0; i < L.NPCA; ++i) v += pc[i] * comp[i * SFX_NHAND + c];
-            if (left) S.lh45[c] = v; else S.rh45[c] = v;
-        }
-        S.full_pose[t] = v + M.pose_mean[t];
-    }
-    if (t < M.S) S.feat[t] = (t < L.NB) ? S.x[L.betas + t] : S.x[L.expr + t - L.NB];
-    __syncthreads();
-
-    MARK(2);
-    // ------------------------------------------------------------------ Rodrigues, rest joints
-    if (t < SFX_J) {
-        float R[9];
-        rodrigues_fwd(&S.full_pose[3 * t], R);
-#pragma unroll
-        for (int e = 0; e < 9; ++e) S.R[t * 9 + e] = R[e];
-        if (t > 0) {
-#pragma unroll
-            for (int e = 0; e < 9; ++e)
-                S.feat[M.S + 9 * (t - 1) + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
-        }
-    } else if (t >= 64 && t < 64 + SFX_J * 3) {
-        const int i = t - 64;
-        float v = M.J_template[i];
-        const float* jd = M.J_dirs + (size_t)i * M.S;
-        for (int l = 0; l < M.S; ++l) v += jd[l] * S.feat[l];
-        S.Jr[i] = v;
-    }
-    __syncthreads();
-
-    MARK(3);
-    // ------------------------------------------------------------------ kinematic chain
-    // one lane per (joint of the level, matrix element): 12 lanes per joint, <=10 joints per level
-    for (int lev = 0; lev < M.n_levels; ++lev) {
-        const int i0 = M.level_start[lev], n = M.level_start[lev + 1] - i0;
-        const int jn = t / 12, e = t % 12;
-        if (jn < n) {
-            const int j = S.meta[MO_LJ + i0 + jn];
-            const int p = S.meta[MO_PAR + j];
-            const int r = e >> 2, c = e & 3;
-            const float* Rj = &S.R[j * 9];
-            float v;
-            if (p < 0) v = (c < 3) ? Rj[r * 3 + c] : S.Jr[j * 3 + r];
-            else {
-                const float* Gp = &S.G[p * 12 + r * 4];
-                if (c < 3) v = Gp[0] * Rj[c] + Gp[1] * Rj[3 + c] + Gp[2] * Rj[6 + c];
-                else v = Gp[0] * (S.Jr[j * 3] - S.Jr[p * 3]) + Gp[1] * (S.Jr[j * 3 + 1] - S.Jr[p * 3 + 1]) +
-                         Gp[2] * (S.Jr[j * 3 + 2] - S.Jr[p * 3 + 2]) + Gp[3];
-            }
-            S.G[j * 12 + e] = v;
-        }
-        __syncthreads();
-    }
-    if (t < SFX_J) {
-        const float* Gj = &S.G[t * 12];
-        float* Aj = &S.A[t * 12];
-        const float* Jj = &S.Jr[t * 3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            Aj[r * 4 + 0] = Gj[r * 4 + 0]; Aj[r * 4 + 1] = Gj[r * 4 + 1]; Aj[r * 4 + 2] = Gj[r * 4 + 2];
-            Aj[r * 4 + 3] = Gj[r * 4 + 3] - (Gj[r * 4 + 0] * Jj[0] + Gj[r * 4 + 1] * Jj[1] + Gj[r * 4 + 2] * Jj[2]);
-        }
-    }
-    // dynamic-contour LUT row (smplx find_dynamic_lmk_idx_and_bcoords; no gradient)
-    if (t == CT - 1) {
-        int row = 0;
-        if (M.n_dyn > 0) {
-            float rel[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-            const int chain[5] = {12, 9, 6, 3, 0};
-            for (int q = 0; q < 5; ++q) {
-                const float* Rk = &S.R[chain[q] * 9];
-                float o[9];
-                for (int i = 0; i < 3; ++i)
-                    for (int j = 0; j < 3; ++j)
-                        o[i * 3 + j] = Rk[i * 3] * rel[j] + Rk[i * 3 + 1] * rel[3 + j] + Rk[i * 3 + 2] * rel[6 + j];
-                for (int e = 0; e < 9; ++e) rel[e] = o[e];
-            }
-            const float sy = sqrtf(rel[0] * rel[0] + rel[3] * rel[3]);
-            const float ang = atan2f(-rel[6], sy);
-            float deg = (-ang) * 180.0f / 3.14159265358979323846f;
-            deg = fminf(deg, 39.f);
-            const int y = (int)rintf(deg);
-            row = (y < -39) ? 78 : ((y < 0) ? (39 - y) : y);
-        }
-        S.lut_row = row;
-    }
-    __syncthreads();
-
-    MARK(4);
-    // ------------------------------------------------------------------ dense export
-    if (args.export_dense) {
-        for (int k = t; k < M.KD; k += CT) D.featT[(size_t)k * D.Bpad + b] = S.feat[k];
-        for (int i = t; i < SFX_J * 12; i += CT) {
-            const int j = i / 12, e = i % 12;
-            D.AT[((size_t)e * SFX_JPAD + j) * D.Bpad + b] = S.A[i];
-        }
-        if (args.forward_only == 2) return;     // export pass only
-    }
-
-    MARK(5);
-    // ------------------------------------------------------------------ needed vertices
-    const int NI = M.n_items;
-    for (int i = t; i < NI; i += CT) {
-        const int dd = M.item_dyn[i];
-        if (dd < 0) { S.ivid[i] = M.item_vid[i]; S.iw[i] = M.item_w[i]; }
-        else {
-            const int l = dd / 3, c = dd % 3;
-            const int face = M.dyn_faces[S.lut_row * M.n_dyn + l];
-            S.ivid[i] = M.faces[face * 3 + c];
-            S.iw[i] = M.dyn_bary[(S.lut_row * M.n_dyn + l) * 3 + c];
-        }
-    }
-    __syncthreads();
-    // v_posed rows: one wavefront per (item, coord) dot product of length KD_PAD
-    {
-        const float4* f4 = reinterpret_cast<const float4*>(S.feat);
-        const float4 fa = f4[lane], fb = f4[64 + lane];
-        // 4 rows per wavefront per pass: 8 independent 1-KiB loads in flight before the reductions
-        for (int w0 = wv * 4; w0 < NI * 3; w0 += (CT / 64) * 4) {
-            float4 da[4], db[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int w = (w0 + u < NI * 3) ? w0 + u : w0;
-                const int v = S.ivid[w / 3];
-                const float4* row = reinterpret_cast<const float4*>(M.dirsT + ((size_t)v * 3 + w % 3) * SFX_KD_PAD);
-                da[u] = row[lane]; db[u] = row[64 + lane];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int w = w0 + u;
-                float acc = fa.x * da[u].x + fa.y * da[u].y + fa.z * da[u].z + fa.w * da[u].w +
-                            fb.x * db[u].x + fb.y * db[u].y + fb.z * db[u].z + fb.w * db[u].w;
-                acc = wave_sum(acc);
-                if (lane == 0 && w < NI * 3) S.vp[w] = M.v_template[S.ivid[w / 3] * 3 + w % 3] + acc;
-            }
-        }
-    }
-    MARK(6);
-    // skinning transforms of the items
-    // (sparse rows of lbs_weights: <= SFX_NW nonzeros per vertex, ascending joint order, so the
-    //  sum visits the same nonzero terms in the same order as the dense product)
-    for (int w = t; w < NI * SFX_NW; w += CT) {
-        const int i = w / SFX_NW, q2 = w % SFX_NW;
-        S.wj[w] = M.Wsp_j[(size_t)S.ivid[i] * SFX_NW + q2];
-        S.ww[w] = M.Wsp_w[(size_t)S.ivid[i] * SFX_NW + q2];
-    }
-    __syncthreads();
-    for (int w = t; w < NI * 12; w += CT) {
-        const int i = w / 12, e = w % 12;
-        float acc = 0.f;
-#pragma unroll
-        for (int q2 = 0; q2 < SFX_NW; ++q2) {
-            const float wq = S.ww[i * SFX_NW + q2];
-            if (wq != 0.f) acc += wq * S.A[S.wj[i * SFX_NW + q2] * 12 + e];
-        }
-        S.T[w] = acc;
-    }
-    __syncthreads();
-    for (int w = t; w < NI * 3; w += CT) {
-        const int i = w / 3, r = w % 3;
-        const float* Ti = &S.T[i * 12 + r * 4];
-        const float* vp = &S.vp[i * 3];
-        float v = Ti[0] * vp[0] + Ti[1] * vp[1] + Ti[2] * vp[2] + Ti[3];
-        if (args.use_dense_verts) v = D.verts[((size_t)b * M.V + S.ivid[i]) * 3 + r];
-        S.vert[w] = v;
-    }
-    __syncthreads();
-
-    MARK(7);
-    // ------------------------------------------------------------------ mapped joints
-    const int K = M.K;
-    for (int w = t; w < K * 3; w += CT) {
-        const int k = w / 3, r = w % 3;
-        float v;
-        if (S.meta[MO_JT + k] == 0) v = S.G[S.meta[MO_JS + k] * 12 + r * 4 + 3];
-        else {
-            v = 0.f;
-            const int i0 = S.meta[MO_JI0 + k], n = S.meta[MO_JN + k];
-            if (n == 1 && S.iw[i0] == 1.f) v = S.vert[i0 * 3 + r];
-            else for (int i = 0; i < n; ++i) v += S.vert[(i0 + i) * 3 + r] * S.iw[i0 + i];
-        }
-        S.joints[w] = v;
-    }
-    __syncthreads();
-    if (args.forward_only) {
-        if (D.joints) for (int w = t; w < K * 3; w += CT) D.joints[(size_t)b * K * 3 + w] = S.joints[w];
-        if (D.fullpose) for (int w = t; w < SFX_POSE; w += CT) D.fullpose[(size_t)b * SFX_POSE + w] = S.full_pose[w];
-        return;
-    }
-
-    MARK(8);
-    // ------------------------------------------------------------------ losses
-    // per-frame data was prefetched into LDS (S.fd) at kernel entry; all sums of this section go
-    // through ONE fixed-order reduction (DPP per wavefront, then 4 partials): 2 barriers in total
-    const float* fd = S.fd;
-    const float fx = fd[FD_CAM + 0], fy = fd[FD_CAM + 1], cx = fd[FD_CAM + 2], cy = fd[FD_CAM + 3];
-    const float dwt = fd[FD_CAM + 4], est_tz = fd[FD_CAM + 5];
-    const float* Rc = fd + FD_CAMR;
-    const float* ct = S.x + L.cam_t;
-    const float dw2 = dwt * dwt;
-    const float rho2 = C.rho * C.rho;
-    const StageW sw = cam_stage ? StageW{} : sws[stage];
-
-    float csum = 1.f;
-    if (cam_stage && C.use_conf_cam) {
-        float p = 0.f;
-        if (t < K) { const float cm = fd[FD_CMASK + t]; const float cf = fd[FD_CONF + t]; p = (cm != 0.f) ? cf * cf : 0.f; }
-        csum = block_sum(p, S.red);
-    }
-    enum { Q_L = 0, Q_D0, Q_D1, Q_D2, Q_PP, Q_SH, Q_ANG, Q_LH, Q_RH, Q_EX, Q_JW, NQ };
-    float q[NQ];
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) q[i] = 0.f;
-    if (t < K) {
-        const float* p = &S.joints[t * 3];
-        const float pcx = Rc[0] * p[0] + Rc[1] * p[1] + Rc[2] * p[2] + ct[0];
-        const float pcy = Rc[3] * p[0] + Rc[4] * p[1] + Rc[5] * p[2] + ct[1];
-        const float pcz = Rc[6] * p[0] + Rc[7] * p[1] + Rc[8] * p[2] + ct[2];
-        const float ix = pcx / pcz, iy = pcy / pcz;
-        const float u = fx * ix + cx, v = fy * iy + cy;
-        const float rx = fd[FD_GT + 2 * t] - u, ry = fd[FD_GT + 2 * t + 1] - v;
-        float du, dv;       // dL/du, dL/dv
-        if (cam_stage) {
-            if (fd[FD_CMASK + t] != 0.f) {
-                q[Q_L] = rx * rx + ry * ry;
-                du = -2.f * rx * csum * dw2; dv = -2.f * ry * csum * dw2;
-            } else { du = 0.f; dv = 0.f; }
-        } else {
-            float w = fd[FD_JW + t];
-            if (t >= C.nbj) w = (t < C.nbj + 42) ? ((w != 0.f) ? sw.hand_jw : 0.f) : ((w != 0.f) ? sw.face_jw : 0.f);
-            if (C.use_conf) w *= fd[FD_CONF + t];
-            const float w2 = w * w;
-            if (w2 != 0.f) {
-                const float sx = rx * rx, sy = ry * ry;
-                const float gmx = rho2 * (sx / (sx + rho2)), gmy = rho2 * (sy / (sy + rho2));
-                q[Q_L] = w2 * gmx + w2 * gmy;
-                du = -(w2 * dw2) * gmof_grad(rx, rho2);
-                dv = -(w2 * dw2) * gmof_grad(ry, rho2);
-            } else { du = 0.f; dv = 0.f; }
-        }
-        const float dix = du * fx, diy = dv * fy;
-        const float d0 = dix / pcz, d1 = diy / pcz, d2 = -(dix * pcx + diy * pcy) / (pcz * pcz);
-        q[Q_D0] = d0; q[Q_D1] = d1; q[Q_D2] = d2;
-        S.dj[t * 3 + 0] = Rc[0] * d0 + Rc[3] * d1 + Rc[6] * d2;
-        S.dj[t * 3 + 1] = Rc[1] * d0 + Rc[4] * d1 + Rc[7] * d2;
-        S.dj[t * 3 + 2] = Rc[2] * d0 + Rc[5] * d1 + Rc[8] * d2;
-    }
-    const float bpw2 = sw.bpw * sw.bpw, sw2 = sw.sw * sw.sw, h2 = sw.hpw * sw.hpw, e2 = sw.epw * sw.epw;
-    if (!cam_stage) {
-        const bool latent_reg = C.use_vposer ? (stage + 1 == C.n_stages && C.has_reg) : (C.has_reg != 0);
-        if (t < L.NEMB) {       // pose prior on the embedding (fitting.py:390-401)
-            const float e = S.x[L.emb + t];
-            const float dlt = latent_reg ? (e - fd[FD_REG + t]) : e;
-            q[Q_PP] = dlt * dlt;
-            S.gc[L.emb + t] = 2.f * dlt * bpw2;
-        }
-        if (t < L.NB) { const float bt = S.x[L.betas + t]; q[Q_SH] = bt * bt; S.gc[L.betas + t] = 2.f * bt * sw2; }
-        if (t < 4) {            // angle prior: exp(pose[idx]*sign)^2 * bending weight (prior.py:73-89)
-            const int idx = (t == 0) ? 52 : (t == 1) ? 55 : (t == 2) ? 9 : 12;
-            const float sg = (t == 0) ? 1.f : -1.f;
-            const float e = expf(S.full_pose[3 + idx] * sg);
-            q[Q_ANG] = e * e;
-            S.dpose[3 + idx] = 2.f * (e * e) * sg * sw.bend;
-        }
-        if (C.use_hands && t < SFX_NHAND) {
-            q[Q_LH] = S.lh45[t] * S.lh45[t]; q[Q_RH] = S.rh45[t] * S.rh45[t];
-            S.dpose[75 + t] = 2.f * S.lh45[t] * h2; S.dpose[120 + t] = 2.f * S.rh45[t] * h2;
-        }
-        if (C.use_face) {
-            if (t < L.NE) { const float ev = S.x[L.expr + t]; q[Q_EX] = ev * ev; S.gc[L.expr + t] = 2.f * ev * e2; }
-            if (t < 3) { const float jv = S.x[L.jaw + t] * sw.jaw[t]; q[Q_JW] = jv * jv; S.gc[L.jaw + t] = 2.f * jv * sw.jaw[t]; }
-        }
-    }
-    {
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const float w = wave_sum_dpp(q[i]);
-            if (lane == 0) S.red[wv * NQ + i] = w;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            float r = S.red[i];
-#pragma unroll
-            for (int w = 1; w < CT / 64; ++w) r += S.red[w * NQ + i];
-            q[i] = r;
-        }
-    }
-    float total;
-    if (cam_stage) {
-        float joint = q[Q_L];
-        if (C.use_conf_cam) joint *= csum;
-        joint *= dw2;
-        const float dz = ct[2] - est_tz;
-        float depth = 0.f;
-        if (C.depth_w > 0.f) depth = (C.depth_w * C.depth_w) * (dz * dz);
-        total = joint + depth;
-        if (t < 3) {
-            float g = (t == 0) ? q[Q_D0] : (t == 1) ? q[Q_D1] : q[Q_D2];
-            if (t == 2 && C.depth_w > 0.f) g += (C.depth_w * C.depth_w) * 2.f * dz;
-            S.gc[L.cam_t + t] = g;
-        }
-    } else {
-        total = q[Q_L] * dw2 + q[Q_PP] * bpw2 + q[Q_SH] * sw2 + q[Q_ANG] * sw.bend;
-        if (C.use_face) total = total + q[Q_JW] + q[Q_EX] * e2;
-        if (C.use_hands) total = total + q[Q_LH] * h2 + q[Q_RH] * h2;
-        if (t < 3) S.gc[L.cam_t + t] = (t == 0) ? q[Q_D0] : (t == 1) ? q[Q_D1] : q[Q_D2];
-    }
-    __syncthreads();
-
-    MARK(9);
-    // ------------------------------------------------------------------ reverse sweep
-    // d joints -> items / kinematic joints
-    for (int w = t; w < NI * 3; w += CT) {
-        const int i = w / 3, r = w % 3;
-        S.dvert[w] = S.dj[S.meta[MO_IK + i] * 3 + r] * S.iw[i];
-    }
-    __syncthreads();
-    for (int w = t; w < NI * 3; w += CT) {
-        const int i = w / 3, c = w % 3;
-        S.dvp[w] = S.T[i * 12 + 0 + c] * S.dvert[i * 3] + S.T[i * 12 + 4 + c] * S.dvert[i * 3 + 1] +
-                   S.T[i * 12 + 8 + c] * S.dvert[i * 3 + 2];
-    }
-    __syncthreads();
-    MARK(10);
-    // dA[j][e] = sum_items W[v][j] * dT[e]: per-joint item lists (CSR built at model creation,
-    // one per dynamic-contour LUT row), visited in ascending item order -> deterministic
-    for (int w = t; w < SFX_J * 12; w += CT) {
-        const int j = w / 12, e = w % 12, r = e >> 2, c = e & 3;
-        float acc = 0.f;
-        for (int pass = 0; pass < 2; ++pass) {
-            const int* st = pass ? (M.dj_start + (size_t)S.lut_row * (SFX_J + 1)) : M.sj_start;
-            const int* it = pass ? M.dj_item : M.sj_item;
-            const float* wt = pass ? M.dj_w : M.sj_w;
-            if (pass && M.n_dyn_items == 0) break;
-            for (int q2 = st[j]; q2 < st[j + 1]; ++q2) {
-                const int i = it[q2];
-                const float dv = S.dvert[i * 3 + r];
-                if (dv != 0.f) acc += wt[q2] * (dv * (c < 3 ? S.vp[i * 3 + c] : 1.f));
-            }
-        }
-        S.dA[w] = acc;
-    }
-    MARK(11);
-    // dfeat[k] = sum_items sum_c dirsT[v][c][k] * dvp[c]
-    for (int k = t; k < M.KD; k += CT) {
-        float acc = 0.f;
-        for (int i = 0; i < NI; ++i) {
-            const float d0 = S.dvp[i * 3], d1 = S.dvp[i * 3 + 1], d2 = S.dvp[i * 3 + 2];
-            if (d0 == 0.f && d1 == 0.f && d2 == 0.f) continue;
-            const float* row = M.dirsT + (size_t)S.ivid[i] * 3 * SFX_KD_PAD + k;
-            acc += row[0] * d0 + row[SFX_KD_PAD] * d1 + row[2 * SFX_KD_PAD] * d2;
-        }
-        S.dfeat[k] = acc;
-    }
-    __syncthreads();
-    MARK(12);
-    // kinematic chain, deepest level first; parents gather from their children (no atomics).
-    // pass 0: posed-joint adjoints; pass 1 (per level): dG, one lane per matrix element;
-    // pass 2 (all joints at once): dR, d(rel); pass 3: dJ.
-    for (int w = t; w < SFX_J * 3; w += CT) {
-        const int j = w / 3, r = w % 3;
-        float acc = 0.f;
-        for (int q2 = S.meta[MO_SK0 + j]; q2 < S.meta[MO_SK0 + j + 1]; ++q2) acc += S.dj[S.meta[MO_SKL + q2] * 3 + r];
-        S.dpj[w] = acc;
-    }
-    __syncthreads();
-    for (int lev = M.n_levels - 1; lev >= 0; --lev) {
-        const int i0 = M.level_start[lev], n = M.level_start[lev + 1] - i0;
-        const int jn = t / 12, e = t % 12;
-        if (jn < n) {
-            const int j = S.meta[MO_LJ + i0 + jn];
-            const int r = e >> 2, c = e & 3;
-            const float dat = S.dA[j * 12 + r * 4 + 3];
-            float v = (c < 3) ? (S.dA[j * 12 + e] - dat * S.Jr[j * 3 + c]) : (dat + S.dpj[j * 3 + r]);
-            for (int q2 = S.meta[MO_CS + j]; q2 < S.meta[MO_CS + j + 1]; ++q2) {
-                const int ch = S.meta[MO_CL + q2];
-                const float* dGc = &S.dG[ch * 12 + r * 4];
-                if (c < 3) {
-                    const float* Rch = &S.R[ch * 9 + c * 3];
-                    v += dGc[0] * Rch[0] + dGc[1] * Rch[1] + dGc[2] * Rch[2] + dGc[3] * (S.Jr[ch * 3 + c] - S.Jr[j * 3 + c]);
-                } else v += dGc[3];
-            }
-            S.dG[j * 12 + e] = v;
-        }
-        __syncthreads();
-    }
-    for (int w = t; w < SFX_J * 12; w += CT) {
-        const int j = w / 12, e = w % 12;
-        const int p = S.meta[MO_PAR + j];
-        const float* dGj = &S.dG[j * 12];
-        if (e < 9) {
-            const int r = e / 3, c = e % 3;
-            float v;
-            if (p < 0) v = dGj[r * 4 + c];
-            else { const float* Gp = &S.G[p * 12]; v = Gp[0 + r] * dGj[0 + c] + Gp[4 + r] * dGj[4 + c] + Gp[8 + r] * dGj[8 + c]; }
-            if (j > 0) v += S.dfeat[M.S + 9 * (j - 1) + e];
-            S.dR[j * 9 + e] = v;
-        } else {
-            const int r = e - 9;
-            float v;
-            if (p < 0) v = dGj[r * 4 + 3];
-            else { const float* Gp = &S.G[p * 12]; v = Gp[0 + r] * dGj[3] + Gp[4 + r] * dGj[7] + Gp[8 + r] * dGj[11]; }
-            S.drel[j * 3 + r] = v;
-        }
-    }
-    __syncthreads();
-    for (int w = t; w < SFX_J * 3; w += CT) {
-        const int j = w / 3, c = w % 3;
-        float v = -(S.G[j * 12 + 0 + c] * S.dA[j * 12 + 3] + S.G[j * 12 + 4 + c] * S.dA[j * 12 + 7] +
-                    S.G[j * 12 + 8 + c] * S.dA[j * 12 + 11]);
-        for (int q2 = S.meta[MO_CS + j]; q2 < S.meta[MO_CS + j + 1]; ++q2) v -= S.drel[S.meta[MO_CL + q2] * 3 + c];
-        S.dJ[w] = v + S.drel[w];
-    }
-    __syncthreads();
-    MARK(13);
-    // Rodrigues adjoint -> dpose ; joint regression adjoint -> shape coefficients
-    if (t < SFX_J) {
-        float dth[3] = {0.f, 0.f, 0.f};
-        rodrigues_bwd(&S.full_pose[3 * t], &S.dR[t * 9], dth);
-        S.dpose[3 * t] += dth[0]; S.dpose[3 * t + 1] += dth[1]; S.dpose[3 * t + 2] += dth[2];
-    } else if (t >= 64 && t < 64 + M.S) {
-        const int l = t - 64;
-        float acc = S.dfeat[l];
-        for (int i = 0; i < SFX_J * 3; ++i) acc += M.J_dirs[(size_t)i * M.S + l] * S.dJ[i];
-        if (l < L.NB) S.gc[L.betas + l] += acc; else S.gc[L.expr + l - L.NB] += acc;
-    }
-    __syncthreads();
-    MARK(14);
-    // dpose -> canonical parameters
-    if (t < 3) { S.gc[L.go + t] += S.dpose[t]; S.gc[L.jaw + t] += S.dpose[66 + t];
-                 S.gc[L.leye + t] += S.dpose[69 + t]; S.gc[L.reye + t] += S.dpose[72 + t]; }
-    if (!C.use_vposer && t >= 64 && t < 64 + 63) S.gc[L.emb + t - 64] += S.dpose[3 + t - 64];
-    if (t >= 128 && t < 128 + 2 * L.NPCA) {
-        const int q = t - 128; const bool left = q < L.NPCA; const int i = left ? q : q - L.NPCA;
-        const float* comp = (left ? M.comp_l : M.comp_r) + i * SFX_NHAND;
-        const float* dp = &S.dpose[left ? 75 : 120];
-        float acc = 0.f;
-        for (int c = 0; c < SFX_NHAND; ++c) acc += comp[c] * dp[c];
-        S.gc[(left ? L.lh : L.rh) + i] += acc;
-    }
-    __syncthreads();
-    MARK(15);
-    // TODO(vposer): body-pose adjoint through the VPoser decoder is applied by k_vposer_bwd.
-    const VarList& vl = vls[cam_stage ? 0 : 1];
-    float* gout = D.g + (size_t)b * SFX_NVAR_MAX;
-    for (int i = t; i < vl.n; i += CT) gout[i] = S.gc[vl.idx[i]];
-    if (t == 0) D.f[b] = total;
-    MARK(16);
+    closure_body(S, M, D, vls, sws, args, blockIdx.x, nullptr, nullptr);
 }
 
 void launch_closure(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,

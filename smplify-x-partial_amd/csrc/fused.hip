@@ -1,0 +1,66 @@
+// fused.hip -- the fitting loop with as few launches as the data dependencies allow.
+//
+//  k_fit_rows   (needed-rows LBS): ONE workgroup per frame runs that frame's whole schedule
+//               -- closure (256 threads) -> optimiser tick (wavefront 0) -> closure -> ... --
+//               without returning to the host: no launch latency, no lock-step between frames;
+//               workgroups of finished frames retire and queued frames take their CU.
+//  k_tick_dense (dense LBS): between two launches of the batched MFMA GEMM (lbs_dense.hip) one
+//               launch does [loss + adjoint of evaluation i] -> [optimiser tick] -> [pose
+//               assembly / kinematic chain of evaluation i+1 and its export to the GEMM operands].
+#include "closure_body.h"
+#include "lbfgs_body.h"
+
+__global__ __launch_bounds__(CT)
+void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const StageW* __restrict__ sws,
+                int first_stage, int last_stage, int max_ticks) {
+    __shared__ FrameLDS S;
+    __shared__ float gflat[SFX_NVAR_MAX];
+    __shared__ float fval;
+    __shared__ float s_al[SFX_HIST];
+    __shared__ OptScal st;
+    const int b = blockIdx.x;
+    ClosureArgs a{};
+    a.stage_override = -2;
+    for (int it = 0; it < max_ticks; ++it) {
+        if (D.stage[b] > last_stage) break;
+        closure_body(S, M, D, vls, sws, a, b, gflat, &fval);
+        __syncthreads();
+        if (threadIdx.x < 64)
+            lbfgs_tick_body(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, &fval, gflat);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(CT)
+void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const StageW* __restrict__ sws,
+                  int first_stage, int last_stage, int has_eval) {
+    __shared__ FrameLDS S;
+    __shared__ float gflat[SFX_NVAR_MAX];
+    __shared__ float fval;
+    __shared__ float s_al[SFX_HIST];
+    __shared__ OptScal st;
+    const int b = blockIdx.x;
+    if (D.stage[b] > last_stage) return;
+    if (has_eval) {
+        ClosureArgs a{};
+        a.stage_override = -2; a.use_dense_verts = 1;
+        closure_body(S, M, D, vls, sws, a, b, gflat, &fval);
+        __syncthreads();
+        if (threadIdx.x < 64)
+            lbfgs_tick_body(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, &fval, gflat);
+        __syncthreads();
+        if (D.stage[b] > last_stage) return;
+    }
+    ClosureArgs e{};
+    e.stage_override = -2; e.export_dense = 1; e.forward_only = 2;
+    closure_body(S, M, D, vls, sws, e, b, nullptr, nullptr);
+}
+
+void launch_fit_rows(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
+                     int first_stage, int last_stage, int max_ticks, hipStream_t s) {
+    hipLaunchKernelGGL(k_fit_rows, dim3(D.cfg.B), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, max_ticks);
+}
+void launch_tick_dense(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
+                       int first_stage, int last_stage, int has_eval, hipStream_t s) {
+    hipLaunchKernelGGL(k_tick_dense, dim3(D.cfg.B), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
+}

@@ -1,0 +1,591 @@
+// lbfgs.hip -- batched on-device optimiser: one wavefront per frame advances that frame's
+// run_fitting / L-BFGS / strong-Wolfe state machine by ONE closure evaluation per launch.
+//
+// Replaces (per frame, with all Python-side control flow moved on device):
+//   FittingMonitor.run_fitting        smplifyx/fitting.py:147-217
+//   LBFGS.step                        smplifyx/optimizers/lbfgs_ls.py:256-445
+//   _strong_Wolfe / _cubic_interpolate smplifyx/optimizers/lbfgs_ls.py:11-167
+//   per-stage optimiser re-creation   smplifyx/fit_single_frame.py:553-564
+// The specification is oracle/lbfgs_machine.py (same transitions, same rounding rule).
+//
+// The reference mixes Python floats (double) and 0-d float32 tensors; PyTorch computes in
+// float32 whenever a tensor takes part.  `Sc` carries that distinction so that every
+// branch is decided on identically rounded numbers.  Compile with -ffp-contract=off: the
+// only fused multiply-adds are the explicit fmaf() of the axpy updates (ATen's
+// add_(alpha) vector path).
+#pragma once
+#include "sfx_internal.h"
+#include "wave_ops.h"
+// every multiply-add in this file is written out: no implicit contraction (see header comment)
+#pragma clang fp contract(off)
+// single-wavefront synchronisation: order LDS/global accesses of the 64 lanes
+#define LB_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+enum { PH_ENTRY = 0, PH_BRACKET = 1, PH_ZOOM = 2 };
+enum { A_NONE = 0, A_ENTRY, A_ITER_HEAD, A_ZOOM_NEXT, A_FINISH_LS, A_END_STEP, A_FINISH_STAGE };
+
+struct Sc { double v; int t; };
+__device__ __forceinline__ Sc P(double v) { Sc s; s.v = v; s.t = 0; return s; }
+__device__ __forceinline__ Sc T(float v) { Sc s; s.v = (double)v; s.t = 1; return s; }
+__device__ __forceinline__ Sc sc_add(Sc a, Sc b) { return (a.t | b.t) ? T((float)a.v + (float)b.v) : P(a.v + b.v); }
+__device__ __forceinline__ Sc sc_sub(Sc a, Sc b) { return (a.t | b.t) ? T((float)a.v - (float)b.v) : P(a.v - b.v); }
+__device__ __forceinline__ Sc sc_mul(Sc a, Sc b) { return (a.t | b.t) ? T((float)a.v * (float)b.v) : P(a.v * b.v); }
+__device__ __forceinline__ Sc sc_div(Sc a, Sc b) { return (a.t | b.t) ? T((float)a.v / (float)b.v) : P(a.v / b.v); }
+__device__ __forceinline__ bool sc_lt(Sc a, Sc b) { return (a.t | b.t) ? ((float)a.v < (float)b.v) : (a.v < b.v); }
+__device__ __forceinline__ bool sc_le(Sc a, Sc b) { return (a.t | b.t) ? ((float)a.v <= (float)b.v) : (a.v <= b.v); }
+__device__ __forceinline__ bool sc_gt(Sc a, Sc b) { return (a.t | b.t) ? ((float)a.v > (float)b.v) : (a.v > b.v); }
+__device__ __forceinline__ bool sc_ge(Sc a, Sc b) { return (a.t | b.t) ? ((float)a.v >= (float)b.v) : (a.v >= b.v); }
+__device__ __forceinline__ Sc sc_pmax(Sc a, Sc b) { return sc_gt(b, a) ? b : a; }   // Python max(a, b)
+__device__ __forceinline__ Sc sc_pmin(Sc a, Sc b) { return sc_lt(b, a) ? b : a; }   // Python min(a, b)
+__device__ __forceinline__ Sc sc_abs(Sc a) { a.v = fabs(a.v); return a; }
+__device__ __forceinline__ Sc sc_neg(Sc a) { a.v = -a.v; return a; }
+__device__ __forceinline__ Sc sc_sqrt(Sc a) { return a.t ? T(sqrtf((float)a.v)) : P(sqrt(a.v)); }
+
+// lbfgs_ls.py:11-36
+__device__ __forceinline__ Sc cubic_interpolate(Sc x1, Sc f1, Sc g1, Sc x2, Sc f2, Sc g2, bool has_bounds, Sc lo, Sc hi) {
+    if (!has_bounds) {
+        if (sc_le(x1, x2)) { lo = x1; hi = x2; } else { lo = x2; hi = x1; }
+    }
+    const Sc d1 = sc_sub(sc_add(g1, g2), sc_div(sc_mul(P(3.0), sc_sub(f1, f2)), sc_sub(x1, x2)));
+    const Sc d2sq = sc_sub(sc_mul(d1, d1), sc_mul(g1, g2));
+    if (sc_ge(d2sq, P(0.0))) {
+        const Sc d2 = sc_sqrt(d2sq);
+        Sc mp;
+        if (sc_le(x1, x2))
+            mp = sc_sub(x2, sc_mul(sc_sub(x2, x1), sc_div(sc_sub(sc_add(g2, d2), d1),
+                                                          sc_add(sc_sub(g2, g1), sc_mul(P(2.0), d2)))));
+        else
+            mp = sc_sub(x1, sc_mul(sc_sub(x1, x2), sc_div(sc_sub(sc_add(g1, d2), d1),
+                                                          sc_add(sc_sub(g1, g2), sc_mul(P(2.0), d2)))));
+        return sc_pmin(sc_pmax(mp, lo), hi);
+    }
+    return sc_div(sc_add(lo, hi), P(2.0));
+}
+
+// cv2.Rodrigues semantics (fit_single_frame.py:528-535): rotvec -> R, R . R([0,pi,0]), -> rotvec
+__device__ void flipped_orientation(const float* go, float* out) {
+    const double r0 = go[0], r1 = go[1], r2 = go[2];
+    const double a = sqrt(r0 * r0 + r1 * r1 + r2 * r2);
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (a >= 1e-12) {
+        const double k0 = r0 / a, k1 = r1 / a, k2 = r2 / a, s = sin(a), c = 1.0 - cos(a);
+        const double K[9] = {0, -k2, k1, k2, 0, -k0, -k1, k0, 0};
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            double kk = 0; for (int q = 0; q < 3; ++q) kk += K[i * 3 + q] * K[q * 3 + j];
+            R[i * 3 + j] = (i == j ? 1.0 : 0.0) + s * K[i * 3 + j] + c * kk;
+        }
+    }
+    // R . Ry(pi): Ry(pi) = diag(-1, 1, -1) up to rounding of sin(pi); use the exact Rodrigues value
+    const double sp = sin(3.14159265358979323846), cp = 1.0 - cos(3.14159265358979323846);
+    const double Y[9] = {1 - cp, 0, sp, 0, 1, 0, -sp, 0, 1 - cp};
+    double M_[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        double v = 0; for (int q = 0; q < 3; ++q) v += R[i * 3 + q] * Y[q * 3 + j];
+        M_[i * 3 + j] = v;
+    }
+    double cth = (M_[0] + M_[4] + M_[8] - 1.0) / 2.0;
+    cth = cth < -1.0 ? -1.0 : (cth > 1.0 ? 1.0 : cth);
+    const double ang = acos(cth);
+    const double v0 = M_[7] - M_[5], v1 = M_[2] - M_[6], v2 = M_[3] - M_[1];
+    const double sn = sqrt(v0 * v0 + v1 * v1 + v2 * v2) / 2.0;
+    if (sn < 1e-10) {
+        if (cth > 0) { out[0] = out[1] = out[2] = 0.f; return; }
+        double d0 = sqrt(fmax((M_[0] + 1) / 2, 0.0)), d1 = sqrt(fmax((M_[4] + 1) / 2, 0.0)), d2 = sqrt(fmax((M_[8] + 1) / 2, 0.0));
+        if (M_[1] < 0) d1 = -d1;
+        if (M_[2] < 0) d2 = -d2;
+        const double n = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        out[0] = (float)(d0 / n * ang); out[1] = (float)(d1 / n * ang); out[2] = (float)(d2 / n * ang);
+        return;
+    }
+    out[0] = (float)(v0 / (2 * sn) * ang); out[1] = (float)(v1 / (2 * sn) * ang); out[2] = (float)(v2 / (2 * sn) * ang);
+}
+
+struct OptScal {
+    int phase, outer, n_iter, n_iter_total, cur_evals, func_evals;
+    int ls_evals, ls_iter, ls_done, insuf, low, high;
+    int hist_n, hist_head, cache_valid, has_prev_outer;
+    int evals, ref_evals, pad0, pad1;
+    Sc t, t_prev, H_diag;
+    Sc loss, prev_loss, orig_loss, f_prev, ls_f0;
+    Sc gtd_prev, ls_gtd0, d_norm;
+    Sc br0, br1, bf0, bf1, bgtd0, bgtd1;
+    double prev_loss_outer;
+};
+struct OptState {
+    OptScal s;
+    float ro[SFX_HIST];
+};
+
+
+#define NE3 3     // elements per lane (NVAR_MAX / 64)
+
+struct Lane3 { float v[NE3]; };
+
+__device__ __forceinline__ float wsum(float v) { return wave_sum_dpp(v); }
+__device__ __forceinline__ float wmax(float v) { return wave_max_dpp(v); }
+// lane l owns elements 3l, 3l+1, 3l+2 of a (<=192)-vector: one 12-byte load per lane, 768
+// contiguous bytes per wavefront instruction.  Rows are allocated NVAR_MAX long, so the wide
+// load is always in bounds; elements >= N are masked to zero.
+__device__ __forceinline__ Lane3 ld3(const float* p, int lane, int N) {
+    Lane3 r;
+    const float3 v = *reinterpret_cast<const float3*>(p + 3 * lane);
+    r.v[0] = (3 * lane + 0 < N) ? v.x : 0.f;
+    r.v[1] = (3 * lane + 1 < N) ? v.y : 0.f;
+    r.v[2] = (3 * lane + 2 < N) ? v.z : 0.f;
+    return r;
+}
+__device__ __forceinline__ void st3(float* p, const Lane3& a, int lane, int N) {
+#pragma unroll
+    for (int e = 0; e < NE3; ++e) { const int i = 3 * lane + e; if (i < N) p[i] = a.v[e]; }
+}
+__device__ __forceinline__ float dot3(const Lane3& a, const Lane3& b) {
+    float p = a.v[0] * b.v[0];
+    p = p + a.v[1] * b.v[1];
+    p = p + a.v[2] * b.v[2];
+    return wsum(p);
+}
+__device__ __forceinline__ float absmax3(const Lane3& a, int lane, int N) {
+    float m = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE3; ++e) if (3 * lane + e < N) m = fmaxf(m, fabsf(a.v[e]));
+    return wmax(m);
+}
+__device__ __forceinline__ Lane3 axpy3(const Lane3& x, float a, const Lane3& d) {
+    Lane3 r;
+#pragma unroll
+    for (int e = 0; e < NE3; ++e) r.v[e] = fmaf(a, d.v[e], x.v[e]);
+    return r;
+}
+
+__device__ __forceinline__ OptScal fresh_state() {
+    OptScal s;
+    s.phase = PH_ENTRY; s.outer = 0; s.n_iter = 0; s.n_iter_total = 0; s.cur_evals = 0; s.func_evals = 0;
+    s.ls_evals = 0; s.ls_iter = 0; s.ls_done = 0; s.insuf = 0; s.low = 0; s.high = 1;
+    s.hist_n = 0; s.hist_head = 0; s.cache_valid = 0; s.has_prev_outer = 0; s.evals = 0; s.ref_evals = 0;
+    s.pad0 = 0; s.pad1 = 0;
+    s.t = P(0.0); s.t_prev = P(0.0); s.H_diag = P(1.0);
+    s.loss = P(0.0); s.prev_loss = P(0.0); s.orig_loss = P(0.0); s.f_prev = P(0.0); s.ls_f0 = P(0.0);
+    s.gtd_prev = P(0.0); s.ls_gtd0 = P(0.0); s.d_norm = P(0.0);
+    s.br0 = s.br1 = s.bf0 = s.bf1 = s.bgtd0 = s.bgtd1 = P(0.0);
+    s.prev_loss_outer = 0.0;
+    return s;
+}
+
+// One tick of frame b's optimiser, executed by ONE wavefront (lanes 0..63).  f_in / g_in: the
+// closure result (global D.f/D.g, or LDS copies in fused kernels).  s_al[SFX_HIST] and s_state
+// are LDS scratch owned by the caller.
+__device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDev& D, const VarList* __restrict__ vls,
+                                                int first_stage, int last_stage, int init, int step_mode,
+                                                const int b, const int lane, float* s_al, OptScal& s_state,
+                                                const float* f_src, const float* g_src) {
+    const BatchCfgDev& C = D.cfg;
+    OptState* gst = reinterpret_cast<OptState*>(D.opt) + b;
+    int stage = D.stage[b];
+    float* X = D.X + (size_t)b * SFX_NPAR_MAX;
+    float* Xt = D.Xt + (size_t)b * SFX_NPAR_MAX;
+    float* vec = D.vec + (size_t)b * NVEC * SFX_NVAR_MAX;
+    float* hY = D.hist + (size_t)b * 2 * SFX_HIST * SFX_NVAR_MAX;
+    float* hS = hY + (size_t)SFX_HIST * SFX_NVAR_MAX;
+#define VEC(k) (vec + (k) * SFX_NVAR_MAX)
+
+    // ---------------------------------------------------------------- (re)initialisation
+    if (init) {
+        const OptScal s = fresh_state();
+        stage = first_stage;
+        if (lane == 0) {
+            D.stage[b] = stage;
+            gst->s = s;            // ro[] needs no initialisation (guarded by hist_n)
+            D.orient_pass[b] = 0;
+            int both = 0;
+            if (C.side_thsh > 0.f) {     // torch.dist of the 2-D shoulders (fit_single_frame.py:461-463)
+                const float* g2 = D.gt + (size_t)b * M.K * 2;
+                const float dx = g2[2 * C.lsh] - g2[2 * C.rsh], dy = g2[2 * C.lsh + 1] - g2[2 * C.rsh + 1];
+                both = sqrtf(dx * dx + dy * dy) < C.side_thsh;
+            }
+            D.try_both[b] = both;
+        }
+        for (int q = lane; q < 1 + SFX_MAX_STAGES; q += 64) {
+            if (q >= first_stage + 1 && q <= last_stage + 1) {
+                D.stage_evals[(size_t)b * (1 + SFX_MAX_STAGES) + q] = 0;
+                D.stage_ref_evals[(size_t)b * (1 + SFX_MAX_STAGES) + q] = 0;
+            }
+        }
+        for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
+        return;
+    }
+    if (init == 2) {           // resume after a pause (optimizer.step granularity): keep the state
+        if (stage >= 1000 && lane == 0) D.stage[b] = stage - 1000;
+        for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
+        return;
+    }
+    if (stage > last_stage) return;
+
+    // scalar state lives in LDS for the duration of the tick: every lane reads (broadcast) and
+    // writes (identical values) the same words, so the single wavefront stays uniform
+    if (lane == 0) s_state = gst->s;
+    LB_SYNC();
+    OptScal& s = s_state;
+    const VarList& vl = vls[stage < 0 ? 0 : 1];
+    int N = vl.n;
+    const double tol_change = 1e-9;
+    const int max_iter = C.maxiters, max_eval = C.max_eval, max_ls = 25;
+
+    // incoming evaluation
+    const Sc f_in = P((double)*f_src);
+    Lane3 g_in = ld3(g_src, lane, N);
+    int glast_cached = 0;
+    s.evals += 1; s.ref_evals += 1;
+
+    auto gather_x = [X, lane, N, &vl]() { Lane3 r;
+        for (int e = 0; e < NE3; ++e) { const int i = 3 * lane + e; r.v[e] = (i < N) ? X[vl.idx[i]] : 0.f; } return r; };
+    auto write_trial = [X, Xt, vec, lane, N, &vl](Sc t) {
+        const Lane3 xi = ld3(VEC(VEC_XINIT), lane, N), d = ld3(VEC(VEC_D), lane, N);
+        const Lane3 xt = axpy3(xi, (float)t.v, d);
+        for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
+        LB_SYNC();
+        for (int e = 0; e < NE3; ++e) { const int i = 3 * lane + e; if (i < N) Xt[vl.idx[i]] = xt.v[e]; }
+    };
+#define armijo_fail(f_new, t) sc_gt((f_new), sc_add(s.ls_f0, sc_mul(sc_mul(P(1e-4), (t)), s.ls_gtd0)))
+#define curv_ok(gtd_new) sc_le(sc_abs(gtd_new), sc_mul(P(-0.9), s.ls_gtd0))
+    // bracket set-up: gradient slot 0 = G0 (a Lane3 value), slot 1 = the incoming gradient
+#define start_zoom(b0, b1, f0, f1, G0, gd0, gd1, done) do {                                              \
+        s.br0 = (b0); s.br1 = (b1); s.bf0 = (f0); s.bf1 = (f1); s.bgtd0 = (gd0); s.bgtd1 = (gd1);        \
+        st3(VEC(VEC_BG0), (G0), lane, N); st3(VEC(VEC_BG1), g_in, lane, N);                               \
+        s.ls_done = (done) ? 1 : 0; s.insuf = 0;                                                         \
+        if (sc_le(s.bf0, s.bf1)) { s.low = 0; s.high = 1; } else { s.low = 1; s.high = 0; } } while (0)
+
+    int act = A_NONE;
+    // ---------------------------------------------------------------- consume the evaluation
+    if (s.phase == PH_ENTRY) {
+        st3(VEC(VEC_G), g_in, lane, N);
+        s.loss = f_in;
+        act = A_ENTRY;
+    } else if (s.phase == PH_BRACKET) {
+        s.ls_evals += 1;
+        const Sc t = s.t;
+        const Lane3 d = ld3(VEC(VEC_D), lane, N);
+        const Sc gtd_new = T(dot3(g_in, d));
+        if (s.ls_iter == max_ls) {
+            start_zoom(P(0.0), t, s.ls_f0, f_in, ld3(VEC(VEC_LSG0), lane, N), s.ls_gtd0, gtd_new, false);
+            act = A_ZOOM_NEXT;
+        } else if (armijo_fail(f_in, t) || (s.ls_iter > 1 && sc_ge(f_in, s.f_prev))) {
+            start_zoom(s.t_prev, t, s.f_prev, f_in, ld3(VEC(VEC_GPREV), lane, N), s.gtd_prev, gtd_new, false);
+            act = A_ZOOM_NEXT;
+        } else if (curv_ok(gtd_new)) {
+            // single-point bracket: the point itself is accepted
+            start_zoom(t, t, f_in, f_in, g_in, gtd_new, gtd_new, true);
+            s.low = 0; s.high = 1;
+            act = A_ZOOM_NEXT;
+        } else if (sc_ge(gtd_new, P(0.0))) {
+            start_zoom(s.t_prev, t, s.f_prev, f_in, ld3(VEC(VEC_GPREV), lane, N), s.gtd_prev, gtd_new, false);
+            act = A_ZOOM_NEXT;
+        } else {
+            const Sc lo = sc_add(t, sc_mul(P(0.01), sc_sub(t, s.t_prev)));
+            const Sc hi = sc_mul(t, P(10.0));
+            const Sc t_next = cubic_interpolate(s.t_prev, s.f_prev, s.gtd_prev, t, f_in, gtd_new, true, lo, hi);
+            s.t_prev = t; s.f_prev = f_in; s.gtd_prev = gtd_new;
+            st3(VEC(VEC_GPREV), g_in, lane, N);
+            s.t = t_next;
+            s.ls_iter += 1;
+            write_trial(t_next);
+            act = A_NONE;
+        }
+    } else {   // PH_ZOOM
+        s.ls_evals += 1; s.ls_iter += 1;
+        const Sc t = s.t;
+        const Lane3 d = ld3(VEC(VEC_D), lane, N);
+        const Sc gtd_new = T(dot3(g_in, d));
+        const int lo = s.low, hi = s.high;
+        if (armijo_fail(f_in, t) || sc_ge(f_in, (lo ? s.bf1 : s.bf0))) {
+            { const Sc v_ = t; if (hi) s.br1 = v_; else s.br0 = v_; } { const Sc v_ = f_in; if (hi) s.bf1 = v_; else s.bf0 = v_; } { const Sc v_ = gtd_new; if (hi) s.bgtd1 = v_; else s.bgtd0 = v_; }
+            st3(VEC(hi ? VEC_BG1 : VEC_BG0), g_in, lane, N);
+            if (sc_le(s.bf0, s.bf1)) { s.low = 0; s.high = 1; } else { s.low = 1; s.high = 0; }
+        } else {
+            if (curv_ok(gtd_new)) s.ls_done = 1;
+            else if (sc_ge(sc_mul(gtd_new, sc_sub((hi ? s.br1 : s.br0), (lo ? s.br1 : s.br0))), P(0.0))) {
+                { const Sc v_ = (lo ? s.br1 : s.br0); if (hi) s.br1 = v_; else s.br0 = v_; } { const Sc v_ = (lo ? s.bf1 : s.bf0); if (hi) s.bf1 = v_; else s.bf0 = v_; } { const Sc v_ = (lo ? s.bgtd1 : s.bgtd0); if (hi) s.bgtd1 = v_; else s.bgtd0 = v_; }
+                const Lane3 tmp = ld3(VEC(lo ? VEC_BG1 : VEC_BG0), lane, N);
+                st3(VEC(hi ? VEC_BG1 : VEC_BG0), tmp, lane, N);
+            }
+            { const Sc v_ = t; if (lo) s.br1 = v_; else s.br0 = v_; } { const Sc v_ = f_in; if (lo) s.bf1 = v_; else s.bf0 = v_; } { const Sc v_ = gtd_new; if (lo) s.bgtd1 = v_; else s.bgtd0 = v_; }
+            st3(VEC(lo ? VEC_BG1 : VEC_BG0), g_in, lane, N);
+        }
+        if (sc_lt(sc_mul(sc_abs(sc_sub(s.br1, s.br0)), s.d_norm), P(tol_change))) act = A_FINISH_LS;
+        else act = A_ZOOM_NEXT;
+    }
+
+    // ---------------------------------------------------------------- run until an evaluation is needed
+    int guard = 0;
+    while (act != A_NONE && guard++ < 4096) {
+        switch (act) {
+        case A_ENTRY: {          // LBFGS.step prologue (lbfgs_ls.py:279-290); (loss, G) hold f, g at x
+            s.cache_valid = 1;
+            s.func_evals += 1;
+            s.orig_loss = s.loss;
+            s.cur_evals = 1; s.n_iter = 0;
+            const Lane3 g = ld3(VEC(VEC_G), lane, N);
+            if (sc_le(T(absmax3(g, lane, N)), P((double)1e-5))) act = A_END_STEP;
+            else act = A_ITER_HEAD;
+            break;
+        }
+        case A_ITER_HEAD: {      // direction + first trial point (lbfgs_ls.py:304-397)
+            if (!(s.n_iter < max_iter)) { act = A_END_STEP; break; }
+            s.n_iter += 1; s.n_iter_total += 1;
+            const Lane3 g = ld3(VEC(VEC_G), lane, N);
+            Lane3 d;
+            if (s.n_iter_total == 1) {
+                for (int e = 0; e < NE3; ++e) d.v[e] = -g.v[e];
+                s.hist_n = 0; s.hist_head = 0; s.H_diag = P(1.0);
+            } else {
+                const Lane3 pg = ld3(VEC(VEC_PREVG), lane, N), dold = ld3(VEC(VEC_D), lane, N);
+                Lane3 y, sv;
+                const float tf = (float)s.t.v;
+                for (int e = 0; e < NE3; ++e) { y.v[e] = g.v[e] - pg.v[e]; sv.v[e] = dold.v[e] * tf; }
+                const float ys = dot3(y, sv);
+                if (ys > 1e-10f) {
+                    if (s.hist_n == SFX_HIST) { s.hist_head = (s.hist_head + 1) % SFX_HIST; s.hist_n -= 1; }
+                    const int ph = (s.hist_head + s.hist_n) % SFX_HIST;
+                    st3(hY + (size_t)ph * SFX_NVAR_MAX, y, lane, N);
+                    st3(hS + (size_t)ph * SFX_NVAR_MAX, sv, lane, N);
+                    const float ro = 1.0f / ys;
+                    if (lane == 0) gst->ro[ph] = ro;
+                    s.hist_n += 1;
+                    s.H_diag = T(ys / dot3(y, y));
+                }
+                LB_SYNC();
+                Lane3 q;
+                for (int e = 0; e < NE3; ++e) q.v[e] = -g.v[e];
+                // two-loop recursion; history rows are prefetched CH at a time so that the
+                // serial chain is dot/axpy latency only, not HBM latency
+                constexpr int CH = 16;
+                for (int i0 = s.hist_n - 1; i0 >= 0; i0 -= CH) {
+                    Lane3 Sb[CH], Yb[CH]; float rb[CH];
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int i = i0 - c;
+                        const int ph = (s.hist_head + (i >= 0 ? i : 0)) % SFX_HIST;
+                        Sb[c] = ld3(hS + (size_t)ph * SFX_NVAR_MAX, lane, N);
+                        Yb[c] = ld3(hY + (size_t)ph * SFX_NVAR_MAX, lane, N);
+                        rb[c] = gst->ro[ph];
+                    }
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int i = i0 - c;
+                        if (i >= 0) {
+                            const float al = dot3(Sb[c], q) * rb[c];
+                            if (lane == 0) s_al[i] = al;
+                            q = axpy3(q, -al, Yb[c]);
+                        }
+                    }
+                }
+                LB_SYNC();
+                Lane3 r;
+                const float hd = (float)s.H_diag.v;
+                for (int e = 0; e < NE3; ++e) r.v[e] = q.v[e] * hd;
+                for (int i0 = 0; i0 < s.hist_n; i0 += CH) {
+                    Lane3 Sb[CH], Yb[CH]; float rb[CH], ab[CH];
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const int i = i0 + c;
+                        const int ph = (s.hist_head + (i < s.hist_n ? i : 0)) % SFX_HIST;
+                        Sb[c] = ld3(hS + (size_t)ph * SFX_NVAR_MAX, lane, N);
+                        Yb[c] = ld3(hY + (size_t)ph * SFX_NVAR_MAX, lane, N);
+                        rb[c] = gst->ro[ph];
+                        ab[c] = s_al[i < s.hist_n ? i : 0];
+                    }
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        if (i0 + c < s.hist_n) {
+                            const float be = dot3(Yb[c], r) * rb[c];
+                            r = axpy3(r, ab[c] - be, Sb[c]);
+                        }
+                    }
+                }
+                d = r;
+            }
+            st3(VEC(VEC_D), d, lane, N);
+            st3(VEC(VEC_PREVG), g, lane, N);
+            s.prev_loss = s.loss;
+            Sc t;
+            if (s.n_iter_total == 1) {
+                float asum = 0.f;
+                for (int e = 0; e < NE3; ++e) asum = asum + fabsf(g.v[e]);
+                asum = wsum(asum);
+                t = sc_mul(sc_pmin(P(1.0), sc_div(P(1.0), T(asum))), P((double)C.lr));
+            } else t = P((double)C.lr);
+            s.t = t;
+            const Sc gtd = T(dot3(g, d));
+            if (sc_gt(gtd, P(-tol_change))) { act = A_END_STEP; break; }
+            // strong-Wolfe set-up (lbfgs_ls.py:39-52)
+            const Lane3 xi = gather_x();
+            st3(VEC(VEC_XINIT), xi, lane, N);
+            st3(VEC(VEC_LSG0), g, lane, N);
+            st3(VEC(VEC_GPREV), g, lane, N);
+            s.ls_f0 = s.loss; s.ls_gtd0 = gtd;
+            s.d_norm = T(absmax3(d, lane, N));
+            s.ls_evals = 0; s.ls_iter = 0;
+            s.t_prev = P(0.0); s.f_prev = s.loss; s.gtd_prev = gtd;
+            s.phase = PH_BRACKET;
+            LB_SYNC();
+            write_trial(t);
+            act = A_NONE;
+            break;
+        }
+        case A_ZOOM_NEXT: {      // next zoom trial (lbfgs_ls.py:108-131)
+            if (s.ls_done || !(s.ls_iter < max_iter)) { act = A_FINISH_LS; break; }
+            Sc t = cubic_interpolate(s.br0, s.bf0, s.bgtd0, s.br1, s.bf1, s.bgtd1, false, P(0), P(0));
+            const Sc bmax = sc_gt(s.br1, s.br0) ? s.br1 : s.br0;
+            const Sc bmin = sc_lt(s.br1, s.br0) ? s.br1 : s.br0;
+            const Sc eps = sc_mul(P(0.1), sc_sub(bmax, bmin));
+            if (sc_lt(sc_pmin(sc_sub(bmax, t), sc_sub(t, bmin)), eps)) {
+                if (s.insuf || sc_ge(t, bmax) || sc_le(t, bmin)) {
+                    if (sc_lt(sc_abs(sc_sub(t, bmax)), sc_abs(sc_sub(t, bmin)))) t = sc_sub(bmax, eps);
+                    else t = sc_add(bmin, eps);
+                    s.insuf = 0;
+                } else s.insuf = 1;
+            } else s.insuf = 0;
+            s.t = t;
+            s.phase = PH_ZOOM;
+            write_trial(t);
+            act = A_NONE;
+            break;
+        }
+        case A_FINISH_LS: {      // accept the lowest bracket end (lbfgs_ls.py:163-167,398-434)
+            const int lo = s.low;
+            const Sc t = (lo ? s.br1 : s.br0);
+            s.loss = (lo ? s.bf1 : s.bf0); s.t = t;
+            const Lane3 g = ld3(VEC(lo ? VEC_BG1 : VEC_BG0), lane, N);
+            st3(VEC(VEC_G), g, lane, N);
+            const Lane3 xi = ld3(VEC(VEC_XINIT), lane, N), d = ld3(VEC(VEC_D), lane, N);
+            const Lane3 xn = axpy3(xi, (float)t.v, d);
+            for (int e = 0; e < NE3; ++e) { const int i = 3 * lane + e; if (i < N) X[vl.idx[i]] = xn.v[e]; }
+            s.cache_valid = 1;
+            const bool opt_cond = sc_le(T(absmax3(g, lane, N)), P((double)1e-5));
+            s.cur_evals += s.ls_evals; s.func_evals += s.ls_evals;
+            if (s.n_iter == max_iter) { act = A_END_STEP; break; }
+            if (s.cur_evals >= max_eval) { act = A_END_STEP; break; }
+            if (opt_cond) { act = A_END_STEP; break; }
+            Lane3 stp;
+            const float tf = (float)t.v;
+            for (int e = 0; e < NE3; ++e) stp.v[e] = d.v[e] * tf;
+            if (sc_le(T(absmax3(stp, lane, N)), P(tol_change))) { act = A_END_STEP; break; }
+            if (sc_lt(sc_abs(sc_sub(s.loss, s.prev_loss)), P(tol_change))) { act = A_END_STEP; break; }
+            LB_SYNC();
+            act = A_ITER_HEAD;
+            break;
+        }
+        case A_END_STEP: {       // run_fitting bookkeeping (fitting.py:175-217)
+            const double loss = s.orig_loss.v;
+            if (step_mode) {         // one LBFGS.step per call: hand control back, keep the state
+                if (lane == 0) {
+                    D.stage_loss[(size_t)b * (1 + SFX_MAX_STAGES) + stage + 1] = (float)loss;
+                    D.stage[b] = stage + 1000;
+                }
+                s.phase = PH_ENTRY;
+                for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
+                act = A_NONE;
+                break;
+            }
+            bool stop = false;
+            if (isnan(loss) || isinf(loss)) stop = true;
+            if (!stop && s.outer > 0 && s.has_prev_outer && C.ftol > 0.0) {
+                const double pv = s.prev_loss_outer;
+                const double den = fmax(fmax(fabs(pv), fabs(loss)), 1.0);
+                if ((pv - loss) / den <= C.ftol) stop = true;
+            }
+            if (!stop) {
+                const Lane3 gl = glast_cached ? ld3(VEC(VEC_G), lane, N) : g_in;
+                bool all_small = true;
+                for (int gi = 0; gi < vl.ngroups; ++gi) {
+                    if (!vl.g_has[gi]) continue;
+                    float m = -INFINITY;
+                    for (int e = 0; e < NE3; ++e) {
+                        const int i = 3 * lane + e;
+                        if (i >= vl.g_off[gi] && i < vl.g_off[gi] + vl.g_len[gi]) m = fmaxf(m, gl.v[e]);
+                    }
+                    m = wmax(m);
+                    if (!((double)fabsf(m) < C.gtol)) all_small = false;
+                }
+                if (all_small) stop = true;
+            }
+            if (!stop) {
+                s.prev_loss_outer = loss; s.has_prev_outer = 1;
+                s.outer += 1;
+                if (s.outer >= C.maxiters) stop = true;
+            }
+            if (stop) { act = A_FINISH_STAGE; break; }
+            s.phase = PH_ENTRY;
+            if (C.reuse && s.cache_valid) {
+                glast_cached = 1;
+                s.ref_evals += 1;
+                act = A_ENTRY;          // (loss, G) already hold f, g at the unchanged x
+            } else {
+                for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
+                act = A_NONE;
+            }
+            break;
+        }
+        case A_FINISH_STAGE: {
+            const int slot = stage + 1;     // camera stage -> 0
+            const size_t so = (size_t)b * (1 + SFX_MAX_STAGES);
+            const int pass = D.orient_pass[b];
+            const float res = s.has_prev_outer ? (float)s.prev_loss_outer : __int_as_float(0x7fc00000);
+            if (lane == 0) {
+                (pass ? D.stage_loss2 : D.stage_loss)[so + slot] = res;
+                D.stage_evals[so + slot] += s.evals;
+                D.stage_ref_evals[so + slot] += s.ref_evals;
+            }
+            // camera stage done: remember the orientation the flipped candidate is derived from
+            if (stage < 0 && lane < 3) D.gocam[(size_t)b * 4 + lane] = X[D.L.go + lane];
+            stage += 1;
+            // side view (fit_single_frame.py:527-551): second fit from the orientation rotated by pi
+            // about y; pose embedding and camera translation continue from the first fit, every
+            // other body parameter is zeroed; the lower final loss wins (:662-667)
+            if (stage == C.n_stages && last_stage == C.n_stages - 1 && D.try_both[b]) {
+                float* X0 = D.X0 + (size_t)b * SFX_NPAR_MAX;
+                LB_SYNC();
+                if (pass == 0) {
+                    for (int i = lane; i < SFX_NPAR_MAX; i += 64) X0[i] = X[i];
+                    LB_SYNC();
+                    const ParLayout& L = D.L;
+                    for (int i = lane; i < L.npar; i += 64) {
+                        const bool keep = (i >= L.cam_t && i < L.cam_t + 3) || (i >= L.emb && i < L.emb + L.NEMB);
+                        if (!keep) X[i] = 0.f;
+                    }
+                    LB_SYNC();
+                    if (lane == 0) {
+                        float fl[3];
+                        flipped_orientation(D.gocam + (size_t)b * 4, fl);
+                        X[L.go] = fl[0]; X[L.go + 1] = fl[1]; X[L.go + 2] = fl[2];
+                        D.orient_pass[b] = 1;
+                    }
+                    if (L.has_bodyp && lane < 63) X[L.bodyp + lane] = X[L.emb + lane];
+                    LB_SYNC();
+                    stage = 0;
+                } else {
+                    const float l0 = D.stage_loss[so + C.n_stages], l1 = res;
+                    if (l0 < l1) {                       // first orientation wins: restore it
+                        for (int i = lane; i < SFX_NPAR_MAX; i += 64) X[i] = X0[i];
+                    } else if (lane == 0) {
+                        for (int q = 1; q <= C.n_stages; ++q) D.stage_loss[so + q] = D.stage_loss2[so + q];
+                    }
+                    if (lane == 0) D.orient_pass[b] = 2;
+                    LB_SYNC();
+                }
+            }
+            if (lane == 0) D.stage[b] = stage;
+            s = fresh_state();
+            for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
+            act = A_NONE;
+            break;
+        }
+        default: act = A_NONE; break;
+        }
+    }
+    LB_SYNC();
+    if (lane == 0) gst->s = s_state;     // ro[] is written in place
+#undef VEC
+}
+
+
+#pragma clang fp contract(fast)

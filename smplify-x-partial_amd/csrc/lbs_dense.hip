@@ -42,7 +42,7 @@ void k_lbs_dense(DevModel M, BatchDev D) {
     const int fb0 = blockIdx.y * FB;
     const int b0 = fb0 + wv * 32;
     const int jl = lane & 31, kh = lane >> 5;
-    const int V = M.V, B = D.cfg.B;
+    const int V = M.V, B = D.nact;      // active (compacted) frames
     const int vtx = v0 + jl;
     const int v = vtx < V ? vtx : V - 1;
     const size_t Bp = (size_t)D.Bpad;
@@ -135,6 +135,7 @@ void k_lbs_dense(DevModel M, BatchDev D) {
 }
 
 void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s) {
-    dim3 grid((M.V + 31) / 32, (D.Bpad + FB - 1) / FB);
+    dim3 grid((M.V + 31) / 32, (D.nact + FB - 1) / FB);
+    if (D.nact <= 0) return;
     hipLaunchKernelGGL(k_lbs_dense, grid, dim3(DT), 0, s, M, D);
 }

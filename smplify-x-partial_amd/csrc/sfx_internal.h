@@ -132,6 +132,8 @@ struct BatchDev {
     float* joints;     // [B][K][3] (export)
     float* fullpose;   // [B][165]  (export)
     int Bpad;
+    int*   slot;       // [B] frame -> operand column / vertex-buffer row (identity or compacted)
+    int nact;          // columns in use (frames the dense GEMM processes)
     // optimiser state
     int*   stage;      // [B] current stage (-1 camera, 0.. body, n_stages = done)
     void*  opt;        // [B] OptState
@@ -170,3 +172,7 @@ void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s);
 void launch_lbfgs_tick(const DevModel& M, const BatchDev& D, const VarList* vl_dev, int first_stage,
                        int last_stage, int init, int step_mode, hipStream_t s);
 size_t sfx_optstate_size();
+void launch_fit_rows(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
+                     int first_stage, int last_stage, int max_ticks, hipStream_t s);
+void launch_tick_dense(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
+                       int first_stage, int last_stage, int has_eval, hipStream_t s);

@@ -65,9 +65,32 @@ def prepare_frames(cfg, keypoints, joint_weights, reg_pose=None, reg_global=None
 
 def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, reg_global=None,
                cam_prior_t=None, cam_prior_center=None, lbs_mode="dense", reuse_entry_eval=True,
-               want_vertices=False):
+               want_vertices=False, groups=1, _stream=None):
     """Fit B frames.  Arrays are [B, ...]; H, W, focal scalars or [B].  Returns a dict of
-    [B, ...] arrays: the reference's result-pkl fields + per-stage losses / evaluation counts."""
+    [B, ...] arrays: the reference's result-pkl fields + per-stage losses / evaluation counts.
+
+    groups > 1 splits the frames into that many independent sub-batches, each driven from its
+    own host thread on its own HIP stream: while one group's latency-bound optimiser tick runs,
+    another group's MFMA GEMM fills the CUs (frames are independent, results are unchanged)."""
+    B_all = np.asarray(keypoints).shape[0]
+    if groups > 1 and B_all >= 2 * groups:
+        import torch
+        from concurrent.futures import ThreadPoolExecutor
+        cuts = [(B_all * g) // groups for g in range(groups + 1)]
+        per = lambda a, lo, hi: None if a is None else (np.asarray(a)[lo:hi] if np.ndim(a) > 0 and np.asarray(a).shape[0] == B_all else a)
+        jw_all = np.asarray(joint_weights)
+        jw_is_per_frame = jw_all.ndim == 2 and jw_all.shape[0] == B_all
+
+        def run(g):
+            lo, hi = cuts[g], cuts[g + 1]
+            st = torch.cuda.Stream()
+            return fit_frames(dm, cfg, np.asarray(keypoints)[lo:hi], jw_all[lo:hi] if jw_is_per_frame else jw_all,
+                              per(H, lo, hi), per(W, lo, hi), per(focal, lo, hi), per(reg_pose, lo, hi),
+                              per(reg_global, lo, hi), per(cam_prior_t, lo, hi), per(cam_prior_center, lo, hi),
+                              lbs_mode, reuse_entry_eval, want_vertices, groups=1, _stream=st.cuda_stream)
+        with ThreadPoolExecutor(groups) as ex:
+            parts = list(ex.map(run, range(groups)))
+        return {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}
     prep = prepare_frames(cfg, keypoints, joint_weights)
     kp = prep["keypoints"]
     B, K = kp.shape[:2]
@@ -98,7 +121,7 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
     #      (2-D shoulder distance < side_view_thsh, fit_single_frame.py:461-463) are fitted a second
     #      time from the orientation flipped by pi about y and the lower final loss is kept
     #      (:527-551,662-667) -- also on device, inside the same batch.
-    fb.fit(first_stage=-1, last_stage=fb.n_stages - 1)
+    fb.fit(first_stage=-1, last_stage=fb.n_stages - 1, stream=_stream)
     st = fb.stats()
     out = dict(fb.get_params())
     out.update(stage_loss=st["stage_loss"].copy(), stage_evals=st["stage_evals"].copy(),

@@ -311,6 +311,6 @@ def prof_reset():
 
 
 def prof_get(name):
-    ms, n = C.c_double(), C.c_int64()
-    capi.load().sfx_prof_get(name.encode(), C.byref(ms), C.byref(n))
-    return ms.value, n.value
+    ms, n, u = C.c_double(), C.c_int64(), C.c_double()
+    capi.load().sfx_prof_get(name.encode(), C.byref(ms), C.byref(n), C.byref(u))
+    return ms.value, n.value, u.value
