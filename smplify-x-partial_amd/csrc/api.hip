@@ -319,11 +319,19 @@ extern "C" void sfx_model_destroy(sfx_model* m) {
 extern "C" int sfx_model_set_vposer(sfx_model* m, int32_t latent, int32_t hidden, const float* w1, const float* b1,
                                     const float* w2, const float* b2, const float* w3, const float* b3) {
     if (!m) { sfx_set_error("null model"); return -1; }
+    if (hidden != 512 || latent < 1 || latent > 63) { sfx_set_error("VPoser v1 decoder expected (hidden 512), got %d/%d", latent, hidden); return -1; }
     auto v = [](const float* p, size_t n) { return std::vector<float>(p, p + n); };
+    const int H = hidden, L = latent;
+    std::vector<float> w1T((size_t)L * H), w2T((size_t)H * H), w3T((size_t)H * 128, 0.f);
+    for (int o = 0; o < H; ++o) for (int i = 0; i < L; ++i) w1T[(size_t)i * H + o] = w1[(size_t)o * L + i];
+    for (int o = 0; o < H; ++o) for (int i = 0; i < H; ++i) w2T[(size_t)i * H + o] = w2[(size_t)o * H + i];
+    for (int o = 0; o < 126; ++o) for (int i = 0; i < H; ++i) w3T[(size_t)i * 128 + o] = w3[(size_t)o * H + i];
     m->M.vp_latent = latent; m->M.vp_hidden = hidden;
-    m->M.vp_w1 = m->mem.up(v(w1, (size_t)hidden * latent)); m->M.vp_b1 = m->mem.up(v(b1, hidden));
-    m->M.vp_w2 = m->mem.up(v(w2, (size_t)hidden * hidden)); m->M.vp_b2 = m->mem.up(v(b2, hidden));
-    m->M.vp_w3 = m->mem.up(v(w3, (size_t)126 * hidden));    m->M.vp_b3 = m->mem.up(v(b3, 126));
+    m->M.vp_w1 = m->mem.up(v(w1, (size_t)H * L)); m->M.vp_b1 = m->mem.up(v(b1, H));
+    m->M.vp_w2 = m->mem.up(v(w2, (size_t)H * H)); m->M.vp_b2 = m->mem.up(v(b2, H));
+    m->M.vp_w3 = m->mem.up(v(w3, (size_t)126 * H)); m->M.vp_b3 = m->mem.up(v(b3, 126));
+    m->M.vp_w1T = m->mem.up(w1T); m->M.vp_w2T = m->mem.up(w2T); m->M.vp_w3T = m->mem.up(w3T);
+    if (m->fwd) { sfx_batch_destroy(m->fwd); m->fwd = nullptr; }
     return 0;
 }
 
@@ -495,7 +503,12 @@ extern "C" int sfx_batch_get_params(sfx_batch* b, float* cam_t, float* go, float
     take(X, B, L.jaw, 3, jaw); take(X, B, L.leye, 3, leye); take(X, B, L.reye, 3, reye);
     take(X, B, L.emb, L.NEMB, emb);
     if (body_pose) {
-        if (b->D.cfg.use_vposer) SFX_CHECK(hipMemcpy(body_pose, b->D.bodypose, (size_t)B * 63 * 4, hipMemcpyDeviceToHost));
+        if (b->D.cfg.use_vposer) {      // decode the ACCEPTED latent (fit_single_frame.py:653-657)
+            ClosureArgs a{}; a.stage_override = 0; a.forward_only = 1; a.from_X = 1;
+            launch_closure(b->m->M, b->D, b->vl_dev, b->sw_dev, a, 0);
+            SFX_CHECK(hipDeviceSynchronize());
+            SFX_CHECK(hipMemcpy(body_pose, b->D.bodypose, (size_t)B * 63 * 4, hipMemcpyDeviceToHost));
+        }
         else take(X, B, L.emb, 63, body_pose);
     }
     return 0;

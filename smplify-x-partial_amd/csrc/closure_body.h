@@ -18,6 +18,7 @@
 #pragma once
 #include "sfx_internal.h"
 #include "wave_ops.h"
+#include "vposer.h"
 
 #define CT 256
 #define FD_GT 0
@@ -63,6 +64,7 @@ struct __align__(16) FrameLDS {
     float lh45[SFX_NHAND], rh45[SFX_NHAND];
     float scal[16];
     int   lut_row;
+    VposerLDS V;                // VPoser activations (use_vposer only)
     float fd[FD_N];             // this frame's keypoints / weights / camera / regression pose
     int   meta[SFX_META_N];     // tree / joint-map tables (one coalesced load instead of
                                 // dependent global loads inside every level of the chain)
@@ -179,7 +181,11 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
     for (int i = t; i < SFX_NPAR_MAX; i += CT) S.gc[i] = 0.f;
     for (int i = t; i < 168; i += CT) S.dpose[i] = 0.f;
     __syncthreads();
-    const float* bodypose = C.use_vposer ? (D.bodypose + (size_t)b * 63) : (S.x + L.emb);
+    if (C.use_vposer) {          // body_pose = vposer.decode(pose_embedding) (fitting.py:236-238)
+        vposer_forward<CT>(S.V, M, S.x + L.emb);
+        if (t < 63) D.bodypose[(size_t)b * 63 + t] = S.V.body[t];
+    }
+    const float* bodypose = C.use_vposer ? S.V.body : (S.x + L.emb);
 
     MARK(1);
     // ------------------------------------------------------------------ pose assembly
@@ -639,7 +645,7 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
     }
     __syncthreads();
     MARK(15);
-    // TODO(vposer): body-pose adjoint through the VPoser decoder is applied by k_vposer_bwd.
+    if (C.use_vposer) vposer_backward<CT>(S.V, M, &S.dpose[3], &S.gc[L.emb]);   // d body_pose -> d latent
     const VarList& vl = vls[cam_stage ? 0 : 1];
     float* gout = D.g + (size_t)b * SFX_NVAR_MAX;
     for (int i = t; i < vl.n; i += CT) { const float gv = S.gc[vl.idx[i]]; gout[i] = gv; if (gflat) gflat[i] = gv; }

@@ -95,7 +95,8 @@ struct DevModel {
     const int*   meta;         // [SFX_META_N] packed copy of the tables above
     // VPoser decoder
     int vp_latent, vp_hidden;
-    const float *vp_w1, *vp_b1, *vp_w2, *vp_b2, *vp_w3, *vp_b3;
+    const float *vp_w1, *vp_b1, *vp_w2, *vp_b2, *vp_w3, *vp_b3;      // [512][L], [512][512], [126][512]
+    const float *vp_w1T, *vp_w2T, *vp_w3T;                          // [L][512], [512][512], [512][128]
 };
 
 struct BatchCfgDev {

@@ -68,10 +68,16 @@ def oracle_joints_fn(model, cfg):
 
 
 def oracle_frame_fit(model, cfg, frames, i, dtype=torch.float32, **kw):
-    """oracle.fit_frame.FrameFit for synthetic frame i (regression prior = noisy truth)."""
+    """oracle.fit_frame.FrameFit for synthetic frame i (regression prior = noisy truth; with
+    use_vposer: zero latent, synthetic VPoser decoder, no regression prior)."""
     from oracle.fit_frame import FrameFit
     bm = oracle_model(model, cfg, dtype)
     K = frames["keypoints"].shape[1]
+    if cfg.get("use_vposer"):
+        from oracle.vposer import VPoserRef
+        vp = VPoserRef(synthetic.make_synthetic_vposer(0), dtype)
+        return FrameFit(bm, frames["keypoints"][i:i + 1], frames["H"], frames["W"], frames["focal"], cfg,
+                        base_joint_weights(cfg, K), vposer=vp, dtype=dtype, **kw)
     return FrameFit(bm, frames["keypoints"][i:i + 1], frames["H"], frames["W"], frames["focal"], cfg,
                     base_joint_weights(cfg, K), reg_pose=frames["reg_pose"][i], reg_global=frames["reg_global"][i],
                     dtype=dtype, **kw)
@@ -94,9 +100,14 @@ def engine_batch_from_frames(dm, cfg, frames, idx, lbs_mode="rows", reuse=False)
         for j in cfg["init_joints_idxs"]:
             if kp[b, j, 0] != 0 and kp[b, j, 1] != 0 and not low[b, j]:
                 cmask[b, j] = 1
-    fb = engine.FrameBatch(dm, B, cfg, lbs_mode=lbs_mode, reuse_entry_eval=reuse, has_regression_pose=True)
+    vp = bool(cfg.get("use_vposer"))
+    fb = engine.FrameBatch(dm, B, cfg, lbs_mode=lbs_mode, reuse_entry_eval=reuse, has_regression_pose=not vp)
     H, W = frames["H"], frames["W"]
     fb.set_frames(kp, jw, cmask, frames["focal"], np.tile([W * 0.5, H * 0.5], (B, 1)), 1000.0 / H)
-    fb.set_params(regression_pose=frames["reg_pose"][idx], global_orient=frames["reg_global"][idx],
-                  pose_embedding=frames["reg_pose"][idx], cam_translation=np.zeros((B, 3), np.float32))
+    if vp:
+        fb.set_params(pose_embedding=np.zeros((B, fb.nemb), np.float32), global_orient=np.zeros((B, 3), np.float32),
+                      cam_translation=np.zeros((B, 3), np.float32))
+    else:
+        fb.set_params(regression_pose=frames["reg_pose"][idx], global_orient=frames["reg_global"][idx],
+                      pose_embedding=frames["reg_pose"][idx], cam_translation=np.zeros((B, 3), np.float32))
     return fb

@@ -287,3 +287,42 @@ def test_side_view_second_orientation_on_device(gpu, synth_model, cfg_body):
     for k in ("global_orient", "pose_embedding", "betas", "cam_translation"):
         assert np.allclose(res[k][1], want[k][0], rtol=0, atol=1e-6), k
     assert res["stage_evals"][1, 1:].sum() == s0["stage_evals"][0, 1:].sum() + s1["stage_evals"][0, 1:].sum()
+
+
+def test_closure_with_vposer_matches_oracle(gpu, synth_model):
+    """BASELINE config 3: full SMPL-X (hands + face + contour, K=135), VPoser decode in the loop
+    (cfg_files/fit_smplx_smplifyx.yaml: use_vposer True, 5 stages).  Loss + gradient wrt the
+    88-long variable vector (32-D latent last) against oracle autograd (fp64), rows and dense."""
+    from smplifyx_amd import synthetic
+    cfg = H.load_cfg("fit_smplx_smplifyx.yaml")
+    assert cfg["use_vposer"] and cfg["use_hands"] and cfg["use_face"]
+    vpw = synthetic.make_synthetic_vposer(0)
+    dm = _dm(synth_model, cfg, vposer=vpw)
+    B = 2
+    frames = synth_frames(synth_model, cfg, 3)
+    frames = {k: (v[:B] if isinstance(v, np.ndarray) else v) for k, v in frames.items()}
+    rng = np.random.RandomState(5)
+    P = H.random_params(rng, B, scale=0.5)
+    P["pose_embedding"] = rng.normal(size=(B, 32)).astype(np.float32)
+    P["global_orient"] = frames["reg_global"] + 0.1 * rng.normal(size=(B, 3)).astype(np.float32)
+    P["cam_translation"] = (frames["cam_t"] + 0.3 * rng.normal(size=(B, 3))).astype(np.float32)
+    est = (frames["cam_t"][:, 2] + 1.0).astype(np.float32)
+    for mode in ("rows", "dense"):
+        fb = H.engine_batch_from_frames(dm, cfg, frames, range(B), lbs_mode=mode)
+        assert fb.num_vars(0) == 88 and fb.nemb == 32
+        fb.set_frames(frames["keypoints"], _jw(cfg, frames), _cmask(cfg, frames), frames["focal"],
+                      np.tile([frames["W"] * 0.5, frames["H"] * 0.5], (B, 1)), 1000.0 / frames["H"], est_tz=est)
+        fb.set_params(**P)
+        Q = dict(P); Q["est_tz"] = est
+        for stage in (-1, 0, 3, 4):
+            loss, grad = fb.closure(stage)
+            for i in range(B):
+                lo, go = _oracle_closure(synth_model, cfg, frames, i, Q, stage)
+                assert abs(loss[i] - lo) <= 2e-5 * abs(lo), (mode, stage, i, loss[i], lo)
+                err = np.linalg.norm(grad[i] - go) / max(np.linalg.norm(go), 1e-30)
+                assert err < 3e-4, (mode, stage, i, err)
+        # decoded body pose of the accepted latent
+        bp = fb.get_params()["body_pose"]
+        from oracle.vposer import VPoserRef
+        want = VPoserRef(vpw, torch.float64).decode(torch.tensor(P["pose_embedding"], dtype=torch.float64)).view(B, -1).numpy()
+        assert np.abs(bp - want).max() < 2e-5
