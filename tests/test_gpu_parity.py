@@ -326,3 +326,29 @@ def test_closure_with_vposer_matches_oracle(gpu, synth_model):
         from oracle.vposer import VPoserRef
         want = VPoserRef(vpw, torch.float64).decode(torch.tensor(P["pose_embedding"], dtype=torch.float64)).view(B, -1).numpy()
         assert np.abs(bp - want).max() < 2e-5
+
+
+def test_fit_with_vposer_matches_reference(gpu, synth_model):
+    """BASELINE config 3 end to end: the reference's fit_single_frame (with oracle SMPLXRef +
+    VPoserRef plugged in) vs the engine, full K=135, VPoser latent, 5 stages
+    (tests/golden/e2e_vposer.npz holds the reference's fp32 and fp64 runs)."""
+    from smplifyx_amd import synthetic
+    g = _golden("e2e_vposer")
+    cfg = H.load_cfg("fit_smplx_smplifyx.yaml")
+    dm = _dm(synth_model, cfg, vposer=synthetic.make_synthetic_vposer(0))
+    frames = dict(keypoints=g["keypoints"], H=600, W=800, focal=5000.0)
+    for mode in ("rows", "dense"):
+        fb = H.engine_batch_from_frames(dm, cfg, frames, [0], lbs_mode=mode, reuse=True)
+        fb.guess_init(cfg["body_tri_idxs"])
+        fb.fit()
+        st = fb.stats()
+        ref32, ref64 = g["f0_f32_losses"], g["f0_f64_losses"]
+        spread = np.abs(ref32 - ref64) / np.abs(ref64)
+        rel = np.abs(st["stage_loss"][0] - ref32) / np.abs(ref32)
+        assert rel[0] < 1e-4, (mode, st["stage_loss"][0], ref32)
+        assert np.all(rel[1:5] < np.maximum(3 * spread[1:5], 1e-1)), (mode, rel, spread)
+        # last stage (face landmarks weight 2): the dynamic-contour LUT makes the objective
+        # non-smooth on the synthetic head (random landmark triangles); every implementation --
+        # the reference in fp32 (133 evaluations) and fp64 (396), the engine -- stops after a
+        # failed line search at a different point: 1.9e5 / 2.3e5 / 2.9e5..6.7e5.  Same regime only.
+        assert np.isfinite(st["stage_loss"][0, 5]) and 0.2 < st["stage_loss"][0, 5] / ref32[5] < 5.0

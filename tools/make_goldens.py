@@ -261,6 +261,33 @@ def gen_e2e():
     _save("e2e_synth", **out)
 
 
+def gen_e2e_vposer():
+    """BASELINE config 3: full SMPL-X (hands + face + contour, K=135), VPoser decode in the loop,
+    5-stage schedule of cfg_files/fit_smplx_smplifyx.yaml, zero-latent init, guess_init camera:
+    the reference's fit_single_frame driving oracle SMPLXRef + VPoserRef (synthetic weights)."""
+    import helpers as H
+    from smplifyx_amd import synthetic
+    from oracle.vposer import VPoserRef
+    model = synthetic.make_synthetic_model(0)
+    cfg = H.load_cfg("fit_smplx_smplifyx.yaml", use_cuda=False)
+    K = len(H.joint_map_for(cfg))
+    frames = synthetic.make_frames(1, H.oracle_joints_fn(model, cfg), K, focal=5000.0)
+    out = dict(keypoints=frames["keypoints"])
+    vpw = synthetic.make_synthetic_vposer(0)
+    for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        vp = VPoserRef(vpw, dtype)
+        ref.fit_single_frame.load_vposer = lambda ckpt, vp_model="snapshot": (vp, None)
+        bm = H.oracle_model(model, cfg, dtype)
+        res, losses, evals = _run_reference_fit(bm, cfg, frames["keypoints"][:1], frames["H"], frames["W"],
+                                                frames["focal"], H.base_joint_weights(cfg, K), dtype)
+        out["f0_%s_losses" % tag] = losses
+        out["f0_%s_evals" % tag] = evals
+        for k in ("camera_translation", "global_orient", "betas", "body_pose", "expression", "jaw_pose"):
+            out["f0_%s_%s" % (tag, k)] = np.asarray(res[k], np.float64)
+        print("e2e vposer", tag, losses, evals)
+    _save("e2e_vposer", **out)
+
+
 def gen_demo():
     """BASELINE config 1: the two demo/ frames, body-only, combined regression prior +
     camera prior (cfg_files/fit_smplx_combined_coco25.yaml), reference fit in fp32."""
@@ -294,7 +321,7 @@ def gen_demo():
 
 
 if __name__ == "__main__":
-    todo = sys.argv[1:] or ["tables", "euler", "objective", "lbfgs", "e2e", "demo"]
+    todo = sys.argv[1:] or ["tables", "euler", "objective", "lbfgs", "e2e", "demo", "e2e_vposer"]
     for w in todo:
         {"objective": gen_objective, "lbfgs": gen_lbfgs, "euler": gen_euler, "tables": gen_tables,
-         "e2e": gen_e2e, "demo": gen_demo}[w]()
+         "e2e": gen_e2e, "demo": gen_demo, "e2e_vposer": gen_e2e_vposer}[w]()
