@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsfx.so")
+LIB_PATH = os.environ.get("SFX_LIB", os.path.join(_HERE, "libsfx.so"))
 _lib = None
 
 f32p = C.POINTER(C.c_float)

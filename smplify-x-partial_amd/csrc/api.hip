@@ -111,7 +111,7 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
     if (!d || !out) { sfx_set_error("null argument"); return -1; }
     if (d->J != SFX_J) { sfx_set_error("only J=55 (SMPL-X) is supported, got %d", d->J); return -1; }
     const int V = d->V, S = d->num_betas + d->num_expr, P = 9 * (d->J - 1), KD = S + P;
-    if (KD > SFX_KD_PAD || (KD % 22)) { sfx_set_error("blend-shape depth %d unsupported", KD); return -1; }
+    if (KD > SFX_KD_PAD) { sfx_set_error("blend-shape depth %d unsupported", KD); return -1; }
     if (d->K > SFX_MAX_K) { sfx_set_error("K=%d > %d", d->K, SFX_MAX_K); return -1; }
     int dev_count = 0;
     if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count == 0) {
@@ -126,10 +126,10 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
 
     std::vector<float> vt(d->v_template, d->v_template + (size_t)V * 3);
     M.v_template = m->mem.up(vt);
-    // blend-shape matrix, k-major [KD][3*Vpad] and vertex-major [V][3][KD_PAD]
+    // blend-shape matrix, k-major [KD_PAD][3*Vpad] (zero rows beyond KD) and vertex-major [V][3][KD_PAD]
     {
         const size_t LD = (size_t)3 * M.Vpad;
-        std::vector<float> dirs((size_t)KD * LD, 0.f), dirsT((size_t)V * 3 * SFX_KD_PAD, 0.f);
+        std::vector<float> dirs((size_t)SFX_KD_PAD * LD, 0.f), dirsT((size_t)V * 3 * SFX_KD_PAD, 0.f);
         for (int v = 0; v < V; ++v)
             for (int c = 0; c < 3; ++c) {
                 const float* sd = d->shapedirs + ((size_t)v * 3 + c) * S;
