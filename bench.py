@@ -46,6 +46,12 @@ def lbs_flops_per_frame(V, KD=506, J=55):
     return 2.0 * KD * 3 * V + 2.0 * J * 12 * V + 21.0 * V
 
 
+def lbs_flops_executed_per_frame(V, mean_tile_joints, KDP=512):
+    """MFMA flops the kernel actually issues: K padded to 512; the skinning GEMM only visits the
+    joints that carry weight in each 16-vertex tile (structural zeros of lbs_weights skipped)."""
+    return 2.0 * KDP * 3 * V + 2.0 * mean_tile_joints * 12 * V + 21.0 * V
+
+
 def lbs_bytes_per_launch(B, V, KD=506, J=55):
     const = 4.0 * (KD * 3 * V + J * V + 3 * V)              # dirs + W + template
     return const + B * (3.0 * V * 4 + (KD + 12 * J) * 4)    # vertices out + feat/A in
@@ -201,6 +207,17 @@ def main():
                                "traffic": None, "flops_per_launch": fl / n_dense, "bytes_per_launch": by / n_dense,
                                "hbm_GBps": by / t_tot / 1e9, "hbm_frac": by / t_tot / PEAK_HBM,
                                "avg_launch_us": 1e6 * t_tot / n_dense, "launches": n_dense, "frames_per_launch": fpl}
+            W_ = model["weights"]
+            tj = np.mean([((int((W_[i:i + 16] != 0).any(0).sum()) + 3) // 4) * 4 for i in range(0, dm.V, 16)])
+            fle = u_dense * lbs_flops_executed_per_frame(dm.V, tj)
+            out["roofline"].update({"achieved_executed": fle / t_tot / 1e12, "frac_executed": fle / t_tot / PEAK_MFMA_F32,
+                                    "note": "achieved = SURVEY 8(d) algorithmic flops (dense 55-joint skinning product, 45.85 "
+                                            "MFLOP/frame) / kernel time; achieved_executed counts only issued MFMA work "
+                                            "(K padded to 512, skinning restricted to the %.1f joints per 16-vertex tile that "
+                                            "carry weight)" % tj})
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_lbs_dense.json")
+            if os.path.exists(pmc):
+                out["roofline"]["traffic"] = json.load(open(pmc))
         else:
             # persistent per-frame kernel: bytes the needed-rows closure must move per evaluation
             # (11 vertex rows x (3 x 506 blend-shape + 8 skinning entries), forward and adjoint)

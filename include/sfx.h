@@ -165,11 +165,21 @@ int  sfx_batch_guess_init(sfx_batch* b, const int32_t* pairs /* [n_pairs][2] */,
  * (-1 = camera stage).  Blocks until done.                                                */
 int  sfx_batch_fit(sfx_batch* b, int32_t first_stage, int32_t last_stage, void* stream);
 
+/* sfx_batch_fit for several batches at once (sub-batches of one workload, dense LBS): their MFMA
+ * GEMMs run back to back while every batch's latency-bound optimiser tick overlaps the other
+ * batches' GEMMs on its own stream.  Blocks until all are done; results equal sfx_batch_fit's. */
+int  sfx_fit_multi(sfx_batch** batches, int32_t n, int32_t first_stage, int32_t last_stage);
+
 /* ONE optimizer.step(closure) of LBFGS('lbfgsls') for every frame (lbfgs_ls.py:256-445), for
  * callers that drive run_fitting's outer loop themselves.  resume = 0 starts a fresh optimiser
  * (new stage), 1 continues the previous one (history kept).  loss_out [B] (HOST) receives what
  * step() returns: the loss at entry.                                                        */
 int  sfx_batch_step(sfx_batch* b, int32_t stage, int32_t resume, float* loss_out, void* stream);
+
+/* Gradient of the most recent closure evaluation of every frame, grad_out [B][num_vars(stage)]
+ * (HOST): what `var.grad` holds after optimizer.step() in the reference, which run_fitting's
+ * gtol test reads (fitting.py:191-193).                                                       */
+int  sfx_batch_get_grad(sfx_batch* b, int32_t stage, float* grad_out);
 
 /* Per-frame results of the last sfx_batch_fit (HOST pointers, any may be NULL):
  *  stage_loss [B][1+n_stages]  value run_fitting returns per stage (camera first)

@@ -69,7 +69,9 @@ SYMBOLS = {
     "sfx_batch_closure": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_void_p]),
     "sfx_batch_guess_init": (C.c_int, [C.c_void_p, i32p, C.c_int32, C.c_void_p]),
     "sfx_batch_fit": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "sfx_fit_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32]),
     "sfx_batch_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, C.c_void_p]),
+    "sfx_batch_get_grad": (C.c_int, [C.c_void_p, C.c_int32, f32p]),
     "sfx_batch_get_stats": (C.c_int, [C.c_void_p, f32p, i32p, i32p]),
     "sfx_batch_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sfx_debug_phase_clocks": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),

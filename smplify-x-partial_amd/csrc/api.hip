@@ -159,6 +159,23 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
         M.Wsp_j = m->mem.up(wj); M.Wsp_w = m->mem.up(ww);
         M.W = m->mem.up(W);
         M.WT = m->mem.up(WT);
+        // per 16-vertex tile: the joints with any nonzero weight (ascending), weights in MFMA B layout
+        const int nt = M.Vpad / 16;
+        std::vector<int> tn(nt, 0), tl((size_t)nt * SFX_JPAD, 0);
+        std::vector<float> tw((size_t)nt * SFX_JPAD * 16, 0.f);
+        for (int t = 0; t < nt; ++t) {
+            int n = 0;
+            for (int j = 0; j < SFX_J; ++j) {
+                bool used = false;
+                for (int q = 0; q < 16 && !used; ++q) { const int v = t * 16 + q; used = v < V && W[(size_t)v * SFX_J + j] != 0.f; }
+                if (!used) continue;
+                tl[(size_t)t * SFX_JPAD + n] = j;
+                for (int q = 0; q < 16; ++q) { const int v = t * 16 + q; tw[((size_t)t * SFX_JPAD + n) * 16 + q] = v < V ? W[(size_t)v * SFX_J + j] : 0.f; }
+                ++n;
+            }
+            tn[t] = ((n + 3) / 4) * 4;
+        }
+        M.tj_n = m->mem.up(tn); M.tj_list = m->mem.up(tl); M.tj_w = m->mem.up(tw);
     }
     // folded joint regressor: J = J_template + J_dirs . coeff   (J_regressor . v_shaped)
     {
@@ -683,6 +700,99 @@ extern "C" int sfx_batch_fit(sfx_batch* b, int32_t first_stage, int32_t last_sta
     return run_ticks(b, first_stage, last_stage, 1, 0, (hipStream_t)stream);
 }
 
+// Software pipeline over several independent batches (sub-batches of one workload), dense mode:
+// each batch has its own stream; the MFMA GEMMs of the batches are chained by events
+// (GEMM_0 -> GEMM_1 -> ... -> GEMM_0 ...) so they run back to back, while each batch's
+// latency-bound tick kernel (loss/adjoint -> L-BFGS tick -> next pose/chain) runs on its own stream
+// underneath the other batches' GEMMs.  Frames are independent: results equal sfx_batch_fit's.
+extern "C" int sfx_fit_multi(sfx_batch** bs, int32_t n, int32_t first_stage, int32_t last_stage) {
+    if (!bs || n < 1) { sfx_set_error("bad arguments"); return -1; }
+    for (int g = 0; g < n; ++g) {
+        if (!bs[g]) { sfx_set_error("null batch"); return -1; }
+        if (first_stage < -1 || last_stage >= bs[g]->D.cfg.n_stages || last_stage < first_stage) {
+            sfx_set_error("bad stage range [%d,%d]", first_stage, last_stage); return -1; }
+    }
+    bool all_dense = true;
+    for (int g = 0; g < n; ++g) all_dense = all_dense && bs[g]->D.cfg.lbs_mode == 1;
+    if (n == 1 || !all_dense || g_unfused) {
+        for (int g = 0; g < n; ++g) { int rc = run_ticks(bs[g], first_stage, last_stage, 1, 0, 0); if (rc) return rc; }
+        return 0;
+    }
+    std::vector<hipStream_t> st(n);
+    std::vector<hipEvent_t> ev(n);
+    std::vector<int*> hp(n);
+    std::vector<char> done(n, 0);
+    for (int g = 0; g < n; ++g) {
+        SFX_CHECK(hipStreamCreateWithFlags(&st[g], hipStreamNonBlocking));
+        SFX_CHECK(hipEventCreateWithFlags(&ev[g], hipEventDisableTiming));
+        hp[g] = bs[g]->stage_host;
+        if (!hp[g]) { sfx_set_error("pinned buffer missing"); return -2; }
+    }
+    SFX_CHECK(hipDeviceSynchronize());
+    for (int g = 0; g < n; ++g) {
+        sfx_batch* b = bs[g];
+        launch_lbfgs_tick(b->m->M, b->D, b->vl_dev, first_stage, last_stage, 1, 0, st[g]);
+        ProfScope p("tick", st[g]);
+        launch_tick_dense(b->m->M, b->D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, st[g]);
+    }
+    long tick = 0;
+    long max_ticks = 0;
+    for (int g = 0; g < n; ++g) max_ticks = std::max(max_ticks, (long)(last_stage - first_stage + 1) * bs[g]->D.cfg.maxiters * 160 + 64);
+    int remaining = n, prev = -1;
+    int rc = 0;
+    while (remaining > 0 && tick < max_ticks && rc == 0) {
+        for (int q = 0; q < 8; ++q, ++tick) {
+            for (int g = 0; g < n; ++g) {
+                if (done[g]) continue;
+                sfx_batch* b = bs[g];
+                if (prev >= 0 && prev != g) hipStreamWaitEvent(st[g], ev[prev], 0);   // GEMMs back to back
+                { ProfScope p("lbs_dense", st[g], b->D.nact); launch_lbs_dense(b->m->M, b->D, st[g]); }
+                hipEventRecord(ev[g], st[g]);
+                prev = g;
+                ProfScope p("tick", st[g]);
+                launch_tick_dense(b->m->M, b->D, b->vl_dev, b->sw_dev, first_stage, last_stage, 1, st[g]);
+            }
+        }
+        for (int g = 0; g < n; ++g)
+            if (!done[g]) hipMemcpyAsync(hp[g], bs[g]->D.stage, (size_t)bs[g]->D.cfg.B * sizeof(int), hipMemcpyDeviceToHost, st[g]);
+        for (int g = 0; g < n; ++g) {
+            if (done[g]) continue;
+            sfx_batch* b = bs[g];
+            const int B = b->D.cfg.B;
+            if (hipStreamSynchronize(st[g]) != hipSuccess) { sfx_set_error("stream sync failed"); rc = -2; break; }
+            int nact = 0;
+            for (int i = 0; i < B; ++i) if (hp[g][i] <= last_stage) ++nact;
+            if (nact == 0) { done[g] = 1; --remaining; if (prev == g) prev = -1; continue; }
+            if ((b->D.nact + 31) / 32 != (nact + 31) / 32) {
+                std::vector<int>& sl = b->slot_host;
+                sl.assign(B, 0);
+                int k = 0;
+                for (int i = 0; i < B; ++i) sl[i] = (hp[g][i] <= last_stage) ? k++ : 0;
+                hipMemcpyAsync(b->D.slot, sl.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st[g]);
+                hipStreamSynchronize(st[g]);        // sl is reused: finish the copy before the next remap
+                b->D.nact = nact;
+                ProfScope p("tick", st[g]);
+                launch_tick_dense(b->m->M, b->D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, st[g]);
+            }
+        }
+    }
+    for (int g = 0; g < n; ++g) {
+        sfx_batch* b = bs[g];
+        const int B = b->D.cfg.B;
+        std::vector<int>& sl = b->slot_host;
+        sl.resize(B);
+        for (int i = 0; i < B; ++i) sl[i] = i;
+        hipMemcpyAsync(b->D.slot, sl.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st[g]);
+        hipStreamSynchronize(st[g]);
+        b->D.nact = B;
+        hipStreamDestroy(st[g]); hipEventDestroy(ev[g]);
+    }
+    SFX_CHECK(hipGetLastError());
+    if (rc) return rc;
+    if (remaining > 0) { sfx_set_error("fit did not finish within %ld ticks", max_ticks); return -4; }
+    return 0;
+}
+
 extern "C" int sfx_batch_step(sfx_batch* b, int32_t stage, int32_t resume, float* loss_out, void* stream) {
     if (!b) { sfx_set_error("null batch"); return -1; }
     if (stage < -1 || stage >= b->D.cfg.n_stages) { sfx_set_error("stage %d out of range", stage); return -1; }
@@ -694,6 +804,16 @@ extern "C" int sfx_batch_step(sfx_batch* b, int32_t stage, int32_t resume, float
         SFX_CHECK(hipMemcpy(l.data(), b->D.stage_loss, l.size() * 4, hipMemcpyDeviceToHost));
         for (int i = 0; i < B; ++i) loss_out[i] = l[(size_t)i * (1 + SFX_MAX_STAGES) + stage + 1];
     }
+    return 0;
+}
+
+extern "C" int sfx_batch_get_grad(sfx_batch* b, int32_t stage, float* grad_out) {
+    if (!b || !grad_out) { sfx_set_error("null argument"); return -1; }
+    if (stage < -1 || stage >= b->D.cfg.n_stages) { sfx_set_error("stage %d out of range", stage); return -1; }
+    const int B = b->D.cfg.B, n = b->vl_host[stage < 0 ? 0 : 1].n;
+    std::vector<float> g((size_t)B * SFX_NVAR_MAX);
+    SFX_CHECK(hipMemcpy(g.data(), b->D.g, g.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < B; ++i) memcpy(grad_out + (size_t)i * n, g.data() + (size_t)i * SFX_NVAR_MAX, (size_t)n * 4);
     return 0;
 }
 

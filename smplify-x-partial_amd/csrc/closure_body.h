@@ -18,6 +18,10 @@
 #pragma once
 #include "sfx_internal.h"
 #include "wave_ops.h"
+// contraction only inside one source expression (decided by the front end): the stand-alone
+// closure kernel and the fused fit kernels then round identically, so optimizer.step() driven from
+// the host and sfx_batch_fit walk the same trajectory bit for bit
+#pragma clang fp contract(on)
 #include "vposer.h"
 
 #define CT 256
@@ -30,7 +34,8 @@
 #define FD_REG (FD_CAMR + 12)
 #define FD_N (FD_REG + 64)
 // debug timing: block 0 / thread 0 stores the shader clock at phase boundaries when D.dbg != NULL
-#define MARK(i) do { if (D.dbg && blockIdx.x == 0 && threadIdx.x == 0) D.dbg[i] = clock64(); } while (0)
+#define MARK(i) do { if (D.dbg && blockIdx.x == 0 && threadIdx.x == 0) { D.dbg[i] = clock64();             \
+        if ((i) == 0) D.dbg[17] = wall_clock64(); if ((i) == 16) D.dbg[18] = wall_clock64(); } } while (0)
 
 struct __align__(16) FrameLDS {
     float feat[SFX_KD_PAD];        // first: read as float4
@@ -546,16 +551,35 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
         S.dA[w] = acc;
     }
     MARK(11);
-    // dfeat[k] = sum_items sum_c dirsT[v][c][k] * dvp[c]
-    for (int k = t; k < M.KD; k += CT) {
-        float acc = 0.f;
-        for (int i = 0; i < NI; ++i) {
-            const float d0 = S.dvp[i * 3], d1 = S.dvp[i * 3 + 1], d2 = S.dvp[i * 3 + 2];
-            if (d0 == 0.f && d1 == 0.f && d2 == 0.f) continue;
-            const float* row = M.dirsT + (size_t)S.ivid[i] * 3 * SFX_KD_PAD + k;
-            acc += row[0] * d0 + row[SFX_KD_PAD] * d1 + row[2 * SFX_KD_PAD] * d2;
+    // dfeat[k] = sum_items sum_c dirsT[v][c][k] * dvp[c]: each wavefront streams whole 2-KiB rows
+    // (4 in flight), lane l keeps k = 4l..4l+3 and 256+4l..+3; the 4 per-wave partials are added
+    // in wave order (fixed association -> deterministic)
+    {
+        float4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
+        for (int w0 = wv * 4; w0 < NI * 3; w0 += (CT / 64) * 4) {
+            float4 da[4], db[4]; float dv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int w = (w0 + u < NI * 3) ? w0 + u : w0;
+                dv[u] = (w0 + u < NI * 3) ? S.dvp[w] : 0.f;
+                const float4* row = reinterpret_cast<const float4*>(M.dirsT + ((size_t)S.ivid[w / 3] * 3 + w % 3) * SFX_KD_PAD);
+                if (dv[u] != 0.f) { da[u] = row[lane]; db[u] = row[64 + lane]; }
+                else { da[u] = pa; db[u] = pa; dv[u] = 0.f; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                pa.x += da[u].x * dv[u]; pa.y += da[u].y * dv[u]; pa.z += da[u].z * dv[u]; pa.w += da[u].w * dv[u];
+                pb.x += db[u].x * dv[u]; pb.y += db[u].y * dv[u]; pb.z += db[u].z * dv[u]; pb.w += db[u].w * dv[u];
+            }
         }
-        S.dfeat[k] = acc;
+        float4* part = reinterpret_cast<float4*>(S.T);          // S.T is dead here: 4 x 512 floats of scratch
+        part[wv * 128 + lane] = pa; part[wv * 128 + 64 + lane] = pb;
+        __syncthreads();
+        for (int k = t; k < SFX_KD_PAD; k += CT) {
+            const int l4 = (k & 255) >> 2, hi = k >> 8, c = k & 3;
+            const float* pf = S.T + (hi * 64 + l4) * 4 + c;
+            S.dfeat[k] = ((pf[0] + pf[512]) + pf[1024]) + pf[1536];
+        }
     }
     __syncthreads();
     MARK(12);
@@ -623,11 +647,21 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
         float dth[3] = {0.f, 0.f, 0.f};
         rodrigues_bwd(&S.full_pose[3 * t], &S.dR[t * 9], dth);
         S.dpose[3 * t] += dth[0]; S.dpose[3 * t + 1] += dth[1]; S.dpose[3 * t + 2] += dth[2];
-    } else if (t >= 64 && t < 64 + M.S) {
-        const int l = t - 64;
-        float acc = S.dfeat[l];
-        for (int i = 0; i < SFX_J * 3; ++i) acc += M.J_dirs[(size_t)i * M.S + l] * S.dJ[i];
-        if (l < L.NB) S.gc[L.betas + l] += acc; else S.gc[L.expr + l - L.NB] += acc;
+    }
+    {   // d(coefficients) = dfeat[0..S) + J_dirs^T dJ : 12 partial sums of 14 rows per coefficient
+        const int l = t % 20, ch = t / 20;
+        float acc = 0.f;
+        if (ch < 12 && l < M.S) {
+            const int i1 = (ch * 14 + 14 < SFX_J * 3) ? ch * 14 + 14 : SFX_J * 3;
+            for (int i = ch * 14; i < i1; ++i) acc += M.J_dirs[(size_t)i * M.S + l] * S.dJ[i];
+        }
+        S.red[t] = acc;
+    }
+    __syncthreads();
+    if (t < M.S) {
+        float acc = S.dfeat[t];
+        for (int ch = 0; ch < 12; ++ch) acc += S.red[ch * 20 + t];
+        if (t < L.NB) S.gc[L.betas + t] += acc; else S.gc[L.expr + t - L.NB] += acc;
     }
     __syncthreads();
     MARK(14);
@@ -653,3 +687,4 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
     MARK(16);
 }
 
+#pragma clang fp contract(fast)

@@ -19,6 +19,9 @@
 // every multiply-add in this file is written out: no implicit contraction (see header comment)
 #pragma clang fp contract(off)
 // single-wavefront synchronisation: order LDS/global accesses of the 64 lanes
+#ifndef LB_CH
+#define LB_CH 8       // history rows per register set of the two-loop recursion (two sets in flight)
+#endif
 #define LB_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 enum { PH_ENTRY = 0, PH_BRACKET = 1, PH_ZOOM = 2 };
@@ -189,7 +192,7 @@ __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDe
 #define VEC(k) (vec + (k) * SFX_NVAR_MAX)
 
     // ---------------------------------------------------------------- (re)initialisation
-    if (init) {
+    if (init == 1) {
         const OptScal s = fresh_state();
         stage = first_stage;
         if (lane == 0) {
@@ -214,7 +217,7 @@ __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDe
         return;
     }
     if (init == 2) {           // resume after a pause (optimizer.step granularity): keep the state
-        if (stage >= 1000 && lane == 0) D.stage[b] = stage - 1000;
+        if (stage >= 900 && lane == 0) D.stage[b] = stage - 1000;   // camera stage -1 pauses as 999
         for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
         return;
     }
@@ -355,52 +358,60 @@ __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDe
                 LB_SYNC();
                 Lane3 q;
                 for (int e = 0; e < NE3; ++e) q.v[e] = -g.v[e];
-                // two-loop recursion; history rows are prefetched CH at a time so that the
-                // serial chain is dot/axpy latency only, not HBM latency
-                constexpr int CH = 16;
-                for (int i0 = s.hist_n - 1; i0 >= 0; i0 -= CH) {
-                    Lane3 Sb[CH], Yb[CH]; float rb[CH];
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        const int i = i0 - c;
-                        const int ph = (s.hist_head + (i >= 0 ? i : 0)) % SFX_HIST;
-                        Sb[c] = ld3(hS + (size_t)ph * SFX_NVAR_MAX, lane, N);
-                        Yb[c] = ld3(hY + (size_t)ph * SFX_NVAR_MAX, lane, N);
-                        rb[c] = gst->ro[ph];
-                    }
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        const int i = i0 - c;
-                        if (i >= 0) {
-                            const float al = dot3(Sb[c], q) * rb[c];
-                            if (lane == 0) s_al[i] = al;
-                            q = axpy3(q, -al, Yb[c]);
-                        }
+                // two-loop recursion.  History rows are fetched CH at a time into one register set
+                // while the previous CH rows are consumed from the other (software double buffering),
+                // so the serial chain sees dot/axpy latency only, not HBM latency.
+                constexpr int CH = LB_CH;
+                Lane3 SA[CH], YA[CH], SB[CH], YB[CH];
+                float rA[CH], rB[CH];
+#define LB_LOAD(Sx, Yx, rx, base, dir) do { _Pragma("unroll") for (int c = 0; c < CH; ++c) {                 \
+                    const int i_ = (base) + (dir) * c;                                                       \
+                    const int ph_ = (s.hist_head + ((i_ >= 0 && i_ < s.hist_n) ? i_ : 0)) % SFX_HIST;        \
+                    Sx[c] = ld3(hS + (size_t)ph_ * SFX_NVAR_MAX, lane, N);                                   \
+                    Yx[c] = ld3(hY + (size_t)ph_ * SFX_NVAR_MAX, lane, N);                                   \
+                    rx[c] = gst->ro[ph_]; } } while (0)
+#define LB_DOWN(Sx, Yx, rx, base) do { _Pragma("unroll") for (int c = 0; c < CH; ++c) {                      \
+                    const int i_ = (base) - c;                                                               \
+                    if (i_ >= 0) { const float al = dot3(Sx[c], q) * rx[c];                                   \
+                                   if (lane == 0) s_al[i_] = al;                                             \
+                                   q = axpy3(q, -al, Yx[c]); } } } while (0)
+#define LB_UP(Sx, Yx, rx, base) do { _Pragma("unroll") for (int c = 0; c < CH; ++c) {                        \
+                    const int i_ = (base) + c;                                                               \
+                    if (i_ < s.hist_n) { const float be = dot3(Yx[c], r) * rx[c];                             \
+                                         r = axpy3(r, s_al[i_] - be, Sx[c]); } } } while (0)
+                {
+                    int i0 = s.hist_n - 1;
+                    LB_LOAD(SA, YA, rA, i0, -1);
+                    while (i0 >= 0) {
+                        LB_LOAD(SB, YB, rB, i0 - CH, -1);
+                        LB_DOWN(SA, YA, rA, i0);
+                        i0 -= CH;
+                        if (i0 < 0) break;
+                        LB_LOAD(SA, YA, rA, i0 - CH, -1);
+                        LB_DOWN(SB, YB, rB, i0);
+                        i0 -= CH;
                     }
                 }
                 LB_SYNC();
                 Lane3 r;
                 const float hd = (float)s.H_diag.v;
                 for (int e = 0; e < NE3; ++e) r.v[e] = q.v[e] * hd;
-                for (int i0 = 0; i0 < s.hist_n; i0 += CH) {
-                    Lane3 Sb[CH], Yb[CH]; float rb[CH], ab[CH];
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        const int i = i0 + c;
-                        const int ph = (s.hist_head + (i < s.hist_n ? i : 0)) % SFX_HIST;
-                        Sb[c] = ld3(hS + (size_t)ph * SFX_NVAR_MAX, lane, N);
-                        Yb[c] = ld3(hY + (size_t)ph * SFX_NVAR_MAX, lane, N);
-                        rb[c] = gst->ro[ph];
-                        ab[c] = s_al[i < s.hist_n ? i : 0];
-                    }
-#pragma unroll
-                    for (int c = 0; c < CH; ++c) {
-                        if (i0 + c < s.hist_n) {
-                            const float be = dot3(Yb[c], r) * rb[c];
-                            r = axpy3(r, ab[c] - be, Sb[c]);
-                        }
+                {
+                    int i0 = 0;
+                    LB_LOAD(SA, YA, rA, i0, 1);
+                    while (i0 < s.hist_n) {
+                        LB_LOAD(SB, YB, rB, i0 + CH, 1);
+                        LB_UP(SA, YA, rA, i0);
+                        i0 += CH;
+                        if (i0 >= s.hist_n) break;
+                        LB_LOAD(SA, YA, rA, i0 + CH, 1);
+                        LB_UP(SB, YB, rB, i0);
+                        i0 += CH;
                     }
                 }
+#undef LB_LOAD
+#undef LB_DOWN
+#undef LB_UP
                 d = r;
             }
             st3(VEC(VEC_D), d, lane, N);

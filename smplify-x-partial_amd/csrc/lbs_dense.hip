@@ -123,20 +123,24 @@ void k_lbs_dense(DevModel M, BatchDev D) {
     return;
 #endif
     const bool vok = vtx < V;
+    // skinning GEMM T = W . A restricted to the joints that carry weight in this 16-vertex tile
+    // (exact: the skipped products are structural zeros of lbs_weights; ascending joint order kept)
+    const int tile = blockIdx.x;
+    const int njs = M.tj_n[tile] >> 2;
+    const int* jl4 = M.tj_list + (size_t)tile * SFX_JPAD + kq;
+    const float* wl = M.tj_w + ((size_t)tile * SFX_JPAD + kq) * 16 + jl;
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr) {
         f32x4 t00 = {0, 0, 0, 0}, t01 = t00, t02 = t00, t03 = t00, t10 = t00, t11 = t00, t12 = t00, t13 = t00;
-        const float* wt = M.WT + (size_t)kq * M.Vpad + v0 + jl;
-        const float* at = D.AT + ((size_t)(rr * 4) * SFX_JPAD + kq) * Bp + b0 + jl;
+        const float* at0 = D.AT + ((size_t)(rr * 4) * SFX_JPAD) * Bp + b0 + jl;
         const size_t estep = (size_t)SFX_JPAD * Bp;
-#pragma unroll 7
-        for (int js = 0; js < SFX_JPAD / 4; ++js) {
-            const float w = wt[0];
+        for (int js = 0; js < njs; ++js) {
+            const float w = wl[js * 64];
+            const float* at = at0 + (size_t)jl4[js * 4] * Bp;
             const float p0 = at[0], p1 = at[estep], p2 = at[2 * estep], p3 = at[3 * estep];
             const float q0 = at[16], q1 = at[estep + 16], q2 = at[2 * estep + 16], q3 = at[3 * estep + 16];
             t00 = MFMA(p0, w, t00); t01 = MFMA(p1, w, t01); t02 = MFMA(p2, w, t02); t03 = MFMA(p3, w, t03);
             t10 = MFMA(q0, w, t10); t11 = MFMA(q1, w, t11); t12 = MFMA(q2, w, t12); t13 = MFMA(q3, w, t13);
-            wt += (size_t)4 * M.Vpad; at += 4 * Bp;
         }
         if (vok) {
 #pragma unroll

@@ -61,6 +61,10 @@ struct DevModel {
     const float* dirsT;        // [V][3][KD_PAD] vertex-major (needed-rows path)
     const float* W;            // [V][J]
     const float* WT;           // [JPAD][Vpad]   (dense skinning GEMM B operand)
+    // dense skinning GEMM, compressed per 16-vertex tile to the joints that carry weight there
+    const int*   tj_n;         // [ntile16] joints used by the tile, padded to a multiple of 4 (<= JPAD)
+    const int*   tj_list;      // [ntile16][JPAD] joint ids (padding: joint 0 with zero weights)
+    const float* tj_w;         // [ntile16][JPAD][16] weights, row = list slot, col = vertex in tile
     const int*   Wsp_j;        // [V][SFX_NW] joints of the nonzero weights (ascending), pad: j=0,w=0
     const float* Wsp_w;        // [V][SFX_NW]
     const float* J_template;   // [J][3]

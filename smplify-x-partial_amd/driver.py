@@ -63,34 +63,10 @@ def prepare_frames(cfg, keypoints, joint_weights, reg_pose=None, reg_global=None
     return dict(keypoints=kp, jw=jw, cmask=cmask, try_both=both)
 
 
-def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, reg_global=None,
-               cam_prior_t=None, cam_prior_center=None, lbs_mode="dense", reuse_entry_eval=True,
-               want_vertices=False, groups=1, _stream=None):
-    """Fit B frames.  Arrays are [B, ...]; H, W, focal scalars or [B].  Returns a dict of
-    [B, ...] arrays: the reference's result-pkl fields + per-stage losses / evaluation counts.
-
-    groups > 1 splits the frames into that many independent sub-batches, each driven from its
-    own host thread on its own HIP stream: while one group's latency-bound optimiser tick runs,
-    another group's MFMA GEMM fills the CUs (frames are independent, results are unchanged)."""
-    B_all = np.asarray(keypoints).shape[0]
-    if groups > 1 and B_all >= 2 * groups:
-        import torch
-        from concurrent.futures import ThreadPoolExecutor
-        cuts = [(B_all * g) // groups for g in range(groups + 1)]
-        per = lambda a, lo, hi: None if a is None else (np.asarray(a)[lo:hi] if np.ndim(a) > 0 and np.asarray(a).shape[0] == B_all else a)
-        jw_all = np.asarray(joint_weights)
-        jw_is_per_frame = jw_all.ndim == 2 and jw_all.shape[0] == B_all
-
-        def run(g):
-            lo, hi = cuts[g], cuts[g + 1]
-            st = torch.cuda.Stream()
-            return fit_frames(dm, cfg, np.asarray(keypoints)[lo:hi], jw_all[lo:hi] if jw_is_per_frame else jw_all,
-                              per(H, lo, hi), per(W, lo, hi), per(focal, lo, hi), per(reg_pose, lo, hi),
-                              per(reg_global, lo, hi), per(cam_prior_t, lo, hi), per(cam_prior_center, lo, hi),
-                              lbs_mode, reuse_entry_eval, want_vertices, groups=1, _stream=st.cuda_stream)
-        with ThreadPoolExecutor(groups) as ex:
-            parts = list(ex.map(run, range(groups)))
-        return {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}
+def _make_batch(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose, reg_global, cam_prior_t,
+                cam_prior_center, lbs_mode, reuse_entry_eval):
+    """FrameBatch with frames, parameters and the initial camera set the way
+    fit_single_frame.py:209-294,358-411 prepares one frame."""
     prep = prepare_frames(cfg, keypoints, joint_weights)
     kp = prep["keypoints"]
     B, K = kp.shape[:2]
@@ -117,22 +93,59 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
                                    else np.zeros((B, 3), np.float32)))
     if not use_cam_prior:
         fb.guess_init(cfg.get("body_tri_idxs", [(5, 12), (2, 9)]))
-    # ---- camera stage + body stages; frames change stage independently on device.  Side views
-    #      (2-D shoulder distance < side_view_thsh, fit_single_frame.py:461-463) are fitted a second
-    #      time from the orientation flipped by pi about y and the lower final loss is kept
-    #      (:527-551,662-667) -- also on device, inside the same batch.
-    fb.fit(first_stage=-1, last_stage=fb.n_stages - 1, stream=_stream)
+    return fb, prep
+
+
+def _collect(fb, prep, want_vertices):
     st = fb.stats()
     out = dict(fb.get_params())
     out.update(stage_loss=st["stage_loss"].copy(), stage_evals=st["stage_evals"].copy(),
                stage_ref_evals=st["stage_ref_evals"].copy(),
                n_orient=np.where(prep["try_both"] & (fb.n_stages > 0), 2, 1).astype(np.int32))
-    verts = joints = None
-    if want_vertices:
-        v, j = fb.forward()
-        verts, joints = v.cpu().numpy(), j.cpu().numpy()
     out["final_loss"] = out["stage_loss"][:, -1].copy()
     if want_vertices:
-        out["vertices"], out["joints"] = verts, joints
+        v, j = fb.forward()
+        out["vertices"], out["joints"] = v.cpu().numpy(), j.cpu().numpy()
     fb.close()
     return out
+
+
+def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, reg_global=None,
+               cam_prior_t=None, cam_prior_center=None, lbs_mode="dense", reuse_entry_eval=True,
+               want_vertices=False, groups=1):
+    """Fit B frames.  Arrays are [B, ...]; H, W, focal scalars or [B].  Returns a dict of
+    [B, ...] arrays: the reference's result-pkl fields + per-stage losses / evaluation counts.
+
+    The whole schedule -- camera stage, body stages, and for side views (2-D shoulder distance
+    < side_view_thsh, fit_single_frame.py:461-463) the second fit from the orientation flipped
+    by pi about y with the lower final loss kept (:527-551,662-667) -- runs on device; frames
+    change stage independently.
+
+    groups > 1 splits the frames into that many sub-batches that are pipelined through the GPU
+    (sfx_fit_multi): the MFMA GEMMs of the sub-batches run back to back while each sub-batch's
+    latency-bound optimiser tick hides under the others' GEMMs.  Results are unchanged."""
+    B_all = np.asarray(keypoints).shape[0]
+    groups = max(1, min(int(groups), B_all // 32)) if lbs_mode == "dense" else 1
+    cuts = [(B_all * g) // groups for g in range(groups + 1)]
+    jw_all = np.asarray(joint_weights)
+    jw_per_frame = jw_all.ndim == 2 and jw_all.shape[0] == B_all and B_all > 1
+
+    def per(a, lo, hi):
+        if a is None:
+            return None
+        a = np.asarray(a)
+        return a[lo:hi] if a.ndim > 0 and a.shape[0] == B_all and B_all > 1 else a
+    made = []
+    for g in range(groups):
+        lo, hi = cuts[g], cuts[g + 1]
+        made.append(_make_batch(dm, cfg, np.asarray(keypoints)[lo:hi], jw_all[lo:hi] if jw_per_frame else jw_all,
+                                per(H, lo, hi), per(W, lo, hi), per(focal, lo, hi), per(reg_pose, lo, hi),
+                                per(reg_global, lo, hi), per(cam_prior_t, lo, hi), per(cam_prior_center, lo, hi),
+                                lbs_mode, reuse_entry_eval))
+    fbs = [m[0] for m in made]
+    if groups == 1:
+        fbs[0].fit(first_stage=-1, last_stage=fbs[0].n_stages - 1)
+    else:
+        engine.fit_multi(fbs, first_stage=-1, last_stage=fbs[0].n_stages - 1)
+    parts = [_collect(fb, prep, want_vertices) for fb, prep in made]
+    return {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}

@@ -272,6 +272,12 @@ class FrameBatch(object):
         capi.check(self._lib.sfx_batch_step(self._h, stage, int(bool(resume)), capi.fptr(loss), None))
         return loss
 
+    def last_grad(self, stage):
+        """Gradient [B,N] of the most recent closure evaluation (what var.grad holds after step())."""
+        grad = np.zeros((self.B, self.num_vars(stage)), np.float32)
+        capi.check(self._lib.sfx_batch_get_grad(self._h, stage, capi.fptr(grad)))
+        return grad
+
     def stats(self):
         ns = self.n_stages + 1
         loss = np.zeros((self.B, ns), np.float32)
@@ -300,6 +306,13 @@ class FrameBatch(object):
             self.close()
         except Exception:
             pass
+
+
+def fit_multi(batches, first_stage=-1, last_stage=None):
+    """sfx_fit_multi: pipeline several FrameBatches (same configuration) through the GPU."""
+    last = batches[0].n_stages - 1 if last_stage is None else last_stage
+    arr = (C.c_void_p * len(batches))(*[b._h for b in batches])
+    capi.check(capi.load().sfx_fit_multi(arr, len(batches), first_stage, last))
 
 
 def prof_enable(on=True):

@@ -244,15 +244,18 @@ class EngineClosure(object):
         self._push(fb)
         loss, grad = fb.closure(-1 if self.is_camera else 0)
         if backward:
-            o = 0
-            for p in self._var_params():
-                n = p.numel()
-                gsl = torch.as_tensor(grad[0, o:o + n]).reshape(p.shape).to(p)
-                p.grad = gsl if not (self._is_dead(p)) else None
-                o += n
+            self._set_grads(grad)
         self.monitor.steps += 1
         dev = self.body_model.faces_tensor.device
         return torch.tensor(float(loss[0]), dtype=torch.float32, device=dev)
+
+    def _set_grads(self, grad):
+        o = 0
+        for p in self._var_params():
+            n = p.numel()
+            gsl = torch.as_tensor(grad[0, o:o + n]).reshape(p.shape).to(p)
+            p.grad = gsl if not (self._is_dead(p)) else None
+            o += n
 
     def _is_dead(self, p):
         return (not self.use_vposer) and hasattr(self.body_model, "body_pose") and p is self.body_model.body_pose
@@ -274,6 +277,7 @@ class EngineClosure(object):
         loss = fb.step(-1 if self.is_camera else 0, resume=self._stepped)
         self._stepped = True
         self._pull(fb)
+        self._set_grads(fb.last_grad(-1 if self.is_camera else 0))      # var.grad after step()
         dev = self.body_model.faces_tensor.device
         return torch.tensor(float(loss[0]), dtype=torch.float32, device=dev)
 

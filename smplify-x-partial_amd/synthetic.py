@@ -94,7 +94,9 @@ def make_synthetic_model(seed=0, num_verts=NUM_VERTS, num_faces=NUM_FACES,
     share[[1, 2, 4, 5, 7, 8]] = 3.0
     share[[16, 17, 18, 19, 20, 21]] = 2.5
     share[25:] = 0.6
-    bone_of = rng.choice(J, size=V, p=share / share.sum())
+    # vertices are numbered bone by bone (real meshes are spatially coherent too: neighbouring
+    # vertex ids share their few skinning joints)
+    bone_of = np.sort(rng.choice(J, size=V, p=share / share.sum()))
     t = rng.uniform(0.0, 1.0, size=V)
     v_template = np.zeros((V, 3))
     weights = np.zeros((V, J))

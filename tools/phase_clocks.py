@@ -13,4 +13,5 @@ for which in ('body','full'):
     for st in (-1, 1):
         _capi.check(_capi.load().sfx_debug_phase_clocks(fb._h, st, out))
         t = np.array(list(out)[:17], np.float64); d = np.diff(t)
-        print(which, 'stage', st, 'total cycles', t[16]-t[0], 'phases', d.astype(int).tolist())
+        wall = (out[18] - out[17]) * 0.01   # 100 MHz constant clock -> us
+        print(which, 'stage', st, 'total cycles', t[16]-t[0], 'wall us', wall, 'phases', d.astype(int).tolist())
