@@ -202,6 +202,11 @@ void sfx_prof_reset(void);
 /* Debug: shader-clock stamps at the phase boundaries of one closure launch (block 0). */
 int  sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out /* [32] */);
 
+/* Debug: attach (enable=1) a 64-slot clock buffer to the batch, run any entry point, then read it
+ * and detach (enable=0): out[0..18] = closure phase stamps of the last launch, out[32+i] =
+ * shader-clock cycles frame 0 spent between optimiser-tick marks i-1 and i, out[63] = ticks.  */
+int  sfx_debug_clocks(sfx_batch* b, int32_t enable, int64_t* out /* [64] or NULL */);
+
 const char* sfx_last_error(void);
 const char* sfx_version(void);
 

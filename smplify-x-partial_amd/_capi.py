@@ -75,6 +75,7 @@ SYMBOLS = {
     "sfx_batch_get_stats": (C.c_int, [C.c_void_p, f32p, i32p, i32p]),
     "sfx_batch_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sfx_debug_phase_clocks": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
+    "sfx_debug_clocks": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "sfx_prof_enable": (C.c_int, [C.c_int32]),
     "sfx_prof_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "sfx_prof_reset": (None, []),

@@ -549,6 +549,24 @@ extern "C" int sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out 
     return 0;
 }
 
+// debug: attach (enable=1) / read out and detach (enable=0) the 64-slot clock buffer; while attached,
+// closure launches stamp dbg[0..18] and optimiser ticks of frame 0 accumulate dbg[32..63]
+extern "C" int sfx_debug_clocks(sfx_batch* b, int32_t enable, int64_t* out /* [64] or NULL */) {
+    if (!b) { sfx_set_error("null batch"); return -1; }
+    if (enable) {
+        if (!b->D.dbg) SFX_CHECK(hipMalloc((void**)&b->D.dbg, 64 * sizeof(long long)));
+        SFX_CHECK(hipMemset(b->D.dbg, 0, 64 * sizeof(long long)));
+        return 0;
+    }
+    if (!b->D.dbg) { sfx_set_error("clock buffer not attached"); return -1; }
+    SFX_CHECK(hipDeviceSynchronize());
+    long long h[64];
+    SFX_CHECK(hipMemcpy(h, b->D.dbg, sizeof(h), hipMemcpyDeviceToHost));
+    hipFree(b->D.dbg); b->D.dbg = nullptr;
+    if (out) for (int i = 0; i < 64; ++i) out[i] = h[i];
+    return 0;
+}
+
 extern "C" int sfx_batch_num_vars(sfx_batch* b, int32_t stage) {
     if (!b) return -1;
     return b->vl_host[stage < 0 ? 0 : 1].n;

@@ -164,7 +164,7 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
     const ParLayout& L = D.L;
     const BatchCfgDev& C = D.cfg;
 
-    int stage = (args.stage_override != -2) ? args.stage_override : D.stage[b];
+    const int stage = __builtin_amdgcn_readfirstlane((args.stage_override != -2) ? args.stage_override : D.stage[b]);
     if (stage >= C.n_stages && !args.forward_only) return;      // frame finished
     const bool cam_stage = (stage < 0);
 
@@ -410,6 +410,7 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
     const float rho2 = C.rho * C.rho;
     const StageW sw = cam_stage ? StageW{} : sws[stage];
 
+    MARK(20);
     float csum = 1.f;
     if (cam_stage && C.use_conf_cam) {
         float p = 0.f;
@@ -454,6 +455,7 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
         S.dj[t * 3 + 1] = Rc[1] * d0 + Rc[4] * d1 + Rc[7] * d2;
         S.dj[t * 3 + 2] = Rc[2] * d0 + Rc[5] * d1 + Rc[8] * d2;
     }
+    MARK(21);
     const float bpw2 = sw.bpw * sw.bpw, sw2 = sw.sw * sw.sw, h2 = sw.hpw * sw.hpw, e2 = sw.epw * sw.epw;
     if (!cam_stage) {
         const bool latent_reg = C.use_vposer ? (stage + 1 == C.n_stages && C.has_reg) : (C.has_reg != 0);
@@ -477,9 +479,13 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
         }
         if (C.use_face) {
             if (t < L.NE) { const float ev = S.x[L.expr + t]; q[Q_EX] = ev * ev; S.gc[L.expr + t] = 2.f * ev * e2; }
-            if (t < 3) { const float jv = S.x[L.jaw + t] * sw.jaw[t]; q[Q_JW] = jv * jv; S.gc[L.jaw + t] = 2.f * jv * sw.jaw[t]; }
+            if (t < 3) {    // (select, not sw.jaw[t]: a dynamically indexed struct becomes a per-thread LDS copy)
+                const float jwt = (t == 0) ? sw.jaw[0] : (t == 1) ? sw.jaw[1] : sw.jaw[2];
+                const float jv = S.x[L.jaw + t] * jwt; q[Q_JW] = jv * jv; S.gc[L.jaw + t] = 2.f * jv * jwt;
+            }
         }
     }
+    MARK(22);
     {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
@@ -495,6 +501,7 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
             q[i] = r;
         }
     }
+    MARK(23);
     float total;
     if (cam_stage) {
         float joint = q[Q_L];

@@ -41,6 +41,7 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
     __shared__ OptScal st;
     const int b = blockIdx.x;
     if (D.stage[b] > last_stage) return;
+    if (D.dbg && b == 0 && threadIdx.x == 0) D.dbg[24] = clock64();
     if (has_eval) {
         ClosureArgs a{};
         a.stage_override = -2; a.use_dense_verts = 1;
@@ -49,11 +50,13 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
         if (threadIdx.x < 64)
             lbfgs_tick_body(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, &fval, gflat);
         __syncthreads();
+        if (D.dbg && b == 0 && threadIdx.x == 0) { D.dbg[25] = clock64(); for (int i = 0; i < 17; ++i) D.dbg[40 + i] = D.dbg[i]; }
         if (D.stage[b] > last_stage) return;
     }
     ClosureArgs e{};
     e.stage_override = -2; e.export_dense = 1; e.forward_only = 2;
     closure_body(S, M, D, vls, sws, e, b, nullptr, nullptr);
+    if (D.dbg && b == 0 && threadIdx.x == 0) D.dbg[26] = clock64();
 }
 
 void launch_fit_rows(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,

@@ -222,6 +222,11 @@ __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDe
         return;
     }
     if (stage > last_stage) return;
+    // debug: frame 0 accumulates shader-clock deltas between TMARKs into dbg[32+i], tick count in dbg[63]
+    long long tm_prev = 0;
+#define TMARK(i) do { if (D.dbg && b == 0 && lane == 0) { const long long c_ = clock64();                 \
+        if (i) D.dbg[32 + (i)] += c_ - tm_prev; else D.dbg[63] += 1; tm_prev = c_; } } while (0)
+    TMARK(0);
 
     // scalar state lives in LDS for the duration of the tick: every lane reads (broadcast) and
     // writes (identical values) the same words, so the single wavefront stays uniform
@@ -258,6 +263,7 @@ __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDe
         if (sc_le(s.bf0, s.bf1)) { s.low = 0; s.high = 1; } else { s.low = 1; s.high = 0; } } while (0)
 
     int act = A_NONE;
+    TMARK(1);
     // ---------------------------------------------------------------- consume the evaluation
     if (s.phase == PH_ENTRY) {
         st3(VEC(VEC_G), g_in, lane, N);
@@ -317,6 +323,7 @@ __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDe
         else act = A_ZOOM_NEXT;
     }
 
+    TMARK(2);
     // ---------------------------------------------------------------- run until an evaluation is needed
     int guard = 0;
     while (act != A_NONE && guard++ < 4096) {
@@ -356,6 +363,7 @@ __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDe
                     s.H_diag = T(ys / dot3(y, y));
                 }
                 LB_SYNC();
+                TMARK(3);
                 Lane3 q;
                 for (int e = 0; e < NE3; ++e) q.v[e] = -g.v[e];
                 // two-loop recursion.  History rows are fetched CH at a time into one register set
@@ -393,6 +401,7 @@ __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDe
                     }
                 }
                 LB_SYNC();
+                TMARK(4);
                 Lane3 r;
                 const float hd = (float)s.H_diag.v;
                 for (int e = 0; e < NE3; ++e) r.v[e] = q.v[e] * hd;
@@ -412,6 +421,7 @@ __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDe
 #undef LB_LOAD
 #undef LB_DOWN
 #undef LB_UP
+                TMARK(5);
                 d = r;
             }
             st3(VEC(VEC_D), d, lane, N);
@@ -593,8 +603,11 @@ __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDe
         default: act = A_NONE; break;
         }
     }
+    TMARK(6);
     LB_SYNC();
     if (lane == 0) gst->s = s_state;     // ro[] is written in place
+    TMARK(7);
+#undef TMARK
 #undef VEC
 }
 

@@ -49,8 +49,23 @@ void k_lbs_dense(DevModel M, BatchDev D) {
     __shared__ DenseLDS S;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int v0 = blockIdx.x * VB;
-    const int fb0 = blockIdx.y * FB;
+    // XCD-aware mapping of the 1-D grid: workgroups are dealt round-robin to the 8 XCDs, so block
+    // id L runs on XCD L % 8.  Each XCD owns a contiguous range of vertex tiles and visits
+    // (tile, frame block) pairs with the frame block fastest: the frame blocks of one tile and the
+    // neighbouring tiles (whose 192-byte dirs rows share 128-byte lines) meet in the same L2.
+    int tile, fblk, fpb;
+    {
+        const int ny = (D.nact + FB - 1) / FB, ntile = (M.V + VB - 1) / VB;
+        const int tpx = (ntile + 7) / 8;                        // tiles per XCD
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        tile = xcd * tpx + slot / ny; fblk = slot % ny;
+        if (tile >= ntile) return;                              // padding of the last XCD's range
+        // frames are dealt evenly to the ny frame blocks in 32-frame wavefront slices, so that a
+        // batch of 160 active frames runs as 96 + 64 rather than 128 + 32
+        fpb = 32 * (((D.nact + 31) / 32 + ny - 1) / ny);
+    }
+    const int v0 = tile * VB;
+    const int fb0 = fblk * fpb;
     const int b0 = fb0 + wv * 32;
     const int jl = lane & 15, kq = lane >> 4;
     const int V = M.V, B = D.nact;
@@ -58,7 +73,7 @@ void k_lbs_dense(DevModel M, BatchDev D) {
     const int v = vtx < V ? vtx : V - 1;
     const size_t Bp = (size_t)D.Bpad;
     const size_t LD = (size_t)3 * M.Vpad;
-    const bool active = b0 < B;        // wave-uniform: this wavefront's 32 frames exist
+    const bool active = wv * 32 < fpb && b0 < B;        // wave-uniform: this wavefront's 32 frames exist
 
     // staging: 1024 (feat) + 384 (dirs) float4 per chunk: slots tid + q*256; q = 0..3 -> feat rows,
     // slot 4 -> dirs, slot 5 (tid < 128) -> dirs
@@ -124,37 +139,51 @@ void k_lbs_dense(DevModel M, BatchDev D) {
 #endif
     const bool vok = vtx < V;
     // skinning GEMM T = W . A restricted to the joints that carry weight in this 16-vertex tile
-    // (exact: the skipped products are structural zeros of lbs_weights; ascending joint order kept)
-    const int tile = blockIdx.x;
+    // (exact: the skipped products are structural zeros of lbs_weights; ascending joint order kept).
+    // The A-operand gathers of step (rr, js+1) are in flight while step (rr, js) multiplies.
     const int njs = M.tj_n[tile] >> 2;
     const int* jl4 = M.tj_list + (size_t)tile * SFX_JPAD + kq;
     const float* wl = M.tj_w + ((size_t)tile * SFX_JPAD + kq) * 16 + jl;
+    const float* atb = D.AT + b0 + jl;
+    const size_t estep = (size_t)SFX_JPAD * Bp;
+    float P0, P1, P2, P3, Q0, Q1, Q2, Q3, N0, N1, N2, N3, R0, R1, R2, R3, wc, wn;
+#define AT_LOAD(p0, p1, p2, p3, q0, q1, q2, q3, ww, rr, js) do {                                          \
+        const float* at_ = atb + ((size_t)((rr) * 4) * SFX_JPAD + jl4[(js) * 4]) * Bp;                    \
+        p0 = at_[0]; p1 = at_[estep]; p2 = at_[2 * estep]; p3 = at_[3 * estep];                           \
+        q0 = at_[16]; q1 = at_[estep + 16]; q2 = at_[2 * estep + 16]; q3 = at_[3 * estep + 16];           \
+        ww = wl[(js) * 64]; } while (0)
+    float o0[4][3], o1[4][3];
+    AT_LOAD(P0, P1, P2, P3, Q0, Q1, Q2, Q3, wc, 0, 0);
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr) {
         f32x4 t00 = {0, 0, 0, 0}, t01 = t00, t02 = t00, t03 = t00, t10 = t00, t11 = t00, t12 = t00, t13 = t00;
-        const float* at0 = D.AT + ((size_t)(rr * 4) * SFX_JPAD) * Bp + b0 + jl;
-        const size_t estep = (size_t)SFX_JPAD * Bp;
         for (int js = 0; js < njs; ++js) {
-            const float w = wl[js * 64];
-            const float* at = at0 + (size_t)jl4[js * 4] * Bp;
-            const float p0 = at[0], p1 = at[estep], p2 = at[2 * estep], p3 = at[3 * estep];
-            const float q0 = at[16], q1 = at[estep + 16], q2 = at[2 * estep + 16], q3 = at[3 * estep + 16];
-            t00 = MFMA(p0, w, t00); t01 = MFMA(p1, w, t01); t02 = MFMA(p2, w, t02); t03 = MFMA(p3, w, t03);
-            t10 = MFMA(q0, w, t10); t11 = MFMA(q1, w, t11); t12 = MFMA(q2, w, t12); t13 = MFMA(q3, w, t13);
+            if (js + 1 < njs) AT_LOAD(N0, N1, N2, N3, R0, R1, R2, R3, wn, rr, js + 1);
+            else if (rr < 2) AT_LOAD(N0, N1, N2, N3, R0, R1, R2, R3, wn, rr + 1, 0);
+            t00 = MFMA(P0, wc, t00); t01 = MFMA(P1, wc, t01); t02 = MFMA(P2, wc, t02); t03 = MFMA(P3, wc, t03);
+            t10 = MFMA(Q0, wc, t10); t11 = MFMA(Q1, wc, t11); t12 = MFMA(Q2, wc, t12); t13 = MFMA(Q3, wc, t13);
+            P0 = N0; P1 = N1; P2 = N2; P3 = N3; Q0 = R0; Q1 = R1; Q2 = R2; Q3 = R3; wc = wn;
         }
-        if (vok) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f0 = b0 + kq * 4 + r, f1 = f0 + 16;
-                if (f0 < B) D.verts[((size_t)f0 * V + vtx) * 3 + rr] = t00[r] * ax0[r] + t01[r] * ay0[r] + t02[r] * az0[r] + t03[r];
-                if (f1 < B) D.verts[((size_t)f1 * V + vtx) * 3 + rr] = t10[r] * ax1[r] + t11[r] * ay1[r] + t12[r] * az1[r] + t13[r];
-            }
+        for (int r = 0; r < 4; ++r) {
+            o0[r][rr] = t00[r] * ax0[r] + t01[r] * ay0[r] + t02[r] * az0[r] + t03[r];
+            o1[r][rr] = t10[r] * ax1[r] + t11[r] * ay1[r] + t12[r] * az1[r] + t13[r];
+        }
+    }
+#undef AT_LOAD
+    if (vok) {      // one 12-byte store per (frame, vertex): 16 lanes cover 192 contiguous bytes
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f0 = b0 + kq * 4 + r, f1 = f0 + 16;
+            if (f0 < B) { float* o = D.verts + ((size_t)f0 * V + vtx) * 3; o[0] = o0[r][0]; o[1] = o0[r][1]; o[2] = o0[r][2]; }
+            if (f1 < B) { float* o = D.verts + ((size_t)f1 * V + vtx) * 3; o[0] = o1[r][0]; o[1] = o1[r][1]; o[2] = o1[r][2]; }
         }
     }
 }
 
 void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s) {
     if (D.nact <= 0) return;
-    dim3 grid((M.V + VB - 1) / VB, (D.nact + FB - 1) / FB);
+    const int ny = (D.nact + FB - 1) / FB, ntile = (M.V + VB - 1) / VB;
+    dim3 grid(8 * ((ntile + 7) / 8) * ny);
     hipLaunchKernelGGL(k_lbs_dense, grid, dim3(DT), 0, s, M, D);
 }

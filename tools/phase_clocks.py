@@ -14,4 +14,26 @@ for which in ('body','full'):
         _capi.check(_capi.load().sfx_debug_phase_clocks(fb._h, st, out))
         t = np.array(list(out)[:17], np.float64); d = np.diff(t)
         wall = (out[18] - out[17]) * 0.01   # 100 MHz constant clock -> us
+        print('   loss sub-phases (8->20->21->22->23->9):', [int(out[20]-out[8]), int(out[21]-out[20]), int(out[22]-out[21]), int(out[23]-out[22]), int(out[9]-out[23])])
         print(which, 'stage', st, 'total cycles', t[16]-t[0], 'wall us', wall, 'phases', d.astype(int).tolist())
+
+    # optimiser tick profile of frame 0 over a whole fit (rows path)
+    fb = H.engine_batch_from_frames(dm, cfg, fr, idx, lbs_mode="rows")
+    lib = _capi.load()
+    _capi.check(lib.sfx_debug_clocks(fb._h, 1, None))
+    fb.guess_init(cfg["body_tri_idxs"]); fb.fit()
+    o64 = (C.c_int64*64)()
+    _capi.check(lib.sfx_debug_clocks(fb._h, 0, o64))
+    o = np.array(list(o64), np.float64); n = max(o[63], 1)
+    print(which, 'ticks', int(o[63]), 'avg cycles/tick between marks [load, consume, act->hist, loop1, loop2, rest, store]:',
+          (o[33:40] / n).astype(int).tolist(), 'sum', int(o[33:40].sum() / n))
+
+    # dense path: one k_tick_dense launch = [loss+adjoint of eval i] -> [tick] -> [pose/FK/export of eval i+1]
+    fb = H.engine_batch_from_frames(dm, cfg, fr, idx, lbs_mode="dense")
+    _capi.check(lib.sfx_debug_clocks(fb._h, 1, None))
+    fb.guess_init(cfg["body_tri_idxs"]); fb.fit(first_stage=-1, last_stage=0)
+    _capi.check(lib.sfx_debug_clocks(fb._h, 0, o64))
+    o = np.array(list(o64), np.float64)
+    post = np.diff(o[40:57]); pre = np.diff(o[0:9])
+    print(which, 'dense tick kernel (last launch): total', int(o[26]-o[24]), 'post-closure+tick', int(o[25]-o[24]), 'pre/export', int(o[26]-o[25]))
+    print('    post phases', post.astype(int).tolist()); print('    pre phases', pre.astype(int).tolist())

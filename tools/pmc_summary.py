@@ -1,0 +1,34 @@
+"""Summarise rocprofv3 --pmc passes on the GPU box (the raw counter CSVs are too big to travel).
+
+usage: pmc_summary.py OUT.json DIR [DIR ...]      each DIR = one `rocprofv3 --pmc X -d DIR` pass
+Per kernel and counter: launches, mean value per launch, mean grid size.  FETCH_SIZE / WRITE_SIZE
+are reported by rocprofv3 in KiB; per /opt/skills/guides/MI355X_MICROARCH.md (HBM section) gfx950's
+FETCH_SIZE tallies 128-B requests at 64 B, so `hbm_read_bytes` = 2 x FETCH_SIZE x 1024; WRITE_SIZE
+is taken as is (uncalibrated, the guide says so)."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+def main():
+    out_path, dirs = sys.argv[1], sys.argv[2:]
+    acc = defaultdict(lambda: [0, 0.0, 0.0])
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    k = (row["Kernel_Name"].split("(")[0], row["Counter_Name"])
+                    a = acc[k]
+                    a[0] += 1; a[1] += float(row["Counter_Value"]); a[2] += float(row.get("Grid_Size", 0) or 0)
+    res = {}
+    for (kern, ctr), (n, tot, grid) in sorted(acc.items()):
+        e = res.setdefault(kern, {})
+        e[ctr] = {"launches": n, "mean_per_launch": tot / n, "mean_grid_size": grid / n}
+    for kern, e in res.items():
+        if "FETCH_SIZE" in e:
+            e["hbm_read_bytes_per_launch"] = 2.0 * 1024.0 * e["FETCH_SIZE"]["mean_per_launch"]
+        if "WRITE_SIZE" in e:
+            e["hbm_write_bytes_per_launch"] = 1024.0 * e["WRITE_SIZE"]["mean_per_launch"]
+    json.dump(res, open(out_path, "w"), indent=1)
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk.startswith("hbm")} for k, v in res.items()}))
+
+if __name__ == "__main__":
+    main()
