@@ -16,7 +16,7 @@ void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const S
     __shared__ FrameLDS S;
     __shared__ float gflat[SFX_NVAR_MAX];
     __shared__ float fval;
-    __shared__ float s_al[SFX_HIST];
+    __shared__ float s_al[SFX_HIST + 2 * LB_BS];
     __shared__ OptScal st;
     const int b = blockIdx.x;
     ClosureArgs a{};
@@ -37,7 +37,7 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
     __shared__ FrameLDS S;
     __shared__ float gflat[SFX_NVAR_MAX];
     __shared__ float fval;
-    __shared__ float s_al[SFX_HIST];
+    __shared__ float s_al[SFX_HIST + 2 * LB_BS];
     __shared__ OptScal st;
     const int b = blockIdx.x;
     if (D.stage[b] > last_stage) return;

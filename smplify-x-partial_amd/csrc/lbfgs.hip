@@ -6,7 +6,7 @@ size_t sfx_optstate_size() { return sizeof(OptState); }
 __global__ __launch_bounds__(64)
 void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int first_stage, int last_stage,
                   int init, int step_mode) {
-    __shared__ float s_al[SFX_HIST];
+    __shared__ float s_al[SFX_HIST + 2 * LB_BS];
     __shared__ OptScal s_state;
     const int b = blockIdx.x;
     lbfgs_tick_body(M, D, vls, first_stage, last_stage, init, step_mode, b, threadIdx.x, s_al, s_state,

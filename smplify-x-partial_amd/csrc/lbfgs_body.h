@@ -19,8 +19,8 @@
 // every multiply-add in this file is written out: no implicit contraction (see header comment)
 #pragma clang fp contract(off)
 // single-wavefront synchronisation: order LDS/global accesses of the 64 lanes
-#ifndef LB_CH
-#define LB_CH 8       // history rows per register set of the two-loop recursion (two sets in flight)
+#ifndef LB_BS
+#define LB_BS 8       // history pairs per block of the blocked two-loop recursion (LB_BS^2 = 64 band lanes)
 #endif
 #define LB_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 
@@ -117,6 +117,7 @@ struct OptScal {
 struct OptState {
     OptScal s;
     float ro[SFX_HIST];
+    float syb[SFX_HIST * LB_BS];    // syb[p][k] = s_p . y_(k-th successor of p)
 };
 
 
@@ -136,6 +137,48 @@ __device__ __forceinline__ Lane3 ld3(const float* p, int lane, int N) {
     r.v[1] = (3 * lane + 1 < N) ? v.y : 0.f;
     r.v[2] = (3 * lane + 2 < N) ? v.z : 0.f;
     return r;
+}
+// history rows are written full width (elements >= N are zero in every vector derived from masked
+// loads), so they can be read back without masks
+__device__ __forceinline__ Lane3 ld3_raw(const float* base, unsigned row_off, int lane) {
+    Lane3 r;      // 32-bit element offset: uniform base pointer + per-lane offset (saddr addressing)
+    const float3 v = *reinterpret_cast<const float3*>(reinterpret_cast<const char*>(base) + (row_off * 4u + 12u * (unsigned)lane));
+    r.v[0] = v.x; r.v[1] = v.y; r.v[2] = v.z;
+    return r;
+}
+__device__ __forceinline__ void st3_full(float* p, const Lane3& a, int lane) {
+    *reinterpret_cast<float3*>(p + 3 * lane) = make_float3(a.v[0], a.v[1], a.v[2]);
+}
+// BS wavefront sums at once: the DPP steps of the BS independent reductions are issued
+// back to back, which also covers the VALU->DPP wait states
+template <int NB>
+__device__ __forceinline__ void wave_sum_multi(float (&x)[NB]) {
+    // written as DPP adds that update the register in place (rows masked off by row_mask keep
+    // their value, which is the "+0" of the scan), 6 instructions per value.  Inline asm is not
+    // seen by the hazard recogniser: the empty statements pin every producer before the s_nop,
+    // and consecutive DPP reads of one register are NB-1 >= 2 instructions apart.
+    static_assert(NB >= 3, "wait states between dependent DPP steps");
+#pragma unroll
+    for (int c = 0; c < NB; ++c) asm volatile("" : "+v"(x[c]));
+    asm volatile("s_nop 1");
+#define LB_DPP_STEP(ctl)                                                                                   \
+    _Pragma("unroll") for (int c = 0; c < NB; ++c) asm volatile("v_add_f32_dpp %0, %0, %0 " ctl : "+v"(x[c]));
+    LB_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+    LB_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+    LB_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+    LB_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+    LB_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+    LB_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+#undef LB_DPP_STEP
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int c = 0; c < NB; ++c) x[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[c]), 63));
+}
+__device__ __forceinline__ float dot3_part(const Lane3& a, const Lane3& b) {
+    float p = a.v[0] * b.v[0];
+    p = p + a.v[1] * b.v[1];
+    p = p + a.v[2] * b.v[2];
+    return p;
 }
 __device__ __forceinline__ void st3(float* p, const Lane3& a, int lane, int N) {
 #pragma unroll
@@ -175,7 +218,7 @@ __device__ __forceinline__ OptScal fresh_state() {
 }
 
 // One tick of frame b's optimiser, executed by ONE wavefront (lanes 0..63).  f_in / g_in: the
-// closure result (global D.f/D.g, or LDS copies in fused kernels).  s_al[SFX_HIST] and s_state
+// closure result (global D.f/D.g, or LDS copies in fused kernels).  s_al[SFX_HIST + 2 * LB_BS] and s_state
 // are LDS scratch owned by the caller.
 __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDev& D, const VarList* __restrict__ vls,
                                                 int first_stage, int last_stage, int init, int step_mode,
@@ -355,49 +398,97 @@ __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDe
                 if (ys > 1e-10f) {
                     if (s.hist_n == SFX_HIST) { s.hist_head = (s.hist_head + 1) % SFX_HIST; s.hist_n -= 1; }
                     const int ph = (s.hist_head + s.hist_n) % SFX_HIST;
-                    st3(hY + (size_t)ph * SFX_NVAR_MAX, y, lane, N);
-                    st3(hS + (size_t)ph * SFX_NVAR_MAX, sv, lane, N);
+                    st3_full(hY + (size_t)ph * SFX_NVAR_MAX, y, lane);
+                    st3_full(hS + (size_t)ph * SFX_NVAR_MAX, sv, lane);
                     const float ro = 1.0f / ys;
                     if (lane == 0) gst->ro[ph] = ro;
                     s.hist_n += 1;
                     s.H_diag = T(ys / dot3(y, y));
+                    // band of the Gram matrix used by the blocked recursion below:
+                    // syb[p][k] = s_p . y_(k-th successor of p), k = 1..BS-1; the new y closes the
+                    // pairs with its BS-1 predecessors
+                    {
+                        const int n1 = __builtin_amdgcn_readfirstlane(s.hist_n), hd1 = __builtin_amdgcn_readfirstlane(s.hist_head);
+                        Lane3 SP[LB_BS - 1];
+#pragma unroll
+                        for (int k = 1; k < LB_BS; ++k) {
+                            const int i_ = n1 - 1 - k;
+                            int t_ = hd1 + (i_ >= 0 ? i_ : 0); t_ = t_ >= SFX_HIST ? t_ - SFX_HIST : t_;
+                            SP[k - 1] = ld3_raw(hS, (unsigned)t_ * SFX_NVAR_MAX, lane);
+                        }
+                        float eb[LB_BS - 1];
+#pragma unroll
+                        for (int k = 1; k < LB_BS; ++k) eb[k - 1] = dot3_part(SP[k - 1], y);
+                        wave_sum_multi(eb);
+#pragma unroll
+                        for (int k = 1; k < LB_BS; ++k) {
+                            const int i_ = n1 - 1 - k;
+                            const float e = eb[k - 1];
+                            int t_ = hd1 + i_; t_ = t_ >= SFX_HIST ? t_ - SFX_HIST : t_;
+                            if (lane == 0 && i_ >= 0) gst->syb[t_ * LB_BS + k] = e;
+                        }
+                    }
                 }
                 LB_SYNC();
                 TMARK(3);
+                // Two-loop recursion (lbfgs_ls.py:322-341), evaluated in blocks of BS history pairs:
+                // within a block the BS dot products against the running vector are independent
+                // (s_c . q for all c at once); the in-block coupling s_c . (q - sum_m al_m y_m) is
+                // resolved on scalars with the stored band s_p . y_(p+k).  Same arithmetic in exact
+                // terms, BS-fold shorter dependency chain.  History rows for the next block are
+                // fetched into a second register set while the current block is consumed.
+                constexpr int BS = LB_BS;
+                const int n = __builtin_amdgcn_readfirstlane(s.hist_n), head = __builtin_amdgcn_readfirstlane(s.hist_head);
                 Lane3 q;
                 for (int e = 0; e < NE3; ++e) q.v[e] = -g.v[e];
-                // two-loop recursion.  History rows are fetched CH at a time into one register set
-                // while the previous CH rows are consumed from the other (software double buffering),
-                // so the serial chain sees dot/axpy latency only, not HBM latency.
-                constexpr int CH = LB_CH;
-                Lane3 SA[CH], YA[CH], SB[CH], YB[CH];
-                float rA[CH], rB[CH];
-#define LB_LOAD(Sx, Yx, rx, base, dir) do { _Pragma("unroll") for (int c = 0; c < CH; ++c) {                 \
-                    const int i_ = (base) + (dir) * c;                                                       \
-                    const int ph_ = (s.hist_head + ((i_ >= 0 && i_ < s.hist_n) ? i_ : 0)) % SFX_HIST;        \
-                    Sx[c] = ld3(hS + (size_t)ph_ * SFX_NVAR_MAX, lane, N);                                   \
-                    Yx[c] = ld3(hY + (size_t)ph_ * SFX_NVAR_MAX, lane, N);                                   \
-                    rx[c] = gst->ro[ph_]; } } while (0)
-#define LB_DOWN(Sx, Yx, rx, base) do { _Pragma("unroll") for (int c = 0; c < CH; ++c) {                      \
-                    const int i_ = (base) - c;                                                               \
-                    if (i_ >= 0) { const float al = dot3(Sx[c], q) * rx[c];                                   \
-                                   if (lane == 0) s_al[i_] = al;                                             \
-                                   q = axpy3(q, -al, Yx[c]); } } } while (0)
-#define LB_UP(Sx, Yx, rx, base) do { _Pragma("unroll") for (int c = 0; c < CH; ++c) {                        \
-                    const int i_ = (base) + c;                                                               \
-                    if (i_ < s.hist_n) { const float be = dot3(Yx[c], r) * rx[c];                             \
-                                         r = axpy3(r, s_al[i_] - be, Sx[c]); } } } while (0)
+                Lane3 SA[BS], YA[BS], SB[BS], YB[BS];
+                float* s_alp = s_al + BS;        // members below index 0 of the last block land in the padding
+                float bA, bB, rA, rB, aA, aB;    // lane (x, k) = x * BS + k: band row of member x; lane c: ro / alpha of member c
+                // physical slot of logical history index i (clamped into the window; no integer division)
+                auto lb_slot = [head, n](int i_) { int t_ = head + min(max(i_, 0), max(n - 1, 0)); return t_ >= SFX_HIST ? t_ - SFX_HIST : t_; };
+#define LB_SLOT(i_) lb_slot(i_)
+#define LB_RL(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))
+#define LB_LOAD(Sx, Yx, bx, rx, ax, base, dir, want_al) do {                                                 \
+                    _Pragma("unroll") for (int c = 0; c < BS; ++c) {                                         \
+                        const int ph_ = LB_SLOT((base) + (dir) * c);                                         \
+                        Sx[c] = ld3_raw(hS, (unsigned)ph_ * SFX_NVAR_MAX, lane);                                 \
+                        Yx[c] = ld3_raw(hY, (unsigned)ph_ * SFX_NVAR_MAX, lane); }                               \
+                    bx = gst->syb[LB_SLOT((base) + (dir) * (lane / BS)) * BS + lane % BS];                   \
+                    rx = gst->ro[LB_SLOT((base) + (dir) * (lane % BS))];                                     \
+                    if (want_al) { const int i_ = (base) + (dir) * (lane % BS);                              \
+                                   ax = s_alp[min(max(i_, -BS), n)]; } } while (0)
+#define LB_DOWN(Sx, Yx, bx, rx, base) do {                                                                   \
+                    float acc_[BS], al_[BS];                                                                 \
+                    _Pragma("unroll") for (int c = 0; c < BS; ++c) acc_[c] = dot3_part(Sx[c], q);            \
+                    wave_sum_multi(acc_);                                                                    \
+                    _Pragma("unroll") for (int m = 0; m < BS; ++m) {                                         \
+                        al_[m] = ((base) - m >= 0) ? acc_[m] * LB_RL(rx, m) : 0.f;                           \
+                        _Pragma("unroll") for (int c = m + 1; c < BS; ++c)                                   \
+                            acc_[c] = fmaf(-al_[m], LB_RL(bx, c * BS + (c - m)), acc_[c]); }                 \
+                    _Pragma("unroll") for (int c = 0; c < BS; ++c) q = axpy3(q, -al_[c], Yx[c]);             \
+                    if (lane == 0) { _Pragma("unroll") for (int c = 0; c < BS; ++c) s_alp[(base) - c] = al_[c]; } \
+                    } while (0)
+#define LB_UP(Sx, Yx, bx, rx, ax, base) do {                                                                 \
+                    float acc_[BS], cc_[BS];                                                                 \
+                    _Pragma("unroll") for (int c = 0; c < BS; ++c) acc_[c] = dot3_part(Yx[c], r);            \
+                    wave_sum_multi(acc_);                                                                    \
+                    _Pragma("unroll") for (int m = 0; m < BS; ++m) {                                         \
+                        const float be_ = acc_[m] * LB_RL(rx, m);                                            \
+                        cc_[m] = ((base) + m < n) ? LB_RL(ax, m) - be_ : 0.f;                                \
+                        _Pragma("unroll") for (int c = m + 1; c < BS; ++c)                                   \
+                            acc_[c] = fmaf(cc_[m], LB_RL(bx, m * BS + (c - m)), acc_[c]); }                  \
+                    _Pragma("unroll") for (int c = 0; c < BS; ++c) r = axpy3(r, cc_[c], Sx[c]); } while (0)
                 {
-                    int i0 = s.hist_n - 1;
-                    LB_LOAD(SA, YA, rA, i0, -1);
+                    int i0 = n - 1;
+                    LB_LOAD(SA, YA, bA, rA, aA, i0, -1, false);
                     while (i0 >= 0) {
-                        LB_LOAD(SB, YB, rB, i0 - CH, -1);
-                        LB_DOWN(SA, YA, rA, i0);
-                        i0 -= CH;
+                        LB_LOAD(SB, YB, bB, rB, aB, i0 - BS, -1, false);
+                        LB_DOWN(SA, YA, bA, rA, i0);
+                        i0 -= BS;
                         if (i0 < 0) break;
-                        LB_LOAD(SA, YA, rA, i0 - CH, -1);
-                        LB_DOWN(SB, YB, rB, i0);
-                        i0 -= CH;
+                        LB_LOAD(SA, YA, bA, rA, aA, i0 - BS, -1, false);
+                        LB_DOWN(SB, YB, bB, rB, i0);
+                        i0 -= BS;
                     }
                 }
                 LB_SYNC();
@@ -407,20 +498,22 @@ __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDe
                 for (int e = 0; e < NE3; ++e) r.v[e] = q.v[e] * hd;
                 {
                     int i0 = 0;
-                    LB_LOAD(SA, YA, rA, i0, 1);
-                    while (i0 < s.hist_n) {
-                        LB_LOAD(SB, YB, rB, i0 + CH, 1);
-                        LB_UP(SA, YA, rA, i0);
-                        i0 += CH;
-                        if (i0 >= s.hist_n) break;
-                        LB_LOAD(SA, YA, rA, i0 + CH, 1);
-                        LB_UP(SB, YB, rB, i0);
-                        i0 += CH;
+                    LB_LOAD(SA, YA, bA, rA, aA, i0, 1, true);
+                    while (i0 < n) {
+                        LB_LOAD(SB, YB, bB, rB, aB, i0 + BS, 1, true);
+                        LB_UP(SA, YA, bA, rA, aA, i0);
+                        i0 += BS;
+                        if (i0 >= n) break;
+                        LB_LOAD(SA, YA, bA, rA, aA, i0 + BS, 1, true);
+                        LB_UP(SB, YB, bB, rB, aB, i0);
+                        i0 += BS;
                     }
                 }
 #undef LB_LOAD
 #undef LB_DOWN
 #undef LB_UP
+#undef LB_SLOT
+#undef LB_RL
                 TMARK(5);
                 d = r;
             }
