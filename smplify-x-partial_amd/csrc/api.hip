@@ -427,6 +427,7 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.featT = b->mem.zeros<float>((size_t)SFX_KD_PAD * D.Bpad);
     D.AT = b->mem.zeros<float>((size_t)12 * SFX_JPAD * D.Bpad);
     D.verts = b->mem.zeros<float>((size_t)B * m->M.V * 3);
+    D.fwd = b->mem.zeros<float>((size_t)B * SFX_FWD_N);
     D.joints = b->mem.zeros<float>((size_t)B * K * 3);
     D.fullpose = b->mem.zeros<float>((size_t)B * SFX_POSE);
     D.stage = b->mem.zeros<int>(B);

@@ -170,8 +170,16 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
 
     MARK(0);
     // ------------------------------------------------------------------ load parameters
+    // reuse_fwd: the export pass of the previous launch left this frame's forward state (feat, x,
+    // full_pose, R, Jr, G, A -- the leading members of FrameLDS -- plus hand poses, LUT row and
+    // the VPoser activations) in D.fwd; reload it instead of recomputing pose assembly,
+    // Rodrigues, joint regression and the kinematic chain
+    constexpr int FWD_PREFIX = (int)(offsetof(FrameLDS, vp) / sizeof(float));
+    static_assert(FWD_PREFIX % 4 == 0 && FWD_PREFIX + 96 + 2 * VP_H + 128 + 64 <= SFX_FWD_N, "forward-state blob layout");
+    const bool reuse = args.reuse_fwd != 0;
+    float* fwd = D.fwd ? D.fwd + (size_t)b * SFX_FWD_N : nullptr;
     const float* xsrc = (args.from_X ? D.X : D.Xt) + (size_t)b * SFX_NPAR_MAX;
-    for (int i = t; i < L.npar; i += CT) S.x[i] = xsrc[i];
+    if (!reuse) for (int i = t; i < L.npar; i += CT) S.x[i] = xsrc[i];
     for (int i = t; i < SFX_META_N; i += CT) S.meta[i] = M.meta[i];
     {   // per-frame data -> LDS (one coalesced pass instead of dependent global loads later)
         const int K_ = M.K;
@@ -182,15 +190,30 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
         if (t >= 64 && t < 73) S.fd[FD_CAMR + t - 64] = D.camR[(size_t)b * 9 + t - 64];
         if (t >= 128 && t < 128 + 63) S.fd[FD_REG + t - 128] = D.regpose[(size_t)b * 63 + t - 128];
     }
-    for (int i = t; i < SFX_KD_PAD; i += CT) { S.feat[i] = 0.f; S.dfeat[i] = 0.f; }
+    for (int i = t; i < SFX_KD_PAD; i += CT) { if (!reuse) S.feat[i] = 0.f; S.dfeat[i] = 0.f; }
     for (int i = t; i < SFX_NPAR_MAX; i += CT) S.gc[i] = 0.f;
     for (int i = t; i < 168; i += CT) S.dpose[i] = 0.f;
+    if (reuse) {
+        float* sp = reinterpret_cast<float*>(&S);
+        for (int i = t; i < FWD_PREFIX / 4; i += CT)
+            reinterpret_cast<float4*>(sp)[i] = reinterpret_cast<const float4*>(fwd)[i];
+        const float* ex = fwd + FWD_PREFIX;
+        if (t < SFX_NHAND) { S.lh45[t] = ex[t]; S.rh45[t] = ex[SFX_NHAND + t]; }
+        if (t == 64) S.lut_row = __float_as_int(ex[2 * SFX_NHAND]);
+        if (C.use_vposer) {
+            const float* vx = ex + 96;
+            for (int i = t; i < VP_H; i += CT) { S.V.h1[i] = vx[i]; S.V.h2[i] = vx[VP_H + i]; }
+            if (t < 128) S.V.o[t] = vx[2 * VP_H + t];
+            if (t < 64) S.V.body[t] = vx[2 * VP_H + 128 + t];
+        }
+    }
     __syncthreads();
-    if (C.use_vposer) {          // body_pose = vposer.decode(pose_embedding) (fitting.py:236-238)
+    if (C.use_vposer && !reuse) {          // body_pose = vposer.decode(pose_embedding) (fitting.py:236-238)
         vposer_forward<CT>(S.V, M, S.x + L.emb);
         if (t < 63) D.bodypose[(size_t)b * 63 + t] = S.V.body[t];
     }
     const float* bodypose = C.use_vposer ? S.V.body : (S.x + L.emb);
+  if (!reuse) {
 
     MARK(1);
     // ------------------------------------------------------------------ pose assembly
@@ -294,6 +317,7 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
     }
     __syncthreads();
 
+  }   // !reuse
     MARK(4);
     // ------------------------------------------------------------------ dense export
     if (args.export_dense) {
@@ -303,7 +327,23 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
             const int j = i / 12, e = i % 12;
             D.AT[((size_t)e * SFX_JPAD + j) * D.Bpad + slot] = S.A[i];
         }
-        if (args.forward_only == 2) return;     // export pass only
+        if (args.forward_only == 2) {           // export pass only: keep the forward state for the adjoint pass
+            if (fwd) {
+                const float* sp = reinterpret_cast<const float*>(&S);
+                for (int i = t; i < FWD_PREFIX / 4; i += CT)
+                    reinterpret_cast<float4*>(fwd)[i] = reinterpret_cast<const float4*>(sp)[i];
+                float* ex = fwd + FWD_PREFIX;
+                if (t < SFX_NHAND) { ex[t] = S.lh45[t]; ex[SFX_NHAND + t] = S.rh45[t]; }
+                if (t == 64) ex[2 * SFX_NHAND] = __int_as_float(S.lut_row);
+                if (C.use_vposer) {
+                    float* vx = ex + 96;
+                    for (int i = t; i < VP_H; i += CT) { vx[i] = S.V.h1[i]; vx[VP_H + i] = S.V.h2[i]; }
+                    if (t < 128) vx[2 * VP_H + t] = S.V.o[t];
+                    if (t < 64) vx[2 * VP_H + 128 + t] = S.V.body[t];
+                }
+            }
+            return;
+        }
     }
 
     MARK(5);

@@ -44,7 +44,7 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
     if (D.dbg && b == 0 && threadIdx.x == 0) D.dbg[24] = clock64();
     if (has_eval) {
         ClosureArgs a{};
-        a.stage_override = -2; a.use_dense_verts = 1;
+        a.stage_override = -2; a.use_dense_verts = 1; a.reuse_fwd = 1;
         closure_body(S, M, D, vls, sws, a, b, gflat, &fval);
         __syncthreads();
         if (threadIdx.x < 64)

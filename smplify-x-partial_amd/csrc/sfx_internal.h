@@ -13,6 +13,7 @@
 #define SFX_MAX_LEVELS 16
 #define SFX_HIST 100        // L-BFGS history (optim_factory 'lbfgsls' default)
 #define SFX_NVAR_MAX 192    // optimiser vector length (182 / 88 / 6), padded to 3*64
+#define SFX_FWD_N 4352      // floats per frame of saved forward state (FrameLDS prefix + 96 + VPoser 1280)
 #define SFX_NPAR_MAX 192    // canonical per-frame parameter block
 #define SFX_MAX_STAGES 8
 #define SFX_MAX_GROUPS 12
@@ -153,6 +154,7 @@ struct BatchDev {
     float* stage_loss2;// [B][1+MAX_STAGES] second-orientation stage losses
     int*   try_both;   // [B]
     int*   orient_pass;// [B] 0 first fit, 1 second fit running, 2 done
+    float* fwd;             // [B][SFX_FWD_N] forward state handed from the export pass to the adjoint pass
     long long* dbg;         // [64] phase timestamps of block 0 (NULL = off)
 };
 
@@ -170,6 +172,7 @@ struct ClosureArgs {
     int use_dense_verts;    // 1: item vertices come from BatchDev.verts
     int export_dense;       // 1: write featT / AT for the dense kernel
     int from_X;             // 1: evaluate at X instead of Xt
+    int reuse_fwd;          // 1: forward state of this trial point was saved by the export pass
 };
 void launch_closure(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
                     const ClosureArgs& a, hipStream_t s);
