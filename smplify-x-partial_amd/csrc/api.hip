@@ -226,6 +226,33 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
         for (int j = 0; j < SFX_J; ++j) { m->meta_host[MO_PAR + j] = par[j]; m->meta_host[MO_LJ + j] = lj[j]; }
         for (int j = 0; j <= SFX_J; ++j) m->meta_host[MO_CS + j] = cs[j];
         for (size_t q = 0; q < cl.size(); ++q) m->meta_host[MO_CL + q] = cl[q];
+        // DFS pre-order (children in ascending joint order) and subtree sizes: the adjoint of the
+        // chain sums over subtrees, which are contiguous pre-order ranges
+        {
+            std::vector<int> pre(SFX_J, 0), sub(SFX_J, 1), stack{0};
+            int pos = 0;
+            while (!stack.empty()) {
+                const int j = stack.back(); stack.pop_back();
+                pre[j] = pos++;
+                for (int q = cs[j + 1] - 1; q >= cs[j]; --q) stack.push_back(cl[q]);
+            }
+            for (int j = SFX_J - 1; j > 0; --j) sub[par[j]] += sub[j];
+            for (int j = 0; j < SFX_J; ++j) { m->meta_host[MO_PRE + j] = pre[j]; m->meta_host[MO_SUB + j] = sub[j]; }
+        }
+        // 2^k-th ancestors for the pointer-jumping evaluation of the chain
+        {
+            int rounds = 0;
+            while ((1 << rounds) < M.n_levels) ++rounds;
+            if (rounds > SFX_MAX_ROUNDS) { sfx_set_error("tree too deep"); delete m; return -1; }
+            M.n_rounds = rounds;
+            std::vector<int> anc(par);
+            for (int k = 0; k < rounds; ++k) {
+                for (int j = 0; j < SFX_J; ++j) m->meta_host[MO_ANC + k * 56 + j] = anc[j];
+                std::vector<int> nxt(SFX_J);
+                for (int j = 0; j < SFX_J; ++j) nxt[j] = anc[j] < 0 ? -1 : anc[anc[j]];
+                anc = nxt;
+            }
+        }
         M.parents = m->mem.up(par); M.level_joints = m->mem.up(lj);
         M.child_start = m->mem.up(cs); M.child_list = m->mem.up(cl);
     }

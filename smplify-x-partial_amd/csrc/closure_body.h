@@ -37,6 +37,11 @@
 #define MARK(i) do { if (D.dbg && blockIdx.x == 0 && threadIdx.x == 0) { D.dbg[i] = clock64();             \
         if ((i) == 0) D.dbg[17] = wall_clock64(); if ((i) == 16) D.dbg[18] = wall_clock64(); } } while (0)
 
+// thread t handles elements t, t + CT, ... of an N-element pass; the constant trip count lets the
+// compiler unroll and overlap the (dependent) LDS reads of the iterations
+#define FOR_CT(w, N) _Pragma("unroll") for (int w##_i = 0; w##_i < ((N) + CT - 1) / CT; ++w##_i)             \
+                         if (const int w = t + w##_i * CT; w < (N))
+
 struct __align__(16) FrameLDS {
     float feat[SFX_KD_PAD];        // first: read as float4
     float x[SFX_NPAR_MAX];
@@ -180,6 +185,7 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
     float* fwd = D.fwd ? D.fwd + (size_t)b * SFX_FWD_N : nullptr;
     const float* xsrc = (args.from_X ? D.X : D.Xt) + (size_t)b * SFX_NPAR_MAX;
     if (!reuse) for (int i = t; i < L.npar; i += CT) S.x[i] = xsrc[i];
+    if (!args.keep_tables) {   // (a persistent workgroup keeps the tables and its frame's data in LDS between evaluations)
     for (int i = t; i < SFX_META_N; i += CT) S.meta[i] = M.meta[i];
     {   // per-frame data -> LDS (one coalesced pass instead of dependent global loads later)
         const int K_ = M.K;
@@ -189,6 +195,7 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
         if (t < 8) S.fd[FD_CAM + t] = D.cam[(size_t)b * 8 + t];
         if (t >= 64 && t < 73) S.fd[FD_CAMR + t - 64] = D.camR[(size_t)b * 9 + t - 64];
         if (t >= 128 && t < 128 + 63) S.fd[FD_REG + t - 128] = D.regpose[(size_t)b * 63 + t - 128];
+    }
     }
     for (int i = t; i < SFX_KD_PAD; i += CT) { if (!reuse) S.feat[i] = 0.f; S.dfeat[i] = 0.f; }
     for (int i = t; i < SFX_NPAR_MAX; i += CT) S.gc[i] = 0.f;
@@ -261,27 +268,38 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
 
     MARK(3);
     // ------------------------------------------------------------------ kinematic chain
-    // one lane per (joint of the level, matrix element): 12 lanes per joint, <=10 joints per level
-    for (int lev = 0; lev < M.n_levels; ++lev) {
-        const int i0 = M.level_start[lev], n = M.level_start[lev + 1] - i0;
-        const int jn = t / 12, e = t % 12;
-        if (jn < n) {
-            const int j = S.meta[MO_LJ + i0 + jn];
+    // pointer jumping instead of a level-by-level walk: start from the local transforms
+    // T_j = [R_j | J_j - J_parent]; in round k every joint composes with the transform of its
+    // 2^k-th ancestor, T_j <- T_anc o T_j, so after ceil(log2(depth)) rounds T_j = G_j.  Two
+    // buffers (S.G, S.dG) alternate; the result lands in S.G.  4 barriers instead of 11.
+    {
+        float* src = (M.n_rounds & 1) ? S.dG : S.G;
+        float* dst = (M.n_rounds & 1) ? S.G : S.dG;
+        FOR_CT(w, SFX_J * 12) {
+            const int j = w / 12, e = w % 12, r = e >> 2, c = e & 3;
             const int p = S.meta[MO_PAR + j];
-            const int r = e >> 2, c = e & 3;
-            const float* Rj = &S.R[j * 9];
-            float v;
-            if (p < 0) v = (c < 3) ? Rj[r * 3 + c] : S.Jr[j * 3 + r];
-            else {
-                const float* Gp = &S.G[p * 12 + r * 4];
-                if (c < 3) v = Gp[0] * Rj[c] + Gp[1] * Rj[3 + c] + Gp[2] * Rj[6 + c];
-                else v = Gp[0] * (S.Jr[j * 3] - S.Jr[p * 3]) + Gp[1] * (S.Jr[j * 3 + 1] - S.Jr[p * 3 + 1]) +
-                         Gp[2] * (S.Jr[j * 3 + 2] - S.Jr[p * 3 + 2]) + Gp[3];
-            }
-            S.G[j * 12 + e] = v;
+            src[w] = (c < 3) ? S.R[j * 9 + r * 3 + c] : (S.Jr[j * 3 + r] - (p < 0 ? 0.f : S.Jr[p * 3 + r]));
         }
         __syncthreads();
+        MARK(27);
+        for (int k = 0; k < M.n_rounds; ++k) {
+            FOR_CT(w, SFX_J * 12) {
+                const int j = w / 12, e = w % 12, r = e >> 2, c = e & 3;
+                const int a = S.meta[MO_ANC + k * 56 + j];
+                float v = src[w];
+                if (a >= 0) {
+                    const float* Ta = &src[a * 12 + r * 4];
+                    const float* Tb = &src[j * 12 + c];
+                    v = Ta[0] * Tb[0] + Ta[1] * Tb[4] + Ta[2] * Tb[8];
+                    if (c == 3) v += Ta[3];
+                }
+                dst[w] = v;
+            }
+            __syncthreads();
+            float* tmp = src; src = dst; dst = tmp;
+        }
     }
+    MARK(28);
     if (t < SFX_J) {
         const float* Gj = &S.G[t * 12];
         float* Aj = &S.A[t * 12];
@@ -630,9 +648,11 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
     }
     __syncthreads();
     MARK(12);
-    // kinematic chain, deepest level first; parents gather from their children (no atomics).
-    // pass 0: posed-joint adjoints; pass 1 (per level): dG, one lane per matrix element;
-    // pass 2 (all joints at once): dR, d(rel); pass 3: dJ.
+    // adjoint of the kinematic chain without walking it level by level:
+    //   dG_j = sum over the subtree of j of  loc_d . Gh_d^T . Gh_j^-T        (Gh = 4x4 homogeneous G)
+    // because G_d = G_j . Rel(j->d).  Pass A forms M_d = loc_d . Gh_d^T (stored at the DFS
+    // pre-order position of d), pass B sums contiguous pre-order ranges in fixed order (no
+    // atomics -> deterministic), pass C applies Gh_j^-T.  Then dR, d(rel) (pass D) and dJ (pass E).
     for (int w = t; w < SFX_J * 3; w += CT) {
         const int j = w / 3, r = w % 3;
         float acc = 0.f;
@@ -640,27 +660,52 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
         S.dpj[w] = acc;
     }
     __syncthreads();
-    for (int lev = M.n_levels - 1; lev >= 0; --lev) {
-        const int i0 = M.level_start[lev], n = M.level_start[lev + 1] - i0;
-        const int jn = t / 12, e = t % 12;
-        if (jn < n) {
-            const int j = S.meta[MO_LJ + i0 + jn];
-            const int r = e >> 2, c = e & 3;
-            const float dat = S.dA[j * 12 + r * 4 + 3];
-            float v = (c < 3) ? (S.dA[j * 12 + e] - dat * S.Jr[j * 3 + c]) : (dat + S.dpj[j * 3 + r]);
-            for (int q2 = S.meta[MO_CS + j]; q2 < S.meta[MO_CS + j + 1]; ++q2) {
-                const int ch = S.meta[MO_CL + q2];
-                const float* dGc = &S.dG[ch * 12 + r * 4];
-                if (c < 3) {
-                    const float* Rch = &S.R[ch * 9 + c * 3];
-                    v += dGc[0] * Rch[0] + dGc[1] * Rch[1] + dGc[2] * Rch[2] + dGc[3] * (S.Jr[ch * 3 + c] - S.Jr[j * 3 + c]);
-                } else v += dGc[3];
-            }
-            S.dG[j * 12 + e] = v;
+    float* Mpre = S.T;          // scratch: the item transforms are dead here
+    FOR_CT(w, SFX_J * 12) {
+        const int d = w / 12, e = w % 12, r = e >> 2, k = e & 3;
+        const float* dAd = &S.dA[d * 12 + r * 4];
+        const float l3 = dAd[3] + S.dpj[d * 3 + r];
+        float v = l3;
+        if (k < 3) {
+            const float* Gk = &S.G[d * 12 + k * 4];
+            const float* Jd = &S.Jr[d * 3];
+            v = (dAd[0] - dAd[3] * Jd[0]) * Gk[0] + (dAd[1] - dAd[3] * Jd[1]) * Gk[1] + (dAd[2] - dAd[3] * Jd[2]) * Gk[2] + l3 * Gk[3];
         }
-        __syncthreads();
+        Mpre[S.meta[MO_PRE + d] * 12 + e] = v;
     }
-    for (int w = t; w < SFX_J * 12; w += CT) {
+    __syncthreads();
+    FOR_CT(w, SFX_J * 12) {
+        const int j = w / 12, e = w % 12;
+        const int q0 = S.meta[MO_PRE + j], n = S.meta[MO_SUB + j];
+        float acc = 0.f;
+        for (int q2 = 0; q2 < n; ++q2) acc += Mpre[(q0 + q2) * 12 + e];
+        S.dG[w] = acc;          // subtree sum, still in the basis of the world frame
+    }
+    __syncthreads();
+    {
+        static_assert(SFX_J * 12 <= 3 * CT, "three elements per thread");
+        float vv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int w = t + i * CT;
+            vv[i] = 0.f;
+            if (w < SFX_J * 12) {
+                const int j = w / 12, e = w % 12, r = e >> 2, c = e & 3;
+                const float* Sj = &S.dG[j * 12 + r * 4];
+                float v = Sj[3];
+                if (c < 3) {
+                    const float* Gj = &S.G[j * 12];
+                    v = Gj[c] * (Sj[0] - Sj[3] * Gj[3]) + Gj[4 + c] * (Sj[1] - Sj[3] * Gj[7]) + Gj[8 + c] * (Sj[2] - Sj[3] * Gj[11]);
+                }
+                vv[i] = v;
+            }
+        }
+        __syncthreads();        // every thread has read the sums it needs before they are overwritten
+#pragma unroll
+        for (int i = 0; i < 3; ++i) if (t + i * CT < SFX_J * 12) S.dG[t + i * CT] = vv[i];
+    }
+    __syncthreads();
+    FOR_CT(w, SFX_J * 12) {
         const int j = w / 12, e = w % 12;
         const int p = S.meta[MO_PAR + j];
         const float* dGj = &S.dG[j * 12];

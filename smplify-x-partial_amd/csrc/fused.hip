@@ -24,6 +24,7 @@ void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const S
     for (int it = 0; it < max_ticks; ++it) {
         if (D.stage[b] > last_stage) break;
         closure_body(S, M, D, vls, sws, a, b, gflat, &fval);
+        a.keep_tables = 1;
         __syncthreads();
         if (threadIdx.x < 64)
             lbfgs_tick_body(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, &fval, gflat);
@@ -54,7 +55,7 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
         if (D.stage[b] > last_stage) return;
     }
     ClosureArgs e{};
-    e.stage_override = -2; e.export_dense = 1; e.forward_only = 2;
+    e.stage_override = -2; e.export_dense = 1; e.forward_only = 2; e.keep_tables = has_eval;
     closure_body(S, M, D, vls, sws, e, b, nullptr, nullptr);
     if (D.dbg && b == 0 && threadIdx.x == 0) D.dbg[26] = clock64();
 }

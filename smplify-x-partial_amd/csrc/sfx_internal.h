@@ -30,7 +30,11 @@
 #define MO_JI0 712
 #define MO_JN 856
 #define MO_IK 1000
-#define SFX_META_N 1240
+#define MO_PRE 1240         // joint -> DFS pre-order position (subtree = contiguous pre-order range)
+#define MO_SUB 1296         // joint -> subtree size
+#define MO_ANC 1352         // [SFX_MAX_ROUNDS][56] 2^k-th ancestor of each joint (-1 past the root)
+#define SFX_MAX_ROUNDS 5
+#define SFX_META_N 1632
 
 // Canonical per-frame parameter block (floats).  cam_t | global_orient | betas | lhand |
 // rhand | expression | jaw | leye | reye | body_pose param (dead, iff !use_vposer) | embedding
@@ -54,7 +58,7 @@ struct StageW {       // per body stage
 struct DevModel {
     int V, F, S, P, KD, K;            // S = NB+NE, P = 486, KD = S+P
     int n_extra, n_lmk, n_dyn_rows, n_dyn;
-    int n_levels;
+    int n_levels, n_rounds;           // tree depth + 1; ceil(log2(n_levels)) pointer-jumping rounds
     int level_start[SFX_MAX_LEVELS + 1];
     // constants
     const float* v_template;   // [V][3]
@@ -172,6 +176,7 @@ struct ClosureArgs {
     int use_dense_verts;    // 1: item vertices come from BatchDev.verts
     int export_dense;       // 1: write featT / AT for the dense kernel
     int from_X;             // 1: evaluate at X instead of Xt
+    int keep_tables;        // 1: S.meta / S.fd are still valid from the previous evaluation of this workgroup
     int reuse_fwd;          // 1: forward state of this trial point was saved by the export pass
 };
 void launch_closure(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,

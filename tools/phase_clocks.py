@@ -15,6 +15,7 @@ for which in ('body','full'):
         t = np.array(list(out)[:17], np.float64); d = np.diff(t)
         wall = (out[18] - out[17]) * 0.01   # 100 MHz constant clock -> us
         print('   loss sub-phases (8->20->21->22->23->9):', [int(out[20]-out[8]), int(out[21]-out[20]), int(out[22]-out[21]), int(out[23]-out[22]), int(out[9]-out[23])])
+        print('   chain sub-phases (3->27->28->4):', [int(out[27]-out[3]), int(out[28]-out[27]), int(out[4]-out[28])])
         print(which, 'stage', st, 'total cycles', t[16]-t[0], 'wall us', wall, 'phases', d.astype(int).tolist())
 
     # optimiser tick profile of frame 0 over a whole fit (rows path)
