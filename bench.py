@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU")
     ap.add_argument("--lbs", default="dense", choices=["dense", "rows"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra needed-rows measurement")
     ap.add_argument("--groups", type=int, default=1, help="independent sub-batches per GPU (host threads/streams)")
     args = ap.parse_args()
 
@@ -141,10 +142,10 @@ def main():
     jw[cfg["joints_to_ign"]] = 0.0                 # COCO25.get_joint_weights (data_parser.py:159-171)
     n_total = world * B
 
-    def one_fit():
+    def one_fit(lbs_mode=None):
         res = driver.fit_frames(dm, cfg, frames["keypoints"], jw, frames["H"], frames["W"], frames["focal"],
-                                reg_pose=frames["reg_pose"], reg_global=frames["reg_global"], lbs_mode=args.lbs,
-                                reuse_entry_eval=True, groups=args.groups)
+                                reg_pose=frames["reg_pose"], reg_global=frames["reg_global"],
+                                lbs_mode=lbs_mode or args.lbs, reuse_entry_eval=True, groups=args.groups)
         rec = sdist.pack_records(res, rank * B)
         table = sdist.gather_records(rec, n_total, device=dev)      # the one collective (RCCL all_gather)
         assert table.shape[0] == n_total
@@ -171,6 +172,27 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # the same job through the needed-rows path (what the product runs when nothing consumes the
+    # full mesh inside the loop): one warm-up fit, then the same number of timed fits
+    alt = None
+    if args.lbs == "dense" and not args.no_alt:
+        one_fit("rows")
+        sync()
+        t1 = time.time()
+        for _ in range(args.steps):
+            st_alt, _ = one_fit("rows")
+        sync()
+        dta = time.time() - t1
+        if dist is not None:
+            tt = torch.tensor([dta], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dta = float(tt.item())
+        alt = {"lbs_mode": "rows", "value": world * B * args.steps / dta, "unit": "frames/s",
+               "ms_per_step": 1e3 * dta / args.steps,
+               "closure_evals_per_frame_mean": float(st_alt["stage_evals"].sum(1).mean()),
+               "final_loss_mean": float(np.nanmean(st_alt["stage_loss"][:, -1])),
+               "note": "persistent per-frame kernel k_fit_rows: SMPL-X forward/adjoint on the rows the loss reads "
+                       "(SURVEY 8d: legitimate while coll_loss_weight == 0); same objective, same optimiser"}
 
     if rank == 0:
         ms_dense, n_dense, u_dense = engine.prof_get("lbs_dense")
@@ -215,9 +237,15 @@ def main():
                                             "MFLOP/frame) / kernel time; achieved_executed counts only issued MFMA work "
                                             "(K padded to 512, skinning restricted to the %.1f joints per 16-vertex tile that "
                                             "carry weight)" % tj})
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_lbs_dense.json")
-            if os.path.exists(pmc):
-                out["roofline"]["traffic"] = json.load(open(pmc))
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+            if os.path.exists(pmc):     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/run_prof.sh)
+                k = json.load(open(pmc)).get("k_lbs_dense", {})
+                if "hbm_read_bytes_per_launch" in k and "hbm_write_bytes_per_launch" in k:
+                    out["roofline"]["traffic"] = k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"]
+                    out["roofline"]["traffic_detail"] = {
+                        "read_bytes_per_launch": k["hbm_read_bytes_per_launch"],
+                        "write_bytes_per_launch": k["hbm_write_bytes_per_launch"],
+                        "source": "profiles/r01_pmc_summary.json (FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE as reported)"}
         else:
             # persistent per-frame kernel: bytes the needed-rows closure must move per evaluation
             # (11 vertex rows x (3 x 506 blend-shape + 8 skinning entries), forward and adjoint)
@@ -231,6 +259,8 @@ def main():
                                "kernel_ms_total": ms_lb, "launches": n_lb,
                                "note": "latency-bound by construction: one workgroup walks one frame's serial "
                                        "L-BFGS chain; the meaningful figure is frames/s"}
+        if alt is not None:
+            out["alt"] = alt
         if not args.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(model, cfg, frames, float(ref_evals.mean()))

@@ -27,8 +27,12 @@ def main():
             e["hbm_read_bytes_per_launch"] = 2.0 * 1024.0 * e["FETCH_SIZE"]["mean_per_launch"]
         if "WRITE_SIZE" in e:
             e["hbm_write_bytes_per_launch"] = 1024.0 * e["WRITE_SIZE"]["mean_per_launch"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in e and "GRBM_GUI_ACTIVE" in e and e["GRBM_GUI_ACTIVE"]["mean_per_launch"] > 0:
+            # busy cycles are summed over the 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE comes back summed over
+            # the 8 XCDs (1.28 M for a 62 us kernel = 8 x 160 k cycles), so one XCD's active time is /8
+            e["mfma_busy_frac"] = e["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / (e["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0 * 256 * 4)
     json.dump(res, open(out_path, "w"), indent=1)
-    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk.startswith("hbm")} for k, v in res.items()}))
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk.startswith("hbm") or kk.startswith("mfma")} for k, v in res.items()}))
 
 if __name__ == "__main__":
     main()
