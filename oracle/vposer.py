@@ -64,3 +64,40 @@ class VPoserRef(nn.Module):
         b3 = torch.cross(b1, b2, dim=1)
         R = torch.stack([b1, b2, b3], dim=-1)
         return rotmat_to_aa(R).view(B, 1, -1, 3)
+
+
+class VPoserEncoderRef(nn.Module):
+    """Encoder of VPoser-v1 built from torch modules the way the package defines it
+    (`bodyprior_enc_bn1/fc1/bn2/fc2/mu/logvar`); `encode` returns the
+    torch.distributions.Normal the reference samples from (fit_single_frame.py:245)."""
+
+    def __init__(self, w, dtype=torch.float64):
+        super().__init__()
+        n_in, hid = w["enc_fc1_w"].shape[1], w["enc_fc1_w"].shape[0]
+        lat = w["enc_mu_w"].shape[0]
+        self.bodyprior_enc_bn1 = nn.BatchNorm1d(n_in)
+        self.bodyprior_enc_fc1 = nn.Linear(n_in, hid)
+        self.bodyprior_enc_bn2 = nn.BatchNorm1d(hid)
+        self.bodyprior_enc_fc2 = nn.Linear(hid, hid)
+        self.bodyprior_enc_mu = nn.Linear(hid, lat)
+        self.bodyprior_enc_logvar = nn.Linear(hid, lat)
+        t = lambda a: torch.as_tensor(np.asarray(a), dtype=dtype)
+        sd = {}
+        for short, mod in (("enc_bn1", "bodyprior_enc_bn1"), ("enc_bn2", "bodyprior_enc_bn2")):
+            sd[mod + ".weight"], sd[mod + ".bias"] = t(w[short + "_w"]), t(w[short + "_b"])
+            sd[mod + ".running_mean"], sd[mod + ".running_var"] = t(w[short + "_mean"]), t(w[short + "_var"])
+            sd[mod + ".num_batches_tracked"] = torch.tensor(0)
+        for short, mod in (("enc_fc1", "bodyprior_enc_fc1"), ("enc_fc2", "bodyprior_enc_fc2"),
+                           ("enc_mu", "bodyprior_enc_mu"), ("enc_logvar", "bodyprior_enc_logvar")):
+            sd[mod + ".weight"], sd[mod + ".bias"] = t(w[short + "_w"]), t(w[short + "_b"])
+        self.to(dtype)
+        self.load_state_dict(sd)
+        self.eval()
+
+    def encode(self, x):
+        x = x.view(x.size(0), -1)
+        x = self.bodyprior_enc_bn1(x)
+        x = F.leaky_relu(self.bodyprior_enc_fc1(x), negative_slope=0.2)
+        x = self.bodyprior_enc_bn2(x)
+        x = F.leaky_relu(self.bodyprior_enc_fc2(x), negative_slope=0.2)
+        return torch.distributions.normal.Normal(self.bodyprior_enc_mu(x), F.softplus(self.bodyprior_enc_logvar(x)))

@@ -123,6 +123,7 @@ class DeviceModel(object):
         self._h = h
         self._lib = lib
         self.vposer_latent = 0
+        self.vposer_weights = None
         if vposer is not None:
             self.set_vposer(vposer)
 
@@ -133,6 +134,7 @@ class DeviceModel(object):
                                                   capi.fptr(a["fc2_w"]), capi.fptr(a["fc2_b"]),
                                                   capi.fptr(a["out_w"]), capi.fptr(a["out_b"])))
         self.vposer_latent = latent
+        self.vposer_weights = a          # the encoder (if present) runs on the host: vposer.encode
 
     def lbs_forward(self, global_orient, body_pose, betas, expression, jaw_pose, leye_pose, reye_pose,
                     left_hand_pose, right_hand_pose, return_verts=True, return_full_pose=True, stream=None):

@@ -1,8 +1,11 @@
 """Drop-in for smplifyx/fit_single_frame.py:59-677 -- same signature, same result pickle
 (keys and order of :644-657, protocol 2), same optional vertices.ply -- with the whole
 optimisation executed by the MI355X engine (driver.fit_frames with a batch of one).
-Not reproduced: visualisation (`visualize=True`), interpenetration (BVH term),
-VPoser encode().sample() initialisation (random in the reference, :245).
+Not reproduced: visualisation (`visualize=True`), interpenetration (BVH term).
+`vposer.encode(prior).sample()` (:245, random in the reference) uses the posterior mean unless
+`vposer_sample_seed` is given.  kwargs['lbs_mode'] = 'dense' evaluates all 10475 vertices in
+every closure call as the reference does; the default 'rows' evaluates the rows the loss reads
+(same objective, same optimiser; the mesh is produced once at the end).
 """
 import os
 import pickle
@@ -12,6 +15,7 @@ import torch
 
 from . import driver
 from . import utils
+from . import vposer as vposer_host
 
 
 def _write_ply(path, vertices):
@@ -55,13 +59,20 @@ def fit_single_frame(img, keypoints, body_model, camera, joint_weights, body_pos
                left_shoulder_idx=left_shoulder_idx, right_shoulder_idx=right_shoulder_idx, use_vposer=use_vposer)
     if not use_joints_conf:
         raise NameError("name 'joints_conf' is not defined")   # the reference fails here (fit_single_frame.py:286)
+    dm = body_model.device_model
+    if use_vposer and not dm.vposer_latent:         # load_vposer(vposer_ckpt, vp_model='snapshot') (:239-242)
+        dm.set_vposer(vposer_host.load_vposer(vposer_ckpt))
     reg_pose = reg_glob = cam_t = cam_c = None
     if regression_prior:
         reg_pose, reg_glob = utils.regression_prior_pose(regression_prior, expose=expose_results, pixie=pixie_results,
                                                          pare=pare_results)
         if use_vposer:
-            raise NotImplementedError("use_vposer with a regression prior needs VPoser encode().sample() "
-                                      "(random in the reference, SURVEY.md 8f-2)")
+            # pose_embedding = vposer.encode(full_pose_prior).sample() (:245); the same latent is the
+            # regression target of the last stage (:442, fitting.py:391-393).  The posterior MEAN is
+            # used unless kwargs['vposer_sample_seed'] asks for a (seeded) sample.
+            seed = kwargs.get("vposer_sample_seed")
+            gen = np.random.default_rng(seed) if seed is not None else None
+            reg_pose = vposer_host.encode(dm.vposer_weights, reg_pose, generator=gen)
         if kwargs.get("use_camera_prior"):
             if regression_prior in ("ExPose", "combined"):
                 cam_c = np.asarray(expose_results["center"], np.float32)
@@ -79,13 +90,12 @@ def fit_single_frame(img, keypoints, body_model, camera, joint_weights, body_pos
                 pc = pare_results["pred_cam"][0]
                 cam_c = np.array([cx, cy], np.float32)
                 cam_t = np.array([pc[1], pc[2], (2 * focal_length) / (bb * pc[0])])
-    dm = body_model.device_model
     kp = np.asarray(keypoints, np.float32).reshape(1, dm.K, 3)
     jw = joint_weights.detach().cpu().numpy() if torch.is_tensor(joint_weights) else np.asarray(joint_weights)
     want_v = bool(kwargs.get("save_vertices"))
     res = driver.fit_frames(dm, cfg, kp, jw.reshape(1, -1), H, W, focal_length, reg_pose=reg_pose, reg_global=reg_glob,
-                            cam_prior_t=cam_t, cam_prior_center=cam_c, lbs_mode="dense", reuse_entry_eval=True,
-                            want_vertices=want_v)
+                            cam_prior_t=cam_t, cam_prior_center=cam_c, lbs_mode=kwargs.get("lbs_mode", "rows"),
+                            reuse_entry_eval=True, want_vertices=want_v)
     # write the fitted values back into the caller's modules, as the reference leaves them
     with torch.no_grad():
         camera.translation[:] = torch.as_tensor(res["cam_translation"]).to(camera.translation)

@@ -199,9 +199,10 @@ def make_synthetic_model(seed=0, num_verts=NUM_VERTS, num_faces=NUM_FACES,
     return model
 
 
-def make_synthetic_vposer(seed=0, latent=32, hidden=512, dtype=np.float32):
+def make_synthetic_vposer(seed=0, latent=32, hidden=512, dtype=np.float32, encoder_inputs=0):
     """Random-init VPoser-v1 *decoder* weights (appendix A.3): fc1 32->512,
-    fc2 512->512, out 512->126, leaky_relu(0.2).  Scaled so decoded poses are O(0.3 rad)."""
+    fc2 512->512, out 512->126, leaky_relu(0.2).  Scaled so decoded poses are O(0.3 rad).
+    encoder_inputs = 63 or 189 adds random encoder weights (bn1, fc1, bn2, fc2, mu, logvar)."""
     rng = np.random.RandomState(1000 + seed)
     def lin(i, o, s):
         return (rng.normal(size=(o, i)) * s / np.sqrt(i)).astype(dtype), \
@@ -212,7 +213,18 @@ def make_synthetic_vposer(seed=0, latent=32, hidden=512, dtype=np.float32):
     # bias the 6-D output towards identity so z = 0 decodes near the rest pose
     ident6 = np.tile(np.array([1, 0, 0, 1, 0, 0], dtype), 21)   # view(-1,3,2): cols (1,0,0),(0,1,0)
     b3 = b3 + ident6
-    return dict(fc1_w=w1, fc1_b=b1, fc2_w=w2, fc2_b=b2, out_w=w3, out_b=b3)
+    out = dict(fc1_w=w1, fc1_b=b1, fc2_w=w2, fc2_b=b2, out_w=w3, out_b=b3)
+    if encoder_inputs:
+        def bn(n):
+            return ((1 + 0.1 * rng.normal(size=n)).astype(dtype), (0.05 * rng.normal(size=n)).astype(dtype),
+                    (0.1 * rng.normal(size=n)).astype(dtype), (0.5 + rng.uniform(size=n)).astype(dtype))
+        out["enc_bn1_w"], out["enc_bn1_b"], out["enc_bn1_mean"], out["enc_bn1_var"] = bn(encoder_inputs)
+        out["enc_fc1_w"], out["enc_fc1_b"] = lin(encoder_inputs, hidden, 1.0)
+        out["enc_bn2_w"], out["enc_bn2_b"], out["enc_bn2_mean"], out["enc_bn2_var"] = bn(hidden)
+        out["enc_fc2_w"], out["enc_fc2_b"] = lin(hidden, hidden, 1.0)
+        out["enc_mu_w"], out["enc_mu_b"] = lin(hidden, latent, 0.5)
+        out["enc_logvar_w"], out["enc_logvar_b"] = lin(hidden, latent, 0.5)
+    return out
 
 
 def rodrigues_np(theta):

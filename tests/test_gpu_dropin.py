@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _setup(synth_model, cfg):
+def _setup(synth_model, cfg, vposer=None):
     from smplifyx_amd import smplx, utils
     from smplifyx_amd.camera import create_camera
     jm = utils.JointMapper(H.joint_map_for(cfg))
@@ -24,7 +24,7 @@ def _setup(synth_model, cfg):
                         create_right_hand_pose=True, create_expression=True, create_jaw_pose=True,
                         create_leye_pose=True, create_reye_pose=True, create_transl=False, dtype=torch.float32)
     args = {k: v for k, v in cfg.items() if k not in model_params and k != "gender"}
-    bm = smplx.create(gender="neutral", **model_params, **args).to("cuda")
+    bm = smplx.create(gender="neutral", vposer=vposer, **model_params, **args).to("cuda")
     cam = create_camera(focal_length_x=5000.0, focal_length_y=5000.0, dtype=torch.float32, **cfg).to("cuda")
     cam.rotation.requires_grad = False
     return bm, cam
@@ -189,3 +189,99 @@ def test_fit_single_frame_writes_reference_pickle(synth_model, tmp_path):
     assert abs(final - ref32[-1]) / ref32[-1] < max(3 * spread, 5e-2)
     assert res["body_pose"].shape == (1, 63) and res["camera_translation"].shape == (1, 3)
     assert np.abs(res["camera_translation"] - g["f%d_f32_camera_translation" % i]).max() < 5e-2
+
+
+def test_vposer_latent_regression_prior(synth_model, tmp_path):
+    """cfg_files/fit_smplx_combined_vposer_coco25.yaml: VPoser latent started from
+    vposer.encode(regression prior) (fit_single_frame.py:245) and pulled towards it in the LAST
+    stage only (fitting.py:391-395).  (i) the prior term is exactly body_pose_weight^2 |z - r|^2
+    at the last stage and |z|^2 before; (ii) the drop-in fit_single_frame runs that cfg."""
+    from smplifyx_amd import engine, prior, synthetic, vposer
+    from smplifyx_amd.fit_single_frame import fit_single_frame
+    from scipy.spatial.transform import Rotation as Rot
+    g = np.load(os.path.join(GOLD, "e2e_synth.npz"))
+    cfg = H.load_cfg("fit_smplx_combined_vposer_coco25.yaml", use_hands=False, use_face=False)
+    assert cfg["use_vposer"] and cfg["regression_prior"] == "combined"
+    cfg["use_camera_prior"] = False
+    cfg["regression_prior"] = "ExPose"
+    vpw = synthetic.make_synthetic_vposer(0, encoder_inputs=63)
+    bm, camera = _setup(synth_model, cfg, vposer=vpw)
+    dm = bm.device_model
+    z0 = vposer.encode(vpw, g["reg_pose"][:1])
+    assert z0.shape == (1, 32)
+    # (i) analytic check of the latent prior term
+    n_st = len(cfg["body_pose_prior_weights"])
+    losses = {}
+    for tag, reg in (("a", z0), ("b", z0 + 0.25)):
+        fb = engine.FrameBatch(dm, 1, cfg, lbs_mode="rows", has_regression_pose=True)
+        kp = g["keypoints"][:1]
+        fb.set_frames(kp, np.tile(H.base_joint_weights(cfg, 25), (1, 1)), np.zeros((1, 25), np.float32), 5000.0,
+                      np.array([[400.0, 300.0]], np.float32), 1000.0 / 600)
+        z = z0 + 0.1
+        fb.set_params(regression_pose=reg, pose_embedding=z, global_orient=g["reg_global"][:1],
+                      cam_translation=np.array([[0.0, 0.0, 20.0]], np.float32))
+        losses[tag] = [fb.closure(s)[0][0] for s in range(n_st)]
+        fb.close()
+    z = z0 + 0.1
+    bpw = cfg["body_pose_prior_weights"]
+    for s in range(n_st - 1):
+        assert losses["a"][s] == losses["b"][s], s                  # target unused before the last stage
+    want = bpw[-1] ** 2 * (np.sum((z - z0) ** 2) - np.sum((z - z0 - 0.25) ** 2))
+    got = float(losses["a"][-1]) - float(losses["b"][-1])
+    assert abs(got - want) <= 1e-3 * abs(want) + 1e-4 * abs(float(losses["a"][-1])), (got, want)
+    # (ii) the whole drop-in call
+    expose = {"body_pose": Rot.from_euler("XYZ", g["reg_pose"][0].reshape(21, 3).astype(np.float64)).as_matrix().astype(np.float32),
+              "global_orient": Rot.from_euler("XYZ", g["reg_global"][0].astype(np.float64)[None]).as_matrix().astype(np.float32)}
+    a = dict(cfg); a["focal_length"] = 5000.0
+    for k in ("result_folder", "output_folder", "mesh_folder"):
+        a.pop(k, None)
+    mk = lambda t: prior.create_prior(prior_type=t, dtype=torch.float32)
+    fn = str(tmp_path / "000.pkl")
+    jw = torch.tensor(H.base_joint_weights(cfg, 25)).unsqueeze(0)
+    result, final = fit_single_frame(np.zeros((600, 800, 3), np.float32), g["keypoints"][:1], body_model=bm,
+                                     camera=camera, joint_weights=jw, dtype=torch.float32, shape_prior=mk("l2"),
+                                     expr_prior=None, body_pose_prior=mk("l2"), left_hand_prior=None, right_hand_prior=None,
+                                     jaw_prior=None, angle_prior=mk("angle"), result_fn=fn, expose_results=expose,
+                                     result_folder=str(tmp_path), **a)
+    assert np.isfinite(final) and result["body_pose"].shape == (1, 63)
+    assert np.all(np.isfinite(result["body_pose"])) and np.all(np.isfinite(result["camera_translation"]))
+
+
+def test_batched_main_writes_reference_layout(synth_model, tmp_path):
+    """smplifyx_amd.main.main(**cfg): the reference's main.py interface (dataset folder, model
+    folder, ExPose result files, output layout) with all frames fitted as one batch."""
+    import json
+    from PIL import Image
+    from scipy.spatial.transform import Rotation as Rot
+    from smplifyx_amd import main as amd_main
+    g = np.load(os.path.join(GOLD, "e2e_synth.npz"))
+    data, models, expose_dir, out = tmp_path / "data", tmp_path / "models" / "smplx", tmp_path / "expose", tmp_path / "out"
+    for d in (data / "images", data / "keypoints", models, expose_dir):
+        os.makedirs(d)
+    np.savez(models / "SMPLX_NEUTRAL.npz", **synth_model)
+    names = ["frame_a", "frame_b"]
+    for i, n in enumerate(names):
+        Image.fromarray(np.zeros((600, 800, 3), np.uint8)).save(data / "images" / (n + ".png"))
+        json.dump({"people": [{"pose_keypoints_2d": [float(v) for v in g["keypoints"][i].reshape(-1)],
+                               "hand_left_keypoints_2d": [], "hand_right_keypoints_2d": [], "face_keypoints_2d": []}]},
+                  open(data / "keypoints" / (n + "_keypoints.json"), "w"))
+        os.makedirs(expose_dir / (n + ".jpg"))
+        np.savez(expose_dir / (n + ".jpg") / (n + ".jpg_params.npz"),
+                 body_pose=Rot.from_euler("XYZ", g["reg_pose"][i].reshape(21, 3).astype(np.float64)).as_matrix().astype(np.float32),
+                 global_orient=Rot.from_euler("XYZ", g["reg_global"][i].astype(np.float64)[None]).as_matrix().astype(np.float32))
+    cfg = H.load_cfg("fit_smplx_combined_coco25.yaml", use_hands=False, use_face=False)
+    cfg.update(use_camera_prior=False, use_face_contour=False, regression_prior="ExPose", data_folder=str(data), model_folder=str(tmp_path / "models"),
+               output_folder=str(out), expose_results_directory=str(expose_dir), pixie_results_directory=None,
+               focal_length=5000.0, save_vertices=True)
+    n = amd_main.main(**cfg)
+    assert n == 2 and os.path.isfile(out / "conf.yaml")
+    for i, nme in enumerate(names):
+        res = pickle.load(open(out / "results" / nme / "000.pkl", "rb"))
+        assert list(res.keys()) == ["camera_rotation", "camera_translation", "camera_center", "H", "W", "focal_length",
+                                    "betas", "global_orient", "body_pose", "left_hand_pose", "right_hand_pose",
+                                    "jaw_pose", "leye_pose", "reye_pose", "expression"]
+        assert res["H"] == 600 and res["W"] == 800 and res["camera_center"].tolist() == [[400.0, 300.0]]
+        assert np.abs(res["camera_translation"] - g["f%d_f32_camera_translation" % i]).max() < 5e-2
+        assert np.abs(res["betas"] - g["f%d_f32_betas" % i]).max() < 0.25
+        assert os.path.isdir(out / "meshes" / nme) and os.path.isdir(out / "images" / nme / "000")
+        assert os.path.getsize(out / "results" / nme / "vertices.ply") > 10475 * 12

@@ -320,8 +320,42 @@ def gen_demo():
     _save("demo_config1", **out)
 
 
+def gen_parser():
+    """data_parser.read_keypoints / dataset weights / shoulders of the reference on the demo
+    keypoint files.  The fixture keeps numbers only: the json fields as arrays (tests rebuild a
+    json from them) and what the reference returns for every flag combination."""
+    import json
+    out = {}
+    demo = os.path.join(ref_import.REF_ROOT, "demo")
+    for name in ("02_cropped", "18_cropped"):
+        fn = os.path.join(demo, "keypoints", name + "_blended.json")
+        data = json.load(open(fn))
+        out[name + "_n_people"] = np.array(len(data["people"]))
+        for p, person in enumerate(data["people"]):
+            for key in ("pose_keypoints_2d", "hand_left_keypoints_2d", "hand_right_keypoints_2d", "face_keypoints_2d"):
+                out["%s_p%d_%s" % (name, p, key)] = np.asarray(person[key], np.float64)
+        for hands in (0, 1):
+            for face in (0, 1):
+                for contour in (0, 1):
+                    kt = ref.data_parser.read_keypoints(fn, use_hands=bool(hands), use_face=bool(face),
+                                                         use_face_contour=bool(contour))
+                    out["%s_kp_h%d_f%d_c%d" % (name, hands, face, contour)] = np.stack(kt.keypoints)
+    for fmt, cls in (("coco25", ref.data_parser.COCO25), ("halpe", ref.data_parser.Halpe),
+                     ("coco_wholebody", ref.data_parser.COCO_Wholebody)):
+        for hands in (0, 1):
+            for face in (0, 1):
+                for contour in (0, 1):
+                    ds = cls(demo, use_hands=bool(hands), use_face=bool(face), use_face_contour=bool(contour),
+                             joints_to_ign=[1, 9, 12])
+                    out["%s_jw_h%d_f%d_c%d" % (fmt, hands, face, contour)] = ds.get_joint_weights().numpy()
+        ds = cls(demo)
+        out[fmt + "_shoulders"] = np.array([ds.get_left_shoulder(), ds.get_right_shoulder()])
+        out[fmt + "_n_items"] = np.array(len(ds))
+    _save("parser", **out)
+
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or ["tables", "euler", "objective", "lbfgs", "e2e", "demo", "e2e_vposer"]
     for w in todo:
         {"objective": gen_objective, "lbfgs": gen_lbfgs, "euler": gen_euler, "tables": gen_tables,
-         "e2e": gen_e2e, "demo": gen_demo, "e2e_vposer": gen_e2e_vposer}[w]()
+         "e2e": gen_e2e, "demo": gen_demo, "e2e_vposer": gen_e2e_vposer, "parser": gen_parser}[w]()

@@ -24,7 +24,7 @@ def available():
 
 def import_reference():
     """Returns a namespace with the reference modules:
-    fitting, camera, prior, utils, lbfgs_ls, optim_factory, fit_single_frame."""
+    fitting, camera, prior, utils, lbfgs_ls, optim_factory, fit_single_frame, data_parser."""
     if not available():
         raise RuntimeError("reference tree not present at %s" % REF_ROOT)
     if REPO_ROOT not in sys.path:
@@ -57,4 +57,5 @@ def import_reference():
     ns.lbfgs_ls = importlib.import_module("optimizers.lbfgs_ls")
     ns.optim_factory = importlib.import_module("optimizers.optim_factory")
     ns.fit_single_frame = importlib.import_module("fit_single_frame")
+    ns.data_parser = importlib.import_module("data_parser")
     return ns
