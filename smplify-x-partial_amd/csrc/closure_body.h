@@ -42,7 +42,17 @@
 #define FOR_CT(w, N) _Pragma("unroll") for (int w##_i = 0; w##_i < ((N) + CT - 1) / CT; ++w##_i)             \
                          if (const int w = t + w##_i * CT; w < (N))
 
-struct __align__(16) FrameLDS {
+struct EmptyLDS {};
+
+// Per-frame working set of the closure workgroup.  MAXI = item capacity, VP = VPoser activations
+// present.  Two variants are instantiated: <240, true> (any model / configuration, 86 KB) and
+// <32, false> (body-only keypoints without VPoser, 47 KB -> three workgroups per CU, or one next
+// to two 48-KB GEMM workgroups).
+template <int MAXI, bool VP>
+struct __align__(16) FrameLDSx {
+    static constexpr int kMaxItems = MAXI;
+    static constexpr int kBlocksPerCU = (MAXI <= SFX_SMALL_ITEMS && !VP) ? SFX_SMALL_OCC : 1;    // register budget of the fused kernels
+    static constexpr int kScratch = (MAXI * 12 > 2048) ? MAXI * 12 : 2048;
     float feat[SFX_KD_PAD];        // first: read as float4
     float x[SFX_NPAR_MAX];
     float full_pose[168];
@@ -50,15 +60,15 @@ struct __align__(16) FrameLDS {
     float Jr[SFX_J * 3];
     float G[SFX_J * 12];
     float A[SFX_J * 12];
-    float vp[SFX_MAX_ITEMS * 3];
-    float T[SFX_MAX_ITEMS * 12];
-    float vert[SFX_MAX_ITEMS * 3];
-    float dvert[SFX_MAX_ITEMS * 3];
-    float dvp[SFX_MAX_ITEMS * 3];
-    int   ivid[SFX_MAX_ITEMS];
-    float iw[SFX_MAX_ITEMS];
-    int   wj[SFX_MAX_ITEMS * SFX_NW];      // sparse skinning weights of the items
-    float ww[SFX_MAX_ITEMS * SFX_NW];
+    float vp[MAXI * 3];
+    float T[kScratch];             // item transforms [MAXI][12]; reused as scratch (>= 2048 floats) by the reverse sweep
+    float vert[MAXI * 3];
+    float dvert[MAXI * 3];
+    float dvp[MAXI * 3];
+    int   ivid[MAXI];
+    float iw[MAXI];
+    int   wj[MAXI * SFX_NW];       // sparse skinning weights of the items
+    float ww[MAXI * SFX_NW];
     float joints[SFX_MAX_K * 3];
     float dj[SFX_MAX_K * 3];
     float dA[SFX_J * 12];
@@ -74,11 +84,13 @@ struct __align__(16) FrameLDS {
     float lh45[SFX_NHAND], rh45[SFX_NHAND];
     float scal[16];
     int   lut_row;
-    VposerLDS V;                // VPoser activations (use_vposer only)
+    typename std::conditional<VP, VposerLDS, EmptyLDS>::type V;   // VPoser activations (use_vposer only)
     float fd[FD_N];             // this frame's keypoints / weights / camera / regression pose
     int   meta[SFX_META_N];     // tree / joint-map tables (one coalesced load instead of
                                 // dependent global loads inside every level of the chain)
 };
+using FrameLDS = FrameLDSx<SFX_MAX_ITEMS, true>;
+using FrameLDSSmall = FrameLDSx<SFX_SMALL_ITEMS, false>;
 
 __device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 
@@ -161,7 +173,8 @@ __device__ __forceinline__ float gmof_grad(float r, float rho2) {
 // One closure evaluation of frame b by the whole workgroup (CT threads).  When `gflat` is not
 // NULL the flat gradient / loss are ALSO left in LDS (gflat[NVAR_MAX], *fout) for a consumer in
 // the same workgroup (fused kernels).
-__device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, const BatchDev& D,
+template <class LDS>
+__device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const BatchDev& D,
                                              const VarList* __restrict__ vls, const StageW* __restrict__ sws,
                                              const ClosureArgs& args, const int b, float* gflat, float* fout) {
     const int t = threadIdx.x;
@@ -179,7 +192,8 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
     // full_pose, R, Jr, G, A -- the leading members of FrameLDS -- plus hand poses, LUT row and
     // the VPoser activations) in D.fwd; reload it instead of recomputing pose assembly,
     // Rodrigues, joint regression and the kinematic chain
-    constexpr int FWD_PREFIX = (int)(offsetof(FrameLDS, vp) / sizeof(float));
+    constexpr bool HAS_VP = !std::is_same<decltype(S.V), EmptyLDS>::value;
+    constexpr int FWD_PREFIX = (int)(offsetof(LDS, vp) / sizeof(float));
     static_assert(FWD_PREFIX % 4 == 0 && FWD_PREFIX + 96 + 2 * VP_H + 128 + 64 <= SFX_FWD_N, "forward-state blob layout");
     const bool reuse = args.reuse_fwd != 0;
     float* fwd = D.fwd ? D.fwd + (size_t)b * SFX_FWD_N : nullptr;
@@ -207,7 +221,7 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
         const float* ex = fwd + FWD_PREFIX;
         if (t < SFX_NHAND) { S.lh45[t] = ex[t]; S.rh45[t] = ex[SFX_NHAND + t]; }
         if (t == 64) S.lut_row = __float_as_int(ex[2 * SFX_NHAND]);
-        if (C.use_vposer) {
+        if constexpr (HAS_VP) if (C.use_vposer) {
             const float* vx = ex + 96;
             for (int i = t; i < VP_H; i += CT) { S.V.h1[i] = vx[i]; S.V.h2[i] = vx[VP_H + i]; }
             if (t < 128) S.V.o[t] = vx[2 * VP_H + t];
@@ -215,11 +229,14 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
         }
     }
     __syncthreads();
-    if (C.use_vposer && !reuse) {          // body_pose = vposer.decode(pose_embedding) (fitting.py:236-238)
-        vposer_forward<CT>(S.V, M, S.x + L.emb);
-        if (t < 63) D.bodypose[(size_t)b * 63 + t] = S.V.body[t];
+    const float* bodypose = S.x + L.emb;
+    if constexpr (HAS_VP) {
+        if (C.use_vposer && !reuse) {          // body_pose = vposer.decode(pose_embedding) (fitting.py:236-238)
+            vposer_forward<CT>(S.V, M, S.x + L.emb);
+            if (t < 63) D.bodypose[(size_t)b * 63 + t] = S.V.body[t];
+        }
+        if (C.use_vposer) bodypose = S.V.body;
     }
-    const float* bodypose = C.use_vposer ? S.V.body : (S.x + L.emb);
   if (!reuse) {
 
     MARK(1);
@@ -353,7 +370,7 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
                 float* ex = fwd + FWD_PREFIX;
                 if (t < SFX_NHAND) { ex[t] = S.lh45[t]; ex[SFX_NHAND + t] = S.rh45[t]; }
                 if (t == 64) ex[2 * SFX_NHAND] = __int_as_float(S.lut_row);
-                if (C.use_vposer) {
+                if constexpr (HAS_VP) if (C.use_vposer) {
                     float* vx = ex + 96;
                     for (int i = t; i < VP_H; i += CT) { vx[i] = S.V.h1[i]; vx[VP_H + i] = S.V.h2[i]; }
                     if (t < 128) vx[2 * VP_H + t] = S.V.o[t];
@@ -771,7 +788,7 @@ __device__ __forceinline__ void closure_body(FrameLDS& S, const DevModel& M, con
     }
     __syncthreads();
     MARK(15);
-    if (C.use_vposer) vposer_backward<CT>(S.V, M, &S.dpose[3], &S.gc[L.emb]);   // d body_pose -> d latent
+    if constexpr (HAS_VP) if (C.use_vposer) vposer_backward<CT>(S.V, M, &S.dpose[3], &S.gc[L.emb]);   // d body_pose -> d latent
     const VarList& vl = vls[cam_stage ? 0 : 1];
     float* gout = D.g + (size_t)b * SFX_NVAR_MAX;
     for (int i = t; i < vl.n; i += CT) { const float gv = S.gc[vl.idx[i]]; gout[i] = gv; if (gflat) gflat[i] = gv; }

@@ -10,10 +10,11 @@
 #include "closure_body.h"
 #include "lbfgs_body.h"
 
-__global__ __launch_bounds__(CT)
+template <class LDS>
+__global__ __launch_bounds__(CT, LDS::kBlocksPerCU)
 void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const StageW* __restrict__ sws,
                 int first_stage, int last_stage, int max_ticks) {
-    __shared__ FrameLDS S;
+    __shared__ LDS S;
     __shared__ float gflat[SFX_NVAR_MAX];
     __shared__ float fval;
     __shared__ float s_al[SFX_HIST + 2 * LB_BS];
@@ -32,10 +33,11 @@ void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const S
     }
 }
 
+template <class LDS>
 __global__ __launch_bounds__(CT)
 void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const StageW* __restrict__ sws,
                   int first_stage, int last_stage, int has_eval) {
-    __shared__ FrameLDS S;
+    __shared__ LDS S;
     __shared__ float gflat[SFX_NVAR_MAX];
     __shared__ float fval;
     __shared__ float s_al[SFX_HIST + 2 * LB_BS];
@@ -62,9 +64,15 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
 
 void launch_fit_rows(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
                      int first_stage, int last_stage, int max_ticks, hipStream_t s) {
-    hipLaunchKernelGGL(k_fit_rows, dim3(D.cfg.B), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, max_ticks);
+    if (sfx_small_closure(M, D))
+        hipLaunchKernelGGL(k_fit_rows<FrameLDSSmall>, dim3(D.cfg.B), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, max_ticks);
+    else
+        hipLaunchKernelGGL(k_fit_rows<FrameLDS>, dim3(D.cfg.B), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, max_ticks);
 }
 void launch_tick_dense(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
                        int first_stage, int last_stage, int has_eval, hipStream_t s) {
-    hipLaunchKernelGGL(k_tick_dense, dim3(D.cfg.B), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
+    if (sfx_small_closure(M, D))
+        hipLaunchKernelGGL(k_tick_dense<FrameLDSSmall>, dim3(D.cfg.B), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
+    else
+        hipLaunchKernelGGL(k_tick_dense<FrameLDS>, dim3(D.cfg.B), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
 }

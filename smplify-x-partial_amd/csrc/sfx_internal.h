@@ -8,6 +8,10 @@
 #define SFX_NHAND 45
 #define SFX_MAX_K 144       // mapped joints
 #define SFX_MAX_ITEMS 240   // vertex items (21 + 68*3 = 225)
+#define SFX_SMALL_ITEMS 32  // item capacity of the small closure variant (body-only: 11 items)
+#ifndef SFX_SMALL_OCC
+#define SFX_SMALL_OCC 1      // workgroups per CU the register budget of the small fused kernels is sized for
+#endif
 #define SFX_KD_PAD 512      // padded blend-shape depth (20 + 486 = 506)
 #define SFX_JPAD 56         // joints padded to an even MFMA depth
 #define SFX_MAX_LEVELS 16
@@ -179,6 +183,11 @@ struct ClosureArgs {
     int keep_tables;        // 1: S.meta / S.fd are still valid from the previous evaluation of this workgroup
     int reuse_fwd;          // 1: forward state of this trial point was saved by the export pass
 };
+// the 47-KB closure variant serves models whose keypoints need at most SFX_SMALL_ITEMS vertex rows
+// when the VPoser decoder is not in the loop
+static inline bool sfx_small_closure(const DevModel& M, const BatchDev& D) {
+    return M.n_items <= SFX_SMALL_ITEMS && !D.cfg.use_vposer;
+}
 void launch_closure(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
                     const ClosureArgs& a, hipStream_t s);
 void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s);
