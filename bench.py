@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU")
     ap.add_argument("--lbs", default="dense", choices=["dense", "rows"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--prof-every", type=int, default=8, help="HIP-event-time every N-th launch of each kernel")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra needed-rows measurement")
     ap.add_argument("--groups", type=int, default=1, help="independent sub-batches per GPU (host threads/streams)")
     args = ap.parse_args()
@@ -159,7 +160,7 @@ def main():
 
     for _ in range(args.warmup):
         one_fit()
-    engine.prof_enable(True)
+    engine.prof_enable(True, every=args.prof_every)
     engine.prof_reset()
     sync()
     t0 = time.time()
@@ -215,7 +216,7 @@ def main():
                        "final_loss_mean": float(np.nanmean(st["stage_loss"][:, -1]))},
             "kernels_ms_avg": {"lbs_dense": ms_dense / max(n_dense, 1), "tick_dense": ms_clo / max(n_clo, 1),
                                "fit_rows": ms_lb / max(n_lb, 1),
-                               "launches_per_step": (n_dense + n_clo + n_lb) / max(args.steps, 1)},
+                               "timed_launches_per_step": (n_dense + n_clo + n_lb) / max(args.steps, 1)},
         }
         if args.lbs == "dense" and n_dense:
             # active-frame compaction makes the frames per launch vary: achieved = total algorithmic
@@ -228,7 +229,8 @@ def main():
                                "peak": PEAK_MFMA_F32 / 1e12, "unit": "TFLOP/s", "frac": fl / t_tot / PEAK_MFMA_F32,
                                "traffic": None, "flops_per_launch": fl / n_dense, "bytes_per_launch": by / n_dense,
                                "hbm_GBps": by / t_tot / 1e9, "hbm_frac": by / t_tot / PEAK_HBM,
-                               "avg_launch_us": 1e6 * t_tot / n_dense, "launches": n_dense, "frames_per_launch": fpl}
+                               "avg_launch_us": 1e6 * t_tot / n_dense, "launches": n_dense, "frames_per_launch": fpl,
+                               "launch_sampling": "HIP events around every %d-th launch over the whole timed region" % args.prof_every}
             W_ = model["weights"]
             tj = np.mean([((int((W_[i:i + 16] != 0).any(0).sum()) + 3) // 4) * 4 for i in range(0, dm.V, 16)])
             fle = u_dense * lbs_flops_executed_per_frame(dm.V, tj)

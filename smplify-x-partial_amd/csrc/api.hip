@@ -24,34 +24,54 @@ extern "C" const char* sfx_version(void) { return "sfx 0.1.0 (gfx950)"; }
 
 // ---------------------------------------------------------------------------------------
 // profiling: HIP-event timing of named kernels on the launch stream
-struct ProfAcc { double ms = 0; int64_t n = 0; double units = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pend; };
+struct ProfAcc { double ms = 0; int64_t n = 0, seen = 0; double units = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pend; };
 static int g_prof = 0;
+static int g_prof_every = 1;  // time every N-th launch of a name (events cost a queue packet each)
 static int g_unfused = 0;     // debug: run the fitting loop with the stand-alone kernels
 static std::map<std::string, ProfAcc> g_acc;
+static std::vector<hipEvent_t> g_ev_pool;
 static std::mutex g_prof_mu;     // batches may be driven from several host threads (one stream each)
 
+static hipEvent_t ev_get() {
+    if (!g_ev_pool.empty()) { hipEvent_t e = g_ev_pool.back(); g_ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr; hipEventCreate(&e); return e;
+}
 static void prof_flush(ProfAcc& a) {
     for (auto& p : a.pend) {
         hipEventSynchronize(p.second);
         float ms = 0; hipEventElapsedTime(&ms, p.first, p.second);
         a.ms += ms; a.n += 1;
-        hipEventDestroy(p.first); hipEventDestroy(p.second);
+        g_ev_pool.push_back(p.first); g_ev_pool.push_back(p.second);
     }
     a.pend.clear();
 }
 struct ProfScope {
     const char* name; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
     ProfScope(const char* n, hipStream_t st, double units = 0) : name(n), s(st) {
-        if (g_prof) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, s);
-                      std::lock_guard<std::mutex> lk(g_prof_mu); g_acc[name].units += units; }
+        if (!g_prof) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        auto& a = g_acc[name];
+        if (a.seen++ % g_prof_every) return;
+        a.units += units;
+        e0 = ev_get(); e1 = ev_get();
+        hipEventRecord(e0, s);
     }
     ~ProfScope() {
-        if (g_prof && e0) { hipEventRecord(e1, s); std::lock_guard<std::mutex> lk(g_prof_mu);
-                            auto& a = g_acc[name]; a.pend.push_back({e0, e1});
-                            if (a.pend.size() > 4096) prof_flush(a); }
+        if (!e0) return;
+        hipEventRecord(e1, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        auto& a = g_acc[name]; a.pend.push_back({e0, e1});
+        if (a.pend.size() > 4096) prof_flush(a);
     }
 };
-extern "C" int sfx_prof_enable(int32_t on) { g_prof = on & 1; g_unfused = (on >> 1) & 1; return 0; }
+// bit 0: time launches with HIP events; bit 1: debug, stand-alone kernels; bits 8..23: time every
+// N-th launch of each name only (0/1 = every launch)
+extern "C" int sfx_prof_enable(int32_t on) {
+    g_prof = on & 1; g_unfused = (on >> 1) & 1;
+    const int every = (on >> 8) & 0xffff;
+    g_prof_every = every > 1 ? every : 1;
+    return 0;
+}
 extern "C" void sfx_prof_reset(void) { std::lock_guard<std::mutex> lk(g_prof_mu); for (auto& kv : g_acc) { prof_flush(kv.second); } g_acc.clear(); }
 extern "C" int sfx_prof_get(const char* name, double* total_ms, int64_t* launches, double* units) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -317,8 +317,10 @@ def fit_multi(batches, first_stage=-1, last_stage=None):
     capi.check(capi.load().sfx_fit_multi(arr, len(batches), first_stage, last))
 
 
-def prof_enable(on=True):
-    capi.load().sfx_prof_enable(int(on))
+def prof_enable(on=True, every=1):
+    """HIP-event timing of the named kernel launches; `every` = N times only every N-th launch of
+    each name (an event pair costs two queue packets per launch)."""
+    capi.load().sfx_prof_enable((int(on) & 3) | ((max(1, int(every)) & 0xffff) << 8))
 
 
 def prof_reset():
