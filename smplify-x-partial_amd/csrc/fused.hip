@@ -10,6 +10,10 @@
 #include "closure_body.h"
 #include "lbfgs_body.h"
 
+#ifndef LB_COOP_WAVES
+#define LB_COOP_WAVES 1
+#endif
+
 template <class LDS>
 __global__ __launch_bounds__(CT, LDS::kBlocksPerCU)
 void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const StageW* __restrict__ sws,
@@ -19,6 +23,7 @@ void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const S
     __shared__ float fval;
     __shared__ float s_al[SFX_HIST + 2 * LB_BS];
     __shared__ OptScal st;
+    __shared__ LbCoop cp;
     const int b = blockIdx.x;
     ClosureArgs a{};
     a.stage_override = -2;
@@ -27,8 +32,11 @@ void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const S
         closure_body(S, M, D, vls, sws, a, b, gflat, &fval);
         a.keep_tables = 1;
         __syncthreads();
-        if (threadIdx.x < 64)
-            lbfgs_tick_body(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, &fval, gflat);
+        // (LB_COOP_WAVES = 4 lets the idle wavefronts share the dot products of the two-loop recursion;
+        //  measured slower: one workgroup barrier per block of 8 history pairs costs more than the
+        //  3/4 of the reductions it removes -- 42 k vs 37 k cycles per direction)
+        if (LB_COOP_WAVES > 1 || threadIdx.x < 64)
+            lbfgs_tick_body<LB_COOP_WAVES>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, cp, &fval, gflat);
         __syncthreads();
     }
 }
@@ -42,24 +50,29 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
     __shared__ float fval;
     __shared__ float s_al[SFX_HIST + 2 * LB_BS];
     __shared__ OptScal st;
+    __shared__ LbCoop cp;
     const int b = blockIdx.x;
     if (D.stage[b] > last_stage) return;
-    if (D.dbg && b == 0 && threadIdx.x == 0) D.dbg[24] = clock64();
+    // debug clocks: stamps freeze after the 40th launch of this kernel, so a mid-fit launch is what is read back
+    if (D.dbg && b == 0 && threadIdx.x == 0) { D.dbg[62] += 1; if (D.dbg[62] <= 40) D.dbg[24] = clock64(); }
     if (has_eval) {
         ClosureArgs a{};
         a.stage_override = -2; a.use_dense_verts = 1; a.reuse_fwd = 1;
         closure_body(S, M, D, vls, sws, a, b, gflat, &fval);
         __syncthreads();
-        if (threadIdx.x < 64)
-            lbfgs_tick_body(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, &fval, gflat);
+        // (LB_COOP_WAVES = 4 lets the idle wavefronts share the dot products of the two-loop recursion;
+        //  measured slower: one workgroup barrier per block of 8 history pairs costs more than the
+        //  3/4 of the reductions it removes -- 42 k vs 37 k cycles per direction)
+        if (LB_COOP_WAVES > 1 || threadIdx.x < 64)
+            lbfgs_tick_body<LB_COOP_WAVES>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, cp, &fval, gflat);
         __syncthreads();
-        if (D.dbg && b == 0 && threadIdx.x == 0) { D.dbg[25] = clock64(); for (int i = 0; i < 17; ++i) D.dbg[40 + i] = D.dbg[i]; }
+        if (D.dbg && b == 0 && threadIdx.x == 0 && D.dbg[62] <= 40) { D.dbg[25] = clock64(); for (int i = 0; i < 17; ++i) D.dbg[40 + i] = D.dbg[i]; }
         if (D.stage[b] > last_stage) return;
     }
     ClosureArgs e{};
     e.stage_override = -2; e.export_dense = 1; e.forward_only = 2; e.keep_tables = has_eval;
     closure_body(S, M, D, vls, sws, e, b, nullptr, nullptr);
-    if (D.dbg && b == 0 && threadIdx.x == 0) D.dbg[26] = clock64();
+    if (D.dbg && b == 0 && threadIdx.x == 0 && D.dbg[62] <= 40) D.dbg[26] = clock64();
 }
 
 void launch_fit_rows(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,

@@ -9,7 +9,8 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
     __shared__ float s_al[SFX_HIST + 2 * LB_BS];
     __shared__ OptScal s_state;
     const int b = blockIdx.x;
-    lbfgs_tick_body(M, D, vls, first_stage, last_stage, init, step_mode, b, threadIdx.x, s_al, s_state,
+    __shared__ LbCoop cp;
+    lbfgs_tick_body<1>(M, D, vls, first_stage, last_stage, init, step_mode, b, threadIdx.x, s_al, s_state, cp,
                     D.f + b, D.g + (size_t)b * SFX_NVAR_MAX);
 }
 

@@ -157,12 +157,12 @@ __device__ __forceinline__ void wave_sum_multi(float (&x)[NB]) {
     // their value, which is the "+0" of the scan), 6 instructions per value.  Inline asm is not
     // seen by the hazard recogniser: the empty statements pin every producer before the s_nop,
     // and consecutive DPP reads of one register are NB-1 >= 2 instructions apart.
-    static_assert(NB >= 3, "wait states between dependent DPP steps");
 #pragma unroll
     for (int c = 0; c < NB; ++c) asm volatile("" : "+v"(x[c]));
     asm volatile("s_nop 1");
 #define LB_DPP_STEP(ctl)                                                                                   \
-    _Pragma("unroll") for (int c = 0; c < NB; ++c) asm volatile("v_add_f32_dpp %0, %0, %0 " ctl : "+v"(x[c]));
+    _Pragma("unroll") for (int c = 0; c < NB; ++c) asm volatile("v_add_f32_dpp %0, %0, %0 " ctl : "+v"(x[c])); \
+    if (NB < 3) asm volatile("s_nop 1");
     LB_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
     LB_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
     LB_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
@@ -217,13 +217,145 @@ __device__ __forceinline__ OptScal fresh_state() {
     return s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-loop recursion (lbfgs_ls.py:322-341), evaluated in blocks of BS history pairs by NW
+// cooperating wavefronts.  Within a block the BS dot products against the running vector are
+// independent (s_c . q for all c at once): wavefront w computes BS/NW of them, the partial results
+// meet in LDS (one workgroup barrier per block), and every wavefront then resolves the in-block
+// coupling  s_c . (q - sum_m al_m y_m)  on scalars with the stored band s_p . y_(p+k) of the Gram
+// matrix and applies all BS updates to ITS OWN copy of the running vector -- the copies stay
+// bit-identical, so no vector ever crosses wavefronts.  Same arithmetic in exact terms as the
+// sequential recursion; 2 x ceil(n/BS) block steps instead of 2n dependent dot->axpy steps.
+// History rows of the next block are fetched into a second register set while the current block
+// is consumed.  NW = 1: a single wavefront, no barriers (stand-alone tick kernel).
+struct LbCoop {
+    float q[SFX_NVAR_MAX];      // -g, the start of the recursion (zero beyond N)
+    float exch[2][LB_BS];       // dot products of the current block, double buffered
+    float hd;                   // H_diag
+    int n, head, req;           // history window; req = 1: helpers enter lb_two_loop, 0: tick finished
+};
+
+template <int NW>
+__device__ __forceinline__ void lb_block_sync() {
+    if (NW > 1) __syncthreads();
+}
+
+template <int NW>
+__device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, const OptState* gst, float* s_al,
+                                             LbCoop& cp, const int wv, const int lane) {
+    constexpr int BS = LB_BS, RPW = BS / NW;
+    static_assert(BS % NW == 0, "rows per wavefront");
+    const int n = __builtin_amdgcn_readfirstlane(cp.n), head = __builtin_amdgcn_readfirstlane(cp.head);
+    const float hd = cp.hd;
+    float* s_alp = s_al + BS;        // members below index 0 of the last block land in the padding
+    auto slot = [head, n](int i_) { int t_ = head + min(max(i_, 0), max(n - 1, 0)); return t_ >= SFX_HIST ? t_ - SFX_HIST : t_; };
+#define LB_RL(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))
+    struct Set { Lane3 mine[RPW]; Lane3 all[BS]; float band, ro, al; };
+    // loop 1 (dir = -1): mine = my s rows, all = every y row;  loop 2 (dir = +1): mine = my y rows, all = every s row
+    auto load = [&](Set& X, int base, int dir, const float* hMine, const float* hAll, bool want_al) {
+#pragma unroll
+        for (int c = 0; c < RPW; ++c) X.mine[c] = ld3_raw(hMine, (unsigned)slot(base + dir * (wv * RPW + c)) * SFX_NVAR_MAX, lane);
+#pragma unroll
+        for (int c = 0; c < BS; ++c) X.all[c] = ld3_raw(hAll, (unsigned)slot(base + dir * c) * SFX_NVAR_MAX, lane);
+        X.band = gst->syb[slot(base + dir * (lane / BS)) * BS + lane % BS];    // lane (x, k): band row of member x
+        X.ro = gst->ro[slot(base + dir * (lane % BS))];                         // lane c: ro of member c
+        X.al = 0.f;
+        if (want_al) X.al = s_alp[min(max(base + dir * (lane % BS), -BS), n)];
+    };
+    int buf = 0;
+    auto gather = [&](float (&mine)[RPW], float (&acc)[BS]) {
+        wave_sum_multi(mine);
+        if (NW > 1) {
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < RPW; ++c) cp.exch[buf][wv * RPW + c] = mine[c];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < BS; ++c) acc[c] = cp.exch[buf][c];
+            buf ^= 1;
+        } else {
+#pragma unroll
+            for (int c = 0; c < BS; ++c) acc[c] = mine[c % RPW];
+        }
+    };
+    Lane3 q = ld3_raw(cp.q, 0u, lane);
+    Set A, B;
+    auto down = [&](Set& X, int base) {
+        float mine[RPW], acc[BS], al[BS];
+#pragma unroll
+        for (int c = 0; c < RPW; ++c) mine[c] = dot3_part(X.mine[c], q);
+        gather(mine, acc);
+#pragma unroll
+        for (int m = 0; m < BS; ++m) {
+            al[m] = (base - m >= 0) ? acc[m] * LB_RL(X.ro, m) : 0.f;
+#pragma unroll
+            for (int c = m + 1; c < BS; ++c) acc[c] = fmaf(-al[m], LB_RL(X.band, c * BS + (c - m)), acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < BS; ++c) q = axpy3(q, -al[c], X.all[c]);
+        if (wv == 0 && lane == 0) {
+#pragma unroll
+            for (int c = 0; c < BS; ++c) s_alp[base - c] = al[c];
+        }
+    };
+    {
+        int i0 = n - 1;
+        load(A, i0, -1, hS, hY, false);
+        while (i0 >= 0) {
+            load(B, i0 - BS, -1, hS, hY, false);
+            down(A, i0);
+            i0 -= BS;
+            if (i0 < 0) break;
+            load(A, i0 - BS, -1, hS, hY, false);
+            down(B, i0);
+            i0 -= BS;
+        }
+    }
+    if (NW > 1) __syncthreads(); else LB_SYNC();      // alphas (LDS) are read back by every wavefront
+    Lane3 r;
+#pragma unroll
+    for (int e = 0; e < NE3; ++e) r.v[e] = q.v[e] * hd;
+    auto up = [&](Set& X, int base) {
+        float mine[RPW], acc[BS], cc[BS];
+#pragma unroll
+        for (int c = 0; c < RPW; ++c) mine[c] = dot3_part(X.mine[c], r);
+        gather(mine, acc);
+#pragma unroll
+        for (int m = 0; m < BS; ++m) {
+            const float be = acc[m] * LB_RL(X.ro, m);
+            cc[m] = (base + m < n) ? LB_RL(X.al, m) - be : 0.f;
+#pragma unroll
+            for (int c = m + 1; c < BS; ++c) acc[c] = fmaf(cc[m], LB_RL(X.band, m * BS + (c - m)), acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < BS; ++c) r = axpy3(r, cc[c], X.all[c]);
+    };
+    {
+        int i0 = 0;
+        load(A, i0, 1, hY, hS, true);
+        while (i0 < n) {
+            load(B, i0 + BS, 1, hY, hS, true);
+            up(A, i0);
+            i0 += BS;
+            if (i0 >= n) break;
+            load(A, i0 + BS, 1, hY, hS, true);
+            up(B, i0);
+            i0 += BS;
+        }
+    }
+#undef LB_RL
+    return r;
+}
+
 // One tick of frame b's optimiser, executed by ONE wavefront (lanes 0..63).  f_in / g_in: the
 // closure result (global D.f/D.g, or LDS copies in fused kernels).  s_al[SFX_HIST + 2 * LB_BS] and s_state
 // are LDS scratch owned by the caller.
-__device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDev& D, const VarList* __restrict__ vls,
-                                                int first_stage, int last_stage, int init, int step_mode,
-                                                const int b, const int lane, float* s_al, OptScal& s_state,
-                                                const float* f_src, const float* g_src) {
+template <int NW>
+__device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchDev& D, const VarList* __restrict__ vls,
+                                                 int first_stage, int last_stage, int init, int step_mode,
+                                                 const int b, const int lane, float* s_al, OptScal& s_state, LbCoop& cp,
+                                                 const float* f_src, const float* g_src) {
     const BatchCfgDev& C = D.cfg;
     OptState* gst = reinterpret_cast<OptState*>(D.opt) + b;
     int stage = D.stage[b];
@@ -431,89 +563,21 @@ __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDe
                 }
                 LB_SYNC();
                 TMARK(3);
-                // Two-loop recursion (lbfgs_ls.py:322-341), evaluated in blocks of BS history pairs:
-                // within a block the BS dot products against the running vector are independent
-                // (s_c . q for all c at once); the in-block coupling s_c . (q - sum_m al_m y_m) is
-                // resolved on scalars with the stored band s_p . y_(p+k).  Same arithmetic in exact
-                // terms, BS-fold shorter dependency chain.  History rows for the next block are
-                // fetched into a second register set while the current block is consumed.
-                constexpr int BS = LB_BS;
-                const int n = __builtin_amdgcn_readfirstlane(s.hist_n), head = __builtin_amdgcn_readfirstlane(s.hist_head);
-                Lane3 q;
-                for (int e = 0; e < NE3; ++e) q.v[e] = -g.v[e];
-                Lane3 SA[BS], YA[BS], SB[BS], YB[BS];
-                float* s_alp = s_al + BS;        // members below index 0 of the last block land in the padding
-                float bA, bB, rA, rB, aA, aB;    // lane (x, k) = x * BS + k: band row of member x; lane c: ro / alpha of member c
-                // physical slot of logical history index i (clamped into the window; no integer division)
-                auto lb_slot = [head, n](int i_) { int t_ = head + min(max(i_, 0), max(n - 1, 0)); return t_ >= SFX_HIST ? t_ - SFX_HIST : t_; };
-#define LB_SLOT(i_) lb_slot(i_)
-#define LB_RL(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))
-#define LB_LOAD(Sx, Yx, bx, rx, ax, base, dir, want_al) do {                                                 \
-                    _Pragma("unroll") for (int c = 0; c < BS; ++c) {                                         \
-                        const int ph_ = LB_SLOT((base) + (dir) * c);                                         \
-                        Sx[c] = ld3_raw(hS, (unsigned)ph_ * SFX_NVAR_MAX, lane);                                 \
-                        Yx[c] = ld3_raw(hY, (unsigned)ph_ * SFX_NVAR_MAX, lane); }                               \
-                    bx = gst->syb[LB_SLOT((base) + (dir) * (lane / BS)) * BS + lane % BS];                   \
-                    rx = gst->ro[LB_SLOT((base) + (dir) * (lane % BS))];                                     \
-                    if (want_al) { const int i_ = (base) + (dir) * (lane % BS);                              \
-                                   ax = s_alp[min(max(i_, -BS), n)]; } } while (0)
-#define LB_DOWN(Sx, Yx, bx, rx, base) do {                                                                   \
-                    float acc_[BS], al_[BS];                                                                 \
-                    _Pragma("unroll") for (int c = 0; c < BS; ++c) acc_[c] = dot3_part(Sx[c], q);            \
-                    wave_sum_multi(acc_);                                                                    \
-                    _Pragma("unroll") for (int m = 0; m < BS; ++m) {                                         \
-                        al_[m] = ((base) - m >= 0) ? acc_[m] * LB_RL(rx, m) : 0.f;                           \
-                        _Pragma("unroll") for (int c = m + 1; c < BS; ++c)                                   \
-                            acc_[c] = fmaf(-al_[m], LB_RL(bx, c * BS + (c - m)), acc_[c]); }                 \
-                    _Pragma("unroll") for (int c = 0; c < BS; ++c) q = axpy3(q, -al_[c], Yx[c]);             \
-                    if (lane == 0) { _Pragma("unroll") for (int c = 0; c < BS; ++c) s_alp[(base) - c] = al_[c]; } \
-                    } while (0)
-#define LB_UP(Sx, Yx, bx, rx, ax, base) do {                                                                 \
-                    float acc_[BS], cc_[BS];                                                                 \
-                    _Pragma("unroll") for (int c = 0; c < BS; ++c) acc_[c] = dot3_part(Yx[c], r);            \
-                    wave_sum_multi(acc_);                                                                    \
-                    _Pragma("unroll") for (int m = 0; m < BS; ++m) {                                         \
-                        const float be_ = acc_[m] * LB_RL(rx, m);                                            \
-                        cc_[m] = ((base) + m < n) ? LB_RL(ax, m) - be_ : 0.f;                                \
-                        _Pragma("unroll") for (int c = m + 1; c < BS; ++c)                                   \
-                            acc_[c] = fmaf(cc_[m], LB_RL(bx, m * BS + (c - m)), acc_[c]); }                  \
-                    _Pragma("unroll") for (int c = 0; c < BS; ++c) r = axpy3(r, cc_[c], Sx[c]); } while (0)
-                {
-                    int i0 = n - 1;
-                    LB_LOAD(SA, YA, bA, rA, aA, i0, -1, false);
-                    while (i0 >= 0) {
-                        LB_LOAD(SB, YB, bB, rB, aB, i0 - BS, -1, false);
-                        LB_DOWN(SA, YA, bA, rA, i0);
-                        i0 -= BS;
-                        if (i0 < 0) break;
-                        LB_LOAD(SA, YA, bA, rA, aA, i0 - BS, -1, false);
-                        LB_DOWN(SB, YB, bB, rB, i0);
-                        i0 -= BS;
-                    }
-                }
-                LB_SYNC();
-                TMARK(4);
                 Lane3 r;
-                const float hd = (float)s.H_diag.v;
-                for (int e = 0; e < NE3; ++e) r.v[e] = q.v[e] * hd;
                 {
-                    int i0 = 0;
-                    LB_LOAD(SA, YA, bA, rA, aA, i0, 1, true);
-                    while (i0 < n) {
-                        LB_LOAD(SB, YB, bB, rB, aB, i0 + BS, 1, true);
-                        LB_UP(SA, YA, bA, rA, aA, i0);
-                        i0 += BS;
-                        if (i0 >= n) break;
-                        LB_LOAD(SA, YA, bA, rA, aA, i0 + BS, 1, true);
-                        LB_UP(SB, YB, bB, rB, aB, i0);
-                        i0 += BS;
+                    const int n = __builtin_amdgcn_readfirstlane(s.hist_n);
+                    const float hd = (float)s.H_diag.v;
+                    Lane3 q;
+                    for (int e = 0; e < NE3; ++e) q.v[e] = -g.v[e];
+                    if (n == 0) {
+                        for (int e = 0; e < NE3; ++e) r.v[e] = q.v[e] * hd;
+                    } else {
+                        st3_full(cp.q, q, lane);
+                        if (lane == 0) { cp.n = n; cp.head = s.hist_head; cp.hd = hd; cp.req = 1; }
+                        if (NW > 1) __syncthreads(); else LB_SYNC();       // helpers wake up here
+                        r = lb_two_loop<NW>(hS, hY, gst, s_al, cp, 0, lane);
                     }
                 }
-#undef LB_LOAD
-#undef LB_DOWN
-#undef LB_UP
-#undef LB_SLOT
-#undef LB_RL
                 TMARK(5);
                 d = r;
             }
@@ -702,6 +766,33 @@ __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDe
     TMARK(7);
 #undef TMARK
 #undef VEC
+}
+
+// Entry for a workgroup of NW wavefronts (tid = thread index in the workgroup): wavefront 0 runs the
+// state machine; the others wait at a workgroup barrier and join it for every two-loop recursion it
+// announces (cp.req = 1), until it releases them (cp.req = 0).  Every wavefront executes the same
+// number of barriers.
+template <int NW>
+__device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDev& D, const VarList* __restrict__ vls,
+                                                int first_stage, int last_stage, int init, int step_mode,
+                                                const int b, const int tid, float* s_al, OptScal& s_state, LbCoop& cp,
+                                                const float* f_src, const float* g_src) {
+    const int wv = tid >> 6, lane = tid & 63;
+    if (NW > 1 && wv > 0) {
+        const float* hY = D.hist + (size_t)b * 2 * SFX_HIST * SFX_NVAR_MAX;
+        const float* hS = hY + (size_t)SFX_HIST * SFX_NVAR_MAX;
+        const OptState* gst = reinterpret_cast<const OptState*>(D.opt) + b;
+        for (;;) {
+            __syncthreads();
+            if (!cp.req) return;
+            (void)lb_two_loop<NW>(hS, hY, gst, s_al, cp, wv, lane);
+        }
+    }
+    lbfgs_tick_wave0<NW>(M, D, vls, first_stage, last_stage, init, step_mode, b, lane, s_al, s_state, cp, f_src, g_src);
+    if (NW > 1) {
+        if (lane == 0) cp.req = 0;
+        __syncthreads();
+    }
 }
 
 
