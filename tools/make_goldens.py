@@ -320,6 +320,29 @@ def gen_demo():
     _save("demo_config1", **out)
 
 
+def gen_eval():
+    """utils.ProcrustesAlignment / ScaleAlignment / PelvisAlignment(+MPJPE) / mpjpe / v2v of the
+    reference on seeded point sets (fscore thresholds None: open3d is absent)."""
+    rng = np.random.RandomState(11)
+    out = {}
+    U = ref.utils
+    for tag, n in (("j", 14), ("v", 400)):
+        gt = rng.normal(size=(n, 3))
+        A = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        est = 1.3 * gt @ A.T + rng.normal(size=(1, 3)) + 0.05 * rng.normal(size=(n, 3))
+        out[tag + "_gt"], out[tag + "_est"] = gt, est
+        out[tag + "_procrustes"] = U.ProcrustesAlignment()(est, gt)
+        out[tag + "_procrustes_cols"] = U.ProcrustesAlignment()(est.T.copy(), gt.T.copy())
+        out[tag + "_scale"] = U.ScaleAlignment()(est, gt)
+        pa = U.PelvisAlignment()(gt, est)
+        out[tag + "_pelvis_gt"], out[tag + "_pelvis_est"] = pa
+        out[tag + "_mpjpe"] = U.mpjpe(est, gt)
+        out[tag + "_v2v"] = U.vertex_to_vertex_error(est, gt)
+        out[tag + "_pelvis_mpjpe"] = U.PelvisAlignmentMPJPE()(est, gt)["point"]
+        out[tag + "_procrustes_mpjpe"] = U.ProcrustesAlignmentMPJPE()(est, gt)["point"]
+    _save("evaluation", **out)
+
+
 def gen_parser():
     """data_parser.read_keypoints / dataset weights / shoulders of the reference on the demo
     keypoint files.  The fixture keeps numbers only: the json fields as arrays (tests rebuild a
@@ -358,4 +381,4 @@ if __name__ == "__main__":
     todo = sys.argv[1:] or ["tables", "euler", "objective", "lbfgs", "e2e", "demo", "e2e_vposer"]
     for w in todo:
         {"objective": gen_objective, "lbfgs": gen_lbfgs, "euler": gen_euler, "tables": gen_tables,
-         "e2e": gen_e2e, "demo": gen_demo, "e2e_vposer": gen_e2e_vposer, "parser": gen_parser}[w]()
+         "e2e": gen_e2e, "demo": gen_demo, "e2e_vposer": gen_e2e_vposer, "parser": gen_parser, "eval": gen_eval}[w]()
