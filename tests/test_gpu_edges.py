@@ -1,0 +1,118 @@
+"""Edge cases of the HIP path (run with -m gpu): ragged batch sizes, batch-composition
+independence of the dense (MFMA) path, degenerate frames, the halpe format."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+import test_gpu_parity as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cfg_body():
+    return H.load_cfg("fit_smplx_combined_coco25.yaml", use_hands=False, use_face=False)
+
+
+@pytest.mark.parametrize("B", [1, 33, 130])
+def test_dense_path_is_batch_composition_independent(synth_model, cfg_body, B):
+    """Column position in the GEMM operands, frame-block split (1 / 2 blocks, partial slices) and
+    compaction must not change a frame's numbers: frame 2 alone == frame 2 as the LAST of B."""
+    cfg = dict(cfg_body); cfg["use_camera_prior"] = False
+    dm = T._dm(synth_model, cfg)
+    frames = T.synth_frames(synth_model, cfg, 3)
+    idx = [i % 2 for i in range(B - 1)] + [2]
+    out = []
+    for ids in ([2], idx):
+        fb = H.engine_batch_from_frames(dm, cfg, frames, ids, lbs_mode="dense", reuse=True)
+        fb.guess_init(cfg["body_tri_idxs"])
+        l, g = fb.closure(0)
+        fb.fit(first_stage=-1, last_stage=1)
+        out.append((l[-1], g[-1].copy(), {k: v[-1].copy() for k, v in fb.get_params().items()}, fb.stats()))
+        fb.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    for k in out[0][2]:
+        assert np.array_equal(out[0][2][k], out[1][2][k]), k
+    assert np.array_equal(out[0][3]["stage_evals"][-1], out[1][3]["stage_evals"][-1])
+
+
+def test_dense_and_rows_agree_per_closure(synth_model, cfg_body):
+    """The needed-rows kernel and the all-vertices MFMA kernel evaluate the same objective: loss
+    and gradient agree to fp32 rounding (both are compared with the oracle elsewhere)."""
+    cfg = dict(cfg_body); cfg["use_camera_prior"] = False
+    dm = T._dm(synth_model, cfg)
+    frames = T.synth_frames(synth_model, cfg, 3)
+    res = {}
+    for mode in ("rows", "dense"):
+        fb = H.engine_batch_from_frames(dm, cfg, frames, range(3), lbs_mode=mode)
+        fb.guess_init(cfg["body_tri_idxs"])
+        res[mode] = [fb.closure(s) for s in (-1, 0, 2)]
+        fb.close()
+    for (lr, gr), (ld, gd) in zip(res["rows"], res["dense"]):
+        assert np.allclose(lr, ld, rtol=1e-5)          # different fp32 summation orders (MFMA k-chain vs wave scan)
+        assert np.linalg.norm(gr - gd) <= 1e-4 * np.linalg.norm(gr)
+
+
+@pytest.mark.parametrize("mode", ["rows", "dense"])
+def test_degenerate_frames_do_not_poison_the_batch(synth_model, cfg_body, mode):
+    """A frame without any detection (all keypoints and confidences zero): guess_init divides by a
+    zero 2-D limb length as the reference does (fitting.py:61-67 -> t_z = inf), the camera stage
+    sees (inf - inf)^2 = NaN and run_fitting stops it at once returning None (fitting.py:177-183,216);
+    the body stages then only see the priors (every keypoint weight is zero).  The frame must
+    terminate and leave its neighbours untouched."""
+    from smplifyx_amd import driver
+    cfg = dict(cfg_body); cfg["use_camera_prior"] = False
+    dm = T._dm(synth_model, cfg)
+    g = T._golden("e2e_synth")
+    kp = np.concatenate([g["keypoints"][:2], np.zeros((1, 25, 3), np.float32)])
+    rp = np.concatenate([g["reg_pose"][:2], g["reg_pose"][:1]])
+    rg = np.concatenate([g["reg_global"][:2], g["reg_global"][:1]])
+    jw = H.base_joint_weights(cfg, 25)
+    res = driver.fit_frames(dm, cfg, kp, jw, 600, 800, 5000.0, reg_pose=rp, reg_global=rg, lbs_mode=mode)
+    ref = driver.fit_frames(dm, cfg, kp[:2], jw, 600, 800, 5000.0, reg_pose=rp[:2], reg_global=rg[:2], lbs_mode=mode)
+    for k in ("cam_translation", "global_orient", "betas", "pose_embedding", "final_loss"):
+        assert np.array_equal(res[k][:2], ref[k]), k
+    assert np.isnan(res["stage_loss"][2, 0]) and res["stage_evals"][2, 0] <= 2     # camera stage: None in the reference
+    assert np.isinf(res["cam_translation"][2, 2])
+    assert np.all(np.isfinite(res["stage_loss"][2, 1:])) and np.all(np.isfinite(res["pose_embedding"][2]))
+    assert np.all(res["stage_loss"][2, 1:] < 1e5)                                  # priors only
+
+
+def test_halpe_closure_matches_oracle(synth_model):
+    """cfg_files/fit_smplx_combined_halpe.yaml (K = 26 body joints, 3 stages, confidences used in
+    the camera initialisation) without its interpenetration term: loss and gradient vs oracle."""
+    cfg = H.load_cfg("fit_smplx_combined_halpe.yaml", use_hands=False, use_face=False, interpenetration=False)
+    assert cfg["format"] == "halpe" and len(H.joint_map_for(cfg)) == 26
+    dm = T._dm(synth_model, cfg)
+    B = 2
+    frames = T.synth_frames(synth_model, cfg, B) if False else None
+    from smplifyx_amd import synthetic
+    K = len(H.joint_map_for(cfg))
+    frames = synthetic.make_frames(B, H.oracle_joints_fn(synth_model, cfg), K, focal=5000.0)
+    fb = H.engine_batch_from_frames(dm, cfg, frames, range(B), lbs_mode="rows")
+    rng = np.random.RandomState(3)
+    P = H.random_params(rng, B, scale=0.5)
+    P["pose_embedding"] = frames["reg_pose"] + 0.1 * rng.normal(size=(B, 63)).astype(np.float32)
+    P["global_orient"] = frames["reg_global"] + 0.1 * rng.normal(size=(B, 3)).astype(np.float32)
+    P["cam_translation"] = (frames["cam_t"] + 0.3 * rng.normal(size=(B, 3))).astype(np.float32)
+    est = (frames["cam_t"][:, 2] + 1.0).astype(np.float32)
+    kp = frames["keypoints"]
+    thr = np.array([cfg.get("confidence_threshold", 0)] * 26 + [0] * 110)[:K]
+    jw = np.tile(H.base_joint_weights(cfg, K), (B, 1)); jw[kp[:, :, 2] < thr[None]] = 0
+    cm = np.zeros((B, K), np.float32)
+    for b in range(B):
+        for j in cfg["init_joints_idxs"]:
+            if kp[b, j, 0] != 0 and kp[b, j, 1] != 0 and not kp[b, j, 2] < thr[j]:
+                cm[b, j] = 1
+    fb.set_frames(kp, jw, cm, frames["focal"], np.tile([frames["W"] * 0.5, frames["H"] * 0.5], (B, 1)),
+                  1000.0 / frames["H"], est_tz=est)
+    fb.set_params(regression_pose=frames["reg_pose"], **P)
+    P["est_tz"] = est
+    assert fb.n_stages == 3
+    for stage in (-1, 0, 2):
+        loss, grad = fb.closure(stage)
+        for i in range(B):
+            lo, go = T._oracle_closure(synth_model, cfg, frames, i, P, stage)
+            assert abs(loss[i] - lo) <= 2e-5 * abs(lo), (stage, i, loss[i], lo)
+            assert np.linalg.norm(grad[i] - go) / np.linalg.norm(go) < 2e-4, (stage, i)
