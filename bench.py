@@ -111,13 +111,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # SFX_BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend -- lets a 1-GPU box walk the
+    # N > 1 control flow (barriers, max-over-ranks timing, record gather); never a measurement
+    rehearsal = os.environ.get("SFX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     from smplifyx_amd import engine, synthetic, utils as U
     cfg = build_cfg()

@@ -52,6 +52,8 @@ def gather_records(rec, n_frames, device=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return np.asarray(rec, np.float32)
     world = dist.get_world_size()
+    if dist.get_backend() == "gloo":
+        device = None           # gloo gathers host tensors (CPU tests, single-GPU rehearsal of the N > 1 path)
     bmax = max(shard_range(n_frames, r, world)[1] - shard_range(n_frames, r, world)[0] for r in range(world))
     t = torch.zeros([bmax, RECORD_LEN], dtype=torch.float32, device=device)
     t[:rec.shape[0]] = torch.as_tensor(np.asarray(rec, np.float32), device=device)

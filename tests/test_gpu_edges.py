@@ -116,3 +116,22 @@ def test_halpe_closure_matches_oracle(synth_model):
             lo, go = T._oracle_closure(synth_model, cfg, frames, i, P, stage)
             assert abs(loss[i] - lo) <= 2e-5 * abs(lo), (stage, i, loss[i], lo)
             assert np.linalg.norm(grad[i] - go) / np.linalg.norm(go) < 2e-4, (stage, i)
+
+
+def test_bench_two_rank_control_flow_rehearsal():
+    """bench.py under torch.distributed.run with 2 ranks (both on GPU 0, gloo): the N > 1 control
+    flow -- per-rank frame blocks, barriers, max-over-ranks time, the record gather -- produces one
+    JSON line whose frame count is the whole job's."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SFX_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--frames", "32", "--no-cpu", "--no-alt", "--lbs", "rows"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 32 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 32 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
