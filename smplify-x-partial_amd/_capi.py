@@ -91,6 +91,11 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libsfx.so not built (%s): run `python __graft_entry__.py` "
                            "or smplify-x-partial_amd/csrc/build.sh; there is no CPU fallback" % LIB_PATH)
+    # torch ships its own copy of the HIP runtime: it must be the one this process initialises, so
+    # that libsfx.so (linked against libamdhip64 by soname) shares it with the torch tensors whose
+    # data_ptr()s it is handed.  Loading libsfx first makes two runtimes meet in one process and
+    # the second sees no device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)

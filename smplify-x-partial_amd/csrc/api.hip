@@ -584,6 +584,7 @@ extern "C" int sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out 
     long long* d = nullptr;
     SFX_CHECK(hipMalloc((void**)&d, 64 * sizeof(long long)));
     SFX_CHECK(hipMemset(d, 0, 64 * sizeof(long long)));
+    { const long long freeze = 1 << 30; SFX_CHECK(hipMemcpy(d + 61, &freeze, sizeof(freeze), hipMemcpyHostToDevice)); }
     b->D.dbg = d;
     ClosureArgs a{}; a.stage_override = stage; a.from_X = 1;
     launch_closure(b->m->M, b->D, b->vl_dev, b->sw_dev, a, 0);
@@ -604,6 +605,8 @@ extern "C" int sfx_debug_clocks(sfx_batch* b, int32_t enable, int64_t* out /* [6
     if (enable) {
         if (!b->D.dbg) SFX_CHECK(hipMalloc((void**)&b->D.dbg, 64 * sizeof(long long)));
         SFX_CHECK(hipMemset(b->D.dbg, 0, 64 * sizeof(long long)));
+        const long long freeze = enable > 1 ? enable : 40;      // k_tick_dense: stamps freeze after this launch
+        SFX_CHECK(hipMemcpy(b->D.dbg + 61, &freeze, sizeof(freeze), hipMemcpyHostToDevice));
         return 0;
     }
     if (!b->D.dbg) { sfx_set_error("clock buffer not attached"); return -1; }

@@ -34,7 +34,7 @@
 #define FD_REG (FD_CAMR + 12)
 #define FD_N (FD_REG + 64)
 // debug timing: block 0 / thread 0 stores the shader clock at phase boundaries when D.dbg != NULL
-#define MARK(i) do { if (D.dbg && blockIdx.x == 0 && threadIdx.x == 0 && D.dbg[62] <= 40) { D.dbg[i] = clock64(); \
+#define MARK(i) do { if (D.dbg && blockIdx.x == 0 && threadIdx.x == 0 && D.dbg[62] <= D.dbg[61]) { D.dbg[i] = clock64(); \
         if ((i) == 0) D.dbg[17] = wall_clock64(); if ((i) == 16) D.dbg[18] = wall_clock64(); } } while (0)
 
 // thread t handles elements t, t + CT, ... of an N-element pass; the constant trip count lets the

@@ -53,8 +53,8 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
     __shared__ LbCoop cp;
     const int b = blockIdx.x;
     if (D.stage[b] > last_stage) return;
-    // debug clocks: stamps freeze after the 40th launch of this kernel, so a mid-fit launch is what is read back
-    if (D.dbg && b == 0 && threadIdx.x == 0) { D.dbg[62] += 1; if (D.dbg[62] <= 40) D.dbg[24] = clock64(); }
+    // debug clocks: stamps freeze after launch number dbg[61] of this kernel, so a mid-fit launch is what is read back
+    if (D.dbg && b == 0 && threadIdx.x == 0) { D.dbg[62] += 1; if (D.dbg[62] <= D.dbg[61]) D.dbg[24] = clock64(); }
     if (has_eval) {
         ClosureArgs a{};
         a.stage_override = -2; a.use_dense_verts = 1; a.reuse_fwd = 1;
@@ -66,13 +66,13 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
         if (LB_COOP_WAVES > 1 || threadIdx.x < 64)
             lbfgs_tick_body<LB_COOP_WAVES>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, cp, &fval, gflat);
         __syncthreads();
-        if (D.dbg && b == 0 && threadIdx.x == 0 && D.dbg[62] <= 40) { D.dbg[25] = clock64(); for (int i = 0; i < 17; ++i) D.dbg[40 + i] = D.dbg[i]; }
+        if (D.dbg && b == 0 && threadIdx.x == 0 && D.dbg[62] <= D.dbg[61]) { D.dbg[25] = clock64(); for (int i = 0; i < 17; ++i) D.dbg[40 + i] = D.dbg[i]; }
         if (D.stage[b] > last_stage) return;
     }
     ClosureArgs e{};
     e.stage_override = -2; e.export_dense = 1; e.forward_only = 2; e.keep_tables = has_eval;
     closure_body(S, M, D, vls, sws, e, b, nullptr, nullptr);
-    if (D.dbg && b == 0 && threadIdx.x == 0 && D.dbg[62] <= 40) D.dbg[26] = clock64();
+    if (D.dbg && b == 0 && threadIdx.x == 0 && D.dbg[62] <= D.dbg[61]) D.dbg[26] = clock64();
 }
 
 void launch_fit_rows(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,

@@ -31,7 +31,7 @@ for which in ('body','full'):
 
     # dense path: one k_tick_dense launch = [loss+adjoint of eval i] -> [tick] -> [pose/FK/export of eval i+1]
     fb = H.engine_batch_from_frames(dm, cfg, fr, idx, lbs_mode="dense")
-    _capi.check(lib.sfx_debug_clocks(fb._h, 1, None))
+    _capi.check(lib.sfx_debug_clocks(fb._h, 400, None))        # stamps of launch 400: first body stage, history full
     fb.guess_init(cfg["body_tri_idxs"]); fb.fit(first_stage=-1, last_stage=0)
     _capi.check(lib.sfx_debug_clocks(fb._h, 0, o64))
     o = np.array(list(o64), np.float64)
