@@ -192,9 +192,12 @@ int  sfx_batch_get_stats(sfx_batch* b, float* stage_loss, int32_t* stage_evals,
 int  sfx_batch_forward(sfx_batch* b, float* vertices_out_dev /* [B][V][3] */,
                        float* joints_out_dev /* [B][K][3] */, void* stream);
 
-/* Timing hooks for the roofline report: average duration (ms) of the named kernel since
- * the last reset, measured with HIP events on the launch stream.  name: "lbs_dense",
- * "closure", "lbfgs".  Returns launches counted.                                          */
+/* Timing hooks for the roofline report: total duration (ms), number of TIMED launches and
+ * frames processed by them, of the named kernel since the last reset, measured with HIP events
+ * on the launch stream.  name: "lbs_dense", "tick" (k_tick_dense), "fit_rows", "closure",
+ * "export", "lbfgs".  sfx_prof_enable(on): bit 0 = time launches; bit 1 = debug, run the
+ * fitting loop with the stand-alone kernels; bits 8..23 = N: time every N-th launch of each
+ * name only (an event pair costs two queue packets; 0/1 = every launch).                   */
 int  sfx_prof_enable(int32_t on);
 int  sfx_prof_get(const char* name, double* total_ms, int64_t* launches, double* units /* frames processed */);
 void sfx_prof_reset(void);
@@ -202,9 +205,11 @@ void sfx_prof_reset(void);
 /* Debug: shader-clock stamps at the phase boundaries of one closure launch (block 0). */
 int  sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out /* [32] */);
 
-/* Debug: attach (enable=1) a 64-slot clock buffer to the batch, run any entry point, then read it
+/* Debug: attach (enable>=1) a 64-slot clock buffer to the batch, run any entry point, then read it
  * and detach (enable=0): out[0..18] = closure phase stamps of the last launch, out[32+i] =
- * shader-clock cycles frame 0 spent between optimiser-tick marks i-1 and i, out[63] = ticks.  */
+ * shader-clock cycles frame 0 spent between optimiser-tick marks i-1 and i, out[63] = ticks.
+ * enable = N > 1: the stamps of the dense tick kernel freeze after its N-th launch (default 40),
+ * out[24..26] = its start / end of adjoint+tick / end, out[40..56] = phases of its adjoint pass.  */
 int  sfx_debug_clocks(sfx_batch* b, int32_t enable, int64_t* out /* [64] or NULL */);
 
 const char* sfx_last_error(void);
