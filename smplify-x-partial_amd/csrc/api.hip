@@ -172,9 +172,12 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
             for (int j = 0; j < SFX_J; ++j) {
                 const float w = W[(size_t)v * SFX_J + j];
                 if (w == 0.f) continue;
-                if (n == SFX_NW) { sfx_set_error("vertex %d has more than %d skinning weights", v, SFX_NW); delete m; return -1; }
-                wj[(size_t)v * SFX_NW + n] = j; ww[(size_t)v * SFX_NW + n] = w; ++n;
+                if (n < SFX_NW) { wj[(size_t)v * SFX_NW + n] = j; ww[(size_t)v * SFX_NW + n] = w; }
+                ++n;
             }
+            // a row with more nonzeros than the packed form holds is flagged: the needed-rows path
+            // then reads the full row of lbs_weights for this vertex (same ascending joint order)
+            if (n > SFX_NW) wj[(size_t)v * SFX_NW] = -1;
         }
         M.Wsp_j = m->mem.up(wj); M.Wsp_w = m->mem.up(ww);
         M.W = m->mem.up(W);

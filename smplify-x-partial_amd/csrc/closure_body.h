@@ -432,10 +432,15 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     for (int w = t; w < NI * 12; w += CT) {
         const int i = w / 12, e = w % 12;
         float acc = 0.f;
+        if (S.wj[i * SFX_NW] >= 0) {
 #pragma unroll
-        for (int q2 = 0; q2 < SFX_NW; ++q2) {
-            const float wq = S.ww[i * SFX_NW + q2];
-            if (wq != 0.f) acc += wq * S.A[S.wj[i * SFX_NW + q2] * 12 + e];
+            for (int q2 = 0; q2 < SFX_NW; ++q2) {
+                const float wq = S.ww[i * SFX_NW + q2];
+                if (wq != 0.f) acc += wq * S.A[S.wj[i * SFX_NW + q2] * 12 + e];
+            }
+        } else {                    // more than SFX_NW nonzero weights: full row of lbs_weights
+            const float* Wv = M.W + (size_t)S.ivid[i] * SFX_J;
+            for (int j = 0; j < SFX_J; ++j) { const float wq = Wv[j]; if (wq != 0.f) acc += wq * S.A[j * 12 + e]; }
         }
         S.T[w] = acc;
     }

@@ -135,3 +135,45 @@ def test_bench_two_rank_control_flow_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 32 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 32 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("mode", ["rows", "dense"])
+def test_vertices_with_many_skinning_weights(synth_model, cfg_body, mode):
+    """lbs_weights rows with more nonzeros than the packed 8-entry form (learned weights of a real
+    model may have them): the needed-rows path falls back to the full row, the dense path's tile
+    lists cover any count.  Loss and gradient vs oracle on a model whose keypoint vertices carry 12
+    nonzero weights."""
+    cfg = dict(cfg_body); cfg["use_camera_prior"] = False
+    model = dict(synth_model)
+    W = np.array(model["weights"], np.float32).copy()
+    rng = np.random.RandomState(4)
+    vids = [int(v) for v in np.asarray(list(model["extra_vertex_ids"].values()) if isinstance(model["extra_vertex_ids"], dict)
+                                       else model["extra_vertex_ids"]).reshape(-1)]
+    for v in vids:
+        js = rng.choice(55, 12, replace=False)
+        w = rng.uniform(0.2, 1.0, 12).astype(np.float32)
+        W[v] = 0
+        W[v, js] = w / w.sum()
+    model["weights"] = W
+    assert (np.count_nonzero(W[vids], axis=1) == 12).all()
+    dm = T._dm(model, cfg)
+    B = 2
+    from smplifyx_amd import synthetic
+    frames = synthetic.make_frames(B, H.oracle_joints_fn(model, cfg), 25, focal=5000.0)
+    fb = H.engine_batch_from_frames(dm, cfg, frames, range(B), lbs_mode=mode)
+    rng = np.random.RandomState(12)
+    P = H.random_params(rng, B, scale=0.5)
+    P["pose_embedding"] = frames["reg_pose"] + 0.1 * rng.normal(size=(B, 63)).astype(np.float32)
+    P["global_orient"] = frames["reg_global"] + 0.1 * rng.normal(size=(B, 3)).astype(np.float32)
+    P["cam_translation"] = (frames["cam_t"] + 0.3 * rng.normal(size=(B, 3))).astype(np.float32)
+    est = (frames["cam_t"][:, 2] + 1.0).astype(np.float32)
+    fb.set_frames(frames["keypoints"], T._jw(cfg, frames), T._cmask(cfg, frames), frames["focal"],
+                  np.tile([frames["W"] * 0.5, frames["H"] * 0.5], (B, 1)), 1000.0 / frames["H"], est_tz=est)
+    fb.set_params(regression_pose=frames["reg_pose"], **P)
+    P["est_tz"] = est
+    for stage in (-1, 1):
+        loss, grad = fb.closure(stage)
+        for i in range(B):
+            lo, go = T._oracle_closure(model, cfg, frames, i, P, stage)
+            assert abs(loss[i] - lo) <= 2e-5 * abs(lo), (stage, i, loss[i], lo)
+            assert np.linalg.norm(grad[i] - go) / np.linalg.norm(go) < 2e-4, (stage, i)
