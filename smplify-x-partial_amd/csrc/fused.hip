@@ -53,6 +53,7 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
     __shared__ LbCoop cp;
     const int b = blockIdx.x;
     if (D.stage[b] > last_stage) return;
+    const long long wc0 = D.dbg ? wall_clock64() : 0;      // debug: per-workgroup duration statistics (100 MHz clock)
     // debug clocks: stamps freeze after launch number dbg[61] of this kernel, so a mid-fit launch is what is read back
     if (D.dbg && b == 0 && threadIdx.x == 0) { D.dbg[62] += 1; if (D.dbg[62] <= D.dbg[61]) D.dbg[24] = clock64(); }
     if (has_eval) {
@@ -73,6 +74,12 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
     e.stage_override = -2; e.export_dense = 1; e.forward_only = 2; e.keep_tables = has_eval;
     closure_body(S, M, D, vls, sws, e, b, nullptr, nullptr);
     if (D.dbg && b == 0 && threadIdx.x == 0 && D.dbg[62] <= D.dbg[61]) D.dbg[26] = clock64();
+    if (D.dbg && threadIdx.x == 0) {
+        const long long dt = wall_clock64() - wc0;
+        atomicMax((unsigned long long*)&D.dbg[58], (unsigned long long)dt);
+        atomicAdd((unsigned long long*)&D.dbg[59], (unsigned long long)dt);
+        atomicAdd((unsigned long long*)&D.dbg[60], 1ull);
+    }
 }
 
 void launch_fit_rows(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
