@@ -32,12 +32,16 @@ PEAK_MFMA_F32 = 157.3e12      # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector pea
 PEAK_HBM = 8.0e12
 
 
-def build_cfg():
+def build_cfg(workload="body"):
+    """body: BASELINE configs[1] (body-only keypoints, use_vposer=False + synthetic regression prior).
+    full: BASELINE configs[2] (hands + face + contour, K=135, VPoser decode in the loop, z0 = 0) --
+    a side measurement (`--workload full`), never the headline."""
     from smplifyx_amd import cmd_parser
-    cfg = cmd_parser.load_config(os.path.join(ROOT, "cfg_files", "fit_smplx_smplifyx.yaml"),
-                                 dict(use_hands=False, use_face=False, use_vposer=False, interpenetration=False,
-                                      visualize=False, interactive=False, save_vertices=False,
-                                      use_gender_classifier=False))
+    over = dict(interpenetration=False, visualize=False, interactive=False, save_vertices=False,
+                use_gender_classifier=False)
+    if workload == "body":
+        over.update(use_hands=False, use_face=False, use_vposer=False)
+    cfg = cmd_parser.load_config(os.path.join(ROOT, "cfg_files", "fit_smplx_smplifyx.yaml"), over)
     cfg["use_camera_prior"] = False
     return cfg
 
@@ -103,6 +107,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU")
     ap.add_argument("--lbs", default="dense", choices=["dense", "rows"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", default="body", choices=["body", "full"])
     ap.add_argument("--prof-every", type=int, default=8, help="HIP-event-time every N-th launch of each kernel")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra needed-rows measurement")
     ap.add_argument("--groups", type=int, default=1, help="independent sub-batches per GPU (host threads/streams)")
@@ -128,13 +133,17 @@ def main():
                                     device_id=torch.device("cuda", local_rank))
 
     from smplifyx_amd import engine, synthetic, utils as U
-    cfg = build_cfg()
+    cfg = build_cfg(args.workload)
+    full = args.workload == "full"
+    if full:
+        args.no_cpu = True
     model = synthetic.make_synthetic_model(0)
     jm = U.smpl_to_annotation("smplx", use_hands=cfg["use_hands"], use_face=cfg["use_face"],
                               use_face_contour=cfg["use_face_contour"], format=cfg["format"])
     dm = engine.DeviceModel(model, joint_map=jm, num_betas=cfg["num_betas"],
                             num_expression_coeffs=cfg["num_expression_coeffs"],
-                            num_pca_comps=cfg["num_pca_comps"], use_face_contour=cfg["use_face_contour"])
+                            num_pca_comps=cfg["num_pca_comps"], use_face_contour=cfg["use_face_contour"],
+                            vposer=synthetic.make_synthetic_vposer(0) if full else None)
     B = args.frames
     dev = torch.device("cuda", local_rank)
 
@@ -153,7 +162,8 @@ def main():
 
     def one_fit(lbs_mode=None):
         res = driver.fit_frames(dm, cfg, frames["keypoints"], jw, frames["H"], frames["W"], frames["focal"],
-                                reg_pose=frames["reg_pose"], reg_global=frames["reg_global"],
+                                reg_pose=None if full else frames["reg_pose"],
+                                reg_global=None if full else frames["reg_global"],
                                 lbs_mode=lbs_mode or args.lbs, reuse_entry_eval=True, groups=args.groups)
         rec = sdist.pack_records(res, rank * B)
         table = sdist.gather_records(rec, n_total, device=dev)      # the one collective (RCCL all_gather)
@@ -214,9 +224,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d synthetic frames/GPU, neutral SMPL-X-shaped synthetic model, "
-                                   "body-only K=25, camera stage + 5-stage L-BFGS (fit_smplx_smplifyx.yaml weights, "
-                                   "use_vposer=False, synthetic regression prior)" % B,
+            "config": {"workload": ("configs[2]: %d synthetic frames/GPU, neutral SMPL-X-shaped synthetic model, hands + face + "
+                                    "contour K=135, synthetic VPoser decoded in the loop (latent 32, z0 = 0), camera stage + "
+                                    "5-stage L-BFGS (fit_smplx_smplifyx.yaml)" % B) if full else
+                                   ("configs[1]: %d synthetic frames/GPU, neutral SMPL-X-shaped synthetic model, "
+                                    "body-only K=25, camera stage + 5-stage L-BFGS (fit_smplx_smplifyx.yaml weights, "
+                                    "use_vposer=False, synthetic regression prior)" % B),
                        "frames_per_gpu": B, "lbs_mode": args.lbs, "groups_per_gpu": args.groups, "parallelism": "frames sharded, dp%d" % world,
                        "closure_evals_per_frame_mean": float(evals.mean()),
                        "closure_evals_per_frame_max": int(evals.max()),

@@ -386,7 +386,8 @@ extern "C" void sfx_model_destroy(sfx_model* m) {
 extern "C" int sfx_model_set_vposer(sfx_model* m, int32_t latent, int32_t hidden, const float* w1, const float* b1,
                                     const float* w2, const float* b2, const float* w3, const float* b3) {
     if (!m) { sfx_set_error("null model"); return -1; }
-    if (hidden != 512 || latent < 1 || latent > 63) { sfx_set_error("VPoser v1 decoder expected (hidden 512), got %d/%d", latent, hidden); return -1; }
+    if (hidden != 512 || latent < 4 || latent > 60 || latent % 4) {
+        sfx_set_error("VPoser v1 decoder expected (hidden 512, latent a multiple of 4 <= 60), got %d/%d", latent, hidden); return -1; }
     auto v = [](const float* p, size_t n) { return std::vector<float>(p, p + n); };
     const int H = hidden, L = latent;
     std::vector<float> w1T((size_t)L * H), w2T((size_t)H * H), w3T((size_t)H * 128, 0.f);

@@ -25,6 +25,8 @@
 #include "vposer.h"
 
 #define CT 256
+// RIF = 2-KiB blend-shape rows in flight per wavefront (forward dots and dfeat adjoint): 4 for the
+// body-only variant (33 rows: 16 + 16 + 1), 8 for the full model (675 rows)
 #define FD_GT 0
 #define FD_CONF (2 * SFX_MAX_K)
 #define FD_JW (3 * SFX_MAX_K)
@@ -193,6 +195,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     // the VPoser activations) in D.fwd; reload it instead of recomputing pose assembly,
     // Rodrigues, joint regression and the kinematic chain
     constexpr bool HAS_VP = !std::is_same<decltype(S.V), EmptyLDS>::value;
+    constexpr int RIF = (LDS::kMaxItems <= SFX_SMALL_ITEMS) ? 4 : 8;
     constexpr int FWD_PREFIX = (int)(offsetof(LDS, vp) / sizeof(float));
     static_assert(FWD_PREFIX % 4 == 0 && FWD_PREFIX + 96 + 2 * VP_H + 128 + 64 <= SFX_FWD_N, "forward-state blob layout");
     const bool reuse = args.reuse_fwd != 0;
@@ -399,23 +402,31 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     {
         const float4* f4 = reinterpret_cast<const float4*>(S.feat);
         const float4 fa = f4[lane], fb = f4[64 + lane];
-        // 4 rows per wavefront per pass: 8 independent 1-KiB loads in flight before the reductions
-        for (int w0 = wv * 4; w0 < NI * 3; w0 += (CT / 64) * 4) {
-            float4 da[4], db[4];
+        // RIF rows per wavefront per pass: 2 RIF independent 1-KiB loads in flight before the reductions.
+        // All frames need the SAME rows (static items), and workgroups launched together walk them
+        // in step: every CU of an XCD then asks one L2 channel for one 2-KiB row at the same moment.
+        // Each workgroup therefore starts at its own rotation of the row list; the rows are
+        // independent dot products, so the result is bit-identical.
+        const int nrow = NI * 3;
+        const int rot = (int)((blockIdx.x * 40u) % (unsigned)nrow);
+        for (int w0 = wv * RIF; w0 < nrow; w0 += (CT / 64) * RIF) {
+            float4 da[RIF], db[RIF]; int wr[RIF];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int w = (w0 + u < NI * 3) ? w0 + u : w0;
+            for (int u = 0; u < RIF; ++u) {
+                int w = ((w0 + u < nrow) ? w0 + u : w0) + rot;
+                w = w >= nrow ? w - nrow : w;
+                wr[u] = w;
                 const int v = S.ivid[w / 3];
                 const float4* row = reinterpret_cast<const float4*>(M.dirsT + ((size_t)v * 3 + w % 3) * SFX_KD_PAD);
                 da[u] = row[lane]; db[u] = row[64 + lane];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int w = w0 + u;
+            for (int u = 0; u < RIF; ++u) {
+                const int w = wr[u];
                 float acc = fa.x * da[u].x + fa.y * da[u].y + fa.z * da[u].z + fa.w * da[u].w +
                             fb.x * db[u].x + fb.y * db[u].y + fb.z * db[u].z + fb.w * db[u].w;
                 acc = wave_sum(acc);
-                if (lane == 0 && w < NI * 3) S.vp[w] = M.v_template[S.ivid[w / 3] * 3 + w % 3] + acc;
+                if (lane == 0 && w0 + u < nrow) S.vp[w] = M.v_template[S.ivid[w / 3] * 3 + w % 3] + acc;
             }
         }
     }
@@ -639,14 +650,14 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     }
     MARK(11);
     // dfeat[k] = sum_items sum_c dirsT[v][c][k] * dvp[c]: each wavefront streams whole 2-KiB rows
-    // (4 in flight), lane l keeps k = 4l..4l+3 and 256+4l..+3; the 4 per-wave partials are added
+    // (RIF in flight), lane l keeps k = 4l..4l+3 and 256+4l..+3; the 4 per-wave partials are added
     // in wave order (fixed association -> deterministic)
     {
         float4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
-        for (int w0 = wv * 4; w0 < NI * 3; w0 += (CT / 64) * 4) {
-            float4 da[4], db[4]; float dv[4];
+        for (int w0 = wv * RIF; w0 < NI * 3; w0 += (CT / 64) * RIF) {
+            float4 da[RIF], db[RIF]; float dv[RIF];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < RIF; ++u) {
                 const int w = (w0 + u < NI * 3) ? w0 + u : w0;
                 dv[u] = (w0 + u < NI * 3) ? S.dvp[w] : 0.f;
                 const float4* row = reinterpret_cast<const float4*>(M.dirsT + ((size_t)S.ivid[w / 3] * 3 + w % 3) * SFX_KD_PAD);
@@ -654,7 +665,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
                 else { da[u] = pa; db[u] = pa; dv[u] = 0.f; }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < RIF; ++u) {
                 pa.x += da[u].x * dv[u]; pa.y += da[u].y * dv[u]; pa.z += da[u].z * dv[u]; pa.w += da[u].w * dv[u];
                 pb.x += db[u].x * dv[u]; pb.y += db[u].y * dv[u]; pb.z += db[u].z * dv[u]; pb.w += db[u].w * dv[u];
             }
@@ -793,7 +804,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     }
     __syncthreads();
     MARK(15);
-    if constexpr (HAS_VP) if (C.use_vposer) vposer_backward<CT>(S.V, M, &S.dpose[3], &S.gc[L.emb]);   // d body_pose -> d latent
+    if constexpr (HAS_VP) if (C.use_vposer) vposer_backward<CT>(S.V, M, &S.dpose[3], &S.gc[L.emb], S.T);   // d body_pose -> d latent
     const VarList& vl = vls[cam_stage ? 0 : 1];
     float* gout = D.g + (size_t)b * SFX_NVAR_MAX;
     for (int i = t; i < vl.n; i += CT) { const float gv = S.gc[vl.idx[i]]; gout[i] = gv; if (gflat) gflat[i] = gv; }

@@ -94,27 +94,60 @@ __device__ __forceinline__ void vposer_joint(const float* a, float* aa, const fl
     da[1] = dc1[0]; da[3] = dc1[1]; da[5] = dc1[2];
 }
 
+// y[o] = sum_k Wt[k][o] * x[k] for o < nout (nout a multiple of 4), all NT threads of the
+// workgroup: nout/4 threads cover one row with 16-byte loads, the NT / (nout/4) thread groups split
+// the k range and leave partial sums in `part` ([groups][nout], LDS); the caller adds them in group
+// order.  16 bytes per lane and 8 rows in flight per thread keep ~64 KB of weights in flight per
+// CU -- a scalar 4-byte-per-lane loop is latency bound at a tenth of the L2 bandwidth.
+template <int NT>
+__device__ __forceinline__ int vp_gemv_partial(const float* __restrict__ Wt, const int K, const int ld, const int nout,
+                                               const float* x, float* part) {
+    const int t = threadIdx.x;
+    const int tpr = nout >> 2;                  // threads per row
+    const int groups = NT / tpr;
+    const int c4 = t % tpr, g = t / tpr;
+    if (g < groups) {
+        const int k0 = (K * g) / groups, k1 = (K * (g + 1)) / groups;
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float4* w = reinterpret_cast<const float4*>(Wt + (size_t)k0 * ld) + c4;
+        const int ld4 = ld >> 2;
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k, w += ld4) {
+            const float4 wv = *w;
+            const float xv = x[k];
+            acc.x += wv.x * xv; acc.y += wv.y * xv; acc.z += wv.z * xv; acc.w += wv.w * xv;
+        }
+        reinterpret_cast<float4*>(part + (size_t)g * nout)[c4] = acc;
+    }
+    return groups;
+}
+
 // z[latent] (LDS) -> V.body[63]; all threads of the workgroup
 template <int NT>
 __device__ __forceinline__ void vposer_forward(VposerLDS& V, const DevModel& M, const float* z) {
     const int t = threadIdx.x, L = M.vp_latent;
+    float* part = V.dh;                         // dh, dg (2 x 512 floats, contiguous) are free during the forward
+    int G = vp_gemv_partial<NT>(M.vp_w1T, L, VP_H, VP_H, z, part);
+    __syncthreads();
     for (int o = t; o < VP_H; o += NT) {
         float acc = M.vp_b1[o];
-        for (int i = 0; i < L; ++i) acc += M.vp_w1T[i * VP_H + o] * z[i];
+        for (int g = 0; g < G; ++g) acc += part[g * VP_H + o];
         V.h1[o] = leaky(acc);
     }
     __syncthreads();
+    G = vp_gemv_partial<NT>(M.vp_w2T, VP_H, VP_H, VP_H, V.h1, part);
+    __syncthreads();
     for (int o = t; o < VP_H; o += NT) {
         float acc = M.vp_b2[o];
-#pragma unroll 8
-        for (int i = 0; i < VP_H; ++i) acc += M.vp_w2T[i * VP_H + o] * V.h1[i];
+        for (int g = 0; g < G; ++g) acc += part[g * VP_H + o];
         V.h2[o] = leaky(acc);
     }
     __syncthreads();
+    G = vp_gemv_partial<NT>(M.vp_w3T, VP_H, 128, 128, V.h2, part);
+    __syncthreads();
     for (int o = t; o < VP_O; o += NT) {
         float acc = M.vp_b3[o];
-#pragma unroll 8
-        for (int i = 0; i < VP_H; ++i) acc += M.vp_w3T[i * 128 + o] * V.h2[i];
+        for (int g = 0; g < G; ++g) acc += part[g * 128 + o];
         V.o[o] = acc;
     }
     __syncthreads();
@@ -122,28 +155,35 @@ __device__ __forceinline__ void vposer_forward(VposerLDS& V, const DevModel& M, 
     __syncthreads();
 }
 
-// dbody[63] (LDS) -> dz[latent] accumulated into gz (LDS, latent entries)
+// dbody[63] (LDS) -> dz[latent] accumulated into gz (LDS, latent entries).  `part` = 1024 floats of
+// LDS scratch that is dead here (the caller passes the item-transform array).
 template <int NT>
-__device__ __forceinline__ void vposer_backward(VposerLDS& V, const DevModel& M, const float* dbody, float* gz) {
+__device__ __forceinline__ void vposer_backward(VposerLDS& V, const DevModel& M, const float* dbody, float* gz, float* part) {
     const int t = threadIdx.x, L = M.vp_latent;
     if (t < 21) { float aa[3]; vposer_joint(&V.o[6 * t], aa, &dbody[3 * t], &V.dg[6 * t]); }
+    if (t >= 64 && t < 66) V.dg[VP_O + t - 64] = 0.f;        // pad to 128 rows of W3 (rows 126, 127 are not read)
     __syncthreads();
-    for (int i = t; i < VP_H; i += NT) {           // d h2 = W3^T d o, through leaky'
+    int G = vp_gemv_partial<NT>(M.vp_w3, VP_O, VP_H, VP_H, V.dg, part);      // d h2 = W3^T d o, through leaky'
+    __syncthreads();
+    for (int i = t; i < VP_H; i += NT) {
         float acc = 0.f;
-        for (int o = 0; o < VP_O; ++o) acc += M.vp_w3[o * VP_H + i] * V.dg[o];
+        for (int g = 0; g < G; ++g) acc += part[g * VP_H + i];
         V.dh[i] = acc * (V.h2[i] > 0.f ? 1.f : 0.2f);
     }
     __syncthreads();
-    for (int i = t; i < VP_H; i += NT) {           // d h1 = W2^T d pre2, through leaky'
+    G = vp_gemv_partial<NT>(M.vp_w2, VP_H, VP_H, VP_H, V.dh, part);          // d h1 = W2^T d pre2, through leaky'
+    __syncthreads();
+    for (int i = t; i < VP_H; i += NT) {
         float acc = 0.f;
-#pragma unroll 8
-        for (int o = 0; o < VP_H; ++o) acc += M.vp_w2[o * VP_H + i] * V.dh[o];
+        for (int g = 0; g < G; ++g) acc += part[g * VP_H + i];
         V.dg[i] = acc * (V.h1[i] > 0.f ? 1.f : 0.2f);
     }
     __syncthreads();
+    G = vp_gemv_partial<NT>(M.vp_w1, VP_H, L, L, V.dg, part);                // d z = W1^T d pre1
+    __syncthreads();
     for (int i = t; i < L; i += NT) {
         float acc = 0.f;
-        for (int o = 0; o < VP_H; ++o) acc += M.vp_w1[o * L + i] * V.dg[o];
+        for (int g = 0; g < G; ++g) acc += part[g * L + i];
         gz[i] += acc;
     }
     __syncthreads();
