@@ -192,6 +192,26 @@ int  sfx_batch_get_stats(sfx_batch* b, float* stage_loss, int32_t* stage_evals,
 int  sfx_batch_forward(sfx_batch* b, float* vertices_out_dev /* [B][V][3] */,
                        float* joints_out_dev /* [B][K][3] */, void* stream);
 
+/* ---- interpenetration term ---------------------------------------------
+ * Replaces BVH(max_collisions) + FilterFaces(segm, parents, ign_part_pairs) +
+ * DistanceFieldPenetrationLoss(sigma, penalize_outside) of the external mesh_intersection
+ * package as the reference uses them (fitting.py:437-455, fit_single_frame.py:300-328), for a
+ * batch of posed meshes.  faces [F][3]; segm / parents [F] per-face part labels of
+ * smplx_parts_segm.pkl (NULL: no part filter); ign_pairs [n_ign][2] part pairs that never
+ * collide; max_collisions = partners kept per triangle; max_batch = frames per call.            */
+typedef struct sfx_pen sfx_pen;
+int  sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const int32_t* segm, const int32_t* parents,
+                    const int32_t* ign_pairs, int32_t n_ign, int32_t max_collisions, int32_t max_batch,
+                    sfx_pen** out);
+void sfx_pen_destroy(sfx_pen* h);
+/* vertices [B][V][3] (DEVICE) -> loss [B] (DEVICE, unweighted: the caller multiplies by
+ * coll_loss_weight) and d loss / d vertices [B][V][3] (DEVICE).  sigma = df_cone_height.        */
+int  sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
+                  float* loss_dev, float* dverts_dev, void* stream);
+/* per frame (HOST [B][4]): ordered pairs kept, partners dropped by max_collisions, grid entries
+ * when they overflowed the buffer (0 = fine; then the frame reports no pairs), grid cells.       */
+int  sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host);
+
 /* Timing hooks for the roofline report: total duration (ms), number of TIMED launches and
  * frames processed by them, of the named kernel since the last reset, measured with HIP events
  * on the launch stream.  name: "lbs_dense", "tick" (k_tick_dense), "fit_rows", "closure",

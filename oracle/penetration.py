@@ -1,0 +1,124 @@
+"""ORACLE (test infrastructure): the interpenetration term of SMPLify-X
+(smplifyx/fitting.py:437-455 with fit_single_frame.py:300-328).
+
+PARITY UNPINNED.  The reference delegates this term to the external CUDA package
+`mesh_intersection` (xiyichen/torch-mesh-isect, fork of vchoutas/torch-mesh-isect; absent from
+/root/reference and from this image): `BVH(max_collisions)` -> candidate triangle pairs,
+`FilterFaces(faces_segm, faces_parents, ign_part_pairs)` -> pairs between unrelated body parts,
+`DistanceFieldPenetrationLoss(sigma, point2plane=False, penalize_outside)` -> scalar.  This file
+restates the published algorithm the package implements:
+
+  * candidates: pairs of triangles whose axis-aligned bounding boxes overlap and that share no
+    vertex (the broad phase of the BVH; each unordered pair once);
+  * filter: drop a pair when both triangles belong to the same part, when one's part is the
+    other's kinematic parent, or when the (unordered) part pair is listed in ign_part_pairs;
+  * penalty (Tzionas et al. IJCV 2016, eqs. 13-16; SMPLify-X, CVPR 2019, sec. 3.5): each triangle f
+    spans a cone field around its circumscribed circle (centre o_f, radius r_f, unit normal n_f);
+    for a point v with height x = n_f . (v - o_f) and radial distance rho,
+        Phi_f(v) = rho / (r_f - (r_f / sigma) x),
+        Ups(x)   = -x + 1 - sigma                                       x <= -sigma
+                   -(1 - 2 sigma)/(4 sigma^2) x^2 - x/(2 sigma) + (3 - 2 sigma)/4    |x| < sigma
+                   0                                                    x >= sigma
+        Psi_f(v) = ((1 - Phi_f(v)) Ups(x))^2   if Phi_f(v) < 1 and x < sigma,  else 0,
+    and a colliding pair (f, g) costs  sum_{v in g} |Psi_f(v) n_g|^2 + sum_{v in f} |Psi_g(v) n_f|^2
+    = sum Psi^2 (unit normals).  penalize_outside=False keeps only points behind the plane (x <= 0).
+
+Everything is plain numpy / torch (autograd supplies the gradient); brute force over triangle
+pairs, chunked -- small meshes in seconds, the 20908-face topology in tens of seconds per frame.
+"""
+import numpy as np
+import torch
+
+
+def parse_ign_part_pairs(ign_part_pairs):
+    """['9,16', ...] (cfg) -> sorted list of (lo, hi) int tuples."""
+    out = []
+    for p in ign_part_pairs or []:
+        a, b = (int(x) for x in str(p).split(","))
+        out.append((min(a, b), max(a, b)))
+    return sorted(set(out))
+
+
+def candidate_pairs(verts, faces, segm=None, parents=None, ign_part_pairs=None, chunk=512):
+    """[P, 2] int64 array of colliding-candidate triangle pairs (i < j), lexicographically sorted.
+    verts [V,3], faces [F,3]; segm / parents [F] switch the part filter on."""
+    verts = np.asarray(verts, np.float64)
+    faces = np.asarray(faces, np.int64)
+    tri = verts[faces]
+    lo, hi = tri.min(1), tri.max(1)
+    F = faces.shape[0]
+    ign = set(parse_ign_part_pairs(ign_part_pairs))
+    out = []
+    for s in range(0, F, chunk):
+        e = min(F, s + chunk)
+        ov = np.all((lo[s:e, None, :] <= hi[None, :, :]) & (lo[None, :, :] <= hi[s:e, None, :]), axis=2)
+        ov &= (np.arange(s, e)[:, None] < np.arange(F)[None, :])
+        ii, jj = np.nonzero(ov)
+        ii += s
+        if ii.size == 0:
+            continue
+        share = (faces[ii][:, :, None] == faces[jj][:, None, :]).any(axis=(1, 2))
+        keep = ~share
+        if segm is not None:
+            sa, sb = np.asarray(segm)[ii], np.asarray(segm)[jj]
+            pa, pb = np.asarray(parents)[ii], np.asarray(parents)[jj]
+            keep &= ~((sa == sb) | (sa == pb) | (sb == pa))
+            if ign:
+                lo_p, hi_p = np.minimum(sa, sb), np.maximum(sa, sb)
+                keep &= ~np.array([(a, b) in ign for a, b in zip(lo_p, hi_p)], bool)
+        out.append(np.stack([ii[keep], jj[keep]], 1))
+    if not out:
+        return np.zeros((0, 2), np.int64)
+    return np.concatenate(out, 0)
+
+
+def _cone_geometry(tri):
+    """tri [P,3,3] -> circumcentre o [P,3], radius r [P], unit normal n [P,3]."""
+    p0, a, b = tri[:, 0], tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    axb = torch.cross(a, b, dim=1)
+    den = 2.0 * (axb * axb).sum(1, keepdim=True)
+    aa, bb = (a * a).sum(1, keepdim=True), (b * b).sum(1, keepdim=True)
+    o = p0 + (bb * torch.cross(axb, a, dim=1) + aa * torch.cross(b, axb, dim=1)) / den
+    r = (o - p0).norm(dim=1)
+    n = axb / axb.norm(dim=1, keepdim=True)
+    return o, r, n
+
+
+def _psi(o, r, n, pts, sigma, penalize_outside):
+    """Cone distance field of receivers (o, r, n: [P,...]) at points pts [P,3,3] -> Psi [P,3]."""
+    d = pts - o[:, None, :]
+    x = (d * n[:, None, :]).sum(2)
+    rho = (d - x[..., None] * n[:, None, :]).norm(dim=2)
+    rr = r[:, None]
+    phi = rho / (rr - (rr / sigma) * x)
+    ups_in = -x + 1.0 - sigma
+    ups_mid = -(1.0 - 2.0 * sigma) / (4.0 * sigma * sigma) * x * x - x / (2.0 * sigma) + (3.0 - 2.0 * sigma) / 4.0
+    ups = torch.where(x <= -sigma, ups_in, ups_mid)
+    live = (x < sigma) & (phi < 1.0)
+    if not penalize_outside:
+        live = live & (x <= 0.0)
+    val = ((1.0 - phi) * ups) ** 2
+    return torch.where(live, val, torch.zeros_like(val))
+
+
+def penetration_loss(verts, faces, pairs, sigma, penalize_outside=True):
+    """verts torch [V,3] (requires_grad for the gradient), faces [F,3], pairs [P,2] -> scalar."""
+    if len(pairs) == 0:
+        return verts.sum() * 0.0
+    faces_t = torch.as_tensor(np.asarray(faces, np.int64))
+    tri = verts[faces_t]
+    A, Bt = tri[torch.as_tensor(pairs[:, 0])], tri[torch.as_tensor(pairs[:, 1])]
+    oa, ra, na = _cone_geometry(A)
+    ob, rb, nb = _cone_geometry(Bt)
+    return (_psi(oa, ra, na, Bt, sigma, penalize_outside) ** 2).sum() + \
+           (_psi(ob, rb, nb, A, sigma, penalize_outside) ** 2).sum()
+
+
+def penetration(verts, faces, segm=None, parents=None, ign_part_pairs=None, sigma=1e-4, penalize_outside=True,
+                dtype=torch.float64):
+    """Convenience: numpy verts [V,3] -> (loss float, d loss / d verts [V,3], pairs [P,2])."""
+    pairs = candidate_pairs(verts, faces, segm, parents, ign_part_pairs)
+    v = torch.tensor(np.asarray(verts), dtype=dtype, requires_grad=True)
+    loss = penetration_loss(v, faces, pairs, sigma, penalize_outside)
+    loss.backward()
+    return float(loss.item()), v.grad.numpy().copy(), pairs

@@ -1,0 +1,429 @@
+// collide.hip -- the interpenetration term of SMPLify-X on a batch of posed meshes.
+//
+// Replaces, for B frames at once, what the reference obtains from the external CUDA package
+// mesh_intersection (smplifyx/fitting.py:437-455, set-up smplifyx/fit_single_frame.py:300-328):
+//     collision_idxs = BVH(max_collisions)(triangles)            broad phase: AABB overlap
+//     collision_idxs = FilterFaces(segm, parents, ign_part_pairs)(collision_idxs)
+//     pen_loss       = DistanceFieldPenetrationLoss(sigma, penalize_outside)(triangles, collision_idxs)
+// and its gradient with respect to the vertices.  Algorithm and formulas: oracle/penetration.py
+// (the package's source is absent: parity unpinned).
+//
+// MI355X design (not the package's LBVH): one workgroup of 1024 lanes owns one frame and keeps a
+// uniform grid over the frame's bounding box in LDS (<= 24^3 cells, 2 x 54 KB):
+//   k_pen_pairs   triangle AABBs -> cell size from the mean triangle extent -> counting sort of
+//                 (cell, triangle) entries (a triangle is entered in every cell its AABB touches)
+//                 -> every triangle scans the cells of its own AABB: part filter first (one byte
+//                 table lookup rejects ~95 %), then AABB overlap, then shared vertices; a pair seen in
+//                 several cells is kept in the cell that holds the low corner of the intersection box.
+//                 Partners are stored per triangle ([F][cap], both directions).
+//   k_pen_eval    one lane per triangle: partners visited in ascending index (selection, no
+//                 sorting), conic distance field evaluated with forward-mode dual numbers -- the
+//                 lane differentiates with respect to ITS OWN 9 coordinates only, once as receiver
+//                 geometry and once as intruding points -- so every write has one owner: no atomics,
+//                 results independent of scheduling and of batch composition.
+//   k_pen_gather  vertex gradient = fixed-order sum over the incident triangle corners (CSR);
+//                 frame loss = fixed-order block reduction.
+#include "../../include/sfx.h"
+#include "sfx_internal.h"
+#include "wave_ops.h"
+
+#include <algorithm>
+#include <vector>
+
+#define PEN_T 1024
+#define PEN_GRID_MAX 24        // 24^3 cells: histogram + cursors = 2 x 54 KB of LDS
+#define PEN_CELLS (PEN_GRID_MAX * PEN_GRID_MAX * PEN_GRID_MAX)
+
+struct PenDev {
+    int V, F, cap, n_parts;
+    const int* faces;          // [F][3]
+    const int* segm;           // [F]
+    const unsigned char* skip; // [n_parts][n_parts] 1 = pair of parts never collides
+    const int* vf_start;       // [V+1] CSR: incident (face * 3 + corner)
+    const int* vf_list;
+    // per batch (capacity Bmax)
+    float* aabb;               // [B][F][6]
+    int* entries;              // [B][ent_cap] triangle ids sorted by cell
+    int ent_cap;
+    int* partners;             // [B][F][cap]
+    int* pcount;               // [B][F]
+    float* tloss;              // [B][F]
+    float* tgrad;              // [B][F][9]
+    int* stats;                // [B][4]: pairs (ordered), overflow of cap, overflow of entries, cells
+};
+
+// ---------------------------------------------------------------------------------------------
+template <int N> struct Dual { float v; float d[N]; };
+template <int N> __device__ __forceinline__ Dual<N> dconst(float v) { Dual<N> r; r.v = v; for (int i = 0; i < N; ++i) r.d[i] = 0.f; return r; }
+template <int N> __device__ __forceinline__ Dual<N> dvar(float v, int k) { Dual<N> r = dconst<N>(v); r.d[k] = 1.f; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator*(const Dual<N>& a, float s) { Dual<N> r; r.v = a.v * s; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * s; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator+(const Dual<N>& a, float s) { Dual<N> r = a; r.v += s; return r; }
+template <int N> __device__ __forceinline__ Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {
+    Dual<N> r; const float inv = 1.f / b.v; r.v = a.v * inv;
+    for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+    return r;
+}
+template <int N> __device__ __forceinline__ Dual<N> dsqrt(const Dual<N>& a) {
+    Dual<N> r; r.v = sqrtf(a.v); const float h = r.v > 0.f ? 0.5f / r.v : 0.f;
+    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * h;
+    return r;
+}
+template <int N> struct DVec { Dual<N> x, y, z; };
+template <int N> __device__ __forceinline__ DVec<N> operator-(const DVec<N>& a, const DVec<N>& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <int N> __device__ __forceinline__ DVec<N> operator+(const DVec<N>& a, const DVec<N>& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <int N> __device__ __forceinline__ DVec<N> operator*(const DVec<N>& a, const Dual<N>& s) { return {a.x * s, a.y * s, a.z * s}; }
+template <int N> __device__ __forceinline__ Dual<N> ddot(const DVec<N>& a, const DVec<N>& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <int N> __device__ __forceinline__ DVec<N> dcross(const DVec<N>& a, const DVec<N>& b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// circumscribed circle + unit normal of a triangle (oracle/penetration.py: _cone_geometry)
+template <int N>
+__device__ __forceinline__ void cone_geometry(const DVec<N>& p0, const DVec<N>& p1, const DVec<N>& p2,
+                                              DVec<N>& o, Dual<N>& r, DVec<N>& n) {
+    const DVec<N> a = p1 - p0, b = p2 - p0;
+    const DVec<N> axb = dcross(a, b);
+    const Dual<N> n2 = ddot(axb, axb);
+    const Dual<N> den = n2 * 2.f;
+    const Dual<N> aa = ddot(a, a), bb = ddot(b, b);
+    const DVec<N> num = dcross(axb, a) * bb + dcross(b, axb) * aa;
+    const Dual<N> inv = dconst<N>(1.f) / den;
+    const DVec<N> oc = num * inv;
+    o = p0 + oc;
+    r = dsqrt(ddot(oc, oc));
+    const Dual<N> il = dconst<N>(1.f) / dsqrt(n2);
+    n = axb * il;
+}
+
+// Psi(v)^2 of the cone field (o, r, n) at the point v (oracle/penetration.py: _psi, squared)
+template <int N>
+__device__ __forceinline__ Dual<N> cone_penalty(const DVec<N>& o, const Dual<N>& r, const DVec<N>& n, const DVec<N>& v,
+                                                const float sigma, const int penalize_outside) {
+    const DVec<N> d = v - o;
+    const Dual<N> x = ddot(d, n);
+    if (!(x.v < sigma) || (!penalize_outside && x.v > 0.f)) return dconst<N>(0.f);
+    const DVec<N> q = d - n * x;
+    const Dual<N> rho = dsqrt(ddot(q, q));
+    const Dual<N> phi = rho / (r - (r * (1.f / sigma)) * x);
+    if (!(phi.v < 1.f)) return dconst<N>(0.f);
+    Dual<N> ups;
+    if (x.v <= -sigma) ups = (x * -1.f) + (1.f - sigma);
+    else ups = (x * x) * (-(1.f - 2.f * sigma) / (4.f * sigma * sigma)) + x * (-1.f / (2.f * sigma)) + ((3.f - 2.f * sigma) / 4.f);
+    const Dual<N> w = (dconst<N>(1.f) - phi) * ups;
+    const Dual<N> psi = w * w;
+    return psi * psi;
+}
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_min(float v, float* red) {
+    v = -wave_max_dpp(-v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < PEN_T / 64; ++i) r = fminf(r, red[i]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) { return -block_min(-v, red); }
+__device__ __forceinline__ float block_sum_fixed(float v, float* red) {
+    v = wave_sum_dpp(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < PEN_T / 64; ++i) r += red[i];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(PEN_T)
+void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
+    extern __shared__ int cell_cnt[];           // [ncell + 1]: histogram, then start offsets, then cursors
+    __shared__ float red[PEN_T / 64];
+    __shared__ int s_total;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* vb = verts + (size_t)b * P.V * 3;
+    float* aabb = P.aabb + (size_t)b * P.F * 6;
+    const int F = P.F;
+
+    // ---- AABBs, frame bounding box, mean triangle extent
+    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f}, ext_sum = 0.f;
+    for (int f = t; f < F; f += PEN_T) {
+        float a[3] = {3e38f, 3e38f, 3e38f}, c[3] = {-3e38f, -3e38f, -3e38f};
+        for (int k = 0; k < 3; ++k) {
+            const float* p = vb + (size_t)P.faces[f * 3 + k] * 3;
+            for (int e = 0; e < 3; ++e) { a[e] = fminf(a[e], p[e]); c[e] = fmaxf(c[e], p[e]); }
+        }
+        for (int e = 0; e < 3; ++e) { aabb[f * 6 + e] = a[e]; aabb[f * 6 + 3 + e] = c[e];
+                                      lo[e] = fminf(lo[e], a[e]); hi[e] = fmaxf(hi[e], c[e]); }
+        ext_sum += fmaxf(fmaxf(c[0] - a[0], c[1] - a[1]), c[2] - a[2]);
+    }
+    float glo[3], ghi[3];
+    for (int e = 0; e < 3; ++e) { glo[e] = block_min(lo[e], red); ghi[e] = block_max(hi[e], red); }
+    const float mean_ext = block_sum_fixed(ext_sum, red) / (float)F;
+    // cell size: twice the mean extent, but no more than PEN_GRID_MAX cells per axis
+    float h = 2.f * mean_ext;
+    for (int e = 0; e < 3; ++e) h = fmaxf(h, (ghi[e] - glo[e]) / (float)(PEN_GRID_MAX - 1));
+    h = fmaxf(h, 1e-6f);
+    int nd[3];
+    for (int e = 0; e < 3; ++e) nd[e] = min(PEN_GRID_MAX, (int)((ghi[e] - glo[e]) / h) + 1);
+    const int ncell = nd[0] * nd[1] * nd[2];
+    const float ih = 1.f / h;
+    auto cell_of = [&](float x, int e) { return min(nd[e] - 1, max(0, (int)((x - glo[e]) * ih))); };
+
+    // ---- counting sort of (cell, triangle) entries
+    for (int c = t; c <= ncell; c += PEN_T) cell_cnt[c] = 0;
+    __syncthreads();
+    for (int f = t; f < F; f += PEN_T) {
+        int c0[3], c1[3];
+        for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = cell_of(aabb[f * 6 + 3 + e], e); }
+        for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x)
+            atomicAdd(&cell_cnt[(z * nd[1] + y) * nd[0] + x], 1);
+    }
+    __syncthreads();
+    // exclusive scan over the cells: each lane owns a contiguous slice
+    {
+        const int per = (ncell + PEN_T - 1) / PEN_T;
+        const int c0 = min(ncell, t * per), c1 = min(ncell, c0 + per);
+        int s = 0;
+        for (int c = c0; c < c1; ++c) s += cell_cnt[c];
+        // block exclusive scan of the slice sums (fixed order)
+        __shared__ int slice[PEN_T];
+        slice[t] = s;
+        __syncthreads();
+        if (t == 0) { int acc = 0; for (int i = 0; i < PEN_T; ++i) { const int v = slice[i]; slice[i] = acc; acc += v; } s_total = acc; }
+        __syncthreads();
+        int acc = slice[t];
+        for (int c = c0; c < c1; ++c) { const int v = cell_cnt[c]; cell_cnt[c] = acc; acc += v; }
+        __syncthreads();
+        if (t == 0) cell_cnt[ncell] = s_total;
+    }
+    __syncthreads();
+    int* ent = P.entries + (size_t)b * P.ent_cap;
+    int* st = P.stats + b * 4;
+    const bool ent_ok = s_total <= P.ent_cap;
+    if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = ncell; }
+    if (!ent_ok) {       // grid too crowded for the entry buffer: report, produce no pairs
+        for (int f = t; f < F; f += PEN_T) P.pcount[(size_t)b * F + f] = 0;
+        if (t == 0) { st[0] = 0; st[1] = 0; }
+        return;
+    }
+    // scatter with per-cell cursors kept in a second LDS array
+    int* cursor = cell_cnt + (PEN_CELLS + 1);
+    for (int c = t; c < ncell; c += PEN_T) cursor[c] = cell_cnt[c];
+    __syncthreads();
+    for (int f = t; f < F; f += PEN_T) {
+        int c0[3], c1[3];
+        for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = cell_of(aabb[f * 6 + 3 + e], e); }
+        for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x)
+            ent[atomicAdd(&cursor[(z * nd[1] + y) * nd[0] + x], 1)] = f;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- partners of every triangle
+    int n_pairs = 0, n_over = 0;
+    for (int f = t; f < F; f += PEN_T) {
+        float a[6];
+        for (int e = 0; e < 6; ++e) a[e] = aabb[f * 6 + e];
+        const int fv0 = P.faces[f * 3], fv1 = P.faces[f * 3 + 1], fv2 = P.faces[f * 3 + 2];
+        const unsigned char* skip = P.skip + (size_t)P.segm[f] * P.n_parts;
+        int c0[3], c1[3];
+        for (int e = 0; e < 3; ++e) { c0[e] = cell_of(a[e], e); c1[e] = cell_of(a[3 + e], e); }
+        int cnt = 0;
+        int* mine = P.partners + ((size_t)b * F + f) * P.cap;
+        for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x) {
+            const int c = (z * nd[1] + y) * nd[0] + x;
+            for (int q = cell_cnt[c]; q < cell_cnt[c + 1]; ++q) {
+                const int g = ent[q];
+                if (g == f || skip[P.segm[g]]) continue;
+                const float* ga = aabb + g * 6;
+                bool ov = true;
+                float il[3];
+                for (int e = 0; e < 3; ++e) { ov = ov && (a[e] <= ga[3 + e]) && (ga[e] <= a[3 + e]); il[e] = fmaxf(a[e], ga[e]); }
+                if (!ov) continue;
+                // the pair is owned by the cell that holds the low corner of the intersection box
+                if (cell_of(il[0], 0) != x || cell_of(il[1], 1) != y || cell_of(il[2], 2) != z) continue;
+                const int g0 = P.faces[g * 3], g1 = P.faces[g * 3 + 1], g2 = P.faces[g * 3 + 2];
+                if (g0 == fv0 || g0 == fv1 || g0 == fv2 || g1 == fv0 || g1 == fv1 || g1 == fv2 ||
+                    g2 == fv0 || g2 == fv1 || g2 == fv2) continue;
+                if (cnt < P.cap) mine[cnt] = g; else ++n_over;
+                ++cnt;
+            }
+        }
+        P.pcount[(size_t)b * F + f] = min(cnt, P.cap);
+        n_pairs += min(cnt, P.cap);
+    }
+    const float tp = block_sum_fixed((float)n_pairs, red), to = block_sum_fixed((float)n_over, red);
+    if (t == 0) { st[0] = (int)tp; st[1] = (int)to; }
+}
+
+__global__ __launch_bounds__(256)
+void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int penalize_outside) {
+    const int b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= P.F) return;
+    const float* vb = verts + (size_t)b * P.V * 3;
+    const int cnt = P.pcount[(size_t)b * P.F + f];
+    float loss = 0.f, g9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (cnt > 0) {
+        float p[9];
+        for (int k = 0; k < 3; ++k) for (int e = 0; e < 3; ++e) p[k * 3 + e] = vb[(size_t)P.faces[f * 3 + k] * 3 + e];
+        // own geometry as duals over the 9 own coordinates (receiver role) and as constants (intruder role)
+        DVec<9> P0 = {dvar<9>(p[0], 0), dvar<9>(p[1], 1), dvar<9>(p[2], 2)};
+        DVec<9> P1 = {dvar<9>(p[3], 3), dvar<9>(p[4], 4), dvar<9>(p[5], 5)};
+        DVec<9> P2 = {dvar<9>(p[6], 6), dvar<9>(p[7], 7), dvar<9>(p[8], 8)};
+        DVec<9> o9, n9; Dual<9> r9;
+        cone_geometry(P0, P1, P2, o9, r9, n9);
+        const int* mine = P.partners + ((size_t)b * P.F + f) * P.cap;
+        int last = -1;
+        for (int it = 0; it < cnt; ++it) {
+            int g = 0x7fffffff;                          // next partner in ascending index
+            for (int q = 0; q < cnt; ++q) { const int c = mine[q]; if (c > last && c < g) g = c; }
+            last = g;
+            float qv[9];
+            for (int k = 0; k < 3; ++k) for (int e = 0; e < 3; ++e) qv[k * 3 + e] = vb[(size_t)P.faces[g * 3 + k] * 3 + e];
+            // (1) this triangle receives the partner's vertices
+            for (int k = 0; k < 3; ++k) {
+                const DVec<9> v = {dconst<9>(qv[k * 3]), dconst<9>(qv[k * 3 + 1]), dconst<9>(qv[k * 3 + 2])};
+                const Dual<9> pen = cone_penalty(o9, r9, n9, v, sigma, penalize_outside);
+                loss += pen.v;
+                for (int i = 0; i < 9; ++i) g9[i] += pen.d[i];
+            }
+            // (2) this triangle's vertices intrude into the partner's cone (partner geometry constant)
+            DVec<3> Q0 = {dconst<3>(qv[0]), dconst<3>(qv[1]), dconst<3>(qv[2])};
+            DVec<3> Q1 = {dconst<3>(qv[3]), dconst<3>(qv[4]), dconst<3>(qv[5])};
+            DVec<3> Q2 = {dconst<3>(qv[6]), dconst<3>(qv[7]), dconst<3>(qv[8])};
+            DVec<3> o3, n3; Dual<3> r3;
+            cone_geometry(Q0, Q1, Q2, o3, r3, n3);
+            for (int k = 0; k < 3; ++k) {
+                const DVec<3> v = {dvar<3>(p[k * 3], 0), dvar<3>(p[k * 3 + 1], 1), dvar<3>(p[k * 3 + 2], 2)};
+                const Dual<3> pen = cone_penalty(o3, r3, n3, v, sigma, penalize_outside);
+                for (int e = 0; e < 3; ++e) g9[k * 3 + e] += pen.d[e];
+            }
+        }
+    }
+    P.tloss[(size_t)b * P.F + f] = loss;
+    float* tg = P.tgrad + ((size_t)b * P.F + f) * 9;
+    for (int i = 0; i < 9; ++i) tg[i] = g9[i];
+}
+
+__global__ __launch_bounds__(256)
+void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss_out) {
+    __shared__ float red[4];
+    const int b = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v < P.V) {
+        float g[3] = {0.f, 0.f, 0.f};
+        const float* tg = P.tgrad + (size_t)b * P.F * 9;
+        for (int q = P.vf_start[v]; q < P.vf_start[v + 1]; ++q) {
+            const int fc = P.vf_list[q];
+            for (int e = 0; e < 3; ++e) g[e] += tg[(size_t)fc * 3 + e];     // fc = face * 3 + corner -> [face][corner][3]
+        }
+        for (int e = 0; e < 3; ++e) dverts[((size_t)b * P.V + v) * 3 + e] = g[e];
+    }
+    if (blockIdx.x == 0) {      // frame loss: fixed-order sum over the triangles
+        float s = 0.f;
+        for (int f = threadIdx.x; f < P.F; f += 256) s += P.tloss[(size_t)b * P.F + f];
+        s = wave_sum_dpp(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) loss_out[b] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct sfx_pen {
+    PenDev P{};
+    int Bmax = 0;
+    std::vector<void*> mem;
+    template <typename T> T* up(const std::vector<T>& h) {
+        T* d = nullptr;
+        if (hipMalloc((void**)&d, std::max<size_t>(h.size(), 1) * sizeof(T)) != hipSuccess) return nullptr;
+        if (!h.empty()) hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+        mem.push_back(d); return d;
+    }
+    template <typename T> T* zeros(size_t n) {
+        T* d = nullptr;
+        if (hipMalloc((void**)&d, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+        hipMemset(d, 0, std::max<size_t>(n, 1) * sizeof(T));
+        mem.push_back(d); return d;
+    }
+};
+
+extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const int32_t* segm, const int32_t* parents,
+                              const int32_t* ign_pairs, int32_t n_ign, int32_t max_collisions, int32_t max_batch,
+                              sfx_pen** out) {
+    if (!faces || !out || V < 3 || F < 1 || max_batch < 1 || max_collisions < 1) { sfx_set_error("bad arguments"); return -1; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { sfx_set_error("no HIP device: libsfx has no CPU fallback"); return -3; }
+    sfx_pen* h = new sfx_pen();
+    PenDev& P = h->P;
+    P.V = V; P.F = F; P.cap = max_collisions; h->Bmax = max_batch;
+    std::vector<int> fv(faces, faces + (size_t)F * 3), sg(F, 0);
+    int np = 1;
+    if (segm) { for (int f = 0; f < F; ++f) { sg[f] = segm[f]; np = std::max(np, segm[f] + 1); } }
+    // part-level table: same part, parent / child, or listed in ign_part_pairs (fit_single_frame.py:318-328)
+    std::vector<unsigned char> skip((size_t)np * np, 0);
+    if (segm) {
+        std::vector<int> ppar(np, -2);
+        for (int f = 0; f < F; ++f) ppar[segm[f]] = parents ? parents[f] : -1;
+        for (int a = 0; a < np; ++a) for (int b2 = 0; b2 < np; ++b2)
+            skip[(size_t)a * np + b2] = (a == b2) || (ppar[b2] == a) || (ppar[a] == b2);
+        for (int i = 0; i < n_ign; ++i) {
+            const int a = ign_pairs[2 * i], b2 = ign_pairs[2 * i + 1];
+            if (a >= 0 && a < np && b2 >= 0 && b2 < np) { skip[(size_t)a * np + b2] = 1; skip[(size_t)b2 * np + a] = 1; }
+        }
+    }
+    P.n_parts = np;
+    std::vector<int> vs(V + 1, 0), vl((size_t)F * 3);
+    for (size_t i = 0; i < fv.size(); ++i) {
+        if (fv[i] < 0 || fv[i] >= V) { sfx_set_error("face index out of range"); delete h; return -1; }
+        vs[fv[i] + 1]++;
+    }
+    for (int v = 0; v < V; ++v) vs[v + 1] += vs[v];
+    { std::vector<int> cur(vs.begin(), vs.end() - 1); for (size_t i = 0; i < fv.size(); ++i) vl[cur[fv[i]]++] = (int)i; }
+    P.faces = h->up(fv); P.segm = h->up(sg); P.skip = h->up(skip); P.vf_start = h->up(vs); P.vf_list = h->up(vl);
+    const size_t B = max_batch;
+    P.ent_cap = F * 16;
+    P.aabb = h->zeros<float>(B * F * 6); P.entries = h->zeros<int>(B * P.ent_cap);
+    P.partners = h->zeros<int>(B * F * P.cap); P.pcount = h->zeros<int>(B * F);
+    P.tloss = h->zeros<float>(B * F); P.tgrad = h->zeros<float>(B * F * 9); P.stats = h->zeros<int>(B * 4);
+    if (!P.stats || !P.tgrad || !P.partners) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
+    *out = h;
+    return 0;
+}
+
+extern "C" void sfx_pen_destroy(sfx_pen* h) {
+    if (!h) return;
+    for (void* p : h->mem) hipFree(p);
+    delete h;
+}
+
+extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
+                            float* loss_dev, float* dverts_dev, void* stream) {
+    if (!h || !verts_dev || !loss_dev || !dverts_dev) { sfx_set_error("null argument"); return -1; }
+    if (B < 1 || B > h->Bmax) { sfx_set_error("batch %d exceeds the capacity %d given to sfx_pen_create", B, h->Bmax); return -1; }
+    if (!(sigma > 0.f)) { sfx_set_error("df_cone_height must be positive"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)(2 * (PEN_CELLS + 1)) * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_pen_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            sfx_set_error("cannot reserve %zu bytes of LDS", lds); return -2; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_pen_pairs, dim3(B), dim3(PEN_T), lds, s, h->P, verts_dev, B);
+    hipLaunchKernelGGL(k_pen_eval, dim3((h->P.F + 255) / 256, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside);
+    hipLaunchKernelGGL(k_pen_gather, dim3((std::max(h->P.V, 1) + 255) / 256, B), dim3(256), 0, s, h->P, dverts_dev, loss_dev);
+    if (hipGetLastError() != hipSuccess) { sfx_set_error("penetration kernels failed to launch"); return -4; }
+    return 0;
+}
+
+extern "C" int sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host /* [B][4] */) {
+    if (!h || !stats_host || B < 1 || B > h->Bmax) { sfx_set_error("bad arguments"); return -1; }
+    if (hipDeviceSynchronize() != hipSuccess) { sfx_set_error("device error"); return -4; }
+    hipMemcpy(stats_host, h->P.stats, (size_t)B * 4 * sizeof(int), hipMemcpyDeviceToHost);
+    return 0;
+}

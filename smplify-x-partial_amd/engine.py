@@ -331,3 +331,58 @@ def prof_get(name):
     ms, n, u = C.c_double(), C.c_int64(), C.c_double()
     capi.load().sfx_prof_get(name.encode(), C.byref(ms), C.byref(n), C.byref(u))
     return ms.value, n.value, u.value
+
+
+class Penetration(object):
+    """Interpenetration term on a batch of posed meshes (sfx_pen_*):
+    BVH + FilterFaces + DistanceFieldPenetrationLoss of the reference's external package
+    (fitting.py:437-455).  `segm` / `parents`: per-face part labels (smplx_parts_segm.pkl);
+    `ign_part_pairs`: the cfg's ["9,16", ...] strings or (a, b) tuples."""
+
+    def __init__(self, num_verts, faces, segm=None, parents=None, ign_part_pairs=None, max_collisions=128,
+                 max_batch=1):
+        self._lib = capi.load()
+        faces = capi.i32(np.asarray(faces).astype(np.int64).reshape(-1, 3))
+        self.V, self.F, self.max_batch = int(num_verts), int(faces.shape[0]), int(max_batch)
+        pairs = []
+        for p in ign_part_pairs or []:
+            a, b = (int(x) for x in str(p).split(",")) if isinstance(p, str) else p
+            pairs.append((a, b))
+        ign = capi.i32(np.asarray(pairs, np.int64).reshape(-1, 2))
+        sg = capi.i32(segm) if segm is not None else None
+        pr = capi.i32(parents) if parents is not None else None
+        h = C.c_void_p()
+        capi.check(self._lib.sfx_pen_create(self.V, self.F, capi.iptr(faces), capi.iptr(sg) if sg is not None else None,
+                                            capi.iptr(pr) if pr is not None else None,
+                                            capi.iptr(ign) if len(pairs) else None, len(pairs), int(max_collisions),
+                                            self.max_batch, C.byref(h)))
+        self._h = h
+
+    def eval(self, verts, sigma, penalize_outside=True, stream=None):
+        """verts: float32 CUDA tensor [B, V, 3] -> (loss [B], d loss / d verts [B, V, 3]) on the GPU."""
+        import torch
+        assert verts.is_cuda and verts.dtype == torch.float32 and verts.shape[1:] == (self.V, 3)
+        v = verts.contiguous()
+        B = v.shape[0]
+        loss = torch.empty([B], dtype=torch.float32, device=v.device)
+        dv = torch.empty_like(v)
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        capi.check(self._lib.sfx_pen_eval(self._h, B, C.c_void_p(v.data_ptr()), float(sigma), int(bool(penalize_outside)),
+                                          C.c_void_p(loss.data_ptr()), C.c_void_p(dv.data_ptr()), C.c_void_p(s)))
+        return loss, dv
+
+    def stats(self, B):
+        out = np.zeros((B, 4), np.int32)
+        capi.check(self._lib.sfx_pen_stats(self._h, int(B), capi.iptr(out)))
+        return dict(pairs=out[:, 0].copy(), dropped=out[:, 1].copy(), entry_overflow=out[:, 2].copy(), cells=out[:, 3].copy())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sfx_pen_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

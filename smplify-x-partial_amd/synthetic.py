@@ -199,6 +199,18 @@ def make_synthetic_model(seed=0, num_verts=NUM_VERTS, num_faces=NUM_FACES,
     return model
 
 
+def make_synthetic_parts(model):
+    """Per-face body-part labels in the format of smplifyx/smplx_parts_segm.pkl
+    (fit_single_frame.py:318-324): segm[f] = joint with the largest skinning weight on the face's
+    first vertex, parents[f] = that joint's kinematic parent (-1 for the root)."""
+    W = np.asarray(model["weights"])
+    faces = np.asarray(model["f"]).astype(np.int64)
+    par = np.asarray(model["kintree_table"])[0].astype(np.int64).copy()
+    par[0] = -1
+    segm = W[faces[:, 0]].argmax(1).astype(np.int64)
+    return dict(segm=segm, parents=par[segm])
+
+
 def make_synthetic_vposer(seed=0, latent=32, hidden=512, dtype=np.float32, encoder_inputs=0):
     """Random-init VPoser-v1 *decoder* weights (appendix A.3): fc1 32->512,
     fc2 512->512, out 512->126, leaky_relu(0.2).  Scaled so decoded poses are O(0.3 rad).

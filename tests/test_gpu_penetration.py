@@ -1,0 +1,122 @@
+"""Interpenetration term (csrc/collide.hip) against the oracle (oracle/penetration.py) --
+candidate pairs, loss and vertex gradient -- on small meshes and on the synthetic SMPL-X mesh."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import penetration as OP
+from smplifyx_amd import engine
+
+pytestmark = pytest.mark.gpu
+
+
+def _sphere(n_lat, n_lon, center, radius):
+    """Closed triangulated sphere: vertices [V,3], faces [F,3]."""
+    vs = [[0, 0, 1.0]]
+    for i in range(1, n_lat):
+        th = np.pi * i / n_lat
+        for j in range(n_lon):
+            ph = 2 * np.pi * j / n_lon
+            vs.append([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)])
+    vs.append([0, 0, -1.0])
+    vs = np.asarray(vs) * radius + np.asarray(center)
+    fs = []
+    ring = lambda i, j: 1 + (i - 1) * n_lon + (j % n_lon)
+    for j in range(n_lon):
+        fs.append([0, ring(1, j), ring(1, j + 1)])
+    for i in range(1, n_lat - 1):
+        for j in range(n_lon):
+            fs.append([ring(i, j), ring(i + 1, j), ring(i + 1, j + 1)])
+            fs.append([ring(i, j), ring(i + 1, j + 1), ring(i, j + 1)])
+    last = len(vs) - 1
+    for j in range(n_lon):
+        fs.append([last, ring(n_lat - 1, j + 1), ring(n_lat - 1, j)])
+    return vs, np.asarray(fs, np.int64)
+
+
+def _two_spheres(offset):
+    v0, f0 = _sphere(10, 16, [0, 0, 0], 0.10)
+    v1, f1 = _sphere(9, 14, [offset, 0.01, 0.02], 0.08)
+    verts = np.concatenate([v0, v1])
+    faces = np.concatenate([f0, f1 + len(v0)])
+    segm = np.concatenate([np.zeros(len(f0), np.int64), 2 * np.ones(len(f1), np.int64)])
+    parents = np.concatenate([-np.ones(len(f0), np.int64), np.ones(len(f1), np.int64)])   # part 2's parent is part 1
+    return verts, faces, segm, parents
+
+
+def _pairs_from_gpu(pen, B):
+    """ordered partner lists -> set of unordered pairs per frame (debug read-back through torch)."""
+    return pen.stats(B)
+
+
+@pytest.mark.parametrize("sigma,outside", [(0.5, True), (0.5, False), (1e-3, True)])
+def test_two_spheres_loss_and_gradient(sigma, outside):
+    verts, faces, segm, parents = _two_spheres(0.13)
+    B = 3
+    rng = np.random.RandomState(0)
+    vb = np.stack([verts + 0.004 * rng.normal(size=verts.shape) * (b > 0) + [0.01 * b, 0, 0] for b in range(B)])
+    pen = engine.Penetration(len(verts), faces, segm, parents, max_collisions=64, max_batch=B)
+    loss, dv = pen.eval(torch.tensor(vb, dtype=torch.float32, device="cuda"), sigma, outside)
+    st = pen.stats(B)
+    assert np.all(st["dropped"] == 0) and np.all(st["entry_overflow"] == 0)
+    loss, dv = loss.cpu().numpy(), dv.cpu().numpy()
+    for b in range(B):
+        v32 = vb[b].astype(np.float32).astype(np.float64)
+        lo, go, pairs = OP.penetration(v32, faces, segm, parents, None, sigma=sigma, penalize_outside=outside)
+        assert st["pairs"][b] == 2 * len(pairs), (b, st["pairs"][b], len(pairs))
+        assert len(pairs) > 50
+        assert abs(loss[b] - lo) <= 2e-4 * abs(lo) + 1e-9, (b, loss[b], lo)
+        assert np.linalg.norm(dv[b] - go) <= 2e-3 * np.linalg.norm(go) + 1e-9, (b, np.linalg.norm(dv[b] - go), np.linalg.norm(go))
+
+
+def test_part_filter_and_separated_meshes():
+    verts, faces, segm, parents = _two_spheres(0.13)
+    t = torch.tensor(verts[None], dtype=torch.float32, device="cuda")
+    # same part everywhere -> nothing collides; parent/child parts -> nothing; ignored pair -> nothing
+    for sg, pr, ign in ((np.zeros_like(segm), -np.ones_like(parents), None),
+                        (segm, np.where(segm == 2, 0, -1), None),
+                        (segm, parents, ["0,2"])):
+        pen = engine.Penetration(len(verts), faces, sg, pr, ign, max_collisions=64, max_batch=1)
+        loss, dv = pen.eval(t, 0.5)
+        assert float(loss[0]) == 0.0 and float(dv.abs().max()) == 0.0 and pen.stats(1)["pairs"][0] == 0
+    # far apart: no candidates at all
+    v2, f2, s2, p2 = _two_spheres(0.5)
+    pen = engine.Penetration(len(v2), f2, s2, p2, max_collisions=64, max_batch=1)
+    loss, dv = pen.eval(torch.tensor(v2[None], dtype=torch.float32, device="cuda"), 0.5)
+    assert float(loss[0]) == 0.0 and pen.stats(1)["pairs"][0] == 0
+    # without labels every non-adjacent overlapping pair counts (self-collisions of one sphere included)
+    pen = engine.Penetration(len(verts), faces, max_collisions=128, max_batch=1)
+    pen.eval(t, 0.5)
+    pairs = OP.candidate_pairs(verts.astype(np.float32), faces)
+    assert pen.stats(1)["pairs"][0] == 2 * len(pairs) > 0
+
+
+def test_max_collisions_cap_is_reported():
+    verts, faces, segm, parents = _two_spheres(0.13)
+    pen = engine.Penetration(len(verts), faces, segm, parents, max_collisions=2, max_batch=1)
+    pen.eval(torch.tensor(verts[None], dtype=torch.float32, device="cuda"), 0.5)
+    st = pen.stats(1)
+    assert st["dropped"][0] > 0 and st["pairs"][0] <= 2 * len(faces)
+
+
+def test_synthetic_smplx_mesh(synth_model):
+    """The 20908-face synthetic SMPL-X mesh with synthetic part labels and the cfg's ignored pairs
+    (cfg_files/fit_smplx_combined_halpe.yaml): pair count, loss and gradient vs the oracle."""
+    from smplifyx_amd import synthetic
+    parts = synthetic.make_synthetic_parts(synth_model)
+    ign = ["9,16", "9,17", "6,16", "6,17", "1,2", "12,22"]
+    v = np.asarray(synth_model["v_template"], np.float32)
+    f = np.asarray(synth_model["f"]).astype(np.int64)
+    pen = engine.Penetration(len(v), f, parts["segm"], parts["parents"], ign, max_collisions=128, max_batch=2)
+    vb = np.stack([v, v * np.array([1.0, 1.0, 0.9], np.float32)])
+    loss, dv = pen.eval(torch.tensor(vb, device="cuda"), 0.01)
+    st = pen.stats(2)
+    assert np.all(st["dropped"] == 0) and np.all(st["entry_overflow"] == 0)
+    lo, go, pairs = OP.penetration(v.astype(np.float64), f, parts["segm"], parts["parents"], ign, sigma=0.01)
+    assert st["pairs"][0] == 2 * len(pairs)
+    assert abs(float(loss[0]) - lo) <= 5e-4 * abs(lo)
+    g = dv[0].cpu().numpy()
+    assert np.linalg.norm(g - go) <= 5e-3 * np.linalg.norm(go)
+    # frame 1 (a different pose of the same mesh) is independent of frame 0
+    loss1, dv1 = pen.eval(torch.tensor(vb[1:], device="cuda"), 0.01)
+    assert float(loss1[0]) == float(loss[1]) and torch.equal(dv1[0], dv[1])
