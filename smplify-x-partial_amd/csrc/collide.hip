@@ -9,7 +9,7 @@
 // (the package's source is absent: parity unpinned).
 //
 // MI355X design (not the package's LBVH): one workgroup of 1024 lanes owns one frame and keeps a
-// uniform grid over the frame's bounding box in LDS (<= 24^3 cells, 2 x 54 KB):
+// uniform grid (cell = twice the mean triangle extent) hashed into 16384 LDS buckets:
 //   k_pen_pairs   triangle AABBs -> cell size from the mean triangle extent -> counting sort of
 //                 (cell, triangle) entries (a triangle is entered in every cell its AABB touches)
 //                 -> every triangle scans the cells of its own AABB: part filter first (one byte
@@ -31,8 +31,7 @@
 #include <vector>
 
 #define PEN_T 1024
-#define PEN_GRID_MAX 24        // 24^3 cells: histogram + cursors = 2 x 54 KB of LDS
-#define PEN_CELLS (PEN_GRID_MAX * PEN_GRID_MAX * PEN_GRID_MAX)
+#define PEN_CELLS 16384         // hash buckets of the grid: histogram + cursors = 2 x 64 KB of LDS
 
 struct PenDev {
     int V, F, cap, n_parts;
@@ -163,16 +162,15 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
     float glo[3], ghi[3];
     for (int e = 0; e < 3; ++e) { glo[e] = block_min(lo[e], red); ghi[e] = block_max(hi[e], red); }
     const float mean_ext = block_sum_fixed(ext_sum, red) / (float)F;
-    // cell size: twice the mean extent, but no more than PEN_GRID_MAX cells per axis
-    float h = 2.f * mean_ext;
-    for (int e = 0; e < 3; ++e) h = fmaxf(h, (ghi[e] - glo[e]) / (float)(PEN_GRID_MAX - 1));
-    h = fmaxf(h, 1e-6f);
-    int nd[3];
-    for (int e = 0; e < 3; ++e) nd[e] = min(PEN_GRID_MAX, (int)((ghi[e] - glo[e]) / h) + 1);
-    const int ncell = nd[0] * nd[1] * nd[2];
+    // cell size: twice the mean triangle extent; cells are addressed by integer coordinates from
+    // the low corner of the frame's bounding box and hashed into PEN_CELLS buckets (a bucket that
+    // mixes cells only adds candidates the AABB test rejects)
+    const float h = fmaxf(2.f * mean_ext, 1e-6f);
     const float ih = 1.f / h;
-    auto cell_of = [&](float x, int e) { return min(nd[e] - 1, max(0, (int)((x - glo[e]) * ih))); };
-
+    const int ncell = PEN_CELLS;
+    auto cell_of = [&](float x, int e) { return max(0, (int)((x - glo[e]) * ih)); };
+    auto bucket = [](int x, int y, int z) { return (int)(((unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u) & (PEN_CELLS - 1)); };
+    (void)ghi;
     // ---- counting sort of (cell, triangle) entries
     for (int c = t; c <= ncell; c += PEN_T) cell_cnt[c] = 0;
     __syncthreads();
@@ -180,7 +178,7 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
         int c0[3], c1[3];
         for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = cell_of(aabb[f * 6 + 3 + e], e); }
         for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x)
-            atomicAdd(&cell_cnt[(z * nd[1] + y) * nd[0] + x], 1);
+            atomicAdd(&cell_cnt[bucket(x, y, z)], 1);
     }
     __syncthreads();
     // exclusive scan over the cells: each lane owns a contiguous slice
@@ -218,43 +216,69 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
         int c0[3], c1[3];
         for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = cell_of(aabb[f * 6 + 3 + e], e); }
         for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x)
-            ent[atomicAdd(&cursor[(z * nd[1] + y) * nd[0] + x], 1)] = f;
+            ent[atomicAdd(&cursor[bucket(x, y, z)], 1)] = f | (P.segm[f] << 24);     // triangle | part << 24
     }
     __threadfence_block();
     __syncthreads();
 
-    // ---- partners of every triangle
+    // ---- partners of every triangle: one WAVEFRONT per triangle, its 64 lanes stride through the
+    // entries of each cell the triangle touches (coalesced, no divergence between triangles with
+    // short and long candidate lists); survivors are appended with a ballot / prefix count
     int n_pairs = 0, n_over = 0;
-    for (int f = t; f < F; f += PEN_T) {
+    const int lane = t & 63, wv = t >> 6;
+    for (int f = wv; f < F; f += PEN_T / 64) {
         float a[6];
         for (int e = 0; e < 6; ++e) a[e] = aabb[f * 6 + e];
         const int fv0 = P.faces[f * 3], fv1 = P.faces[f * 3 + 1], fv2 = P.faces[f * 3 + 2];
-        const unsigned char* skip = P.skip + (size_t)P.segm[f] * P.n_parts;
+        // parts this triangle never collides with, as a bit mask (parts < 64): the first test of
+        // every candidate is one shift on a word that came with the entry itself
+        unsigned long long skipmask;
+        {
+            const unsigned char* skip = P.skip + (size_t)P.segm[f] * P.n_parts;
+            const unsigned long long m = __ballot(lane < P.n_parts && skip[lane < P.n_parts ? lane : 0] != 0);
+            skipmask = m;
+        }
         int c0[3], c1[3];
         for (int e = 0; e < 3; ++e) { c0[e] = cell_of(a[e], e); c1[e] = cell_of(a[3 + e], e); }
         int cnt = 0;
         int* mine = P.partners + ((size_t)b * F + f) * P.cap;
         for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x) {
-            const int c = (z * nd[1] + y) * nd[0] + x;
-            for (int q = cell_cnt[c]; q < cell_cnt[c + 1]; ++q) {
-                const int g = ent[q];
-                if (g == f || skip[P.segm[g]]) continue;
-                const float* ga = aabb + g * 6;
-                bool ov = true;
-                float il[3];
-                for (int e = 0; e < 3; ++e) { ov = ov && (a[e] <= ga[3 + e]) && (ga[e] <= a[3 + e]); il[e] = fmaxf(a[e], ga[e]); }
-                if (!ov) continue;
-                // the pair is owned by the cell that holds the low corner of the intersection box
-                if (cell_of(il[0], 0) != x || cell_of(il[1], 1) != y || cell_of(il[2], 2) != z) continue;
-                const int g0 = P.faces[g * 3], g1 = P.faces[g * 3 + 1], g2 = P.faces[g * 3 + 2];
-                if (g0 == fv0 || g0 == fv1 || g0 == fv2 || g1 == fv0 || g1 == fv1 || g1 == fv2 ||
-                    g2 == fv0 || g2 == fv1 || g2 == fv2) continue;
-                if (cnt < P.cap) mine[cnt] = g; else ++n_over;
-                ++cnt;
+            const int c = bucket(x, y, z);
+            const int q1 = cell_cnt[c + 1];
+            for (int q0 = cell_cnt[c]; q0 < q1; q0 += 64) {
+                const int q = q0 + lane;
+                bool pass = false;
+                int g = 0;
+                if (q < q1) {
+                    const int en = ent[q];
+                    g = en & 0xffffff;
+                    pass = g != f && !((skipmask >> (en >> 24)) & 1ull);
+                    if (pass) {
+                        const float* ga = aabb + g * 6;
+                        float il[3];
+                        for (int e = 0; e < 3; ++e) { pass = pass && (a[e] <= ga[3 + e]) && (ga[e] <= a[3 + e]); il[e] = fmaxf(a[e], ga[e]); }
+                        // the pair is owned by the cell that holds the low corner of the intersection box
+                        pass = pass && cell_of(il[0], 0) == x && cell_of(il[1], 1) == y && cell_of(il[2], 2) == z;
+                        if (pass) {
+                            const int g0 = P.faces[g * 3], g1 = P.faces[g * 3 + 1], g2 = P.faces[g * 3 + 2];
+                            pass = !(g0 == fv0 || g0 == fv1 || g0 == fv2 || g1 == fv0 || g1 == fv1 || g1 == fv2 ||
+                                     g2 == fv0 || g2 == fv1 || g2 == fv2);
+                        }
+                    }
+                }
+                const unsigned long long m = __ballot(pass);
+                if (m) {
+                    const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pass && pos < P.cap) mine[pos] = g;
+                    cnt += __popcll(m);
+                }
             }
         }
-        P.pcount[(size_t)b * F + f] = min(cnt, P.cap);
-        n_pairs += min(cnt, P.cap);
+        if (lane == 0) {
+            P.pcount[(size_t)b * F + f] = min(cnt, P.cap);
+            n_pairs += min(cnt, P.cap);
+            n_over += max(cnt - P.cap, 0);
+        }
     }
     const float tp = block_sum_fixed((float)n_pairs, red), to = block_sum_fixed((float)n_over, red);
     if (t == 0) { st[0] = (int)tp; st[1] = (int)to; }
@@ -364,6 +388,8 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     std::vector<int> fv(faces, faces + (size_t)F * 3), sg(F, 0);
     int np = 1;
     if (segm) { for (int f = 0; f < F; ++f) { sg[f] = segm[f]; np = std::max(np, segm[f] + 1); } }
+    if (np > 64 || F >= (1 << 24)) { sfx_set_error("at most 64 parts and 2^24 faces"); delete h; return -1; }
+    for (int f = 0; f < F; ++f) if (sg[f] < 0) { sfx_set_error("negative part label"); delete h; return -1; }
     // part-level table: same part, parent / child, or listed in ign_part_pairs (fit_single_frame.py:318-328)
     std::vector<unsigned char> skip((size_t)np * np, 0);
     if (segm) {
@@ -386,7 +412,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     { std::vector<int> cur(vs.begin(), vs.end() - 1); for (size_t i = 0; i < fv.size(); ++i) vl[cur[fv[i]]++] = (int)i; }
     P.faces = h->up(fv); P.segm = h->up(sg); P.skip = h->up(skip); P.vf_start = h->up(vs); P.vf_list = h->up(vl);
     const size_t B = max_batch;
-    P.ent_cap = F * 16;
+    P.ent_cap = F * 32;
     P.aabb = h->zeros<float>(B * F * 6); P.entries = h->zeros<int>(B * P.ent_cap);
     P.partners = h->zeros<int>(B * F * P.cap); P.pcount = h->zeros<int>(B * F);
     P.tloss = h->zeros<float>(B * F); P.tgrad = h->zeros<float>(B * F * 9); P.stats = h->zeros<int>(B * 4);
