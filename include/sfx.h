@@ -67,6 +67,12 @@ int  sfx_model_set_vposer(sfx_model* m, int32_t latent, int32_t hidden,
  * Replaces body_model(return_verts=True, body_pose=..., return_full_pose=True)
  * (fitting.py:82,248; fit_single_frame.py:611).  All pointers are DEVICE pointers to
  * contiguous fp32; any output may be NULL.  `hands` are PCA coefficients [B][num_pca]. */
+/* Per-face part labels of smplx_parts_segm.pkl and the part pairs that never collide
+ * (fit_single_frame.py:316-328): used by batches created with interpenetration = 1.  segm /
+ * parents [F]; ign_pairs [n_ign][2].  Without this call no pair is filtered by part.           */
+int  sfx_model_set_parts(sfx_model* m, const int32_t* segm, const int32_t* parents, const int32_t* ign_pairs,
+                         int32_t n_ign);
+
 int  sfx_lbs_forward(sfx_model* m, int32_t B,
                      const float* global_orient_dev,   /* [B][3]  */
                      const float* body_pose_dev,       /* [B][63] */
@@ -88,7 +94,7 @@ typedef struct sfx_stage_weights {      /* one entry of opt_weights (fit_single_
     float hand_prior_weight, expr_prior_weight;
     float jaw_prior_weight[3];
     float hand_joint_weight, face_joint_weight;   /* joint_weights slices (:569-572)    */
-    float coll_loss_weight;                       /* carried; interpenetration not built */
+    float coll_loss_weight;                       /* coll_loss_weights[stage]; used when interpenetration = 1 */
     float bending_prior_weight;                   /* < 0: derive 3.17 * body_pose_weight (:567-568) */
 } sfx_stage_weights;
 
@@ -115,6 +121,11 @@ typedef struct sfx_batch_cfg {
                                        lower final loss kept (fit_single_frame.py:461-463,
                                        527-551,662-667); needs a fit over stages -1..n-1     */
     int32_t left_shoulder_idx, right_shoulder_idx;
+    int32_t interpenetration;       /* 1: penetration term in the stages with coll_loss_weight > 0
+                                       (fitting.py:437-455); needs lbs_mode 1 (all vertices)      */
+    int32_t max_collisions;         /* partners kept per triangle (cfg: 8 / 128)                   */
+    float   df_cone_height;         /* sigma of the cone distance field (cfg: 0.5 / 1e-4)          */
+    int32_t penalize_outside;
 } sfx_batch_cfg;
 
 int  sfx_batch_create(sfx_model* m, const sfx_batch_cfg* cfg,
@@ -180,6 +191,10 @@ int  sfx_batch_step(sfx_batch* b, int32_t stage, int32_t resume, float* loss_out
  * (HOST): what `var.grad` holds after optimizer.step() in the reference, which run_fitting's
  * gtol test reads (fitting.py:191-193).                                                       */
 int  sfx_batch_get_grad(sfx_batch* b, int32_t stage, float* grad_out);
+
+/* Interpenetration diagnostics of the most recent evaluation (batches with interpenetration = 1),
+ * per active GEMM column: stats as sfx_pen_stats; ext_n = vertices that carried a gradient.    */
+int  sfx_batch_pen_stats(sfx_batch* b, int32_t* stats_host /* [B][4] */, int32_t* ext_n_host /* [B] or NULL */);
 
 /* Per-frame results of the last sfx_batch_fit (HOST pointers, any may be NULL):
  *  stage_loss [B][1+n_stages]  value run_fitting returns per stage (camera first)

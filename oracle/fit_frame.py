@@ -176,8 +176,31 @@ class FrameFit(object):
                                     joints_conf=self.conf,
                                     use_conf=bool(self.cfg.get("use_conf_for_camera_init")))
 
+    def set_penetration(self, faces, segm=None, parents=None, ign_part_pairs=None):
+        """Switch the interpenetration term on (fitting.py:437-455; oracle/penetration.py)."""
+        self.pen = dict(faces=np.asarray(faces).astype(np.int64), segm=segm, parents=parents, ign=ign_part_pairs)
+
+    def penetration_term(self, vertices, w):
+        from . import penetration as P
+        cw = float(w.get("coll_loss_weight", 0.0) or 0.0)
+        if getattr(self, "pen", None) is None or cw <= 0:
+            return None
+        v = vertices[0]
+        pairs = P.candidate_pairs(v.detach().numpy(), self.pen["faces"], self.pen["segm"], self.pen["parents"], self.pen["ign"])
+        return cw * P.penetration_loss(v, self.pen["faces"], pairs, float(self.cfg.get("df_cone_height", 0.5)),
+                                       bool(self.cfg.get("penalize_outside", True)))
+
     def body_terms(self, stage, w, jw):
         out = self.bm(return_verts=True, body_pose=self._body_pose(), return_full_pose=True)
+        terms = self._body_terms_nopen(out, stage, w, jw)
+        pen = self.penetration_term(out.vertices, w)
+        if pen is not None:
+            terms = dict(terms)
+            terms["penetration"] = pen
+            terms["total"] = terms["total"] + pen
+        return terms
+
+    def _body_terms_nopen(self, out, stage, w, jw):
         return obj.smplify_terms(out, self._project(out.joints), self.gt, self.conf, jw, w,
                                  self.pose_embedding, use_vposer=self.use_vposer,
                                  regression_pose=self.regression_pose, stage=stage,

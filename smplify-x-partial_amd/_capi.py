@@ -51,6 +51,8 @@ class BatchCfg(C.Structure):
         ("lr", C.c_float), ("rho", C.c_float), ("depth_loss_weight", C.c_float),
         ("lbs_mode", C.c_int32), ("reuse_entry_eval", C.c_int32),
         ("side_view_thsh", C.c_float), ("left_shoulder_idx", C.c_int32), ("right_shoulder_idx", C.c_int32),
+        ("interpenetration", C.c_int32), ("max_collisions", C.c_int32), ("df_cone_height", C.c_float),
+        ("penalize_outside", C.c_int32),
     ]
 
 
@@ -58,6 +60,7 @@ class BatchCfg(C.Structure):
 SYMBOLS = {
     "sfx_model_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_void_p)]),
     "sfx_model_destroy": (None, [C.c_void_p]),
+    "sfx_model_set_parts": (C.c_int, [C.c_void_p, i32p, i32p, i32p, C.c_int32]),
     "sfx_model_set_vposer": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32] + [f32p] * 6),
     "sfx_lbs_forward": (C.c_int, [C.c_void_p, C.c_int32] + [C.c_void_p] * 12 + [C.c_void_p]),
     "sfx_batch_create": (C.c_int, [C.c_void_p, C.POINTER(BatchCfg), C.POINTER(StageWeights), C.POINTER(C.c_void_p)]),
@@ -71,6 +74,7 @@ SYMBOLS = {
     "sfx_batch_fit": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sfx_fit_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32]),
     "sfx_batch_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, C.c_void_p]),
+    "sfx_batch_pen_stats": (C.c_int, [C.c_void_p, i32p, i32p]),
     "sfx_batch_get_grad": (C.c_int, [C.c_void_p, C.c_int32, f32p]),
     "sfx_batch_get_stats": (C.c_int, [C.c_void_p, f32p, i32p, i32p]),
     "sfx_batch_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

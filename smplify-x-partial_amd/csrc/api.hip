@@ -106,9 +106,19 @@ struct DevAlloc {
     void free_all() { for (void* p : ptrs) hipFree(p); ptrs.clear(); }
 };
 
+struct sfx_pen;
+extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const int32_t* segm, const int32_t* parents,
+                              const int32_t* ign_pairs, int32_t n_ign, int32_t max_collisions, int32_t max_batch,
+                              sfx_pen** out);
+extern "C" void sfx_pen_destroy(sfx_pen* h);
+extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
+                            float* loss_dev, float* dverts_dev, void* stream);
+extern "C" int sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host);
+
 struct sfx_model {
     DevModel M{};
     DevAlloc mem;
+    std::vector<int> faces_host, segm_host, parents_host, ign_host;   // interpenetration set-up
     int NB = 0, NE = 0, NPCA = 0;
     std::vector<int> meta_host = std::vector<int>(SFX_META_N, 0);
     sfx_batch* fwd = nullptr;     // lazily created batch behind sfx_lbs_forward
@@ -125,6 +135,8 @@ struct sfx_batch {
     int* stage_host = nullptr;    // pinned
     std::vector<int> slot_host;
     int K = 0;
+    sfx_pen* pen = nullptr;       // interpenetration operator (cfg.interpenetration)
+    float pen_sigma = 0.f; int pen_outside = 1;
 };
 
 extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
@@ -288,6 +300,7 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
     {
         std::vector<int> faces(d->faces, d->faces + (size_t)d->F * 3);
         M.faces = m->mem.up(faces);
+        m->faces_host = faces;
         std::vector<int> df; std::vector<float> db;
         if (d->n_dyn > 0) {
             df.assign(d->dyn_lmk_faces_idx, d->dyn_lmk_faces_idx + (size_t)d->n_dyn_rows * d->n_dyn);
@@ -383,6 +396,17 @@ extern "C" void sfx_model_destroy(sfx_model* m) {
     delete m;
 }
 
+extern "C" int sfx_model_set_parts(sfx_model* m, const int32_t* segm, const int32_t* parents, const int32_t* ign_pairs,
+                                   int32_t n_ign) {
+    if (!m || !segm || !parents) { sfx_set_error("null argument"); return -1; }
+    const size_t F = m->faces_host.size() / 3;
+    m->segm_host.assign(segm, segm + F);
+    m->parents_host.assign(parents, parents + F);
+    m->ign_host.clear();
+    if (ign_pairs && n_ign > 0) m->ign_host.assign(ign_pairs, ign_pairs + (size_t)2 * n_ign);
+    return 0;
+}
+
 extern "C" int sfx_model_set_vposer(sfx_model* m, int32_t latent, int32_t hidden, const float* w1, const float* b1,
                                     const float* w2, const float* b2, const float* w3, const float* b3) {
     if (!m) { sfx_set_error("null model"); return -1; }
@@ -435,6 +459,10 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.cfg.lr = c->lr; D.cfg.rho = c->rho; D.cfg.depth_w = c->depth_loss_weight; D.cfg.lbs_mode = c->lbs_mode;
     D.cfg.reuse = c->reuse_entry_eval;
     D.cfg.side_thsh = c->side_view_thsh; D.cfg.lsh = c->left_shoulder_idx; D.cfg.rsh = c->right_shoulder_idx;
+    D.cfg.pen = c->interpenetration ? 1 : 0;
+    if (D.cfg.pen && c->lbs_mode != 1) {
+        sfx_set_error("interpenetration needs lbs_mode = 1 (the term reads every vertex)"); delete b; return -1; }
+    if (D.cfg.pen && !(c->df_cone_height > 0.f)) { sfx_set_error("df_cone_height must be positive"); delete b; return -1; }
     if (c->side_view_thsh > 0.f && (c->left_shoulder_idx < 0 || c->left_shoulder_idx >= K || c->right_shoulder_idx < 0 || c->right_shoulder_idx >= K)) {
         sfx_set_error("shoulder indices out of range"); delete b; return -1; }
     build_layout(D.L, m->NB, m->NE, m->NPCA, c->use_vposer, m->M.vp_latent);
@@ -460,6 +488,7 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
         w.hpw = st[i].hand_prior_weight; w.epw = st[i].expr_prior_weight;
         for (int q = 0; q < 3; ++q) w.jaw[q] = st[i].jaw_prior_weight[q];
         w.hand_jw = st[i].hand_joint_weight; w.face_jw = st[i].face_joint_weight;
+        w.coll = D.cfg.pen ? st[i].coll_loss_weight : 0.f;
     }
     b->sw_dev = b->mem.up(sws);
     D.Bpad = ((B + 127) / 128) * 128;
@@ -479,6 +508,19 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.AT = b->mem.zeros<float>((size_t)12 * SFX_JPAD * D.Bpad);
     D.verts = b->mem.zeros<float>((size_t)B * m->M.V * 3);
     D.fwd = b->mem.zeros<float>((size_t)B * SFX_FWD_N);
+    if (D.cfg.pen) {
+        const int F = (int)(m->faces_host.size() / 3);
+        const bool parts = !m->segm_host.empty();
+        int rc = sfx_pen_create(m->M.V, F, m->faces_host.data(), parts ? m->segm_host.data() : nullptr,
+                                parts ? m->parents_host.data() : nullptr, m->ign_host.empty() ? nullptr : m->ign_host.data(),
+                                (int)(m->ign_host.size() / 2), std::max(1, c->max_collisions), B, &b->pen);
+        if (rc) { b->mem.free_all(); delete b; return rc; }
+        b->pen_sigma = c->df_cone_height; b->pen_outside = c->penalize_outside ? 1 : 0;
+        D.pen_loss = b->mem.zeros<float>(B);
+        D.pen_dverts = b->mem.zeros<float>((size_t)B * m->M.V * 3);
+        D.ext_n = b->mem.zeros<int>(B);
+        D.ext_vid = b->mem.zeros<int>((size_t)B * SFX_EXT_CAP);
+    }
     D.joints = b->mem.zeros<float>((size_t)B * K * 3);
     D.fullpose = b->mem.zeros<float>((size_t)B * SFX_POSE);
     D.stage = b->mem.zeros<int>(B);
@@ -503,6 +545,7 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
 
 extern "C" void sfx_batch_destroy(sfx_batch* b) {
     if (!b) return;
+    if (b->pen) sfx_pen_destroy(b->pen);
     b->mem.free_all();
     if (b->stage_host) hipHostFree(b->stage_host);
     delete b;
@@ -628,6 +671,45 @@ extern "C" int sfx_batch_num_vars(sfx_batch* b, int32_t stage) {
 }
 
 // one closure evaluation of every (active) frame; stage_override = -2 -> per-frame stage[]
+// vertices with a nonzero penetration gradient, ascending ids, per GEMM column (slot)
+__global__ __launch_bounds__(256)
+void k_pen_compact(BatchDev D, int V) {
+    __shared__ int s_base;
+    __shared__ int s_cnt[4];
+    const int slot = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const float* g = D.pen_dverts + (size_t)slot * V * 3;
+    int* out = D.ext_vid + (size_t)slot * SFX_EXT_CAP;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int v0 = 0; v0 < V; v0 += 256) {
+        const int v = v0 + t;
+        const bool nz = v < V && (g[v * 3] != 0.f || g[v * 3 + 1] != 0.f || g[v * 3 + 2] != 0.f);
+        const unsigned long long m = __ballot(nz);
+        if (lane == 0) s_cnt[wv] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wv; ++w) off += s_cnt[w];
+        const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+        if (nz && pos < SFX_EXT_CAP) out[pos] = v;
+        __syncthreads();
+        if (t == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+    if (t == 0) D.ext_n[slot] = min(s_base, SFX_EXT_CAP);
+}
+
+// penetration term of the pending evaluation of every active frame (after the dense LBS wrote the
+// vertices, before the loss / adjoint pass reads pen_loss, pen_dverts and the vertex lists)
+static int eval_penetration(sfx_batch* b, hipStream_t s) {
+    const BatchDev& D = b->D;
+    if (!b->pen || D.nact <= 0) return 0;
+    ProfScope p("penetration", s, D.nact);
+    int rc = sfx_pen_eval(b->pen, D.nact, D.verts, b->pen_sigma, b->pen_outside, D.pen_loss, D.pen_dverts, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pen_compact, dim3(D.nact), dim3(256), 0, s, D, b->m->M.V);
+    return 0;
+}
+
 static void eval_closure(sfx_batch* b, int stage_override, int from_X, hipStream_t s) {
     const DevModel& M = b->m->M; const BatchDev& D = b->D;
     ClosureArgs a{};
@@ -638,6 +720,7 @@ static void eval_closure(sfx_batch* b, int stage_override, int from_X, hipStream
         ClosureArgs e = a; e.export_dense = 1; e.forward_only = 2;
         { ProfScope p("export", s); launch_closure(M, D, b->vl_dev, b->sw_dev, e, s); }
         { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
+        eval_penetration(b, s);
         a.use_dense_verts = 1;
     }
     ProfScope p("closure", s);
@@ -720,6 +803,7 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
         } else if (fused) {
             for (int q = 0; q < 8; ++q, ++tick) {
                 { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
+                if (int rc = eval_penetration(b, s)) return rc;
                 ProfScope p("tick", s);
                 launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 1, s);
             }
@@ -820,6 +904,7 @@ extern "C" int sfx_fit_multi(sfx_batch** bs, int32_t n, int32_t first_stage, int
                 sfx_batch* b = bs[g];
                 if (prev >= 0 && prev != g) hipStreamWaitEvent(st[g], ev[prev], 0);   // GEMMs back to back
                 { ProfScope p("lbs_dense", st[g], b->D.nact); launch_lbs_dense(b->m->M, b->D, st[g]); }
+                if (int rc = eval_penetration(b, st[g])) return rc;
                 hipEventRecord(ev[g], st[g]);
                 prev = g;
                 ProfScope p("tick", st[g]);
@@ -877,6 +962,16 @@ extern "C" int sfx_batch_step(sfx_batch* b, int32_t stage, int32_t resume, float
         SFX_CHECK(hipMemcpy(l.data(), b->D.stage_loss, l.size() * 4, hipMemcpyDeviceToHost));
         for (int i = 0; i < B; ++i) loss_out[i] = l[(size_t)i * (1 + SFX_MAX_STAGES) + stage + 1];
     }
+    return 0;
+}
+
+extern "C" int sfx_batch_pen_stats(sfx_batch* b, int32_t* stats_host /* [B][4] */, int32_t* ext_n_host /* [B] or NULL */) {
+    if (!b || !stats_host) { sfx_set_error("null argument"); return -1; }
+    if (!b->pen) { sfx_set_error("batch was created without interpenetration"); return -1; }
+    const int n = std::max(1, b->D.nact);
+    int rc = sfx_pen_stats(b->pen, n, stats_host);
+    if (rc) return rc;
+    if (ext_n_host) SFX_CHECK(hipMemcpy(ext_n_host, b->D.ext_n, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -398,6 +398,9 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         }
     }
     __syncthreads();
+    // v_posed rows and skinning transforms of `ni` vertices listed in S.ivid (the model's items, or a
+    // chunk of vertices that carry a penetration gradient)
+    auto items_forward = [&](const int ni) {
     // v_posed rows: one wavefront per (item, coord) dot product of length KD_PAD
     {
         const float4* f4 = reinterpret_cast<const float4*>(S.feat);
@@ -407,7 +410,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         // in step: every CU of an XCD then asks one L2 channel for one 2-KiB row at the same moment.
         // Each workgroup therefore starts at its own rotation of the row list; the rows are
         // independent dot products, so the result is bit-identical.
-        const int nrow = NI * 3;
+        const int nrow = ni * 3;
         const int rot = (int)((blockIdx.x * 40u) % (unsigned)nrow);
         for (int w0 = wv * RIF; w0 < nrow; w0 += (CT / 64) * RIF) {
             float4 da[RIF], db[RIF]; int wr[RIF];
@@ -430,17 +433,16 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
             }
         }
     }
-    MARK(6);
     // skinning transforms of the items
     // (sparse rows of lbs_weights: <= SFX_NW nonzeros per vertex, ascending joint order, so the
     //  sum visits the same nonzero terms in the same order as the dense product)
-    for (int w = t; w < NI * SFX_NW; w += CT) {
+    for (int w = t; w < ni * SFX_NW; w += CT) {
         const int i = w / SFX_NW, q2 = w % SFX_NW;
         S.wj[w] = M.Wsp_j[(size_t)S.ivid[i] * SFX_NW + q2];
         S.ww[w] = M.Wsp_w[(size_t)S.ivid[i] * SFX_NW + q2];
     }
     __syncthreads();
-    for (int w = t; w < NI * 12; w += CT) {
+    for (int w = t; w < ni * 12; w += CT) {
         const int i = w / 12, e = w % 12;
         float acc = 0.f;
         if (S.wj[i * SFX_NW] >= 0) {
@@ -456,6 +458,9 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         S.T[w] = acc;
     }
     __syncthreads();
+    };
+    items_forward(NI);
+    MARK(6);
     for (int w = t; w < NI * 3; w += CT) {
         const int i = w / 3, r = w % 3;
         const float* Ti = &S.T[i * 12 + r * 4];
@@ -611,6 +616,9 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         total = q[Q_L] * dw2 + q[Q_PP] * bpw2 + q[Q_SH] * sw2 + q[Q_ANG] * sw.bend;
         if (C.use_face) total = total + q[Q_JW] + q[Q_EX] * e2;
         if (C.use_hands) total = total + q[Q_LH] * h2 + q[Q_RH] * h2;
+        // interpenetration (fitting.py:437-455): evaluated on all vertices by csrc/collide.hip right
+        // after the dense LBS; its vertex gradient enters the reverse sweep below
+        if (C.pen && args.use_dense_verts && sw.coll > 0.f) total = total + sw.coll * D.pen_loss[D.slot[b]];
         if (t < 3) S.gc[L.cam_t + t] = (t == 0) ? q[Q_D0] : (t == 1) ? q[Q_D1] : q[Q_D2];
     }
     __syncthreads();
@@ -623,12 +631,15 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         S.dvert[w] = S.dj[S.meta[MO_IK + i] * 3 + r] * S.iw[i];
     }
     __syncthreads();
-    for (int w = t; w < NI * 3; w += CT) {
-        const int i = w / 3, c = w % 3;
-        S.dvp[w] = S.T[i * 12 + 0 + c] * S.dvert[i * 3] + S.T[i * 12 + 4 + c] * S.dvert[i * 3 + 1] +
-                   S.T[i * 12 + 8 + c] * S.dvert[i * 3 + 2];
-    }
-    __syncthreads();
+    auto items_dvp = [&](const int ni) {          // d v_posed = T^T d vertex
+        for (int w = t; w < ni * 3; w += CT) {
+            const int i = w / 3, c = w % 3;
+            S.dvp[w] = S.T[i * 12 + 0 + c] * S.dvert[i * 3] + S.T[i * 12 + 4 + c] * S.dvert[i * 3 + 1] +
+                       S.T[i * 12 + 8 + c] * S.dvert[i * 3 + 2];
+        }
+        __syncthreads();
+    };
+    items_dvp(NI);
     MARK(10);
     // dA[j][e] = sum_items W[v][j] * dT[e]: per-joint item lists (CSR built at model creation,
     // one per dynamic-contour LUT row), visited in ascending item order -> deterministic
@@ -649,17 +660,18 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         S.dA[w] = acc;
     }
     MARK(11);
+    auto items_dfeat = [&](const int ni, const bool accumulate) {
     // dfeat[k] = sum_items sum_c dirsT[v][c][k] * dvp[c]: each wavefront streams whole 2-KiB rows
     // (RIF in flight), lane l keeps k = 4l..4l+3 and 256+4l..+3; the 4 per-wave partials are added
     // in wave order (fixed association -> deterministic)
     {
         float4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
-        for (int w0 = wv * RIF; w0 < NI * 3; w0 += (CT / 64) * RIF) {
+        for (int w0 = wv * RIF; w0 < ni * 3; w0 += (CT / 64) * RIF) {
             float4 da[RIF], db[RIF]; float dv[RIF];
 #pragma unroll
             for (int u = 0; u < RIF; ++u) {
-                const int w = (w0 + u < NI * 3) ? w0 + u : w0;
-                dv[u] = (w0 + u < NI * 3) ? S.dvp[w] : 0.f;
+                const int w = (w0 + u < ni * 3) ? w0 + u : w0;
+                dv[u] = (w0 + u < ni * 3) ? S.dvp[w] : 0.f;
                 const float4* row = reinterpret_cast<const float4*>(M.dirsT + ((size_t)S.ivid[w / 3] * 3 + w % 3) * SFX_KD_PAD);
                 if (dv[u] != 0.f) { da[u] = row[lane]; db[u] = row[64 + lane]; }
                 else { da[u] = pa; db[u] = pa; dv[u] = 0.f; }
@@ -676,10 +688,47 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         for (int k = t; k < SFX_KD_PAD; k += CT) {
             const int l4 = (k & 255) >> 2, hi = k >> 8, c = k & 3;
             const float* pf = S.T + (hi * 64 + l4) * 4 + c;
-            S.dfeat[k] = ((pf[0] + pf[512]) + pf[1024]) + pf[1536];
+            const float sum4 = ((pf[0] + pf[512]) + pf[1024]) + pf[1536];
+            S.dfeat[k] = accumulate ? S.dfeat[k] + sum4 : sum4;
         }
     }
     __syncthreads();
+    };
+    items_dfeat(NI, false);
+    // ---- interpenetration: every vertex with a nonzero penetration gradient is treated like an item
+    // (v_posed rows, skinning transform, then d v_posed -> dfeat and dT -> dA), a chunk at a time
+    if (C.pen && args.use_dense_verts && !cam_stage && sw.coll > 0.f) {
+        const int slot = D.slot[b];
+        const int nx = D.ext_n[slot];
+        const int* xv = D.ext_vid + (size_t)slot * SFX_EXT_CAP;
+        const float* xg = D.pen_dverts + (size_t)slot * M.V * 3;
+        constexpr int CH = LDS::kMaxItems;
+        for (int c0 = 0; c0 < nx; c0 += CH) {
+            const int ni = min(CH, nx - c0);
+            for (int w = t; w < ni; w += CT) S.ivid[w] = xv[c0 + w];
+            __syncthreads();
+            for (int w = t; w < ni * 3; w += CT) S.dvert[w] = sw.coll * xg[(size_t)S.ivid[w / 3] * 3 + w % 3];
+            items_forward(ni);
+            items_dvp(ni);
+            FOR_CT(w, SFX_J * 12) {          // dA[j][e] += sum_i W[v_i][j] * dvert_i[r] * [v_posed_i, 1][c]
+                const int j = w / 12, e = w % 12, r = e >> 2, c = e & 3;
+                float acc = 0.f;
+                for (int i = 0; i < ni; ++i) {
+                    const float dv = S.dvert[i * 3 + r];
+                    if (dv == 0.f) continue;
+                    float wgt = 0.f;
+                    if (S.wj[i * SFX_NW] >= 0) {
+#pragma unroll
+                        for (int q2 = 0; q2 < SFX_NW; ++q2) if (S.wj[i * SFX_NW + q2] == j) wgt += S.ww[i * SFX_NW + q2];
+                    } else wgt = M.W[(size_t)S.ivid[i] * SFX_J + j];
+                    if (wgt != 0.f) acc += wgt * (dv * (c < 3 ? S.vp[i * 3 + c] : 1.f));
+                }
+                S.dA[w] += acc;
+            }
+            __syncthreads();
+            items_dfeat(ni, true);
+        }
+    }
     MARK(12);
     // adjoint of the kinematic chain without walking it level by level:
     //   dG_j = sum over the subtree of j of  loc_d . Gh_d^T . Gh_j^-T        (Gh = 4x4 homogeneous G)

@@ -8,6 +8,7 @@
 #define SFX_NHAND 45
 #define SFX_MAX_K 144       // mapped joints
 #define SFX_MAX_ITEMS 240   // vertex items (21 + 68*3 = 225)
+#define SFX_EXT_CAP 8192    // vertices per frame that may carry a penetration gradient
 #define SFX_SMALL_ITEMS 32  // item capacity of the small closure variant (body-only: 11 items)
 #ifndef SFX_SMALL_OCC
 #define SFX_SMALL_OCC 1      // workgroups per CU the register budget of the small fused kernels is sized for
@@ -56,7 +57,7 @@ struct VarList {
 };
 
 struct StageW {       // per body stage
-    float bpw, sw, bend, hpw, epw, jaw[3], hand_jw, face_jw;
+    float bpw, sw, bend, hpw, epw, jaw[3], hand_jw, face_jw, coll;
 };
 
 struct DevModel {
@@ -121,6 +122,7 @@ struct BatchCfgDev {
     float lr, rho, depth_w;
     int lbs_mode, reuse;
     float side_thsh; int lsh, rsh;     // side-view test: 2-D shoulder distance threshold, indices
+    int pen;                           // interpenetration term enabled (dense mode)
 };
 
 // Per-frame data pointers (all device).
@@ -162,6 +164,10 @@ struct BatchDev {
     float* stage_loss2;// [B][1+MAX_STAGES] second-orientation stage losses
     int*   try_both;   // [B]
     int*   orient_pass;// [B] 0 first fit, 1 second fit running, 2 done
+    float* pen_loss;        // [B] (slot-indexed) unweighted penetration loss of the pending evaluation
+    float* pen_dverts;      // [B][V][3] (slot-indexed) its gradient with respect to the vertices
+    int*   ext_n;           // [B] (slot-indexed) vertices with a nonzero penetration gradient ...
+    int*   ext_vid;         // [B][SFX_EXT_CAP] ... and their ids, ascending
     float* fwd;             // [B][SFX_FWD_N] forward state handed from the export pass to the adjoint pass
     long long* dbg;         // [64] phase timestamps of block 0 (NULL = off)
 };
@@ -186,7 +192,7 @@ struct ClosureArgs {
 // the 47-KB closure variant serves models whose keypoints need at most SFX_SMALL_ITEMS vertex rows
 // when the VPoser decoder is not in the loop
 static inline bool sfx_small_closure(const DevModel& M, const BatchDev& D) {
-    return M.n_items <= SFX_SMALL_ITEMS && !D.cfg.use_vposer;
+    return M.n_items <= SFX_SMALL_ITEMS && !D.cfg.use_vposer && !D.cfg.pen;
 }
 void launch_closure(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
                     const ClosureArgs& a, hipStream_t s);

@@ -127,6 +127,21 @@ class DeviceModel(object):
         if vposer is not None:
             self.set_vposer(vposer)
 
+    def set_parts(self, segm, parents, ign_part_pairs=None):
+        """Per-face part labels (smplx_parts_segm.pkl: 'segm', 'parents') and the cfg's
+        ign_part_pairs (["9,16", ...]) for batches created with interpenetration=True
+        (fit_single_frame.py:316-328)."""
+        sg, pr = capi.i32(np.asarray(segm).astype(np.int64)), capi.i32(np.asarray(parents).astype(np.int64))
+        assert sg.shape == (self.F,) and pr.shape == (self.F,), "one label per face"
+        pairs = []
+        for p in ign_part_pairs or []:
+            a, b = (int(x) for x in str(p).split(",")) if isinstance(p, str) else p
+            pairs.append((a, b))
+        ign = capi.i32(np.asarray(pairs, np.int64).reshape(-1, 2))
+        capi.check(self._lib.sfx_model_set_parts(self._h, capi.iptr(sg), capi.iptr(pr),
+                                                 capi.iptr(ign) if pairs else None, len(pairs)))
+        self.has_parts = True
+
     def set_vposer(self, w):
         a = {k: capi.f32(v) for k, v in w.items()}
         latent, hidden = a["fc1_w"].shape[1], a["fc1_w"].shape[0]
@@ -198,6 +213,13 @@ class FrameBatch(object):
         c.side_view_thsh = float(cfg.get("side_view_thsh", 0.0) or 0.0) if side_view else 0.0
         c.left_shoulder_idx = int(cfg.get("left_shoulder_idx", 2))
         c.right_shoulder_idx = int(cfg.get("right_shoulder_idx", 5))
+        # interpenetration term (fitting.py:437-455): dense mode only, part labels from DeviceModel.set_parts
+        c.interpenetration = int(bool(cfg.get("interpenetration", False)))
+        c.max_collisions = int(cfg.get("max_collisions", 8))
+        c.df_cone_height = float(cfg.get("df_cone_height", 0.5))
+        c.penalize_outside = int(bool(cfg.get("penalize_outside", True)))
+        if c.interpenetration and lbs_mode != "dense":
+            raise ValueError("interpenetration=True needs lbs_mode='dense' (the term reads every vertex)")
         self.use_vposer = bool(c.use_vposer)
         self.nemb = model.vposer_latent if self.use_vposer else 63
         arr = (capi.StageWeights * max(1, self.n_stages))(*stages)
@@ -273,6 +295,14 @@ class FrameBatch(object):
         loss = np.zeros(self.B, np.float32)
         capi.check(self._lib.sfx_batch_step(self._h, stage, int(bool(resume)), capi.fptr(loss), None))
         return loss
+
+    def penetration_stats(self):
+        """Diagnostics of the interpenetration term of the most recent evaluation (per frame):
+        ordered pairs kept, partners dropped by max_collisions, grid overflow, vertices with gradient."""
+        st = np.zeros((self.B, 4), np.int32)
+        ext = np.zeros(self.B, np.int32)
+        capi.check(self._lib.sfx_batch_pen_stats(self._h, capi.iptr(st), capi.iptr(ext)))
+        return dict(pairs=st[:, 0].copy(), dropped=st[:, 1].copy(), entry_overflow=st[:, 2].copy(), vertices=ext)
 
     def last_grad(self, stage):
         """Gradient [B,N] of the most recent closure evaluation (what var.grad holds after step())."""
