@@ -1,7 +1,8 @@
 """Drop-in for smplifyx/fit_single_frame.py:59-677 -- same signature, same result pickle
 (keys and order of :644-657, protocol 2), same optional vertices.ply -- with the whole
 optimisation executed by the MI355X engine (driver.fit_frames with a batch of one).
-Not reproduced: visualisation (`visualize=True`), interpenetration (BVH term).
+Not reproduced: visualisation (`visualize=True`).  `interpenetration=True` runs the penetration
+term of csrc/collide.hip in the stages with coll_loss_weight > 0 (always through the dense path).
 `vposer.encode(prior).sample()` (:245, random in the reference) uses the posterior mean unless
 `vposer_sample_seed` is given.  kwargs['lbs_mode'] = 'dense' evaluates all 10475 vertices in
 every closure call as the reference does; the default 'rows' evaluates the rows the loss reads
@@ -26,6 +27,17 @@ def _write_ply(path, vertices):
         fh.write(v.tobytes())
 
 
+def setup_interpenetration(dm, part_segm_fn, ign_part_pairs):
+    """fit_single_frame.py:316-328: per-face part labels from `part_segm_fn` (pickle with 'segm' and
+    'parents') and the ignored part pairs -> the device model.  Without a file no pair is filtered
+    by part, as in the reference (filter_faces = None)."""
+    if getattr(dm, "has_parts", False) or not part_segm_fn:
+        return
+    with open(os.path.expandvars(part_segm_fn), "rb") as fh:
+        data = pickle.load(fh, encoding="latin1")
+    dm.set_parts(data["segm"], data["parents"], ign_part_pairs)
+
+
 def fit_single_frame(img, keypoints, body_model, camera, joint_weights, body_pose_prior, jaw_prior,
                      left_hand_prior, right_hand_prior, shape_prior, expr_prior, angle_prior,
                      result_fn="out.pkl", mesh_fn="out.obj", loss_type="smplify", use_cuda=True,
@@ -42,8 +54,8 @@ def fit_single_frame(img, keypoints, body_model, camera, joint_weights, body_pos
     assert batch_size == 1, "fit_single_frame handles one frame; use driver.fit_frames for batches"
     if visualize:
         raise NotImplementedError("visualize=True is outside the fitting path")
-    if interpenetration:
-        raise NotImplementedError("interpenetration=True: the BVH penetration term is not built (SURVEY.md 8f-1)")
+    if interpenetration and point2plane:
+        raise NotImplementedError("point2plane=True: only the cone distance field of the shipped cfgs is built")
     if not use_cuda:
         raise RuntimeError("use_cuda=False: this engine has no CPU path")
     H, W, _ = np.asarray(img).shape
@@ -54,12 +66,16 @@ def fit_single_frame(img, keypoints, body_model, camera, joint_weights, body_pos
                hand_pose_prior_weights=hand_pose_prior_weights, jaw_pose_prior_weights=jaw_pose_prior_weights,
                shape_weights=shape_weights, expr_weights=expr_weights, hand_joints_weights=hand_joints_weights,
                face_joints_weights=face_joints_weights, global_orient_weights=global_orient_weights,
-               depth_loss_weight=depth_loss_weight, interpenetration=False, coll_loss_weights=coll_loss_weights,
+               depth_loss_weight=depth_loss_weight, interpenetration=bool(interpenetration),
+               coll_loss_weights=coll_loss_weights, max_collisions=max_collisions, df_cone_height=df_cone_height,
+               penalize_outside=penalize_outside,
                side_view_thsh=side_view_thsh, rho=rho, use_joints_conf=use_joints_conf, format=format,
                left_shoulder_idx=left_shoulder_idx, right_shoulder_idx=right_shoulder_idx, use_vposer=use_vposer)
     if not use_joints_conf:
         raise NameError("name 'joints_conf' is not defined")   # the reference fails here (fit_single_frame.py:286)
     dm = body_model.device_model
+    if interpenetration:
+        setup_interpenetration(dm, part_segm_fn, ign_part_pairs)
     if use_vposer and not dm.vposer_latent:         # load_vposer(vposer_ckpt, vp_model='snapshot') (:239-242)
         dm.set_vposer(vposer_host.load_vposer(vposer_ckpt))
     reg_pose = reg_glob = cam_t = cam_c = None
@@ -94,7 +110,8 @@ def fit_single_frame(img, keypoints, body_model, camera, joint_weights, body_pos
     jw = joint_weights.detach().cpu().numpy() if torch.is_tensor(joint_weights) else np.asarray(joint_weights)
     want_v = bool(kwargs.get("save_vertices"))
     res = driver.fit_frames(dm, cfg, kp, jw.reshape(1, -1), H, W, focal_length, reg_pose=reg_pose, reg_global=reg_glob,
-                            cam_prior_t=cam_t, cam_prior_center=cam_c, lbs_mode=kwargs.get("lbs_mode", "rows"),
+                            cam_prior_t=cam_t, cam_prior_center=cam_c,
+                            lbs_mode="dense" if interpenetration else kwargs.get("lbs_mode", "rows"),
                             reuse_entry_eval=True, want_vertices=want_v)
     # write the fitted values back into the caller's modules, as the reference leaves them
     with torch.no_grad():

@@ -167,7 +167,9 @@ class EngineClosure(object):
             for q in range(3):
                 w.jaw_prior_weight[q] = float(jw[q])
             if getattr(loss, "interpenetration", False) and float(getattr(loss, "coll_loss_weight", 0.0)) > 0:
-                raise NotImplementedError("interpenetration term (coll_loss_weight > 0) is not built (SURVEY.md 8f-1)")
+                raise NotImplementedError("interpenetration through create_loss(search_tree=..., pen_distance=...) needs the "
+                                          "external mesh_intersection objects; use fit_single_frame / main / "
+                                          "driver.fit_frames with interpenetration=True (csrc/collide.hip)")
             reg = loss.regression_pose
             has_reg = reg is not None and (not self.use_vposer or stage + 1 == loss.num_stages)
         cfg = dict(use_vposer=self.use_vposer, use_hands=use_hands, use_face=use_face,

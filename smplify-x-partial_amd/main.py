@@ -31,7 +31,7 @@ from . import driver, utils
 from . import smplx
 from . import vposer as vposer_host
 from .data_parser import create_dataset
-from .fit_single_frame import _write_ply
+from .fit_single_frame import _write_ply, setup_interpenetration
 
 
 def _load_regression(args, img_name):
@@ -90,8 +90,9 @@ def main(**args):
     if args.get("use_cuda", True) and not torch.cuda.is_available():
         print("CUDA is not available, exiting!")
         sys.exit(-1)
-    if args.get("interpenetration", True):
-        raise NotImplementedError("interpenetration=True: the BVH penetration term is not built (SURVEY.md 8f-1)")
+    interpenetration = bool(args.get("interpenetration", True))
+    if interpenetration and args.get("point2plane", False):
+        raise NotImplementedError("point2plane=True: only the cone distance field of the shipped cfgs is built")
     if args.get("use_gender_classifier", False):
         raise NotImplementedError("use_gender_classifier: the homogenus classifier is outside the fitting path")
 
@@ -138,6 +139,8 @@ def main(**args):
                                           vposer=vpw, **{k: v for k, v in args.items() if k not in ("model_path", "dtype")})
         bm = models[gender]
         dm = bm.device_model
+        if interpenetration:
+            setup_interpenetration(dm, args.get("part_segm_fn", ""), args.get("ign_part_pairs"))
         focal = args.get("focal_length", None)
         if focal is None:
             focal = (W_ ** 2 + H_ ** 2) ** 0.5                                   # main.py:213-214
@@ -163,7 +166,8 @@ def main(**args):
         cfg.update(focal_length=focal, left_shoulder_idx=dataset_obj.get_left_shoulder(),
                    right_shoulder_idx=dataset_obj.get_right_shoulder())
         res = driver.fit_frames(dm, cfg, kp, joint_weights, H_, W_, focal, reg_pose=reg_pose, reg_global=reg_glob,
-                                cam_prior_t=cam_t, cam_prior_center=cam_c, lbs_mode=args.get("lbs_mode", "rows"),
+                                cam_prior_t=cam_t, cam_prior_center=cam_c,
+                                lbs_mode="dense" if interpenetration else args.get("lbs_mode", "rows"),
                                 reuse_entry_eval=True, want_vertices=bool(args.get("save_vertices")))
         names = [n for n, _ in bm.named_parameters()]
         for b, it in enumerate(its):

@@ -200,3 +200,34 @@ def test_closure_with_interpenetration_matches_oracle(synth_model):
     loss, grad = fb.closure(2)
     assert np.all(np.isfinite(loss)) and np.all(np.isfinite(grad)) and loss[0] > l0[0] * 0 
     fb.close()
+
+
+def test_fit_frames_with_interpenetration_runs(synth_model):
+    """driver.fit_frames on cfg_files/fit_smplx_combined_halpe.yaml with interpenetration=True: the whole
+    schedule runs on device with the penetration step between the dense LBS and the loss/adjoint
+    pass; the stages with weight 0 are untouched, the others end on a higher loss (the synthetic
+    triangle soup always interpenetrates)."""
+    import helpers as H
+    import test_gpu_parity as T
+    from smplifyx_amd import driver, synthetic
+    cfg = H.load_cfg("fit_smplx_combined_halpe.yaml", use_hands=False, use_face=False, interpenetration=True)
+    cfg.update(use_camera_prior=False, maxiters=4, df_cone_height=1e-2)
+    parts = synthetic.make_synthetic_parts(synth_model)
+    dm = T._dm(synth_model, cfg)
+    dm.set_parts(parts["segm"], parts["parents"], cfg["ign_part_pairs"])
+    K = len(H.joint_map_for(cfg))
+    frames = synthetic.make_frames(2, H.oracle_joints_fn(synth_model, cfg), K, focal=5000.0)
+    jw = H.base_joint_weights(cfg, K)
+    res = driver.fit_frames(dm, cfg, frames["keypoints"], jw, 600, 800, 5000.0, reg_pose=frames["reg_pose"],
+                            reg_global=frames["reg_global"], lbs_mode="dense")
+    cfg0 = dict(cfg); cfg0["interpenetration"] = False
+    ref = driver.fit_frames(dm, cfg0, frames["keypoints"], jw, 600, 800, 5000.0, reg_pose=frames["reg_pose"],
+                            reg_global=frames["reg_global"], lbs_mode="dense")
+    assert np.all(np.isfinite(res["stage_loss"])) and np.all(np.isfinite(res["pose_embedding"]))
+    # camera stage and body stage 0 (coll weight 0) do not see the term (the two runs use closure
+    # variants with different fp32 summation orders: equal to rounding); the later stages do
+    assert np.allclose(res["stage_loss"][:, :2], ref["stage_loss"][:, :2], rtol=1e-4)
+    assert np.all(res["stage_loss"][:, 2:] > ref["stage_loss"][:, 2:] * 1.001)
+    with pytest.raises(ValueError, match="dense"):
+        driver.fit_frames(dm, cfg, frames["keypoints"], jw, 600, 800, 5000.0, reg_pose=frames["reg_pose"],
+                          reg_global=frames["reg_global"], lbs_mode="rows")
