@@ -31,6 +31,8 @@
 #include <vector>
 
 #define PEN_T 1024
+#define PEN_SPAN 8              // cells per axis one triangle may be entered in (a sane triangle spans 1-3; an exploded
+                                // mesh -- diverged fit, NaN / huge coordinates -- must not turn into 10^9 cell visits)
 #define PEN_CELLS 16384         // hash buckets of the grid: histogram + cursors = 2 x 64 KB of LDS
 
 struct PenDev {
@@ -42,7 +44,8 @@ struct PenDev {
     const int* vf_list;
     // per batch (capacity Bmax)
     float* aabb;               // [B][F][6]
-    int* entries;              // [B][ent_cap] triangle ids sorted by cell
+    int* entries;              // [B][ent_cap] triangle | part << 24, sorted by bucket
+    int* ent_cell;             // [B][ent_cap] packed cell coordinates the entry was made for
     int ent_cap;
     int* partners;             // [B][F][cap]
     int* pcount;               // [B][F]
@@ -168,7 +171,7 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
     const float h = fmaxf(2.f * mean_ext, 1e-6f);
     const float ih = 1.f / h;
     const int ncell = PEN_CELLS;
-    auto cell_of = [&](float x, int e) { return max(0, (int)((x - glo[e]) * ih)); };
+    auto cell_of = [&](float x, int e) { return min(1 << 20, max(0, (int)fminf((x - glo[e]) * ih, 1048576.f))); };
     auto bucket = [](int x, int y, int z) { return (int)(((unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u) & (PEN_CELLS - 1)); };
     (void)ghi;
     // ---- counting sort of (cell, triangle) entries
@@ -176,7 +179,7 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
     __syncthreads();
     for (int f = t; f < F; f += PEN_T) {
         int c0[3], c1[3];
-        for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = cell_of(aabb[f * 6 + 3 + e], e); }
+        for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = min(cell_of(aabb[f * 6 + 3 + e], e), c0[e] + PEN_SPAN - 1); }
         for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x)
             atomicAdd(&cell_cnt[bucket(x, y, z)], 1);
     }
@@ -200,6 +203,10 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
     }
     __syncthreads();
     int* ent = P.entries + (size_t)b * P.ent_cap;
+    int* entc = P.ent_cell + (size_t)b * P.ent_cap;
+    // a bucket may mix several cells (and one triangle may sit in it twice, once per cell): entries
+    // carry the cell they were made for, and a scan only looks at those of its own cell
+    auto cell_key = [](int x, int y, int z) { return (x & 1023) | ((y & 1023) << 10) | ((z & 1023) << 20); };
     int* st = P.stats + b * 4;
     const bool ent_ok = s_total <= P.ent_cap;
     if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = ncell; }
@@ -214,9 +221,11 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
     __syncthreads();
     for (int f = t; f < F; f += PEN_T) {
         int c0[3], c1[3];
-        for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = cell_of(aabb[f * 6 + 3 + e], e); }
+        for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = min(cell_of(aabb[f * 6 + 3 + e], e), c0[e] + PEN_SPAN - 1); }
         for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x)
-            ent[atomicAdd(&cursor[bucket(x, y, z)], 1)] = f | (P.segm[f] << 24);     // triangle | part << 24
+            { const int q = atomicAdd(&cursor[bucket(x, y, z)], 1);
+              ent[q] = f | (P.segm[f] << 24);     // triangle | part << 24
+              entc[q] = cell_key(x, y, z); }
     }
     __threadfence_block();
     __syncthreads();
@@ -239,7 +248,7 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
             skipmask = m;
         }
         int c0[3], c1[3];
-        for (int e = 0; e < 3; ++e) { c0[e] = cell_of(a[e], e); c1[e] = cell_of(a[3 + e], e); }
+        for (int e = 0; e < 3; ++e) { c0[e] = cell_of(a[e], e); c1[e] = min(cell_of(a[3 + e], e), c0[e] + PEN_SPAN - 1); }
         int cnt = 0;
         int* mine = P.partners + ((size_t)b * F + f) * P.cap;
         for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x) {
@@ -252,7 +261,7 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
                 if (q < q1) {
                     const int en = ent[q];
                     g = en & 0xffffff;
-                    pass = g != f && !((skipmask >> (en >> 24)) & 1ull);
+                    pass = g != f && !((skipmask >> (en >> 24)) & 1ull) && entc[q] == cell_key(x, y, z);
                     if (pass) {
                         const float* ga = aabb + g * 6;
                         float il[3];
@@ -305,6 +314,7 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
         for (int it = 0; it < cnt; ++it) {
             int g = 0x7fffffff;                          // next partner in ascending index
             for (int q = 0; q < cnt; ++q) { const int c = mine[q]; if (c > last && c < g) g = c; }
+            if (g == 0x7fffffff) break;                  // (list exhausted: never with a consistent list)
             last = g;
             float qv[9];
             for (int k = 0; k < 3; ++k) for (int e = 0; e < 3; ++e) qv[k * 3 + e] = vb[(size_t)P.faces[g * 3 + k] * 3 + e];
@@ -413,7 +423,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     P.faces = h->up(fv); P.segm = h->up(sg); P.skip = h->up(skip); P.vf_start = h->up(vs); P.vf_list = h->up(vl);
     const size_t B = max_batch;
     P.ent_cap = F * 32;
-    P.aabb = h->zeros<float>(B * F * 6); P.entries = h->zeros<int>(B * P.ent_cap);
+    P.aabb = h->zeros<float>(B * F * 6); P.entries = h->zeros<int>(B * P.ent_cap); P.ent_cell = h->zeros<int>(B * P.ent_cap);
     P.partners = h->zeros<int>(B * F * P.cap); P.pcount = h->zeros<int>(B * F);
     P.tloss = h->zeros<float>(B * F); P.tgrad = h->zeros<float>(B * F * 9); P.stats = h->zeros<int>(B * 4);
     if (!P.stats || !P.tgrad || !P.partners) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }

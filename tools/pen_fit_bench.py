@@ -1,0 +1,32 @@
+"""Side measurement (BASELINE configs[4]-like): cfg_files/fit_smplx_combined_halpe.yaml with the
+interpenetration term, synthetic frames / model / part labels.  Not the bench headline."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+import helpers as H, test_gpu_parity as T
+from smplifyx_amd import driver, synthetic, engine
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+body_only = (len(sys.argv) > 2 and sys.argv[2] == "body")
+over = dict(interpenetration=True)
+if body_only: over.update(use_hands=False, use_face=False)
+cfg = H.load_cfg("fit_smplx_combined_halpe.yaml", **over)
+cfg["use_camera_prior"] = False
+m = synthetic.make_synthetic_model(0)
+parts = synthetic.make_synthetic_parts(m)
+dm = T._dm(m, cfg)
+dm.set_parts(parts["segm"], parts["parents"], cfg["ign_part_pairs"])
+K = len(H.joint_map_for(cfg))
+frames = synthetic.make_frames(B, H.oracle_joints_fn(m, cfg), K, focal=5000.0)
+jw = H.base_joint_weights(cfg, K)
+for pen in (False, True):
+    c = dict(cfg); c["interpenetration"] = pen
+    engine.prof_enable(True, every=4); engine.prof_reset()
+    torch.cuda.synchronize(); t0 = time.time()
+    res = driver.fit_frames(dm, c, frames["keypoints"], jw, 600, 800, 5000.0, reg_pose=frames["reg_pose"], reg_global=frames["reg_global"], lbs_mode="dense")
+    torch.cuda.synchronize(); dt = time.time() - t0
+    engine.prof_enable(False)
+    print("interpenetration=%s  B=%d K=%d: %.2f s -> %.1f frames/s; evals/frame mean %.0f; kernels us: lbs %.0f tick %.0f pen %.0f" % (
+        pen, B, K, dt, B / dt, res["stage_evals"].sum(1).mean(),
+        1e3 * engine.prof_get("lbs_dense")[0] / max(1, engine.prof_get("lbs_dense")[1]),
+        1e3 * engine.prof_get("tick")[0] / max(1, engine.prof_get("tick")[1]),
+        1e3 * engine.prof_get("penetration")[0] / max(1, engine.prof_get("penetration")[1])))
