@@ -8,19 +8,23 @@
 // and its gradient with respect to the vertices.  Algorithm and formulas: oracle/penetration.py
 // (the package's source is absent: parity unpinned).
 //
-// MI355X design (not the package's LBVH): one workgroup of 1024 lanes owns one frame and keeps a
-// uniform grid (cell = twice the mean triangle extent) hashed into 16384 LDS buckets:
-//   k_pen_pairs   triangle AABBs -> cell size from the mean triangle extent -> counting sort of
-//                 (cell, triangle) entries (a triangle is entered in every cell its AABB touches)
-//                 -> every triangle scans the cells of its own AABB: part filter first (one byte
-//                 table lookup rejects ~95 %), then AABB overlap, then shared vertices; a pair seen in
-//                 several cells is kept in the cell that holds the low corner of the intersection box.
-//                 Partners are stored per triangle ([F][cap], both directions).
+// MI355X design (not the package's LBVH): one workgroup of 1024 lanes owns one frame.
+//   k_pen_pairs   triangle AABBs -> bounding box per body part: a triangle whose box meets the box of
+//                 no part it may collide with is dropped (in most poses nearly all of them) -> the
+//                 rest enters a uniform grid (cell = twice the mean triangle extent, every cell the
+//                 AABB touches) hashed into 8192 LDS buckets by a counting sort -> pair tests run
+//                 over blocks of 64 consecutive entries of the bucket-sorted list: each lane holds
+//                 one entry (AABB, vertex ids, part, cell), the same 64 headers sit in a
+//                 wavefront-private LDS tile and are read back by broadcast, so memory is touched
+//                 once per ENTRY, not per pair.  Tests in order: same cell, part mask (one 64-bit
+//                 word), AABB overlap, ownership by the cell of the intersection's low corner,
+//                 shared vertices.  Accepted pairs are queued per wavefront and appended to both
+//                 triangles' partner lists 64 at a time.
 //   k_pen_eval    one lane per triangle: partners visited in ascending index (selection, no
 //                 sorting), conic distance field evaluated with forward-mode dual numbers -- the
 //                 lane differentiates with respect to ITS OWN 9 coordinates only, once as receiver
-//                 geometry and once as intruding points -- so every write has one owner: no atomics,
-//                 results independent of scheduling and of batch composition.
+//                 geometry and once as intruding points -- so every write has one owner: no atomics
+//                 in the arithmetic, results independent of scheduling and of batch composition.
 //   k_pen_gather  vertex gradient = fixed-order sum over the incident triangle corners (CSR);
 //                 frame loss = fixed-order block reduction.
 #include "../../include/sfx.h"
@@ -31,9 +35,10 @@
 #include <vector>
 
 #define PEN_T 1024
+#define PEN_GRID_INTS (((2 * (PEN_CELLS + 1) + 3) / 4) * 4)
 #define PEN_SPAN 8              // cells per axis one triangle may be entered in (a sane triangle spans 1-3; an exploded
                                 // mesh -- diverged fit, NaN / huge coordinates -- must not turn into 10^9 cell visits)
-#define PEN_CELLS 16384         // hash buckets of the grid: histogram + cursors = 2 x 64 KB of LDS
+#define PEN_CELLS 8192          // hash buckets of the grid: histogram + cursors = 2 x 32 KB of LDS (+ 48 KB of wavefront tiles)
 
 struct PenDev {
     int V, F, cap, n_parts;
@@ -150,6 +155,14 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
     float* aabb = P.aabb + (size_t)b * P.F * 6;
     const int F = P.F;
 
+    // per-part masks of the parts a triangle never collides with (parts < 64)
+    __shared__ unsigned long long s_mask[64];
+    if (t < 64) {
+        unsigned long long m = 0;
+        if (t < P.n_parts) for (int q = 0; q < P.n_parts; ++q) m |= (unsigned long long)(P.skip[(size_t)t * P.n_parts + q] != 0) << q;
+        s_mask[t] = m;
+    }
+    for (int f = t; f < P.F; f += PEN_T) P.pcount[(size_t)b * P.F + f] = 0;
     // ---- AABBs, frame bounding box, mean triangle extent
     float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f}, ext_sum = 0.f;
     for (int f = t; f < F; f += PEN_T) {
@@ -164,6 +177,32 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
     }
     float glo[3], ghi[3];
     for (int e = 0; e < 3; ++e) { glo[e] = block_min(lo[e], red); ghi[e] = block_max(hi[e], red); }
+    // ---- part-level broad phase: bounding box of every part; a triangle whose box meets the box of
+    // no part it may collide with cannot have a partner and never enters the grid (at rest and in most
+    // poses that is nearly every triangle: the grid only sees the regions where unrelated parts meet)
+    __shared__ int s_pbox[64][6];
+    auto ford = [](float x) { int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); };      // order-preserving
+    if (t < 64) { for (int e = 0; e < 3; ++e) { s_pbox[t][e] = 0x7fffffff; s_pbox[t][3 + e] = (int)0x80000000; } }
+    __syncthreads();
+    for (int f = t; f < F; f += PEN_T) {
+        const int pf = P.segm[f];
+        for (int e = 0; e < 3; ++e) { atomicMin(&s_pbox[pf][e], ford(aabb[f * 6 + e])); atomicMax(&s_pbox[pf][3 + e], ford(aabb[f * 6 + 3 + e])); }
+    }
+    __syncthreads();
+    unsigned char* alive = reinterpret_cast<unsigned char*>(P.ent_cell + (size_t)b * P.ent_cap + P.ent_cap - (F + 3) / 4);   // tail of the entry buffer
+    for (int f = t; f < F; f += PEN_T) {
+        const unsigned long long sk = s_mask[P.segm[f]];
+        int a6[6];
+        for (int e = 0; e < 3; ++e) { a6[e] = ford(aabb[f * 6 + e]); a6[3 + e] = ford(aabb[f * 6 + 3 + e]); }
+        bool any = false;
+        for (int q = 0; q < P.n_parts && !any; ++q) {
+            if ((sk >> q) & 1ull) continue;
+            any = a6[0] <= s_pbox[q][3] && s_pbox[q][0] <= a6[3] && a6[1] <= s_pbox[q][4] && s_pbox[q][1] <= a6[4] &&
+                  a6[2] <= s_pbox[q][5] && s_pbox[q][2] <= a6[5];
+        }
+        alive[f] = any ? 1 : 0;
+    }
+    __syncthreads();
     const float mean_ext = block_sum_fixed(ext_sum, red) / (float)F;
     // cell size: twice the mean triangle extent; cells are addressed by integer coordinates from
     // the low corner of the frame's bounding box and hashed into PEN_CELLS buckets (a bucket that
@@ -178,6 +217,7 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
     for (int c = t; c <= ncell; c += PEN_T) cell_cnt[c] = 0;
     __syncthreads();
     for (int f = t; f < F; f += PEN_T) {
+        if (!alive[f]) continue;
         int c0[3], c1[3];
         for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = min(cell_of(aabb[f * 6 + 3 + e], e), c0[e] + PEN_SPAN - 1); }
         for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x)
@@ -208,7 +248,7 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
     // carry the cell they were made for, and a scan only looks at those of its own cell
     auto cell_key = [](int x, int y, int z) { return (x & 1023) | ((y & 1023) << 10) | ((z & 1023) << 20); };
     int* st = P.stats + b * 4;
-    const bool ent_ok = s_total <= P.ent_cap;
+    const bool ent_ok = s_total <= P.ent_cap - (F + 3) / 4 - 4;
     if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = ncell; }
     if (!ent_ok) {       // grid too crowded for the entry buffer: report, produce no pairs
         for (int f = t; f < F; f += PEN_T) P.pcount[(size_t)b * F + f] = 0;
@@ -220,6 +260,7 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
     for (int c = t; c < ncell; c += PEN_T) cursor[c] = cell_cnt[c];
     __syncthreads();
     for (int f = t; f < F; f += PEN_T) {
+        if (!alive[f]) continue;
         int c0[3], c1[3];
         for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = min(cell_of(aabb[f * 6 + 3 + e], e), c0[e] + PEN_SPAN - 1); }
         for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x)
@@ -230,64 +271,99 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
     __threadfence_block();
     __syncthreads();
 
-    // ---- partners of every triangle: one WAVEFRONT per triangle, its 64 lanes stride through the
-    // entries of each cell the triangle touches (coalesced, no divergence between triangles with
-    // short and long candidate lists); survivors are appended with a ballot / prefix count
-    int n_pairs = 0, n_over = 0;
+    // ---- pairs, bucket by bucket.  A wavefront takes a bucket: its lanes hold one entry each
+    // (header = AABB, vertex ids, part, cell) and the same 64 headers sit in a wavefront-private LDS
+    // tile; lane i then tests itself against entries k > i read from the tile by broadcast.  All
+    // memory traffic is one gather per ENTRY; the pair tests run on registers and LDS.  A pair is
+    // accepted in the cell that holds the low corner of the AABB intersection (both triangles are
+    // entered there), and appended to both triangles' partner lists.
     const int lane = t & 63, wv = t >> 6;
-    for (int f = wv; f < F; f += PEN_T / 64) {
-        float a[6];
-        for (int e = 0; e < 6; ++e) a[e] = aabb[f * 6 + e];
-        const int fv0 = P.faces[f * 3], fv1 = P.faces[f * 3 + 1], fv2 = P.faces[f * 3 + 2];
-        // parts this triangle never collides with, as a bit mask (parts < 64): the first test of
-        // every candidate is one shift on a word that came with the entry itself
-        unsigned long long skipmask;
-        {
-            const unsigned char* skip = P.skip + (size_t)P.segm[f] * P.n_parts;
-            const unsigned long long m = __ballot(lane < P.n_parts && skip[lane < P.n_parts ? lane : 0] != 0);
-            skipmask = m;
+    int* tile = cell_cnt + PEN_GRID_INTS + wv * 64 * 12;          // 16-byte aligned
+    int* pc = P.pcount + (size_t)b * F;
+    int* part = P.partners + (size_t)b * F * P.cap;
+    auto load_hdr = [&](int q, bool ok, int (&hd)[12]) {
+        hd[0] = ok ? ent[q] : 0; hd[1] = ok ? entc[q] : -1;
+        const int f = hd[0] & 0xffffff;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) hd[2 + e] = ok ? __float_as_int(aabb[f * 6 + e]) : 0;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) hd[8 + e] = ok ? P.faces[f * 3 + e] : -1 - e;
+        hd[11] = 0;
+    };
+    // work items are blocks of 64 consecutive entries of the bucket-sorted list (NOT whole buckets:
+    // a crowded bucket is shared by many wavefronts); the partners of an entry lie between it and the
+    // end of its bucket, and the cell key comparison keeps different cells of one bucket apart
+    int* queue = cell_cnt + PEN_GRID_INTS + (PEN_T / 64) * 64 * 12 + wv * 256;      // 128 pairs per wavefront
+    int qn = 0;
+    auto flush_queue = [&](int n) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+        for (int q = lane; q < n; q += 64) {
+            const int fa = queue[2 * q], fb = queue[2 * q + 1];
+            const int pa = atomicAdd(&pc[fa], 1), pb = atomicAdd(&pc[fb], 1);
+            if (pa < P.cap) part[(size_t)fa * P.cap + pa] = fb;
+            if (pb < P.cap) part[(size_t)fb * P.cap + pb] = fa;
         }
-        int c0[3], c1[3];
-        for (int e = 0; e < 3; ++e) { c0[e] = cell_of(a[e], e); c1[e] = min(cell_of(a[3 + e], e), c0[e] + PEN_SPAN - 1); }
-        int cnt = 0;
-        int* mine = P.partners + ((size_t)b * F + f) * P.cap;
-        for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x) {
-            const int c = bucket(x, y, z);
-            const int q1 = cell_cnt[c + 1];
-            for (int q0 = cell_cnt[c]; q0 < q1; q0 += 64) {
-                const int q = q0 + lane;
-                bool pass = false;
-                int g = 0;
-                if (q < q1) {
-                    const int en = ent[q];
-                    g = en & 0xffffff;
-                    pass = g != f && !((skipmask >> (en >> 24)) & 1ull) && entc[q] == cell_key(x, y, z);
-                    if (pass) {
-                        const float* ga = aabb + g * 6;
-                        float il[3];
-                        for (int e = 0; e < 3; ++e) { pass = pass && (a[e] <= ga[3 + e]) && (ga[e] <= a[3 + e]); il[e] = fmaxf(a[e], ga[e]); }
-                        // the pair is owned by the cell that holds the low corner of the intersection box
-                        pass = pass && cell_of(il[0], 0) == x && cell_of(il[1], 1) == y && cell_of(il[2], 2) == z;
-                        if (pass) {
-                            const int g0 = P.faces[g * 3], g1 = P.faces[g * 3 + 1], g2 = P.faces[g * 3 + 2];
-                            pass = !(g0 == fv0 || g0 == fv1 || g0 == fv2 || g1 == fv0 || g1 == fv1 || g1 == fv2 ||
-                                     g2 == fv0 || g2 == fv1 || g2 == fv2);
-                        }
-                    }
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int i0 = wv * 64; i0 < s_total; i0 += PEN_T) {
+        const int qi = i0 + lane;
+        const bool vi = qi < s_total;
+        int hi_[12];
+        load_hdr(qi, vi, hi_);
+        const int fi = hi_[0] & 0xffffff;
+        const unsigned long long skip_i = vi ? s_mask[hi_[0] >> 24] : ~0ull;
+        float ai[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) ai[e] = __int_as_float(hi_[2 + e]);
+        // end of the bucket that holds the block's last entry
+        const int klast = __builtin_amdgcn_readfirstlane(entc[min(i0 + 63, s_total - 1)]);
+        const int jend = __builtin_amdgcn_readfirstlane(cell_cnt[bucket(klast & 1023, (klast >> 10) & 1023, (klast >> 20) & 1023) + 1]);
+        for (int j0 = i0; j0 < jend; j0 += 64) {
+            int hj[12];
+            if (j0 == i0) {
+#pragma unroll
+                for (int e = 0; e < 12; ++e) hj[e] = hi_[e];
+            } else load_hdr(j0 + lane, j0 + lane < jend, hj);
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                *reinterpret_cast<int4*>(&tile[lane * 12 + e * 4]) = make_int4(hj[e * 4], hj[e * 4 + 1], hj[e * 4 + 2], hj[e * 4 + 3]);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+            const int nj = min(64, jend - j0);
+            for (int k = 0; k < nj; ++k) {
+                const int4 h0 = *reinterpret_cast<const int4*>(&tile[k * 12]);
+                const int4 h1 = *reinterpret_cast<const int4*>(&tile[k * 12 + 4]);
+                const int4 h2 = *reinterpret_cast<const int4*>(&tile[k * 12 + 8]);
+                bool pass = vi && (j0 + k > qi) && h0.y == hi_[1] && !((skip_i >> (h0.x >> 24)) & 1ull);
+                const float kl0 = __int_as_float(h0.z), kl1 = __int_as_float(h0.w), kl2 = __int_as_float(h1.x);
+                const float kh0 = __int_as_float(h1.y), kh1 = __int_as_float(h1.z), kh2 = __int_as_float(h1.w);
+                pass = pass && ai[0] <= kh0 && kl0 <= ai[3] && ai[1] <= kh1 && kl1 <= ai[4] && ai[2] <= kh2 && kl2 <= ai[5];
+                if (pass) {
+                    pass = cell_key(cell_of(fmaxf(ai[0], kl0), 0), cell_of(fmaxf(ai[1], kl1), 1), cell_of(fmaxf(ai[2], kl2), 2)) == hi_[1];
+                    const int g0 = h2.x, g1 = h2.y, g2 = h2.z;
+                    pass = pass && !(g0 == hi_[8] || g0 == hi_[9] || g0 == hi_[10] || g1 == hi_[8] || g1 == hi_[9] || g1 == hi_[10] ||
+                                     g2 == hi_[8] || g2 == hi_[9] || g2 == hi_[10]);
                 }
+                // accepted pairs go to a wavefront-private queue and are appended to the partner lists
+                // 64 at a time: the list cursors are returning atomics, one memory round trip each
                 const unsigned long long m = __ballot(pass);
                 if (m) {
-                    const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-                    if (pass && pos < P.cap) mine[pos] = g;
-                    cnt += __popcll(m);
+                    const int pos = qn + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pass) { queue[2 * pos] = fi; queue[2 * pos + 1] = h0.x & 0xffffff; }
+                    qn += __popcll(m);
+                    if (qn >= 64) { flush_queue(qn); qn = 0; }
                 }
             }
+            __builtin_amdgcn_wave_barrier();
         }
-        if (lane == 0) {
-            P.pcount[(size_t)b * F + f] = min(cnt, P.cap);
-            n_pairs += min(cnt, P.cap);
-            n_over += max(cnt - P.cap, 0);
-        }
+    }
+    if (qn) flush_queue(qn);
+    __threadfence();
+    __syncthreads();
+    int n_pairs = 0, n_over = 0;
+    for (int f = t; f < F; f += PEN_T) {
+        const int cnt = pc[f];
+        n_pairs += min(cnt, P.cap); n_over += max(cnt - P.cap, 0);
+        pc[f] = min(cnt, P.cap);
     }
     const float tp = block_sum_fixed((float)n_pairs, red), to = block_sum_fixed((float)n_over, red);
     if (t == 0) { st[0] = (int)tp; st[1] = (int)to; }
@@ -443,7 +519,7 @@ extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float
     if (B < 1 || B > h->Bmax) { sfx_set_error("batch %d exceeds the capacity %d given to sfx_pen_create", B, h->Bmax); return -1; }
     if (!(sigma > 0.f)) { sfx_set_error("df_cone_height must be positive"); return -1; }
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)(2 * (PEN_CELLS + 1)) * sizeof(int);
+    const size_t lds = (size_t)(PEN_GRID_INTS + (PEN_T / 64) * (64 * 12 + 256)) * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)k_pen_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
