@@ -76,10 +76,17 @@ def _bone_radius(j):
 
 
 def make_synthetic_model(seed=0, num_verts=NUM_VERTS, num_faces=NUM_FACES,
-                         dtype=np.float32):
+                         dtype=np.float32, surface=False):
     """Return a dict with the key set of an SMPL-X ``.npz`` (appendix A.1) plus
     ``extra_vertex_ids`` (the 21 vertex-joint picks valid for this geometry).
-    Deterministic in ``seed``."""
+    Deterministic in ``seed``.
+
+    surface=False (default, what every golden fixture is made with): vertices are scattered in the
+    volume around the bones -- fine for LBS / keypoint work, but as a mesh it is a triangle soup that
+    interpenetrates everywhere.  surface=True moves every vertex onto a tube around its bone
+    (same random draws, offset projected off the bone axis and normalised to the tube radius): the
+    faces, built from near neighbours, then form surface patches, which is what collision handling
+    sees on a real body mesh."""
     from scipy.spatial import cKDTree
     rng = np.random.RandomState(seed)
     V, F, J = num_verts, num_faces, NUM_JOINTS
@@ -108,7 +115,12 @@ def make_synthetic_model(seed=0, num_verts=NUM_VERTS, num_faces=NUM_FACES,
         a = Jrest[p] if p >= 0 else Jrest[j] + np.array([0.0, -0.08, 0.0])
         b = Jrest[j]
         tt = t[idx][:, None]
-        pts = a * (1 - tt) + b * tt + rng.normal(0, _bone_radius(j), (idx.size, 3))
+        off = rng.normal(0, _bone_radius(j), (idx.size, 3))
+        if surface:
+            ax = (b - a) / max(np.linalg.norm(b - a), 1e-9)
+            off = off - (off @ ax)[:, None] * ax
+            off = off / np.maximum(np.linalg.norm(off, axis=1, keepdims=True), 1e-9) * (1.5 * _bone_radius(j))
+        pts = a * (1 - tt) + b * tt + off
         v_template[idx] = pts
         # <=4 nonzero skinning weights: bone owner (parent joint), this joint,
         # grand-parent and one child-side neighbour, blended along the bone

@@ -1,7 +1,7 @@
 import sys; sys.path.insert(0,'/root/repo')
 import numpy as np, torch, time
 from smplifyx_amd import engine, synthetic
-m = synthetic.make_synthetic_model(0)
+m = synthetic.make_synthetic_model(0, surface=("soup" not in sys.argv))
 parts = synthetic.make_synthetic_parts(m)
 ign = ["9,16", "9,17", "6,16", "6,17", "1,2", "12,22"]
 v = np.asarray(m["v_template"], np.float32); f = np.asarray(m["f"]).astype(np.int64)

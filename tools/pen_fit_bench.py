@@ -11,7 +11,7 @@ over = dict(interpenetration=True)
 if body_only: over.update(use_hands=False, use_face=False)
 cfg = H.load_cfg("fit_smplx_combined_halpe.yaml", **over)
 cfg["use_camera_prior"] = False
-m = synthetic.make_synthetic_model(0)
+m = synthetic.make_synthetic_model(0, surface=("soup" not in sys.argv))
 parts = synthetic.make_synthetic_parts(m)
 dm = T._dm(m, cfg)
 dm.set_parts(parts["segm"], parts["parents"], cfg["ign_part_pairs"])
