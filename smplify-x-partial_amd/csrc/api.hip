@@ -379,6 +379,20 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
         }
         M.jk_type = m->mem.up(jt); M.jk_src = m->mem.up(js); M.jk_item0 = m->mem.up(ji0); M.jk_nitem = m->mem.up(jn);
         M.item_vid = m->mem.up(ivid); M.item_w = m->mem.up(iw); M.item_dyn = m->mem.up(idyn); M.item_k = m->mem.up(ik);
+        {   // distinct vertices of the static items: the dense GEMM hands their v_posed / T to the adjoint pass
+            std::vector<int> vslot(M.Vpad, -1), uslot(ivid.size(), -1);
+            int nu = 0, nstat = 0;
+            for (size_t i = 0; i < ivid.size(); ++i) {
+                if (idyn[i] >= 0) continue;
+                ++nstat;
+                if (vslot[ivid[i]] < 0) vslot[ivid[i]] = nu++;
+                uslot[i] = vslot[ivid[i]];
+            }
+            for (size_t i = 0; i + 1 < ivid.size(); ++i)
+                if (idyn[i] >= 0 && idyn[i + 1] < 0) { sfx_set_error("internal: dynamic items must trail the static ones"); delete m; return -1; }
+            M.n_uniq = nu; M.n_static_items = nstat;
+            M.vslot = m->mem.up(vslot); M.item_uslot = m->mem.up(uslot);
+        }
         M.src_k0 = m->mem.up(sk0); M.src_klist = m->mem.up(skl);
     }
     if (m->meta_host.size() != SFX_META_N) { sfx_set_error("internal: meta table"); delete m; return -1; }
@@ -508,6 +522,8 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.AT = b->mem.zeros<float>((size_t)12 * SFX_JPAD * D.Bpad);
     D.verts = b->mem.zeros<float>((size_t)B * m->M.V * 3);
     D.fwd = b->mem.zeros<float>((size_t)B * SFX_FWD_N);
+    D.uvp = b->mem.zeros<float>((size_t)B * std::max(1, m->M.n_uniq) * 3);
+    D.uT = b->mem.zeros<float>((size_t)B * std::max(1, m->M.n_uniq) * 12);
     if (D.cfg.pen) {
         const int F = (int)(m->faces_host.size() / 3);
         const bool parts = !m->segm_host.empty();

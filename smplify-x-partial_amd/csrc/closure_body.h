@@ -400,7 +400,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     __syncthreads();
     // v_posed rows and skinning transforms of `ni` vertices listed in S.ivid (the model's items, or a
     // chunk of vertices that carry a penetration gradient)
-    auto items_forward = [&](const int ni) {
+    auto items_forward = [&](const int ib, const int ni) {       // items ib .. ib + ni - 1
     // v_posed rows: one wavefront per (item, coord) dot product of length KD_PAD
     {
         const float4* f4 = reinterpret_cast<const float4*>(S.feat);
@@ -410,7 +410,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         // in step: every CU of an XCD then asks one L2 channel for one 2-KiB row at the same moment.
         // Each workgroup therefore starts at its own rotation of the row list; the rows are
         // independent dot products, so the result is bit-identical.
-        const int nrow = ni * 3;
+        const int nrow = ni * 3, rb = ib * 3;
         const int rot = (int)((blockIdx.x * 40u) % (unsigned)nrow);
         for (int w0 = wv * RIF; w0 < nrow; w0 += (CT / 64) * RIF) {
             float4 da[RIF], db[RIF]; int wr[RIF];
@@ -418,6 +418,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
             for (int u = 0; u < RIF; ++u) {
                 int w = ((w0 + u < nrow) ? w0 + u : w0) + rot;
                 w = w >= nrow ? w - nrow : w;
+                w += rb;
                 wr[u] = w;
                 const int v = S.ivid[w / 3];
                 const float4* row = reinterpret_cast<const float4*>(M.dirsT + ((size_t)v * 3 + w % 3) * SFX_KD_PAD);
@@ -436,13 +437,13 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     // skinning transforms of the items
     // (sparse rows of lbs_weights: <= SFX_NW nonzeros per vertex, ascending joint order, so the
     //  sum visits the same nonzero terms in the same order as the dense product)
-    for (int w = t; w < ni * SFX_NW; w += CT) {
+    for (int w = t + ib * SFX_NW; w < (ib + ni) * SFX_NW; w += CT) {
         const int i = w / SFX_NW, q2 = w % SFX_NW;
         S.wj[w] = M.Wsp_j[(size_t)S.ivid[i] * SFX_NW + q2];
         S.ww[w] = M.Wsp_w[(size_t)S.ivid[i] * SFX_NW + q2];
     }
     __syncthreads();
-    for (int w = t; w < ni * 12; w += CT) {
+    for (int w = t + ib * 12; w < (ib + ni) * 12; w += CT) {
         const int i = w / 12, e = w % 12;
         float acc = 0.f;
         if (S.wj[i * SFX_NW] >= 0) {
@@ -459,7 +460,16 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     }
     __syncthreads();
     };
-    items_forward(NI);
+    if (args.use_dense_verts && !args.from_scratch_items) {
+        // dense path: the GEMM that produced the vertices also left v_posed and the skinning transform
+        // of every static item vertex (lbs_dense.hip epilogue); only the dynamic contour items, whose
+        // vertices depend on this frame's head pose, are evaluated here
+        const size_t ub = (size_t)D.slot[b] * M.n_uniq;
+        for (int w = t; w < M.n_static_items * 3; w += CT) S.vp[w] = D.uvp[(ub + M.item_uslot[w / 3]) * 3 + w % 3];
+        for (int w = t; w < M.n_static_items * 12; w += CT) S.T[w] = D.uT[(ub + M.item_uslot[w / 12]) * 12 + w % 12];
+        if (NI > M.n_static_items) items_forward(M.n_static_items, NI - M.n_static_items);
+        else __syncthreads();
+    } else items_forward(0, NI);
     MARK(6);
     for (int w = t; w < NI * 3; w += CT) {
         const int i = w / 3, r = w % 3;
@@ -708,7 +718,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
             for (int w = t; w < ni; w += CT) S.ivid[w] = xv[c0 + w];
             __syncthreads();
             for (int w = t; w < ni * 3; w += CT) S.dvert[w] = sw.coll * xg[(size_t)S.ivid[w / 3] * 3 + w % 3];
-            items_forward(ni);
+            items_forward(0, ni);
             items_dvp(ni);
             FOR_CT(w, SFX_J * 12) {          // dA[j][e] += sum_i W[v_i][j] * dvert_i[r] * [v_posed_i, 1][c]
                 const int j = w / 12, e = w % 12, r = e >> 2, c = e & 3;

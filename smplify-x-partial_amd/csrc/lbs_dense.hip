@@ -153,6 +153,7 @@ void k_lbs_dense(DevModel M, BatchDev D) {
         q0 = at_[16]; q1 = at_[estep + 16]; q2 = at_[2 * estep + 16]; q3 = at_[3 * estep + 16];           \
         ww = wl[(js) * 64]; } while (0)
     float o0[4][3], o1[4][3];
+    const int us = vok ? M.vslot[vtx] : -1;      // export index of an item vertex
     AT_LOAD(P0, P1, P2, P3, Q0, Q1, Q2, Q3, wc, 0, 0);
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr) {
@@ -168,6 +169,22 @@ void k_lbs_dense(DevModel M, BatchDev D) {
         for (int r = 0; r < 4; ++r) {
             o0[r][rr] = t00[r] * ax0[r] + t01[r] * ay0[r] + t02[r] * az0[r] + t03[r];
             o1[r][rr] = t10[r] * ax1[r] + t11[r] * ay1[r] + t12[r] * az1[r] + t13[r];
+        }
+        if (us >= 0) {      // item vertex: its transform row goes to the adjoint pass (a fraction of a percent of the lanes)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f0 = b0 + kq * 4 + r, f1 = f0 + 16;
+                if (f0 < B) { float* o = D.uT + ((size_t)f0 * M.n_uniq + us) * 12 + rr * 4; o[0] = t00[r]; o[1] = t01[r]; o[2] = t02[r]; o[3] = t03[r]; }
+                if (f1 < B) { float* o = D.uT + ((size_t)f1 * M.n_uniq + us) * 12 + rr * 4; o[0] = t10[r]; o[1] = t11[r]; o[2] = t12[r]; o[3] = t13[r]; }
+            }
+        }
+    }
+    if (us >= 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f0 = b0 + kq * 4 + r, f1 = f0 + 16;
+            if (f0 < B) { float* o = D.uvp + ((size_t)f0 * M.n_uniq + us) * 3; o[0] = ax0[r]; o[1] = ay0[r]; o[2] = az0[r]; }
+            if (f1 < B) { float* o = D.uvp + ((size_t)f1 * M.n_uniq + us) * 3; o[0] = ax1[r]; o[1] = ay1[r]; o[2] = az1[r]; }
         }
     }
 #undef AT_LOAD

@@ -95,6 +95,9 @@ struct DevModel {
     const int*   jk_item0;     // [K] first item (type 1)
     const int*   jk_nitem;     // [K]
     int n_items, n_static_items;
+    int n_uniq;                // distinct vertices of the static items: the dense GEMM exports their v_posed and T
+    const int* vslot;          // [Vpad] vertex -> index into the export arrays, or -1
+    const int* item_uslot;     // [n_items] export index of a static item's vertex (-1: dynamic item)
     const int*   item_vid;     // [n_items] static vertex id (dynamic items: -1)
     const float* item_w;       // [n_items] static bary weight
     const int*   item_dyn;     // [n_items] -1, or (landmark*3 + corner) of the dynamic LUT
@@ -164,6 +167,8 @@ struct BatchDev {
     float* stage_loss2;// [B][1+MAX_STAGES] second-orientation stage losses
     int*   try_both;   // [B]
     int*   orient_pass;// [B] 0 first fit, 1 second fit running, 2 done
+    float* uvp;             // [B][n_uniq][3]  (slot-indexed) v_posed of the item vertices, written by the dense GEMM
+    float* uT;              // [B][n_uniq][12] (slot-indexed) their skinning transforms
     float* pen_loss;        // [B] (slot-indexed) unweighted penetration loss of the pending evaluation
     float* pen_dverts;      // [B][V][3] (slot-indexed) its gradient with respect to the vertices
     int*   ext_n;           // [B] (slot-indexed) vertices with a nonzero penetration gradient ...
@@ -186,6 +191,7 @@ struct ClosureArgs {
     int use_dense_verts;    // 1: item vertices come from BatchDev.verts
     int export_dense;       // 1: write featT / AT for the dense kernel
     int from_X;             // 1: evaluate at X instead of Xt
+    int from_scratch_items; // 1: dense mode, but evaluate the item rows here (the GEMM export belongs to another call)
     int keep_tables;        // 1: S.meta / S.fd are still valid from the previous evaluation of this workgroup
     int reuse_fwd;          // 1: forward state of this trial point was saved by the export pass
 };
