@@ -1,13 +1,12 @@
-import sys, ctypes as C; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
-import numpy as np, torch, helpers as H, test_gpu_parity as T
+import os, sys, ctypes as C; sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np, torch, _frames as FR
 from smplifyx_amd import synthetic, _capi
 m = synthetic.make_synthetic_model(0)
-cfg = H.load_cfg("fit_smplx_smplifyx.yaml")
-dm = T._dm(m, cfg, vposer=synthetic.make_synthetic_vposer(0)); B=256
-fr = T.synth_frames(m, cfg, 3)
+cfg = FR.load_cfg("fit_smplx_smplifyx.yaml", use_camera_prior=False)
+dm, jm = FR.device_model(m, cfg, vposer=synthetic.make_synthetic_vposer(0)); B=256
+fr = FR.frames(dm, jm, 3)
 idx = [i%3 for i in range(B)]
-fb = H.engine_batch_from_frames(dm, cfg, fr, idx, lbs_mode="rows")
-fb.guess_init(cfg["body_tri_idxs"])
+fb = FR.batch(dm, cfg, fr, idx, lbs_mode="rows")
 out = (C.c_int64*32)()
 for st in (-1, 1):
     _capi.check(_capi.load().sfx_debug_phase_clocks(fb._h, st, out))

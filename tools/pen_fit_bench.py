@@ -1,23 +1,23 @@
 """Side measurement (BASELINE configs[4]-like): cfg_files/fit_smplx_combined_halpe.yaml with the
 interpenetration term, synthetic frames / model / part labels.  Not the bench headline."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
-import helpers as H, test_gpu_parity as T
+import _frames as FR
 from smplifyx_amd import driver, synthetic, engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 body_only = (len(sys.argv) > 2 and sys.argv[2] == "body")
 over = dict(interpenetration=True)
 if body_only: over.update(use_hands=False, use_face=False)
-cfg = H.load_cfg("fit_smplx_combined_halpe.yaml", **over)
+cfg = FR.load_cfg("fit_smplx_combined_halpe.yaml", **over)
 cfg["use_camera_prior"] = False
 m = synthetic.make_synthetic_model(0, surface=("soup" not in sys.argv))
 parts = synthetic.make_synthetic_parts(m)
-dm = T._dm(m, cfg)
+dm, jm = FR.device_model(m, cfg)
 dm.set_parts(parts["segm"], parts["parents"], cfg["ign_part_pairs"])
-K = len(H.joint_map_for(cfg))
-frames = synthetic.make_frames(B, H.oracle_joints_fn(m, cfg), K, focal=5000.0)
-jw = H.base_joint_weights(cfg, K)
+K = len(jm)
+frames = FR.frames(dm, jm, B)
+jw = FR.joint_weights(cfg, K)
 for pen in (False, True):
     c = dict(cfg); c["interpenetration"] = pen
     engine.prof_enable(True, every=4); engine.prof_reset()

@@ -1,14 +1,13 @@
-import sys, ctypes as C; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
-import numpy as np, torch, helpers as H, test_gpu_parity as T
+import os, sys, ctypes as C; sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np, torch, _frames as FR
 from smplifyx_amd import synthetic, _capi
 m = synthetic.make_synthetic_model(0)
 for which in ('body','full'):
-    cfg = H.load_cfg("fit_smplx_combined_coco25.yaml", use_hands=(which=='full'), use_face=(which=='full'))
-    dm = T._dm(m, cfg); B=256
-    fr = T.synth_frames(m, cfg, 3)
+    cfg = FR.load_cfg("fit_smplx_combined_coco25.yaml", use_hands=(which=='full'), use_face=(which=='full'), use_camera_prior=False)
+    dm, jm = FR.device_model(m, cfg); B=256
+    fr = FR.frames(dm, jm, 3)
     idx = [i%3 for i in range(B)]
-    fb = H.engine_batch_from_frames(dm, cfg, fr, idx, lbs_mode="rows")
-    fb.guess_init(cfg["body_tri_idxs"])
+    fb = FR.batch(dm, cfg, fr, idx, lbs_mode="rows")
     out = (C.c_int64*32)()
     for st in (-1, 1):
         _capi.check(_capi.load().sfx_debug_phase_clocks(fb._h, st, out))
@@ -19,10 +18,10 @@ for which in ('body','full'):
         print(which, 'stage', st, 'total cycles', t[16]-t[0], 'wall us', wall, 'phases', d.astype(int).tolist())
 
     # optimiser tick profile of frame 0 over a whole fit (rows path)
-    fb = H.engine_batch_from_frames(dm, cfg, fr, idx, lbs_mode="rows")
+    fb = FR.batch(dm, cfg, fr, idx, lbs_mode="rows")
     lib = _capi.load()
     _capi.check(lib.sfx_debug_clocks(fb._h, 1, None))
-    fb.guess_init(cfg["body_tri_idxs"]); fb.fit()
+    fb.fit()
     o64 = (C.c_int64*64)()
     _capi.check(lib.sfx_debug_clocks(fb._h, 0, o64))
     o = np.array(list(o64), np.float64); n = max(o[63], 1)
@@ -30,9 +29,9 @@ for which in ('body','full'):
           (o[33:40] / n).astype(int).tolist(), 'sum', int(o[33:40].sum() / n))
 
     # dense path: one k_tick_dense launch = [loss+adjoint of eval i] -> [tick] -> [pose/FK/export of eval i+1]
-    fb = H.engine_batch_from_frames(dm, cfg, fr, idx, lbs_mode="dense")
+    fb = FR.batch(dm, cfg, fr, idx, lbs_mode="dense")
     _capi.check(lib.sfx_debug_clocks(fb._h, 400, None))        # stamps of launch 400: first body stage, history full
-    fb.guess_init(cfg["body_tri_idxs"]); fb.fit(first_stage=-1, last_stage=0)
+    fb.fit(first_stage=-1, last_stage=0)
     _capi.check(lib.sfx_debug_clocks(fb._h, 0, o64))
     o = np.array(list(o64), np.float64)
     post = np.diff(o[40:57]); pre = np.diff(o[0:9])
