@@ -99,6 +99,44 @@ def cpu_baseline(model, cfg, frames, ref_evals_per_frame, budget_s=25.0):
                       "reference-equivalent evaluations per fitted frame" % (threads, dt, n[0], ref_evals_per_frame)}
 
 
+def reference_parity(model, lbs_mode):
+    """Second half of BASELINE's metric ("mean reprojection-loss delta vs reference"): the frames of
+    tests/golden/e2e_synth.npz were fitted by the REAL reference (smplifyx/fit_single_frame.py imported
+    in the build container, fp32 and fp64; tools/make_goldens.py); fit the same frames here and report
+    the relative difference of the final loss next to the reference's own fp32-vs-fp64 difference."""
+    from smplifyx_amd import cmd_parser, driver, engine, utils as U
+    path = os.path.join(ROOT, "tests", "golden", "e2e_synth.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    cfg = cmd_parser.load_config(os.path.join(ROOT, "cfg_files", "fit_smplx_combined_coco25.yaml"),
+                                 dict(interpenetration=False, visualize=False, interactive=False, save_vertices=False,
+                                      use_gender_classifier=False, use_hands=False, use_face=False))
+    cfg["use_camera_prior"] = False
+    jm = U.smpl_to_annotation("smplx", use_hands=False, use_face=False, use_face_contour=cfg["use_face_contour"],
+                              format=cfg["format"])
+    dm = engine.DeviceModel(model, joint_map=jm, num_betas=cfg["num_betas"],
+                            num_expression_coeffs=cfg["num_expression_coeffs"], num_pca_comps=cfg["num_pca_comps"],
+                            use_face_contour=cfg["use_face_contour"])
+    jw = np.ones(len(jm), np.float32)
+    ign = cfg.get("joints_to_ign")
+    if ign is not None and -1 not in ign:
+        jw[ign] = 0.0
+    n = g["keypoints"].shape[0]
+    res = driver.fit_frames(dm, cfg, g["keypoints"], jw, 600, 800, 5000.0, reg_pose=g["reg_pose"],
+                            reg_global=g["reg_global"], lbs_mode=lbs_mode, reuse_entry_eval=True)
+    ours = res["stage_loss"][:, -1]
+    r32 = np.array([g["f%d_f32_losses" % i][-1] for i in range(n)])
+    r64 = np.array([g["f%d_f64_losses" % i][-1] for i in range(n)])
+    cam = np.array([abs(res["stage_loss"][i, 0] - g["f%d_f32_losses" % i][0]) / abs(g["f%d_f32_losses" % i][0]) for i in range(n)])
+    return {"frames": int(n), "source": "tests/golden/e2e_synth.npz: reference fit_single_frame (fp32 / fp64) on the same frames",
+            "final_loss": [float(x) for x in ours], "reference_final_loss_f32": [float(x) for x in r32],
+            "final_loss_rel_delta_mean": float(np.mean(np.abs(ours - r32) / np.abs(r32))),
+            "reference_f32_vs_f64_rel_delta_mean": float(np.mean(np.abs(r32 - r64) / np.abs(r64))),
+            "camera_stage_loss_rel_delta_max": float(cam.max()),
+            "note": "the optimisation is chaotic past the camera stage; the reference's own fp32-vs-fp64 difference is the yardstick"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,6 +322,10 @@ def main():
                                        "L-BFGS chain; the meaningful figure is frames/s"}
         if alt is not None:
             out["alt"] = alt
+        try:
+            out["reference_parity"] = reference_parity(model, args.lbs)
+        except Exception as e:
+            out["reference_parity"] = {"error": repr(e)}
         if not args.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(model, cfg, frames, float(ref_evals.mean()))
