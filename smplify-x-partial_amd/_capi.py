@@ -84,6 +84,7 @@ SYMBOLS = {
     "sfx_pen_destroy": (None, [C.c_void_p]),
     "sfx_pen_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sfx_pen_stats": (C.c_int, [C.c_void_p, C.c_int32, i32p]),
+    "sfx_pen_phase_clocks": (C.c_int, [C.c_void_p, C.c_int32, i32p]),
     "sfx_debug_clocks": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "sfx_prof_enable": (C.c_int, [C.c_int32]),
     "sfx_prof_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

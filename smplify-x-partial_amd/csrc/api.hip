@@ -114,6 +114,9 @@ extern "C" void sfx_pen_destroy(sfx_pen* h);
 extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
                             float* loss_dev, float* dverts_dev, void* stream);
 extern "C" int sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host);
+int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
+                        float* loss_dev, float* dverts_dev, const int* want_dev, void* stream);
+const int* sfx_pen_pair_totals(const sfx_pen* h);
 
 struct sfx_model {
     DevModel M{};
@@ -535,6 +538,7 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
         D.pen_loss = b->mem.zeros<float>(B);
         D.pen_dverts = b->mem.zeros<float>((size_t)B * m->M.V * 3);
         D.ext_n = b->mem.zeros<int>(B);
+        D.pen_want = b->mem.zeros<int>(B);
         D.ext_vid = b->mem.zeros<int>((size_t)B * SFX_EXT_CAP);
     }
     D.joints = b->mem.zeros<float>((size_t)B * K * 3);
@@ -689,10 +693,11 @@ extern "C" int sfx_batch_num_vars(sfx_batch* b, int32_t stage) {
 // one closure evaluation of every (active) frame; stage_override = -2 -> per-frame stage[]
 // vertices with a nonzero penetration gradient, ascending ids, per GEMM column (slot)
 __global__ __launch_bounds__(256)
-void k_pen_compact(BatchDev D, int V) {
+void k_pen_compact(BatchDev D, int V, const int* __restrict__ totals) {
     __shared__ int s_base;
     __shared__ int s_cnt[4];
     const int slot = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (!D.pen_want[slot] || totals[slot] == 0) { if (t == 0) D.ext_n[slot] = 0; return; }
     const float* g = D.pen_dverts + (size_t)slot * V * 3;
     int* out = D.ext_vid + (size_t)slot * SFX_EXT_CAP;
     if (t == 0) s_base = 0;
@@ -716,13 +721,24 @@ void k_pen_compact(BatchDev D, int V) {
 
 // penetration term of the pending evaluation of every active frame (after the dense LBS wrote the
 // vertices, before the loss / adjoint pass reads pen_loss, pen_dverts and the vertex lists)
-static int eval_penetration(sfx_batch* b, hipStream_t s) {
+// which GEMM columns hold a frame whose pending evaluation carries a collision weight (fitting.py:437:
+// the term is only evaluated while coll_loss_weight > 0)
+__global__ void k_pen_want(BatchDev D, const StageW* __restrict__ sws, int stage_override) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= D.cfg.B) return;
+    const int st = stage_override != -2 ? stage_override : D.stage[b];
+    if (st >= 0 && st < D.cfg.n_stages) D.pen_want[D.slot[b]] = sws[st].coll > 0.f;
+}
+
+static int eval_penetration(sfx_batch* b, int stage_override, hipStream_t s) {
     const BatchDev& D = b->D;
     if (!b->pen || D.nact <= 0) return 0;
     ProfScope p("penetration", s, D.nact);
-    int rc = sfx_pen_eval(b->pen, D.nact, D.verts, b->pen_sigma, b->pen_outside, D.pen_loss, D.pen_dverts, s);
+    hipMemsetAsync(D.pen_want, 0, (size_t)D.cfg.B * sizeof(int), s);
+    hipLaunchKernelGGL(k_pen_want, dim3((D.cfg.B + 63) / 64), dim3(64), 0, s, D, b->sw_dev, stage_override);
+    int rc = sfx_pen_eval_masked(b->pen, D.nact, D.verts, b->pen_sigma, b->pen_outside, D.pen_loss, D.pen_dverts, D.pen_want, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_pen_compact, dim3(D.nact), dim3(256), 0, s, D, b->m->M.V);
+    hipLaunchKernelGGL(k_pen_compact, dim3(D.nact), dim3(256), 0, s, D, b->m->M.V, sfx_pen_pair_totals(b->pen));
     return 0;
 }
 
@@ -736,7 +752,7 @@ static void eval_closure(sfx_batch* b, int stage_override, int from_X, hipStream
         ClosureArgs e = a; e.export_dense = 1; e.forward_only = 2;
         { ProfScope p("export", s); launch_closure(M, D, b->vl_dev, b->sw_dev, e, s); }
         { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
-        eval_penetration(b, s);
+        eval_penetration(b, stage_override, s);
         a.use_dense_verts = 1;
     }
     ProfScope p("closure", s);
@@ -819,7 +835,7 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
         } else if (fused) {
             for (int q = 0; q < 8; ++q, ++tick) {
                 { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
-                if (int rc = eval_penetration(b, s)) return rc;
+                if (int rc = eval_penetration(b, -2, s)) return rc;
                 ProfScope p("tick", s);
                 launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 1, s);
             }
@@ -920,7 +936,7 @@ extern "C" int sfx_fit_multi(sfx_batch** bs, int32_t n, int32_t first_stage, int
                 sfx_batch* b = bs[g];
                 if (prev >= 0 && prev != g) hipStreamWaitEvent(st[g], ev[prev], 0);   // GEMMs back to back
                 { ProfScope p("lbs_dense", st[g], b->D.nact); launch_lbs_dense(b->m->M, b->D, st[g]); }
-                if (int rc = eval_penetration(b, st[g])) return rc;
+                if (int rc = eval_penetration(b, -2, st[g])) return rc;
                 hipEventRecord(ev[g], st[g]);
                 prev = g;
                 ProfScope p("tick", st[g]);

@@ -12,21 +12,24 @@
 //   k_pen_pairs   triangle AABBs -> bounding box per body part: a triangle whose box meets the box of
 //                 no part it may collide with is dropped (in most poses nearly all of them) -> the
 //                 rest enters a uniform grid (cell = twice the mean triangle extent, every cell the
-//                 AABB touches) hashed into 8192 LDS buckets by a counting sort -> pair tests run
+//                 AABB touches) hashed into 16384 LDS buckets by a counting sort -> pair tests run
 //                 over blocks of 64 consecutive entries of the bucket-sorted list: each lane holds
 //                 one entry (AABB, vertex ids, part, cell), the same 64 headers sit in a
-//                 wavefront-private LDS tile and are read back by broadcast, so memory is touched
-//                 once per ENTRY, not per pair.  Tests in order: same cell, part mask (one 64-bit
+//                 wavefront-private LDS tile, and lane i walks the entries after it in its bucket,
+//                 so memory is touched once per ENTRY, not per pair.  Tests in order: same cell, part mask (one 64-bit
 //                 word), AABB overlap, ownership by the cell of the intersection's low corner,
 //                 shared vertices.  Accepted pairs are queued per wavefront and appended to both
 //                 triangles' partner lists 64 at a time.
-//   k_pen_eval    one lane per triangle: partners visited in ascending index (selection, no
-//                 sorting), conic distance field evaluated with forward-mode dual numbers -- the
-//                 lane differentiates with respect to ITS OWN 9 coordinates only, once as receiver
-//                 geometry and once as intruding points -- so every write has one owner: no atomics
-//                 in the arithmetic, results independent of scheduling and of batch composition.
-//   k_pen_gather  vertex gradient = fixed-order sum over the incident triangle corners (CSR);
-//                 frame loss = fixed-order block reduction.
+//                 The lists are then ranked into the frame's pair list (triangles ascending,
+//                 partners ascending), which fixes every later summation order.
+//   k_pen_eval    one lane per ORDERED pair of that list: conic distance field evaluated with
+//                 forward-mode dual numbers -- the lane differentiates with respect to the OWNER's 9
+//                 coordinates only, once as receiver geometry and once as intruding points -- so
+//                 every number has one owner: no atomics in the arithmetic, results independent of
+//                 scheduling and of batch composition, and the work is balanced over the chip however
+//                 unevenly the collisions are spread over the triangles.
+//   k_pen_gather  vertex gradient = fixed-order sum over the incident triangle corners (CSR) and
+//                 their pair ranges; frame loss = fixed-order reduction over the pair list.
 #include "../../include/sfx.h"
 #include "sfx_internal.h"
 #include "wave_ops.h"
@@ -35,10 +38,13 @@
 #include <vector>
 
 #define PEN_T 1024
-#define PEN_GRID_INTS (((2 * (PEN_CELLS + 1) + 3) / 4) * 4)
+#define PEN_GRID_INTS ((((PEN_CELLS + 1) + 3) / 4) * 4)
 #define PEN_SPAN 8              // cells per axis one triangle may be entered in (a sane triangle spans 1-3; an exploded
                                 // mesh -- diverged fit, NaN / huge coordinates -- must not turn into 10^9 cell visits)
-#define PEN_CELLS 8192          // hash buckets of the grid: histogram + cursors = 2 x 32 KB of LDS (+ 48 KB of wavefront tiles)
+#define PEN_STATS 16
+#define PEN_EVAL_BLOCKS 32      // workgroups per frame of the pair evaluation (grid-stride over the pair list)
+#define PEN_CELLS 16384         // hash buckets of the grid: one 64-KB LDS array serves as histogram, start offsets and
+                                // scatter cursors (+ 48 KB of wavefront tiles, 16 KB of pair queues)
 
 struct PenDev {
     int V, F, cap, n_parts;
@@ -54,9 +60,13 @@ struct PenDev {
     int ent_cap;
     int* partners;             // [B][F][cap]
     int* pcount;               // [B][F]
-    float* tloss;              // [B][F]
-    float* tgrad;              // [B][F][9]
-    int* stats;                // [B][4]: pairs (ordered), overflow of cap, overflow of entries, cells
+    int* poff;                 // [B][F] start of the triangle's partner range in the frame's pair list
+    int* pown;                 // [B][pair_cap] pair list: receiving triangle (ascending) ...
+    int* plist;                // [B][pair_cap] ... and its partner (ascending within the triangle)
+    int pair_cap;
+    float* pout;               // [B][10][pair_cap] per ordered pair: gradient w.r.t. the owner's 9 coordinates, loss
+    int* ptotal;               // [B] ordered pairs in the list
+    int* stats;                // [B][PEN_STATS]: pairs (ordered), dropped partners, overflow of entries, cells, phase clocks
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -145,12 +155,35 @@ __device__ __forceinline__ float block_sum_fixed(float v, float* red) {
     return r;
 }
 
+// exclusive prefix sum over the PEN_T lanes of the block (fixed order); *total = sum of all
+__device__ __forceinline__ int block_excl_scan(const int v, int* wsum /* [PEN_T / 64] */, int* total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    __syncthreads();
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int i = 0; i < PEN_T / 64; ++i) { const int x = wsum[i]; if (i < wv) base += x; tot += x; }
+    *total = tot;
+    return base + inc - v;
+}
+
 __global__ __launch_bounds__(PEN_T)
-void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
+void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B, const int* __restrict__ want) {
     extern __shared__ int cell_cnt[];           // [ncell + 1]: histogram, then start offsets, then cursors
     __shared__ float red[PEN_T / 64];
     __shared__ int s_total;
+    __shared__ int slice[PEN_T];
     const int b = blockIdx.x, t = threadIdx.x;
+    int* st = P.stats + b * PEN_STATS;
+    if (want && !want[b]) {                     // the frame's stage carries no collision weight: nothing to do
+        if (t == 0) { P.ptotal[b] = 0; st[0] = st[1] = st[2] = st[3] = 0; }
+        return;
+    }
+    const long long clk0 = wall_clock64();
+#define PEN_CLK(i) if (t == 0) st[4 + (i)] = (int)(wall_clock64() - clk0)
     const float* vb = verts + (size_t)b * P.V * 3;
     float* aabb = P.aabb + (size_t)b * P.F * 6;
     const int F = P.F;
@@ -175,8 +208,10 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
                                       lo[e] = fminf(lo[e], a[e]); hi[e] = fmaxf(hi[e], c[e]); }
         ext_sum += fmaxf(fmaxf(c[0] - a[0], c[1] - a[1]), c[2] - a[2]);
     }
+    PEN_CLK(0);
     float glo[3], ghi[3];
     for (int e = 0; e < 3; ++e) { glo[e] = block_min(lo[e], red); ghi[e] = block_max(hi[e], red); }
+    PEN_CLK(1);
     // ---- part-level broad phase: bounding box of every part; a triangle whose box meets the box of
     // no part it may collide with cannot have a partner and never enters the grid (at rest and in most
     // poses that is nearly every triangle: the grid only sees the regions where unrelated parts meet)
@@ -189,20 +224,40 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
         for (int e = 0; e < 3; ++e) { atomicMin(&s_pbox[pf][e], ford(aabb[f * 6 + e])); atomicMax(&s_pbox[pf][3 + e], ford(aabb[f * 6 + 3 + e])); }
     }
     __syncthreads();
+    PEN_CLK(2);
     unsigned char* alive = reinterpret_cast<unsigned char*>(P.ent_cell + (size_t)b * P.ent_cap + P.ent_cap - (F + 3) / 4);   // tail of the entry buffer
+    // parts whose boxes meet and that may collide, as one 64-bit word per part
+    __shared__ unsigned long long s_near[64];
+    if (t < 64) {
+        unsigned long long m = 0;
+        if (t < P.n_parts && s_pbox[t][0] <= s_pbox[t][3]) {
+            const unsigned long long sk = s_mask[t];
+            for (int q = 0; q < P.n_parts; ++q) {
+                const bool meet = s_pbox[t][0] <= s_pbox[q][3] && s_pbox[q][0] <= s_pbox[t][3] && s_pbox[t][1] <= s_pbox[q][4] &&
+                                  s_pbox[q][1] <= s_pbox[t][4] && s_pbox[t][2] <= s_pbox[q][5] && s_pbox[q][2] <= s_pbox[t][5];
+                if (meet && !((sk >> q) & 1ull)) m |= 1ull << q;
+            }
+        }
+        s_near[t] = m;
+    }
+    __syncthreads();
     for (int f = t; f < F; f += PEN_T) {
-        const unsigned long long sk = s_mask[P.segm[f]];
-        int a6[6];
-        for (int e = 0; e < 3; ++e) { a6[e] = ford(aabb[f * 6 + e]); a6[3 + e] = ford(aabb[f * 6 + 3 + e]); }
+        unsigned long long nm = s_near[P.segm[f]];
         bool any = false;
-        for (int q = 0; q < P.n_parts && !any; ++q) {
-            if ((sk >> q) & 1ull) continue;
-            any = a6[0] <= s_pbox[q][3] && s_pbox[q][0] <= a6[3] && a6[1] <= s_pbox[q][4] && s_pbox[q][1] <= a6[4] &&
-                  a6[2] <= s_pbox[q][5] && s_pbox[q][2] <= a6[5];
+        if (nm) {
+            int a6[6];
+            for (int e = 0; e < 3; ++e) { a6[e] = ford(aabb[f * 6 + e]); a6[3 + e] = ford(aabb[f * 6 + 3 + e]); }
+            while (nm && !any) {
+                const int q = __ffsll((long long)nm) - 1;
+                nm &= nm - 1;
+                any = a6[0] <= s_pbox[q][3] && s_pbox[q][0] <= a6[3] && a6[1] <= s_pbox[q][4] && s_pbox[q][1] <= a6[4] &&
+                      a6[2] <= s_pbox[q][5] && s_pbox[q][2] <= a6[5];
+            }
         }
         alive[f] = any ? 1 : 0;
     }
     __syncthreads();
+    PEN_CLK(3);
     const float mean_ext = block_sum_fixed(ext_sum, red) / (float)F;
     // cell size: twice the mean triangle extent; cells are addressed by integer coordinates from
     // the low corner of the frame's bounding box and hashed into PEN_CELLS buckets (a bucket that
@@ -213,70 +268,95 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
     auto cell_of = [&](float x, int e) { return min(1 << 20, max(0, (int)fminf((x - glo[e]) * ih, 1048576.f))); };
     auto bucket = [](int x, int y, int z) { return (int)(((unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u) & (PEN_CELLS - 1)); };
     (void)ghi;
-    // ---- counting sort of (cell, triangle) entries
+    // ---- which parts are present in each bucket (folded to 32 bits; the wavefront tiles are not in
+    // use yet and lend their 64 KB): a triangle only enters a cell that also holds a part it may
+    // collide with -- the crowded interior of a limb, and joints where only parent and child meet,
+    // never reach the pair tests
+    static_assert((PEN_T / 64) * (64 * 12 + 256) >= PEN_CELLS, "part masks borrow the tile / queue area");
+    unsigned* pmask = reinterpret_cast<unsigned*>(cell_cnt + PEN_GRID_INTS);
+    __shared__ unsigned s_coll32[64];
+    if (t < 64) {
+        unsigned m = 0;
+        if (t < P.n_parts) for (int q = 0; q < P.n_parts; ++q) if (!((s_mask[t] >> q) & 1ull)) m |= 1u << (q & 31);
+        s_coll32[t] = m;
+    }
     for (int c = t; c <= ncell; c += PEN_T) cell_cnt[c] = 0;
+    for (int c = t; c < ncell; c += PEN_T) pmask[c] = 0u;
     __syncthreads();
     for (int f = t; f < F; f += PEN_T) {
         if (!alive[f]) continue;
+        const unsigned bit = 1u << (P.segm[f] & 31);
         int c0[3], c1[3];
         for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = min(cell_of(aabb[f * 6 + 3 + e], e), c0[e] + PEN_SPAN - 1); }
         for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x)
-            atomicAdd(&cell_cnt[bucket(x, y, z)], 1);
+            atomicOr(&pmask[bucket(x & 1023, y & 1023, z & 1023)], bit);
     }
     __syncthreads();
+    // ---- counting sort of (cell, triangle) entries
+    for (int f = t; f < F; f += PEN_T) {
+        if (!alive[f]) continue;
+        const unsigned want32 = s_coll32[P.segm[f]];
+        int c0[3], c1[3];
+        for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = min(cell_of(aabb[f * 6 + 3 + e], e), c0[e] + PEN_SPAN - 1); }
+        for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x) {
+            const int bk = bucket(x & 1023, y & 1023, z & 1023);
+            if (pmask[bk] & want32) atomicAdd(&cell_cnt[bk], 1);
+        }
+    }
+    __syncthreads();
+    PEN_CLK(4);
     // exclusive scan over the cells: each lane owns a contiguous slice
     {
         const int per = (ncell + PEN_T - 1) / PEN_T;
         const int c0 = min(ncell, t * per), c1 = min(ncell, c0 + per);
         int s = 0;
         for (int c = c0; c < c1; ++c) s += cell_cnt[c];
-        // block exclusive scan of the slice sums (fixed order)
-        __shared__ int slice[PEN_T];
-        slice[t] = s;
-        __syncthreads();
-        if (t == 0) { int acc = 0; for (int i = 0; i < PEN_T; ++i) { const int v = slice[i]; slice[i] = acc; acc += v; } s_total = acc; }
-        __syncthreads();
-        int acc = slice[t];
+        int tot;
+        int acc = block_excl_scan(s, slice, &tot);
         for (int c = c0; c < c1; ++c) { const int v = cell_cnt[c]; cell_cnt[c] = acc; acc += v; }
+        if (t == 0) { cell_cnt[ncell] = tot; s_total = tot; }
         __syncthreads();
-        if (t == 0) cell_cnt[ncell] = s_total;
     }
     __syncthreads();
+    PEN_CLK(5);
     int* ent = P.entries + (size_t)b * P.ent_cap;
     int* entc = P.ent_cell + (size_t)b * P.ent_cap;
     // a bucket may mix several cells (and one triangle may sit in it twice, once per cell): entries
     // carry the cell they were made for, and a scan only looks at those of its own cell
     auto cell_key = [](int x, int y, int z) { return (x & 1023) | ((y & 1023) << 10) | ((z & 1023) << 20); };
-    int* st = P.stats + b * 4;
     const bool ent_ok = s_total <= P.ent_cap - (F + 3) / 4 - 4;
-    if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = ncell; }
+    if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = ncell; st[14] = s_total; }
     if (!ent_ok) {       // grid too crowded for the entry buffer: report, produce no pairs
         for (int f = t; f < F; f += PEN_T) P.pcount[(size_t)b * F + f] = 0;
-        if (t == 0) { st[0] = 0; st[1] = 0; }
+        if (t == 0) { st[0] = 0; st[1] = 0; P.ptotal[b] = 0; }
         return;
     }
-    // scatter with per-cell cursors kept in a second LDS array
-    int* cursor = cell_cnt + (PEN_CELLS + 1);
-    for (int c = t; c < ncell; c += PEN_T) cursor[c] = cell_cnt[c];
-    __syncthreads();
+    // scatter: the start offsets double as cursors, so bucket c ends up holding its END offset
+    // (= the start of bucket c + 1); a bucket's entries are [c ? cell_cnt[c - 1] : 0, cell_cnt[c])
     for (int f = t; f < F; f += PEN_T) {
         if (!alive[f]) continue;
+        const unsigned want32 = s_coll32[P.segm[f]];
         int c0[3], c1[3];
         for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = min(cell_of(aabb[f * 6 + 3 + e], e), c0[e] + PEN_SPAN - 1); }
-        for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x)
-            { const int q = atomicAdd(&cursor[bucket(x, y, z)], 1);
-              ent[q] = f | (P.segm[f] << 24);     // triangle | part << 24
-              entc[q] = cell_key(x, y, z); }
+        for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x) {
+            const int bk = bucket(x & 1023, y & 1023, z & 1023);
+            if (!(pmask[bk] & want32)) continue;
+            const int q = atomicAdd(&cell_cnt[bk], 1);
+            ent[q] = f | (P.segm[f] << 24);     // triangle | part << 24
+            entc[q] = cell_key(x, y, z);
+        }
     }
     __threadfence_block();
     __syncthreads();
+    PEN_CLK(6);
 
-    // ---- pairs, bucket by bucket.  A wavefront takes a bucket: its lanes hold one entry each
-    // (header = AABB, vertex ids, part, cell) and the same 64 headers sit in a wavefront-private LDS
-    // tile; lane i then tests itself against entries k > i read from the tile by broadcast.  All
-    // memory traffic is one gather per ENTRY; the pair tests run on registers and LDS.  A pair is
-    // accepted in the cell that holds the low corner of the AABB intersection (both triangles are
-    // entered there), and appended to both triangles' partner lists.
+    // ---- pairs.  A wavefront takes 64 consecutive entries of the bucket-sorted list: its lanes hold
+    // one entry each (header = AABB, vertex ids, part, cell) and the same 64 headers sit in a
+    // wavefront-private LDS tile (three int4 arrays: lane i reading entry i + d is conflict-free);
+    // lane i tests itself against the entries after it in its bucket.  All memory traffic is one
+    // gather per ENTRY; the pair tests run on registers and LDS.  A pair is accepted in the cell that
+    // holds the low corner of the AABB intersection (both triangles are entered there), and appended
+    // to both triangles' partner lists.
     const int lane = t & 63, wv = t >> 6;
     int* tile = cell_cnt + PEN_GRID_INTS + wv * 64 * 12;          // 16-byte aligned
     int* pc = P.pcount + (size_t)b * F;
@@ -290,9 +370,8 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
         for (int e = 0; e < 3; ++e) hd[8 + e] = ok ? P.faces[f * 3 + e] : -1 - e;
         hd[11] = 0;
     };
-    // work items are blocks of 64 consecutive entries of the bucket-sorted list (NOT whole buckets:
-    // a crowded bucket is shared by many wavefronts); the partners of an entry lie between it and the
-    // end of its bucket, and the cell key comparison keeps different cells of one bucket apart
+    // (blocks of 64 entries, NOT whole buckets: a crowded bucket is shared by many wavefronts; the
+    // cell key comparison keeps different cells of one bucket apart)
     int* queue = cell_cnt + PEN_GRID_INTS + (PEN_T / 64) * 64 * 12 + wv * 256;      // 128 pairs per wavefront
     int qn = 0;
     auto flush_queue = [&](int n) {
@@ -305,6 +384,9 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
         }
         __builtin_amdgcn_wave_barrier();
     };
+    int4* tA = reinterpret_cast<int4*>(tile);        // [64] entry | cell | lo.x | lo.y
+    int4* tB = tA + 64;                              // [64] lo.z | hi.x | hi.y | hi.z
+    int4* tC = tA + 128;                             // [64] vertex ids
     for (int i0 = wv * 64; i0 < s_total; i0 += PEN_T) {
         const int qi = i0 + lane;
         const bool vi = qi < s_total;
@@ -315,93 +397,141 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B) {
         float ai[6];
 #pragma unroll
         for (int e = 0; e < 6; ++e) ai[e] = __int_as_float(hi_[2 + e]);
-        // end of the bucket that holds the block's last entry
-        const int klast = __builtin_amdgcn_readfirstlane(entc[min(i0 + 63, s_total - 1)]);
-        const int jend = __builtin_amdgcn_readfirstlane(cell_cnt[bucket(klast & 1023, (klast >> 10) & 1023, (klast >> 20) & 1023) + 1]);
-        for (int j0 = i0; j0 < jend; j0 += 64) {
-            int hj[12];
-            if (j0 == i0) {
-#pragma unroll
-                for (int e = 0; e < 12; ++e) hj[e] = hi_[e];
-            } else load_hdr(j0 + lane, j0 + lane < jend, hj);
-#pragma unroll
-            for (int e = 0; e < 3; ++e)
-                *reinterpret_cast<int4*>(&tile[lane * 12 + e * 4]) = make_int4(hj[e * 4], hj[e * 4 + 1], hj[e * 4 + 2], hj[e * 4 + 3]);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
-            const int nj = min(64, jend - j0);
-            for (int k = 0; k < nj; ++k) {
-                const int4 h0 = *reinterpret_cast<const int4*>(&tile[k * 12]);
-                const int4 h1 = *reinterpret_cast<const int4*>(&tile[k * 12 + 4]);
-                const int4 h2 = *reinterpret_cast<const int4*>(&tile[k * 12 + 8]);
-                bool pass = vi && (j0 + k > qi) && h0.y == hi_[1] && !((skip_i >> (h0.x >> 24)) & 1ull);
-                const float kl0 = __int_as_float(h0.z), kl1 = __int_as_float(h0.w), kl2 = __int_as_float(h1.x);
-                const float kh0 = __int_as_float(h1.y), kh1 = __int_as_float(h1.z), kh2 = __int_as_float(h1.w);
-                pass = pass && ai[0] <= kh0 && kl0 <= ai[3] && ai[1] <= kh1 && kl1 <= ai[4] && ai[2] <= kh2 && kl2 <= ai[5];
-                if (pass) {
-                    pass = cell_key(cell_of(fmaxf(ai[0], kl0), 0), cell_of(fmaxf(ai[1], kl1), 1), cell_of(fmaxf(ai[2], kl2), 2)) == hi_[1];
-                    const int g0 = h2.x, g1 = h2.y, g2 = h2.z;
-                    pass = pass && !(g0 == hi_[8] || g0 == hi_[9] || g0 == hi_[10] || g1 == hi_[8] || g1 == hi_[9] || g1 == hi_[10] ||
-                                     g2 == hi_[8] || g2 == hi_[9] || g2 == hi_[10]);
-                }
-                // accepted pairs go to a wavefront-private queue and are appended to the partner lists
-                // 64 at a time: the list cursors are returning atomics, one memory round trip each
-                const unsigned long long m = __ballot(pass);
-                if (m) {
-                    const int pos = qn + __popcll(m & ((1ull << lane) - 1ull));
-                    if (pass) { queue[2 * pos] = fi; queue[2 * pos + 1] = h0.x & 0xffffff; }
-                    qn += __popcll(m);
-                    if (qn >= 64) { flush_queue(qn); qn = 0; }
-                }
+        // partners of an entry: the entries after it up to the end of ITS bucket (buckets hold a few
+        // entries, so this per-lane walk takes as many steps as the fullest bucket of the block)
+        const int ck = hi_[1];
+        const int bend = vi ? cell_cnt[bucket(ck & 1023, (ck >> 10) & 1023, (ck >> 20) & 1023)] : 0;
+        tA[lane] = make_int4(hi_[0], hi_[1], hi_[2], hi_[3]);
+        tB[lane] = make_int4(hi_[4], hi_[5], hi_[6], hi_[7]);
+        tC[lane] = make_int4(hi_[8], hi_[9], hi_[10], 0);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+        for (int d = 1; ; ++d) {
+            const int k = qi + d;
+            const bool act = k < bend;
+            if (!__ballot(act)) break;
+            const int kl = min(lane + d, 63);
+            int4 h0 = tA[kl], h1 = tB[kl], h2 = tC[kl];
+            if (act && lane + d > 63) {          // the bucket runs past this block's tile: fetch from memory (rare)
+                int hg[12];
+                load_hdr(k, true, hg);
+                h0 = make_int4(hg[0], hg[1], hg[2], hg[3]); h1 = make_int4(hg[4], hg[5], hg[6], hg[7]); h2 = make_int4(hg[8], hg[9], hg[10], 0);
             }
-            __builtin_amdgcn_wave_barrier();
+            bool pass = act && h0.y == ck && !((skip_i >> (h0.x >> 24)) & 1ull);
+            const float kl0 = __int_as_float(h0.z), kl1 = __int_as_float(h0.w), kl2 = __int_as_float(h1.x);
+            const float kh0 = __int_as_float(h1.y), kh1 = __int_as_float(h1.z), kh2 = __int_as_float(h1.w);
+            pass = pass && ai[0] <= kh0 && kl0 <= ai[3] && ai[1] <= kh1 && kl1 <= ai[4] && ai[2] <= kh2 && kl2 <= ai[5];
+            if (pass) {
+                pass = cell_key(cell_of(fmaxf(ai[0], kl0), 0), cell_of(fmaxf(ai[1], kl1), 1), cell_of(fmaxf(ai[2], kl2), 2)) == ck;
+                const int g0 = h2.x, g1 = h2.y, g2 = h2.z;
+                pass = pass && !(g0 == hi_[8] || g0 == hi_[9] || g0 == hi_[10] || g1 == hi_[8] || g1 == hi_[9] || g1 == hi_[10] ||
+                                 g2 == hi_[8] || g2 == hi_[9] || g2 == hi_[10]);
+            }
+            // accepted pairs go to a wavefront-private queue and are appended to the partner lists
+            // 64 at a time: the list cursors are returning atomics, one memory round trip each
+            const unsigned long long m = __ballot(pass);
+            if (m) {
+                const int pos = qn + __popcll(m & ((1ull << lane) - 1ull));
+                if (pass) { queue[2 * pos] = fi; queue[2 * pos + 1] = h0.x & 0xffffff; }
+                qn += __popcll(m);
+                if (qn >= 64) { flush_queue(qn); qn = 0; }
+            }
         }
+        __builtin_amdgcn_wave_barrier();
     }
     if (qn) flush_queue(qn);
     __threadfence();
     __syncthreads();
-    int n_pairs = 0, n_over = 0;
-    for (int f = t; f < F; f += PEN_T) {
-        const int cnt = pc[f];
-        n_pairs += min(cnt, P.cap); n_over += max(cnt - P.cap, 0);
-        pc[f] = min(cnt, P.cap);
+    PEN_CLK(7);
+    // ---- the frame's pair list: triangles ascending, partners ascending within a triangle (the
+    // partner lists were appended in scheduling order; ranking them here fixes every later summation
+    // order).  Lists longer than max_collisions, and pairs beyond pair_cap, are cut and counted.
+    int* poff = P.poff + (size_t)b * F;
+    {
+        const int per = (F + PEN_T - 1) / PEN_T;
+        const int f0 = min(F, t * per), f1 = min(F, f0 + per);
+        int sum = 0, n_over = 0;
+        for (int f = f0; f < f1; ++f) { const int cnt = pc[f]; n_over += max(cnt - P.cap, 0); sum += min(cnt, P.cap); }
+        int ptot;
+        int acc = block_excl_scan(sum, slice, &ptot);
+        for (int f = f0; f < f1; ++f) {
+            const int c = min(pc[f], P.cap);
+            const int keep = max(0, min(c, P.pair_cap - acc));
+            n_over += c - keep;
+            poff[f] = acc; pc[f] = c;            // readers cut at pair_cap: kept = clamp(pair_cap - poff, 0, pcount)
+            acc += c;
+        }
+        const float to = block_sum_fixed((float)n_over, red);
+        if (t == 0) { const int tot = min(ptot, P.pair_cap); P.ptotal[b] = tot; st[0] = tot; st[1] = (int)to; }
     }
-    const float tp = block_sum_fixed((float)n_pairs, red), to = block_sum_fixed((float)n_over, red);
-    if (t == 0) { st[0] = (int)tp; st[1] = (int)to; }
+    __threadfence();
+    __syncthreads();
+    PEN_CLK(8);
+    int* pown = P.pown + (size_t)b * P.pair_cap;
+    int* plist = P.plist + (size_t)b * P.pair_cap;
+    // 64 consecutive triangles at a time per wavefront; their list elements are dealt to the lanes
+    // (owner found by bisection of the 64 offsets in LDS), each lane ranks its element within its list
+    const int fper = (F + PEN_T / 64 - 1) / (PEN_T / 64);
+    const int flim = min(F, (wv + 1) * fper);
+    for (int fw = wv * fper; fw < flim; fw += 64) {
+        const int f = fw + lane;
+        const bool inr = f < flim;
+        const int c_l = inr ? pc[f] : 0, off_l = inr ? poff[f] : 0x3fffffff;
+        const int base = __builtin_amdgcn_readfirstlane(off_l);
+        const int lastv = min(63, flim - 1 - fw);
+        const int E = __builtin_amdgcn_readlane(off_l + c_l, lastv) - base;
+        __builtin_amdgcn_wave_barrier();
+        tile[lane] = off_l - base;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < E; e += 64) {
+            int l = 0;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) if (tile[l + d] <= e) l += d;      // last l with offset <= e
+            const int ff = fw + l, lo = tile[l], slot = e - lo, off = base + lo;
+            const int cc = pc[ff];
+            const int* mine = part + (size_t)ff * P.cap;
+            const int x = mine[slot];
+            int rank = 0;
+            for (int r = 0; r < cc; ++r) { const int y = mine[r]; rank += (y < x) || (y == x && r < slot); }
+            if (off + rank < P.pair_cap) { plist[off + rank] = x; pown[off + rank] = ff; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    PEN_CLK(9);
+#undef PEN_CLK
 }
 
+// one lane per ORDERED pair (f receives g, and f's vertices intrude into g): the lane differentiates
+// with respect to f's 9 coordinates only, so every number has one owner
 __global__ __launch_bounds__(256)
 void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int penalize_outside) {
-    const int b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= P.F) return;
+    const int b = blockIdx.y;
+    const int total = P.ptotal[b];
     const float* vb = verts + (size_t)b * P.V * 3;
-    const int cnt = P.pcount[(size_t)b * P.F + f];
-    float loss = 0.f, g9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (cnt > 0) {
-        float p[9];
-        for (int k = 0; k < 3; ++k) for (int e = 0; e < 3; ++e) p[k * 3 + e] = vb[(size_t)P.faces[f * 3 + k] * 3 + e];
-        // own geometry as duals over the 9 own coordinates (receiver role) and as constants (intruder role)
-        DVec<9> P0 = {dvar<9>(p[0], 0), dvar<9>(p[1], 1), dvar<9>(p[2], 2)};
-        DVec<9> P1 = {dvar<9>(p[3], 3), dvar<9>(p[4], 4), dvar<9>(p[5], 5)};
-        DVec<9> P2 = {dvar<9>(p[6], 6), dvar<9>(p[7], 7), dvar<9>(p[8], 8)};
-        DVec<9> o9, n9; Dual<9> r9;
-        cone_geometry(P0, P1, P2, o9, r9, n9);
-        const int* mine = P.partners + ((size_t)b * P.F + f) * P.cap;
-        int last = -1;
-        for (int it = 0; it < cnt; ++it) {
-            int g = 0x7fffffff;                          // next partner in ascending index
-            for (int q = 0; q < cnt; ++q) { const int c = mine[q]; if (c > last && c < g) g = c; }
-            if (g == 0x7fffffff) break;                  // (list exhausted: never with a consistent list)
-            last = g;
-            float qv[9];
-            for (int k = 0; k < 3; ++k) for (int e = 0; e < 3; ++e) qv[k * 3 + e] = vb[(size_t)P.faces[g * 3 + k] * 3 + e];
-            // (1) this triangle receives the partner's vertices
+    const int* pown = P.pown + (size_t)b * P.pair_cap;
+    const int* plist = P.plist + (size_t)b * P.pair_cap;
+    float* po = P.pout + (size_t)b * 10 * P.pair_cap;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int f = pown[i], g = plist[i];
+        float p[9], qv[9];
+        for (int k = 0; k < 3; ++k) for (int e = 0; e < 3; ++e) {
+            p[k * 3 + e] = vb[(size_t)P.faces[f * 3 + k] * 3 + e];
+            qv[k * 3 + e] = vb[(size_t)P.faces[g * 3 + k] * 3 + e];
+        }
+        float loss = 0.f, g9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        {   // (1) this triangle receives the partner's vertices: own geometry as duals over the 9 own coordinates
+            DVec<9> P0 = {dvar<9>(p[0], 0), dvar<9>(p[1], 1), dvar<9>(p[2], 2)};
+            DVec<9> P1 = {dvar<9>(p[3], 3), dvar<9>(p[4], 4), dvar<9>(p[5], 5)};
+            DVec<9> P2 = {dvar<9>(p[6], 6), dvar<9>(p[7], 7), dvar<9>(p[8], 8)};
+            DVec<9> o9, n9; Dual<9> r9;
+            cone_geometry(P0, P1, P2, o9, r9, n9);
             for (int k = 0; k < 3; ++k) {
                 const DVec<9> v = {dconst<9>(qv[k * 3]), dconst<9>(qv[k * 3 + 1]), dconst<9>(qv[k * 3 + 2])};
                 const Dual<9> pen = cone_penalty(o9, r9, n9, v, sigma, penalize_outside);
                 loss += pen.v;
-                for (int i = 0; i < 9; ++i) g9[i] += pen.d[i];
+                for (int j = 0; j < 9; ++j) g9[j] += pen.d[j];
             }
-            // (2) this triangle's vertices intrude into the partner's cone (partner geometry constant)
+        }
+        {   // (2) this triangle's vertices intrude into the partner's cone (partner geometry constant)
             DVec<3> Q0 = {dconst<3>(qv[0]), dconst<3>(qv[1]), dconst<3>(qv[2])};
             DVec<3> Q1 = {dconst<3>(qv[3]), dconst<3>(qv[4]), dconst<3>(qv[5])};
             DVec<3> Q2 = {dconst<3>(qv[6]), dconst<3>(qv[7]), dconst<3>(qv[8])};
@@ -413,29 +543,38 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
                 for (int e = 0; e < 3; ++e) g9[k * 3 + e] += pen.d[e];
             }
         }
+        for (int j = 0; j < 9; ++j) po[(size_t)j * P.pair_cap + i] = g9[j];
+        po[(size_t)9 * P.pair_cap + i] = loss;
     }
-    P.tloss[(size_t)b * P.F + f] = loss;
-    float* tg = P.tgrad + ((size_t)b * P.F + f) * 9;
-    for (int i = 0; i < 9; ++i) tg[i] = g9[i];
 }
 
+// vertex gradient = fixed-order sum over the incident triangle corners (CSR) and their pair ranges;
+// frame loss = fixed-order sum over the pair list
 __global__ __launch_bounds__(256)
-void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss_out) {
+void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss_out, const int* __restrict__ want) {
     __shared__ float red[4];
     const int b = blockIdx.y;
+    if (want && !want[b]) { if (blockIdx.x == 0 && threadIdx.x == 0) loss_out[b] = 0.f; return; }
     const int v = blockIdx.x * 256 + threadIdx.x;
+    const int total = P.ptotal[b];
+    const float* po = P.pout + (size_t)b * 10 * P.pair_cap;
     if (v < P.V) {
         float g[3] = {0.f, 0.f, 0.f};
-        const float* tg = P.tgrad + (size_t)b * P.F * 9;
-        for (int q = P.vf_start[v]; q < P.vf_start[v + 1]; ++q) {
-            const int fc = P.vf_list[q];
-            for (int e = 0; e < 3; ++e) g[e] += tg[(size_t)fc * 3 + e];     // fc = face * 3 + corner -> [face][corner][3]
+        if (total > 0) {
+            const int* poff = P.poff + (size_t)b * P.F;
+            const int* pc = P.pcount + (size_t)b * P.F;
+            for (int q = P.vf_start[v]; q < P.vf_start[v + 1]; ++q) {
+                const int fc = P.vf_list[q], face = fc / 3, corner = fc - face * 3;
+                const int off = poff[face], n = max(0, min(pc[face], P.pair_cap - off));
+                for (int i = off; i < off + n; ++i)
+                    for (int e = 0; e < 3; ++e) g[e] += po[(size_t)(corner * 3 + e) * P.pair_cap + i];
+            }
         }
         for (int e = 0; e < 3; ++e) dverts[((size_t)b * P.V + v) * 3 + e] = g[e];
     }
-    if (blockIdx.x == 0) {      // frame loss: fixed-order sum over the triangles
+    if (blockIdx.x == 0) {
         float s = 0.f;
-        for (int f = threadIdx.x; f < P.F; f += 256) s += P.tloss[(size_t)b * P.F + f];
+        for (int i = threadIdx.x; i < total; i += 256) s += po[(size_t)9 * P.pair_cap + i];
         s = wave_sum_dpp(s);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         __syncthreads();
@@ -501,8 +640,10 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     P.ent_cap = F * 32;
     P.aabb = h->zeros<float>(B * F * 6); P.entries = h->zeros<int>(B * P.ent_cap); P.ent_cell = h->zeros<int>(B * P.ent_cap);
     P.partners = h->zeros<int>(B * F * P.cap); P.pcount = h->zeros<int>(B * F);
-    P.tloss = h->zeros<float>(B * F); P.tgrad = h->zeros<float>(B * F * 9); P.stats = h->zeros<int>(B * 4);
-    if (!P.stats || !P.tgrad || !P.partners) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
+    P.pair_cap = (int)std::min<size_t>((size_t)F * P.cap, std::max<size_t>(65536, (size_t)16 * F));
+    P.poff = h->zeros<int>(B * F); P.pown = h->zeros<int>(B * P.pair_cap); P.plist = h->zeros<int>(B * P.pair_cap);
+    P.pout = h->zeros<float>(B * 10 * P.pair_cap); P.ptotal = h->zeros<int>(B); P.stats = h->zeros<int>(B * PEN_STATS);
+    if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.ptotal) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     *out = h;
     return 0;
 }
@@ -513,8 +654,10 @@ extern "C" void sfx_pen_destroy(sfx_pen* h) {
     delete h;
 }
 
-extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
-                            float* loss_dev, float* dverts_dev, void* stream) {
+const int* sfx_pen_pair_totals(const sfx_pen* h) { return h->P.ptotal; }
+
+int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
+                        float* loss_dev, float* dverts_dev, const int* want_dev, void* stream) {
     if (!h || !verts_dev || !loss_dev || !dverts_dev) { sfx_set_error("null argument"); return -1; }
     if (B < 1 || B > h->Bmax) { sfx_set_error("batch %d exceeds the capacity %d given to sfx_pen_create", B, h->Bmax); return -1; }
     if (!(sigma > 0.f)) { sfx_set_error("df_cone_height must be positive"); return -1; }
@@ -526,16 +669,34 @@ extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float
             sfx_set_error("cannot reserve %zu bytes of LDS", lds); return -2; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_pen_pairs, dim3(B), dim3(PEN_T), lds, s, h->P, verts_dev, B);
-    hipLaunchKernelGGL(k_pen_eval, dim3((h->P.F + 255) / 256, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside);
-    hipLaunchKernelGGL(k_pen_gather, dim3((std::max(h->P.V, 1) + 255) / 256, B), dim3(256), 0, s, h->P, dverts_dev, loss_dev);
+    hipLaunchKernelGGL(k_pen_pairs, dim3(B), dim3(PEN_T), lds, s, h->P, verts_dev, B, want_dev);
+    hipLaunchKernelGGL(k_pen_eval, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside);
+    hipLaunchKernelGGL(k_pen_gather, dim3((std::max(h->P.V, 1) + 255) / 256, B), dim3(256), 0, s, h->P, dverts_dev, loss_dev, want_dev);
     if (hipGetLastError() != hipSuccess) { sfx_set_error("penetration kernels failed to launch"); return -4; }
+    return 0;
+}
+
+extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
+                            float* loss_dev, float* dverts_dev, void* stream) {
+    return sfx_pen_eval_masked(h, B, verts_dev, sigma, penalize_outside, loss_dev, dverts_dev, nullptr, stream);
+}
+
+// debug: wall-clock ticks (100 MHz) at the end of k_pen_pairs' steps for the first B frames: [B][10] = triangle boxes,
+// frame box, part boxes, part culling, grid histogram, scan, scatter, pair tests, list offsets, ranked list; [10] = grid entries
+extern "C" int sfx_pen_phase_clocks(sfx_pen* h, int32_t B, int32_t* out) {
+    if (!h || !out || B < 1 || B > h->Bmax) return -1;
+    std::vector<int> st((size_t)B * PEN_STATS);
+    hipDeviceSynchronize();
+    hipMemcpy(st.data(), h->P.stats, st.size() * sizeof(int), hipMemcpyDeviceToHost);
+    for (int i = 0; i < B; ++i) for (int k = 0; k < 11; ++k) out[i * 11 + k] = st[(size_t)i * PEN_STATS + 4 + k];
     return 0;
 }
 
 extern "C" int sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host /* [B][4] */) {
     if (!h || !stats_host || B < 1 || B > h->Bmax) { sfx_set_error("bad arguments"); return -1; }
     if (hipDeviceSynchronize() != hipSuccess) { sfx_set_error("device error"); return -4; }
-    hipMemcpy(stats_host, h->P.stats, (size_t)B * 4 * sizeof(int), hipMemcpyDeviceToHost);
+    std::vector<int> st((size_t)B * PEN_STATS);
+    hipMemcpy(st.data(), h->P.stats, st.size() * sizeof(int), hipMemcpyDeviceToHost);
+    for (int i = 0; i < B; ++i) for (int k = 0; k < 4; ++k) stats_host[i * 4 + k] = st[(size_t)i * PEN_STATS + k];
     return 0;
 }

@@ -171,6 +171,7 @@ struct BatchDev {
     float* uT;              // [B][n_uniq][12] (slot-indexed) their skinning transforms
     float* pen_loss;        // [B] (slot-indexed) unweighted penetration loss of the pending evaluation
     float* pen_dverts;      // [B][V][3] (slot-indexed) its gradient with respect to the vertices
+    int*   pen_want;        // [B] (slot-indexed) 1 = the column's pending evaluation carries a collision weight
     int*   ext_n;           // [B] (slot-indexed) vertices with a nonzero penetration gradient ...
     int*   ext_vid;         // [B][SFX_EXT_CAP] ... and their ids, ascending
     float* fwd;             // [B][SFX_FWD_N] forward state handed from the export pass to the adjoint pass

@@ -406,6 +406,14 @@ class Penetration(object):
         capi.check(self._lib.sfx_pen_stats(self._h, int(B), capi.iptr(out)))
         return dict(pairs=out[:, 0].copy(), dropped=out[:, 1].copy(), entry_overflow=out[:, 2].copy(), cells=out[:, 3].copy())
 
+    def phase_clocks(self, B):
+        """Debug: microseconds at the end of the broad phase's ten steps, grid entries (see sfx_pen_phase_clocks)."""
+        out = np.zeros((B, 11), np.int32)
+        capi.check(self._lib.sfx_pen_phase_clocks(self._h, int(B), capi.iptr(out)))
+        res = out / 100.0
+        res[:, 10] = out[:, 10]
+        return res
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.sfx_pen_destroy(self._h)

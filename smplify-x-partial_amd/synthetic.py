@@ -86,7 +86,7 @@ def make_synthetic_model(seed=0, num_verts=NUM_VERTS, num_faces=NUM_FACES,
     interpenetrates everywhere.  surface=True moves every vertex onto a tube around its bone
     (same random draws, offset projected off the bone axis and normalised to the tube radius): the
     faces, built from near neighbours, then form surface patches, which is what collision handling
-    sees on a real body mesh."""
+    sees on a real body mesh; the blend shapes become smooth displacement fields for the same reason."""
     from scipy.spatial import cKDTree
     rng = np.random.RandomState(seed)
     V, F, J = num_verts, num_faces, NUM_JOINTS
@@ -147,6 +147,20 @@ def make_synthetic_model(seed=0, num_verts=NUM_VERTS, num_faces=NUM_FACES,
     shapedirs[:, :, 1] += 0.03 * v_template * np.array([1.0, 0.1, 1.0])
     shapedirs[:, :, 2] += 0.02 * v_template * np.array([1.0, 0.0, 0.0])
     posedirs = 0.001 * rng.normal(size=(V, 3, NUM_POSE_BASIS))
+    if surface:
+        # per-vertex white noise would shred the surface patches as soon as betas != 0; use smooth
+        # displacement fields (random plane waves, wavelength >= 0.4 m) of the same magnitude instead
+        r2 = np.random.RandomState(seed + 1000)
+
+        def smooth_field(n, amp):
+            k = r2.normal(size=(n, 3, 3)) * (2 * np.pi / 0.6)            # [n, component, xyz]
+            ph = r2.uniform(0, 2 * np.pi, size=(n, 3))
+            return amp * np.sin(np.einsum("vx,ncx->vcn", v_template, k) + ph.T[None])
+        shapedirs = smooth_field(20, 0.01 * np.sqrt(2.0))
+        shapedirs[:, :, 0] += 0.03 * v_template * np.array([0.3, 1.0, 0.3])
+        shapedirs[:, :, 1] += 0.03 * v_template * np.array([1.0, 0.1, 1.0])
+        shapedirs[:, :, 2] += 0.02 * v_template * np.array([1.0, 0.0, 0.0])
+        posedirs = smooth_field(NUM_POSE_BASIS, 0.001 * np.sqrt(2.0))
 
     # ---- faces: each vertex + two of its near neighbours ------------------------------
     _, nbr = tree.query(v_template, k=8)
