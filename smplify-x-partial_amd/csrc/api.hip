@@ -195,6 +195,14 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
             if (n > SFX_NW) wj[(size_t)v * SFX_NW] = -1;
         }
         M.Wsp_j = m->mem.up(wj); M.Wsp_w = m->mem.up(ww);
+        {   // transposed CSR: per joint the vertices it skins, ascending
+            std::vector<int> js(SFX_J + 1, 0), jv; std::vector<float> jw;
+            for (int j = 0; j < SFX_J; ++j) {
+                for (int v = 0; v < V; ++v) { const float w = W[(size_t)v * SFX_J + j]; if (w != 0.f) { jv.push_back(v); jw.push_back(w); } }
+                js[j + 1] = (int)jv.size();
+            }
+            M.jv_start = m->mem.up(js); M.jv_vid = m->mem.up(jv); M.jv_w = m->mem.up(jw);
+        }
         M.W = m->mem.up(W);
         M.WT = m->mem.up(WT);
         // per 16-vertex tile: the joints with any nonzero weight (ascending), weights in MFMA B layout
@@ -539,6 +547,12 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
         D.pen_dverts = b->mem.zeros<float>((size_t)B * m->M.V * 3);
         D.ext_n = b->mem.zeros<int>(B);
         D.pen_want = b->mem.zeros<int>(B);
+        D.vposed = b->mem.zeros<float>((size_t)B * m->M.V * 3);
+        D.adj_G = b->mem.zeros<float>((size_t)D.Bpad * 3 * m->M.Vpad);
+        D.adj_part = b->mem.zeros<float>((size_t)sfx_adj_slices(m->M) * SFX_KD_PAD * D.Bpad);
+        D.pen_dfeat = b->mem.zeros<float>((size_t)B * SFX_KD_PAD);
+        D.pen_dA = b->mem.zeros<float>((size_t)B * SFX_J * 12);
+        if (!D.adj_G || !D.adj_part || !D.vposed) { sfx_set_error("out of device memory"); b->mem.free_all(); delete b; return -2; }
         D.ext_vid = b->mem.zeros<int>((size_t)B * SFX_EXT_CAP);
     }
     D.joints = b->mem.zeros<float>((size_t)B * K * 3);
@@ -739,6 +753,7 @@ static int eval_penetration(sfx_batch* b, int stage_override, hipStream_t s) {
     int rc = sfx_pen_eval_masked(b->pen, D.nact, D.verts, b->pen_sigma, b->pen_outside, D.pen_loss, D.pen_dverts, D.pen_want, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pen_compact, dim3(D.nact), dim3(256), 0, s, D, b->m->M.V, sfx_pen_pair_totals(b->pen));
+    launch_pen_adjoint(b->m->M, D, s);
     return 0;
 }
 

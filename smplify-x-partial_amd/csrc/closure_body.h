@@ -705,39 +705,15 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     __syncthreads();
     };
     items_dfeat(NI, false);
-    // ---- interpenetration: every vertex with a nonzero penetration gradient is treated like an item
-    // (v_posed rows, skinning transform, then d v_posed -> dfeat and dT -> dA), a chunk at a time
+    // ---- interpenetration: its gradient lives on every vertex; lbs_adjoint.hip has already taken it
+    // back to feat and to the skinning transforms (adjoint GEMM), the chain adjoint below does the rest
     if (C.pen && args.use_dense_verts && !cam_stage && sw.coll > 0.f) {
         const int slot = D.slot[b];
-        const int nx = D.ext_n[slot];
-        const int* xv = D.ext_vid + (size_t)slot * SFX_EXT_CAP;
-        const float* xg = D.pen_dverts + (size_t)slot * M.V * 3;
-        constexpr int CH = LDS::kMaxItems;
-        for (int c0 = 0; c0 < nx; c0 += CH) {
-            const int ni = min(CH, nx - c0);
-            for (int w = t; w < ni; w += CT) S.ivid[w] = xv[c0 + w];
-            __syncthreads();
-            for (int w = t; w < ni * 3; w += CT) S.dvert[w] = sw.coll * xg[(size_t)S.ivid[w / 3] * 3 + w % 3];
-            items_forward(0, ni);
-            items_dvp(ni);
-            FOR_CT(w, SFX_J * 12) {          // dA[j][e] += sum_i W[v_i][j] * dvert_i[r] * [v_posed_i, 1][c]
-                const int j = w / 12, e = w % 12, r = e >> 2, c = e & 3;
-                float acc = 0.f;
-                for (int i = 0; i < ni; ++i) {
-                    const float dv = S.dvert[i * 3 + r];
-                    if (dv == 0.f) continue;
-                    float wgt = 0.f;
-                    if (S.wj[i * SFX_NW] >= 0) {
-#pragma unroll
-                        for (int q2 = 0; q2 < SFX_NW; ++q2) if (S.wj[i * SFX_NW + q2] == j) wgt += S.ww[i * SFX_NW + q2];
-                    } else wgt = M.W[(size_t)S.ivid[i] * SFX_J + j];
-                    if (wgt != 0.f) acc += wgt * (dv * (c < 3 ? S.vp[i * 3 + c] : 1.f));
-                }
-                S.dA[w] += acc;
-            }
-            __syncthreads();
-            items_dfeat(ni, true);
-        }
+        const float* pf = D.pen_dfeat + (size_t)slot * SFX_KD_PAD;
+        const float* pa = D.pen_dA + (size_t)slot * SFX_J * 12;
+        for (int k = t; k < SFX_KD_PAD; k += CT) S.dfeat[k] += sw.coll * pf[k];
+        for (int w = t; w < SFX_J * 12; w += CT) S.dA[w] += sw.coll * pa[w];
+        __syncthreads();
     }
     MARK(12);
     // adjoint of the kinematic chain without walking it level by level:

@@ -188,6 +188,14 @@ void k_lbs_dense(DevModel M, BatchDev D) {
         }
     }
 #undef AT_LOAD
+    if (vok && D.vposed) {      // interpenetration on: the adjoint of a gradient on every vertex needs every v_posed
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f0 = b0 + kq * 4 + r, f1 = f0 + 16;
+            if (f0 < B) { float* o = D.vposed + ((size_t)f0 * V + vtx) * 3; o[0] = ax0[r]; o[1] = ay0[r]; o[2] = az0[r]; }
+            if (f1 < B) { float* o = D.vposed + ((size_t)f1 * V + vtx) * 3; o[0] = ax1[r]; o[1] = ay1[r]; o[2] = az1[r]; }
+        }
+    }
     if (vok) {      // one 12-byte store per (frame, vertex): 16 lanes cover 192 contiguous bytes
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

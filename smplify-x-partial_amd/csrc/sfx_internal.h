@@ -75,6 +75,9 @@ struct DevModel {
     const int*   tj_n;         // [ntile16] joints used by the tile, padded to a multiple of 4 (<= JPAD)
     const int*   tj_list;      // [ntile16][JPAD] joint ids (padding: joint 0 with zero weights)
     const float* tj_w;         // [ntile16][JPAD][16] weights, row = list slot, col = vertex in tile
+    const int*   jv_start;     // [J+1] transposed CSR of lbs_weights: the vertices (ascending) skinned by joint j ...
+    const int*   jv_vid;       // [nnz]
+    const float* jv_w;         // [nnz] ... and their weights (adjoint of a gradient on every vertex, lbs_adjoint.hip)
     const int*   Wsp_j;        // [V][SFX_NW] joints of the nonzero weights (ascending), pad: j=0,w=0
     const float* Wsp_w;        // [V][SFX_NW]
     const float* J_template;   // [J][3]
@@ -171,6 +174,11 @@ struct BatchDev {
     float* uT;              // [B][n_uniq][12] (slot-indexed) their skinning transforms
     float* pen_loss;        // [B] (slot-indexed) unweighted penetration loss of the pending evaluation
     float* pen_dverts;      // [B][V][3] (slot-indexed) its gradient with respect to the vertices
+    float* vposed;          // [B][V][3] (slot-indexed) v_posed of every vertex, written by the dense GEMM when the term is on
+    float* adj_G;           // [Bpad][3*Vpad] (slot-indexed) d v_posed = T^T d verts: operand of the adjoint GEMM
+    float* adj_part;        // [slices][KD_PAD][Bpad] its per-slice partial sums
+    float* pen_dfeat;       // [B][KD_PAD] (slot-indexed) d pen_loss / d feat
+    float* pen_dA;          // [B][J][12] (slot-indexed) d pen_loss / d A
     int*   pen_want;        // [B] (slot-indexed) 1 = the column's pending evaluation carries a collision weight
     int*   ext_n;           // [B] (slot-indexed) vertices with a nonzero penetration gradient ...
     int*   ext_vid;         // [B][SFX_EXT_CAP] ... and their ids, ascending
@@ -203,6 +211,8 @@ static inline bool sfx_small_closure(const DevModel& M, const BatchDev& D) {
 }
 void launch_closure(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
                     const ClosureArgs& a, hipStream_t s);
+void launch_pen_adjoint(const DevModel& M, const BatchDev& D, hipStream_t s);
+int sfx_adj_slices(const DevModel& M);
 void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s);
 void launch_lbfgs_tick(const DevModel& M, const BatchDev& D, const VarList* vl_dev, int first_stage,
                        int last_stage, int init, int step_mode, hipStream_t s);
