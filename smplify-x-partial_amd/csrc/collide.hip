@@ -42,6 +42,8 @@
 #define PEN_SPAN 8              // cells per axis one triangle may be entered in (a sane triangle spans 1-3; an exploded
                                 // mesh -- diverged fit, NaN / huge coordinates -- must not turn into 10^9 cell visits)
 #define PEN_STATS 16
+#define PEN_WALK_BLOCKS 32      // workgroups (of 4 wavefronts) per frame of the pair tests: a frame whose limbs are pushed
+                                // through each other has 100x the candidates of a clean one, and must not hold up the launch
 #define PEN_EVAL_BLOCKS 32      // workgroups per frame of the pair evaluation (grid-stride over the pair list)
 #define PEN_CELLS 16384         // hash buckets of the grid: one 64-KB LDS array serves as histogram, start offsets and
                                 // scatter cursors (+ 48 KB of wavefront tiles, 16 KB of pair queues)
@@ -65,7 +67,11 @@ struct PenDev {
     int* plist;                // [B][pair_cap] ... and its partner (ascending within the triangle)
     int pair_cap;
     float* pout;               // [B][10][pair_cap] per ordered pair: gradient w.r.t. the owner's 9 coordinates, loss
+    float* tgrad;              // [B][F][9] per triangle: sum over its pairs (valid where pcount > 0)
+    float* tloss;              // [B][F]
     int* ptotal;               // [B] ordered pairs in the list
+    int* cells;                // [B][PEN_CELLS + 1] bucket END offsets into entries ([PEN_CELLS] = number of entries)
+    float* gridp;              // [B][4] low corner of the frame's box, 1 / cell size
     int* stats;                // [B][PEN_STATS]: pairs (ordered), dropped partners, overflow of entries, cells, phase clocks
 };
 
@@ -171,7 +177,7 @@ __device__ __forceinline__ int block_excl_scan(const int v, int* wsum /* [PEN_T 
 }
 
 __global__ __launch_bounds__(PEN_T)
-void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B, const int* __restrict__ want) {
+void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __restrict__ want) {
     extern __shared__ int cell_cnt[];           // [ncell + 1]: histogram, then start offsets, then cursors
     __shared__ float red[PEN_T / 64];
     __shared__ int s_total;
@@ -179,7 +185,7 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B, const int* __
     const int b = blockIdx.x, t = threadIdx.x;
     int* st = P.stats + b * PEN_STATS;
     if (want && !want[b]) {                     // the frame's stage carries no collision weight: nothing to do
-        if (t == 0) { P.ptotal[b] = 0; st[0] = st[1] = st[2] = st[3] = 0; }
+        if (t == 0) { P.ptotal[b] = 0; P.cells[(size_t)b * (PEN_CELLS + 1) + PEN_CELLS] = 0; st[0] = st[1] = st[2] = st[3] = 0; }
         return;
     }
     const long long clk0 = wall_clock64();
@@ -328,7 +334,7 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B, const int* __
     if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = ncell; st[14] = s_total; }
     if (!ent_ok) {       // grid too crowded for the entry buffer: report, produce no pairs
         for (int f = t; f < F; f += PEN_T) P.pcount[(size_t)b * F + f] = 0;
-        if (t == 0) { st[0] = 0; st[1] = 0; P.ptotal[b] = 0; }
+        if (t == 0) { st[0] = 0; st[1] = 0; P.ptotal[b] = 0; P.cells[(size_t)b * (PEN_CELLS + 1) + PEN_CELLS] = 0; }
         return;
     }
     // scatter: the start offsets double as cursors, so bucket c ends up holding its END offset
@@ -349,6 +355,39 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B, const int* __
     __threadfence_block();
     __syncthreads();
     PEN_CLK(6);
+    // hand the grid to the pair tests (k_pen_walk, several workgroups per frame)
+    int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
+    for (int c = t; c <= ncell; c += PEN_T) cells[c] = cell_cnt[c];
+    if (t == 0) { float* gp = P.gridp + b * 4; gp[0] = glo[0]; gp[1] = glo[1]; gp[2] = glo[2]; gp[3] = ih; }
+#undef PEN_CLK
+}
+
+
+// pair tests over the bucket-sorted entries of k_pen_grid; PEN_WALK_BLOCKS workgroups per frame
+__global__ __launch_bounds__(256)
+void k_pen_walk(PenDev P, const int* __restrict__ want) {
+    __shared__ __align__(16) int s_tile[4 * 64 * 12];
+    __shared__ int s_queue[4 * 256];
+    __shared__ unsigned long long s_mask[64];
+    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
+    const int s_total = cells[PEN_CELLS];
+    if ((want && !want[b]) || blockIdx.x * 256 >= s_total) return;
+    const int F = P.F;
+    const float* aabb = P.aabb + (size_t)b * F * 6;
+    const int* ent = P.entries + (size_t)b * P.ent_cap;
+    const int* entc = P.ent_cell + (size_t)b * P.ent_cap;
+    if (t < 64) {
+        unsigned long long m = 0;
+        if (t < P.n_parts) for (int q = 0; q < P.n_parts; ++q) m |= (unsigned long long)(P.skip[(size_t)t * P.n_parts + q] != 0) << q;
+        s_mask[t] = m;
+    }
+    __syncthreads();
+    const float glo[3] = {P.gridp[b * 4], P.gridp[b * 4 + 1], P.gridp[b * 4 + 2]};
+    const float ih = P.gridp[b * 4 + 3];
+    auto cell_of = [&](float x, int e) { return min(1 << 20, max(0, (int)fminf((x - glo[e]) * ih, 1048576.f))); };
+    auto bucket = [](int x, int y, int z) { return (int)(((unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u) & (PEN_CELLS - 1)); };
+    auto cell_key = [](int x, int y, int z) { return (x & 1023) | ((y & 1023) << 10) | ((z & 1023) << 20); };
 
     // ---- pairs.  A wavefront takes 64 consecutive entries of the bucket-sorted list: its lanes hold
     // one entry each (header = AABB, vertex ids, part, cell) and the same 64 headers sit in a
@@ -357,8 +396,7 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B, const int* __
     // gather per ENTRY; the pair tests run on registers and LDS.  A pair is accepted in the cell that
     // holds the low corner of the AABB intersection (both triangles are entered there), and appended
     // to both triangles' partner lists.
-    const int lane = t & 63, wv = t >> 6;
-    int* tile = cell_cnt + PEN_GRID_INTS + wv * 64 * 12;          // 16-byte aligned
+    int* tile = s_tile + wv * 64 * 12;
     int* pc = P.pcount + (size_t)b * F;
     int* part = P.partners + (size_t)b * F * P.cap;
     auto load_hdr = [&](int q, bool ok, int (&hd)[12]) {
@@ -372,7 +410,7 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B, const int* __
     };
     // (blocks of 64 entries, NOT whole buckets: a crowded bucket is shared by many wavefronts; the
     // cell key comparison keeps different cells of one bucket apart)
-    int* queue = cell_cnt + PEN_GRID_INTS + (PEN_T / 64) * 64 * 12 + wv * 256;      // 128 pairs per wavefront
+    int* queue = s_queue + wv * 256;                 // 128 pairs per wavefront
     int qn = 0;
     auto flush_queue = [&](int n) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
@@ -387,7 +425,7 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B, const int* __
     int4* tA = reinterpret_cast<int4*>(tile);        // [64] entry | cell | lo.x | lo.y
     int4* tB = tA + 64;                              // [64] lo.z | hi.x | hi.y | hi.z
     int4* tC = tA + 128;                             // [64] vertex ids
-    for (int i0 = wv * 64; i0 < s_total; i0 += PEN_T) {
+    for (int i0 = (blockIdx.x * 4 + wv) * 64; i0 < s_total; i0 += gridDim.x * 256) {
         const int qi = i0 + lane;
         const bool vi = qi < s_total;
         int hi_[12];
@@ -400,7 +438,7 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B, const int* __
         // partners of an entry: the entries after it up to the end of ITS bucket (buckets hold a few
         // entries, so this per-lane walk takes as many steps as the fullest bucket of the block)
         const int ck = hi_[1];
-        const int bend = vi ? cell_cnt[bucket(ck & 1023, (ck >> 10) & 1023, (ck >> 20) & 1023)] : 0;
+        const int bend = vi ? cells[bucket(ck & 1023, (ck >> 10) & 1023, (ck >> 20) & 1023)] : 0;
         tA[lane] = make_int4(hi_[0], hi_[1], hi_[2], hi_[3]);
         tB[lane] = make_int4(hi_[4], hi_[5], hi_[6], hi_[7]);
         tC[lane] = make_int4(hi_[8], hi_[9], hi_[10], 0);
@@ -439,9 +477,19 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B, const int* __
         __builtin_amdgcn_wave_barrier();
     }
     if (qn) flush_queue(qn);
-    __threadfence();
-    __syncthreads();
-    PEN_CLK(7);
+}
+
+// offsets of the triangles' partner ranges in the frame's pair list (k_pen_rank fills the list)
+__global__ __launch_bounds__(PEN_T)
+void k_pen_list(PenDev P, const int* __restrict__ want) {
+    __shared__ float red[PEN_T / 64];
+    __shared__ int slice[PEN_T];
+    const int b = blockIdx.x, t = threadIdx.x;
+    int* st = P.stats + b * PEN_STATS;
+    if ((want && !want[b]) || st[2] != 0) return;          // skipped frame / grid overflow: k_pen_grid has zeroed the totals
+    const int F = P.F;
+    int* pc = P.pcount + (size_t)b * F;
+
     // ---- the frame's pair list: triangles ascending, partners ascending within a triangle (the
     // partner lists were appended in scheduling order; ranking them here fixes every later summation
     // order).  Lists longer than max_collisions, and pairs beyond pair_cap, are cut and counted.
@@ -463,22 +511,38 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B, const int* __
         const float to = block_sum_fixed((float)n_over, red);
         if (t == 0) { const int tot = min(ptot, P.pair_cap); P.ptotal[b] = tot; st[0] = tot; st[1] = (int)to; }
     }
-    __threadfence();
-    __syncthreads();
-    PEN_CLK(8);
+}
+
+// ranks every triangle's partner list into the frame's pair list; PEN_RANK_BLOCKS workgroups per frame
+#define PEN_RANK_BLOCKS 16
+#define PEN_SHORT 16            // lists up to this length are ranked element-wise, longer ones sorted by a wavefront
+__global__ __launch_bounds__(256)
+void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
+    extern __shared__ int s_sort[];             // [4][max(cap_pad, 64)]
+    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if ((want && !want[b]) || P.ptotal[b] == 0) return;
+    const int F = P.F;
+    const int* pc = P.pcount + (size_t)b * F;
+    const int* poff = P.poff + (size_t)b * F;
+    const int* part = P.partners + (size_t)b * F * P.cap;
     int* pown = P.pown + (size_t)b * P.pair_cap;
     int* plist = P.plist + (size_t)b * P.pair_cap;
-    // 64 consecutive triangles at a time per wavefront; their list elements are dealt to the lanes
-    // (owner found by bisection of the 64 offsets in LDS), each lane ranks its element within its list
-    const int fper = (F + PEN_T / 64 - 1) / (PEN_T / 64);
-    const int flim = min(F, (wv + 1) * fper);
-    for (int fw = wv * fper; fw < flim; fw += 64) {
+    int* tile = s_sort + wv * min(max(cap_pad, 64), 2048);
+    const bool can_sort = cap_pad <= 2048;
+    // 64 consecutive triangles at a time per wavefront.  Short lists: their elements are dealt to the
+    // lanes (owner found by bisection of the 64 offsets in LDS), each lane ranks its element within its
+    // list.  Long lists: bitonic sort by the whole wavefront in LDS.
+    const int nw = gridDim.x * 4, gw = blockIdx.x * 4 + wv;
+    const int fper = (((F + nw - 1) / nw + 63) / 64) * 64;
+    const int flim = min(F, (gw + 1) * fper);
+    for (int fw = gw * fper; fw < flim; fw += 64) {
         const int f = fw + lane;
         const bool inr = f < flim;
         const int c_l = inr ? pc[f] : 0, off_l = inr ? poff[f] : 0x3fffffff;
         const int base = __builtin_amdgcn_readfirstlane(off_l);
         const int lastv = min(63, flim - 1 - fw);
         const int E = __builtin_amdgcn_readlane(off_l + c_l, lastv) - base;
+        if (E == 0) continue;
         __builtin_amdgcn_wave_barrier();
         tile[lane] = off_l - base;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
@@ -488,6 +552,7 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B, const int* __
             for (int d = 32; d > 0; d >>= 1) if (tile[l + d] <= e) l += d;      // last l with offset <= e
             const int ff = fw + l, lo = tile[l], slot = e - lo, off = base + lo;
             const int cc = pc[ff];
+            if (can_sort && cc > PEN_SHORT) continue;
             const int* mine = part + (size_t)ff * P.cap;
             const int x = mine[slot];
             int rank = 0;
@@ -495,9 +560,33 @@ void k_pen_pairs(PenDev P, const float* __restrict__ verts, int B, const int* __
             if (off + rank < P.pair_cap) { plist[off + rank] = x; pown[off + rank] = ff; }
         }
         __builtin_amdgcn_wave_barrier();
+        unsigned long long m = __ballot(can_sort && c_l > PEN_SHORT && off_l < P.pair_cap);
+        while (m) {
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int ff = fw + bit;
+            const int cc = __builtin_amdgcn_readlane(c_l, bit), off = __builtin_amdgcn_readlane(off_l, bit);
+            const int* mine = part + (size_t)ff * P.cap;
+            int np = 64;
+            while (np < cc) np <<= 1;
+            for (int q = lane; q < np; q += 64) tile[q] = q < cc ? mine[q] : 0x7fffffff;
+            for (int k = 2; k <= np; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+                    for (int i = lane; i < np; i += 64) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const int va = tile[i], vb = tile[ixj];
+                            if ((va > vb) == ((i & k) == 0)) { tile[i] = vb; tile[ixj] = va; }
+                        }
+                    }
+                }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+            const int keep = min(cc, P.pair_cap - off);
+            for (int q = lane; q < keep; q += 64) { plist[off + q] = tile[q]; pown[off + q] = ff; }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    PEN_CLK(9);
-#undef PEN_CLK
 }
 
 // one lane per ORDERED pair (f receives g, and f's vertices intrude into g): the lane differentiates
@@ -548,8 +637,33 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
     }
 }
 
-// vertex gradient = fixed-order sum over the incident triangle corners (CSR) and their pair ranges;
-// frame loss = fixed-order sum over the pair list
+// per triangle: sum over its pair range (ascending partner) of the 9 gradient components and the loss.
+// The lane that sits on the first pair of a triangle's range does the whole range (ten contiguous
+// streams); the ranges are short and the list is dense, so this costs microseconds.
+__global__ __launch_bounds__(256)
+void k_pen_facesum(PenDev P) {
+    const int b = blockIdx.y;
+    const int total = P.ptotal[b];
+    const int* pown = P.pown + (size_t)b * P.pair_cap;
+    const int* pc = P.pcount + (size_t)b * P.F;
+    const float* po = P.pout + (size_t)b * 10 * P.pair_cap;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int f = pown[i];
+        if (i > 0 && pown[i - 1] == f) continue;
+        const int n = min(pc[f], total - i);
+        float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = i; q < i + n; ++q)
+#pragma unroll
+            for (int j = 0; j < 10; ++j) acc[j] += po[(size_t)j * P.pair_cap + q];
+        float* tg = P.tgrad + ((size_t)b * P.F + f) * 9;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) tg[j] = acc[j];
+        P.tloss[(size_t)b * P.F + f] = acc[9];
+    }
+}
+
+// vertex gradient = fixed-order sum over the incident triangle corners (CSR); frame loss = sum over the
+// triangles in index order (independent of where a pair sits in the list)
 __global__ __launch_bounds__(256)
 void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss_out, const int* __restrict__ want) {
     __shared__ float red[4];
@@ -557,24 +671,24 @@ void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss
     if (want && !want[b]) { if (blockIdx.x == 0 && threadIdx.x == 0) loss_out[b] = 0.f; return; }
     const int v = blockIdx.x * 256 + threadIdx.x;
     const int total = P.ptotal[b];
-    const float* po = P.pout + (size_t)b * 10 * P.pair_cap;
+    const int* poff = P.poff + (size_t)b * P.F;
+    const int* pc = P.pcount + (size_t)b * P.F;
     if (v < P.V) {
         float g[3] = {0.f, 0.f, 0.f};
         if (total > 0) {
-            const int* poff = P.poff + (size_t)b * P.F;
-            const int* pc = P.pcount + (size_t)b * P.F;
+            const float* tg = P.tgrad + (size_t)b * P.F * 9;
             for (int q = P.vf_start[v]; q < P.vf_start[v + 1]; ++q) {
-                const int fc = P.vf_list[q], face = fc / 3, corner = fc - face * 3;
-                const int off = poff[face], n = max(0, min(pc[face], P.pair_cap - off));
-                for (int i = off; i < off + n; ++i)
-                    for (int e = 0; e < 3; ++e) g[e] += po[(size_t)(corner * 3 + e) * P.pair_cap + i];
+                const int fc = P.vf_list[q], face = fc / 3;
+                if (pc[face] > 0 && poff[face] < P.pair_cap)
+                    for (int e = 0; e < 3; ++e) g[e] += tg[(size_t)fc * 3 + e];      // fc = face * 3 + corner -> [face][corner][3]
             }
         }
         for (int e = 0; e < 3; ++e) dverts[((size_t)b * P.V + v) * 3 + e] = g[e];
     }
     if (blockIdx.x == 0) {
         float s = 0.f;
-        for (int i = threadIdx.x; i < total; i += 256) s += po[(size_t)9 * P.pair_cap + i];
+        if (total > 0) for (int f = threadIdx.x; f < P.F; f += 256)
+            if (pc[f] > 0 && poff[f] < P.pair_cap) s += P.tloss[(size_t)b * P.F + f];
         s = wave_sum_dpp(s);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         __syncthreads();
@@ -643,6 +757,9 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     P.pair_cap = (int)std::min<size_t>((size_t)F * P.cap, std::max<size_t>(65536, (size_t)16 * F));
     P.poff = h->zeros<int>(B * F); P.pown = h->zeros<int>(B * P.pair_cap); P.plist = h->zeros<int>(B * P.pair_cap);
     P.pout = h->zeros<float>(B * 10 * P.pair_cap); P.ptotal = h->zeros<int>(B); P.stats = h->zeros<int>(B * PEN_STATS);
+    P.cells = h->zeros<int>(B * (PEN_CELLS + 1)); P.gridp = h->zeros<float>(B * 4);
+    P.tgrad = h->zeros<float>(B * F * 9); P.tloss = h->zeros<float>(B * F);
+    if (!P.cells || !P.gridp || !P.tgrad || !P.tloss) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.ptotal) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     *out = h;
     return 0;
@@ -665,12 +782,19 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
     const size_t lds = (size_t)(PEN_GRID_INTS + (PEN_T / 64) * (64 * 12 + 256)) * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_pen_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_pen_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             sfx_set_error("cannot reserve %zu bytes of LDS", lds); return -2; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_pen_pairs, dim3(B), dim3(PEN_T), lds, s, h->P, verts_dev, B, want_dev);
+    hipLaunchKernelGGL(k_pen_grid, dim3(B), dim3(PEN_T), lds, s, h->P, verts_dev, B, want_dev);
+    hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, h->P, want_dev);
+    hipLaunchKernelGGL(k_pen_list, dim3(B), dim3(PEN_T), 0, s, h->P, want_dev);
+    int cap_pad = 64;
+    while (cap_pad < h->P.cap) cap_pad <<= 1;
+    hipLaunchKernelGGL(k_pen_rank, dim3(PEN_RANK_BLOCKS, B), dim3(256), (size_t)4 * std::min(std::max(cap_pad, 64), 2048) * sizeof(int), s,
+                       h->P, want_dev, cap_pad);
     hipLaunchKernelGGL(k_pen_eval, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside);
+    hipLaunchKernelGGL(k_pen_facesum, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P);
     hipLaunchKernelGGL(k_pen_gather, dim3((std::max(h->P.V, 1) + 255) / 256, B), dim3(256), 0, s, h->P, dverts_dev, loss_dev, want_dev);
     if (hipGetLastError() != hipSuccess) { sfx_set_error("penetration kernels failed to launch"); return -4; }
     return 0;
