@@ -226,9 +226,9 @@ int  sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, in
 /* per frame (HOST [B][4]): ordered pairs kept, partners dropped by max_collisions / the pair list's capacity, grid entries
  * when they overflowed the buffer (0 = fine; then the frame reports no pairs), grid cells.       */
 int  sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host);
-/* debug: elapsed 100 MHz wall-clock ticks at the end of the broad phase's ten steps (triangle boxes,
- * frame box, part boxes, part culling, grid histogram, scan, scatter, pair tests, list offsets,
- * ranked pair list) of the most recent evaluation, then the number of grid entries: HOST [B][11]. */
+/* debug: elapsed 100 MHz wall-clock ticks at the end of k_pen_grid's seven steps (triangle boxes,
+ * frame box, part boxes, part culling, grid histogram, scan, scatter; [7..9] unused) of the most
+ * recent evaluation, then the number of grid entries: HOST [B][11].                               */
 int  sfx_pen_phase_clocks(sfx_pen* h, int32_t B, int32_t* clocks_host);
 
 /* Timing hooks for the roofline report: total duration (ms), number of TIMED launches and

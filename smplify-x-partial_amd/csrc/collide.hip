@@ -8,28 +8,29 @@
 // and its gradient with respect to the vertices.  Algorithm and formulas: oracle/penetration.py
 // (the package's source is absent: parity unpinned).
 //
-// MI355X design (not the package's LBVH): one workgroup of 1024 lanes owns one frame.
-//   k_pen_pairs   triangle AABBs -> bounding box per body part: a triangle whose box meets the box of
-//                 no part it may collide with is dropped (in most poses nearly all of them) -> the
-//                 rest enters a uniform grid (cell = twice the mean triangle extent, every cell the
-//                 AABB touches) hashed into 16384 LDS buckets by a counting sort -> pair tests run
-//                 over blocks of 64 consecutive entries of the bucket-sorted list: each lane holds
-//                 one entry (AABB, vertex ids, part, cell), the same 64 headers sit in a
-//                 wavefront-private LDS tile, and lane i walks the entries after it in its bucket,
-//                 so memory is touched once per ENTRY, not per pair.  Tests in order: same cell, part mask (one 64-bit
-//                 word), AABB overlap, ownership by the cell of the intersection's low corner,
-//                 shared vertices.  Accepted pairs are queued per wavefront and appended to both
-//                 triangles' partner lists 64 at a time.
-//                 The lists are then ranked into the frame's pair list (triangles ascending,
-//                 partners ascending), which fixes every later summation order.
+// MI355X design (not the package's LBVH; DESIGN.md 4.6 has the table):
+//   k_pen_grid    (1 x 1024 lanes per frame) triangle AABBs -> bounding box per body part: a triangle
+//                 whose box meets the box of no part it may collide with is dropped -> the rest enters a
+//                 uniform grid (cell = twice the mean triangle extent, every cell the AABB touches)
+//                 hashed into 16384 LDS buckets by a counting sort.
+//   k_pen_walk    (32 x 256 lanes per frame) pair tests over blocks of 64 consecutive entries of the
+//                 bucket-sorted list: each lane holds one entry (AABB, vertex ids, part, cell), the same
+//                 64 headers sit in a wavefront-private LDS tile, and lane i walks the entries after it
+//                 in its bucket, so memory is touched once per ENTRY, not per pair.  Tests in order: same
+//                 cell, part mask (one 64-bit word), AABB overlap, ownership by the cell of the
+//                 intersection's low corner, shared vertices.  Accepted pairs are queued per wavefront
+//                 and appended to both triangles' partner lists 64 at a time.
+//   k_pen_list /  offsets and ranks turn the partner lists (appended in scheduling order) into the
+//   k_pen_rank    frame's pair list -- triangles ascending, partners ascending -- which fixes every
+//                 later summation order.
 //   k_pen_eval    one lane per ORDERED pair of that list: conic distance field evaluated with
 //                 forward-mode dual numbers -- the lane differentiates with respect to the OWNER's 9
 //                 coordinates only, once as receiver geometry and once as intruding points -- so
 //                 every number has one owner: no atomics in the arithmetic, results independent of
 //                 scheduling and of batch composition, and the work is balanced over the chip however
 //                 unevenly the collisions are spread over the triangles.
-//   k_pen_gather  vertex gradient = fixed-order sum over the incident triangle corners (CSR) and
-//                 their pair ranges; frame loss = fixed-order reduction over the pair list.
+//   k_pen_facesum / k_pen_gather   per-triangle sums over the pair ranges; vertex gradient = fixed-order
+//                 sum over the incident triangle corners (CSR); frame loss = triangles in index order.
 #include "../../include/sfx.h"
 #include "sfx_internal.h"
 #include "wave_ops.h"
@@ -806,7 +807,7 @@ extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float
 }
 
 // debug: wall-clock ticks (100 MHz) at the end of k_pen_pairs' steps for the first B frames: [B][10] = triangle boxes,
-// frame box, part boxes, part culling, grid histogram, scan, scatter, pair tests, list offsets, ranked list; [10] = grid entries
+// frame box, part boxes, part culling, grid histogram, scan, scatter ([7..9] unused: those steps are kernels of their own); [10] = grid entries
 extern "C" int sfx_pen_phase_clocks(sfx_pen* h, int32_t B, int32_t* out) {
     if (!h || !out || B < 1 || B > h->Bmax) return -1;
     std::vector<int> st((size_t)B * PEN_STATS);
