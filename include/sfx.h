@@ -250,6 +250,10 @@ int  sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out /* [32] */
  * enable = N > 1: the stamps of the dense tick kernel freeze after its N-th launch (default 40),
  * out[24..26] = its start / end of adjoint+tick / end, out[40..56] = phases of its adjoint pass.  */
 int  sfx_debug_clocks(sfx_batch* b, int32_t enable, int64_t* out /* [64] or NULL */);
+/* debug / tests: copy a device buffer of the dense path's most recent evaluation to the host, [B][per frame]:
+ * "verts", "vposed", "pen_dverts" (V*3), "pen_dfeat", "feat" (512), "pen_dA", "A" (12*55), "pen_loss" (1).
+ * n_out = number of floats the caller's buffer holds (checked).                                          */
+int  sfx_batch_debug_read(sfx_batch* b, const char* name, float* out, int64_t n_out);
 
 const char* sfx_last_error(void);
 const char* sfx_version(void);

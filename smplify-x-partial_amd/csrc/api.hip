@@ -679,6 +679,42 @@ extern "C" int sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out 
     return 0;
 }
 
+// debug / tests: copy one of the dense path's device buffers of the most recent evaluation to the host.
+// name -> floats per frame (rows are GEMM columns = frames while no compaction is in force):
+//   "verts" V*3, "vposed" V*3, "pen_dverts" V*3, "pen_dfeat" 512, "pen_dA" 55*12, "pen_loss" 1,
+//   "A" 12*55 (skinning transforms, [row*4+col][joint] gathered from the GEMM operand), "feat" 512
+extern "C" int sfx_batch_debug_read(sfx_batch* b, const char* name, float* out, int64_t n_out) {
+    if (!b || !name || !out) { sfx_set_error("null argument"); return -1; }
+    const BatchDev& D = b->D; const int B = D.cfg.B, V = b->m->M.V;
+    const std::string k(name);
+    SFX_CHECK(hipDeviceSynchronize());
+    auto plain = [&](const float* src, size_t per) -> int {
+        if (!src) { sfx_set_error("buffer '%s' is not allocated in this batch", name); return -1; }
+        if ((int64_t)(per * B) != n_out) { sfx_set_error("'%s' holds %zu floats, caller asked for %lld", name, per * B, (long long)n_out); return -1; }
+        SFX_CHECK(hipMemcpy(out, src, per * B * sizeof(float), hipMemcpyDeviceToHost));
+        return 0;
+    };
+    if (k == "verts") return plain(D.verts, (size_t)V * 3);
+    if (k == "vposed") return plain(D.vposed, (size_t)V * 3);
+    if (k == "pen_dverts") return plain(D.pen_dverts, (size_t)V * 3);
+    if (k == "pen_dfeat") return plain(D.pen_dfeat, SFX_KD_PAD);
+    if (k == "pen_dA") return plain(D.pen_dA, (size_t)SFX_J * 12);
+    if (k == "pen_loss") return plain(D.pen_loss, 1);
+    if (k == "A" || k == "feat") {
+        const size_t rows = k == "A" ? (size_t)12 * SFX_JPAD : SFX_KD_PAD, per = k == "A" ? (size_t)12 * SFX_J : SFX_KD_PAD;
+        if ((int64_t)(per * B) != n_out) { sfx_set_error("'%s' holds %zu floats, caller asked for %lld", name, per * B, (long long)n_out); return -1; }
+        std::vector<float> h(rows * D.Bpad);
+        SFX_CHECK(hipMemcpy(h.data(), k == "A" ? D.AT : D.featT, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int i = 0; i < B; ++i) {
+            if (k == "A") { for (int e = 0; e < 12; ++e) for (int j = 0; j < SFX_J; ++j) out[((size_t)i * 12 + e) * SFX_J + j] = h[((size_t)e * SFX_JPAD + j) * D.Bpad + i]; }
+            else for (int q = 0; q < SFX_KD_PAD; ++q) out[(size_t)i * SFX_KD_PAD + q] = h[(size_t)q * D.Bpad + i];
+        }
+        return 0;
+    }
+    sfx_set_error("unknown buffer '%s'", name);
+    return -1;
+}
+
 // debug: attach (enable=1) / read out and detach (enable=0) the 64-slot clock buffer; while attached,
 // closure launches stamp dbg[0..18] and optimiser ticks of frame 0 accumulate dbg[32..63]
 extern "C" int sfx_debug_clocks(sfx_batch* b, int32_t enable, int64_t* out /* [64] or NULL */) {

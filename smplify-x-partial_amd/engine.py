@@ -296,6 +296,18 @@ class FrameBatch(object):
         capi.check(self._lib.sfx_batch_step(self._h, stage, int(bool(resume)), capi.fptr(loss), None))
         return loss
 
+    _DEBUG_PER_FRAME = dict(verts="V3", vposed="V3", pen_dverts="V3", pen_dfeat=512, feat=512, pen_dA=55 * 12, A=12 * 55,
+                            pen_loss=1)
+
+    def debug_read(self, name):
+        """Tests: one of the dense path's device buffers of the most recent evaluation as [B, per-frame]
+        (sfx_batch_debug_read)."""
+        per = self._DEBUG_PER_FRAME[name]
+        per = self.model.V * 3 if per == "V3" else per
+        out = np.zeros((self.B, per), np.float32)
+        capi.check(self._lib.sfx_batch_debug_read(self._h, name.encode(), capi.fptr(out), out.size))
+        return out
+
     def penetration_stats(self):
         """Diagnostics of the interpenetration term of the most recent evaluation (per frame):
         ordered pairs kept, partners dropped by max_collisions, grid overflow, vertices with gradient."""

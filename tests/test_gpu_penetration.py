@@ -202,6 +202,57 @@ def test_closure_with_interpenetration_matches_oracle(synth_model):
     fb.close()
 
 
+def test_dense_skinning_adjoint_matches_torch_reference(synth_model):
+    """csrc/lbs_adjoint.hip in isolation (k_adj_prep -> fp32-MFMA split-K GEMM k_lbs_dense_adj ->
+    k_adj_reduce, and k_adj_dA): from the evaluation's own vertex gradient g, skinning transforms A,
+    v_posed and the model constants, a plain torch fp64 restatement of
+        d feat[k] = sum_{v,c} dirs[k][3v+c] (T_v^T g_v)[c],   T_v = sum_j W[v][j] A_j
+        d A_j     = sum_v W[v][j] g_v (x) [v_posed_v; 1]
+    must agree with what the kernels wrote.  Tolerance 2e-5 relative (fp32 accumulation over 31 425 terms)."""
+    import helpers as H
+    import test_gpu_parity as T
+    from smplifyx_amd import synthetic
+    cfg = H.load_cfg("fit_smplx_combined_halpe.yaml", use_hands=False, use_face=False, interpenetration=True)
+    cfg["df_cone_height"] = 1e-2
+    cfg["max_collisions"] = 1024
+    parts = synthetic.make_synthetic_parts(synth_model)
+    dm = T._dm(synth_model, cfg)
+    dm.set_parts(parts["segm"], parts["parents"], cfg["ign_part_pairs"])
+    B = 3
+    K = len(H.joint_map_for(cfg))
+    frames = synthetic.make_frames(B, H.oracle_joints_fn(synth_model, cfg), K, focal=5000.0)
+    fb = H.engine_batch_from_frames(dm, cfg, frames, range(B), lbs_mode="dense")
+    rng = np.random.RandomState(5)
+    P = H.random_params(rng, B, scale=0.2)
+    P["pose_embedding"] = (0.05 * rng.normal(size=(B, 63))).astype(np.float32)
+    fb.set_params(regression_pose=frames["reg_pose"], **P)
+    fb.closure(2)
+    g = fb.debug_read("pen_dverts").reshape(B, -1, 3).astype(np.float64)
+    A = fb.debug_read("A").reshape(B, 3, 4, 55).astype(np.float64)            # [b][row][col][joint]
+    vp = fb.debug_read("vposed").reshape(B, -1, 3).astype(np.float64)
+    dfeat = fb.debug_read("pen_dfeat")
+    dA = fb.debug_read("pen_dA").reshape(B, 55, 3, 4)
+    assert np.abs(g).max() > 0
+    W = np.asarray(synth_model["weights"], np.float64)                         # [V][55]
+    V = W.shape[0]
+    nb, ne = cfg["num_betas"], cfg["num_expression_coeffs"]
+    sd = np.asarray(synth_model["shapedirs"], np.float64)
+    dirs = np.concatenate([sd[:, :, :nb], sd[:, :, 300:300 + ne] if sd.shape[2] > 300 else sd[:, :, nb:nb + ne],
+                           np.asarray(synth_model["posedirs"], np.float64).reshape(V, 3, -1)], axis=2)      # [V][3][506]
+    for b in range(B):
+        T_v = np.einsum("vj,rcj->vrc", W, A[b])                                # [V][3][4]
+        dvp = np.einsum("vrc,vr->vc", T_v[:, :, :3], g[b])
+        ref_feat = np.einsum("vck,vc->k", dirs, dvp)
+        err = np.linalg.norm(dfeat[b, :ref_feat.size] - ref_feat) / np.linalg.norm(ref_feat)
+        assert err < 2e-5, (b, err)
+        assert np.all(dfeat[b, ref_feat.size:] == 0)
+        hom = np.concatenate([vp[b], np.ones((V, 1))], 1)
+        ref_dA = np.einsum("vj,vr,vc->jrc", W, g[b], hom)
+        errA = np.linalg.norm(dA[b] - ref_dA) / np.linalg.norm(ref_dA)
+        assert errA < 2e-5, (b, errA)
+    fb.close()
+
+
 def test_fit_frames_with_interpenetration_runs(synth_model):
     """driver.fit_frames on cfg_files/fit_smplx_combined_halpe.yaml with interpenetration=True: the whole
     schedule runs on device with the penetration step between the dense LBS and the loss/adjoint
