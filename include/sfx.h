@@ -203,6 +203,12 @@ int  sfx_batch_pen_stats(sfx_batch* b, int32_t* stats_host /* [B][4] */, int32_t
 int  sfx_batch_get_stats(sfx_batch* b, float* stage_loss, int32_t* stage_evals,
                          int32_t* stage_ref_evals);
 
+/* Gaussian-mixture body pose prior (MaxMixturePrior, smplifyx/prior.py:100-231; body_prior_type 'gmm'):
+ * used by the closure when use_vposer is off and the batch has no regression pose (fitting.py:399-401).
+ * means [M][D], precisions [M][D][D], nll_weights [M] = the module's buffers; D = 63, M <= 8 (HOST). */
+int  sfx_batch_set_gmm(sfx_batch* b, int32_t M, int32_t D, const float* means, const float* precisions,
+                       const float* nll_weights);
+
 /* Final meshes / joints at the current parameters (dense LBS; DEVICE pointers, may be NULL). */
 int  sfx_batch_forward(sfx_batch* b, float* vertices_out_dev /* [B][V][3] */,
                        float* joints_out_dev /* [B][K][3] */, void* stream);

@@ -95,8 +95,9 @@ class FrameFit(object):
 
     def __init__(self, bm, keypoints, H, W, focal_length, cfg, joint_weights,
                  reg_pose=None, reg_global=None, cam_prior=None, vposer=None,
-                 dtype=torch.float32, reuse_entry_eval=False, machine_kwargs=None):
+                 dtype=torch.float32, reuse_entry_eval=False, machine_kwargs=None, body_pose_prior=None):
         self.bm, self.cfg, self.dtype = bm, cfg, dtype
+        self.body_pose_prior = body_pose_prior
         self.vposer = vposer
         self.reuse = reuse_entry_eval
         self.mk = machine_kwargs or {}
@@ -125,6 +126,8 @@ class FrameFit(object):
             self.reg_global = torch.tensor(np.asarray(reg_global), dtype=dtype).reshape(1, 3)
         elif self.use_vposer:
             self.pose_embedding = torch.zeros([1, cfg.get("vposer_latent_dim", 32)], dtype=dtype, requires_grad=True)
+        elif body_pose_prior is not None:        # fit_single_frame.py:250-252: start from the mixture's mean
+            self.pose_embedding = body_pose_prior.get_mean().to(dtype).clone().detach().requires_grad_(True)
         else:
             raise ValueError("use_vposer=False needs a regression prior (the reference crashes here, "
                              "fit_single_frame.py:252 with body_prior_type 'l2')")
@@ -206,7 +209,8 @@ class FrameFit(object):
                                  regression_pose=self.regression_pose, stage=stage,
                                  num_stages=len(self.cfg.get("body_pose_prior_weights") or [0] * 4),
                                  use_joints_conf=self.use_conf, use_hands=self.use_hands,
-                                 use_face=self.use_face, rho=self.cfg.get("rho", 100))
+                                 use_face=self.use_face, rho=self.cfg.get("rho", 100),
+                                 body_pose_prior=None if (self.use_vposer or self.regression) else self.body_pose_prior)
 
     # ---- flat-vector closure -----------------------------------------------------------------
     def _make_closure(self, params, fn):

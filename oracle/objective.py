@@ -48,7 +48,7 @@ def rel_change(prev, cur):
 
 def smplify_terms(out, proj, gt_joints, joints_conf, joint_weights, w, pose_embedding,
                   use_vposer=False, regression_pose=None, stage=0, num_stages=3,
-                  use_joints_conf=True, use_hands=True, use_face=True, rho=100.0):
+                  use_joints_conf=True, use_hands=True, use_face=True, rho=100.0, body_pose_prior=None):
     """All terms of SMPLifyLoss.forward as a dict (+ 'total').  `w` holds the stage's 0-d
     weight tensors: data_weight, body_pose_weight, shape_weight, bending_prior_weight,
     hand_prior_weight, expr_prior_weight, jaw_prior_weight[3]."""
@@ -62,6 +62,8 @@ def smplify_terms(out, proj, gt_joints, joints_conf, joint_weights, w, pose_embe
             terms["pprior"] = pose_embedding.pow(2).sum() * w["body_pose_weight"] ** 2
     elif regression_pose is not None:
         terms["pprior"] = (pose_embedding - regression_pose).pow(2).sum() * w["body_pose_weight"] ** 2
+    elif body_pose_prior is not None:   # body_prior_type 'gmm' (fitting.py:399-401, oracle/prior_gmm.py)
+        terms["pprior"] = torch.sum(body_pose_prior(out.body_pose, out.betas)) * w["body_pose_weight"] ** 2
     else:   # body_prior_type 'l2' on the model's body_pose (fitting.py:399-401)
         terms["pprior"] = out.body_pose.pow(2).sum() * w["body_pose_weight"] ** 2
     terms["shape"] = out.betas.pow(2).sum() * w["shape_weight"] ** 2

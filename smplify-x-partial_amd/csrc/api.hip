@@ -1048,6 +1048,30 @@ extern "C" int sfx_batch_step(sfx_batch* b, int32_t stage, int32_t resume, float
     return 0;
 }
 
+// body_pose_prior = MaxMixturePrior (prior.py:100-231) for use_vposer=False fits without a regression
+// prior (fitting.py:399-401).  means [M][D], precisions [M][D][D], nll_weights [M] (as the module's buffers)
+extern "C" int sfx_batch_set_gmm(sfx_batch* b, int32_t M, int32_t Dm, const float* means, const float* precisions,
+                                 const float* nll_weights) {
+    if (!b || !means || !precisions || !nll_weights) { sfx_set_error("null argument"); return -1; }
+    if (M < 1 || M > 2 * (256 / 64)) { sfx_set_error("1..8 mixture components supported, got %d", M); return -1; }
+    if (b->D.cfg.use_vposer) { sfx_set_error("the mixture prior acts on body_pose: use_vposer must be off"); return -1; }
+    if (Dm != b->D.L.NEMB) { sfx_set_error("mixture dimension %d != body pose dimension %d", Dm, b->D.L.NEMB); return -1; }
+    std::vector<float> mu((size_t)M * 64, 0.f), P((size_t)M * 64 * 64, 0.f), lw(M);
+    for (int m = 0; m < M; ++m) {
+        if (!(nll_weights[m] > 0.f)) { sfx_set_error("nll_weights must be positive"); return -1; }
+        lw[m] = logf(nll_weights[m]);
+        for (int i = 0; i < Dm; ++i) {
+            mu[(size_t)m * 64 + i] = means[(size_t)m * Dm + i];
+            for (int j = 0; j < Dm; ++j)
+                P[((size_t)m * 64 + j) * 64 + i] = 0.5f * (precisions[((size_t)m * Dm + i) * Dm + j] + precisions[((size_t)m * Dm + j) * Dm + i]);
+        }
+    }
+    b->D.gmm_mean = b->mem.up(mu); b->D.gmm_prec = b->mem.up(P); b->D.gmm_lognw = b->mem.up(lw);
+    if (!b->D.gmm_mean || !b->D.gmm_prec || !b->D.gmm_lognw) { sfx_set_error("out of device memory"); return -2; }
+    b->D.gmm_M = M;
+    return 0;
+}
+
 extern "C" int sfx_batch_pen_stats(sfx_batch* b, int32_t* stats_host /* [B][4] */, int32_t* ext_n_host /* [B] or NULL */) {
     if (!b || !stats_host) { sfx_set_error("null argument"); return -1; }
     if (!b->pen) { sfx_set_error("batch was created without interpenetration"); return -1; }

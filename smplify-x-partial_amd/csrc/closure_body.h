@@ -565,7 +565,37 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     const float bpw2 = sw.bpw * sw.bpw, sw2 = sw.sw * sw.sw, h2 = sw.hpw * sw.hpw, e2 = sw.epw * sw.epw;
     if (!cam_stage) {
         const bool latent_reg = C.use_vposer ? (stage + 1 == C.n_stages && C.has_reg) : (C.has_reg != 0);
-        if (t < L.NEMB) {       // pose prior on the embedding (fitting.py:390-401)
+        const bool gmm = D.gmm_M > 0 && !C.use_vposer && !C.has_reg;
+        if (gmm) {
+            // MaxMixturePrior.merged_log_likelihood (prior.py:174-187) on body_pose = the embedding:
+            //   min_m [ 0.5 (x - mu_m)^T P_m (x - mu_m) - log nll_weights_m ],  gradient through the minimum's component
+            // (P symmetrised on the host: autograd's 0.5 (P + P^T) d).  Wavefront wv takes components wv, wv + 4;
+            // lane i forms (P d)_i from column i (coalesced), the quadratic form is a DPP sum.
+            float gy[2] = {0.f, 0.f};
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int m = wv + mi * (CT / 64);
+                float contrib = 0.f;
+                if (m < D.gmm_M && lane < L.NEMB) {
+                    const float* mu = D.gmm_mean + m * 64;
+                    const float* Pm = D.gmm_prec + (size_t)m * 64 * 64;
+                    float y = 0.f;
+                    for (int j = 0; j < L.NEMB; ++j) y += Pm[j * 64 + lane] * (S.x[L.emb + j] - mu[j]);
+                    gy[mi] = y;
+                    contrib = y * (S.x[L.emb + lane] - mu[lane]);
+                }
+                const float quad = wave_sum_dpp(contrib);
+                if (lane == 0 && m < D.gmm_M) S.red[m] = 0.5f * quad - D.gmm_lognw[m];
+            }
+            __syncthreads();
+            int best = 0; float bl = S.red[0];
+            for (int m = 1; m < D.gmm_M; ++m) { const float v = S.red[m]; if (v < bl) { bl = v; best = m; } }
+            __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                if (wv + mi * (CT / 64) == best && lane < L.NEMB) S.gc[L.emb + lane] = gy[mi] * bpw2;
+            if (t == 0) q[Q_PP] = bl;
+        } else if (t < L.NEMB) {       // pose prior on the embedding (fitting.py:390-401)
             const float e = S.x[L.emb + t];
             const float dlt = latent_reg ? (e - fd[FD_REG + t]) : e;
             q[Q_PP] = dlt * dlt;

@@ -174,6 +174,10 @@ struct BatchDev {
     float* uT;              // [B][n_uniq][12] (slot-indexed) their skinning transforms
     float* pen_loss;        // [B] (slot-indexed) unweighted penetration loss of the pending evaluation
     float* pen_dverts;      // [B][V][3] (slot-indexed) its gradient with respect to the vertices
+    int gmm_M;              // Gaussian-mixture body pose prior: components (0 = off) ...
+    const float* gmm_mean;  // [M][64]
+    const float* gmm_prec;  // [M][64][64] symmetrised precisions, rows padded
+    const float* gmm_lognw; // [M] log nll_weights
     float* vposed;          // [B][V][3] (slot-indexed) v_posed of every vertex, written by the dense GEMM when the term is on
     float* adj_G;           // [Bpad][3*Vpad] (slot-indexed) d v_posed = T^T d verts: operand of the adjoint GEMM
     float* adj_part;        // [slices][KD_PAD][Bpad] its per-slice partial sums

@@ -64,7 +64,7 @@ def prepare_frames(cfg, keypoints, joint_weights, reg_pose=None, reg_global=None
 
 
 def _make_batch(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose, reg_global, cam_prior_t,
-                cam_prior_center, lbs_mode, reuse_entry_eval):
+                cam_prior_center, lbs_mode, reuse_entry_eval, body_pose_prior=None):
     """FrameBatch with frames, parameters and the initial camera set the way
     fit_single_frame.py:209-294,358-411 prepares one frame."""
     prep = prepare_frames(cfg, keypoints, joint_weights)
@@ -72,16 +72,29 @@ def _make_batch(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose, reg_gl
     B, K = kp.shape[:2]
     use_vposer = bool(cfg.get("use_vposer", True))
     has_reg = reg_pose is not None
+    gmm = None
     if not has_reg and not use_vposer:
-        raise ValueError("use_vposer=False needs a regression prior (the reference crashes here: "
-                         "fit_single_frame.py:252 with body_prior_type 'l2')")
+        # fit_single_frame.py:250-252: the body pose starts from body_pose_prior.get_mean(), which only the
+        # mixture prior has (body_prior_type 'gmm'); with 'l2' the reference crashes here
+        gmm = body_pose_prior
+        if gmm is None and cfg.get("body_prior_type") == "gmm":
+            from . import prior as _prior
+            gmm = _prior.create_prior("gmm", prior_folder=cfg.get("prior_folder", "prior"),
+                                      num_gaussians=cfg.get("num_gaussians", 8))
+        if gmm is None or not hasattr(gmm, "get_mean"):
+            raise ValueError("use_vposer=False without a regression prior needs body_prior_type 'gmm' (the reference "
+                             "crashes here: fit_single_frame.py:252 with body_prior_type 'l2')")
     Hh = np.broadcast_to(np.asarray(H, np.float32), (B,))
     Ww = np.broadcast_to(np.asarray(W, np.float32), (B,))
     f = np.broadcast_to(np.asarray(focal, np.float32), (B,))
     fb = engine.FrameBatch(dm, B, cfg, lbs_mode=lbs_mode, reuse_entry_eval=reuse_entry_eval,
                            has_regression_pose=has_reg, side_view=True)
     nemb = fb.nemb
-    emb0 = np.asarray(reg_pose, np.float32).reshape(B, nemb) if has_reg else np.zeros((B, nemb), np.float32)
+    if gmm is not None:
+        fb.set_gmm(gmm)
+        emb0 = np.tile(gmm.get_mean().detach().cpu().numpy().astype(np.float32).reshape(1, nemb), (B, 1))
+    else:
+        emb0 = np.asarray(reg_pose, np.float32).reshape(B, nemb) if has_reg else np.zeros((B, nemb), np.float32)
     go0 = np.asarray(reg_global, np.float32).reshape(B, 3) if reg_global is not None else np.zeros((B, 3), np.float32)
     use_cam_prior = bool(cfg.get("use_camera_prior")) and has_reg and cam_prior_t is not None
     center = (np.asarray(cam_prior_center, np.float32).reshape(B, 2) if use_cam_prior
@@ -112,7 +125,7 @@ def _collect(fb, prep, want_vertices):
 
 def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, reg_global=None,
                cam_prior_t=None, cam_prior_center=None, lbs_mode="dense", reuse_entry_eval=True,
-               want_vertices=False, groups=1):
+               want_vertices=False, groups=1, body_pose_prior=None):
     """Fit B frames.  Arrays are [B, ...]; H, W, focal scalars or [B].  Returns a dict of
     [B, ...] arrays: the reference's result-pkl fields + per-stage losses / evaluation counts.
 
@@ -141,7 +154,7 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
         made.append(_make_batch(dm, cfg, np.asarray(keypoints)[lo:hi], jw_all[lo:hi] if jw_per_frame else jw_all,
                                 per(H, lo, hi), per(W, lo, hi), per(focal, lo, hi), per(reg_pose, lo, hi),
                                 per(reg_global, lo, hi), per(cam_prior_t, lo, hi), per(cam_prior_center, lo, hi),
-                                lbs_mode, reuse_entry_eval))
+                                lbs_mode, reuse_entry_eval, body_pose_prior))
     fbs = [m[0] for m in made]
     if groups == 1:
         fbs[0].fit(first_stage=-1, last_stage=fbs[0].n_stages - 1)

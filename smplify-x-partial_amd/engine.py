@@ -296,6 +296,16 @@ class FrameBatch(object):
         capi.check(self._lib.sfx_batch_step(self._h, stage, int(bool(resume)), capi.fptr(loss), None))
         return loss
 
+    def set_gmm(self, prior):
+        """Body pose prior = prior.MaxMixturePrior (body_prior_type 'gmm'): used by the closure when
+        use_vposer is off and the batch has no regression pose (fitting.py:399-401)."""
+        if not getattr(prior, "use_merged", True):
+            raise NotImplementedError("MaxMixturePrior(use_merged=False): only the merged form (the reference's default) is on the device")
+        mu = np.ascontiguousarray(prior.means.detach().cpu().numpy(), np.float32)
+        P = np.ascontiguousarray(prior.precisions.detach().cpu().numpy(), np.float32)
+        nw = np.ascontiguousarray(prior.nll_weights.detach().cpu().numpy().reshape(-1), np.float32)
+        capi.check(self._lib.sfx_batch_set_gmm(self._h, mu.shape[0], mu.shape[1], capi.fptr(mu), capi.fptr(P), capi.fptr(nw)))
+
     _DEBUG_PER_FRAME = dict(verts="V3", vposed="V3", pen_dverts="V3", pen_dfeat=512, feat=512, pen_dA=55 * 12, A=12 * 55,
                             pen_loss=1)
 

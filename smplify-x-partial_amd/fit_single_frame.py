@@ -112,7 +112,8 @@ def fit_single_frame(img, keypoints, body_model, camera, joint_weights, body_pos
     res = driver.fit_frames(dm, cfg, kp, jw.reshape(1, -1), H, W, focal_length, reg_pose=reg_pose, reg_global=reg_glob,
                             cam_prior_t=cam_t, cam_prior_center=cam_c,
                             lbs_mode="dense" if interpenetration else kwargs.get("lbs_mode", "rows"),
-                            reuse_entry_eval=True, want_vertices=want_v)
+                            reuse_entry_eval=True, want_vertices=want_v,
+                            body_pose_prior=body_pose_prior if hasattr(body_pose_prior, "get_mean") else None)
     # write the fitted values back into the caller's modules, as the reference leaves them
     with torch.no_grad():
         camera.translation[:] = torch.as_tensor(res["cam_translation"]).to(camera.translation)

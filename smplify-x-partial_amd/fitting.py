@@ -181,6 +181,9 @@ class EngineClosure(object):
                                       if getattr(loss, "trans_estimation", None) is not None else 0.0))
         fb = engine.FrameBatch(dm, 1, cfg, lbs_mode="dense" if self.return_verts else "rows",
                                reuse_entry_eval=False, has_regression_pose=has_reg, stages=[w], num_body_joints=K)
+        if (not self.is_camera and not self.use_vposer and not has_reg
+                and hasattr(getattr(loss, "body_pose_prior", None), "nll_weights")):
+            fb.set_gmm(loss.body_pose_prior)         # body_prior_type 'gmm' (fitting.py:399-401)
         gt = _np(self.gt_joints).reshape(1, K, 2)
         if self.is_camera:
             conf = _np(loss.joints_conf).reshape(1, K) if loss.joints_conf is not None else np.ones((1, K), np.float32)

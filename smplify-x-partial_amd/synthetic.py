@@ -237,6 +237,21 @@ def make_synthetic_parts(model):
     return dict(segm=segm, parents=par[segm])
 
 
+def make_synthetic_gmm(seed=0, num_gaussians=8, dim=63):
+    """Synthetic stand-in for SMPLify's gmm_08.pkl (not shipped with the reference; 69-D for SMPL):
+    dict(means [M,dim], covars [M,dim,dim] SPD, weights [M]) with pose-like scales (means ~0.15 rad,
+    standard deviations 0.05-0.4 rad, correlated)."""
+    rng = np.random.RandomState(2000 + seed)
+    means = 0.15 * rng.normal(size=(num_gaussians, dim))
+    covars = []
+    for m in range(num_gaussians):
+        q, _ = np.linalg.qr(rng.normal(size=(dim, dim)))
+        sd = np.exp(rng.uniform(np.log(0.05), np.log(0.4), size=dim))
+        covars.append((q * sd ** 2) @ q.T)
+    weights = rng.dirichlet(3.0 * np.ones(num_gaussians))
+    return dict(means=means, covars=np.stack(covars), weights=weights)
+
+
 def make_synthetic_vposer(seed=0, latent=32, hidden=512, dtype=np.float32, encoder_inputs=0):
     """Random-init VPoser-v1 *decoder* weights (appendix A.3): fc1 32->512,
     fc2 512->512, out 512->126, leaky_relu(0.2).  Scaled so decoded poses are O(0.3 rad).
