@@ -600,14 +600,18 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
     const int* pown = P.pown + (size_t)b * P.pair_cap;
     const int* plist = P.plist + (size_t)b * P.pair_cap;
     float* po = P.pout + (size_t)b * 10 * P.pair_cap;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int f = pown[i], g = plist[i];
+    const int lane = threadIdx.x & 63;
+    for (int i0 = blockIdx.x * 256 + (threadIdx.x & ~63); i0 < total; i0 += gridDim.x * 256) {      // wave-uniform trip count
+        const int i = i0 + lane;
+        const bool valid = i < total;
+        const int f = valid ? pown[i] : 0, g = valid ? plist[i] : 0;
         float p[9], qv[9];
         for (int k = 0; k < 3; ++k) for (int e = 0; e < 3; ++e) {
             p[k * 3 + e] = vb[(size_t)P.faces[f * 3 + k] * 3 + e];
             qv[k * 3 + e] = vb[(size_t)P.faces[g * 3 + k] * 3 + e];
         }
         float loss = 0.f, g9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (valid)
         {   // (1) this triangle receives the partner's vertices: own geometry as duals over the 9 own coordinates
             DVec<9> P0 = {dvar<9>(p[0], 0), dvar<9>(p[1], 1), dvar<9>(p[2], 2)};
             DVec<9> P1 = {dvar<9>(p[3], 3), dvar<9>(p[4], 4), dvar<9>(p[5], 5)};
@@ -621,6 +625,7 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
                 for (int j = 0; j < 9; ++j) g9[j] += pen.d[j];
             }
         }
+        if (valid)
         {   // (2) this triangle's vertices intrude into the partner's cone (partner geometry constant)
             DVec<3> Q0 = {dconst<3>(qv[0]), dconst<3>(qv[1]), dconst<3>(qv[2])};
             DVec<3> Q1 = {dconst<3>(qv[3]), dconst<3>(qv[4]), dconst<3>(qv[5])};
@@ -633,14 +638,31 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
                 for (int e = 0; e < 3; ++e) g9[k * 3 + e] += pen.d[e];
             }
         }
-        for (int j = 0; j < 9; ++j) po[(size_t)j * P.pair_cap + i] = g9[j];
-        po[(size_t)9 * P.pair_cap + i] = loss;
+        // sum over the pairs of one triangle that sit in this wavefront (they are adjacent lanes): segmented
+        // inclusive scan, then the last lane of every run stores the run's sum at its own list position
+        float v[10];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) v[j] = g9[j];
+        v[9] = loss;
+        const int fkey = valid ? f : -1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int fu = __shfl_up(fkey, d);
+            const bool take = lane >= d && fu == fkey;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) { const float vu = __shfl_up(v[j], d); if (take) v[j] += vu; }
+        }
+        const int fnext = __shfl_down(fkey, 1);
+        if (valid && (lane == 63 || fnext != fkey)) {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) po[(size_t)j * P.pair_cap + i] = v[j];
+        }
     }
 }
 
-// per triangle: sum over its pair range (ascending partner) of the 9 gradient components and the loss.
-// The lane that sits on the first pair of a triangle's range does the whole range (ten contiguous
-// streams); the ranges are short and the list is dense, so this costs microseconds.
+// per triangle: sum over its pair range of the 9 gradient components and the loss.  k_pen_eval has summed
+// the pairs of a triangle inside each 64-pair chunk of the list; the lane that sits on the first pair of
+// a range adds the (1 + range / 64) chunk sums in ascending order.
 __global__ __launch_bounds__(256)
 void k_pen_facesum(PenDev P) {
     const int b = blockIdx.y;
@@ -653,9 +675,12 @@ void k_pen_facesum(PenDev P) {
         if (i > 0 && pown[i - 1] == f) continue;
         const int n = min(pc[f], total - i);
         float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (int q = i; q < i + n; ++q)
+        const int end = i + n - 1;
+        for (int c = i >> 6; c <= end >> 6; ++c) {           // k_pen_eval left one run sum per 64-pair chunk of the range
+            const int q = min(end, c * 64 + 63);
 #pragma unroll
             for (int j = 0; j < 10; ++j) acc[j] += po[(size_t)j * P.pair_cap + q];
+        }
         float* tg = P.tgrad + ((size_t)b * P.F + f) * 9;
 #pragma unroll
         for (int j = 0; j < 9; ++j) tg[j] = acc[j];
