@@ -34,13 +34,20 @@ PEAK_HBM = 8.0e12
 
 def build_cfg(workload="body"):
     """body: BASELINE configs[1] (body-only keypoints, use_vposer=False + synthetic regression prior).
-    full: BASELINE configs[2] (hands + face + contour, K=135, VPoser decode in the loop, z0 = 0) --
-    a side measurement (`--workload full`), never the headline."""
+    full: BASELINE configs[2] (hands + face + contour, K=135, VPoser decode in the loop, z0 = 0);
+    pen: BASELINE configs[4] (cfg_files/fit_smplx_combined_halpe.yaml: regression prior + interpenetration
+    term, body-only keypoints, surface-like synthetic mesh with synthetic part labels) --
+    side measurements (`--workload full|pen`), never the headline."""
     from smplifyx_amd import cmd_parser
     over = dict(interpenetration=False, visualize=False, interactive=False, save_vertices=False,
                 use_gender_classifier=False)
     if workload == "body":
         over.update(use_hands=False, use_face=False, use_vposer=False)
+    if workload == "pen":
+        over.update(use_hands=False, use_face=False, interpenetration=True)
+        cfg = cmd_parser.load_config(os.path.join(ROOT, "cfg_files", "fit_smplx_combined_halpe.yaml"), over)
+        cfg["use_camera_prior"] = False
+        return cfg
     cfg = cmd_parser.load_config(os.path.join(ROOT, "cfg_files", "fit_smplx_smplifyx.yaml"), over)
     cfg["use_camera_prior"] = False
     return cfg
@@ -145,7 +152,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU")
     ap.add_argument("--lbs", default="dense", choices=["dense", "rows"])
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", default="body", choices=["body", "full"])
+    ap.add_argument("--workload", default="body", choices=["body", "full", "pen"])
     ap.add_argument("--prof-every", type=int, default=8, help="HIP-event-time every N-th launch of each kernel")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra needed-rows measurement")
     ap.add_argument("--groups", type=int, default=1, help="independent sub-batches per GPU (host threads/streams)")
@@ -173,15 +180,21 @@ def main():
     from smplifyx_amd import engine, synthetic, utils as U
     cfg = build_cfg(args.workload)
     full = args.workload == "full"
-    if full:
+    pen = args.workload == "pen"
+    if full or pen:
         args.no_cpu = True
-    model = synthetic.make_synthetic_model(0)
+    if pen:
+        args.no_alt = True          # the term reads the whole mesh: the dense path is the only one
+    model = synthetic.make_synthetic_model(0, surface=pen)
     jm = U.smpl_to_annotation("smplx", use_hands=cfg["use_hands"], use_face=cfg["use_face"],
                               use_face_contour=cfg["use_face_contour"], format=cfg["format"])
     dm = engine.DeviceModel(model, joint_map=jm, num_betas=cfg["num_betas"],
                             num_expression_coeffs=cfg["num_expression_coeffs"],
                             num_pca_comps=cfg["num_pca_comps"], use_face_contour=cfg["use_face_contour"],
                             vposer=synthetic.make_synthetic_vposer(0) if full else None)
+    if pen:
+        parts = synthetic.make_synthetic_parts(model)
+        dm.set_parts(parts["segm"], parts["parents"], cfg["ign_part_pairs"])
     B = args.frames
     dev = torch.device("cuda", local_rank)
 
@@ -191,7 +204,7 @@ def main():
         _, j, _ = dm.lbs_forward(t(P["global_orient"]), t(P["body_pose"]), t(P["betas"]), z(10), z(3), z(3), z(3),
                                  z(12), z(12), return_verts=False, return_full_pose=False)
         return j.cpu().numpy()
-    frames = synthetic.make_frames(B, joints_fn, len(jm), start=rank * B, focal=float(cfg["focal_length"]))
+    frames = synthetic.make_frames(B, joints_fn, len(jm), start=rank * B, focal=float(cfg.get("focal_length") or 5000.0))
 
     from smplifyx_amd import driver, dist as sdist
     jw = np.ones(len(jm), np.float32)
@@ -262,7 +275,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("configs[2]: %d synthetic frames/GPU, neutral SMPL-X-shaped synthetic model, hands + face + "
+            "config": {"workload": ("configs[4]: %d synthetic frames/GPU, neutral SMPL-X-shaped synthetic model (surface-like mesh, "
+                                    "synthetic part labels), body-only halpe keypoints K=26, synthetic regression prior, "
+                                    "interpenetration term (max_collisions 128, df_cone_height 1e-4), camera stage + 3-stage "
+                                    "L-BFGS (fit_smplx_combined_halpe.yaml)" % B) if pen else
+                                   ("configs[2]: %d synthetic frames/GPU, neutral SMPL-X-shaped synthetic model, hands + face + "
                                     "contour K=135, synthetic VPoser decoded in the loop (latent 32, z0 = 0), camera stage + "
                                     "5-stage L-BFGS (fit_smplx_smplifyx.yaml)" % B) if full else
                                    ("configs[1]: %d synthetic frames/GPU, neutral SMPL-X-shaped synthetic model, "

@@ -116,7 +116,6 @@ extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float
 extern "C" int sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host);
 int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
                         float* loss_dev, float* dverts_dev, const int* want_dev, void* stream);
-const int* sfx_pen_pair_totals(const sfx_pen* h);
 
 struct sfx_model {
     DevModel M{};
@@ -553,7 +552,6 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
         D.pen_dfeat = b->mem.zeros<float>((size_t)B * SFX_KD_PAD);
         D.pen_dA = b->mem.zeros<float>((size_t)B * SFX_J * 12);
         if (!D.adj_G || !D.adj_part || !D.vposed) { sfx_set_error("out of device memory"); b->mem.free_all(); delete b; return -2; }
-        D.ext_vid = b->mem.zeros<int>((size_t)B * SFX_EXT_CAP);
     }
     D.joints = b->mem.zeros<float>((size_t)B * K * 3);
     D.fullpose = b->mem.zeros<float>((size_t)B * SFX_POSE);
@@ -741,34 +739,6 @@ extern "C" int sfx_batch_num_vars(sfx_batch* b, int32_t stage) {
 }
 
 // one closure evaluation of every (active) frame; stage_override = -2 -> per-frame stage[]
-// vertices with a nonzero penetration gradient, ascending ids, per GEMM column (slot)
-__global__ __launch_bounds__(256)
-void k_pen_compact(BatchDev D, int V, const int* __restrict__ totals) {
-    __shared__ int s_base;
-    __shared__ int s_cnt[4];
-    const int slot = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    if (!D.pen_want[slot] || totals[slot] == 0) { if (t == 0) D.ext_n[slot] = 0; return; }
-    const float* g = D.pen_dverts + (size_t)slot * V * 3;
-    int* out = D.ext_vid + (size_t)slot * SFX_EXT_CAP;
-    if (t == 0) s_base = 0;
-    __syncthreads();
-    for (int v0 = 0; v0 < V; v0 += 256) {
-        const int v = v0 + t;
-        const bool nz = v < V && (g[v * 3] != 0.f || g[v * 3 + 1] != 0.f || g[v * 3 + 2] != 0.f);
-        const unsigned long long m = __ballot(nz);
-        if (lane == 0) s_cnt[wv] = __popcll(m);
-        __syncthreads();
-        int off = s_base;
-        for (int w = 0; w < wv; ++w) off += s_cnt[w];
-        const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
-        if (nz && pos < SFX_EXT_CAP) out[pos] = v;
-        __syncthreads();
-        if (t == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        __syncthreads();
-    }
-    if (t == 0) D.ext_n[slot] = min(s_base, SFX_EXT_CAP);
-}
-
 // penetration term of the pending evaluation of every active frame (after the dense LBS wrote the
 // vertices, before the loss / adjoint pass reads pen_loss, pen_dverts and the vertex lists)
 // which GEMM columns hold a frame whose pending evaluation carries a collision weight (fitting.py:437:
@@ -788,7 +758,7 @@ static int eval_penetration(sfx_batch* b, int stage_override, hipStream_t s) {
     hipLaunchKernelGGL(k_pen_want, dim3((D.cfg.B + 63) / 64), dim3(64), 0, s, D, b->sw_dev, stage_override);
     int rc = sfx_pen_eval_masked(b->pen, D.nact, D.verts, b->pen_sigma, b->pen_outside, D.pen_loss, D.pen_dverts, D.pen_want, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_pen_compact, dim3(D.nact), dim3(256), 0, s, D, b->m->M.V, sfx_pen_pair_totals(b->pen));
+    hipMemsetAsync(D.ext_n, 0, (size_t)D.cfg.B * sizeof(int), s);        // k_adj_prep counts the vertices that carry a gradient
     launch_pen_adjoint(b->m->M, D, s);
     return 0;
 }

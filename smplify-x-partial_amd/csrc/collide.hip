@@ -797,8 +797,6 @@ extern "C" void sfx_pen_destroy(sfx_pen* h) {
     delete h;
 }
 
-const int* sfx_pen_pair_totals(const sfx_pen* h) { return h->P.ptotal; }
-
 int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
                         float* loss_dev, float* dverts_dev, const int* want_dev, void* stream) {
     if (!h || !verts_dev || !loss_dev || !dverts_dev) { sfx_set_error("null argument"); return -1; }

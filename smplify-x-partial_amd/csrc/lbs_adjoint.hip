@@ -39,7 +39,12 @@ void k_adj_prep(DevModel M, BatchDev D) {
     const float* g = D.pen_dverts + ((size_t)b * M.V + v) * 3;
     const float g0 = g[0], g1 = g[1], g2 = g[2];
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-    if (g0 != 0.f || g1 != 0.f || g2 != 0.f) {
+    const bool nz = g0 != 0.f || g1 != 0.f || g2 != 0.f;
+    {   // diagnostics: vertices that carry a gradient (one integer atomic per wavefront)
+        const unsigned long long m = __ballot(nz);
+        if (m && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&D.ext_n[b], __popcll(m));
+    }
+    if (nz) {
         const size_t Bp = (size_t)D.Bpad;
         float T[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         auto add = [&](const int j, const float w) {

