@@ -26,8 +26,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 #define ADJ_T 256
-#define ADJ_RW 512              // r range of one wavefront
-#define ADJ_RB (4 * ADJ_RW)     // r range of one workgroup
+#define ADJ_RW_MIN 256           // r range of one wavefront: 256 (few frame tiles: more workgroups) or 512
 
 // d v_posed = T^T g for every vertex of every column that wants the term (zeros where g = 0)
 __global__ __launch_bounds__(256)
@@ -71,7 +70,7 @@ void k_adj_prep(DevModel M, BatchDev D) {
 struct __align__(16) AdjLDS { float acc[3][64][64]; };      // wavefronts 1..3 hand their tile to wavefront 0's lanes
 
 __global__ __launch_bounds__(ADJ_T, 2)
-void k_lbs_dense_adj(DevModel M, BatchDev D, int n_slices) {
+void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
     __shared__ AdjLDS S;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int m = lane & 15, q = lane >> 4;
@@ -79,8 +78,8 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int n_slices) {
     // y = k tile (8), z = frame tile
     const int slice = blockIdx.x, k0 = blockIdx.y * 64, b0 = blockIdx.z * 64;
     const int LD = 3 * M.Vpad;
-    const int r_lo = slice * ADJ_RB + wv * ADJ_RW;
-    const int r_hi = min(LD, r_lo + ADJ_RW);
+    const int r_lo = min(LD, (slice * 4 + wv) * rw);
+    const int r_hi = min(LD, r_lo + rw);
     const float* pa = M.dirs + (size_t)(k0 + m) * LD + 4 * q;
     const float* pb = D.adj_G + (size_t)(b0 + m) * LD + 4 * q;
     const size_t sa = (size_t)16 * LD;          // next MFMA tile: 16 rows further
@@ -138,7 +137,6 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int n_slices) {
                     out[(size_t)kr * D.Bpad + bc] = s;
                 }
     }
-    (void)n_slices;
 }
 
 // d feat[b][k] = sum over the slices, in slice order
@@ -182,15 +180,17 @@ void k_adj_dA(DevModel M, BatchDev D) {
     }
 }
 
-int sfx_adj_slices(const DevModel& M) { return (3 * M.Vpad + ADJ_RB - 1) / ADJ_RB; }
+int sfx_adj_slices(const DevModel& M) { return (3 * M.Vpad + 4 * ADJ_RW_MIN - 1) / (4 * ADJ_RW_MIN); }      // capacity of adj_part
 
 // gradient of the penetration term with respect to feat (betas / expression / pose feature) and the
 // skinning transforms, for every active column whose pen_want flag is set
 void launch_pen_adjoint(const DevModel& M, const BatchDev& D, hipStream_t s) {
     if (D.nact <= 0) return;
-    const int ns = sfx_adj_slices(M);
+    const int ftiles = (D.nact + 63) / 64;
+    const int rw = ftiles >= 3 ? 512 : ADJ_RW_MIN;       // 8 k tiles x ftiles x slices workgroups: keep >= 256 of them
+    const int ns = (3 * M.Vpad + 4 * rw - 1) / (4 * rw);
     hipLaunchKernelGGL(k_adj_prep, dim3((M.V + 255) / 256, D.nact), dim3(256), 0, s, M, D);
     hipLaunchKernelGGL(k_adj_dA, dim3(SFX_J, D.nact), dim3(64), 0, s, M, D);
-    hipLaunchKernelGGL(k_lbs_dense_adj, dim3(ns, SFX_KD_PAD / 64, (D.nact + 63) / 64), dim3(ADJ_T), 0, s, M, D, ns);
+    hipLaunchKernelGGL(k_lbs_dense_adj, dim3(ns, SFX_KD_PAD / 64, ftiles), dim3(ADJ_T), 0, s, M, D, rw);
     hipLaunchKernelGGL(k_adj_reduce, dim3((D.nact + 63) / 64, SFX_KD_PAD / 4), dim3(256), 0, s, D, ns);
 }
