@@ -36,6 +36,7 @@
 #include "wave_ops.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <vector>
 
 #define PEN_T 1024
@@ -367,7 +368,7 @@ void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __r
 // pair tests over the bucket-sorted entries of k_pen_grid; PEN_WALK_BLOCKS workgroups per frame
 __global__ __launch_bounds__(256)
 void k_pen_walk(PenDev P, const int* __restrict__ want) {
-    __shared__ __align__(16) int s_tile[4 * 64 * 12];
+    __shared__ __align__(16) int s_tile[4 * 128 * 12];       // per wavefront: a sliding window of 128 entry headers
     __shared__ int s_queue[4 * 256];
     __shared__ unsigned long long s_mask[64];
     const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -397,7 +398,7 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
     // gather per ENTRY; the pair tests run on registers and LDS.  A pair is accepted in the cell that
     // holds the low corner of the AABB intersection (both triangles are entered there), and appended
     // to both triangles' partner lists.
-    int* tile = s_tile + wv * 64 * 12;
+    int* tile = s_tile + wv * 128 * 12;
     int* pc = P.pcount + (size_t)b * F;
     int* part = P.partners + (size_t)b * F * P.cap;
     auto load_hdr = [&](int q, bool ok, int (&hd)[12]) {
@@ -423,9 +424,9 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
         }
         __builtin_amdgcn_wave_barrier();
     };
-    int4* tA = reinterpret_cast<int4*>(tile);        // [64] entry | cell | lo.x | lo.y
-    int4* tB = tA + 64;                              // [64] lo.z | hi.x | hi.y | hi.z
-    int4* tC = tA + 128;                             // [64] vertex ids
+    int4* tA = reinterpret_cast<int4*>(tile);        // [128] entry | cell | lo.x | lo.y
+    int4* tB = tA + 128;                             // [128] lo.z | hi.x | hi.y | hi.z
+    int4* tC = tA + 256;                             // [128] vertex ids
     for (int i0 = (blockIdx.x * 4 + wv) * 64; i0 < s_total; i0 += gridDim.x * 256) {
         const int qi = i0 + lane;
         const bool vi = qi < s_total;
@@ -440,24 +441,44 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
         // entries, so this per-lane walk takes as many steps as the fullest bucket of the block)
         const int ck = hi_[1];
         const int bend = vi ? cells[bucket(ck & 1023, (ck >> 10) & 1023, (ck >> 20) & 1023)] : 0;
+        // the walk of all lanes advances in lockstep (lane i looks at entry i + d), so the headers it needs
+        // form a window of 64 entries sliding over the list: two 64-entry halves in LDS, the next half
+        // fetched (one header per lane) whenever the window reaches it -- a crowded bucket of hundreds of
+        // entries is walked out of LDS as well
+        const int bend_max = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)bend));      // entries < 2^24: exact
         tA[lane] = make_int4(hi_[0], hi_[1], hi_[2], hi_[3]);
         tB[lane] = make_int4(hi_[4], hi_[5], hi_[6], hi_[7]);
         tC[lane] = make_int4(hi_[8], hi_[9], hi_[10], 0);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+        int staged = 64;                               // entries i0 .. i0 + staged - 1 are (or were) in the window
         for (int d = 1; ; ++d) {
             const int k = qi + d;
             const bool act = k < bend;
             if (!__ballot(act)) break;
-            const int kl = min(lane + d, 63);
-            int4 h0 = tA[kl], h1 = tB[kl], h2 = tC[kl];
-            if (act && lane + d > 63) {          // the bucket runs past this block's tile: fetch from memory (rare)
-                int hg[12];
-                load_hdr(k, true, hg);
-                h0 = make_int4(hg[0], hg[1], hg[2], hg[3]); h1 = make_int4(hg[4], hg[5], hg[6], hg[7]); h2 = make_int4(hg[8], hg[9], hg[10], 0);
+            if (63 + d >= staged) {                    // wave-uniform: the window's leading edge reaches the next half
+                int hn[12];
+                const int qn_ = i0 + staged + lane;
+                load_hdr(qn_, qn_ < bend_max, hn);
+                const int sl = (staged + lane) & 127;
+                tA[sl] = make_int4(hn[0], hn[1], hn[2], hn[3]);
+                tB[sl] = make_int4(hn[4], hn[5], hn[6], hn[7]);
+                tC[sl] = make_int4(hn[8], hn[9], hn[10], 0);
+                staged += 64;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();     // (d = 1 always refills: covers the first half too)
             }
+            const int kl = (lane + d) & 127;
+            const int4 h0 = tA[kl], h1 = tB[kl], h2 = tC[kl];
             bool pass = act && h0.y == ck && !((skip_i >> (h0.x >> 24)) & 1ull);
             const float kl0 = __int_as_float(h0.z), kl1 = __int_as_float(h0.w), kl2 = __int_as_float(h1.x);
             const float kh0 = __int_as_float(h1.y), kh1 = __int_as_float(h1.z), kh2 = __int_as_float(h1.w);
+#ifdef PEN_COUNT    // diagnostic build: where do the candidates die?  stats[16..19] = walked, same cell, part mask passed, boxes overlap
+            {
+                int* st = P.stats + b * PEN_STATS;
+                const bool c1 = act && h0.y == ck;
+                const bool c2 = ai[0] <= kh0 && kl0 <= ai[3] && ai[1] <= kh1 && kl1 <= ai[4] && ai[2] <= kh2 && kl2 <= ai[5];
+                const unsigned long long m0 = __ballot(act), m1 = __ballot(c1), m2 = __ballot(pass), m3 = __ballot(pass && c2);
+                if (lane == 0) { atomicAdd(&st[16], __popcll(m0)); atomicAdd(&st[17], __popcll(m1)); atomicAdd(&st[18], __popcll(m2)); atomicAdd(&st[19], __popcll(m3)); }
+            }
+#endif
             pass = pass && ai[0] <= kh0 && kl0 <= ai[3] && ai[1] <= kh1 && kl1 <= ai[4] && ai[2] <= kh2 && kl2 <= ai[5];
             if (pass) {
                 pass = cell_key(cell_of(fmaxf(ai[0], kl0), 0), cell_of(fmaxf(ai[1], kl1), 1), cell_of(fmaxf(ai[2], kl2), 2)) == ck;
@@ -837,6 +858,11 @@ extern "C" int sfx_pen_phase_clocks(sfx_pen* h, int32_t B, int32_t* out) {
     hipDeviceSynchronize();
     hipMemcpy(st.data(), h->P.stats, st.size() * sizeof(int), hipMemcpyDeviceToHost);
     for (int i = 0; i < B; ++i) for (int k = 0; k < 11; ++k) out[i * 11 + k] = st[(size_t)i * PEN_STATS + 4 + k];
+#ifdef PEN_COUNT
+    for (int i = 0; i < std::min(B, 4); ++i)
+        fprintf(stderr, "[pen count] frame %d: walked %d, same cell %d, part mask passed %d, boxes overlap %d\n", i,
+                st[(size_t)i * PEN_STATS + 16], st[(size_t)i * PEN_STATS + 17], st[(size_t)i * PEN_STATS + 18], st[(size_t)i * PEN_STATS + 19]);
+#endif
     return 0;
 }
 
