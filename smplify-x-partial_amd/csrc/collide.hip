@@ -591,6 +591,28 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
             const int* mine = part + (size_t)ff * P.cap;
             int np = 64;
             while (np < cc) np <<= 1;
+            if (np <= 128) {
+                // up to 128 partners (the cfgs' max_collisions): bitonic network on one or two registers per
+                // lane, element e = lane + 64 r; exchanges through ds_bpermute, no LDS traffic
+                int x0 = lane < cc ? mine[lane] : 0x7fffffff;
+                int x1 = (np == 128 && lane + 64 < cc) ? mine[lane + 64] : 0x7fffffff;
+                for (int k = 2; k <= np; k <<= 1)
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        if (j == 64) { const int lo = min(x0, x1), hi = max(x0, x1); x0 = lo; x1 = hi; continue; }   // k = 128: ascending
+                        const bool lower = (lane & j) == 0;
+                        const int y0 = __shfl_xor(x0, j);
+                        x0 = (lower == ((lane & k) == 0)) ? min(x0, y0) : max(x0, y0);
+                        if (np == 128) {
+                            const int y1 = __shfl_xor(x1, j);
+                            x1 = (lower == (((lane + 64) & k) == 0)) ? min(x1, y1) : max(x1, y1);
+                        }
+                    }
+                const int keep = min(cc, P.pair_cap - off);
+                if (lane < keep) { plist[off + lane] = x0; pown[off + lane] = ff; }
+                if (lane + 64 < keep) { plist[off + lane + 64] = x1; pown[off + lane + 64] = ff; }
+                continue;
+            }
+
             for (int q = lane; q < np; q += 64) tile[q] = q < cc ? mine[q] : 0x7fffffff;
             for (int k = 2; k <= np; k <<= 1)
                 for (int j = k >> 1; j > 0; j >>= 1) {
