@@ -134,7 +134,8 @@ struct sfx_batch {
     VarList* vl_dev = nullptr;    // [2]: camera, body
     StageW* sw_dev = nullptr;     // [n_stages]
     VarList vl_host[2];
-    int* stage_host = nullptr;    // pinned
+    int* stage_host = nullptr;    // pinned, [2][B]
+    hipEvent_t poll_ev[2] = {nullptr, nullptr};
     std::vector<int> slot_host;
     int K = 0;
     sfx_pen* pen = nullptr;       // interpenetration operator (cfg.interpenetration)
@@ -570,7 +571,9 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.try_both = b->mem.zeros<int>(B);
     D.orient_pass = b->mem.zeros<int>(B);
     if (!D.hist || !D.verts) { sfx_set_error("out of device memory"); b->mem.free_all(); delete b; return -2; }
-    if (hipHostMalloc((void**)&b->stage_host, (size_t)B * sizeof(int)) != hipSuccess) b->stage_host = nullptr;
+    if (hipHostMalloc((void**)&b->stage_host, (size_t)2 * B * sizeof(int)) != hipSuccess) b->stage_host = nullptr;      // two poll buffers
+    if (hipEventCreateWithFlags(&b->poll_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->poll_ev[1], hipEventDisableTiming) != hipSuccess) { sfx_set_error("event creation failed"); b->mem.free_all(); delete b; return -2; }
     *out = b;
     return 0;
 }
@@ -580,6 +583,7 @@ extern "C" void sfx_batch_destroy(sfx_batch* b) {
     if (b->pen) sfx_pen_destroy(b->pen);
     b->mem.free_all();
     if (b->stage_host) hipHostFree(b->stage_host);
+    for (int i = 0; i < 2; ++i) if (b->poll_ev[i]) hipEventDestroy(b->poll_ev[i]);
     delete b;
 }
 
@@ -847,6 +851,48 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
     long tick = 0;
     bool done = false;
     if (fused && dense) { ProfScope p("tick", s); launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, s); }
+    if (fused && dense && b->stage_host) {
+        // dense fused loop, polled one batch of rounds AHEAD: while the host waits for the stage flags
+        // copied after rounds 8i .. 8i+7, rounds 8i+8 .. 8i+15 are already queued, so the GPU never idles
+        // on the host round trip.  A decision (all done / compaction) therefore lags by 8 rounds: finished
+        // frames only ever stay finished, so that is safe; the 8 surplus rounds at the end find nothing to do.
+        auto rounds = [&](int buf) -> int {
+            for (int q = 0; q < 8; ++q, ++tick) {
+                { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
+                if (int rc = eval_penetration(b, -2, s)) return rc;
+                ProfScope p("tick", s);
+                launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 1, s);
+            }
+            SFX_CHECK(hipMemcpyAsync(b->stage_host + (size_t)buf * B, D.stage, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+            SFX_CHECK(hipEventRecord(b->poll_ev[buf], s));
+            return 0;
+        };
+        int cur = 0;
+        if (int rc = rounds(cur)) return rc;
+        while (!done && tick < max_ticks) {
+            if (int rc = rounds(cur ^ 1)) return rc;
+            SFX_CHECK(hipEventSynchronize(b->poll_ev[cur]));
+            const int* hq = b->stage_host + (size_t)cur * B;
+            int n = 0;
+            for (int i = 0; i < B; ++i) if (hq[i] <= last_stage) ++n;
+            done = n == 0;
+            if (!done && (b->D.nact + 31) / 32 != (n + 31) / 32) {      // a 32-frame MFMA tile became free
+                // compaction: finished frames give up their GEMM columns.  The pending evaluation of every
+                // active frame lives in column slot[b] of featT/AT, so re-export after remapping (queued
+                // behind the rounds already in flight, which still use the old mapping consistently).
+                std::vector<int>& sl = b->slot_host;
+                sl.assign(B, 0);
+                int q = 0;
+                for (int i = 0; i < B; ++i) sl[i] = (hq[i] <= last_stage) ? q++ : 0;
+                SFX_CHECK(hipMemcpyAsync(D.slot, sl.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
+                b->D.nact = n;
+                ProfScope p("tick", s);
+                launch_tick_dense(M, b->D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, s);   // re-export only
+            }
+            cur ^= 1;
+        }
+        SFX_CHECK(hipStreamSynchronize(s));
+    } else
     while (!done && tick < max_ticks) {
         if (fused && !dense) {
             // persistent per-frame workgroups; the host only re-launches frames that need more ticks
