@@ -856,7 +856,10 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
         // copied after rounds 8i .. 8i+7, rounds 8i+8 .. 8i+15 are already queued, so the GPU never idles
         // on the host round trip.  A decision (all done / compaction) therefore lags by 8 rounds: finished
         // frames only ever stay finished, so that is safe; the 8 surplus rounds at the end find nothing to do.
+        static const bool dbg_nact = getenv("SFX_DEBUG_NACT") != nullptr;
+        static long nact_hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // rounds by active GEMM columns: <=32, <=64, ..., <=256, more
         auto rounds = [&](int buf) -> int {
+            if (dbg_nact) nact_hist[std::min(8, (D.nact - 1) / 32)] += 8;
             for (int q = 0; q < 8; ++q, ++tick) {
                 { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
                 if (int rc = eval_penetration(b, -2, s)) return rc;
@@ -892,6 +895,11 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
             cur ^= 1;
         }
         SFX_CHECK(hipStreamSynchronize(s));
+        if (dbg_nact) {
+            fprintf(stderr, "[sfx] rounds by active columns (<=32, <=64, ..., <=256, more), cumulative:");
+            for (int i = 0; i < 9; ++i) fprintf(stderr, " %ld", nact_hist[i]);
+            fprintf(stderr, "\n");
+        }
     } else
     while (!done && tick < max_ticks) {
         if (fused && !dense) {
