@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--workload", default="body", choices=["body", "full", "pen"])
     ap.add_argument("--prof-every", type=int, default=8, help="HIP-event-time every N-th launch of each kernel")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra needed-rows measurement")
+    ap.add_argument("--no-parity", action="store_true", help="skip the fit of the reference's golden frames (profiling passes: "
+                    "keeps their 2-frame launches out of the per-kernel averages)")
     ap.add_argument("--groups", type=int, default=1, help="independent sub-batches per GPU (host threads/streams)")
     args = ap.parse_args()
 
@@ -339,10 +341,11 @@ def main():
                                        "L-BFGS chain; the meaningful figure is frames/s"}
         if alt is not None:
             out["alt"] = alt
-        try:
-            out["reference_parity"] = reference_parity(model, args.lbs)
-        except Exception as e:
-            out["reference_parity"] = {"error": repr(e)}
+        if not args.no_parity and not full and not pen:
+            try:
+                out["reference_parity"] = reference_parity(model, args.lbs)
+            except Exception as e:
+                out["reference_parity"] = {"error": repr(e)}
         if not args.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(model, cfg, frames, float(ref_evals.mean()))

@@ -4,9 +4,9 @@
 set -x
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r1prof; mkdir -p $O
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu"
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu --no-parity"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o p -- $CMD > $O/bench_under_rocprof.json 2> $O/kt.log
-PM="python bench.py --steps 1 --warmup 0 --no-cpu --no-alt"
+PM="python bench.py --steps 1 --warmup 0 --no-cpu --no-alt --no-parity"
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o p -- $PM > /dev/null 2> $O/pmc_f.log
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o p -- $PM > /dev/null 2> $O/pmc_w.log
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_s -o p -- $PM > /dev/null 2> $O/pmc_s.log
