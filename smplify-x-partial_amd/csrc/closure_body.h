@@ -26,7 +26,7 @@
 
 #define CT 256
 // RIF = 2-KiB blend-shape rows in flight per wavefront (forward dots and dfeat adjoint): 4 for the
-// body-only variant (33 rows: 16 + 16 + 1), 8 for the full model (675 rows)
+// body-only variant (33 rows: 16 + 16 + 1), SFX_RIF_BIG for the full model (675 rows)
 #define FD_GT 0
 #define FD_CONF (2 * SFX_MAX_K)
 #define FD_JW (3 * SFX_MAX_K)
@@ -195,7 +195,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     // the VPoser activations) in D.fwd; reload it instead of recomputing pose assembly,
     // Rodrigues, joint regression and the kinematic chain
     constexpr bool HAS_VP = !std::is_same<decltype(S.V), EmptyLDS>::value;
-    constexpr int RIF = (LDS::kMaxItems <= SFX_SMALL_ITEMS) ? 4 : 8;
+    constexpr int RIF = (LDS::kMaxItems <= SFX_SMALL_ITEMS) ? 4 : SFX_RIF_BIG;
     constexpr int FWD_PREFIX = (int)(offsetof(LDS, vp) / sizeof(float));
     static_assert(FWD_PREFIX % 4 == 0 && FWD_PREFIX + 96 + 2 * VP_H + 128 + 64 <= SFX_FWD_N, "forward-state blob layout");
     const bool reuse = args.reuse_fwd != 0;
