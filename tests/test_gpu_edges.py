@@ -137,6 +137,33 @@ def test_bench_two_rank_control_flow_rehearsal():
     assert abs(d["value"] - 2 * 32 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
+@pytest.mark.parametrize("workload", ["body", "full", "pen"])
+def test_bench_line_contract(workload):
+    """bench.py on a small batch: one JSON line with the contract's keys, the roofline object of the dense
+    kernel, and (headline workload) the loss delta against the reference's own fits of the golden frames."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--frames", "32", "--no-cpu",
+           "--no-alt", "--workload", workload]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["kernel"] == "k_lbs_dense" and r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert np.isfinite(d["config"]["final_loss_mean"])
+    if workload == "body":
+        rp = d["reference_parity"]
+        assert rp["frames"] == 2 and rp["camera_stage_loss_rel_delta_max"] < 1e-4
+        assert rp["final_loss_rel_delta_mean"] < max(5 * rp["reference_f32_vs_f64_rel_delta_mean"], 5e-2)
+
+
 @pytest.mark.parametrize("mode", ["rows", "dense"])
 def test_vertices_with_many_skinning_weights(synth_model, cfg_body, mode):
     """lbs_weights rows with more nonzeros than the packed 8-entry form (learned weights of a real
