@@ -239,6 +239,32 @@ def test_demo_config1_matches_reference(gpu, synth_model, cfg_body):
         assert np.all(rel[1:] < 5e-2), (name, st["stage_loss"][0], ref)
 
 
+@pytest.mark.parametrize("name,yaml_", [("coco25", "fit_smplx_combined_coco25.yaml"), ("halpe", "fit_smplx_combined_halpe.yaml")])
+@pytest.mark.parametrize("mode", ["rows", "dense"])
+def test_full_model_fit_matches_reference(gpu, synth_model, name, yaml_, mode):
+    """Hands + face + contour (K = 135 / 136 keypoints, every prior term of SMPLifyLoss active, hand / face
+    joint weights of the schedule) with a regression prior, coco25 and halpe formats, against the REAL
+    reference's fit_single_frame (tests/golden/e2e_full.npz, fp32 and fp64 runs): camera stage 1e-4, body
+    stages within the reference's own fp32 / fp64 spread as everywhere else."""
+    from smplifyx_amd import driver
+    g = _golden("e2e_full")
+    cfg = H.load_cfg(yaml_, interpenetration=False)
+    cfg["use_camera_prior"] = False
+    dm = _dm(synth_model, cfg)
+    kp = g[name + "_keypoints"]
+    K = kp.shape[1]
+    assert K == len(H.joint_map_for(cfg))
+    res = driver.fit_frames(dm, cfg, kp, H.base_joint_weights(cfg, K), 600, 800, 5000.0, reg_pose=g[name + "_reg_pose"],
+                            reg_global=g[name + "_reg_global"], lbs_mode=mode)
+    ref32, ref64 = g[name + "_f32_losses"], g[name + "_f64_losses"]
+    spread = np.abs(ref32 - ref64) / np.abs(ref64)
+    rel = np.abs(res["stage_loss"][0] - ref32) / np.abs(ref32)
+    assert rel[0] < 1e-4, (rel, res["stage_loss"][0], ref32)
+    assert rel[1] < max(2 * spread[1], 3e-3), (rel, spread)
+    assert np.all(rel[2:] < np.maximum(3 * spread[2:], 5e-2)), (rel, spread)
+    assert res["left_hand_pose"].shape == (1, 12) and res["expression"].shape == (1, 10) and np.all(np.isfinite(res["jaw_pose"]))
+
+
 def test_shard_invariance_bitwise(gpu, synth_model, cfg_body):
     """A frame's result does not depend on which other frames share its batch."""
     cfg = dict(cfg_body); cfg["use_camera_prior"] = False

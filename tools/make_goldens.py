@@ -2,7 +2,7 @@
 """Generate tests/golden/*.npz by running the REAL reference (imported from
 /root/reference, this container only) on seeded inputs.  The reference Python never
 ships; only these numeric arrays do.  Re-run: `python tools/make_goldens.py [what ...]`
-with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm}.
+with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full}.
 
 The LBS itself has no reference implementation here (external `smplx`, absent): wherever a
 body model is needed the reference drives oracle.body_model.SMPLXRef built from
@@ -289,6 +289,40 @@ def gen_e2e_vposer():
     _save("e2e_vposer", **out)
 
 
+def gen_e2e_full():
+    """Reference fit_single_frame with hands + face + face contour (K = 135 keypoints, all prior terms of
+    SMPLifyLoss active) and a regression prior, use_vposer False: cfg_files/fit_smplx_combined_coco25.yaml
+    (3 stages) and cfg_files/fit_smplx_combined_halpe.yaml (halpe keypoints K = 136, joint confidences
+    used) without the interpenetration term, one synthetic frame each, fp32 and fp64."""
+    import helpers as H
+    from smplifyx_amd import synthetic
+    from scipy.spatial.transform import Rotation as Rot
+    model = synthetic.make_synthetic_model(0)
+    out = {}
+    for name, yaml_ in (("coco25", "fit_smplx_combined_coco25.yaml"), ("halpe", "fit_smplx_combined_halpe.yaml")):
+        cfg = H.load_cfg(yaml_, use_cuda=False, interpenetration=False)
+        cfg["use_camera_prior"] = False
+        K = len(H.joint_map_for(cfg))
+        frames = synthetic.make_frames(1, H.oracle_joints_fn(model, cfg), K, focal=5000.0)
+        out[name + "_keypoints"] = frames["keypoints"]
+        out[name + "_reg_pose"], out[name + "_reg_global"] = frames["reg_pose"], frames["reg_global"]
+        bp = Rot.from_euler("XYZ", frames["reg_pose"][0].reshape(21, 3).astype(np.float64)).as_matrix().astype(np.float32)
+        go = Rot.from_euler("XYZ", frames["reg_global"][0].astype(np.float64)[None]).as_matrix().astype(np.float32)
+        c = dict(cfg); c["regression_prior"] = "ExPose"
+        for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+            bm = H.oracle_model(model, cfg, dtype)
+            res, losses, evals = _run_reference_fit(bm, c, frames["keypoints"][:1], frames["H"], frames["W"], frames["focal"],
+                                                    H.base_joint_weights(cfg, K), dtype,
+                                                    expose={"body_pose": bp, "global_orient": go})
+            out["%s_%s_losses" % (name, tag)] = losses
+            out["%s_%s_evals" % (name, tag)] = evals
+            for k in ("camera_translation", "global_orient", "betas", "body_pose", "left_hand_pose", "right_hand_pose",
+                      "expression", "jaw_pose"):
+                out["%s_%s_%s" % (name, tag, k)] = np.asarray(res[k], np.float64)
+            print("e2e full", name, tag, losses, evals)
+    _save("e2e_full", **out)
+
+
 def gen_demo():
     """BASELINE config 1: the two demo/ frames, body-only, combined regression prior +
     camera prior (cfg_files/fit_smplx_combined_coco25.yaml), reference fit in fp32."""
@@ -436,4 +470,4 @@ if __name__ == "__main__":
     for w in todo:
         {"objective": gen_objective, "lbfgs": gen_lbfgs, "euler": gen_euler, "tables": gen_tables,
          "e2e": gen_e2e, "demo": gen_demo, "e2e_vposer": gen_e2e_vposer, "parser": gen_parser, "eval": gen_eval,
-         "gmm": gen_gmm}[w]()
+         "gmm": gen_gmm, "e2e_full": gen_e2e_full}[w]()
