@@ -317,6 +317,32 @@ def test_side_view_second_orientation_on_device(gpu, synth_model, cfg_body):
     assert res["stage_evals"][1, 1:].sum() == s0["stage_evals"][0, 1:].sum() + s1["stage_evals"][0, 1:].sum()
 
 
+@pytest.mark.parametrize("mode", ["rows", "dense"])
+def test_side_view_fit_matches_reference(gpu, synth_model, cfg_body, mode):
+    """The same side-view frame through the REAL reference (tests/golden/e2e_side.npz: both orientation
+    passes, fp32 and fp64): camera stage 1e-4; the first body stage of the first pass and the kept final
+    loss (minimum over the two passes) within the reference's own fp32 / fp64 spread.  Which pass wins is
+    itself chaotic here (pass 1 in the reference's fp32 run, pass 2 in its fp64 run: 10040.4 vs 10041.6 /
+    10039.8 vs 10023.8), so the kept parameters are not compared."""
+    from smplifyx_amd import driver
+    g = _golden("e2e_side")
+    cfg = dict(cfg_body); cfg["use_camera_prior"] = False
+    dm = _dm(synth_model, cfg)
+    res = driver.fit_frames(dm, cfg, g["keypoints"], H.base_joint_weights(cfg, 25), 600, 800, 5000.0, reg_pose=g["reg_pose"],
+                            reg_global=g["reg_global"], lbs_mode=mode)
+    assert list(res["n_orient"]) == [2]
+    r32, r64 = g["f32_losses"], g["f64_losses"]
+    spread = np.abs(r32 - r64) / np.abs(r64)
+    sl = res["stage_loss"][0]
+    assert abs(sl[0] - r32[0]) / r32[0] < 1e-4, (sl, r32)
+    tol = max(3 * spread[1:].max(), 5e-2)
+    kept_ref = min(r32[3], r32[6])
+    assert abs(res["final_loss"][0] - kept_ref) / kept_ref < tol, (res["final_loss"], r32, tol)
+    assert min(abs(sl[1] - r32[1]) / r32[1], abs(sl[1] - r32[4]) / r32[4]) < max(2 * spread[[1, 4]].max(), 3e-3), (sl, r32)
+    ev = res["stage_evals"][0, 1:].sum()
+    assert 0.5 * g["f32_evals"][1:].sum() <= ev <= 1.5 * max(g["f32_evals"][1:].sum(), g["f64_evals"][1:].sum()), ev
+
+
 def test_closure_with_vposer_matches_oracle(gpu, synth_model):
     """BASELINE config 3: full SMPL-X (hands + face + contour, K=135), VPoser decode in the loop
     (cfg_files/fit_smplx_smplifyx.yaml: use_vposer True, 5 stages).  Loss + gradient wrt the
