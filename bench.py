@@ -107,19 +107,17 @@ def cpu_baseline(model, cfg, frames, ref_evals_per_frame, budget_s=25.0):
 
 
 def reference_parity(model, lbs_mode):
-    """Second half of BASELINE's metric ("mean reprojection-loss delta vs reference"): the frames of
-    tests/golden/e2e_synth.npz were fitted by the REAL reference (smplifyx/fit_single_frame.py imported
-    in the build container, fp32 and fp64; tools/make_goldens.py); fit the same frames here and report
-    the relative difference of the final loss next to the reference's own fp32-vs-fp64 difference."""
-    from smplifyx_amd import cmd_parser, driver, engine, utils as U
-    path = os.path.join(ROOT, "tests", "golden", "e2e_synth.npz")
+    """Second half of BASELINE's metric ("mean reprojection-loss delta vs reference"): frames 0-3 of this
+    benchmark's synthetic sequence were fitted by the REAL reference with this benchmark's configuration
+    (smplifyx/fit_single_frame.py imported in the build container, fp32 and fp64; tools/make_goldens.py
+    e2e_bench -> tests/golden/e2e_bench.npz); fit the same frames here and report the relative difference
+    of the final loss next to the reference's own fp32-vs-fp64 difference."""
+    from smplifyx_amd import driver, engine, utils as U
+    path = os.path.join(ROOT, "tests", "golden", "e2e_bench.npz")
     if not os.path.exists(path):
         return None
     g = np.load(path)
-    cfg = cmd_parser.load_config(os.path.join(ROOT, "cfg_files", "fit_smplx_combined_coco25.yaml"),
-                                 dict(interpenetration=False, visualize=False, interactive=False, save_vertices=False,
-                                      use_gender_classifier=False, use_hands=False, use_face=False))
-    cfg["use_camera_prior"] = False
+    cfg = build_cfg("body")
     jm = U.smpl_to_annotation("smplx", use_hands=False, use_face=False, use_face_contour=cfg["use_face_contour"],
                               format=cfg["format"])
     dm = engine.DeviceModel(model, joint_map=jm, num_betas=cfg["num_betas"],
@@ -136,12 +134,26 @@ def reference_parity(model, lbs_mode):
     r32 = np.array([g["f%d_f32_losses" % i][-1] for i in range(n)])
     r64 = np.array([g["f%d_f64_losses" % i][-1] for i in range(n)])
     cam = np.array([abs(res["stage_loss"][i, 0] - g["f%d_f32_losses" % i][0]) / abs(g["f%d_f32_losses" % i][0]) for i in range(n)])
-    return {"frames": int(n), "source": "tests/golden/e2e_synth.npz: reference fit_single_frame (fp32 / fp64) on the same frames",
+    return {"frames": int(n), "source": "tests/golden/e2e_bench.npz: reference fit_single_frame (fp32 / fp64) on frames 0-%d of this "
+                                        "benchmark's sequence, this benchmark's configuration" % (n - 1),
             "final_loss": [float(x) for x in ours], "reference_final_loss_f32": [float(x) for x in r32],
+            "reference_final_loss_f64": [float(x) for x in r64],
             "final_loss_rel_delta_mean": float(np.mean(np.abs(ours - r32) / np.abs(r32))),
             "reference_f32_vs_f64_rel_delta_mean": float(np.mean(np.abs(r32 - r64) / np.abs(r64))),
             "camera_stage_loss_rel_delta_max": float(cam.max()),
-            "note": "the optimisation is chaotic past the camera stage; the reference's own fp32-vs-fp64 difference is the yardstick"}
+            "per_stage_loss_rel_delta_mean": [float(np.mean([abs(res["stage_loss"][i, k] - g["f%d_f32_losses" % i][k]) /
+                                                             abs(g["f%d_f32_losses" % i][k]) for i in range(n)]))
+                                              for k in range(res["stage_loss"].shape[1])],
+            "reference_f32_vs_f64_per_stage_rel_delta_mean": [float(np.mean([abs(g["f%d_f32_losses" % i][k] - g["f%d_f64_losses" % i][k]) /
+                                                                             abs(g["f%d_f64_losses" % i][k]) for i in range(n)]))
+                                                              for k in range(res["stage_loss"].shape[1])],
+            "closure_evals": [int(x) for x in res["stage_evals"].sum(1)],
+            "reference_closure_evals_f32": [int(g["f%d_f32_evals" % i].sum()) for i in range(n)],
+            "note": "per stage: camera stage, then the 5 body stages.  The optimisation is chaotic past the camera stage and "
+                    "the last two stages (body pose prior weight 4.78) end on run_fitting's ftol test, which fp32 noise "
+                    "trips at different iterations in every implementation (the reference's own fp32 run stops the last "
+                    "stage after 10-13 evaluations on frames 2 and 3, its fp64 run after ~1000): the reference's fp32-vs-"
+                    "fp64 difference is the yardstick"}
 
 
 def main():

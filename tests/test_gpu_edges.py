@@ -160,7 +160,7 @@ def test_bench_line_contract(workload):
     assert np.isfinite(d["config"]["final_loss_mean"])
     if workload == "body":
         rp = d["reference_parity"]
-        assert rp["frames"] == 2 and rp["camera_stage_loss_rel_delta_max"] < 1e-4
+        assert rp["frames"] == 4 and rp["camera_stage_loss_rel_delta_max"] < 1e-4
         assert rp["final_loss_rel_delta_mean"] < max(5 * rp["reference_f32_vs_f64_rel_delta_mean"], 5e-2)
 
 

@@ -2,7 +2,7 @@
 """Generate tests/golden/*.npz by running the REAL reference (imported from
 /root/reference, this container only) on seeded inputs.  The reference Python never
 ships; only these numeric arrays do.  Re-run: `python tools/make_goldens.py [what ...]`
-with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_side}.
+with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_side, e2e_bench}.
 
 The LBS itself has no reference implementation here (external `smplx`, absent): wherever a
 body model is needed the reference drives oracle.body_model.SMPLXRef built from
@@ -369,6 +369,38 @@ def gen_e2e_side():
     _save("e2e_side", **out)
 
 
+def gen_e2e_bench():
+    """The benchmark's own configuration (bench.py build_cfg('body'): cfg_files/fit_smplx_smplifyx.yaml
+    weights, 5 body stages, body-only keypoints, use_vposer False + regression prior) through the
+    reference: frames 0-3 of the benchmark's synthetic sequence, fp32 and fp64.  bench.py's
+    reference_parity leg reports the loss delta against these."""
+    import helpers as H
+    from smplifyx_amd import synthetic
+    from scipy.spatial.transform import Rotation as Rot
+    model = synthetic.make_synthetic_model(0)
+    cfg = H.load_cfg("fit_smplx_smplifyx.yaml", use_hands=False, use_face=False, use_vposer=False, use_cuda=False)
+    cfg["use_camera_prior"] = False
+    K = len(H.joint_map_for(cfg))
+    n = 4
+    frames = synthetic.make_frames(n, H.oracle_joints_fn(model, cfg), K, focal=5000.0)
+    out = dict(keypoints=frames["keypoints"], reg_pose=frames["reg_pose"], reg_global=frames["reg_global"])
+    c = dict(cfg); c["regression_prior"] = "ExPose"
+    for i in range(n):
+        bp = Rot.from_euler("XYZ", frames["reg_pose"][i].reshape(21, 3).astype(np.float64)).as_matrix().astype(np.float32)
+        go = Rot.from_euler("XYZ", frames["reg_global"][i].astype(np.float64)[None]).as_matrix().astype(np.float32)
+        for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+            bm = H.oracle_model(model, cfg, dtype)
+            res, losses, evals = _run_reference_fit(bm, c, frames["keypoints"][i:i + 1], frames["H"], frames["W"],
+                                                    frames["focal"], H.base_joint_weights(cfg, K), dtype,
+                                                    expose={"body_pose": bp, "global_orient": go})
+            out["f%d_%s_losses" % (i, tag)] = losses
+            out["f%d_%s_evals" % (i, tag)] = evals
+            for k in ("camera_translation", "global_orient", "betas", "body_pose"):
+                out["f%d_%s_%s" % (i, tag, k)] = np.asarray(res[k], np.float64)
+            print("e2e bench frame", i, tag, losses, evals)
+    _save("e2e_bench", **out)
+
+
 def gen_demo():
     """BASELINE config 1: the two demo/ frames, body-only, combined regression prior +
     camera prior (cfg_files/fit_smplx_combined_coco25.yaml), reference fit in fp32."""
@@ -516,4 +548,4 @@ if __name__ == "__main__":
     for w in todo:
         {"objective": gen_objective, "lbfgs": gen_lbfgs, "euler": gen_euler, "tables": gen_tables,
          "e2e": gen_e2e, "demo": gen_demo, "e2e_vposer": gen_e2e_vposer, "parser": gen_parser, "eval": gen_eval,
-         "gmm": gen_gmm, "e2e_full": gen_e2e_full, "e2e_side": gen_e2e_side}[w]()
+         "gmm": gen_gmm, "e2e_full": gen_e2e_full, "e2e_side": gen_e2e_side, "e2e_bench": gen_e2e_bench}[w]()
