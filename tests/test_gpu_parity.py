@@ -265,6 +265,29 @@ def test_full_model_fit_matches_reference(gpu, synth_model, name, yaml_, mode):
     assert res["left_hand_pose"].shape == (1, 12) and res["expression"].shape == (1, 10) and np.all(np.isfinite(res["jaw_pose"]))
 
 
+@pytest.mark.parametrize("mode", ["rows", "dense"])
+def test_benchmark_configuration_matches_reference(gpu, synth_model, mode):
+    """bench.py's own configuration (fit_smplx_smplifyx.yaml weights, 5 body stages, body-only, regression
+    prior) on frames 0-3 of its sequence against the REAL reference (tests/golden/e2e_bench.npz).  Camera
+    stage 1e-4; body stages 1-3 within max(2 x the reference's fp32/fp64 spread, 3e-3); stages 4-5 (prior
+    weight 4.78: they end on the ftol test, tripped by fp32 noise) within max(3 x spread, 0.25) per frame."""
+    import bench as BB
+    from smplifyx_amd import driver
+    g = _golden("e2e_bench")
+    cfg = BB.build_cfg("body")
+    dm = _dm(synth_model, cfg)
+    n = g["keypoints"].shape[0]
+    res = driver.fit_frames(dm, cfg, g["keypoints"], H.base_joint_weights(cfg, 25), 600, 800, 5000.0, reg_pose=g["reg_pose"],
+                            reg_global=g["reg_global"], lbs_mode=mode)
+    for i in range(n):
+        r32, r64 = g["f%d_f32_losses" % i], g["f%d_f64_losses" % i]
+        spread = np.abs(r32 - r64) / np.abs(r64)
+        rel = np.abs(res["stage_loss"][i] - r32) / np.abs(r32)
+        assert rel[0] < 1e-4, (i, rel)
+        assert np.all(rel[1:4] < np.maximum(2 * spread[1:4], 3e-3)), (i, rel, spread)
+        assert np.all(rel[4:] < np.maximum(3 * spread[4:], 0.25)), (i, rel, spread)
+
+
 def test_shard_invariance_bitwise(gpu, synth_model, cfg_body):
     """A frame's result does not depend on which other frames share its batch."""
     cfg = dict(cfg_body); cfg["use_camera_prior"] = False
