@@ -49,8 +49,10 @@ def gather_records(rec, n_frames, device=None):
     """All ranks call with their [B_r, RECORD_LEN] block; every rank gets [n_frames, RECORD_LEN]
     in frame order.  Blocks are padded to the largest shard so one all_gather suffices."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return np.asarray(rec, np.float32)
+    import os
+    if not (dist.is_available() and dist.is_initialized()) or \
+            (dist.get_world_size() == 1 and os.environ.get("SFX_FORCE_COLLECTIVE") != "1"):
+        return np.asarray(rec, np.float32)         # (SFX_FORCE_COLLECTIVE=1: a 1-GPU box walks the RCCL call as well)
     world = dist.get_world_size()
     if dist.get_backend() == "gloo":
         device = None           # gloo gathers host tensors (CPU tests, single-GPU rehearsal of the N > 1 path)

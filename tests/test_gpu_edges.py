@@ -137,6 +137,25 @@ def test_bench_two_rank_control_flow_rehearsal():
     assert abs(d["value"] - 2 * 32 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
+def test_bench_rccl_calls_single_rank():
+    """bench.py under torch.distributed.run with ONE rank and SFX_FORCE_COLLECTIVE=1: the RCCL calls of the
+    N > 1 path (init_process_group('nccl', device_id=...), barrier, all_reduce(MAX) of the float64 time on the
+    device, the all_gather of the result records as device tensors) against the real backend."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SFX_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1")
+    env.pop("SFX_BENCH_REHEARSAL", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+           "--frames", "32", "--no-cpu", "--no-alt", "--no-parity"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["frames_per_gpu"] == 32 and d["value"] > 0
+
+
 @pytest.mark.parametrize("workload", ["body", "full", "pen"])
 def test_bench_line_contract(workload):
     """bench.py on a small batch: one JSON line with the contract's keys, the roofline object of the dense
