@@ -4,7 +4,6 @@ None})`.  Inside the fitting loop these terms are evaluated by the HIP closure k
 modules below hold the constants and give the same numbers stand-alone."""
 import os
 import pickle
-import sys
 
 import numpy as np
 import torch
