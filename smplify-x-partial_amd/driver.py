@@ -67,6 +67,10 @@ def _make_batch(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose, reg_gl
                 cam_prior_center, lbs_mode, reuse_entry_eval, body_pose_prior=None):
     """FrameBatch with frames, parameters and the initial camera set the way
     fit_single_frame.py:209-294,358-411 prepares one frame."""
+    if cfg.get("optim_type", "lbfgsls") != "lbfgsls":
+        raise NotImplementedError("the batched device path runs optim_type 'lbfgsls' (every shipped cfg); %r is available "
+                                  "through optimizers.create_optimizer + FittingMonitor.run_fitting (host-driven steps, "
+                                  "HIP closure)" % cfg.get("optim_type"))
     prep = prepare_frames(cfg, keypoints, joint_weights)
     kp = prep["keypoints"]
     B, K = kp.shape[:2]

@@ -305,12 +305,27 @@ class FittingMonitor(object):
 
     def run_fitting(self, optimizer, closure, params, body_model, stage, use_vposer=True, pose_embedding=None,
                     vposer=None, **kwargs):
-        """The whole step loop (fitting.py:174-217) on device; returns the step-entry loss of the
-        last step, like the reference."""
+        """The whole step loop (fitting.py:174-217) on device for the 'lbfgsls' optimiser; returns the
+        step-entry loss of the last step, like the reference.  Any other optimiser (torch.optim objects of
+        optim_factory) is driven from the host with the same stopping rules, each closure evaluation on
+        the device."""
         if not isinstance(closure, EngineClosure):
             raise TypeError("run_fitting needs the closure returned by create_fitting_closure")
-        closure._check_params(list(params))
-        return closure.run_stage(stage)
+        if hasattr(optimizer, "_bind"):
+            closure._check_params(list(params))
+            return closure.run_stage(stage)
+        prev_loss = None
+        for n in range(self.maxiters):
+            loss = optimizer.step(lambda: closure(stage=stage))
+            if torch.isnan(loss).sum() > 0 or torch.isinf(loss).sum() > 0:
+                break
+            if n > 0 and prev_loss is not None and self.ftol > 0:
+                if utils.rel_change(prev_loss, loss.item()) <= self.ftol:
+                    break
+            if all(torch.abs(var.grad.view(-1).max()).item() < self.gtol for var in params if var.grad is not None):
+                break
+            prev_loss = loss.item()
+        return prev_loss
 
     def create_fitting_closure(self, optimizer, body_model, camera=None, gt_joints=None, loss=None,
                                joints_conf=None, joint_weights=None, return_verts=True, return_full_pose=False,

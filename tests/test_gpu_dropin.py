@@ -285,3 +285,56 @@ def test_batched_main_writes_reference_layout(synth_model, tmp_path):
         assert np.abs(res["betas"] - g["f%d_f32_betas" % i]).max() < 0.25
         assert os.path.isdir(out / "meshes" / nme) and os.path.isdir(out / "images" / nme / "000")
         assert os.path.getsize(out / "results" / nme / "vertices.ply") > 10475 * 12
+
+
+@pytest.mark.parametrize("optim_type,lr,iters", [("adam", 0.01, 25), ("lbfgs", 1.0, 5), ("sgd", None, 10), ("rmsprop", 1e-3, 10)])
+def test_other_optimizers_are_driven_from_the_host(synth_model, optim_type, lr, iters):
+    """optim_factory's adam / lbfgs / sgd / rmsprop (smplifyx/optimizers/optim_factory.py:45-63): torch.optim
+    objects stepping the caller's tensors, every closure evaluation (loss + .grad) on the device.  The
+    camera stage (6 variables, well conditioned) must make progress with each of them; the batched
+    driver refuses anything but 'lbfgsls' loudly."""
+    from smplifyx_amd import driver, fitting
+    from smplifyx_amd.optimizers import optim_factory
+    g = np.load(os.path.join(GOLD, "e2e_synth.npz"))
+    cfg = H.load_cfg("fit_smplx_combined_coco25.yaml", use_hands=False, use_face=False)
+    cfg.update(use_camera_prior=False, optim_type=optim_type, lr=lr if lr is not None else 1.0, maxiters=iters)
+    bm, camera = _setup(synth_model, cfg)
+    dev = torch.device("cuda")
+    dtype = torch.float32
+    pose_embedding = torch.tensor(g["reg_pose"][:1], device=dev, requires_grad=True)
+    bm.reset_params(global_orient=torch.tensor(g["reg_global"][:1], device=dev), body_pose=pose_embedding)
+    kd = torch.tensor(g["keypoints"][:1], dtype=dtype, device=dev)
+    gt_joints, joints_conf = kd[:, :, :2], kd[:, :, 2].reshape(1, -1)
+    init_idxs = [k for k in cfg["init_joints_idxs"] if float(gt_joints[0, k, 0]) != 0]
+    init_t = fitting.guess_init(bm, gt_joints, cfg["body_tri_idxs"], use_vposer=False, pose_embedding=pose_embedding,
+                                model_type="smplx", focal_length=5000.0, dtype=dtype).reshape(1, -1)
+    with torch.no_grad():
+        camera.translation[:] = init_t
+        camera.center[:] = torch.tensor([800, 600], dtype=dtype) * 0.5
+    camera_loss = fitting.create_loss("camera_init", joints_conf=joints_conf, use_conf=cfg["use_conf_for_camera_init"],
+                                      trans_estimation=init_t, init_joints_idxs=torch.tensor(init_idxs, device=dev),
+                                      depth_loss_weight=1e2, dtype=dtype).to(dev)
+    with fitting.FittingMonitor(**cfg) as monitor:
+        camera_loss.reset_loss_weights({"data_weight": 1000 / 600})
+        camera.translation.requires_grad = True
+        bm.global_orient.requires_grad = True
+        cam_params = [camera.translation, bm.global_orient]
+        opt, cg = optim_factory.create_optimizer(cam_params, **cfg)
+        assert type(opt).__module__.startswith("torch.optim")
+        fit_camera = monitor.create_fitting_closure(opt, bm, camera, gt_joints, camera_loss, create_graph=cg, use_vposer=False,
+                                                    pose_embedding=pose_embedding, return_full_pose=False, return_verts=False)
+        l0 = float(fit_camera(stage=0))
+        if lr is None:      # plain gradient descent needs a step matched to the gradient's scale: move 1 cm per step at most
+            gmax = max(float(p.grad.abs().max()) for p in cam_params)
+            for grp in opt.param_groups:
+                grp["lr"] = 0.01 / gmax
+                grp["momentum"] = 0.0
+                grp["nesterov"] = False
+        t0 = camera.translation.detach().clone()
+        lf = monitor.run_fitting(opt, fit_camera, cam_params, bm, stage=0, use_vposer=False, pose_embedding=pose_embedding)
+        l1 = float(fit_camera(stage=0))
+        assert lf is not None and np.isfinite(lf) and np.isfinite(l1) and l1 < l0, (optim_type, l0, lf, l1)
+        assert not torch.equal(camera.translation.detach(), t0)
+    with pytest.raises(NotImplementedError):
+        driver.fit_frames(bm.device_model, cfg, g["keypoints"][:1], H.base_joint_weights(cfg, 25), 600, 800, 5000.0,
+                          reg_pose=g["reg_pose"][:1], reg_global=g["reg_global"][:1])
