@@ -353,12 +353,12 @@ def main():
                                        "L-BFGS chain; the meaningful figure is frames/s"}
         if alt is not None:
             out["alt"] = alt
-        if not args.no_parity and not full and not pen:
+        if not args.no_parity and not full and not pen and world == 1:
             try:
                 out["reference_parity"] = reference_parity(model, args.lbs)
             except Exception as e:
                 out["reference_parity"] = {"error": repr(e)}
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:       # (the CPU baseline is reported at N = 1 only)
             try:
                 out["cpu_baseline"] = cpu_baseline(model, cfg, frames, float(ref_evals.mean()))
             except Exception as e:      # the baseline is a report, never the product path
