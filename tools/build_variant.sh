@@ -4,6 +4,7 @@
 set -e
 HERE=/root/repo/smplify-x-partial_amd/csrc; TAG=$1; FILE=$2; shift; shift
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result "$@" -c $HERE/$FILE.hip -o /tmp/${FILE}_$TAG.o
+case " api closure lbs_dense lbfgs fused collide lbs_adjoint " in *" $FILE "*) ;; *) echo "unknown csrc file $FILE"; exit 1;; esac
 OBJS=""
 for f in api closure lbs_dense lbfgs fused collide lbs_adjoint; do
   if [ "$f" == "$FILE" ]; then OBJS="$OBJS /tmp/${FILE}_$TAG.o"; else OBJS="$OBJS $HERE/obj/$f.o"; fi
