@@ -10,6 +10,9 @@
 #include "closure_body.h"
 #include "lbfgs_body.h"
 
+#ifndef SFX_TICK_OCC
+#define SFX_TICK_OCC 2
+#endif
 #ifndef LB_COOP_WAVES
 #define LB_COOP_WAVES 1
 #endif
@@ -41,8 +44,9 @@ void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const S
     }
 }
 
+// (small variant: 2 workgroups per CU -- batches of more than 256 frames then run two latency-bound frames per CU)
 template <class LDS>
-__global__ __launch_bounds__(CT)
+__global__ __launch_bounds__(CT, (LDS::kMaxItems <= SFX_SMALL_ITEMS) ? SFX_TICK_OCC : 1)
 void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const StageW* __restrict__ sws,
                   int first_stage, int last_stage, int has_eval) {
     __shared__ LDS S;
