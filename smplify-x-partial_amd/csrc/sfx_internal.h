@@ -212,7 +212,7 @@ struct ClosureArgs {
 // the 47-KB closure variant serves models whose keypoints need at most SFX_SMALL_ITEMS vertex rows
 // when the VPoser decoder is not in the loop
 static inline bool sfx_small_closure(const DevModel& M, const BatchDev& D) {
-    return M.n_items <= SFX_SMALL_ITEMS && !D.cfg.use_vposer && !D.cfg.pen;
+    return M.n_items <= SFX_SMALL_ITEMS && !D.cfg.use_vposer;
 }
 void launch_closure(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
                     const ClosureArgs& a, hipStream_t s);
