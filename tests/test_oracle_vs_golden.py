@@ -231,3 +231,25 @@ def test_frame_driver_matches_reference_fit(synth_model, i):
     rel = np.abs(got - want32) / np.abs(want32)
     assert rel[0] < 1e-5                                      # camera stage: well conditioned
     assert np.all(rel < np.maximum(5 * spread, 2e-3)), (rel, spread)
+
+
+def test_frame_driver_matches_reference_fit_on_the_benchmark_configuration(synth_model):
+    """The oracle frame driver is bench.py's cpu_baseline ("port"): on the benchmark's own configuration
+    (fit_smplx_smplifyx.yaml weights, 5 body stages, body-only, regression prior) it must reproduce the
+    reference's fit of benchmark frame 3 (tests/golden/e2e_bench.npz), fp32 against fp32, within the
+    reference's own fp32 / fp64 spread."""
+    path = os.path.join(GOLD, "e2e_bench.npz")
+    g = np.load(path)
+    cfg = H.load_cfg("fit_smplx_smplifyx.yaml", use_hands=False, use_face=False, use_vposer=False)
+    cfg["use_camera_prior"] = False
+    frames = dict(keypoints=g["keypoints"], reg_pose=g["reg_pose"], reg_global=g["reg_global"], H=600, W=800, focal=5000.0)
+    torch.set_num_threads(4)
+    i = 3
+    ref = H.oracle_frame_fit(synth_model, cfg, frames, i, dtype=torch.float32).run()
+    got = np.array([ref["cam_loss"]] + list(ref["stage_losses"]))
+    want32, want64 = g["f%d_f32_losses" % i], g["f%d_f64_losses" % i]
+    spread = np.abs(want32 - want64) / np.abs(want64)
+    rel = np.abs(got - want32) / np.abs(want32)
+    assert rel[0] < 1e-5
+    assert np.all(rel[1:4] < np.maximum(2 * spread[1:4], 3e-3)), (rel, spread)
+    assert np.all(rel[4:] < np.maximum(3 * spread[4:], 5e-2)), (rel, spread)
