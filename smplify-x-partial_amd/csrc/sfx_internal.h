@@ -9,11 +9,11 @@
 #define SFX_MAX_K 144       // mapped joints
 #define SFX_MAX_ITEMS 240   // vertex items (21 + 68*3 = 225)
 #define SFX_SMALL_ITEMS 32  // item capacity of the small closure variant (body-only: 11 items)
-#ifndef SFX_SMALL_OCC
 #ifndef SFX_RIF_BIG
 #define SFX_RIF_BIG 8        // 2-KiB blend-shape rows in flight per wavefront in the full-model closure (1 workgroup per CU:
 #endif                       // the loads of 4 wavefronts are all the memory parallelism a frame gets)
-#define SFX_SMALL_OCC 1      // workgroups per CU the register budget of the small fused kernels is sized for
+#ifndef SFX_SMALL_OCC
+#define SFX_SMALL_OCC 1      // workgroups per CU the register budget of the persistent small kernel is sized for
 #endif
 #define SFX_KD_PAD 512      // padded blend-shape depth (20 + 486 = 506)
 #define SFX_JPAD 56         // joints padded to an even MFMA depth
