@@ -126,6 +126,12 @@ typedef struct sfx_batch_cfg {
     int32_t max_collisions;         /* partners kept per triangle (cfg: 8 / 128)                   */
     float   df_cone_height;         /* sigma of the cone distance field (cfg: 0.5 / 1e-4)          */
     int32_t penalize_outside;
+    int32_t slots;                  /* dense mode: GEMM columns (frames resident in the fit loop at a time);
+                                       0 or >= B: every frame has a column.  With slots < B the frames beyond
+                                       the first `slots` wait in a queue and take over the columns of frames
+                                       that finish (continuous batching): the reference's loop over frames
+                                       (main.py:207) for jobs larger than one GEMM batch.  A frame's result does
+                                       not depend on when it is admitted or which column it gets              */
 } sfx_batch_cfg;
 
 int  sfx_batch_create(sfx_model* m, const sfx_batch_cfg* cfg,

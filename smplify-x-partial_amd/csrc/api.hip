@@ -135,6 +135,10 @@ struct sfx_batch {
     StageW* sw_dev = nullptr;     // [n_stages]
     VarList vl_host[2];
     int* stage_host = nullptr;    // pinned, [2][B]
+    int* map_host = nullptr;      // pinned, [2][3B]: slot[], running-frame list, newly admitted frames (two uploads may be in flight)
+    int* act_dev = nullptr;       // [B] running frames of the fused dense loop
+    int* act_new_dev = nullptr;   // [B] frames admitted at the latest poll (export-only launch)
+    int slots = 0;                // GEMM columns of the fused dense loop (0: one per frame)
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
     std::vector<int> slot_host;
     int K = 0;
@@ -534,7 +538,6 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.verts = b->mem.zeros<float>((size_t)B * m->M.V * 3);
     D.fwd = b->mem.zeros<float>((size_t)B * SFX_FWD_N);
     D.uvp = b->mem.zeros<float>((size_t)B * std::max(1, m->M.n_uniq) * 3);
-    D.uT = b->mem.zeros<float>((size_t)B * std::max(1, m->M.n_uniq) * 12);
     if (D.cfg.pen) {
         const int F = (int)(m->faces_host.size() / 3);
         const bool parts = !m->segm_host.empty();
@@ -558,6 +561,9 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.fullpose = b->mem.zeros<float>((size_t)B * SFX_POSE);
     D.stage = b->mem.zeros<int>(B);
     { std::vector<int> id(B); for (int i = 0; i < B; ++i) id[i] = i; D.slot = b->mem.up(id); D.nact = B; }
+    b->act_dev = b->mem.zeros<int>(B); b->act_new_dev = b->mem.zeros<int>(B);
+    b->slots = (c->slots > 0 && c->slots < B && c->lbs_mode == 1) ? ((c->slots + 31) / 32) * 32 : 0;
+    if (b->slots >= B) b->slots = 0;
     D.opt = b->mem.zeros<char>((size_t)B * sfx_optstate_size());
     D.vec = b->mem.zeros<float>((size_t)B * NVEC * SFX_NVAR_MAX);
     D.hist = b->mem.zeros<float>((size_t)B * 2 * SFX_HIST * SFX_NVAR_MAX);
@@ -572,6 +578,7 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.orient_pass = b->mem.zeros<int>(B);
     if (!D.hist || !D.verts) { sfx_set_error("out of device memory"); b->mem.free_all(); delete b; return -2; }
     if (hipHostMalloc((void**)&b->stage_host, (size_t)2 * B * sizeof(int)) != hipSuccess) b->stage_host = nullptr;      // two poll buffers
+    if (hipHostMalloc((void**)&b->map_host, (size_t)6 * B * sizeof(int)) != hipSuccess) b->map_host = nullptr;
     if (hipEventCreateWithFlags(&b->poll_ev[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&b->poll_ev[1], hipEventDisableTiming) != hipSuccess) { sfx_set_error("event creation failed"); b->mem.free_all(); delete b; return -2; }
     *out = b;
@@ -583,6 +590,7 @@ extern "C" void sfx_batch_destroy(sfx_batch* b) {
     if (b->pen) sfx_pen_destroy(b->pen);
     b->mem.free_all();
     if (b->stage_host) hipHostFree(b->stage_host);
+    if (b->map_host) hipHostFree(b->map_host);
     for (int i = 0; i < 2; ++i) if (b->poll_ev[i]) hipEventDestroy(b->poll_ev[i]);
     delete b;
 }
@@ -751,7 +759,7 @@ __global__ void k_pen_want(BatchDev D, const StageW* __restrict__ sws, int stage
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= D.cfg.B) return;
     const int st = stage_override != -2 ? stage_override : D.stage[b];
-    if (st >= 0 && st < D.cfg.n_stages) D.pen_want[D.slot[b]] = sws[st].coll > 0.f;
+    if (st >= 0 && st < D.cfg.n_stages && D.slot[b] >= 0) D.pen_want[D.slot[b]] = sws[st].coll > 0.f;
 }
 
 static int eval_penetration(sfx_batch* b, int stage_override, hipStream_t s) {
@@ -850,20 +858,49 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
     int* hp = b->stage_host ? b->stage_host : hs.data();
     long tick = 0;
     bool done = false;
-    if (fused && dense) { ProfScope p("tick", s); launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, s); }
-    if (fused && dense && b->stage_host) {
+    if (fused && dense && !(b->stage_host && b->map_host)) { ProfScope p("tick", s, B); launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, s); }
+    if (fused && dense && b->stage_host && b->map_host) {
         // dense fused loop, polled one batch of rounds AHEAD: while the host waits for the stage flags
         // copied after rounds 8i .. 8i+7, rounds 8i+8 .. 8i+15 are already queued, so the GPU never idles
-        // on the host round trip.  A decision (all done / compaction) therefore lags by 8 rounds: finished
-        // frames only ever stay finished, so that is safe; the 8 surplus rounds at the end find nothing to do.
+        // on the host round trip.  A decision (all done / admission / compaction) therefore lags by 8 rounds:
+        // finished frames only ever stay finished, so that is safe; the surplus rounds at the end find nothing to do.
+        //
+        // Column pool (continuous batching, cfg.slots): `pool` GEMM columns; frames beyond the first `pool` wait in
+        // a queue (slot = -1, not in the running list) and take over the column of a frame that has finished -- their
+        // first pose / chain export is one extra launch over the admitted frames only.  Once the queue is dry the
+        // columns are compacted whenever a 32-frame MFMA slice has emptied, as before.  Frames are independent and a
+        // column's arithmetic does not depend on its index: results equal those of a batch with one column per frame.
         static const bool dbg_nact = getenv("SFX_DEBUG_NACT") != nullptr;
         static long nact_hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // rounds by active GEMM columns: <=32, <=64, ..., <=256, more
+        const int pool = b->slots > 0 ? std::min(b->slots, B) : B;
+        std::vector<int>& col = b->slot_host;                          // frame -> column, -1 = queued or retired
+        col.assign(B, -1);
+        std::vector<int> run;                                          // running frames, ascending admission order
+        run.reserve(B);
+        for (int i = 0; i < pool; ++i) { col[i] = i; run.push_back(i); }
+        int next_q = pool, upl = 0;
+        auto upload = [&](const std::vector<int>* fresh) -> int {      // slot[], running list (+ admitted list) through pinned memory
+            int* h = b->map_host + (size_t)upl * 3 * B; upl ^= 1;
+            memcpy(h, col.data(), (size_t)B * sizeof(int));
+            memcpy(h + B, run.data(), run.size() * sizeof(int));
+            SFX_CHECK(hipMemcpyAsync(D.slot, h, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
+            if (!run.empty()) SFX_CHECK(hipMemcpyAsync(b->act_dev, h + B, run.size() * sizeof(int), hipMemcpyHostToDevice, s));
+            if (fresh && !fresh->empty()) {
+                memcpy(h + 2 * B, fresh->data(), fresh->size() * sizeof(int));
+                SFX_CHECK(hipMemcpyAsync(b->act_new_dev, h + 2 * B, fresh->size() * sizeof(int), hipMemcpyHostToDevice, s));
+            }
+            D.act = b->act_dev; D.nrun = (int)run.size();
+            return 0;
+        };
+        D.nact = pool;
+        if (int rc = upload(nullptr)) return rc;
+        { ProfScope p("tick", s, D.nrun); launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, s); }
         auto rounds = [&](int buf) -> int {
             if (dbg_nact) nact_hist[std::min(8, (D.nact - 1) / 32)] += 8;
             for (int q = 0; q < 8; ++q, ++tick) {
                 { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
                 if (int rc = eval_penetration(b, -2, s)) return rc;
-                ProfScope p("tick", s);
+                ProfScope p("tick", s, D.nrun);
                 launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 1, s);
             }
             SFX_CHECK(hipMemcpyAsync(b->stage_host + (size_t)buf * B, D.stage, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -876,25 +913,46 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
             if (int rc = rounds(cur ^ 1)) return rc;
             SFX_CHECK(hipEventSynchronize(b->poll_ev[cur]));
             const int* hq = b->stage_host + (size_t)cur * B;
-            int n = 0;
-            for (int i = 0; i < B; ++i) if (hq[i] <= last_stage) ++n;
-            done = n == 0;
-            if (!done && (b->D.nact + 31) / 32 != (n + 31) / 32) {      // a 32-frame MFMA tile became free
-                // compaction: finished frames give up their GEMM columns.  The pending evaluation of every
-                // active frame lives in column slot[b] of featT/AT, so re-export after remapping (queued
-                // behind the rounds already in flight, which still use the old mapping consistently).
-                std::vector<int>& sl = b->slot_host;
-                sl.assign(B, 0);
-                int q = 0;
-                for (int i = 0; i < B; ++i) sl[i] = (hq[i] <= last_stage) ? q++ : 0;
-                SFX_CHECK(hipMemcpyAsync(D.slot, sl.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
-                b->D.nact = n;
-                ProfScope p("tick", s);
-                launch_tick_dense(M, b->D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, s);   // re-export only
+            // frames of the running list that have finished (frames admitted after this snapshot show their start stage)
+            std::vector<int> fresh;
+            size_t w = 0;
+            bool changed = false;
+            for (size_t r = 0; r < run.size(); ++r) {
+                const int f = run[r];
+                if (hq[f] <= last_stage) { run[w++] = f; continue; }
+                changed = true;
+                const int c = col[f];
+                col[f] = -1;
+                if (next_q < B) { const int nf = next_q++; col[nf] = c; fresh.push_back(nf); }
+            }
+            run.resize(w);
+            for (int nf : fresh) run.push_back(nf);
+            done = run.empty();
+            if (!done && changed) {
+                if (!fresh.empty()) {
+                    // admission: the new frames inherit the freed columns; only they need an export pass
+                    if (int rc = upload(&fresh)) return rc;
+                    BatchDev Dn = D; Dn.act = b->act_new_dev; Dn.nrun = (int)fresh.size();
+                    ProfScope p("tick_admit", s, Dn.nrun);
+                    launch_tick_dense(M, Dn, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, s);
+                } else if ((D.nact + 31) / 32 != ((int)run.size() + 31) / 32) {
+                    // queue dry and a 32-frame MFMA slice has emptied: compact.  The pending evaluation of every running
+                    // frame lives in column slot[f] of featT / AT, so re-export after remapping (queued behind the rounds
+                    // already in flight, which still use the old mapping consistently).
+                    int q = 0;
+                    for (int f : run) col[f] = q++;
+                    D.nact = q;
+                    if (int rc = upload(nullptr)) return rc;
+                    ProfScope p("tick", s, D.nrun);
+                    launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, s);   // re-export only
+                } else {
+                    if (int rc = upload(nullptr)) return rc;      // shorter running list: fewer workgroups per tick launch
+                }
             }
             cur ^= 1;
         }
         SFX_CHECK(hipStreamSynchronize(s));
+        D.act = nullptr; D.nrun = 0;
         if (dbg_nact) {
             fprintf(stderr, "[sfx] rounds by active columns (<=32, <=64, ..., <=256, more), cumulative:");
             for (int i = 0; i < 9; ++i) fprintf(stderr, " %ld", nact_hist[i]);
@@ -1137,6 +1195,14 @@ extern "C" int sfx_batch_forward(sfx_batch* b, float* verts_dev, float* joints_d
     if (!b) { sfx_set_error("null batch"); return -1; }
     hipStream_t s = (hipStream_t)stream;
     const DevModel& M = b->m->M; const BatchDev& D = b->D;
+    if (D.cfg.lbs_mode == 0 && !verts_dev) {       // needed-rows batch, joints only: the forward the rows closure runs
+        ClosureArgs a{}; a.stage_override = 0; a.forward_only = 1; a.from_X = 1;
+        launch_closure(M, D, b->vl_dev, b->sw_dev, a, s);
+        if (joints_dev) SFX_CHECK(hipMemcpyAsync(joints_dev, D.joints, (size_t)D.cfg.B * M.K * 3 * 4, hipMemcpyDeviceToDevice, s));
+        SFX_CHECK(hipStreamSynchronize(s));
+        SFX_CHECK(hipGetLastError());
+        return 0;
+    }
     ClosureArgs e{}; e.stage_override = 0; e.export_dense = 1; e.forward_only = 2; e.from_X = 1;
     launch_closure(M, D, b->vl_dev, b->sw_dev, e, s);
     { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }

@@ -62,9 +62,17 @@ struct __align__(16) FrameLDSx {
     float Jr[SFX_J * 3];
     float G[SFX_J * 12];
     float A[SFX_J * 12];
-    float vp[MAXI * 3];
+    // the part of the forward whose ROUNDING NOISE decides when the line search stalls is carried in fp64 (see
+    // "forward precision" below): skinning transforms and posed kinematic joints; saved with the prefix above
+    double Ad[SFX_J * 12];
+    double Gt[SFX_J * 3 + 1];      // (+1: keeps the saved prefix a multiple of 16 bytes)
+    float vp[MAXI * 3];            // v_posed of the items (template + blend offsets), for the reverse sweep
+    float vpo[MAXI * 3];           // the blend offsets alone (small numbers: fp32 sums of them carry ~1e-10 m)
+    float vt[MAXI * 3];            // v_template rows of the items
     float T[kScratch];             // item transforms [MAXI][12]; reused as scratch (>= 2048 floats) by the reverse sweep
-    float vert[MAXI * 3];
+    double cd[2 * SFX_J * 12];     // kinematic chain in fp64: the two buffers of the pointer-jumping rounds
+    double Jd[SFX_J * 3];          // rest joints, fp64
+    double jd[SFX_MAX_K * 3];      // mapped joints, fp64 (what the projection reads)
     float dvert[MAXI * 3];
     float dvp[MAXI * 3];
     int   ivid[MAXI];
@@ -123,6 +131,25 @@ __device__ __forceinline__ void rodrigues_fwd(const float* th, float* R) {
         for (int j = 0; j < 3; ++j) {
             float kk = K[i * 3 + 0] * K[0 * 3 + j] + K[i * 3 + 1] * K[1 * 3 + j] + K[i * 3 + 2] * K[2 * 3 + j];
             R[i * 3 + j] = ((i == j) ? 1.f : 0.f) + s * K[i * 3 + j] + omc * kk;
+        }
+}
+
+// the same in fp64 (forward precision, see closure_body): R row-major
+__device__ __forceinline__ void rodrigues_fwd_d(const float* th, double* R) {
+    const double t0 = th[0], t1 = th[1], t2 = th[2];
+    const double ex = t0 + 1e-8, ey = t1 + 1e-8, ez = t2 + 1e-8;
+    const double a = sqrt(ex * ex + ey * ey + ez * ez);
+    const double dx = t0 / a, dy = t1 / a, dz = t2 / a;
+    double s, c;
+    sincos(a, &s, &c);
+    const double K[9] = {0.0, -dz, dy, dz, 0.0, -dx, -dy, dx, 0.0};
+    const double omc = 1.0 - c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double kk = K[i * 3 + 0] * K[0 * 3 + j] + K[i * 3 + 1] * K[1 * 3 + j] + K[i * 3 + 2] * K[2 * 3 + j];
+            R[i * 3 + j] = ((i == j) ? 1.0 : 0.0) + s * K[i * 3 + j] + omc * kk;
         }
 }
 
@@ -198,6 +225,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     constexpr int RIF = (LDS::kMaxItems <= SFX_SMALL_ITEMS) ? 4 : SFX_RIF_BIG;
     constexpr int FWD_PREFIX = (int)(offsetof(LDS, vp) / sizeof(float));
     static_assert(FWD_PREFIX % 4 == 0 && FWD_PREFIX + 96 + 2 * VP_H + 128 + 64 <= SFX_FWD_N, "forward-state blob layout");
+    static_assert(offsetof(LDS, Ad) % 8 == 0 && offsetof(LDS, cd) % 8 == 0, "fp64 members");
     const bool reuse = args.reuse_fwd != 0;
     float* fwd = D.fwd ? D.fwd + (size_t)b * SFX_FWD_N : nullptr;
     const float* xsrc = (args.from_X ? D.X : D.Xt) + (size_t)b * SFX_NPAR_MAX;
@@ -267,22 +295,31 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
 
     MARK(2);
     // ------------------------------------------------------------------ Rodrigues, rest joints
+    // Forward precision.  Near the optimum the gradient is the small difference of keypoint forces of
+    // ~5e3 per metre each, and d(force)/d(joint position) ~ 1e6 per metre: a joint position off by 1e-7 m
+    // (fp32 rounding of the chain) moves the gradient by 0.1 while |g| ~ 4 -- the line search stalls on that
+    // noise and run_fitting's ftol test (fitting.py:185-189) ends the stage (measured: tests/probe_drift.py).
+    // Rotations, rest joints, the kinematic chain, the skinning of the keypoint vertices and the projection
+    // are therefore evaluated in fp64 (a few thousand flops per evaluation); parameters, blend-shape sums,
+    // losses and the whole reverse sweep stay fp32, as in the reference.
     if (t < SFX_J) {
-        float R[9];
-        rodrigues_fwd(&S.full_pose[3 * t], R);
+        double R[9];
+        rodrigues_fwd_d(&S.full_pose[3 * t], R);
+        double* src0 = (M.n_rounds & 1) ? (S.cd + SFX_J * 12) : S.cd;
 #pragma unroll
-        for (int e = 0; e < 9; ++e) S.R[t * 9 + e] = R[e];
+        for (int e = 0; e < 9; ++e) { S.R[t * 9 + e] = (float)R[e]; src0[t * 12 + (e / 3) * 4 + e % 3] = R[e]; }
         if (t > 0) {
 #pragma unroll
             for (int e = 0; e < 9; ++e)
-                S.feat[M.S + 9 * (t - 1) + e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+                S.feat[M.S + 9 * (t - 1) + e] = (float)(R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0 : 0.0));
         }
     } else if (t >= 64 && t < 64 + SFX_J * 3) {
         const int i = t - 64;
-        float v = M.J_template[i];
+        double v = M.J_template[i];
         const float* jd = M.J_dirs + (size_t)i * M.S;
-        for (int l = 0; l < M.S; ++l) v += jd[l] * S.feat[l];
-        S.Jr[i] = v;
+        for (int l = 0; l < M.S; ++l) v += (double)jd[l] * (double)S.feat[l];
+        S.Jd[i] = v;
+        S.Jr[i] = (float)v;
     }
     __syncthreads();
 
@@ -291,14 +328,14 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     // pointer jumping instead of a level-by-level walk: start from the local transforms
     // T_j = [R_j | J_j - J_parent]; in round k every joint composes with the transform of its
     // 2^k-th ancestor, T_j <- T_anc o T_j, so after ceil(log2(depth)) rounds T_j = G_j.  Two
-    // buffers (S.G, S.dG) alternate; the result lands in S.G.  4 barriers instead of 11.
+    // buffers alternate; the result lands in S.cd[0 ..).  4 barriers instead of 11.
     {
-        float* src = (M.n_rounds & 1) ? S.dG : S.G;
-        float* dst = (M.n_rounds & 1) ? S.G : S.dG;
-        FOR_CT(w, SFX_J * 12) {
-            const int j = w / 12, e = w % 12, r = e >> 2, c = e & 3;
+        double* src = (M.n_rounds & 1) ? (S.cd + SFX_J * 12) : S.cd;
+        double* dst = (M.n_rounds & 1) ? S.cd : (S.cd + SFX_J * 12);
+        if (t < SFX_J * 3) {
+            const int j = t / 3, r = t % 3;
             const int p = S.meta[MO_PAR + j];
-            src[w] = (c < 3) ? S.R[j * 9 + r * 3 + c] : (S.Jr[j * 3 + r] - (p < 0 ? 0.f : S.Jr[p * 3 + r]));
+            src[j * 12 + r * 4 + 3] = S.Jd[t] - (p < 0 ? 0.0 : S.Jd[p * 3 + r]);
         }
         __syncthreads();
         MARK(27);
@@ -306,28 +343,33 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
             FOR_CT(w, SFX_J * 12) {
                 const int j = w / 12, e = w % 12, r = e >> 2, c = e & 3;
                 const int a = S.meta[MO_ANC + k * 56 + j];
-                float v = src[w];
+                double v = src[w];
                 if (a >= 0) {
-                    const float* Ta = &src[a * 12 + r * 4];
-                    const float* Tb = &src[j * 12 + c];
+                    const double* Ta = &src[a * 12 + r * 4];
+                    const double* Tb = &src[j * 12 + c];
                     v = Ta[0] * Tb[0] + Ta[1] * Tb[4] + Ta[2] * Tb[8];
                     if (c == 3) v += Ta[3];
                 }
                 dst[w] = v;
             }
             __syncthreads();
-            float* tmp = src; src = dst; dst = tmp;
+            double* tmp = src; src = dst; dst = tmp;
         }
     }
     MARK(28);
     if (t < SFX_J) {
-        const float* Gj = &S.G[t * 12];
-        float* Aj = &S.A[t * 12];
-        const float* Jj = &S.Jr[t * 3];
+        const double* Gj = &S.cd[t * 12];
+        const double* Jj = &S.Jd[t * 3];
+        double* Adj = &S.Ad[t * 12];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            Aj[r * 4 + 0] = Gj[r * 4 + 0]; Aj[r * 4 + 1] = Gj[r * 4 + 1]; Aj[r * 4 + 2] = Gj[r * 4 + 2];
-            Aj[r * 4 + 3] = Gj[r * 4 + 3] - (Gj[r * 4 + 0] * Jj[0] + Gj[r * 4 + 1] * Jj[1] + Gj[r * 4 + 2] * Jj[2]);
+            const double at = Gj[r * 4 + 3] - (Gj[r * 4 + 0] * Jj[0] + Gj[r * 4 + 1] * Jj[1] + Gj[r * 4 + 2] * Jj[2]);
+            Adj[r * 4 + 0] = Gj[r * 4 + 0]; Adj[r * 4 + 1] = Gj[r * 4 + 1]; Adj[r * 4 + 2] = Gj[r * 4 + 2]; Adj[r * 4 + 3] = at;
+            S.Gt[t * 3 + r] = Gj[r * 4 + 3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) S.G[t * 12 + r * 4 + c] = (float)Gj[r * 4 + c];
+            S.A[t * 12 + r * 4 + 0] = (float)Gj[r * 4 + 0]; S.A[t * 12 + r * 4 + 1] = (float)Gj[r * 4 + 1];
+            S.A[t * 12 + r * 4 + 2] = (float)Gj[r * 4 + 2]; S.A[t * 12 + r * 4 + 3] = (float)at;
         }
     }
     // dynamic-contour LUT row (smplx find_dynamic_lmk_idx_and_bcoords; no gradient)
@@ -389,13 +431,16 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     const int NI = M.n_items;
     for (int i = t; i < NI; i += CT) {
         const int dd = M.item_dyn[i];
-        if (dd < 0) { S.ivid[i] = M.item_vid[i]; S.iw[i] = M.item_w[i]; }
+        int vid;
+        if (dd < 0) { vid = M.item_vid[i]; S.iw[i] = M.item_w[i]; }
         else {
             const int l = dd / 3, c = dd % 3;
             const int face = M.dyn_faces[S.lut_row * M.n_dyn + l];
-            S.ivid[i] = M.faces[face * 3 + c];
+            vid = M.faces[face * 3 + c];
             S.iw[i] = M.dyn_bary[(S.lut_row * M.n_dyn + l) * 3 + c];
         }
+        S.ivid[i] = vid;
+        S.vt[i * 3] = M.v_template[vid * 3]; S.vt[i * 3 + 1] = M.v_template[vid * 3 + 1]; S.vt[i * 3 + 2] = M.v_template[vid * 3 + 2];
     }
     __syncthreads();
     // v_posed rows and skinning transforms of `ni` vertices listed in S.ivid (the model's items, or a
@@ -430,13 +475,15 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
                 float acc = fa.x * da[u].x + fa.y * da[u].y + fa.z * da[u].z + fa.w * da[u].w +
                             fb.x * db[u].x + fb.y * db[u].y + fb.z * db[u].z + fb.w * db[u].w;
                 acc = wave_sum(acc);
-                if (lane == 0 && w0 + u < nrow) S.vp[w] = M.v_template[S.ivid[w / 3] * 3 + w % 3] + acc;
+                if (lane == 0 && w0 + u < nrow) { S.vpo[w] = acc; S.vp[w] = S.vt[w] + acc; }
             }
         }
     }
-    // skinning transforms of the items
+    };
+    // skinning transforms of the items (fp32 copy for the reverse sweep)
     // (sparse rows of lbs_weights: <= SFX_NW nonzeros per vertex, ascending joint order, so the
     //  sum visits the same nonzero terms in the same order as the dense product)
+    auto items_transforms = [&](const int ib, const int ni) {
     for (int w = t + ib * SFX_NW; w < (ib + ni) * SFX_NW; w += CT) {
         const int i = w / SFX_NW, q2 = w % SFX_NW;
         S.wj[w] = M.Wsp_j[(size_t)S.ivid[i] * SFX_NW + q2];
@@ -461,40 +508,54 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     __syncthreads();
     };
     if (args.use_dense_verts && !args.from_scratch_items) {
-        // dense path: the GEMM that produced the vertices also left v_posed and the skinning transform
+        // dense path: the GEMM that produced the vertices also left the blend offsets (v_posed - v_template)
         // of every static item vertex (lbs_dense.hip epilogue); only the dynamic contour items, whose
         // vertices depend on this frame's head pose, are evaluated here
         const size_t ub = (size_t)D.slot[b] * M.n_uniq;
-        for (int w = t; w < M.n_static_items * 3; w += CT) S.vp[w] = D.uvp[(ub + M.item_uslot[w / 3]) * 3 + w % 3];
-        for (int w = t; w < M.n_static_items * 12; w += CT) S.T[w] = D.uT[(ub + M.item_uslot[w / 12]) * 12 + w % 12];
+        for (int w = t; w < M.n_static_items * 3; w += CT) {
+            const float o = D.uvp[(ub + M.item_uslot[w / 3]) * 3 + w % 3];
+            S.vpo[w] = o; S.vp[w] = S.vt[w] + o;
+        }
         if (NI > M.n_static_items) items_forward(M.n_static_items, NI - M.n_static_items);
-        else __syncthreads();
     } else items_forward(0, NI);
+    items_transforms(0, NI);
     MARK(6);
-    for (int w = t; w < NI * 3; w += CT) {
-        const int i = w / 3, r = w % 3;
-        const float* Ti = &S.T[i * 12 + r * 4];
-        const float* vp = &S.vp[i * 3];
-        float v = Ti[0] * vp[0] + Ti[1] * vp[1] + Ti[2] * vp[2] + Ti[3];
-        if (args.use_dense_verts) v = D.verts[((size_t)D.slot[b] * M.V + S.ivid[i]) * 3 + r];
-        S.vert[w] = v;
-    }
-    __syncthreads();
 
     MARK(7);
     // ------------------------------------------------------------------ mapped joints
+    // keypoint vertices: sum_j w_j (A_j [v_posed; 1]) in fp64 on the fp64 transforms (the dense kernel's fp32
+    // vertex of the same index serves the interpenetration term and the output mesh, not the keypoints)
     const int K = M.K;
+    auto item_vertex = [&](const int i, const int r) -> double {
+        const double vx = (double)S.vt[i * 3] + (double)S.vpo[i * 3], vy = (double)S.vt[i * 3 + 1] + (double)S.vpo[i * 3 + 1],
+                     vz = (double)S.vt[i * 3 + 2] + (double)S.vpo[i * 3 + 2];
+        double acc = 0.0;
+        if (S.wj[i * SFX_NW] >= 0) {
+#pragma unroll
+            for (int q2 = 0; q2 < SFX_NW; ++q2) {
+                const float wq = S.ww[i * SFX_NW + q2];
+                if (wq != 0.f) { const double* Aq = &S.Ad[S.wj[i * SFX_NW + q2] * 12 + r * 4];
+                                 acc += (double)wq * (Aq[0] * vx + Aq[1] * vy + Aq[2] * vz + Aq[3]); }
+            }
+        } else {
+            const float* Wv = M.W + (size_t)S.ivid[i] * SFX_J;
+            for (int j = 0; j < SFX_J; ++j) { const float wq = Wv[j];
+                if (wq != 0.f) { const double* Aq = &S.Ad[j * 12 + r * 4]; acc += (double)wq * (Aq[0] * vx + Aq[1] * vy + Aq[2] * vz + Aq[3]); } }
+        }
+        return acc;
+    };
     for (int w = t; w < K * 3; w += CT) {
         const int k = w / 3, r = w % 3;
-        float v;
-        if (S.meta[MO_JT + k] == 0) v = S.G[S.meta[MO_JS + k] * 12 + r * 4 + 3];
+        double v;
+        if (S.meta[MO_JT + k] == 0) v = S.Gt[S.meta[MO_JS + k] * 3 + r];
         else {
-            v = 0.f;
+            v = 0.0;
             const int i0 = S.meta[MO_JI0 + k], n = S.meta[MO_JN + k];
-            if (n == 1 && S.iw[i0] == 1.f) v = S.vert[i0 * 3 + r];
-            else for (int i = 0; i < n; ++i) v += S.vert[(i0 + i) * 3 + r] * S.iw[i0 + i];
+            if (n == 1 && S.iw[i0] == 1.f) v = item_vertex(i0, r);
+            else for (int i = 0; i < n; ++i) v += item_vertex(i0 + i, r) * (double)S.iw[i0 + i];
         }
-        S.joints[w] = v;
+        S.jd[w] = v;
+        S.joints[w] = (float)v;
     }
     __syncthreads();
     if (args.forward_only) {
@@ -528,13 +589,15 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
 #pragma unroll
     for (int i = 0; i < NQ; ++i) q[i] = 0.f;
     if (t < K) {
-        const float* p = &S.joints[t * 3];
-        const float pcx = Rc[0] * p[0] + Rc[1] * p[1] + Rc[2] * p[2] + ct[0];
-        const float pcy = Rc[3] * p[0] + Rc[4] * p[1] + Rc[5] * p[2] + ct[1];
-        const float pcz = Rc[6] * p[0] + Rc[7] * p[1] + Rc[8] * p[2] + ct[2];
-        const float ix = pcx / pcz, iy = pcy / pcz;
-        const float u = fx * ix + cx, v = fy * iy + cy;
-        const float rx = fd[FD_GT + 2 * t] - u, ry = fd[FD_GT + 2 * t + 1] - v;
+        // camera.py:93-117, in fp64 up to the residual (pixel coordinates of ~500 carry 3e-5 px in fp32: the
+        // same order as the 1-px residuals' useful digits, see "forward precision" above)
+        const double* p = &S.jd[t * 3];
+        const double pxd = (double)Rc[0] * p[0] + (double)Rc[1] * p[1] + (double)Rc[2] * p[2] + (double)ct[0];
+        const double pyd = (double)Rc[3] * p[0] + (double)Rc[4] * p[1] + (double)Rc[5] * p[2] + (double)ct[1];
+        const double pzd = (double)Rc[6] * p[0] + (double)Rc[7] * p[1] + (double)Rc[8] * p[2] + (double)ct[2];
+        const float pcx = (float)pxd, pcy = (float)pyd, pcz = (float)pzd;
+        const float rx = (float)((double)fd[FD_GT + 2 * t] - ((double)fx * (pxd / pzd) + (double)cx));
+        const float ry = (float)((double)fd[FD_GT + 2 * t + 1] - ((double)fy * (pyd / pzd) + (double)cy));
         float du, dv;       // dL/du, dL/dv
         if (cam_stage) {
             if (fd[FD_CMASK + t] != 0.f) {

@@ -55,11 +55,11 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
     __shared__ float s_al[SFX_HIST + 2 * LB_BS];
     __shared__ OptScal st;
     __shared__ LbCoop cp;
-    const int b = blockIdx.x;
+    const int b = D.act ? D.act[blockIdx.x] : blockIdx.x;      // (frames that finished or still wait in the queue are not launched)
     if (D.stage[b] > last_stage) return;
     const long long wc0 = D.dbg ? wall_clock64() : 0;      // debug: per-workgroup duration statistics (100 MHz clock)
     // debug clocks: stamps freeze after launch number dbg[61] of this kernel, so a mid-fit launch is what is read back
-    if (D.dbg && b == 0 && threadIdx.x == 0) { D.dbg[62] += 1; if (D.dbg[62] <= D.dbg[61]) D.dbg[24] = clock64(); }
+    if (D.dbg && blockIdx.x == 0 && threadIdx.x == 0) { D.dbg[62] += 1; if (D.dbg[62] <= D.dbg[61]) D.dbg[24] = clock64(); }
     if (has_eval) {
         ClosureArgs a{};
         a.stage_override = -2; a.use_dense_verts = 1; a.reuse_fwd = 1;
@@ -95,8 +95,10 @@ void launch_fit_rows(const DevModel& M, const BatchDev& D, const VarList* vl_dev
 }
 void launch_tick_dense(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
                        int first_stage, int last_stage, int has_eval, hipStream_t s) {
+    const int grid = D.act ? D.nrun : D.cfg.B;
+    if (grid <= 0) return;
     if (sfx_small_closure(M, D))
-        hipLaunchKernelGGL(k_tick_dense<FrameLDSSmall>, dim3(D.cfg.B), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
+        hipLaunchKernelGGL(k_tick_dense<FrameLDSSmall>, dim3(grid), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
     else
-        hipLaunchKernelGGL(k_tick_dense<FrameLDS>, dim3(D.cfg.B), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
+        hipLaunchKernelGGL(k_tick_dense<FrameLDS>, dim3(grid), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
 }

@@ -104,20 +104,23 @@ void k_lbs_dense(DevModel M, BatchDev D) {
         *reinterpret_cast<float4*>(&S.b[buf][0][0] + lB4) = s4;                                        \
         if (ok5) *reinterpret_cast<float4*>(&S.b[buf][0][0] + lB5) = s5; } while (0)
 
-    f32x4 ax0, ay0, az0, ax1, ay1, az1;       // frames 0-15 / 16-31 of this wavefront's slice
-    {
-        const float tx = M.v_template[v * 3], ty = M.v_template[v * 3 + 1], tz = M.v_template[v * 3 + 2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { ax0[r] = tx; ay0[r] = ty; az0[r] = tz; ax1[r] = tx; ay1[r] = ty; az1[r] = tz; }
-    }
-    STAGE_LOAD(0);
+    // the accumulators collect the 506 blend-shape terms alone (millimetres: their fp32 chain carries ~1e-10 m);
+    // v_template is added once at the end -- started from the template (~0.5 m) the chain rounds 506 times at
+    // 3e-8 m and v_posed ends 2e-7 m off (measured, tests/probe_drift.py)
+    f32x4 ax0 = {0, 0, 0, 0}, ay0 = ax0, az0 = ax0, ax1 = ax0, ay1 = ax0, az1 = ax0;       // frames 0-15 / 16-31 of this wavefront's slice
+    const float tx = M.v_template[v * 3], ty = M.v_template[v * 3 + 1], tz = M.v_template[v * 3 + 2];
+    // K order: chunks 1, 2, ..., 15, 0 -- the 486 pose-corrective terms (1e-4 m each) are summed first and the 20
+    // shape / expression terms (centimetres, rows 0-19 of chunk 0) last: added to a centimetre-sized partial sum,
+    // every one of the small terms would round at 2e-9 m (2.5e-8 m over the chain, measured on the keypoints)
+    constexpr int NCHUNK = SFX_KD_PAD / KC;
+#define KCHUNK(c) (((c) + 1) % NCHUNK)
+    STAGE_LOAD(KCHUNK(0));
     STAGE_WRITE(0);
     __syncthreads();
 
-    constexpr int NCHUNK = SFX_KD_PAD / KC;
     for (int c = 0; c < NCHUNK; ++c) {
         const int cur = c & 1;
-        if (c + 1 < NCHUNK) STAGE_LOAD(c + 1);
+        if (c + 1 < NCHUNK) STAGE_LOAD(KCHUNK(c + 1));
         if (active) {
             const float* sa = &S.a[cur][kq][wv * 32 + jl];
             const float* sb = &S.b[cur][kq][jl * 3];
@@ -138,6 +141,17 @@ void k_lbs_dense(DevModel M, BatchDev D) {
     return;
 #endif
     const bool vok = vtx < V;
+    const int us = vok ? M.vslot[vtx] : -1;      // export index of an item vertex
+    if (us >= 0) {      // keypoint vertex: its blend offsets go to the loss / adjoint pass (a fraction of a percent of the lanes)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f0 = b0 + kq * 4 + r, f1 = f0 + 16;
+            if (f0 < B) { float* o = D.uvp + ((size_t)f0 * M.n_uniq + us) * 3; o[0] = ax0[r]; o[1] = ay0[r]; o[2] = az0[r]; }
+            if (f1 < B) { float* o = D.uvp + ((size_t)f1 * M.n_uniq + us) * 3; o[0] = ax1[r]; o[1] = ay1[r]; o[2] = az1[r]; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ax0[r] += tx; ay0[r] += ty; az0[r] += tz; ax1[r] += tx; ay1[r] += ty; az1[r] += tz; }
     // skinning GEMM T = W . A restricted to the joints that carry weight in this 16-vertex tile
     // (exact: the skipped products are structural zeros of lbs_weights; ascending joint order kept).
     // The A-operand gathers of step (rr, js+1) are in flight while step (rr, js) multiplies.
@@ -153,7 +167,6 @@ void k_lbs_dense(DevModel M, BatchDev D) {
         q0 = at_[16]; q1 = at_[estep + 16]; q2 = at_[2 * estep + 16]; q3 = at_[3 * estep + 16];           \
         ww = wl[(js) * 64]; } while (0)
     float o0[4][3], o1[4][3];
-    const int us = vok ? M.vslot[vtx] : -1;      // export index of an item vertex
     AT_LOAD(P0, P1, P2, P3, Q0, Q1, Q2, Q3, wc, 0, 0);
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr) {
@@ -169,22 +182,6 @@ void k_lbs_dense(DevModel M, BatchDev D) {
         for (int r = 0; r < 4; ++r) {
             o0[r][rr] = t00[r] * ax0[r] + t01[r] * ay0[r] + t02[r] * az0[r] + t03[r];
             o1[r][rr] = t10[r] * ax1[r] + t11[r] * ay1[r] + t12[r] * az1[r] + t13[r];
-        }
-        if (us >= 0) {      // item vertex: its transform row goes to the adjoint pass (a fraction of a percent of the lanes)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f0 = b0 + kq * 4 + r, f1 = f0 + 16;
-                if (f0 < B) { float* o = D.uT + ((size_t)f0 * M.n_uniq + us) * 12 + rr * 4; o[0] = t00[r]; o[1] = t01[r]; o[2] = t02[r]; o[3] = t03[r]; }
-                if (f1 < B) { float* o = D.uT + ((size_t)f1 * M.n_uniq + us) * 12 + rr * 4; o[0] = t10[r]; o[1] = t11[r]; o[2] = t12[r]; o[3] = t13[r]; }
-            }
-        }
-    }
-    if (us >= 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f0 = b0 + kq * 4 + r, f1 = f0 + 16;
-            if (f0 < B) { float* o = D.uvp + ((size_t)f0 * M.n_uniq + us) * 3; o[0] = ax0[r]; o[1] = ay0[r]; o[2] = az0[r]; }
-            if (f1 < B) { float* o = D.uvp + ((size_t)f1 * M.n_uniq + us) * 3; o[0] = ax1[r]; o[1] = ay1[r]; o[2] = az1[r]; }
         }
     }
 #undef AT_LOAD

@@ -20,7 +20,7 @@
 #define SFX_MAX_LEVELS 16
 #define SFX_HIST 100        // L-BFGS history (optim_factory 'lbfgsls' default)
 #define SFX_NVAR_MAX 192    // optimiser vector length (182 / 88 / 6), padded to 3*64
-#define SFX_FWD_N 4352      // floats per frame of saved forward state (FrameLDS prefix + 96 + VPoser 1280)
+#define SFX_FWD_N 6016      // floats per frame of saved forward state (FrameLDS prefix incl. the fp64 transforms + 96 + VPoser 1280)
 #define SFX_NPAR_MAX 192    // canonical per-frame parameter block
 #define SFX_MAX_STAGES 8
 #define SFX_MAX_GROUPS 12
@@ -156,8 +156,10 @@ struct BatchDev {
     float* joints;     // [B][K][3] (export)
     float* fullpose;   // [B][165]  (export)
     int Bpad;
-    int*   slot;       // [B] frame -> operand column / vertex-buffer row (identity or compacted)
+    int*   slot;       // [B] frame -> operand column / vertex-buffer row (identity or compacted; -1: waiting in the queue)
     int nact;          // columns in use (frames the dense GEMM processes)
+    const int* act;    // [nrun] frames the fused dense tick kernel works on (NULL: all B frames, block = frame)
+    int nrun;          // length of act[]
     // optimiser state
     int*   stage;      // [B] current stage (-1 camera, 0.. body, n_stages = done)
     void*  opt;        // [B] OptState
@@ -172,8 +174,7 @@ struct BatchDev {
     float* stage_loss2;// [B][1+MAX_STAGES] second-orientation stage losses
     int*   try_both;   // [B]
     int*   orient_pass;// [B] 0 first fit, 1 second fit running, 2 done
-    float* uvp;             // [B][n_uniq][3]  (slot-indexed) v_posed of the item vertices, written by the dense GEMM
-    float* uT;              // [B][n_uniq][12] (slot-indexed) their skinning transforms
+    float* uvp;             // [B][n_uniq][3]  (slot-indexed) blend offsets (v_posed - v_template) of the item vertices, written by the dense GEMM
     float* pen_loss;        // [B] (slot-indexed) unweighted penetration loss of the pending evaluation
     float* pen_dverts;      // [B][V][3] (slot-indexed) its gradient with respect to the vertices
     int gmm_M;              // Gaussian-mixture body pose prior: components (0 = off) ...

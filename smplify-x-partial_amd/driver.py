@@ -64,7 +64,7 @@ def prepare_frames(cfg, keypoints, joint_weights, reg_pose=None, reg_global=None
 
 
 def _make_batch(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose, reg_global, cam_prior_t,
-                cam_prior_center, lbs_mode, reuse_entry_eval, body_pose_prior=None):
+                cam_prior_center, lbs_mode, reuse_entry_eval, body_pose_prior=None, slots=0):
     """FrameBatch with frames, parameters and the initial camera set the way
     fit_single_frame.py:209-294,358-411 prepares one frame."""
     if cfg.get("optim_type", "lbfgsls") != "lbfgsls":
@@ -92,7 +92,7 @@ def _make_batch(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose, reg_gl
     Ww = np.broadcast_to(np.asarray(W, np.float32), (B,))
     f = np.broadcast_to(np.asarray(focal, np.float32), (B,))
     fb = engine.FrameBatch(dm, B, cfg, lbs_mode=lbs_mode, reuse_entry_eval=reuse_entry_eval,
-                           has_regression_pose=has_reg, side_view=True)
+                           has_regression_pose=has_reg, side_view=True, slots=slots)
     nemb = fb.nemb
     if gmm is not None:
         fb.set_gmm(gmm)
@@ -129,7 +129,7 @@ def _collect(fb, prep, want_vertices):
 
 def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, reg_global=None,
                cam_prior_t=None, cam_prior_center=None, lbs_mode="dense", reuse_entry_eval=True,
-               want_vertices=False, groups=1, body_pose_prior=None):
+               want_vertices=False, groups=1, body_pose_prior=None, slots=0):
     """Fit B frames.  Arrays are [B, ...]; H, W, focal scalars or [B].  Returns a dict of
     [B, ...] arrays: the reference's result-pkl fields + per-stage losses / evaluation counts.
 
@@ -140,7 +140,11 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
 
     groups > 1 splits the frames into that many sub-batches that are pipelined through the GPU
     (sfx_fit_multi): the MFMA GEMMs of the sub-batches run back to back while each sub-batch's
-    latency-bound optimiser tick hides under the others' GEMMs.  Results are unchanged."""
+    latency-bound optimiser tick hides under the others' GEMMs.  Results are unchanged.
+
+    slots (dense mode, groups == 1): size of the GEMM column pool when there are more frames than that --
+    the reference's loop over frames (main.py:207) as continuous batching: frames queue and take over the
+    columns of frames that finish.  Results are unchanged."""
     B_all = np.asarray(keypoints).shape[0]
     groups = max(1, min(int(groups), B_all // 32)) if lbs_mode == "dense" else 1
     cuts = [(B_all * g) // groups for g in range(groups + 1)]
@@ -158,7 +162,7 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
         made.append(_make_batch(dm, cfg, np.asarray(keypoints)[lo:hi], jw_all[lo:hi] if jw_per_frame else jw_all,
                                 per(H, lo, hi), per(W, lo, hi), per(focal, lo, hi), per(reg_pose, lo, hi),
                                 per(reg_global, lo, hi), per(cam_prior_t, lo, hi), per(cam_prior_center, lo, hi),
-                                lbs_mode, reuse_entry_eval, body_pose_prior))
+                                lbs_mode, reuse_entry_eval, body_pose_prior, slots if groups == 1 else 0))
     fbs = [m[0] for m in made]
     if groups == 1:
         fbs[0].fit(first_stage=-1, last_stage=fbs[0].n_stages - 1)

@@ -184,10 +184,12 @@ class FrameBatch(object):
     """B frames under one configuration (sfx_batch)."""
 
     def __init__(self, model, B, cfg, lbs_mode="dense", reuse_entry_eval=True, has_regression_pose=True,
-                 stages=None, num_body_joints=None, side_view=False):
+                 stages=None, num_body_joints=None, side_view=False, slots=0):
         """`cfg` uses the reference's key names (cmd_parser).  `stages` (list of
         capi.StageWeights) overrides the schedule derived from cfg; `num_body_joints` overrides
-        where the per-stage hand/face joint weights start (K = never: weights passed verbatim)."""
+        where the per-stage hand/face joint weights start (K = never: weights passed verbatim).
+        `slots` (dense mode): GEMM columns when B is larger -- the other frames queue and are admitted as
+        columns free up (continuous batching); 0 = one column per frame."""
         self.model, self.B, self.cfg = model, int(B), dict(cfg)
         self._lib = model._lib
         if stages is None:
@@ -218,6 +220,7 @@ class FrameBatch(object):
         c.max_collisions = int(cfg.get("max_collisions", 8))
         c.df_cone_height = float(cfg.get("df_cone_height", 0.5))
         c.penalize_outside = int(bool(cfg.get("penalize_outside", True)))
+        c.slots = int(slots or 0)
         if c.interpenetration and lbs_mode != "dense":
             raise ValueError("interpenetration=True needs lbs_mode='dense' (the term reads every vertex)")
         self.use_vposer = bool(c.use_vposer)

@@ -119,14 +119,16 @@ def test_halpe_closure_matches_oracle(synth_model):
 
 
 def test_bench_two_rank_control_flow_rehearsal():
-    """bench.py under torch.distributed.run with 2 ranks (both on GPU 0, gloo): the N > 1 control
+    """`python bench.py --gpus 2` (it launches its own 2 ranks; both on GPU 0, gloo, in this rehearsal): the N > 1 control
     flow -- per-rank frame blocks, barriers, max-over-ranks time, the record gather -- produces one
     JSON line whose frame count is the whole job's."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SFX_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    # exactly what the driver types, no launcher: bench.py starts its ranks itself
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
            "--frames", "32", "--no-cpu", "--no-alt", "--lbs", "rows"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -135,6 +137,11 @@ def test_bench_two_rank_control_flow_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 32 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 32 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and all(r["closure_evals_total"] > 0 for r in d["ranks"])
+    # ... and under an external launcher whose world size disagrees with --gpus it refuses instead of mis-reporting
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=root, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "must agree" in bad.stderr
 
 
 def test_bench_rccl_calls_single_rank():

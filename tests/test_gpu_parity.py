@@ -268,24 +268,61 @@ def test_full_model_fit_matches_reference(gpu, synth_model, name, yaml_, mode):
 @pytest.mark.parametrize("mode", ["rows", "dense"])
 def test_benchmark_configuration_matches_reference(gpu, synth_model, mode):
     """bench.py's own configuration (fit_smplx_smplifyx.yaml weights, 5 body stages, body-only, regression
-    prior) on frames 0-3 of its sequence against the REAL reference (tests/golden/e2e_bench.npz).  Camera
-    stage 1e-4; body stages 1-3 within max(2 x the reference's fp32/fp64 spread, 3e-3); stages 4-5 (prior
-    weight 4.78: they end on the ftol test, tripped by fp32 noise) within max(3 x spread, 0.25) per frame."""
+    prior) on frames 0-31 of its sequence against the REAL reference (tests/golden/e2e_bench.npz: 32 fits in
+    fp32 and 32 in fp64).  The optimisation is chaotic, so single frames say nothing: the DISTRIBUTION of the
+    differences to the reference's fp32 fits has to sit inside what the reference's own fp64 fits show over the
+    same frames (fp64 ends 1.95 % lower on average, mean |difference| 2.6 %, median 2.2 %).
+      camera stage (well conditioned): every frame within 1e-4;
+      every body stage: signed mean difference within +-1 x the reference's own mean |fp64 - fp32| of that stage
+        (floor 3e-3), mean |difference| within 1.5 x it;
+      final loss: signed mean within +-1 x the reference's mean |fp64 - fp32|, median |difference| within 1.5 x the
+        reference's, at most 25 % of the frames further from the reference's [fp32, fp64] band than the band is wide;
+      work: mean closure evaluations between 0.8 x the reference's fp32 count and 1.1 x its fp64 count."""
     import bench as BB
     from smplifyx_amd import driver
     g = _golden("e2e_bench")
     cfg = BB.build_cfg("body")
     dm = _dm(synth_model, cfg)
     n = g["keypoints"].shape[0]
+    assert n >= 32
     res = driver.fit_frames(dm, cfg, g["keypoints"], H.base_joint_weights(cfg, 25), 600, 800, 5000.0, reg_pose=g["reg_pose"],
                             reg_global=g["reg_global"], lbs_mode=mode)
-    for i in range(n):
-        r32, r64 = g["f%d_f32_losses" % i], g["f%d_f64_losses" % i]
-        spread = np.abs(r32 - r64) / np.abs(r64)
-        rel = np.abs(res["stage_loss"][i] - r32) / np.abs(r32)
-        assert rel[0] < 1e-4, (i, rel)
-        assert np.all(rel[1:4] < np.maximum(2 * spread[1:4], 3e-3)), (i, rel, spread)
-        assert np.all(rel[4:] < np.maximum(3 * spread[4:], 0.25)), (i, rel, spread)
+    ours = res["stage_loss"].astype(np.float64)
+    r32 = np.stack([g["f%d_f32_losses" % i] for i in range(n)])
+    r64 = np.stack([g["f%d_f64_losses" % i] for i in range(n)])
+    d = (ours - r32) / np.abs(r32)
+    y = (r64 - r32) / np.abs(r32)
+    assert np.abs(d[:, 0]).max() < 1e-4, d[:, 0]
+    for k in range(1, ours.shape[1]):
+        yard = max(np.abs(y[:, k]).mean(), 3e-3)
+        assert abs(d[:, k].mean()) <= yard, (k, d[:, k].mean(), yard)
+        assert np.abs(d[:, k]).mean() <= 1.5 * yard, (k, np.abs(d[:, k]).mean(), yard)
+    st = BB.parity_stats(ours[:, -1], r32[:, -1], r64[:, -1])
+    assert abs(st["final_loss_rel_delta_signed_mean"]) <= st["reference_f32_vs_f64_rel_delta_mean"], st
+    assert st["final_loss_rel_delta_median"] <= 1.5 * st["reference_f32_vs_f64_rel_delta_median"], st
+    assert st["fraction_outside_reference_spread"] <= 0.25, st
+    ev = res["stage_ref_evals"].sum(1).mean()
+    e32 = np.mean([g["f%d_f32_evals" % i].sum() for i in range(n)]); e64 = np.mean([g["f%d_f64_evals" % i].sum() for i in range(n)])
+    assert 0.8 * e32 <= ev <= 1.1 * e64, (ev, e32, e64)
+
+
+def test_continuous_batching_matches_resident_batch(gpu, synth_model):
+    """Dense mode with a column pool smaller than the job (cfg.slots: frames queue and take over the columns of
+    frames that finish) gives every frame the result it has when all frames are resident -- bit for bit: frames are
+    independent and a GEMM column's arithmetic does not depend on its index or on the other columns."""
+    import bench as BB
+    from smplifyx_amd import driver
+    g = _golden("e2e_bench")
+    cfg = BB.build_cfg("body")
+    dm = _dm(synth_model, cfg)
+    n = 80
+    kp = np.concatenate([g["keypoints"]] * 3)[:n]; rp = np.concatenate([g["reg_pose"]] * 3)[:n]; rg = np.concatenate([g["reg_global"]] * 3)[:n]
+    kp = kp.copy(); kp[32:, :, :2] += 0.37          # (not exact repeats)
+    a = driver.fit_frames(dm, cfg, kp, H.base_joint_weights(cfg, 25), 600, 800, 5000.0, reg_pose=rp, reg_global=rg, lbs_mode="dense")
+    b = driver.fit_frames(dm, cfg, kp, H.base_joint_weights(cfg, 25), 600, 800, 5000.0, reg_pose=rp, reg_global=rg, lbs_mode="dense",
+                          slots=32)
+    for k in ("stage_loss", "stage_evals", "pose_embedding", "betas", "global_orient", "cam_translation"):
+        assert np.array_equal(a[k], b[k]), k
 
 
 def test_shard_invariance_bitwise(gpu, synth_model, cfg_body):

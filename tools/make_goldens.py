@@ -369,35 +369,72 @@ def gen_e2e_side():
     _save("e2e_side", **out)
 
 
-def gen_e2e_bench():
-    """The benchmark's own configuration (bench.py build_cfg('body'): cfg_files/fit_smplx_smplifyx.yaml
-    weights, 5 body stages, body-only keypoints, use_vposer False + regression prior) through the
-    reference: frames 0-3 of the benchmark's synthetic sequence, fp32 and fp64.  bench.py's
-    reference_parity leg reports the loss delta against these."""
+def _bench_task(task):
+    """One reference fit of benchmark frame i in one precision (worker of gen_e2e_bench): per-stage results plus
+    the per-LBFGS.step trace (step-entry loss, cumulative closure evaluations, cumulative inner iterations)."""
+    i, tag = task
     import helpers as H
     from smplifyx_amd import synthetic
     from scipy.spatial.transform import Rotation as Rot
+    dtype = torch.float32 if tag == "f32" else torch.float64
     model = synthetic.make_synthetic_model(0)
     cfg = H.load_cfg("fit_smplx_smplifyx.yaml", use_hands=False, use_face=False, use_vposer=False, use_cuda=False)
     cfg["use_camera_prior"] = False
     K = len(H.joint_map_for(cfg))
-    n = 4
-    frames = synthetic.make_frames(n, H.oracle_joints_fn(model, cfg), K, focal=5000.0)
-    out = dict(keypoints=frames["keypoints"], reg_pose=frames["reg_pose"], reg_global=frames["reg_global"])
+    frames = synthetic.make_frames(1, H.oracle_joints_fn(model, cfg), K, start=i, focal=5000.0)
     c = dict(cfg); c["regression_prior"] = "ExPose"
-    for i in range(n):
-        bp = Rot.from_euler("XYZ", frames["reg_pose"][i].reshape(21, 3).astype(np.float64)).as_matrix().astype(np.float32)
-        go = Rot.from_euler("XYZ", frames["reg_global"][i].astype(np.float64)[None]).as_matrix().astype(np.float32)
-        for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
-            bm = H.oracle_model(model, cfg, dtype)
-            res, losses, evals = _run_reference_fit(bm, c, frames["keypoints"][i:i + 1], frames["H"], frames["W"],
-                                                    frames["focal"], H.base_joint_weights(cfg, K), dtype,
-                                                    expose={"body_pose": bp, "global_orient": go})
-            out["f%d_%s_losses" % (i, tag)] = losses
-            out["f%d_%s_evals" % (i, tag)] = evals
-            for k in ("camera_translation", "global_orient", "betas", "body_pose"):
-                out["f%d_%s_%s" % (i, tag, k)] = np.asarray(res[k], np.float64)
-            print("e2e bench frame", i, tag, losses, evals)
+    bp = Rot.from_euler("XYZ", frames["reg_pose"][0].reshape(21, 3).astype(np.float64)).as_matrix().astype(np.float32)
+    go = Rot.from_euler("XYZ", frames["reg_global"][0].astype(np.float64)[None]).as_matrix().astype(np.float32)
+    trace = []
+    orig_step = ref.lbfgs_ls.LBFGS.step
+
+    def step(self, closure):
+        r = orig_step(self, closure)
+        st = self.state[self._params[0]]
+        trace.append((float(r), st["func_evals"], st["n_iter"], id(self)))
+        return r
+    ref.lbfgs_ls.LBFGS.step = step
+    try:
+        bm = H.oracle_model(model, cfg, dtype)
+        res, losses, evals = _run_reference_fit(bm, c, frames["keypoints"], frames["H"], frames["W"], frames["focal"],
+                                                H.base_joint_weights(cfg, K), dtype, expose={"body_pose": bp, "global_orient": go})
+    finally:
+        ref.lbfgs_ls.LBFGS.step = orig_step
+    ids = []
+    for t in trace:
+        if not ids or ids[-1] != t[3]:
+            ids.append(t[3])
+    stage_of = np.array([ids.index(t[3]) for t in trace], np.int32)      # one optimiser object per stage
+    out = {"losses": losses, "evals": evals,
+           "step_loss": np.array([t[0] for t in trace], np.float64),
+           "step_evals": np.array([t[1] for t in trace], np.int32),
+           "step_iters": np.array([t[2] for t in trace], np.int32),
+           "step_stage": stage_of}
+    for k in ("camera_translation", "global_orient", "betas", "body_pose", "left_hand_pose", "right_hand_pose",
+              "jaw_pose", "leye_pose", "reye_pose", "expression"):
+        out[k] = np.asarray(res[k], np.float64)
+    print("e2e bench frame", i, tag, losses, evals, flush=True)
+    return i, tag, frames["keypoints"][0], frames["reg_pose"][0], frames["reg_global"][0], out
+
+
+def gen_e2e_bench():
+    """The benchmark's own configuration (bench.py build_cfg('body'): cfg_files/fit_smplx_smplifyx.yaml
+    weights, 5 body stages, body-only keypoints, use_vposer False + regression prior) through the
+    reference: frames 0..N-1 of the benchmark's synthetic sequence (N = SFX_GOLDEN_BENCH_FRAMES, default 32),
+    fp32 and fp64, one process per (frame, precision).  bench.py's reference_parity leg and
+    test_benchmark_configuration_matches_reference compare the DISTRIBUTION of final losses against these."""
+    import multiprocessing as mp
+    n = int(os.environ.get("SFX_GOLDEN_BENCH_FRAMES", "32"))
+    tasks = [(i, tag) for i in range(n) for tag in ("f32", "f64")]
+    with mp.get_context("fork").Pool(int(os.environ.get("SFX_GOLDEN_WORKERS", "6"))) as pool:
+        results = pool.map(_bench_task, tasks, chunksize=1)
+    kp = [None] * n; rp = [None] * n; rg = [None] * n
+    out = {}
+    for i, tag, k_, p_, g_, o in results:
+        kp[i], rp[i], rg[i] = k_, p_, g_
+        for key, v in o.items():
+            out["f%d_%s_%s" % (i, tag, key)] = v
+    out.update(keypoints=np.stack(kp), reg_pose=np.stack(rp), reg_global=np.stack(rg))
     _save("e2e_bench", **out)
 
 
