@@ -209,6 +209,16 @@ int  sfx_batch_pen_stats(sfx_batch* b, int32_t* stats_host /* [B][4] */, int32_t
 int  sfx_batch_get_stats(sfx_batch* b, float* stage_loss, int32_t* stage_evals,
                          int32_t* stage_ref_evals);
 
+/* Optimiser trace (tests of step-level parity with smplifyx/optimizers/lbfgs_ls.py:256-445 and
+ * smplifyx/fitting.py:147-217): capacity > 0 attaches a buffer of `capacity` records per frame that every
+ * later sfx_batch_fit / sfx_batch_step fills, capacity = 0 detaches it.  A record is 4 floats:
+ *   (0, t, loss, ls_evals)                 a line search ended: accepted step length, loss there, its evaluations
+ *   (1, entry loss, func_evals, n_iter)    one LBFGS.step returned (cumulative evaluations / iterations of the stage)
+ *   (2, result, closure evaluations, stage) run_fitting returned for a stage (camera stage = -1)
+ * sfx_batch_get_trace: records [B][capacity][4] and the number written per frame (HOST; counts may exceed capacity). */
+int  sfx_batch_trace(sfx_batch* b, int32_t capacity);
+int  sfx_batch_get_trace(sfx_batch* b, float* records, int32_t* counts);
+
 /* Gaussian-mixture body pose prior (MaxMixturePrior, smplifyx/prior.py:100-231; body_prior_type 'gmm'):
  * used by the closure when use_vposer is off and the batch has no regression pose (fitting.py:399-401).
  * means [M][D], precisions [M][D][D], nll_weights [M] = the module's buffers; D = 63, M <= 8 (HOST). */

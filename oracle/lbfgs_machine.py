@@ -139,6 +139,7 @@ class StageMachine(object):
         self.cache = None              # (f, g) valid at self.x
         self.evals = 0                 # closure evaluations actually requested
         self.trace = []
+        self.records = []              # same records as the device trace (include/sfx.h: sfx_batch_trace)
 
     # ---- helpers -----------------------------------------------------------------------
     def _axpy(self, x, a, d):
@@ -342,6 +343,7 @@ class StageMachine(object):
         self.cur_evals += self.ls_evals
         self.func_evals += self.ls_evals
         self.trace.append((self.n_iter_total, float(self.loss.v), float(t.v), self.ls_evals))
+        self.records.append((0, float(t.v), float(self.loss.v), self.ls_evals))
         if self.n_iter == self.max_iter:
             return self._end_step()
         if self.cur_evals >= self.max_eval:
@@ -358,6 +360,7 @@ class StageMachine(object):
     # ---- run_fitting bookkeeping after optimizer.step (fitting.py:175-217) ---------------------
     def _end_step(self):
         loss = float(self.orig_loss.v)           # step() returns the ENTRY loss
+        self.records.append((1, loss, self.func_evals, self.n_iter_total))
         n = self.outer
         stop = False
         if np.isnan(loss) or np.isinf(loss):
@@ -383,6 +386,7 @@ class StageMachine(object):
         self.x_trial = self.x.copy()
 
     def _finish_stage(self):
+        self.records.append((2, float("nan") if self.result is None else float(self.result), self.evals, 0))
         self.phase = PH_DONE
         self.x_trial = self.x.copy()
 

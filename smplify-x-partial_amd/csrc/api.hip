@@ -588,6 +588,8 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
 extern "C" void sfx_batch_destroy(sfx_batch* b) {
     if (!b) return;
     if (b->pen) sfx_pen_destroy(b->pen);
+    if (b->D.trace) hipFree(b->D.trace);
+    if (b->D.trace_n) hipFree(b->D.trace_n);
     b->mem.free_all();
     if (b->stage_host) hipHostFree(b->stage_host);
     if (b->map_host) hipHostFree(b->map_host);
@@ -1171,6 +1173,30 @@ extern "C" int sfx_batch_get_grad(sfx_batch* b, int32_t stage, float* grad_out) 
     std::vector<float> g((size_t)B * SFX_NVAR_MAX);
     SFX_CHECK(hipMemcpy(g.data(), b->D.g, g.size() * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < B; ++i) memcpy(grad_out + (size_t)i * n, g.data() + (size_t)i * SFX_NVAR_MAX, (size_t)n * 4);
+    return 0;
+}
+
+extern "C" int sfx_batch_trace(sfx_batch* b, int32_t capacity) {
+    if (!b || capacity < 0) { sfx_set_error("bad argument"); return -1; }
+    BatchDev& D = b->D;
+    SFX_CHECK(hipDeviceSynchronize());
+    if (D.trace) { hipFree(D.trace); D.trace = nullptr; }
+    if (D.trace_n) { hipFree(D.trace_n); D.trace_n = nullptr; }
+    D.trace_cap = 0;
+    if (capacity == 0) return 0;
+    SFX_CHECK(hipMalloc((void**)&D.trace, (size_t)D.cfg.B * capacity * sizeof(float4)));
+    SFX_CHECK(hipMalloc((void**)&D.trace_n, (size_t)D.cfg.B * sizeof(int)));
+    SFX_CHECK(hipMemset(D.trace_n, 0, (size_t)D.cfg.B * sizeof(int)));
+    D.trace_cap = capacity;
+    return 0;
+}
+
+extern "C" int sfx_batch_get_trace(sfx_batch* b, float* records, int32_t* counts) {
+    if (!b || !b->D.trace) { sfx_set_error("no trace buffer attached (sfx_batch_trace)"); return -1; }
+    const BatchDev& D = b->D;
+    SFX_CHECK(hipDeviceSynchronize());
+    if (records) SFX_CHECK(hipMemcpy(records, D.trace, (size_t)D.cfg.B * D.trace_cap * sizeof(float4), hipMemcpyDeviceToHost));
+    if (counts) SFX_CHECK(hipMemcpy(counts, D.trace_n, (size_t)D.cfg.B * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
 

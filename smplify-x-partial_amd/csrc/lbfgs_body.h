@@ -437,6 +437,10 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
         s.ls_done = (done) ? 1 : 0; s.insuf = 0;                                                         \
         if (sc_le(s.bf0, s.bf1)) { s.low = 0; s.high = 1; } else { s.low = 1; s.high = 0; } } while (0)
 
+    // optimiser trace (sfx_batch_trace): one record per finished line search / LBFGS.step / stage
+#define TRACE(ty, a_, b_, c_) do { if (D.trace && lane == 0) { const int n_ = D.trace_n[b];                         \
+        if (n_ < D.trace_cap) D.trace[(size_t)b * D.trace_cap + n_] = make_float4((float)(ty), (float)(a_), (float)(b_), (float)(c_)); \
+        D.trace_n[b] = n_ + 1; } } while (0)
     int act = A_NONE;
     TMARK(1);
     // ---------------------------------------------------------------- consume the evaluation
@@ -640,6 +644,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
             s.cache_valid = 1;
             const bool opt_cond = sc_le(T(absmax3(g, lane, N)), P((double)1e-5));
             s.cur_evals += s.ls_evals; s.func_evals += s.ls_evals;
+            TRACE(0, t.v, s.loss.v, s.ls_evals);
             if (s.n_iter == max_iter) { act = A_END_STEP; break; }
             if (s.cur_evals >= max_eval) { act = A_END_STEP; break; }
             if (opt_cond) { act = A_END_STEP; break; }
@@ -654,6 +659,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
         }
         case A_END_STEP: {       // run_fitting bookkeeping (fitting.py:175-217)
             const double loss = s.orig_loss.v;
+            TRACE(1, loss, s.func_evals, s.n_iter_total);
             if (step_mode) {         // one LBFGS.step per call: hand control back, keep the state
                 if (lane == 0) {
                     D.stage_loss[(size_t)b * (1 + SFX_MAX_STAGES) + stage + 1] = (float)loss;
@@ -708,6 +714,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
             const size_t so = (size_t)b * (1 + SFX_MAX_STAGES);
             const int pass = D.orient_pass[b];
             const float res = s.has_prev_outer ? (float)s.prev_loss_outer : __int_as_float(0x7fc00000);
+            TRACE(2, res, s.evals, stage);
             if (lane == 0) {
                 (pass ? D.stage_loss2 : D.stage_loss)[so + slot] = res;
                 D.stage_evals[so + slot] += s.evals;
@@ -765,6 +772,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
     if (lane == 0) gst->s = s_state;     // ro[] is written in place
     TMARK(7);
 #undef TMARK
+#undef TRACE
 #undef VEC
 }
 

@@ -190,6 +190,9 @@ struct BatchDev {
     int*   ext_n;           // [B] (slot-indexed) vertices with a nonzero penetration gradient (diagnostics)
     float* fwd;             // [B][SFX_FWD_N] forward state handed from the export pass to the adjoint pass
     long long* dbg;         // [64] phase timestamps of block 0 (NULL = off)
+    float4* trace;          // [B][trace_cap] optimiser trace records (NULL = off), see sfx_batch_trace
+    int*   trace_n;         // [B] records written
+    int    trace_cap;
 };
 
 enum { VEC_XINIT = 0, VEC_D, VEC_G, VEC_PREVG, VEC_GPREV, VEC_BG0, VEC_BG1, VEC_LSG0, NVEC };

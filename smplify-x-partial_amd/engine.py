@@ -335,6 +335,22 @@ class FrameBatch(object):
         capi.check(self._lib.sfx_batch_get_grad(self._h, stage, capi.fptr(grad)))
         return grad
 
+    def trace(self, capacity):
+        """Attach (capacity > 0 records per frame) or detach (0) the optimiser trace (sfx_batch_trace)."""
+        capi.check(self._lib.sfx_batch_trace(self._h, int(capacity)))
+        self._trace_cap = int(capacity)
+
+    def get_trace(self):
+        """Per frame: array [n, 4] of the records written since the trace was attached
+        ((0, t, loss, ls_evals) | (1, entry loss, func_evals, n_iter) | (2, result, evals, stage))."""
+        cap = self._trace_cap
+        rec = np.zeros((self.B, cap, 4), np.float32)
+        cnt = np.zeros(self.B, np.int32)
+        capi.check(self._lib.sfx_batch_get_trace(self._h, capi.fptr(rec), capi.iptr(cnt)))
+        if (cnt > cap).any():
+            raise RuntimeError("optimiser trace overflowed: %d records, capacity %d" % (cnt.max(), cap))
+        return [rec[i, :cnt[i]].copy() for i in range(self.B)]
+
     def stats(self):
         ns = self.n_stages + 1
         loss = np.zeros((self.B, ns), np.float32)

@@ -1,0 +1,170 @@
+"""Step-level parity of the on-device optimiser (csrc/lbfgs_body.h) with its specification
+oracle/lbfgs_machine.py -- which tests/golden/lbfgs.npz pins to the reference's
+FittingMonitor.run_fitting (smplifyx/fitting.py:147-217), LBFGS.step (optimizers/lbfgs_ls.py:256-445) and
+_strong_Wolfe / _cubic_interpolate (:11-167) evaluation by evaluation.
+
+Whole fits only show the optimiser through a chaotic trajectory.  Here the device's trace of a stage (every finished
+line search: step length, loss, evaluations; every LBFGS.step: entry loss, cumulative evaluations and iterations; the
+stage result -- include/sfx.h sfx_batch_trace) is compared record by record with the machine's, the machine being
+driven (a) by the SAME HIP closure, so that any difference is the state machine's -- dot products are summed in a
+different order and the two-loop recursion is blocked on the device, so directions differ in the last bits: every branch
+decision and every count must agree exactly above the fp32 noise floor, accepted losses to 5e-5, step lengths (cubic
+interpolations: ill-conditioned) to 5e-3 -- and (b) by the oracle's torch fp32 closure on the camera stage (N = 6):
+same decisions and counts, losses along the way within 1e-3, the same stage result.
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+import test_gpu_parity as T
+
+pytestmark = pytest.mark.gpu
+
+@pytest.fixture(scope="module")
+def cfg_body():
+    return H.load_cfg("fit_smplx_combined_coco25.yaml", use_hands=False, use_face=False)
+
+
+ORDER = (("betas", 10), ("global_orient", 3), (None, 63), ("left_hand_pose", 12), ("right_hand_pose", 12), ("jaw_pose", 3),
+         ("leye_pose", 3), ("reye_pose", 3), ("expression", 10), ("pose_embedding", 63))
+
+
+def _flat(P, i):
+    return np.concatenate([np.zeros(n, np.float32) if k is None else P[k][i] for k, n in ORDER])
+
+
+def _unflat(x):
+    out, o = {}, 0
+    for k, n in ORDER:
+        if k is not None:
+            out[k] = x[o:o + n][None].astype(np.float32)
+        o += n
+    return out
+
+
+def _setup(synth_model, cfg_body):
+    g = T._golden("e2e_synth")
+    cfg = dict(cfg_body); cfg["use_camera_prior"] = False
+    dm = T._dm(synth_model, cfg)
+    frames = dict(keypoints=g["keypoints"], reg_pose=g["reg_pose"], reg_global=g["reg_global"], H=600, W=800, focal=5000.0)
+    return cfg, dm, frames
+
+
+def _machine(x0, cfg, groups, reuse):
+    from oracle.lbfgs_machine import StageMachine
+    return StageMachine(x0, groups=groups, maxiters=cfg["maxiters"], ftol=cfg["ftol"], gtol=cfg["gtol"], lr=cfg.get("lr", 1.0),
+                        dtype=np.float32, reuse_entry_eval=reuse)
+
+
+def _above_noise_floor(rec, floor=1e-6):
+    """Number of leading records before the first accepted loss within `floor` (relative) of the stage's result: past that
+    point successive losses differ by an ulp or two of fp32 and every Armijo / curvature test is a coin toss decided by
+    the summation order of a dot product -- only the part of the trajectory above the noise floor can agree event by event."""
+    rec = np.asarray(rec, np.float64)
+    final = rec[rec[:, 0] == 2][-1, 1] if (rec[:, 0] == 2).any() else rec[rec[:, 0] == 0][-1, 2]
+    for k, r in enumerate(rec):
+        if r[0] == 0 and abs(r[2] - final) <= floor * abs(final):
+            return k
+    return len(rec)
+
+
+def _compare(dev, mac, rtol, what, whole_stage=True, t_rtol=None):
+    dev = np.asarray(dev, np.float64); mac = np.asarray(mac, np.float64)
+    n = min(_above_noise_floor(dev), _above_noise_floor(mac)) if whole_stage else min(len(dev), len(mac))
+    assert n >= 8, (what, "too few events above the noise floor", n)
+    d, m = dev[:n], mac[:n]
+    assert np.array_equal(d[:, 0], m[:, 0]), what                         # record types: the same sequence of events
+    ls, st = d[:, 0] == 0, d[:, 0] == 1
+    assert np.array_equal(d[ls, 3], m[ls, 3]), (what, "evaluations per line search")
+    assert np.array_equal(d[st, 2], m[st, 2]) and np.array_equal(d[st, 3], m[st, 3]), (what, "evaluations / iterations per LBFGS.step")
+    # (a step length comes out of a cubic interpolation -- differences of nearly equal numbers: rounding of the directional
+    #  derivative's dot product is amplified ~500 x there, the loss at the accepted point is flat in t and agrees far better)
+    assert np.allclose(d[ls, 1], m[ls, 1], rtol=t_rtol or 100 * rtol, atol=0), (what, "step lengths", np.abs(d[ls, 1] / m[ls, 1] - 1).max())
+    assert np.allclose(d[ls, 2], m[ls, 2], rtol=rtol, atol=0), (what, "accepted losses", np.abs(d[ls, 2] / m[ls, 2] - 1).max())
+    assert np.allclose(d[st, 1], m[st, 1], rtol=rtol, atol=0), (what, "entry losses", np.abs(d[st, 1] / m[st, 1] - 1).max())
+    if whole_stage:      # the converged tail: same result, comparable work
+        assert dev[-1, 0] == 2 and mac[-1, 0] == 2
+        assert abs(dev[-1, 1] - mac[-1, 1]) <= 2e-6 * abs(mac[-1, 1]), (what, "stage result", dev[-1], mac[-1])
+        assert abs(dev[-1, 2] - mac[-1, 2]) <= max(0.3 * mac[-1, 2], 12), (what, "closure evaluations of the stage", dev[-1], mac[-1])
+    return n
+
+
+@pytest.mark.parametrize("reuse", [False, True])
+def test_camera_stage_steps_match_the_machine(synth_model, cfg_body, reuse):
+    cfg, dm, frames = _setup(synth_model, cfg_body)
+    for i in range(2):
+        fb = H.engine_batch_from_frames(dm, cfg, frames, [i], lbs_mode="rows", reuse=reuse)
+        fb.guess_init(cfg["body_tri_idxs"])
+        P0 = fb.get_params()
+        fb.trace(4096)
+        fb.fit(first_stage=-1, last_stage=-1)
+        dev = fb.get_trace()[0]
+        assert dev[-1, 0] == 2 and dev[-1, 3] == -1
+        # (a) the machine on the HIP closure
+        fc = H.engine_batch_from_frames(dm, cfg, frames, [i], lbs_mode="rows", reuse=reuse)
+        fc.guess_init(cfg["body_tri_idxs"])
+        m = _machine(np.concatenate([P0["cam_translation"][0], P0["global_orient"][0]]), cfg, [(0, 3, True), (3, 3, True)], reuse)
+        while not m.done:
+            x = m.x_trial
+            fc.set_params(regression_pose=frames["reg_pose"][i:i + 1], cam_translation=x[None, :3], global_orient=x[None, 3:],
+                          pose_embedding=P0["pose_embedding"])
+            f, gr = fc.closure(-1)
+            m.feed(f[0], gr[0])
+        mac = np.array(m.records); mac[-1, 3] = -1
+        n = _compare(dev, mac, 5e-5, "camera stage, frame %d, machine on the HIP closure" % i)
+        assert n >= 20, n                      # (the camera stage takes ~30 line searches; the last few sit on the noise floor)
+        assert fb.stats()["stage_evals"][0, 0] == dev[-1, 2]
+        # (b) the machine on the oracle's torch fp32 closure
+        Q = dict(P0); Q["est_tz"] = P0["cam_translation"][:, 2].copy(); Q.pop("body_pose")
+        Qf = {k: np.repeat(v, 2, 0) if v.shape[0] == 1 else v for k, v in Q.items()}       # (_oracle_closure indexes by frame)
+        m2 = _machine(np.concatenate([P0["cam_translation"][0], P0["global_orient"][0]]), cfg, [(0, 3, True), (3, 3, True)], reuse)
+        fr1 = {k: (v[i:i + 1] if isinstance(v, np.ndarray) else v) for k, v in frames.items()}
+        while not m2.done:
+            x = m2.x_trial
+            Qx = {k: v[:1].copy() for k, v in Qf.items()}
+            Qx["cam_translation"] = x[None, :3].astype(np.float32); Qx["global_orient"] = x[None, 3:].astype(np.float32)
+            f, gr = T._oracle_closure(synth_model, cfg, fr1, 0, Qx, -1, dtype=torch.float32)
+            m2.feed(f, gr)
+        mac2 = np.array(m2.records); mac2[-1, 3] = -1
+        _compare(dev, mac2, 1e-3, "camera stage, frame %d, machine on the oracle's fp32 closure" % i, t_rtol=0.05)
+
+
+def test_first_body_stage_steps_match_the_machine(synth_model, cfg_body):
+    """N = 182 (119 live variables), ~400 evaluations, history filling up to 100 pairs: blocked two-loop recursion on the
+    device against the plain one of the machine, both fed by the HIP closure.  Rounding differs (summation order), so the
+    trajectories separate slowly: the first ten LBFGS.step calls must agree event by event, the stage as a whole in its
+    result (1e-3) and its work (10 %)."""
+    cfg, dm, frames = _setup(synth_model, cfg_body)
+    i = 0
+    fb = H.engine_batch_from_frames(dm, cfg, frames, [i], lbs_mode="rows", reuse=True)
+    fb.guess_init(cfg["body_tri_idxs"])
+    fb.fit(first_stage=-1, last_stage=-1)
+    P1 = fb.get_params()
+    fb.trace(8192)
+    fb.fit(first_stage=0, last_stage=0)
+    dev = fb.get_trace()[0]
+    fc = H.engine_batch_from_frames(dm, cfg, frames, [i], lbs_mode="rows", reuse=True)
+    fc.guess_init(cfg["body_tri_idxs"])
+    groups, o = [], 0
+    for k, n in ORDER:
+        groups.append((o, n, k is not None)); o += n
+    m = _machine(_flat(P1, 0), cfg, groups, True)
+    while not m.done:
+        fc.set_params(regression_pose=frames["reg_pose"][i:i + 1], cam_translation=P1["cam_translation"], **_unflat(m.x_trial))
+        f, gr = fc.closure(0)
+        assert np.all(gr[0][13:76] == 0)
+        m.feed(f[0], gr[0])
+    mac = np.array(m.records)
+    # event by event for as long as the two trajectories take the same decisions: at least the first 40 line searches
+    # (rounding separates them slowly: after a few dozen iterations one Armijo test falls the other way)
+    k = 0
+    while k < min(len(dev), len(mac)) and dev[k, 0] == mac[k, 0] and (dev[k, 0] != 0 or dev[k, 3] == mac[k, 3]) \
+            and (dev[k, 0] != 1 or (dev[k, 2] == mac[k, 2] and dev[k, 3] == mac[k, 3])):
+        k += 1
+    assert (dev[:k, 0] == 0).sum() >= 40, ((dev[:k, 0] == 0).sum(), k)
+    _compare(dev[:k], mac[:k], 2e-3, "first body stage, common prefix", whole_stage=False, t_rtol=0.1)
+    k10 = np.flatnonzero(dev[:, 0] == 0)[9] + 1                      # ... and tightly while rounding has not yet spread
+    _compare(dev[:k10], mac[:k10], 1e-5, "first body stage, first ten line searches", whole_stage=False, t_rtol=1e-3)
+    assert abs(dev[-1, 1] - mac[-1, 1]) <= 1e-3 * abs(mac[-1, 1]), (dev[-1], mac[-1])
+    assert abs(dev[-1, 2] - mac[-1, 2]) <= 0.1 * mac[-1, 2], (dev[-1], mac[-1])
