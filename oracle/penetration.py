@@ -114,6 +114,39 @@ def penetration_loss(verts, faces, pairs, sigma, penalize_outside=True):
            (_psi(ob, rb, nb, A, sigma, penalize_outside) ** 2).sum()
 
 
+def ordered_pairs_capped(pairs, max_collisions):
+    """The pair set the device keeps when a triangle has more than max_collisions partners (include/sfx.h,
+    csrc/collide.hip k_pen_list / k_pen_eval): every triangle keeps its max_collisions LOWEST partner ids, and a pair
+    counts only if both triangles kept each other.  Returns the ORDERED pairs (f, g) -- f receives g's vertices; the
+    set is symmetric -- and the number of ordered pairs cut.  (The package the reference calls keeps the partners its
+    BVH traversal meets first: implementation defined; PARITY UNPINNED.)"""
+    pairs = np.asarray(pairs, np.int64).reshape(-1, 2)
+    both = np.concatenate([pairs, pairs[:, ::-1]], 0)
+    both = both[np.lexsort((both[:, 1], both[:, 0]))]
+    keep = np.ones(len(both), bool)
+    start = 0
+    while start < len(both):
+        end = start
+        while end < len(both) and both[end, 0] == both[start, 0]:
+            end += 1
+        keep[start + max_collisions:end] = False
+        start = end
+    kept = set(map(tuple, both[keep].tolist()))
+    sym = np.array([keep[i] and (int(both[i, 1]), int(both[i, 0])) in kept for i in range(len(both))], bool)
+    return both[sym], int((~sym).sum())
+
+
+def penetration_loss_ordered(verts, faces, opairs, sigma, penalize_outside=True):
+    """sum over ordered pairs (f, g) of sum_{v in g} Psi_f(v)^2 (one direction per ordered pair)."""
+    if len(opairs) == 0:
+        return verts.sum() * 0.0
+    faces_t = torch.as_tensor(np.asarray(faces, np.int64))
+    tri = verts[faces_t]
+    A, Bt = tri[torch.as_tensor(opairs[:, 0])], tri[torch.as_tensor(opairs[:, 1])]
+    oa, ra, na = _cone_geometry(A)
+    return (_psi(oa, ra, na, Bt, sigma, penalize_outside) ** 2).sum()
+
+
 def penetration(verts, faces, segm=None, parents=None, ign_part_pairs=None, sigma=1e-4, penalize_outside=True,
                 dtype=torch.float64):
     """Convenience: numpy verts [V,3] -> (loss float, d loss / d verts [V,3], pairs [P,2])."""

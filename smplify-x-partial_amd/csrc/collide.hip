@@ -51,7 +51,8 @@
                                 // scatter cursors (+ 48 KB of wavefront tiles, 16 KB of pair queues)
 
 struct PenDev {
-    int V, F, cap, n_parts;
+    int V, F, cap, n_parts;    // cap = max_collisions: partners KEPT per triangle
+    int pcap;                  // partners HELD per triangle while the list is being collected (2 x cap)
     const int* faces;          // [F][3]
     const int* segm;           // [F]
     const unsigned char* skip; // [n_parts][n_parts] 1 = pair of parts never collides
@@ -62,7 +63,8 @@ struct PenDev {
     int* entries;              // [B][ent_cap] triangle | part << 24, sorted by bucket
     int* ent_cell;             // [B][ent_cap] packed cell coordinates the entry was made for
     int ent_cap;
-    int* partners;             // [B][F][cap]
+    int* partners;             // [B][F][pcap]
+    int* pavail;               // [B][F] partners held: min(found, pcap)
     int* pcount;               // [B][F]
     int* poff;                 // [B][F] start of the triangle's partner range in the frame's pair list
     int* pown;                 // [B][pair_cap] pair list: receiving triangle (ascending) ...
@@ -187,7 +189,7 @@ void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __r
     const int b = blockIdx.x, t = threadIdx.x;
     int* st = P.stats + b * PEN_STATS;
     if (want && !want[b]) {                     // the frame's stage carries no collision weight: nothing to do
-        if (t == 0) { P.ptotal[b] = 0; P.cells[(size_t)b * (PEN_CELLS + 1) + PEN_CELLS] = 0; st[0] = st[1] = st[2] = st[3] = 0; }
+        if (t == 0) { P.ptotal[b] = 0; P.cells[(size_t)b * (PEN_CELLS + 1) + PEN_CELLS] = 0; st[0] = st[1] = st[2] = st[3] = 0; st[15] = 0; }
         return;
     }
     const long long clk0 = wall_clock64();
@@ -333,7 +335,7 @@ void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __r
     // carry the cell they were made for, and a scan only looks at those of its own cell
     auto cell_key = [](int x, int y, int z) { return (x & 1023) | ((y & 1023) << 10) | ((z & 1023) << 20); };
     const bool ent_ok = s_total <= P.ent_cap - (F + 3) / 4 - 4;
-    if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = ncell; st[14] = s_total; }
+    if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = ncell; st[14] = s_total; st[15] = 0; }
     if (!ent_ok) {       // grid too crowded for the entry buffer: report, produce no pairs
         for (int f = t; f < F; f += PEN_T) P.pcount[(size_t)b * F + f] = 0;
         if (t == 0) { st[0] = 0; st[1] = 0; P.ptotal[b] = 0; P.cells[(size_t)b * (PEN_CELLS + 1) + PEN_CELLS] = 0; }
@@ -400,7 +402,7 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
     // to both triangles' partner lists.
     int* tile = s_tile + wv * 128 * 12;
     int* pc = P.pcount + (size_t)b * F;
-    int* part = P.partners + (size_t)b * F * P.cap;
+    int* part = P.partners + (size_t)b * F * P.pcap;
     auto load_hdr = [&](int q, bool ok, int (&hd)[12]) {
         hd[0] = ok ? ent[q] : 0; hd[1] = ok ? entc[q] : -1;
         const int f = hd[0] & 0xffffff;
@@ -419,8 +421,8 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
         for (int q = lane; q < n; q += 64) {
             const int fa = queue[2 * q], fb = queue[2 * q + 1];
             const int pa = atomicAdd(&pc[fa], 1), pb = atomicAdd(&pc[fb], 1);
-            if (pa < P.cap) part[(size_t)fa * P.cap + pa] = fb;
-            if (pb < P.cap) part[(size_t)fb * P.cap + pb] = fa;
+            if (pa < P.pcap) part[(size_t)fa * P.pcap + pa] = fb;
+            if (pb < P.pcap) part[(size_t)fb * P.pcap + pb] = fa;
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -514,8 +516,13 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
 
     // ---- the frame's pair list: triangles ascending, partners ascending within a triangle (the
     // partner lists were appended in scheduling order; ranking them here fixes every later summation
-    // order).  Lists longer than max_collisions, and pairs beyond pair_cap, are cut and counted.
+    // order).  A triangle with more than max_collisions partners keeps the max_collisions LOWEST triangle
+    // ids (the package the reference calls keeps the ones its BVH traversal meets first: implementation
+    // defined there; a rule on ids does not depend on scheduling or on the other frames of the batch).  The lists
+    // hold up to pcap = 2 x max_collisions partners while they are collected; only beyond that is the choice
+    // left to arrival order.  Cut partners, and pairs beyond pair_cap, are counted.
     int* poff = P.poff + (size_t)b * F;
+    int* pav = P.pavail + (size_t)b * F;
     {
         const int per = (F + PEN_T - 1) / PEN_T;
         const int f0 = min(F, t * per), f1 = min(F, f0 + per);
@@ -527,6 +534,7 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
             const int c = min(pc[f], P.cap);
             const int keep = max(0, min(c, P.pair_cap - acc));
             n_over += c - keep;
+            pav[f] = min(pc[f], P.pcap);
             poff[f] = acc; pc[f] = c;            // readers cut at pair_cap: kept = clamp(pair_cap - poff, 0, pcount)
             acc += c;
         }
@@ -546,7 +554,8 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
     const int F = P.F;
     const int* pc = P.pcount + (size_t)b * F;
     const int* poff = P.poff + (size_t)b * F;
-    const int* part = P.partners + (size_t)b * F * P.cap;
+    const int* part = P.partners + (size_t)b * F * P.pcap;
+    const int* pav = P.pavail + (size_t)b * F;
     int* pown = P.pown + (size_t)b * P.pair_cap;
     int* plist = P.plist + (size_t)b * P.pair_cap;
     int* tile = s_sort + wv * min(max(cap_pad, 64), 2048);
@@ -561,6 +570,7 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
         const int f = fw + lane;
         const bool inr = f < flim;
         const int c_l = inr ? pc[f] : 0, off_l = inr ? poff[f] : 0x3fffffff;
+        const int a_l = inr ? pav[f] : 0;              // partners held (> c_l: the list is cut to its c_l lowest ids)
         const int base = __builtin_amdgcn_readfirstlane(off_l);
         const int lastv = min(63, flim - 1 - fw);
         const int E = __builtin_amdgcn_readlane(off_l + c_l, lastv) - base;
@@ -574,28 +584,29 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
             for (int d = 32; d > 0; d >>= 1) if (tile[l + d] <= e) l += d;      // last l with offset <= e
             const int ff = fw + l, lo = tile[l], slot = e - lo, off = base + lo;
             const int cc = pc[ff];
-            if (can_sort && cc > PEN_SHORT) continue;
-            const int* mine = part + (size_t)ff * P.cap;
+            if (can_sort && (cc > PEN_SHORT || pav[ff] > cc)) continue;
+            const int* mine = part + (size_t)ff * P.pcap;
             const int x = mine[slot];
             int rank = 0;
             for (int r = 0; r < cc; ++r) { const int y = mine[r]; rank += (y < x) || (y == x && r < slot); }
             if (off + rank < P.pair_cap) { plist[off + rank] = x; pown[off + rank] = ff; }
         }
         __builtin_amdgcn_wave_barrier();
-        unsigned long long m = __ballot(can_sort && c_l > PEN_SHORT && off_l < P.pair_cap);
+        unsigned long long m = __ballot(can_sort && (c_l > PEN_SHORT || a_l > c_l) && off_l < P.pair_cap);
         while (m) {
             const int bit = __ffsll((long long)m) - 1;
             m &= m - 1;
             const int ff = fw + bit;
             const int cc = __builtin_amdgcn_readlane(c_l, bit), off = __builtin_amdgcn_readlane(off_l, bit);
-            const int* mine = part + (size_t)ff * P.cap;
+            const int av = __builtin_amdgcn_readlane(a_l, bit);       // sort all av held partners, keep the cc lowest
+            const int* mine = part + (size_t)ff * P.pcap;
             int np = 64;
-            while (np < cc) np <<= 1;
+            while (np < av) np <<= 1;
             if (np <= 128) {
                 // up to 128 partners (the cfgs' max_collisions): bitonic network on one or two registers per
                 // lane, element e = lane + 64 r; exchanges through ds_bpermute, no LDS traffic
-                int x0 = lane < cc ? mine[lane] : 0x7fffffff;
-                int x1 = (np == 128 && lane + 64 < cc) ? mine[lane + 64] : 0x7fffffff;
+                int x0 = lane < av ? mine[lane] : 0x7fffffff;
+                int x1 = (np == 128 && lane + 64 < av) ? mine[lane + 64] : 0x7fffffff;
                 for (int k = 2; k <= np; k <<= 1)
                     for (int j = k >> 1; j > 0; j >>= 1) {
                         if (j == 64) { const int lo = min(x0, x1), hi = max(x0, x1); x0 = lo; x1 = hi; continue; }   // k = 128: ascending
@@ -613,7 +624,7 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
                 continue;
             }
 
-            for (int q = lane; q < np; q += 64) tile[q] = q < cc ? mine[q] : 0x7fffffff;
+            for (int q = lane; q < np; q += 64) tile[q] = q < av ? mine[q] : 0x7fffffff;
             for (int k = 2; k <= np; k <<= 1)
                 for (int j = k >> 1; j > 0; j >>= 1) {
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
@@ -634,7 +645,9 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
 }
 
 // one lane per ORDERED pair (f receives g, and f's vertices intrude into g): the lane differentiates
-// with respect to f's 9 coordinates only, so every number has one owner
+// with respect to f's 9 coordinates only, so every number has one owner.
+// Loss of the frame = sum over the kept ordered pairs (f, g) of sum_{v in g} Psi_f(v)^2; the kept set is symmetric
+// (see below), so the gradient is exact also when max_collisions cuts a list
 __global__ __launch_bounds__(256)
 void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int penalize_outside) {
     const int b = blockIdx.y;
@@ -654,7 +667,26 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
             qv[k * 3 + e] = vb[(size_t)P.faces[g * 3 + k] * 3 + e];
         }
         float loss = 0.f, g9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (valid)
+        // BVH(max_collisions): a triangle with more than max_collisions partners keeps its lowest ids (k_pen_list), and a
+        // pair counts only if BOTH triangles kept each other -- the kept set is symmetric, so the two lanes (f, g) and
+        // (g, f) exist together and every gradient term has its owner.  Lists that were not cut hold every partner; a cut
+        // list is searched for f.
+        bool sym = valid;
+        if (valid) {
+            const int cg = P.pcount[(size_t)b * P.F + g];
+            if (P.pavail[(size_t)b * P.F + g] > cg) {
+                const int og = P.poff[(size_t)b * P.F + g];
+                int lo = 0, hi = max(0, min(cg, P.pair_cap - og));
+                const int top = hi;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (plist[og + mid] < f) lo = mid + 1; else hi = mid; }
+                sym = lo < top && plist[og + lo] == f;
+            }
+        }
+        {   // pairs kept by one side only: counted as dropped (stats), contribute nothing
+            const unsigned long long dead = __ballot(valid && !sym);
+            if (dead && lane == 0) atomicAdd(&P.stats[b * PEN_STATS + 15], __popcll(dead));
+        }
+        if (sym)
         {   // (1) this triangle receives the partner's vertices: own geometry as duals over the 9 own coordinates
             DVec<9> P0 = {dvar<9>(p[0], 0), dvar<9>(p[1], 1), dvar<9>(p[2], 2)};
             DVec<9> P1 = {dvar<9>(p[3], 3), dvar<9>(p[4], 4), dvar<9>(p[5], 5)};
@@ -668,7 +700,7 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
                 for (int j = 0; j < 9; ++j) g9[j] += pen.d[j];
             }
         }
-        if (valid)
+        if (sym)
         {   // (2) this triangle's vertices intrude into the partner's cone (partner geometry constant)
             DVec<3> Q0 = {dconst<3>(qv[0]), dconst<3>(qv[1]), dconst<3>(qv[2])};
             DVec<3> Q1 = {dconst<3>(qv[3]), dconst<3>(qv[4]), dconst<3>(qv[5])};
@@ -793,6 +825,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     sfx_pen* h = new sfx_pen();
     PenDev& P = h->P;
     P.V = V; P.F = F; P.cap = max_collisions; h->Bmax = max_batch;
+    P.pcap = std::max(P.cap, std::min(2 * P.cap, 2048));
     std::vector<int> fv(faces, faces + (size_t)F * 3), sg(F, 0);
     int np = 1;
     if (segm) { for (int f = 0; f < F; ++f) { sg[f] = segm[f]; np = std::max(np, segm[f] + 1); } }
@@ -822,7 +855,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     const size_t B = max_batch;
     P.ent_cap = F * 32;
     P.aabb = h->zeros<float>(B * F * 6); P.entries = h->zeros<int>(B * P.ent_cap); P.ent_cell = h->zeros<int>(B * P.ent_cap);
-    P.partners = h->zeros<int>(B * F * P.cap); P.pcount = h->zeros<int>(B * F);
+    P.partners = h->zeros<int>(B * F * P.pcap); P.pcount = h->zeros<int>(B * F); P.pavail = h->zeros<int>(B * F);
     P.pair_cap = (int)std::min<size_t>((size_t)F * P.cap, std::max<size_t>(65536, (size_t)16 * F));
     P.poff = h->zeros<int>(B * F); P.pown = h->zeros<int>(B * P.pair_cap); P.plist = h->zeros<int>(B * P.pair_cap);
     P.pout = h->zeros<float>(B * 10 * P.pair_cap); P.ptotal = h->zeros<int>(B); P.stats = h->zeros<int>(B * PEN_STATS);
@@ -857,7 +890,7 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
     hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, h->P, want_dev);
     hipLaunchKernelGGL(k_pen_list, dim3(B), dim3(PEN_T), 0, s, h->P, want_dev);
     int cap_pad = 64;
-    while (cap_pad < h->P.cap) cap_pad <<= 1;
+    while (cap_pad < h->P.pcap) cap_pad <<= 1;
     hipLaunchKernelGGL(k_pen_rank, dim3(PEN_RANK_BLOCKS, B), dim3(256), (size_t)4 * std::min(std::max(cap_pad, 64), 2048) * sizeof(int), s,
                        h->P, want_dev, cap_pad);
     hipLaunchKernelGGL(k_pen_eval, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside);
@@ -893,6 +926,12 @@ extern "C" int sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host /* [B][4
     if (hipDeviceSynchronize() != hipSuccess) { sfx_set_error("device error"); return -4; }
     std::vector<int> st((size_t)B * PEN_STATS);
     hipMemcpy(st.data(), h->P.stats, st.size() * sizeof(int), hipMemcpyDeviceToHost);
-    for (int i = 0; i < B; ++i) for (int k = 0; k < 4; ++k) stats_host[i * 4 + k] = st[(size_t)i * PEN_STATS + k];
+    for (int i = 0; i < B; ++i) {
+        const int* r = &st[(size_t)i * PEN_STATS];
+        // r[15]: ordered pairs in the list that only one of the two triangles kept (max_collisions cut the other's list):
+        // they contribute nothing and count as dropped
+        stats_host[i * 4 + 0] = r[0] - r[15]; stats_host[i * 4 + 1] = r[1] + r[15];
+        stats_host[i * 4 + 2] = r[2]; stats_host[i * 4 + 3] = r[3];
+    }
     return 0;
 }

@@ -11,6 +11,8 @@ every closure call as the reference does; the default 'rows' evaluates the rows 
 import os
 import pickle
 
+import warnings
+
 import numpy as np
 import torch
 
@@ -52,8 +54,8 @@ def fit_single_frame(img, keypoints, body_model, camera, joint_weights, body_pos
                      result_folder=".", img_name="", pixie_results=None, expose_results=None, pare_results=None,
                      regression_prior=None, format="coco25", smplx_path="", curr_img_folder=".", **kwargs):
     assert batch_size == 1, "fit_single_frame handles one frame; use driver.fit_frames for batches"
-    if visualize:
-        raise NotImplementedError("visualize=True is outside the fitting path")
+    if visualize:      # (every shipped cfg sets it) rendering is outside the fitting path: the fit runs, nothing is drawn
+        warnings.warn("visualize=True: no images are rendered by this engine; the fit itself is unaffected")
     if interpenetration and point2plane:
         raise NotImplementedError("point2plane=True: only the cone distance field of the shipped cfgs is built")
     if not use_cuda:

@@ -293,8 +293,9 @@ class FittingMonitor(object):
         self.maxiters, self.ftol, self.gtol = maxiters, ftol, gtol
         self.visualize, self.summary_steps = visualize, summary_steps
         self.body_color, self.model_type = body_color, model_type
-        if visualize:
-            raise NotImplementedError("visualize=True: the mesh viewer is outside the fitting path")
+        if visualize:       # fitting.py:126-138: the mesh viewer; outside the fitting path, so nothing is drawn
+            import warnings
+            warnings.warn("FittingMonitor(visualize=True): no mesh viewer in this engine; the fit itself is unaffected")
 
     def __enter__(self):
         self.steps = 0

@@ -16,6 +16,7 @@ dist.shard_range gives it; there is no collective in the data path (each rank wr
 result files).
 """
 import os
+import warnings
 import os.path as osp
 import pickle
 import shutil
@@ -93,8 +94,18 @@ def main(**args):
     interpenetration = bool(args.get("interpenetration", True))
     if interpenetration and args.get("point2plane", False):
         raise NotImplementedError("point2plane=True: only the cone distance field of the shipped cfgs is built")
+    # flags every shipped cfg sets that lie outside the fitting path: they must not stop a run of the unmodified cfg
     if args.get("use_gender_classifier", False):
-        raise NotImplementedError("use_gender_classifier: the homogenus classifier is outside the fitting path")
+        # main.py:197-200,258-262: the external homogenus network picks the model's gender per image; without it the
+        # cfg's `gender` is used, which is also what the reference does when the flag is off
+        warnings.warn("use_gender_classifier: the homogenus classifier is not part of this engine; using cfg gender %r"
+                      % args.get("gender", "neutral"))
+    if args.get("visualize", False) or args.get("interactive", False):
+        warnings.warn("visualize / interactive: rendering and progress output are outside the fitting path; the fit itself "
+                      "is unaffected")
+    args["visualize"] = False
+    if not args.get("use_joints_conf", False):
+        raise NameError("name 'joints_conf' is not defined")   # the reference fails here (fit_single_frame.py:286)
 
     img_folder = args.pop("img_folder", "images")
     dataset_obj = create_dataset(img_folder=img_folder, **args)
