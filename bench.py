@@ -43,8 +43,8 @@ PEAK_HBM = 8.0e12
 def build_cfg(workload="body"):
     """body: BASELINE configs[1] (body-only keypoints, use_vposer=False + synthetic regression prior).
     full: BASELINE configs[2] (hands + face + contour, K=135, VPoser decode in the loop, z0 = 0);
-    pen: BASELINE configs[4] (cfg_files/fit_smplx_combined_halpe.yaml: regression prior + interpenetration
-    term, body-only keypoints, surface-like synthetic mesh with synthetic part labels) --
+    pen: BASELINE configs[4] (cfg_files/fit_smplx_combined_halpe.yaml VERBATIM: hands + face, K = 136, combined regression
+    prior, camera prior, interpenetration term; surface-like synthetic mesh with synthetic part labels) --
     side measurements (`--workload full|pen`), never the headline."""
     from smplifyx_amd import cmd_parser
     over = dict(interpenetration=False, visualize=False, interactive=False, save_vertices=False,
@@ -52,9 +52,11 @@ def build_cfg(workload="body"):
     if workload == "body":
         over.update(use_hands=False, use_face=False, use_vposer=False)
     if workload == "pen":
-        over.update(use_hands=False, use_face=False, interpenetration=True)
-        cfg = cmd_parser.load_config(os.path.join(ROOT, "cfg_files", "fit_smplx_combined_halpe.yaml"), over)
-        cfg["use_camera_prior"] = False
+        # the cfg verbatim: hands + face + contour (halpe K = 136), regression prior 'combined', camera prior,
+        # use_conf_for_camera_init, interpenetration (max_collisions 128, df_cone_height 1e-4, coll_loss_weights [0, 0.1, 1])
+        cfg = cmd_parser.load_config(os.path.join(ROOT, "cfg_files", "fit_smplx_combined_halpe.yaml"),
+                                     dict(visualize=False, interactive=False, save_vertices=False, use_gender_classifier=False))
+        assert cfg["interpenetration"] and cfg["use_hands"] and cfg["use_face"] and cfg["use_camera_prior"]
         return cfg
     cfg = cmd_parser.load_config(os.path.join(ROOT, "cfg_files", "fit_smplx_smplifyx.yaml"), over)
     cfg["use_camera_prior"] = False
@@ -407,10 +409,17 @@ def main():
     n_total = world * B
     gather_ms = [0.0]
 
+    cam_t_prior = cam_c_prior = None
+    if pen:     # synthetic "ExPose" camera (fit_single_frame.py:359-401): the true translation + 5 cm noise, image centre
+        rngc = np.random.RandomState(1000 + rank)
+        cam_t_prior = (frames["cam_t"] + 0.05 * rngc.normal(size=frames["cam_t"].shape)).astype(np.float32)
+        cam_c_prior = np.tile(np.array([frames["W"] * 0.5, frames["H"] * 0.5], np.float32), (B, 1))
+
     def one_fit(lbs_mode=None):
         res = driver.fit_frames(dm, cfg, frames["keypoints"], jw, frames["H"], frames["W"], frames["focal"],
                                 reg_pose=None if full else frames["reg_pose"],
                                 reg_global=None if full else frames["reg_global"],
+                                cam_prior_t=cam_t_prior, cam_prior_center=cam_c_prior,
                                 lbs_mode=lbs_mode or args.lbs, reuse_entry_eval=True, groups=args.groups,
                                 slots=args.slots if (lbs_mode or args.lbs) == "dense" else 0)
         tg = time.time()
@@ -490,9 +499,10 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("configs[4]: %d synthetic frames/GPU, neutral SMPL-X-shaped synthetic model (surface-like mesh, "
-                                    "synthetic part labels), body-only halpe keypoints K=26, synthetic regression prior, "
-                                    "interpenetration term (max_collisions 128, df_cone_height 1e-4), camera stage + 3-stage "
-                                    "L-BFGS (fit_smplx_combined_halpe.yaml)" % B) if pen else
+                                    "synthetic part labels), cfg_files/fit_smplx_combined_halpe.yaml verbatim: hands + face + contour "
+                                    "halpe keypoints K=136, synthetic combined regression prior + camera prior, interpenetration "
+                                    "term (max_collisions 128, df_cone_height 1e-4, coll_loss_weights [0, 0.1, 1]), camera stage + "
+                                    "3-stage L-BFGS" % B) if pen else
                                    ("configs[2]: %d synthetic frames/GPU, neutral SMPL-X-shaped synthetic model, hands + face + "
                                     "contour K=135, synthetic VPoser decoded in the loop (latent 32, z0 = 0), camera stage + "
                                     "5-stage L-BFGS (fit_smplx_smplifyx.yaml)" % B) if full else

@@ -87,20 +87,21 @@ extern "C" int sfx_prof_get(const char* name, double* total_ms, int64_t* launche
 // ---------------------------------------------------------------------------------------
 struct DevAlloc {
     std::vector<void*> ptrs;
+    bool failed = false;        // sticky: any hipMalloc / hipMemcpy / hipMemset of this owner failed (checked once by the creator)
     template <typename T> T* up(const std::vector<T>& h) {
         T* d = nullptr;
         size_t n = std::max<size_t>(h.size(), 1) * sizeof(T);
-        if (hipMalloc((void**)&d, n) != hipSuccess) return nullptr;
-        if (!h.empty()) hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+        if (hipMalloc((void**)&d, n) != hipSuccess) { failed = true; return nullptr; }
         ptrs.push_back(d);
+        if (!h.empty() && hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) failed = true;
         return d;
     }
     template <typename T> T* zeros(size_t count) {
         T* d = nullptr;
         size_t n = std::max<size_t>(count, 1) * sizeof(T);
-        if (hipMalloc((void**)&d, n) != hipSuccess) return nullptr;
-        hipMemset(d, 0, n);
+        if (hipMalloc((void**)&d, n) != hipSuccess) { failed = true; return nullptr; }
         ptrs.push_back(d);
+        if (hipMemset(d, 0, n) != hipSuccess) failed = true;
         return d;
     }
     void free_all() { for (void* p : ptrs) hipFree(p); ptrs.clear(); }
@@ -412,7 +413,8 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
     }
     if (m->meta_host.size() != SFX_META_N) { sfx_set_error("internal: meta table"); delete m; return -1; }
     M.meta = m->mem.up(m->meta_host);
-    if (hipDeviceSynchronize() != hipSuccess) { sfx_set_error("model upload failed"); delete m; return -2; }
+    if (m->mem.failed) { (void)hipGetLastError(); sfx_set_error("out of device memory (model constants)"); m->mem.free_all(); delete m; return -2; }
+    if (hipDeviceSynchronize() != hipSuccess) { sfx_set_error("model upload failed"); m->mem.free_all(); delete m; return -2; }
     *out = m;
     return 0;
 }
@@ -452,6 +454,7 @@ extern "C" int sfx_model_set_vposer(sfx_model* m, int32_t latent, int32_t hidden
     m->M.vp_w2 = m->mem.up(v(w2, (size_t)H * H)); m->M.vp_b2 = m->mem.up(v(b2, H));
     m->M.vp_w3 = m->mem.up(v(w3, (size_t)126 * H)); m->M.vp_b3 = m->mem.up(v(b3, 126));
     m->M.vp_w1T = m->mem.up(w1T); m->M.vp_w2T = m->mem.up(w2T); m->M.vp_w3T = m->mem.up(w3T);
+    if (m->mem.failed) { (void)hipGetLastError(); m->M.vp_latent = 0; sfx_set_error("out of device memory (VPoser weights)"); return -2; }
     if (m->fwd) { sfx_batch_destroy(m->fwd); m->fwd = nullptr; }
     return 0;
 }
@@ -470,7 +473,7 @@ static void build_layout(ParLayout& L, int NB, int NE, int NPCA, int use_vposer,
 static void add_group(VarList& v, int off, int len, int has) {
     const int g = v.ngroups++;
     v.g_off[g] = (short)v.n; v.g_len[g] = (short)len; v.g_has[g] = (short)has;
-    for (int i = 0; i < len; ++i) v.idx[v.n++] = (short)(off + i);
+    for (int i = 0; i < len; ++i, ++v.n) if (v.n < SFX_NVAR_MAX) v.idx[v.n] = (short)(off + i);     // (n > NVAR_MAX: rejected by the caller)
 }
 
 extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_stage_weights* st, sfx_batch** out) {
@@ -505,6 +508,12 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     add_group(body, L.lh, L.NPCA, 1); add_group(body, L.rh, L.NPCA, 1);
     add_group(body, L.jaw, 3, 1); add_group(body, L.leye, 3, 1); add_group(body, L.reye, 3, 1);
     add_group(body, L.expr, L.NE, 1); add_group(body, L.emb, L.NEMB, 1);
+    if (body.n > SFX_NVAR_MAX) {
+        // e.g. all 45 hand components: more optimisation variables than the optimiser's vectors hold.  Such a batch can
+        // still evaluate the forward (sfx_lbs_forward / sfx_batch_forward); n_stages = 0 declares that intent
+        if (c->n_stages > 0) { sfx_set_error("%d optimisation variables (limit %d): reduce num_pca_comps", body.n, SFX_NVAR_MAX); delete b; return -1; }
+        body.n = SFX_NVAR_MAX;
+    }
     b->vl_host[0] = cam; b->vl_host[1] = body;
     std::vector<VarList> vls = {cam, body};
     b->vl_dev = b->mem.up(vls);
@@ -576,9 +585,15 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.stage_loss2 = b->mem.zeros<float>((size_t)B * (1 + SFX_MAX_STAGES));
     D.try_both = b->mem.zeros<int>(B);
     D.orient_pass = b->mem.zeros<int>(B);
-    if (!D.hist || !D.verts) { sfx_set_error("out of device memory"); b->mem.free_all(); delete b; return -2; }
+    if (b->mem.failed || !D.hist || !D.verts) {
+        (void)hipGetLastError();
+        sfx_set_error("out of device memory (batch of %d frames)", B);
+        if (b->pen) sfx_pen_destroy(b->pen);
+        b->mem.free_all(); delete b; return -2; }
     if (hipHostMalloc((void**)&b->stage_host, (size_t)2 * B * sizeof(int)) != hipSuccess) b->stage_host = nullptr;      // two poll buffers
     if (hipHostMalloc((void**)&b->map_host, (size_t)6 * B * sizeof(int)) != hipSuccess) b->map_host = nullptr;
+    if (c->lbs_mode == 1 && (!b->stage_host || !b->map_host)) {       // the fused dense loop polls through pinned memory
+        sfx_set_error("out of pinned host memory"); sfx_batch_destroy(b); return -2; }
     if (hipEventCreateWithFlags(&b->poll_ev[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&b->poll_ev[1], hipEventDisableTiming) != hipSuccess) { sfx_set_error("event creation failed"); b->mem.free_all(); delete b; return -2; }
     *out = b;
@@ -1260,7 +1275,7 @@ extern "C" int sfx_lbs_forward(sfx_model* m, int32_t B, const float* go, const f
     hipStream_t s = (hipStream_t)stream;
     if (!m->fwd || m->fwd_B != B) {
         if (m->fwd) sfx_batch_destroy(m->fwd);
-        sfx_batch_cfg c{}; c.B = B; c.n_stages = 1; c.maxiters = 1; c.num_body_joints = m->M.K; c.lbs_mode = 1;
+        sfx_batch_cfg c{}; c.B = B; c.n_stages = 0; c.maxiters = 1; c.num_body_joints = m->M.K; c.lbs_mode = 1;   // forward only
         sfx_stage_weights w{};
         int rc = sfx_batch_create(m, &c, &w, &m->fwd);
         if (rc) return rc;

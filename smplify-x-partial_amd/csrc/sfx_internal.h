@@ -21,7 +21,7 @@
 #define SFX_HIST 100        // L-BFGS history (optim_factory 'lbfgsls' default)
 #define SFX_NVAR_MAX 192    // optimiser vector length (182 / 88 / 6), padded to 3*64
 #define SFX_FWD_N 6016      // floats per frame of saved forward state (FrameLDS prefix incl. the fp64 transforms + 96 + VPoser 1280)
-#define SFX_NPAR_MAX 192    // canonical per-frame parameter block
+#define SFX_NPAR_MAX 256    // canonical per-frame parameter block (182 with 12 hand components; 248 with all 45: forward only)
 #define SFX_MAX_STAGES 8
 #define SFX_MAX_GROUPS 12
 #define SFX_NW 8             // nonzero skinning weights kept per vertex (needed-rows path)

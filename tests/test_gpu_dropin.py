@@ -338,3 +338,68 @@ def test_other_optimizers_are_driven_from_the_host(synth_model, optim_type, lr, 
     with pytest.raises(NotImplementedError):
         driver.fit_frames(bm.device_model, cfg, g["keypoints"][:1], H.base_joint_weights(cfg, 25), 600, 800, 5000.0,
                           reg_pose=g["reg_pose"][:1], reg_global=g["reg_global"][:1])
+
+
+@pytest.mark.parametrize("yaml_", ["fit_smplx_combined_coco25.yaml", "fit_smplx_combined_halpe.yaml",
+                                   "fit_smplx_combined_vposer_coco25.yaml", "fit_smplx_smplifyx.yaml"])
+def test_main_runs_every_shipped_cfg_unmodified(tmp_path, yaml_):
+    """`main(**parse_config(['-c', cfg]))` with each cfg_files/*.yaml AS SHIPPED -- hands + face + contour keypoints,
+    interpenetration, regression / camera priors, VPoser, and the flags the reference's cfgs carry for things outside the
+    fitting path (visualize, interactive, use_gender_classifier: warnings, not errors).  Only locations are overridden
+    (data / model / output folders, regression result directories, part segmentation and VPoser files)."""
+    import json
+    import warnings
+    import joblib
+    from PIL import Image
+    from scipy.spatial.transform import Rotation as Rot
+    from smplifyx_amd import cmd_parser, main as amd_main, synthetic
+    model = synthetic.make_synthetic_model(0, surface=True)
+    parts = synthetic.make_synthetic_parts(model)
+    raw = cmd_parser.load_config(os.path.join(H.CFG_DIR, yaml_), {})
+    assert raw["visualize"] and raw["use_gender_classifier"] and raw["interpenetration"] and raw["use_hands"] and raw["use_face"]
+    K = len(H.joint_map_for(raw))
+    nb = {"coco25": 25, "halpe": 26}[raw["format"]]
+    assert K == nb + 42 + 51 + 17
+    frames = synthetic.make_frames(2, H.oracle_joints_fn(model, raw), K, focal=5000.0)
+    data, models, out = tmp_path / "data", tmp_path / "models" / "smplx", tmp_path / "out"
+    expose_dir, pixie_dir = tmp_path / "expose", tmp_path / "pixie"
+    for d in (data / "images", data / "keypoints", models, expose_dir, pixie_dir):
+        os.makedirs(d)
+    np.savez(models / "SMPLX_NEUTRAL.npz", **model)
+    with open(tmp_path / "parts.pkl", "wb") as fh:
+        pickle.dump({"segm": parts["segm"], "parents": parts["parents"]}, fh, protocol=2)
+    np.savez(tmp_path / "vposer.npz", **synthetic.make_synthetic_vposer(0, encoder_inputs=63))
+    names = ["frame_a", "frame_b"]
+    rot = lambda a: Rot.from_euler("XYZ", np.asarray(a, np.float64).reshape(-1, 3)).as_matrix().astype(np.float32)
+    for i, n in enumerate(names):
+        Image.fromarray(np.zeros((600, 800, 3), np.uint8)).save(data / "images" / (n + ".png"))
+        kp = frames["keypoints"][i]
+        face = np.concatenate([kp[nb + 42 + 51:], kp[nb + 42:nb + 42 + 51]])         # json order: 17 contour, then 51 inner
+        flat = lambda a: [float(v) for v in np.asarray(a).reshape(-1)]
+        json.dump({"people": [{"pose_keypoints_2d": flat(kp[:nb]), "hand_left_keypoints_2d": flat(kp[nb:nb + 21]),
+                               "hand_right_keypoints_2d": flat(kp[nb + 21:nb + 42]), "face_keypoints_2d": flat(face)}]},
+                  open(data / "keypoints" / (n + "_keypoints.json"), "w"))
+        os.makedirs(expose_dir / (n + ".jpg")); os.makedirs(pixie_dir / n)
+        np.savez(expose_dir / (n + ".jpg") / (n + ".jpg_params.npz"), body_pose=rot(frames["reg_pose"][i]),
+                 global_orient=rot(frames["reg_global"][i]), transl=frames["cam_t"][i].astype(np.float64),
+                 center=np.array([400.0, 300.0], np.float32))
+        joblib.dump({"body_pose": rot(frames["reg_pose"][i]), "global_pose": rot(frames["reg_global"][i])},
+                    pixie_dir / n / (n + "_param.pkl"))
+    cfg = cmd_parser.parse_config(["-c", os.path.join(H.CFG_DIR, yaml_), "--data_folder", str(data), "--model_folder",
+                                   str(tmp_path / "models"), "--output_folder", str(out), "--part_segm_fn", str(tmp_path / "parts.pkl"),
+                                   "--vposer_ckpt", str(tmp_path / "vposer.npz"), "--expose_results_directory", str(expose_dir),
+                                   "--pixie_results_directory", str(pixie_dir), "--focal_length", "5000"])
+    for k in ("visualize", "interactive", "use_gender_classifier", "interpenetration", "use_hands", "use_face", "maxiters",
+              "df_cone_height", "max_collisions", "use_vposer", "regression_prior", "use_camera_prior"):
+        assert cfg[k] == raw[k], k
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        n = amd_main.main(**cfg)
+    assert n == 2
+    msgs = " ".join(str(w.message) for w in wlist)
+    assert "use_gender_classifier" in msgs and "visualize" in msgs
+    for nme in names:
+        res = pickle.load(open(out / "results" / nme / "000.pkl", "rb"))
+        assert res["left_hand_pose"].shape == (1, 12) and res["expression"].shape == (1, 10) and res["body_pose"].shape == (1, 63)
+        assert all(np.all(np.isfinite(np.asarray(v, np.float64))) for v in res.values())
+        assert os.path.getsize(out / "results" / nme / "vertices.ply") > 10475 * 12
