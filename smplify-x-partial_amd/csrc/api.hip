@@ -375,7 +375,7 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
             for (int i = 0; i < (int)ivid.size(); ++i) { if (idyn[i] < 0) { svid.push_back(ivid[i]); sitem.push_back(i); } else dynitems.push_back(i); }
             std::vector<int> ss, si; std::vector<float> sw2;
             build(svid, sitem, ss, si, sw2, 0);
-            M.sj_start = m->mem.up(ss); M.sj_item = m->mem.up(si); M.sj_w = m->mem.up(sw2);
+            M.sj_start = m->mem.up(ss); M.sj_item = m->mem.up(si); M.sj_w = m->mem.up(sw2); M.n_sj = (int)si.size();
             std::vector<int> ds, di; std::vector<float> dw;
             M.n_dyn_items = (int)dynitems.size();
             for (int row = 0; row < d->n_dyn_rows && !dynitems.empty(); ++row) {

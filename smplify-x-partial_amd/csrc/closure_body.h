@@ -79,6 +79,9 @@ struct __align__(16) FrameLDSx {
     float iw[MAXI];
     int   wj[MAXI * SFX_NW];       // sparse skinning weights of the items
     float ww[MAXI * SFX_NW];
+    int   sjs[SFX_J + 1];          // per-joint lists of the static items (adjoint of the skinning: dA), copied from the
+    int   sji[MAXI * SFX_NW];      //   model's CSR when it fits (M.n_sj <= MAXI * SFX_NW): two dependent global round trips
+    float sjw[MAXI * SFX_NW];      //   per evaluation otherwise
     float joints[SFX_MAX_K * 3];
     float dj[SFX_MAX_K * 3];
     float dA[SFX_J * 12];
@@ -222,7 +225,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     // the VPoser activations) in D.fwd; reload it instead of recomputing pose assembly,
     // Rodrigues, joint regression and the kinematic chain
     constexpr bool HAS_VP = !std::is_same<decltype(S.V), EmptyLDS>::value;
-    constexpr int RIF = (LDS::kMaxItems <= SFX_SMALL_ITEMS) ? 4 : SFX_RIF_BIG;
+    constexpr int RIF = (LDS::kMaxItems <= SFX_SMALL_ITEMS) ? SFX_RIF_SMALL : SFX_RIF_BIG;
     constexpr int FWD_PREFIX = (int)(offsetof(LDS, vp) / sizeof(float));
     static_assert(FWD_PREFIX % 4 == 0 && FWD_PREFIX + 96 + 2 * VP_H + 128 + 64 <= SFX_FWD_N, "forward-state blob layout");
     static_assert(offsetof(LDS, Ad) % 8 == 0 && offsetof(LDS, cd) % 8 == 0, "fp64 members");
@@ -240,6 +243,23 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         if (t < 8) S.fd[FD_CAM + t] = D.cam[(size_t)b * 8 + t];
         if (t >= 64 && t < 73) S.fd[FD_CAMR + t - 64] = D.camR[(size_t)b * 9 + t - 64];
         if (t >= 128 && t < 128 + 63) S.fd[FD_REG + t - 128] = D.regpose[(size_t)b * 63 + t - 128];
+    }
+    // static items (vertex joints, static landmarks): vertex ids, weights, template rows, skinning weights, per-joint
+    // adjoint lists -- none of it depends on the pose, so it is fetched here, next to the other tables (one overlapped
+    // round trip at kernel entry; a persistent workgroup keeps it for the whole fit), not item by item inside the evaluation
+    for (int i = t; i < M.n_static_items; i += CT) {
+        const int vid = M.item_vid[i];
+        S.ivid[i] = vid; S.iw[i] = M.item_w[i];
+        S.vt[i * 3] = M.v_template[vid * 3]; S.vt[i * 3 + 1] = M.v_template[vid * 3 + 1]; S.vt[i * 3 + 2] = M.v_template[vid * 3 + 2];
+    }
+    for (int w = t; w < M.n_static_items * SFX_NW; w += CT) {
+        const int vid = M.item_vid[w / SFX_NW], q2 = w % SFX_NW;
+        S.wj[w] = M.Wsp_j[(size_t)vid * SFX_NW + q2];
+        S.ww[w] = M.Wsp_w[(size_t)vid * SFX_NW + q2];
+    }
+    if (M.n_sj <= LDS::kMaxItems * SFX_NW) {
+        for (int i = t; i <= SFX_J; i += CT) S.sjs[i] = M.sj_start[i];
+        for (int i = t; i < M.n_sj; i += CT) { S.sji[i] = M.sj_item[i]; S.sjw[i] = M.sj_w[i]; }
     }
     }
     for (int i = t; i < SFX_KD_PAD; i += CT) { if (!reuse) S.feat[i] = 0.f; S.dfeat[i] = 0.f; }
@@ -429,20 +449,16 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     MARK(5);
     // ------------------------------------------------------------------ needed vertices
     const int NI = M.n_items;
-    for (int i = t; i < NI; i += CT) {
+    for (int i = M.n_static_items + t; i < NI; i += CT) {       // dynamic contour items: their vertices follow the head pose
         const int dd = M.item_dyn[i];
-        int vid;
-        if (dd < 0) { vid = M.item_vid[i]; S.iw[i] = M.item_w[i]; }
-        else {
-            const int l = dd / 3, c = dd % 3;
-            const int face = M.dyn_faces[S.lut_row * M.n_dyn + l];
-            vid = M.faces[face * 3 + c];
-            S.iw[i] = M.dyn_bary[(S.lut_row * M.n_dyn + l) * 3 + c];
-        }
+        const int l = dd / 3, c = dd % 3;
+        const int face = M.dyn_faces[S.lut_row * M.n_dyn + l];
+        const int vid = M.faces[face * 3 + c];
+        S.iw[i] = M.dyn_bary[(S.lut_row * M.n_dyn + l) * 3 + c];
         S.ivid[i] = vid;
         S.vt[i * 3] = M.v_template[vid * 3]; S.vt[i * 3 + 1] = M.v_template[vid * 3 + 1]; S.vt[i * 3 + 2] = M.v_template[vid * 3 + 2];
     }
-    __syncthreads();
+    if (NI > M.n_static_items) __syncthreads();
     // v_posed rows and skinning transforms of `ni` vertices listed in S.ivid (the model's items, or a
     // chunk of vertices that carry a penetration gradient)
     auto items_forward = [&](const int ib, const int ni) {       // items ib .. ib + ni - 1
@@ -484,7 +500,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     // (sparse rows of lbs_weights: <= SFX_NW nonzeros per vertex, ascending joint order, so the
     //  sum visits the same nonzero terms in the same order as the dense product)
     auto items_transforms = [&](const int ib, const int ni) {
-    for (int w = t + ib * SFX_NW; w < (ib + ni) * SFX_NW; w += CT) {
+    for (int w = t + M.n_static_items * SFX_NW; w < (ib + ni) * SFX_NW; w += CT) {       // (static items: loaded with the tables)
         const int i = w / SFX_NW, q2 = w % SFX_NW;
         S.wj[w] = M.Wsp_j[(size_t)S.ivid[i] * SFX_NW + q2];
         S.ww[w] = M.Wsp_w[(size_t)S.ivid[i] * SFX_NW + q2];
@@ -749,10 +765,11 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     for (int w = t; w < SFX_J * 12; w += CT) {
         const int j = w / 12, e = w % 12, r = e >> 2, c = e & 3;
         float acc = 0.f;
+        const bool sj_lds = M.n_sj <= LDS::kMaxItems * SFX_NW;
         for (int pass = 0; pass < 2; ++pass) {
-            const int* st = pass ? (M.dj_start + (size_t)S.lut_row * (SFX_J + 1)) : M.sj_start;
-            const int* it = pass ? M.dj_item : M.sj_item;
-            const float* wt = pass ? M.dj_w : M.sj_w;
+            const int* st = pass ? (M.dj_start + (size_t)S.lut_row * (SFX_J + 1)) : (sj_lds ? S.sjs : M.sj_start);
+            const int* it = pass ? M.dj_item : (sj_lds ? S.sji : M.sj_item);
+            const float* wt = pass ? M.dj_w : (sj_lds ? S.sjw : M.sj_w);
             if (pass && M.n_dyn_items == 0) break;
             for (int q2 = st[j]; q2 < st[j + 1]; ++q2) {
                 const int i = it[q2];

@@ -12,6 +12,9 @@
 #ifndef SFX_RIF_BIG
 #define SFX_RIF_BIG 8        // 2-KiB blend-shape rows in flight per wavefront in the full-model closure (1 workgroup per CU:
 #endif                       // the loads of 4 wavefronts are all the memory parallelism a frame gets)
+#ifndef SFX_RIF_SMALL
+#define SFX_RIF_SMALL 9      // ... in the body-only closure: 33 rows over 4 wavefronts in ONE pass (every pass is a ~1-us round trip to L2 / MALL: 4 -> 9 rows in flight made the needed-rows fit 14 % faster)
+#endif
 #ifndef SFX_SMALL_OCC
 #define SFX_SMALL_OCC 1      // workgroups per CU the register budget of the persistent small kernel is sized for
 #endif
@@ -114,6 +117,7 @@ struct DevModel {
     const int *sj_start, *sj_item; const float* sj_w;      // [J+1], [..]
     const int *dj_start, *dj_item; const float* dj_w;      // [rows][J+1] (absolute offsets), [..]
     int n_dyn_items;
+    int n_sj;                  // entries of sj_item / sj_w
     const int*   meta;         // [SFX_META_N] packed copy of the tables above
     // VPoser decoder
     int vp_latent, vp_hidden;
