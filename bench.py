@@ -300,8 +300,11 @@ def loss_distribution(fl):
 def paired_stats(a, b, name_a, name_b):
     """Per-frame paired comparison of two runs over the SAME frames."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    ok = np.isfinite(a) & np.isfinite(b)          # (a stage that ends inside its first step returns None in the reference, NaN here)
+    n_bad = int((~ok).sum())
+    a, b = a[ok], b[ok]
     d = (a - b) / np.maximum(np.abs(b), 1e-30)
-    out = {"frames": int(a.size), "signed_rel_delta_mean": float(d.mean()), "signed_rel_delta_median": float(np.median(d)),
+    out = {"frames": int(a.size), "frames_without_a_finite_pair": n_bad, "signed_rel_delta_mean": float(d.mean()), "signed_rel_delta_median": float(np.median(d)),
            "abs_rel_delta_median": float(np.median(np.abs(d))), "frames_%s_lower" % name_a: int((a < b).sum()),
            "frames_%s_lower" % name_b: int((b < a).sum()), "frames_beyond_10_percent": int((np.abs(d) > 0.1).sum())}
     try:

@@ -215,6 +215,7 @@ int  sfx_batch_get_stats(sfx_batch* b, float* stage_loss, int32_t* stage_evals,
  *   (0, t, loss, ls_evals)                 a line search ended: accepted step length, loss there, its evaluations
  *   (1, entry loss, func_evals, n_iter)    one LBFGS.step returned (cumulative evaluations / iterations of the stage)
  *   (2, result, closure evaluations, stage) run_fitting returned for a stage (camera stage = -1)
+ *   (3, trial step, loss, |gradient|inf)   (only with a NEGATIVE capacity, |capacity| records) every closure evaluation
  * sfx_batch_get_trace: records [B][capacity][4] and the number written per frame (HOST; counts may exceed capacity). */
 int  sfx_batch_trace(sfx_batch* b, int32_t capacity);
 int  sfx_batch_get_trace(sfx_batch* b, float* records, int32_t* counts);
@@ -265,6 +266,10 @@ void sfx_prof_reset(void);
 
 /* Debug: shader-clock stamps at the phase boundaries of one closure launch (block 0). */
 int  sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out /* [32] */);
+
+/* Experiment (timing only): `rounds` rounds of the dense loop; mode 0 serial (GEMM -> tick), mode 1 GEMM and tick of a
+ * round launched together on two streams.  out_ms = elapsed time.  The batch's results are meaningless afterwards.     */
+int  sfx_debug_overlap_test(sfx_batch* b, int32_t rounds, int32_t mode, double* out_ms);
 
 /* Debug: attach (enable>=1) a 64-slot clock buffer to the batch, run any entry point, then read it
  * and detach (enable=0): out[0..18] = closure phase stamps of the last launch, out[32+i] =

@@ -744,6 +744,43 @@ extern "C" int sfx_batch_debug_read(sfx_batch* b, const char* name, float* out, 
 
 // debug: attach (enable=1) / read out and detach (enable=0) the 64-slot clock buffer; while attached,
 // closure launches stamp dbg[0..18] and optimiser ticks of frame 0 accumulate dbg[32..63]
+// Experiment (timing only, results are not meaningful): `rounds` rounds of the dense fit loop with the GEMM on a second
+// stream.  mode 0: serial as in sfx_batch_fit (GEMM -> tick); mode 1: GEMM(i) and tick(i) launched together (what a loop
+// whose loss pass does not wait for the GEMM would cost); out_ms = elapsed wall time of the rounds.
+extern "C" int sfx_debug_overlap_test(sfx_batch* b, int32_t rounds, int32_t mode, double* out_ms) {
+    if (!b || b->D.cfg.lbs_mode != 1) { sfx_set_error("dense batch needed"); return -1; }
+    BatchDev& D = b->D; const DevModel& M = b->m->M;
+    hipStream_t sT, sG; hipEvent_t eT, eG, t0, t1;
+    SFX_CHECK(hipStreamCreateWithFlags(&sT, hipStreamNonBlocking)); SFX_CHECK(hipStreamCreateWithFlags(&sG, hipStreamNonBlocking));
+    SFX_CHECK(hipEventCreateWithFlags(&eT, hipEventDisableTiming)); SFX_CHECK(hipEventCreateWithFlags(&eG, hipEventDisableTiming));
+    SFX_CHECK(hipEventCreate(&t0)); SFX_CHECK(hipEventCreate(&t1));
+    const int ns = D.cfg.n_stages - 1;
+    launch_lbfgs_tick(M, D, b->vl_dev, 0, ns, 1, 0, sT);
+    launch_tick_dense(M, D, b->vl_dev, b->sw_dev, 0, ns, 0, sT);
+    launch_lbs_dense(M, D, sT);
+    SFX_CHECK(hipStreamSynchronize(sT));
+    SFX_CHECK(hipEventRecord(t0, sT));
+    for (int r = 0; r < rounds; ++r) {
+        if (mode == 0) {
+            launch_lbs_dense(M, D, sT);
+            launch_tick_dense(M, D, b->vl_dev, b->sw_dev, 0, ns, 1, sT);
+        } else {
+            SFX_CHECK(hipEventRecord(eT, sT));
+            SFX_CHECK(hipStreamWaitEvent(sG, eT, 0));
+            launch_lbs_dense(M, D, sG);
+            SFX_CHECK(hipEventRecord(eG, sG));
+            launch_tick_dense(M, D, b->vl_dev, b->sw_dev, 0, ns, 1, sT);
+            SFX_CHECK(hipStreamWaitEvent(sT, eG, 0));
+        }
+    }
+    SFX_CHECK(hipEventRecord(t1, sT));
+    SFX_CHECK(hipStreamSynchronize(sT)); SFX_CHECK(hipStreamSynchronize(sG));
+    float ms = 0.f; SFX_CHECK(hipEventElapsedTime(&ms, t0, t1));
+    if (out_ms) *out_ms = ms;
+    hipEventDestroy(eT); hipEventDestroy(eG); hipEventDestroy(t0); hipEventDestroy(t1); hipStreamDestroy(sT); hipStreamDestroy(sG);
+    return 0;
+}
+
 extern "C" int sfx_debug_clocks(sfx_batch* b, int32_t enable, int64_t* out /* [64] or NULL */) {
     if (!b) { sfx_set_error("null batch"); return -1; }
     if (enable) {
@@ -1192,8 +1229,10 @@ extern "C" int sfx_batch_get_grad(sfx_batch* b, int32_t stage, float* grad_out) 
 }
 
 extern "C" int sfx_batch_trace(sfx_batch* b, int32_t capacity) {
-    if (!b || capacity < 0) { sfx_set_error("bad argument"); return -1; }
+    if (!b) { sfx_set_error("bad argument"); return -1; }
     BatchDev& D = b->D;
+    D.trace_evals = capacity < 0 ? 1 : 0;          // negative capacity: also one record per closure evaluation (debug)
+    if (capacity < 0) capacity = -capacity;
     SFX_CHECK(hipDeviceSynchronize());
     if (D.trace) { hipFree(D.trace); D.trace = nullptr; }
     if (D.trace_n) { hipFree(D.trace_n); D.trace_n = nullptr; }

@@ -441,6 +441,10 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
 #define TRACE(ty, a_, b_, c_) do { if (D.trace && lane == 0) { const int n_ = D.trace_n[b];                         \
         if (n_ < D.trace_cap) D.trace[(size_t)b * D.trace_cap + n_] = make_float4((float)(ty), (float)(a_), (float)(b_), (float)(c_)); \
         D.trace_n[b] = n_ + 1; } } while (0)
+    if (D.trace && D.trace_evals) {      // (debug) every evaluation: trial step, loss, |g|inf  (the reduction is wave-wide: outside TRACE)
+        const float ginf_ = absmax3(g_in, lane, N);
+        TRACE(3, s.t.v, f_in.v, ginf_);
+    }
     int act = A_NONE;
     TMARK(1);
     // ---------------------------------------------------------------- consume the evaluation

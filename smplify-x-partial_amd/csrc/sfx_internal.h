@@ -197,6 +197,7 @@ struct BatchDev {
     float4* trace;          // [B][trace_cap] optimiser trace records (NULL = off), see sfx_batch_trace
     int*   trace_n;         // [B] records written
     int    trace_cap;
+    int    trace_evals;     // 1: also one record (3, t, loss, |g|inf) per closure evaluation
 };
 
 enum { VEC_XINIT = 0, VEC_D, VEC_G, VEC_PREVG, VEC_GPREV, VEC_BG0, VEC_BG1, VEC_LSG0, NVEC };

@@ -335,9 +335,10 @@ class FrameBatch(object):
         capi.check(self._lib.sfx_batch_get_grad(self._h, stage, capi.fptr(grad)))
         return grad
 
-    def trace(self, capacity):
-        """Attach (capacity > 0 records per frame) or detach (0) the optimiser trace (sfx_batch_trace)."""
-        capi.check(self._lib.sfx_batch_trace(self._h, int(capacity)))
+    def trace(self, capacity, evaluations=False):
+        """Attach (capacity > 0 records per frame) or detach (0) the optimiser trace (sfx_batch_trace);
+        evaluations=True adds one record per closure evaluation."""
+        capi.check(self._lib.sfx_batch_trace(self._h, -int(capacity) if evaluations else int(capacity)))
         self._trace_cap = int(capacity)
 
     def get_trace(self):
