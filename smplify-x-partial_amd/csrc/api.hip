@@ -906,6 +906,7 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
     const int B = D.cfg.B;
     const bool dense = D.cfg.lbs_mode == 1;
     const bool fused = !step_mode && !g_unfused;
+    D.act = nullptr; D.nrun = 0;          // (a previous fit that ended on an error may have left its running list attached)
     launch_lbfgs_tick(M, D, b->vl_dev, first_stage, last_stage, init, step_mode, s);
     const long max_ticks = (long)(last_stage - first_stage + 1) * D.cfg.maxiters * 80 * 2 + 64;
     std::vector<int> hs(B);
