@@ -1,0 +1,71 @@
+"""CPU tests of bench.py's host-side logic (no GPU): the distribution statistics of the parity report, the paired
+dense / needed-rows comparison, usable-core detection, and the launcher's refusal of a mismatched world size."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench as BB      # noqa: E402
+
+
+def test_parity_stats_against_a_known_distribution():
+    rng = np.random.RandomState(0)
+    r32 = 50 + 100 * rng.rand(64)
+    r64 = r32 * (1 - 0.02 + 0.01 * rng.randn(64))           # the reference against itself: ~2 % lower
+    ours = r32 * (1 - 0.015 + 0.01 * rng.randn(64))
+    st = BB.parity_stats(ours, r32, r64)
+    assert st["frames"] == 64
+    assert abs(st["final_loss_rel_delta_signed_mean"] - np.mean((ours - r32) / r32)) < 1e-12
+    assert abs(st["reference_f64_minus_f32_signed_mean"] - np.mean((r64 - r32) / r32)) < 1e-12
+    assert st["frames_below_reference_f32"] + st["frames_above_reference_f32"] == 64
+    assert 0.0 <= st["fraction_outside_reference_spread"] <= st["fraction_outside_reference_band"] <= 1.0
+    assert st["paired_wilcoxon_p_vs_reference_f32"] < 0.05                  # a 1.5 % shift over 64 frames is visible
+    # identical runs: nothing to report
+    same = BB.parity_stats(r32, r32, r64)
+    assert same["final_loss_rel_delta_mean"] == 0.0 and same["fraction_outside_reference_band"] == 0.0
+
+
+def test_loss_distribution_and_paired_stats_tolerate_non_finite_frames():
+    a = np.array([10.0, 12.0, np.nan, 400.0, 11.0])
+    b = np.array([10.5, 11.0, 13.0, 9.0, np.inf])
+    d = BB.loss_distribution(a)
+    assert d["non_finite"] == 1 and d["final_loss_median"] == 11.5 and d["outliers_gt_3x_median"] == 1
+    p = BB.paired_stats(a, b, "x", "y")
+    assert p["frames"] == 3 and p["frames_without_a_finite_pair"] == 2
+    assert p["frames_x_lower"] == 1 and p["frames_y_lower"] == 2 and np.isfinite(p["signed_rel_delta_median"])
+
+
+def test_usable_cores_is_bounded_by_affinity():
+    n, info = BB._usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1) and info["usable"] == n
+    if "affinity" in info:
+        assert n <= info["affinity"]
+
+
+def test_bench_refuses_a_launcher_world_size_that_differs_from_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "must agree" in out.stderr
+
+
+def test_record_widths_follow_the_configuration():
+    """dist.pack_records / unpack_records with num_betas 16, 6 hand components, 20 expression coefficients (the cmd_parser
+    default of num_pca_comps is 6): widths come from the result dict, frame index and evaluation count stay exact."""
+    from smplifyx_amd import dist as sd
+    B = 5
+    rng = np.random.RandomState(1)
+    res = dict(cam_translation=rng.randn(B, 3), global_orient=rng.randn(B, 3), betas=rng.randn(B, 16),
+               left_hand_pose=rng.randn(B, 6), right_hand_pose=rng.randn(B, 6), expression=rng.randn(B, 20),
+               jaw_pose=rng.randn(B, 3), leye_pose=rng.randn(B, 3), reye_pose=rng.randn(B, 3), body_pose=rng.randn(B, 63),
+               final_loss=rng.rand(B), stage_evals=np.full((B, 6), 3_000_000, np.int64))
+    first = 2 ** 24 + 3                                             # beyond float32's exact integers
+    rec = sd.pack_records(res, first)
+    fields = sd.record_fields(res)
+    assert rec.dtype == np.float64 and rec.shape == (B, sum(n for _, n in fields))
+    u = sd.unpack_records(rec, fields)
+    assert np.array_equal(u["frame"][:, 0], first + np.arange(B)) and np.all(u["evals"][:, 0] == 18_000_000)
+    assert u["betas"].shape == (B, 16) and u["left_hand_pose"].shape == (B, 6) and np.array_equal(u["betas"], res["betas"])
