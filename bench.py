@@ -202,11 +202,27 @@ def cpu_baseline_report(m, ref_evals_per_frame):
                           m["throughput_processes"] - 1, m["throughput_s"], m["throughput_evals"], per)}
 
 
-def parity_stats(ours, r32, r64):
+def self_consistent_frames(r32_stages, r64_stages, limit=0.25):
+    """Frames on which the reference agrees with ITSELF: its fp32 and fp64 runs stay within `limit` (relative) of each
+    other after every stage.  A frame that fails this (benchmark frame 51: 401 vs 2 730 after the fourth body stage, two
+    of its four camera-init keypoints missing) has more than one basin; which one a run ends in is not a property of
+    the arithmetic being tested, so such frames are listed, not averaged."""
+    r32_stages, r64_stages = np.asarray(r32_stages, np.float64), np.asarray(r64_stages, np.float64)
+    return (np.abs(r64_stages - r32_stages) / np.abs(r32_stages)).max(1) <= limit
+
+
+def parity_stats(ours, r32, r64, scored=None):
     """Distribution of the final-loss difference to the reference's fp32 fits, with the reference's own fp64-vs-fp32
     difference over the same frames as the yardstick (the optimisation is chaotic: single frames differ by per cent
-    between any two correctly rounded runs, the DISTRIBUTIONS have to agree)."""
+    between any two correctly rounded runs, the DISTRIBUTIONS have to agree).  `scored`: boolean mask of the frames
+    that enter the statistics (self_consistent_frames); the others are reported one by one."""
     ours, r32, r64 = (np.asarray(a, np.float64) for a in (ours, r32, r64))
+    listed = None
+    if scored is not None:
+        scored = np.asarray(scored, bool)
+        listed = [{"frame": int(i), "final_loss": float(ours[i]), "reference_f32": float(r32[i]), "reference_f64": float(r64[i])}
+                  for i in np.flatnonzero(~scored)]
+        ours, r32, r64 = ours[scored], r32[scored], r64[scored]
     d = (ours - r32) / r32                      # signed relative difference per frame
     y = (r64 - r32) / r32                       # the reference against itself
     band_lo, band_hi = np.minimum(r32, r64), np.maximum(r32, r64)
@@ -226,6 +242,10 @@ def parity_stats(ours, r32, r64):
            "reference_mean_final_loss_f64": float(r64.mean()),
            "median_final_loss": float(np.median(ours)), "reference_median_final_loss_f32": float(np.median(r32)),
            "reference_median_final_loss_f64": float(np.median(r64))}
+    if listed is not None:
+        out["frames_not_scored"] = listed
+        out["frames_not_scored_reason"] = ("the reference's own fp32 and fp64 runs differ by more than 25 % after some stage "
+                                           "on these frames (several basins): listed, not averaged")
     try:
         from scipy.stats import binomtest, wilcoxon
         out["paired_sign_test_p_vs_reference_f32"] = float(binomtest(n_low, int((ours != r32).sum()), 0.5).pvalue)
@@ -263,7 +283,10 @@ def reference_parity(model, lbs_mode):
     ours = res["stage_loss"]                                              # [n, 1 + stages]
     r32 = np.stack([g["f%d_f32_losses" % i] for i in range(n)])
     r64 = np.stack([g["f%d_f64_losses" % i] for i in range(n)])
-    out = parity_stats(ours[:, -1], r32[:, -1], r64[:, -1])
+    ok = self_consistent_frames(r32, r64)
+    out = parity_stats(ours[:, -1], r32[:, -1], r64[:, -1], scored=ok)
+    ours_all, r32_all, r64_all = ours, r32, r64
+    ours, r32, r64 = ours[ok], r32[ok], r64[ok]
     out.update({
         "source": "tests/golden/e2e_bench.npz: reference fit_single_frame (fp32 / fp64) on frames 0-%d of this "
                   "benchmark's sequence, this benchmark's configuration" % (n - 1),
@@ -277,8 +300,9 @@ def reference_parity(model, lbs_mode):
         "reference_equiv_evals_mean": float(res["stage_ref_evals"].sum(1).mean()),
         "reference_closure_evals_f32_mean": float(np.mean([g["f%d_f32_evals" % i].sum() for i in range(n)])),
         "reference_closure_evals_f64_mean": float(np.mean([g["f%d_f64_evals" % i].sum() for i in range(n)])),
-        "final_loss": [float(x) for x in ours[:, -1]],
-        "reference_final_loss_f32": [float(x) for x in r32[:, -1]], "reference_final_loss_f64": [float(x) for x in r64[:, -1]],
+        "frames_fitted": int(n),
+        "final_loss": [float(x) for x in ours_all[:, -1]],
+        "reference_final_loss_f32": [float(x) for x in r32_all[:, -1]], "reference_final_loss_f64": [float(x) for x in r64_all[:, -1]],
         "note": "per stage: camera stage, then the 5 body stages.  signed = (ours - reference fp32) / reference fp32; the "
                 "reference's fp64 run against its fp32 run over the same frames is the yardstick.  The keypoint forward of "
                 "this engine (rotations, kinematic chain, keypoint-vertex skinning, projection) is carried in fp64, so its "

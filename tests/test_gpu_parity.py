@@ -268,8 +268,8 @@ def test_full_model_fit_matches_reference(gpu, synth_model, name, yaml_, mode):
 @pytest.mark.parametrize("mode", ["rows", "dense"])
 def test_benchmark_configuration_matches_reference(gpu, synth_model, mode):
     """bench.py's own configuration (fit_smplx_smplifyx.yaml weights, 5 body stages, body-only, regression
-    prior) on frames 0-31 of its sequence against the REAL reference (tests/golden/e2e_bench.npz: 32 fits in
-    fp32 and 32 in fp64).  The optimisation is chaotic, so single frames say nothing: the DISTRIBUTION of the
+    prior) on frames 0-63 of its sequence against the REAL reference (tests/golden/e2e_bench.npz: 64 fits in
+    fp32 and 64 in fp64).  The optimisation is chaotic, so single frames say nothing: the DISTRIBUTION of the
     differences to the reference's fp32 fits has to sit inside what the reference's own fp64 fits show over the
     same frames (fp64 ends 1.95 % lower on average, mean |difference| 2.6 %, median 2.2 %).
       camera stage (well conditioned): every frame within 1e-4;
@@ -290,9 +290,14 @@ def test_benchmark_configuration_matches_reference(gpu, synth_model, mode):
     ours = res["stage_loss"].astype(np.float64)
     r32 = np.stack([g["f%d_f32_losses" % i] for i in range(n)])
     r64 = np.stack([g["f%d_f64_losses" % i] for i in range(n)])
+    # frames on which the reference disagrees with itself by more than 25 % after some stage (frame 51: two basins) are not
+    # averaged: which basin a run ends in is not a property of the arithmetic under test
+    ok = BB.self_consistent_frames(r32, r64)
+    assert ok.sum() >= n - 2, np.flatnonzero(~ok)
+    assert np.abs((ours[:, 0] - r32[:, 0]) / r32[:, 0]).max() < 1e-4
+    ours, r32, r64 = ours[ok], r32[ok], r64[ok]
     d = (ours - r32) / np.abs(r32)
     y = (r64 - r32) / np.abs(r32)
-    assert np.abs(d[:, 0]).max() < 1e-4, d[:, 0]
     for k in range(1, ours.shape[1]):
         yard = max(np.abs(y[:, k]).mean(), 3e-3)
         assert abs(d[:, k].mean()) <= yard, (k, d[:, k].mean(), yard)
@@ -301,7 +306,7 @@ def test_benchmark_configuration_matches_reference(gpu, synth_model, mode):
     assert abs(st["final_loss_rel_delta_signed_mean"]) <= st["reference_f32_vs_f64_rel_delta_mean"], st
     assert st["final_loss_rel_delta_median"] <= 1.5 * st["reference_f32_vs_f64_rel_delta_median"], st
     assert st["fraction_outside_reference_spread"] <= 0.25, st
-    ev = res["stage_ref_evals"].sum(1).mean()
+    ev = res["stage_ref_evals"][ok].sum(1).mean()
     e32 = np.mean([g["f%d_f32_evals" % i].sum() for i in range(n)]); e64 = np.mean([g["f%d_f64_evals" % i].sum() for i in range(n)])
     assert 0.8 * e32 <= ev <= 1.1 * e64, (ev, e32, e64)
 
