@@ -24,6 +24,26 @@
 #pragma clang fp contract(on)
 #include "vposer.h"
 
+// Precision of the keypoint forward (rotations, rest joints, kinematic chain, keypoint skinning: fwd_t) and of the
+// projection up to the pixel residual (proj_t); see "forward precision" in closure_body.  Measured on the 64 + 64
+// reference fits of the benchmark configuration (evaluations per frame / signed mean final-loss
+// difference to the reference's fp32 run; the reference: 2 362 in fp32, 4 098 and -2.1 % in fp64):
+//   fwd fp64, proj fp64 : 3 221 / -1.7 %   gradient noise 0.13 x torch fp32's: keeps working where the reference stalls
+//   fwd fp64, proj fp32 : 2 482 / -0.4 %   <- built: never noisier than the reference, closest to it in loss and in work
+//   fwd fp32, proj fp32 : 2 233 / +0.6 %   noise ~ torch's (pointer-jumping chain 1.3 x): stops a little early
+#ifdef SFX_FWD_FP32
+typedef float fwd_t;
+#else
+typedef double fwd_t;
+#endif
+#ifdef SFX_PROJ_FP64
+typedef double proj_t;
+#else
+typedef float proj_t;
+#endif
+__device__ __forceinline__ void sincos_t(double a, double* s, double* c) { sincos(a, s, c); }
+__device__ __forceinline__ void sincos_t(float a, float* s, float* c) { *s = sinf(a); *c = cosf(a); }
+
 #define CT 256
 // RIF = 2-KiB blend-shape rows in flight per wavefront (forward dots and dfeat adjoint): 4 for the
 // body-only variant (33 rows: 16 + 16 + 1), SFX_RIF_BIG for the full model (675 rows)
@@ -64,15 +84,15 @@ struct __align__(16) FrameLDSx {
     float A[SFX_J * 12];
     // the part of the forward whose ROUNDING NOISE decides when the line search stalls is carried in fp64 (see
     // "forward precision" below): skinning transforms and posed kinematic joints; saved with the prefix above
-    double Ad[SFX_J * 12];
-    double Gt[SFX_J * 3 + 1];      // (+1: keeps the saved prefix a multiple of 16 bytes)
+    fwd_t Ad[SFX_J * 12];
+    fwd_t Gt[SFX_J * 3 + 3];      // (+3: keeps the saved prefix a multiple of 16 bytes in either precision)
     float vp[MAXI * 3];            // v_posed of the items (template + blend offsets), for the reverse sweep
     float vpo[MAXI * 3];           // the blend offsets alone (small numbers: fp32 sums of them carry ~1e-10 m)
     float vt[MAXI * 3];            // v_template rows of the items
     float T[kScratch];             // item transforms [MAXI][12]; reused as scratch (>= 2048 floats) by the reverse sweep
-    double cd[2 * SFX_J * 12];     // kinematic chain in fp64: the two buffers of the pointer-jumping rounds
-    double Jd[SFX_J * 3];          // rest joints, fp64
-    double jd[SFX_MAX_K * 3];      // mapped joints, fp64 (what the projection reads)
+    fwd_t cd[2 * SFX_J * 12];     // kinematic chain in fp64: the two buffers of the pointer-jumping rounds
+    fwd_t Jd[SFX_J * 3];          // rest joints, fp64
+    fwd_t jd[SFX_MAX_K * 3];      // mapped joints, fp64 (what the projection reads)
     float dvert[MAXI * 3];
     float dvp[MAXI * 3];
     int   ivid[MAXI];
@@ -138,21 +158,21 @@ __device__ __forceinline__ void rodrigues_fwd(const float* th, float* R) {
 }
 
 // the same in fp64 (forward precision, see closure_body): R row-major
-__device__ __forceinline__ void rodrigues_fwd_d(const float* th, double* R) {
-    const double t0 = th[0], t1 = th[1], t2 = th[2];
-    const double ex = t0 + 1e-8, ey = t1 + 1e-8, ez = t2 + 1e-8;
-    const double a = sqrt(ex * ex + ey * ey + ez * ez);
-    const double dx = t0 / a, dy = t1 / a, dz = t2 / a;
-    double s, c;
-    sincos(a, &s, &c);
-    const double K[9] = {0.0, -dz, dy, dz, 0.0, -dx, -dy, dx, 0.0};
-    const double omc = 1.0 - c;
+__device__ __forceinline__ void rodrigues_fwd_d(const float* th, fwd_t* R) {
+    const fwd_t t0 = th[0], t1 = th[1], t2 = th[2];
+    const fwd_t ex = t0 + (fwd_t)1e-8, ey = t1 + (fwd_t)1e-8, ez = t2 + (fwd_t)1e-8;
+    const fwd_t a = sqrt(ex * ex + ey * ey + ez * ez);
+    const fwd_t dx = t0 / a, dy = t1 / a, dz = t2 / a;
+    fwd_t s, c;
+    sincos_t(a, &s, &c);
+    const fwd_t K[9] = {0, -dz, dy, dz, 0, -dx, -dy, dx, 0};
+    const fwd_t omc = (fwd_t)1 - c;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const double kk = K[i * 3 + 0] * K[0 * 3 + j] + K[i * 3 + 1] * K[1 * 3 + j] + K[i * 3 + 2] * K[2 * 3 + j];
-            R[i * 3 + j] = ((i == j) ? 1.0 : 0.0) + s * K[i * 3 + j] + omc * kk;
+            const fwd_t kk = K[i * 3 + 0] * K[0 * 3 + j] + K[i * 3 + 1] * K[1 * 3 + j] + K[i * 3 + 2] * K[2 * 3 + j];
+            R[i * 3 + j] = ((i == j) ? (fwd_t)1 : (fwd_t)0) + s * K[i * 3 + j] + omc * kk;
         }
 }
 
@@ -228,7 +248,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     constexpr int RIF = (LDS::kMaxItems <= SFX_SMALL_ITEMS) ? SFX_RIF_SMALL : SFX_RIF_BIG;
     constexpr int FWD_PREFIX = (int)(offsetof(LDS, vp) / sizeof(float));
     static_assert(FWD_PREFIX % 4 == 0 && FWD_PREFIX + 96 + 2 * VP_H + 128 + 64 <= SFX_FWD_N, "forward-state blob layout");
-    static_assert(offsetof(LDS, Ad) % 8 == 0 && offsetof(LDS, cd) % 8 == 0, "fp64 members");
+    static_assert(offsetof(LDS, Ad) % sizeof(fwd_t) == 0 && offsetof(LDS, cd) % sizeof(fwd_t) == 0, "forward-precision members");
     const bool reuse = args.reuse_fwd != 0;
     float* fwd = D.fwd ? D.fwd + (size_t)b * SFX_FWD_N : nullptr;
     const float* xsrc = (args.from_X ? D.X : D.Xt) + (size_t)b * SFX_NPAR_MAX;
@@ -317,27 +337,30 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     // ------------------------------------------------------------------ Rodrigues, rest joints
     // Forward precision.  Near the optimum the gradient is the small difference of keypoint forces of
     // ~5e3 per metre each, and d(force)/d(joint position) ~ 1e6 per metre: a joint position off by 1e-7 m
-    // (fp32 rounding of the chain) moves the gradient by 0.1 while |g| ~ 4 -- the line search stalls on that
-    // noise and run_fitting's ftol test (fitting.py:185-189) ends the stage (measured: tests/probe_drift.py).
-    // Rotations, rest joints, the kinematic chain, the skinning of the keypoint vertices and the projection
-    // are therefore evaluated in fp64 (a few thousand flops per evaluation); parameters, blend-shape sums,
-    // losses and the whole reverse sweep stay fp32, as in the reference.
+    // (fp32 rounding of a carelessly ordered chain / skinning) moves the gradient by 0.1 while |g| ~ 4 -- the line search
+    // stalls on that noise and run_fitting's ftol test (fitting.py:185-189) ends the stage (measured:
+    // tests/probe_drift.py).  Rotations, rest joints, the kinematic chain and the skinning of the keypoint vertices are
+    // therefore evaluated in fwd_t = fp64 (a few thousand flops per evaluation): whatever this implementation's
+    // summation orders are, the joints carry less rounding noise than torch fp32's.  The joints are then rounded to
+    // fp32 and projected in fp32 like the reference's camera (proj_t): that rounding is the noise floor the reference
+    // itself has, and with it the fits stop where the reference's fp32 fits stop.  Parameters, blend-shape sums, losses
+    // and the whole reverse sweep are fp32, as in the reference.
     if (t < SFX_J) {
-        double R[9];
+        fwd_t R[9];
         rodrigues_fwd_d(&S.full_pose[3 * t], R);
-        double* src0 = (M.n_rounds & 1) ? (S.cd + SFX_J * 12) : S.cd;
+        fwd_t* src0 = (M.n_rounds & 1) ? (S.cd + SFX_J * 12) : S.cd;
 #pragma unroll
         for (int e = 0; e < 9; ++e) { S.R[t * 9 + e] = (float)R[e]; src0[t * 12 + (e / 3) * 4 + e % 3] = R[e]; }
         if (t > 0) {
 #pragma unroll
             for (int e = 0; e < 9; ++e)
-                S.feat[M.S + 9 * (t - 1) + e] = (float)(R[e] - ((e == 0 || e == 4 || e == 8) ? 1.0 : 0.0));
+                S.feat[M.S + 9 * (t - 1) + e] = (float)(R[e] - ((e == 0 || e == 4 || e == 8) ? (fwd_t)1 : (fwd_t)0));
         }
     } else if (t >= 64 && t < 64 + SFX_J * 3) {
         const int i = t - 64;
-        double v = M.J_template[i];
+        fwd_t v = M.J_template[i];
         const float* jd = M.J_dirs + (size_t)i * M.S;
-        for (int l = 0; l < M.S; ++l) v += (double)jd[l] * (double)S.feat[l];
+        for (int l = 0; l < M.S; ++l) v += (fwd_t)jd[l] * (fwd_t)S.feat[l];
         S.Jd[i] = v;
         S.Jr[i] = (float)v;
     }
@@ -350,12 +373,12 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     // 2^k-th ancestor, T_j <- T_anc o T_j, so after ceil(log2(depth)) rounds T_j = G_j.  Two
     // buffers alternate; the result lands in S.cd[0 ..).  4 barriers instead of 11.
     {
-        double* src = (M.n_rounds & 1) ? (S.cd + SFX_J * 12) : S.cd;
-        double* dst = (M.n_rounds & 1) ? S.cd : (S.cd + SFX_J * 12);
+        fwd_t* src = (M.n_rounds & 1) ? (S.cd + SFX_J * 12) : S.cd;
+        fwd_t* dst = (M.n_rounds & 1) ? S.cd : (S.cd + SFX_J * 12);
         if (t < SFX_J * 3) {
             const int j = t / 3, r = t % 3;
             const int p = S.meta[MO_PAR + j];
-            src[j * 12 + r * 4 + 3] = S.Jd[t] - (p < 0 ? 0.0 : S.Jd[p * 3 + r]);
+            src[j * 12 + r * 4 + 3] = S.Jd[t] - (p < 0 ? (fwd_t)0 : S.Jd[p * 3 + r]);
         }
         __syncthreads();
         MARK(27);
@@ -363,27 +386,27 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
             FOR_CT(w, SFX_J * 12) {
                 const int j = w / 12, e = w % 12, r = e >> 2, c = e & 3;
                 const int a = S.meta[MO_ANC + k * 56 + j];
-                double v = src[w];
+                fwd_t v = src[w];
                 if (a >= 0) {
-                    const double* Ta = &src[a * 12 + r * 4];
-                    const double* Tb = &src[j * 12 + c];
+                    const fwd_t* Ta = &src[a * 12 + r * 4];
+                    const fwd_t* Tb = &src[j * 12 + c];
                     v = Ta[0] * Tb[0] + Ta[1] * Tb[4] + Ta[2] * Tb[8];
                     if (c == 3) v += Ta[3];
                 }
                 dst[w] = v;
             }
             __syncthreads();
-            double* tmp = src; src = dst; dst = tmp;
+            fwd_t* tmp = src; src = dst; dst = tmp;
         }
     }
     MARK(28);
     if (t < SFX_J) {
-        const double* Gj = &S.cd[t * 12];
-        const double* Jj = &S.Jd[t * 3];
-        double* Adj = &S.Ad[t * 12];
+        const fwd_t* Gj = &S.cd[t * 12];
+        const fwd_t* Jj = &S.Jd[t * 3];
+        fwd_t* Adj = &S.Ad[t * 12];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const double at = Gj[r * 4 + 3] - (Gj[r * 4 + 0] * Jj[0] + Gj[r * 4 + 1] * Jj[1] + Gj[r * 4 + 2] * Jj[2]);
+            const fwd_t at = Gj[r * 4 + 3] - (Gj[r * 4 + 0] * Jj[0] + Gj[r * 4 + 1] * Jj[1] + Gj[r * 4 + 2] * Jj[2]);
             Adj[r * 4 + 0] = Gj[r * 4 + 0]; Adj[r * 4 + 1] = Gj[r * 4 + 1]; Adj[r * 4 + 2] = Gj[r * 4 + 2]; Adj[r * 4 + 3] = at;
             S.Gt[t * 3 + r] = Gj[r * 4 + 3];
 #pragma unroll
@@ -542,33 +565,33 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     // keypoint vertices: sum_j w_j (A_j [v_posed; 1]) in fp64 on the fp64 transforms (the dense kernel's fp32
     // vertex of the same index serves the interpenetration term and the output mesh, not the keypoints)
     const int K = M.K;
-    auto item_vertex = [&](const int i, const int r) -> double {
-        const double vx = (double)S.vt[i * 3] + (double)S.vpo[i * 3], vy = (double)S.vt[i * 3 + 1] + (double)S.vpo[i * 3 + 1],
-                     vz = (double)S.vt[i * 3 + 2] + (double)S.vpo[i * 3 + 2];
-        double acc = 0.0;
+    auto item_vertex = [&](const int i, const int r) -> fwd_t {
+        const fwd_t vx = (fwd_t)S.vt[i * 3] + (fwd_t)S.vpo[i * 3], vy = (fwd_t)S.vt[i * 3 + 1] + (fwd_t)S.vpo[i * 3 + 1],
+                     vz = (fwd_t)S.vt[i * 3 + 2] + (fwd_t)S.vpo[i * 3 + 2];
+        fwd_t acc = 0;
         if (S.wj[i * SFX_NW] >= 0) {
 #pragma unroll
             for (int q2 = 0; q2 < SFX_NW; ++q2) {
                 const float wq = S.ww[i * SFX_NW + q2];
-                if (wq != 0.f) { const double* Aq = &S.Ad[S.wj[i * SFX_NW + q2] * 12 + r * 4];
-                                 acc += (double)wq * (Aq[0] * vx + Aq[1] * vy + Aq[2] * vz + Aq[3]); }
+                if (wq != 0.f) { const fwd_t* Aq = &S.Ad[S.wj[i * SFX_NW + q2] * 12 + r * 4];
+                                 acc += (fwd_t)wq * (Aq[0] * vx + Aq[1] * vy + Aq[2] * vz + Aq[3]); }
             }
         } else {
             const float* Wv = M.W + (size_t)S.ivid[i] * SFX_J;
             for (int j = 0; j < SFX_J; ++j) { const float wq = Wv[j];
-                if (wq != 0.f) { const double* Aq = &S.Ad[j * 12 + r * 4]; acc += (double)wq * (Aq[0] * vx + Aq[1] * vy + Aq[2] * vz + Aq[3]); } }
+                if (wq != 0.f) { const fwd_t* Aq = &S.Ad[j * 12 + r * 4]; acc += (fwd_t)wq * (Aq[0] * vx + Aq[1] * vy + Aq[2] * vz + Aq[3]); } }
         }
         return acc;
     };
     for (int w = t; w < K * 3; w += CT) {
         const int k = w / 3, r = w % 3;
-        double v;
+        fwd_t v;
         if (S.meta[MO_JT + k] == 0) v = S.Gt[S.meta[MO_JS + k] * 3 + r];
         else {
-            v = 0.0;
+            v = 0;
             const int i0 = S.meta[MO_JI0 + k], n = S.meta[MO_JN + k];
             if (n == 1 && S.iw[i0] == 1.f) v = item_vertex(i0, r);
-            else for (int i = 0; i < n; ++i) v += item_vertex(i0 + i, r) * (double)S.iw[i0 + i];
+            else for (int i = 0; i < n; ++i) v += item_vertex(i0 + i, r) * (fwd_t)S.iw[i0 + i];
         }
         S.jd[w] = v;
         S.joints[w] = (float)v;
@@ -605,15 +628,15 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
 #pragma unroll
     for (int i = 0; i < NQ; ++i) q[i] = 0.f;
     if (t < K) {
-        // camera.py:93-117, in fp64 up to the residual (pixel coordinates of ~500 carry 3e-5 px in fp32: the
-        // same order as the 1-px residuals' useful digits, see "forward precision" above)
-        const double* p = &S.jd[t * 3];
-        const double pxd = (double)Rc[0] * p[0] + (double)Rc[1] * p[1] + (double)Rc[2] * p[2] + (double)ct[0];
-        const double pyd = (double)Rc[3] * p[0] + (double)Rc[4] * p[1] + (double)Rc[5] * p[2] + (double)ct[1];
-        const double pzd = (double)Rc[6] * p[0] + (double)Rc[7] * p[1] + (double)Rc[8] * p[2] + (double)ct[2];
+        // camera.py:93-117 in proj_t (fp32, as the reference; see "forward precision" above)
+        const fwd_t* pj = &S.jd[t * 3];
+        const proj_t p[3] = {(proj_t)pj[0], (proj_t)pj[1], (proj_t)pj[2]};
+        const proj_t pxd = (proj_t)Rc[0] * p[0] + (proj_t)Rc[1] * p[1] + (proj_t)Rc[2] * p[2] + (proj_t)ct[0];
+        const proj_t pyd = (proj_t)Rc[3] * p[0] + (proj_t)Rc[4] * p[1] + (proj_t)Rc[5] * p[2] + (proj_t)ct[1];
+        const proj_t pzd = (proj_t)Rc[6] * p[0] + (proj_t)Rc[7] * p[1] + (proj_t)Rc[8] * p[2] + (proj_t)ct[2];
         const float pcx = (float)pxd, pcy = (float)pyd, pcz = (float)pzd;
-        const float rx = (float)((double)fd[FD_GT + 2 * t] - ((double)fx * (pxd / pzd) + (double)cx));
-        const float ry = (float)((double)fd[FD_GT + 2 * t + 1] - ((double)fy * (pyd / pzd) + (double)cy));
+        const float rx = (float)((proj_t)fd[FD_GT + 2 * t] - ((proj_t)fx * (pxd / pzd) + (proj_t)cx));
+        const float ry = (float)((proj_t)fd[FD_GT + 2 * t + 1] - ((proj_t)fy * (pyd / pzd) + (proj_t)cy));
         float du, dv;       // dL/du, dL/dv
         if (cam_stage) {
             if (fd[FD_CMASK + t] != 0.f) {

@@ -186,7 +186,7 @@ def test_bench_line_contract(workload):
     assert np.isfinite(d["config"]["final_loss_mean"])
     if workload == "body":
         rp = d["reference_parity"]
-        assert rp["frames"] >= 32 and rp["camera_stage_loss_rel_delta_max"] < 1e-4
+        assert rp["frames"] >= 32 and rp["camera_stage_loss_rel_delta_max"] < 2e-4
         assert abs(rp["final_loss_rel_delta_signed_mean"]) <= rp["reference_f32_vs_f64_rel_delta_mean"]
         assert rp["final_loss_rel_delta_median"] <= 1.5 * rp["reference_f32_vs_f64_rel_delta_median"]
         assert "roofline_tick" in d and d["roofline_tick"]["kernel"] == "k_tick_dense"
