@@ -2,7 +2,7 @@
 """Generate tests/golden/*.npz by running the REAL reference (imported from
 /root/reference, this container only) on seeded inputs.  The reference Python never
 ships; only these numeric arrays do.  Re-run: `python tools/make_goldens.py [what ...]`
-with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_side, e2e_bench}.
+with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_full_set, e2e_side, e2e_bench}.
 
 The LBS itself has no reference implementation here (external `smplx`, absent): wherever a
 body model is needed the reference drives oracle.body_model.SMPLXRef built from
@@ -323,6 +323,48 @@ def gen_e2e_full():
     _save("e2e_full", **out)
 
 
+def _full_task(task):
+    """One reference fit of frame i with hands + face + contour (cfg_files/fit_smplx_combined_halpe.yaml, K = 136,
+    interpenetration off: the package is absent) in one precision (worker of gen_e2e_full_set)."""
+    i, tag = task
+    import helpers as H
+    from smplifyx_amd import synthetic
+    from scipy.spatial.transform import Rotation as Rot
+    dtype = torch.float32 if tag == "f32" else torch.float64
+    model = synthetic.make_synthetic_model(0)
+    cfg = H.load_cfg("fit_smplx_combined_halpe.yaml", use_cuda=False, interpenetration=False)
+    cfg["use_camera_prior"] = False
+    K = len(H.joint_map_for(cfg))
+    frames = synthetic.make_frames(1, H.oracle_joints_fn(model, cfg), K, start=i, focal=5000.0)
+    bp = Rot.from_euler("XYZ", frames["reg_pose"][0].reshape(21, 3).astype(np.float64)).as_matrix().astype(np.float32)
+    go = Rot.from_euler("XYZ", frames["reg_global"][0].astype(np.float64)[None]).as_matrix().astype(np.float32)
+    c = dict(cfg); c["regression_prior"] = "ExPose"
+    bm = H.oracle_model(model, cfg, dtype)
+    res, losses, evals = _run_reference_fit(bm, c, frames["keypoints"], frames["H"], frames["W"], frames["focal"],
+                                            H.base_joint_weights(cfg, K), dtype, expose={"body_pose": bp, "global_orient": go})
+    print("e2e full set frame", i, tag, losses, evals, flush=True)
+    return i, tag, frames["keypoints"][0], frames["reg_pose"][0], frames["reg_global"][0], losses, evals
+
+
+def gen_e2e_full_set():
+    """A SET of reference fits of the full model (halpe cfg, hands + face + contour, K = 136, every prior term, joint
+    confidences; 3 stages) for a distributional comparison like e2e_bench: frames 0..N-1 (SFX_GOLDEN_FULL_FRAMES, default
+    16), fp32 and fp64."""
+    import multiprocessing as mp
+    n = int(os.environ.get("SFX_GOLDEN_FULL_FRAMES", "16"))
+    tasks = [(i, tag) for i in range(n) for tag in ("f32", "f64")]
+    with mp.get_context("fork").Pool(int(os.environ.get("SFX_GOLDEN_WORKERS", "6"))) as pool:
+        results = pool.map(_full_task, tasks, chunksize=1)
+    kp = [None] * n; rp = [None] * n; rg = [None] * n
+    out = {}
+    for i, tag, k_, p_, g_, losses, evals in results:
+        kp[i], rp[i], rg[i] = k_, p_, g_
+        out["f%d_%s_losses" % (i, tag)] = losses
+        out["f%d_%s_evals" % (i, tag)] = evals
+    out.update(keypoints=np.stack(kp), reg_pose=np.stack(rp), reg_global=np.stack(rg))
+    _save("e2e_full_set", **out)
+
+
 def _cv2_rodrigues(x):
     """Functional stand-in for the one cv2 call on the fitting path (fit_single_frame.py:529-531; cv2 is
     not installed and is otherwise a MagicMock): rotation vector <-> matrix via scipy."""
@@ -595,4 +637,4 @@ if __name__ == "__main__":
     for w in todo:
         {"objective": gen_objective, "lbfgs": gen_lbfgs, "euler": gen_euler, "tables": gen_tables,
          "e2e": gen_e2e, "demo": gen_demo, "e2e_vposer": gen_e2e_vposer, "parser": gen_parser, "eval": gen_eval,
-         "gmm": gen_gmm, "e2e_full": gen_e2e_full, "e2e_side": gen_e2e_side, "e2e_bench": gen_e2e_bench}[w]()
+         "gmm": gen_gmm, "e2e_full": gen_e2e_full, "e2e_full_set": gen_e2e_full_set, "e2e_side": gen_e2e_side, "e2e_bench": gen_e2e_bench}[w]()
