@@ -540,6 +540,9 @@ def main():
                        "parallelism": "frames sharded, dp%d" % world,
                        "closure_evals_per_frame_mean": float(evals.mean()),
                        "closure_evals_per_frame_max": int(evals.max()),
+                       # frames/s depends on how many evaluations a fit takes (a noisier closure stops earlier: round 1
+                       # took 2 046 per frame and ended 3.4 % above the reference); evaluations/s is the engine's own rate
+                       "closure_evals_per_s": float(world * args.steps * evals.sum() / dt) if world == 1 else None,
                        "reference_equiv_evals_per_frame_mean": float(ref_evals.mean()),
                        "arithmetic": "fp32 parameters, blend shapes, projection, losses, reverse sweep and optimiser (as the reference); "
                                      "fp64 inside the keypoint forward (rotations, kinematic chain, keypoint-vertex skinning), rounded "

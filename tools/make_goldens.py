@@ -2,7 +2,7 @@
 """Generate tests/golden/*.npz by running the REAL reference (imported from
 /root/reference, this container only) on seeded inputs.  The reference Python never
 ships; only these numeric arrays do.  Re-run: `python tools/make_goldens.py [what ...]`
-with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_full_set, e2e_side, e2e_bench}.
+with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_full_set, e2e_vposer_set, e2e_side, e2e_bench}.
 
 The LBS itself has no reference implementation here (external `smplx`, absent): wherever a
 body model is needed the reference drives oracle.body_model.SMPLXRef built from
@@ -287,6 +287,45 @@ def gen_e2e_vposer():
             out["f0_%s_%s" % (tag, k)] = np.asarray(res[k], np.float64)
         print("e2e vposer", tag, losses, evals)
     _save("e2e_vposer", **out)
+
+
+def _vposer_task(task):
+    """One reference fit of frame i under BASELINE config 3 (worker of gen_e2e_vposer_set)."""
+    i, tag = task
+    import helpers as H
+    from smplifyx_amd import synthetic
+    from oracle.vposer import VPoserRef
+    dtype = torch.float32 if tag == "f32" else torch.float64
+    model = synthetic.make_synthetic_model(0)
+    cfg = H.load_cfg("fit_smplx_smplifyx.yaml", use_cuda=False)
+    K = len(H.joint_map_for(cfg))
+    frames = synthetic.make_frames(1, H.oracle_joints_fn(model, cfg), K, start=i, focal=5000.0)
+    vp = VPoserRef(synthetic.make_synthetic_vposer(0), dtype)
+    ref.fit_single_frame.load_vposer = lambda ckpt, vp_model="snapshot": (vp, None)
+    bm = H.oracle_model(model, cfg, dtype)
+    res, losses, evals = _run_reference_fit(bm, cfg, frames["keypoints"], frames["H"], frames["W"], frames["focal"],
+                                            H.base_joint_weights(cfg, K), dtype)
+    print("e2e vposer set frame", i, tag, losses, evals, flush=True)
+    return i, tag, frames["keypoints"][0], losses, evals
+
+
+def gen_e2e_vposer_set():
+    """A SET of reference fits under BASELINE config 3 (full SMPL-X K = 135, VPoser decode in the loop, 5 stages of
+    cfg_files/fit_smplx_smplifyx.yaml, zero-latent start) for a distributional comparison: frames 0..N-1
+    (SFX_GOLDEN_VPOSER_FRAMES, default 16), fp32 and fp64."""
+    import multiprocessing as mp
+    n = int(os.environ.get("SFX_GOLDEN_VPOSER_FRAMES", "16"))
+    tasks = [(i, tag) for i in range(n) for tag in ("f32", "f64")]
+    with mp.get_context("fork").Pool(int(os.environ.get("SFX_GOLDEN_WORKERS", "6"))) as pool:
+        results = pool.map(_vposer_task, tasks, chunksize=1)
+    kp = [None] * n
+    out = {}
+    for i, tag, k_, losses, evals in results:
+        kp[i] = k_
+        out["f%d_%s_losses" % (i, tag)] = losses
+        out["f%d_%s_evals" % (i, tag)] = evals
+    out.update(keypoints=np.stack(kp))
+    _save("e2e_vposer_set", **out)
 
 
 def gen_e2e_full():
@@ -637,4 +676,4 @@ if __name__ == "__main__":
     for w in todo:
         {"objective": gen_objective, "lbfgs": gen_lbfgs, "euler": gen_euler, "tables": gen_tables,
          "e2e": gen_e2e, "demo": gen_demo, "e2e_vposer": gen_e2e_vposer, "parser": gen_parser, "eval": gen_eval,
-         "gmm": gen_gmm, "e2e_full": gen_e2e_full, "e2e_full_set": gen_e2e_full_set, "e2e_side": gen_e2e_side, "e2e_bench": gen_e2e_bench}[w]()
+         "gmm": gen_gmm, "e2e_full": gen_e2e_full, "e2e_full_set": gen_e2e_full_set, "e2e_vposer_set": gen_e2e_vposer_set, "e2e_side": gen_e2e_side, "e2e_bench": gen_e2e_bench}[w]()
