@@ -554,6 +554,7 @@ def main():
         out["config"].update(loss_distribution(st["stage_loss"][:, -1]))
         if ranks is not None:
             out["ranks"] = ranks
+            out["config"]["closure_evals_per_s"] = float(sum(r["closure_evals_total"] for r in ranks) * args.steps / dt)
         if args.lbs == "dense" and n_dense:
             # active-frame compaction makes the frames per launch vary: achieved = total algorithmic
             # flops of all launches / total kernel time (HIP events on the launch stream)

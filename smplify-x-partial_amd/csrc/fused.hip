@@ -99,7 +99,7 @@ void launch_tick_dense(const DevModel& M, const BatchDev& D, const VarList* vl_d
                        int first_stage, int last_stage, int has_eval, hipStream_t s) {
     const int grid = D.act ? D.nrun : D.cfg.B;
     if (grid <= 0) return;
-    static const int n_cu = [] { hipDeviceProp_t p; int dev = 0; hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
+    static const int n_cu = [] { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
     if (sfx_small_closure(M, D)) {
         if (grid <= n_cu)
             hipLaunchKernelGGL((k_tick_dense<FrameLDSSmall, 1>), dim3(grid), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
