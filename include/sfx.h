@@ -270,6 +270,10 @@ int  sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out /* [32] */
 /* Experiment (timing only): `rounds` rounds of the dense loop; mode 0 serial (GEMM -> tick), mode 1 GEMM and tick of a
  * round launched together on two streams.  out_ms = elapsed time.  The batch's results are meaningless afterwards.     */
 int  sfx_debug_overlap_test(sfx_batch* b, int32_t rounds, int32_t mode, double* out_ms);
+/* Debug: direction of the device's blocked two-loop recursion for a caller-supplied history (rows of 192 floats, zero
+ * padded; `count` pairs pushed in order, the window keeps the last 100) and gradient g[192]; d_out[192].  Host pointers.
+ * Specification: optimizers/lbfgs_ls.py:312-341. */
+int  sfx_debug_two_loop(const float* S, const float* Y, int32_t count, const float* g, float* d_out);
 
 /* Debug: attach (enable>=1) a 64-slot clock buffer to the batch, run any entry point, then read it
  * and detach (enable=0): out[0..18] = closure phase stamps of the last launch, out[32+i] =

@@ -575,7 +575,7 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     if (b->slots >= B) b->slots = 0;
     D.opt = b->mem.zeros<char>((size_t)B * sfx_optstate_size());
     D.vec = b->mem.zeros<float>((size_t)B * NVEC * SFX_NVAR_MAX);
-    D.hist = b->mem.zeros<float>((size_t)B * 2 * SFX_HIST * SFX_NVAR_MAX);
+    D.hist = b->mem.zeros<float>((size_t)B * 2 * SFX_HROWS * SFX_NVAR_MAX);
     D.n_active = b->mem.zeros<int>(4);
     D.stage_loss = b->mem.zeros<float>((size_t)B * (1 + SFX_MAX_STAGES));
     D.stage_evals = b->mem.zeros<int>((size_t)B * (1 + SFX_MAX_STAGES));
@@ -740,6 +740,16 @@ extern "C" int sfx_batch_debug_read(sfx_batch* b, const char* name, float* out, 
     }
     sfx_set_error("unknown buffer '%s'", name);
     return -1;
+}
+
+// debug: the direction the device's blocked two-loop recursion (lbfgs_body.h lb_two_loop) computes from a history of `count`
+// curvature pairs pushed in order (rows of SFX_NVAR_MAX = 192 floats, zero padded; the window keeps the last 100) and a
+// gradient g: d = -H g with H_diag = y.s / y.y of the last pair (lbfgs_ls.py:312-341).  Host pointers.
+extern "C" int sfx_debug_two_loop(const float* S, const float* Y, int32_t count, const float* g, float* d_out) {
+    if (!S || !Y || !g || !d_out || count < 1) { sfx_set_error("sfx_debug_two_loop: bad arguments"); return -1; }
+    const int rc = debug_two_loop(S, Y, count, g, d_out);
+    if (rc) { sfx_set_error("sfx_debug_two_loop: HIP error"); return -1; }
+    return 0;
 }
 
 // debug: attach (enable=1) / read out and detach (enable=0) the 64-slot clock buffer; while attached,

@@ -13,9 +13,6 @@
 #ifndef SFX_TICK_OCC
 #define SFX_TICK_OCC 2
 #endif
-#ifndef LB_COOP_WAVES
-#define LB_COOP_WAVES 1
-#endif
 
 template <class LDS>
 __global__ __launch_bounds__(CT, LDS::kBlocksPerCU)
@@ -26,7 +23,6 @@ void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const S
     __shared__ float fval;
     __shared__ float s_al[SFX_HIST + 2 * LB_BS];
     __shared__ OptScal st;
-    __shared__ LbCoop cp;
     const int b = blockIdx.x;
     ClosureArgs a{};
     a.stage_override = -2;
@@ -35,11 +31,10 @@ void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const S
         closure_body(S, M, D, vls, sws, a, b, gflat, &fval);
         a.keep_tables = 1;
         __syncthreads();
-        // (LB_COOP_WAVES = 4 lets the idle wavefronts share the dot products of the two-loop recursion;
-        //  measured slower: one workgroup barrier per block of 8 history pairs costs more than the
-        //  3/4 of the reductions it removes -- 42 k vs 37 k cycles per direction)
-        if (LB_COOP_WAVES > 1 || threadIdx.x < 64)
-            lbfgs_tick_body<LB_COOP_WAVES>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, cp, &fval, gflat);
+        // (one wavefront: sharing the dot products of the two-loop recursion between four was measured slower --
+        //  a workgroup barrier per block of 8 history pairs costs more than the reductions it removes)
+        if (threadIdx.x < 64)
+            lbfgs_tick_body<2>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, &fval, gflat);
         __syncthreads();
     }
 }
@@ -56,7 +51,6 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
     __shared__ float fval;
     __shared__ float s_al[SFX_HIST + 2 * LB_BS];
     __shared__ OptScal st;
-    __shared__ LbCoop cp;
     const int b = D.act ? D.act[blockIdx.x] : blockIdx.x;      // (frames that finished or still wait in the queue are not launched)
     if (D.stage[b] > last_stage) return;
     const long long wc0 = D.dbg ? wall_clock64() : 0;      // debug: per-workgroup duration statistics (100 MHz clock)
@@ -67,11 +61,10 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
         a.stage_override = -2; a.use_dense_verts = 1; a.reuse_fwd = 1;
         closure_body(S, M, D, vls, sws, a, b, gflat, &fval);
         __syncthreads();
-        // (LB_COOP_WAVES = 4 lets the idle wavefronts share the dot products of the two-loop recursion;
-        //  measured slower: one workgroup barrier per block of 8 history pairs costs more than the
-        //  3/4 of the reductions it removes -- 42 k vs 37 k cycles per direction)
-        if (LB_COOP_WAVES > 1 || threadIdx.x < 64)
-            lbfgs_tick_body<LB_COOP_WAVES>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, cp, &fval, gflat);
+        // (one wavefront: sharing the dot products of the two-loop recursion between four was measured slower --
+        //  a workgroup barrier per block of 8 history pairs costs more than the reductions it removes)
+        if (threadIdx.x < 64)
+            lbfgs_tick_body<3>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, &fval, gflat);
         __syncthreads();
         if (D.dbg && b == 0 && threadIdx.x == 0 && D.dbg[62] <= D.dbg[61]) { D.dbg[25] = clock64(); for (int i = 0; i < 17; ++i) D.dbg[40 + i] = D.dbg[i]; }
         if (D.stage[b] > last_stage) return;

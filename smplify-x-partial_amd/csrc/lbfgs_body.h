@@ -114,10 +114,17 @@ struct OptScal {
     Sc br0, br1, bf0, bf1, bgtd0, bgtd1;
     double prev_loss_outer;
 };
+// Band of the Gram matrix S^T Y used by the blocked two-loop recursion, one 16-float row per history slot:
+// row[8 + k], k = 1..7, holds  syb: s_p . y_(k-th successor of p)   (loop 2 walks old -> new)
+//                              syt: s_(k-th predecessor of p) . y_p  (loop 1 walks new -> old);
+// row[0..8] stay ZERO, so a lane that reads row[8 + (c - m)] for a member c <= m of the block gets the "+0" of the
+// in-block coupling without a mask.
+#define LB_BROW 16
 struct OptState {
     OptScal s;
-    float ro[SFX_HIST];
-    float syb[SFX_HIST * LB_BS];    // syb[p][k] = s_p . y_(k-th successor of p)
+    float ro[SFX_HROWS];                 // (rows HIST..HIST+7 of all three mirror slots 0..7, as the history does)
+    float syb[SFX_HROWS * LB_BROW];
+    float syt[SFX_HROWS * LB_BROW];
 };
 
 
@@ -218,143 +225,231 @@ __device__ __forceinline__ OptScal fresh_state() {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Two-loop recursion (lbfgs_ls.py:322-341), evaluated in blocks of BS history pairs by NW
-// cooperating wavefronts.  Within a block the BS dot products against the running vector are
-// independent (s_c . q for all c at once): wavefront w computes BS/NW of them, the partial results
-// meet in LDS (one workgroup barrier per block), and every wavefront then resolves the in-block
-// coupling  s_c . (q - sum_m al_m y_m)  on scalars with the stored band s_p . y_(p+k) of the Gram
-// matrix and applies all BS updates to ITS OWN copy of the running vector -- the copies stay
-// bit-identical, so no vector ever crosses wavefronts.  Same arithmetic in exact terms as the
-// sequential recursion; 2 x ceil(n/BS) block steps instead of 2n dependent dot->axpy steps.
-// History rows of the next block are fetched into a second register set while the current block
-// is consumed.  NW = 1: a single wavefront, no barriers (stand-alone tick kernel).
-struct LbCoop {
-    float q[SFX_NVAR_MAX];      // -g, the start of the recursion (zero beyond N)
-    float exch[2][LB_BS];       // dot products of the current block, double buffered
-    float hd;                   // H_diag
-    int n, head, req;           // history window; req = 1: helpers enter lb_two_loop, 0: tick finished
-};
-
-template <int NW>
-__device__ __forceinline__ void lb_block_sync() {
-    if (NW > 1) __syncthreads();
+// Two-loop recursion (lbfgs_ls.py:322-341) on ONE wavefront, in blocks of 8 history pairs.  A single wavefront issues
+// one instruction every 4 cycles whatever its kind, so the recursion is priced in instructions: per block
+//   * 16 row loads (8 s rows, 8 y rows; lane l owns elements 3l..3l+2) from CONTIGUOUS history slots -- one uniform
+//     base and immediate offsets; only the block that wraps around the ring or sticks out of the window computes
+//     clamped slots row by row;
+//   * the 8 dot products against the running vector, 3 FMAs each;
+//   * ONE recursive-halving reduction of all 8 (wave_sum8_groups: 17 instructions) that leaves the sum of member c in
+//     the 8 lanes of group c;
+//   * the in-block coupling  s_c . (q - sum_{m<c} al_m y_m)  resolved lane-parallel on those groups with the stored
+//     band of S^T Y (one 64-byte row per step, zeros where c <= m): multiply, v_readlane (the broadcast the axpy
+//     needs anyway), FMA per step;
+//   * the 8 axpys.
+// Same arithmetic in exact terms as the sequential recursion (the order of the updates is the reference's; only the
+// summation tree of each dot product differs).  Two blocks of look-ahead in registers cover the history's
+// L2 / MALL latency.
+template <int CTRL>
+__device__ __forceinline__ float lb_dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// in: v[c] = this lane's partial of sum c.  out: every lane of group g (lanes 8g..8g+7) holds the wave-wide sum g.
+__device__ __forceinline__ float wave_sum8_groups(const float (&v)[8], const int lane) {
+    // halves (stride 32): lanes 0-31 keep a, lanes 32-63 keep b
+    auto halves = [](float a_, float b_) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a_), __float_as_uint(b_), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]); };
+    // rows of 16 (stride 16): rows 0, 2 keep a, rows 1, 3 keep b
+    auto rows = [](float a_, float b_) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a_), __float_as_uint(b_), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]); };
+    // operand order chosen so that sum g ends in group g: rows of AB = sums 0, 2, 4, 6 and of CD = 1, 3, 5, 7
+    const float A = halves(v[0], v[4]), B = halves(v[2], v[6]), C = halves(v[1], v[5]), D = halves(v[3], v[7]);
+    const float AB = rows(A, B), CD = rows(C, D);
+    // stride 8: lanes 0-7 of a row keep AB, lanes 8-15 keep CD
+    const float tA = AB + lb_dpp<0x128>(AB), tC = CD + lb_dpp<0x128>(CD);          // row_ror:8
+    float t = (lane & 8) ? tC : tA;
+    t = t + lb_dpp<0x141>(t);          // row_half_mirror: l <-> 7 - l
+    t = t + lb_dpp<0xB1>(t);           // quad_perm [1,0,3,2]
+    t = t + lb_dpp<0x4E>(t);           // quad_perm [2,3,0,1]
+    return t;
 }
 
-template <int NW>
+#define LB_ROWB (SFX_NVAR_MAX * 4)      // bytes per history row
+// a lane's 3 elements of a history row as (pair, single): the 12-byte load lands in an even-aligned register triple, so
+// the pair feeds v_pk_fma_f32 as it is (left to itself the compiler pairs elements 1, 2 and copies every row)
+typedef float lb_v2 __attribute__((ext_vector_type(2)));
+struct LbRow { lb_v2 a; float b; };
+struct LbSet { LbRow mine[8]; LbRow all[8]; float bnd[7]; float ro, al; };
+__device__ __forceinline__ LbRow lb_ldrow(const char* p) {
+    const float3 u = *reinterpret_cast<const float3*>(p);
+    LbRow r; r.a.x = u.x; r.a.y = u.y; r.b = u.z; return r;
+}
+__device__ __forceinline__ float lb_dotpart(const LbRow& x, const LbRow& y) { return fmaf(x.b, y.b, fmaf(x.a.y, y.a.y, x.a.x * y.a.x)); }
+__device__ __forceinline__ void lb_axpy(LbRow& y, const float a, const LbRow& x) {
+    const lb_v2 aa = {a, a};
+    y.a = __builtin_elementwise_fma(aa, x.a, y.a); y.b = fmaf(a, x.b, y.b);
+}
+
+// rows of the block whose member 0 is logical index `base`, members base + DIR * c: always 8 CONSECUTIVE rows (the ring
+// is followed by a mirror of its first 8 slots).  Members outside the window [0, n) get ro = al = 0: their rows are
+// other slots of the ring (stale pairs or the zeros of the allocation -- finite), their steps are exact no-ops.
+// mine / all: the two history arrays in the order the loop uses them; tab: the band table of this direction.  The rows
+// the block touches first (mine) are requested last: one s_waitcnt at the dot products covers the whole set.
+template <int DIR>
+__device__ __forceinline__ void lb_load(LbSet& X, const int base, const int n, const int head, const float* hMine,
+                                        const float* hAll, const float* tab, const float* ro, const float* s_alp,
+                                        const bool want_al, const int lane) {
+    const int grp = lane >> 3;
+    int p = head + base; p = p >= SFX_HIST ? p - SFX_HIST : p;
+    if (DIR < 0 && p < 7) p += SFX_HIST;
+    const float* tb = tab + p * LB_BROW + 8 + grp;
+#pragma unroll
+    for (int m = 0; m < 7; ++m) X.bnd[m] = tb[DIR * m * LB_BROW - m];
+    const int ig = base + DIR * grp;
+    const bool valid = ig >= 0 && ig < n;
+    const float rv = ro[p + DIR * grp];
+    X.ro = valid ? rv : 0.f;
+    X.al = 0.f;
+    if (want_al) { const float av = s_alp[ig]; X.al = valid ? av : 0.f; }
+    const char* ra = reinterpret_cast<const char*>(hAll) + (size_t)p * LB_ROWB + 12 * lane;
+    const char* rm = reinterpret_cast<const char*>(hMine) + (size_t)p * LB_ROWB + 12 * lane;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) X.all[c] = lb_ldrow(ra + DIR * c * LB_ROWB);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) X.mine[c] = lb_ldrow(rm + DIR * c * LB_ROWB);
+}
+
+// A new curvature pair (lbfgs_ls.py:312-320: the oldest one leaves when the window is full) with what the blocked
+// recursion keeps per pair: ro, the band entries s_(k-th predecessor) . y_new -- the syt row of the new pair and entry k
+// of the k-th predecessor's syb row -- and the mirror of slots 0..7 behind the ring.
+__device__ __forceinline__ void lb_push_pair(float* hY, float* hS, OptState* gst, int& hist_n, int& hist_head, const Lane3& y,
+                                             const Lane3& sv, const float ys, const int lane) {
+    if (hist_n == SFX_HIST) { hist_head = (hist_head + 1) % SFX_HIST; hist_n -= 1; }
+    const int ph = (hist_head + hist_n) % SFX_HIST;
+    st3_full(hY + (size_t)ph * SFX_NVAR_MAX, y, lane);
+    st3_full(hS + (size_t)ph * SFX_NVAR_MAX, sv, lane);
+    const float ro = 1.0f / ys;
+    if (lane == 0) gst->ro[ph] = ro;
+    if (ph < 8) {
+        st3_full(hY + (size_t)(ph + SFX_HIST) * SFX_NVAR_MAX, y, lane);
+        st3_full(hS + (size_t)(ph + SFX_HIST) * SFX_NVAR_MAX, sv, lane);
+        if (lane == 0) gst->ro[ph + SFX_HIST] = ro;
+    }
+    hist_n += 1;
+    const int n1 = __builtin_amdgcn_readfirstlane(hist_n), hd1 = __builtin_amdgcn_readfirstlane(hist_head);
+    Lane3 SP[7];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const int i_ = n1 - 1 - k;
+        int t_ = hd1 + (i_ >= 0 ? i_ : 0); t_ = t_ >= SFX_HIST ? t_ - SFX_HIST : t_;
+        SP[k - 1] = ld3_raw(hS, (unsigned)t_ * SFX_NVAR_MAX, lane);
+    }
+    float eb[8];
+    eb[0] = 0.f;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) eb[k] = fmaf(SP[k - 1].v[2], y.v[2], fmaf(SP[k - 1].v[1], y.v[1], SP[k - 1].v[0] * y.v[0]));
+    const float e = wave_sum8_groups(eb, lane);      // group k: s_(k-th predecessor) . y_new
+    const int k = lane >> 3, i_ = n1 - 1 - k;
+    int t_ = hd1 + (i_ >= 0 ? i_ : 0); t_ = t_ >= SFX_HIST ? t_ - SFX_HIST : t_;
+    const float ev = (k >= 1 && i_ >= 0) ? e : 0.f;   // (no such predecessor: a finite 0)
+    if ((lane & 7) == 0) {
+        gst->syt[ph * LB_BROW + 8 + k] = ev;
+        gst->syb[ph * LB_BROW + 8 + k] = 0.f;         // successors of the new pair do not exist yet
+        if (ph < 8) { gst->syt[(ph + SFX_HIST) * LB_BROW + 8 + k] = ev; gst->syb[(ph + SFX_HIST) * LB_BROW + 8 + k] = 0.f; }
+        if (k >= 1 && i_ >= 0) {
+            gst->syb[t_ * LB_BROW + 8 + k] = ev;
+            if (t_ < 8) gst->syb[(t_ + SFX_HIST) * LB_BROW + 8 + k] = ev;
+        }
+    }
+}
+
+template <int SETS>
 __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, const OptState* gst, float* s_al,
-                                             LbCoop& cp, const int wv, const int lane) {
-    constexpr int BS = LB_BS, RPW = BS / NW;
-    static_assert(BS % NW == 0, "rows per wavefront");
-    const int n = __builtin_amdgcn_readfirstlane(cp.n), head = __builtin_amdgcn_readfirstlane(cp.head);
-    const float hd = cp.hd;
-    float* s_alp = s_al + BS;        // members below index 0 of the last block land in the padding
-    auto slot = [head, n](int i_) { int t_ = head + min(max(i_, 0), max(n - 1, 0)); return t_ >= SFX_HIST ? t_ - SFX_HIST : t_; };
+                                             const int n_, const int head_, const float hd, const Lane3 q_in, const int lane) {
+    const int n = __builtin_amdgcn_readfirstlane(n_), head = __builtin_amdgcn_readfirstlane(head_);
+    float* s_alp = s_al + 8;        // members below index 0 of the last block land in the padding
+    const int grp = lane >> 3;
 #define LB_RL(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))
-    struct Set { Lane3 mine[RPW]; Lane3 all[BS]; float band, ro, al; };
-    // loop 1 (dir = -1): mine = my s rows, all = every y row;  loop 2 (dir = +1): mine = my y rows, all = every s row
-    auto load = [&](Set& X, int base, int dir, const float* hMine, const float* hAll, bool want_al) {
+    // SETS register sets of history rows: the block in use + (SETS - 1) blocks of look-ahead (3 where the registers are
+    // there -- the tick kernels; 2 inside the persistent per-frame kernel, which would spill)
+    static_assert(SETS == 2 || SETS == 3, "register sets");
+    LbSet A, B, C;
+    LbRow q; q.a.x = q_in.v[0]; q.a.y = q_in.v[1]; q.b = q_in.v[2];
+    // ---- loop 1: newest -> oldest;  al_i = ro_i s_i . q;  q -= al_i y_i
+    auto down = [&](const LbSet& X, const int base) {
+        float part[8];
 #pragma unroll
-        for (int c = 0; c < RPW; ++c) X.mine[c] = ld3_raw(hMine, (unsigned)slot(base + dir * (wv * RPW + c)) * SFX_NVAR_MAX, lane);
+        for (int c = 0; c < 8; ++c) part[c] = lb_dotpart(X.mine[c], q);
+        float acc = wave_sum8_groups(part, lane);
+        float al[8];
 #pragma unroll
-        for (int c = 0; c < BS; ++c) X.all[c] = ld3_raw(hAll, (unsigned)slot(base + dir * c) * SFX_NVAR_MAX, lane);
-        X.band = gst->syb[slot(base + dir * (lane / BS)) * BS + lane % BS];    // lane (x, k): band row of member x
-        X.ro = gst->ro[slot(base + dir * (lane % BS))];                         // lane c: ro of member c
-        X.al = 0.f;
-        if (want_al) X.al = s_alp[min(max(base + dir * (lane % BS), -BS), n)];
-    };
-    int buf = 0;
-    auto gather = [&](float (&mine)[RPW], float (&acc)[BS]) {
-        wave_sum_multi(mine);
-        if (NW > 1) {
-            if (lane == 0) {
-#pragma unroll
-                for (int c = 0; c < RPW; ++c) cp.exch[buf][wv * RPW + c] = mine[c];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < BS; ++c) acc[c] = cp.exch[buf][c];
-            buf ^= 1;
-        } else {
-#pragma unroll
-            for (int c = 0; c < BS; ++c) acc[c] = mine[c % RPW];
+        for (int m = 0; m < 8; ++m) {
+            al[m] = LB_RL(acc * X.ro, 8 * m);
+            if (m < 7) acc = fmaf(-al[m], X.bnd[m], acc);
         }
+        s_alp[base - grp] = acc * X.ro;          // (members c <= m see zeros of the band: acc[c] is final after step c)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) lb_axpy(q, -al[c], X.all[c]);
     };
-    Lane3 q = ld3_raw(cp.q, 0u, lane);
-    Set A, B;
-    auto down = [&](Set& X, int base) {
-        float mine[RPW], acc[BS], al[BS];
-#pragma unroll
-        for (int c = 0; c < RPW; ++c) mine[c] = dot3_part(X.mine[c], q);
-        gather(mine, acc);
-#pragma unroll
-        for (int m = 0; m < BS; ++m) {
-            al[m] = (base - m >= 0) ? acc[m] * LB_RL(X.ro, m) : 0.f;
-#pragma unroll
-            for (int c = m + 1; c < BS; ++c) acc[c] = fmaf(-al[m], LB_RL(X.band, c * BS + (c - m)), acc[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < BS; ++c) q = axpy3(q, -al[c], X.all[c]);
-        if (wv == 0 && lane == 0) {
-#pragma unroll
-            for (int c = 0; c < BS; ++c) s_alp[base - c] = al[c];
-        }
-    };
+#define LB_LD1(X, b_) lb_load<-1>(X, (b_), n, head, hS, hY, gst->syt, gst->ro, s_alp, false, lane)
     {
         int i0 = n - 1;
-        load(A, i0, -1, hS, hY, false);
-        while (i0 >= 0) {
-            load(B, i0 - BS, -1, hS, hY, false);
-            down(A, i0);
-            i0 -= BS;
-            if (i0 < 0) break;
-            load(A, i0 - BS, -1, hS, hY, false);
-            down(B, i0);
-            i0 -= BS;
+        if constexpr (SETS == 3) {
+        LB_LD1(A, i0); if (i0 >= 8) LB_LD1(B, i0 - 8);
+        for (;;) {
+            if (i0 >= 16) LB_LD1(C, i0 - 16); down(A, i0); i0 -= 8; if (i0 < 0) break;
+            if (i0 >= 16) LB_LD1(A, i0 - 16); down(B, i0); i0 -= 8; if (i0 < 0) break;
+            if (i0 >= 16) LB_LD1(B, i0 - 16); down(C, i0); i0 -= 8; if (i0 < 0) break;
+        }
+        } else {
+        LB_LD1(A, i0);
+        for (;;) {
+            if (i0 >= 8) LB_LD1(B, i0 - 8); down(A, i0); i0 -= 8; if (i0 < 0) break;
+            if (i0 >= 8) LB_LD1(A, i0 - 8); down(B, i0); i0 -= 8; if (i0 < 0) break;
+        }
         }
     }
-    if (NW > 1) __syncthreads(); else LB_SYNC();      // alphas (LDS) are read back by every wavefront
-    Lane3 r;
+#undef LB_LD1
+    LB_SYNC();      // alphas (LDS) are read back below
+    LbRow r; r.a = q.a * hd; r.b = q.b * hd;
+    // ---- loop 2: oldest -> newest;  be_i = ro_i y_i . r;  r += (al_i - be_i) s_i
+    auto up = [&](const LbSet& X) {
+        float part[8];
 #pragma unroll
-    for (int e = 0; e < NE3; ++e) r.v[e] = q.v[e] * hd;
-    auto up = [&](Set& X, int base) {
-        float mine[RPW], acc[BS], cc[BS];
+        for (int c = 0; c < 8; ++c) part[c] = lb_dotpart(X.mine[c], r);
+        float acc = wave_sum8_groups(part, lane);
+        float cc[8];
 #pragma unroll
-        for (int c = 0; c < RPW; ++c) mine[c] = dot3_part(X.mine[c], r);
-        gather(mine, acc);
-#pragma unroll
-        for (int m = 0; m < BS; ++m) {
-            const float be = acc[m] * LB_RL(X.ro, m);
-            cc[m] = (base + m < n) ? LB_RL(X.al, m) - be : 0.f;
-#pragma unroll
-            for (int c = m + 1; c < BS; ++c) acc[c] = fmaf(cc[m], LB_RL(X.band, m * BS + (c - m)), acc[c]);
+        for (int m = 0; m < 8; ++m) {
+            cc[m] = LB_RL(X.al - acc * X.ro, 8 * m);
+            if (m < 7) acc = fmaf(cc[m], X.bnd[m], acc);
         }
 #pragma unroll
-        for (int c = 0; c < BS; ++c) r = axpy3(r, cc[c], X.all[c]);
+        for (int c = 0; c < 8; ++c) lb_axpy(r, cc[c], X.all[c]);
     };
+#define LB_LD2(X, b_) lb_load<1>(X, (b_), n, head, hY, hS, gst->syb, gst->ro, s_alp, true, lane)
     {
         int i0 = 0;
-        load(A, i0, 1, hY, hS, true);
-        while (i0 < n) {
-            load(B, i0 + BS, 1, hY, hS, true);
-            up(A, i0);
-            i0 += BS;
-            if (i0 >= n) break;
-            load(A, i0 + BS, 1, hY, hS, true);
-            up(B, i0);
-            i0 += BS;
+        if constexpr (SETS == 3) {
+        LB_LD2(A, i0); if (i0 + 8 < n) LB_LD2(B, i0 + 8);
+        for (;;) {
+            if (i0 + 16 < n) LB_LD2(C, i0 + 16); up(A); i0 += 8; if (i0 >= n) break;
+            if (i0 + 16 < n) LB_LD2(A, i0 + 16); up(B); i0 += 8; if (i0 >= n) break;
+            if (i0 + 16 < n) LB_LD2(B, i0 + 16); up(C); i0 += 8; if (i0 >= n) break;
+        }
+        } else {
+        LB_LD2(A, i0);
+        for (;;) {
+            if (i0 + 8 < n) LB_LD2(B, i0 + 8); up(A); i0 += 8; if (i0 >= n) break;
+            if (i0 + 8 < n) LB_LD2(A, i0 + 8); up(B); i0 += 8; if (i0 >= n) break;
+        }
         }
     }
+#undef LB_LD2
 #undef LB_RL
-    return r;
+    Lane3 out; out.v[0] = r.a.x; out.v[1] = r.a.y; out.v[2] = r.b;
+    return out;
 }
 
 // One tick of frame b's optimiser, executed by ONE wavefront (lanes 0..63).  f_in / g_in: the
 // closure result (global D.f/D.g, or LDS copies in fused kernels).  s_al[SFX_HIST + 2 * LB_BS] and s_state
 // are LDS scratch owned by the caller.
-template <int NW>
+template <int SETS>
 __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchDev& D, const VarList* __restrict__ vls,
                                                  int first_stage, int last_stage, int init, int step_mode,
-                                                 const int b, const int lane, float* s_al, OptScal& s_state, LbCoop& cp,
+                                                 const int b, const int lane, float* s_al, OptScal& s_state,
                                                  const float* f_src, const float* g_src) {
     const BatchCfgDev& C = D.cfg;
     OptState* gst = reinterpret_cast<OptState*>(D.opt) + b;
@@ -362,8 +457,8 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
     float* X = D.X + (size_t)b * SFX_NPAR_MAX;
     float* Xt = D.Xt + (size_t)b * SFX_NPAR_MAX;
     float* vec = D.vec + (size_t)b * NVEC * SFX_NVAR_MAX;
-    float* hY = D.hist + (size_t)b * 2 * SFX_HIST * SFX_NVAR_MAX;
-    float* hS = hY + (size_t)SFX_HIST * SFX_NVAR_MAX;
+    float* hY = D.hist + (size_t)b * 2 * SFX_HROWS * SFX_NVAR_MAX;
+    float* hS = hY + (size_t)SFX_HROWS * SFX_NVAR_MAX;
 #define VEC(k) (vec + (k) * SFX_NVAR_MAX)
 
     // ---------------------------------------------------------------- (re)initialisation
@@ -382,6 +477,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
             }
             D.try_both[b] = both;
         }
+        for (int i = lane; i < SFX_HROWS * LB_BROW; i += 64) { gst->syb[i] = 0.f; gst->syt[i] = 0.f; }     // (columns 0..8 stay zero)
         for (int q = lane; q < 1 + SFX_MAX_STAGES; q += 64) {
             if (q >= first_stage + 1 && q <= last_stage + 1) {
                 D.stage_evals[(size_t)b * (1 + SFX_MAX_STAGES) + q] = 0;
@@ -536,38 +632,10 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
                 for (int e = 0; e < NE3; ++e) { y.v[e] = g.v[e] - pg.v[e]; sv.v[e] = dold.v[e] * tf; }
                 const float ys = dot3(y, sv);
                 if (ys > 1e-10f) {
-                    if (s.hist_n == SFX_HIST) { s.hist_head = (s.hist_head + 1) % SFX_HIST; s.hist_n -= 1; }
-                    const int ph = (s.hist_head + s.hist_n) % SFX_HIST;
-                    st3_full(hY + (size_t)ph * SFX_NVAR_MAX, y, lane);
-                    st3_full(hS + (size_t)ph * SFX_NVAR_MAX, sv, lane);
-                    const float ro = 1.0f / ys;
-                    if (lane == 0) gst->ro[ph] = ro;
-                    s.hist_n += 1;
+                    int hn = s.hist_n, hh = s.hist_head;
+                    lb_push_pair(hY, hS, gst, hn, hh, y, sv, ys, lane);
+                    s.hist_n = hn; s.hist_head = hh;
                     s.H_diag = T(ys / dot3(y, y));
-                    // band of the Gram matrix used by the blocked recursion below:
-                    // syb[p][k] = s_p . y_(k-th successor of p), k = 1..BS-1; the new y closes the
-                    // pairs with its BS-1 predecessors
-                    {
-                        const int n1 = __builtin_amdgcn_readfirstlane(s.hist_n), hd1 = __builtin_amdgcn_readfirstlane(s.hist_head);
-                        Lane3 SP[LB_BS - 1];
-#pragma unroll
-                        for (int k = 1; k < LB_BS; ++k) {
-                            const int i_ = n1 - 1 - k;
-                            int t_ = hd1 + (i_ >= 0 ? i_ : 0); t_ = t_ >= SFX_HIST ? t_ - SFX_HIST : t_;
-                            SP[k - 1] = ld3_raw(hS, (unsigned)t_ * SFX_NVAR_MAX, lane);
-                        }
-                        float eb[LB_BS - 1];
-#pragma unroll
-                        for (int k = 1; k < LB_BS; ++k) eb[k - 1] = dot3_part(SP[k - 1], y);
-                        wave_sum_multi(eb);
-#pragma unroll
-                        for (int k = 1; k < LB_BS; ++k) {
-                            const int i_ = n1 - 1 - k;
-                            const float e = eb[k - 1];
-                            int t_ = hd1 + i_; t_ = t_ >= SFX_HIST ? t_ - SFX_HIST : t_;
-                            if (lane == 0 && i_ >= 0) gst->syb[t_ * LB_BS + k] = e;
-                        }
-                    }
                 }
                 LB_SYNC();
                 TMARK(3);
@@ -580,10 +648,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
                     if (n == 0) {
                         for (int e = 0; e < NE3; ++e) r.v[e] = q.v[e] * hd;
                     } else {
-                        st3_full(cp.q, q, lane);
-                        if (lane == 0) { cp.n = n; cp.head = s.hist_head; cp.hd = hd; cp.req = 1; }
-                        if (NW > 1) __syncthreads(); else LB_SYNC();       // helpers wake up here
-                        r = lb_two_loop<NW>(hS, hY, gst, s_al, cp, 0, lane);
+                        r = lb_two_loop<SETS>(hS, hY, gst, s_al, n, s.hist_head, hd, q, lane);
                     }
                 }
                 TMARK(5);
@@ -780,31 +845,14 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
 #undef VEC
 }
 
-// Entry for a workgroup of NW wavefronts (tid = thread index in the workgroup): wavefront 0 runs the
-// state machine; the others wait at a workgroup barrier and join it for every two-loop recursion it
-// announces (cp.req = 1), until it releases them (cp.req = 0).  Every wavefront executes the same
-// number of barriers.
-template <int NW>
+// Entry for a workgroup: wavefront 0 runs the state machine, the others pass through.  SETS: see lb_two_loop.
+template <int SETS>
 __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDev& D, const VarList* __restrict__ vls,
                                                 int first_stage, int last_stage, int init, int step_mode,
-                                                const int b, const int tid, float* s_al, OptScal& s_state, LbCoop& cp,
+                                                const int b, const int tid, float* s_al, OptScal& s_state,
                                                 const float* f_src, const float* g_src) {
-    const int wv = tid >> 6, lane = tid & 63;
-    if (NW > 1 && wv > 0) {
-        const float* hY = D.hist + (size_t)b * 2 * SFX_HIST * SFX_NVAR_MAX;
-        const float* hS = hY + (size_t)SFX_HIST * SFX_NVAR_MAX;
-        const OptState* gst = reinterpret_cast<const OptState*>(D.opt) + b;
-        for (;;) {
-            __syncthreads();
-            if (!cp.req) return;
-            (void)lb_two_loop<NW>(hS, hY, gst, s_al, cp, wv, lane);
-        }
-    }
-    lbfgs_tick_wave0<NW>(M, D, vls, first_stage, last_stage, init, step_mode, b, lane, s_al, s_state, cp, f_src, g_src);
-    if (NW > 1) {
-        if (lane == 0) cp.req = 0;
-        __syncthreads();
-    }
+    if (tid >= 64) return;
+    lbfgs_tick_wave0<SETS>(M, D, vls, first_stage, last_stage, init, step_mode, b, tid, s_al, s_state, f_src, g_src);
 }
 
 

@@ -22,6 +22,8 @@
 #define SFX_JPAD 56         // joints padded to an even MFMA depth
 #define SFX_MAX_LEVELS 16
 #define SFX_HIST 100        // L-BFGS history (optim_factory 'lbfgsls' default)
+#define SFX_HROWS (SFX_HIST + 8)   // ring of SFX_HIST slots + rows HIST..HIST+7 mirroring slots 0..7: any 8 consecutive
+                                  // members of the window are 8 consecutive rows (lbfgs_body.h lb_load)
 #define SFX_NVAR_MAX 192    // optimiser vector length (182 / 88 / 6), padded to 3*64
 #define SFX_FWD_N 6016      // floats per frame of saved forward state (FrameLDS prefix incl. the fp64 transforms + 96 + VPoser 1280)
 #define SFX_NPAR_MAX 256    // canonical per-frame parameter block (182 with 12 hand components; 248 with all 45: forward only)
@@ -168,7 +170,7 @@ struct BatchDev {
     int*   stage;      // [B] current stage (-1 camera, 0.. body, n_stages = done)
     void*  opt;        // [B] OptState
     float* vec;        // [B][NVEC][NVAR_MAX] optimiser vectors
-    float* hist;       // [B][2][HIST][NVAR_MAX]
+    float* hist;       // [B][2][HROWS][NVAR_MAX]
     int*   n_active;   // [1] frames not done
     float* stage_loss; // [B][1+MAX_STAGES]
     int*   stage_evals;     // [B][1+MAX_STAGES]
@@ -231,6 +233,7 @@ void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s);
 void launch_lbfgs_tick(const DevModel& M, const BatchDev& D, const VarList* vl_dev, int first_stage,
                        int last_stage, int init, int step_mode, hipStream_t s);
 size_t sfx_optstate_size();
+int debug_two_loop(const float* S, const float* Y, int cnt, const float* g, float* d_out);   // lbfgs.hip (host pointers)
 void launch_fit_rows(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
                      int first_stage, int last_stage, int max_ticks, hipStream_t s);
 void launch_tick_dense(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,

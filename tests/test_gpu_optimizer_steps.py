@@ -172,3 +172,42 @@ def test_first_body_stage_steps_match_the_machine(synth_model, cfg_body):
     _compare(dev[:k10], mac[:k10], 1e-5, "first body stage, first ten line searches", whole_stage=False, t_rtol=1e-3)
     assert abs(dev[-1, 1] - mac[-1, 1]) <= 1e-3 * abs(mac[-1, 1]), (dev[-1], mac[-1])
     assert abs(dev[-1, 2] - mac[-1, 2]) <= 0.1 * mac[-1, 2], (dev[-1], mac[-1])
+
+
+def _two_loop_fp64(S, Y, g):
+    """lbfgs_ls.py:312-341 in float64: direction from the window's pairs (oldest first)."""
+    ro = 1.0 / np.einsum("ij,ij->i", Y, S)
+    q = -g.astype(np.float64)
+    al = np.zeros(len(S))
+    for i in range(len(S) - 1, -1, -1):
+        al[i] = ro[i] * S[i].dot(q)
+        q = q - al[i] * Y[i]
+    r = q * (Y[-1].dot(S[-1]) / Y[-1].dot(Y[-1]))
+    for i in range(len(S)):
+        be = ro[i] * Y[i].dot(r)
+        r = r + (al[i] - be) * S[i]
+    return r
+
+
+@pytest.mark.parametrize("count", [1, 5, 8, 9, 16, 23, 100, 101, 104, 107, 108, 115, 199, 200, 257])
+def test_blocked_two_loop_matches_the_sequential_recursion(count):
+    """The device's blocked recursion (8 pairs per block, band of S^T Y, mirrored ring) against the sequential one in fp64 on
+    the same pairs, for window lengths that leave partial blocks and ring positions that wrap at every offset: 2e-5 of the
+    direction's norm (fp32 dot products of 182 terms), i.e. no block, band entry or mirror row is ever the wrong one."""
+    import ctypes as C
+    from smplifyx_amd import _capi
+    rng = np.random.default_rng(count)
+    N, W = 182, 192
+    Hm = rng.standard_normal((N, N)) / np.sqrt(N); Hm = Hm @ Hm.T + 0.5 * np.eye(N)      # an SPD "Hessian": y = H s keeps y.s > 0
+    S = np.zeros((count, W), np.float32); Y = np.zeros((count, W), np.float32)
+    S[:, :N] = rng.standard_normal((count, N)) * 0.1
+    Y[:, :N] = (S[:, :N].astype(np.float64) @ Hm).astype(np.float32)
+    g = np.zeros(W, np.float32); g[:N] = rng.standard_normal(N)
+    d = np.zeros(W, np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    _capi.check(_capi.load().sfx_debug_two_loop(p(S), p(Y), count, p(g), p(d)))
+    w = slice(max(0, count - 100), count)
+    ref = _two_loop_fp64(S[w, :N].astype(np.float64), Y[w, :N].astype(np.float64), g[:N])
+    assert np.all(d[N:] == 0)
+    err = np.abs(d[:N] - ref).max() / np.abs(ref).max()
+    assert err < 2e-5, (count, err)
