@@ -103,7 +103,8 @@ struct __align__(16) FrameLDSx {
     float vp[MAXI * 3];            // v_posed of the items (template + blend offsets), for the reverse sweep
     float vpo[MAXI * 3];           // the blend offsets alone (small numbers: fp32 sums of them carry ~1e-10 m)
     float vt[MAXI * 3];            // v_template rows of the items
-    float T[kScratch];             // item transforms [MAXI][12]; reused as scratch (>= 2048 floats) by the reverse sweep
+    alignas(16) float T[kScratch]; // item transforms [MAXI][12]; reused as scratch (>= 2048 floats) by the reverse sweep and, between
+                                   // evaluations, as the working set of the optimiser tick (float4 accesses)
     fwd_t cd[2 * SFX_J * 12];     // kinematic chain in fp64: the two buffers of the pointer-jumping rounds
     fwd_t Jd[SFX_J * 3];          // rest joints, fp64
     fwd_t jd[SFX_MAX_K * 3];      // mapped joints, fp64 (what the projection reads)

@@ -34,7 +34,7 @@ void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const S
         // (one wavefront: sharing the dot products of the two-loop recursion between four was measured slower --
         //  a workgroup barrier per block of 8 history pairs costs more than the reductions it removes)
         if (threadIdx.x < 64)
-            lbfgs_tick_body<2>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, &fval, gflat);
+            lbfgs_tick_body<2>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, S.T, &fval, gflat);      // (S.T: >= 2048 floats of closure scratch, dead between evaluations)
         __syncthreads();
     }
 }
@@ -64,7 +64,7 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
         // (one wavefront: sharing the dot products of the two-loop recursion between four was measured slower --
         //  a workgroup barrier per block of 8 history pairs costs more than the reductions it removes)
         if (threadIdx.x < 64)
-            lbfgs_tick_body<3>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, &fval, gflat);
+            lbfgs_tick_body<(OCC == 1 ? 3 : 2)>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, S.T, &fval, gflat);      // (S.T: >= 2048 floats of closure scratch, dead between evaluations)
         __syncthreads();
         if (D.dbg && b == 0 && threadIdx.x == 0 && D.dbg[62] <= D.dbg[61]) { D.dbg[25] = clock64(); for (int i = 0; i < 17; ++i) D.dbg[40 + i] = D.dbg[i]; }
         if (D.stage[b] > last_stage) return;

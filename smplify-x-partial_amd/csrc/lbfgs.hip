@@ -8,8 +8,9 @@ void k_lbfgs_tick(DevModel M, BatchDev D, const VarList* __restrict__ vls, int f
                   int init, int step_mode) {
     __shared__ float s_al[SFX_HIST + 2 * LB_BS];
     __shared__ OptScal s_state;
+    __shared__ __align__(16) float s_work[2048];
     const int b = blockIdx.x;
-    lbfgs_tick_body<3>(M, D, vls, first_stage, last_stage, init, step_mode, b, threadIdx.x, s_al, s_state,
+    lbfgs_tick_body<3>(M, D, vls, first_stage, last_stage, init, step_mode, b, threadIdx.x, s_al, s_state, s_work,
                     D.f + b, D.g + (size_t)b * SFX_NVAR_MAX);
 }
 

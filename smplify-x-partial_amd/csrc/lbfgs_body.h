@@ -444,19 +444,20 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
 }
 
 // One tick of frame b's optimiser, executed by ONE wavefront (lanes 0..63).  f_in / g_in: the
-// closure result (global D.f/D.g, or LDS copies in fused kernels).  s_al[SFX_HIST + 2 * LB_BS] and s_state
+// closure result (global D.f/D.g, or LDS copies in fused kernels).  s_al[SFX_HIST + 2 * LB_BS], s_state and
+// s_work[2048] (the tick's working copies; may alias any LDS that is dead during the tick)
 // are LDS scratch owned by the caller.
 template <int SETS>
 __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchDev& D, const VarList* __restrict__ vls,
                                                  int first_stage, int last_stage, int init, int step_mode,
-                                                 const int b, const int lane, float* s_al, OptScal& s_state,
+                                                 const int b, const int lane, float* s_al, OptScal& s_state, float* s_work,
                                                  const float* f_src, const float* g_src) {
     const BatchCfgDev& C = D.cfg;
     OptState* gst = reinterpret_cast<OptState*>(D.opt) + b;
     int stage = D.stage[b];
-    float* X = D.X + (size_t)b * SFX_NPAR_MAX;
-    float* Xt = D.Xt + (size_t)b * SFX_NPAR_MAX;
-    float* vec = D.vec + (size_t)b * NVEC * SFX_NVAR_MAX;
+    float* Xg = D.X + (size_t)b * SFX_NPAR_MAX;          // global homes of the parameters, the trial point and the vectors;
+    float* Xtg = D.Xt + (size_t)b * SFX_NPAR_MAX;        // a tick works on LDS copies (below)
+    float* vecg = D.vec + (size_t)b * NVEC * SFX_NVAR_MAX;
     float* hY = D.hist + (size_t)b * 2 * SFX_HROWS * SFX_NVAR_MAX;
     float* hS = hY + (size_t)SFX_HROWS * SFX_NVAR_MAX;
 #define VEC(k) (vec + (k) * SFX_NVAR_MAX)
@@ -484,12 +485,12 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
                 D.stage_ref_evals[(size_t)b * (1 + SFX_MAX_STAGES) + q] = 0;
             }
         }
-        for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
+        for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xtg[i] = Xg[i];
         return;
     }
     if (init == 2) {           // resume after a pause (optimizer.step granularity): keep the state
         if (stage >= 900 && lane == 0) D.stage[b] = stage - 1000;   // camera stage -1 pauses as 999
-        for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
+        for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xtg[i] = Xg[i];
         return;
     }
     if (stage > last_stage) return;
@@ -499,13 +500,32 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
         if (i) D.dbg[32 + (i)] += c_ - tm_prev; else D.dbg[63] += 1; tm_prev = c_; } } while (0)
     TMARK(0);
 
-    // scalar state lives in LDS for the duration of the tick: every lane reads (broadcast) and
-    // writes (identical values) the same words, so the single wavefront stays uniform
-    if (lane == 0) s_state = gst->s;
-    LB_SYNC();
-    OptScal& s = s_state;
+    // Working set in LDS for the duration of the tick, fetched in ONE round trip and written back at the end: the scalar
+    // state (every lane reads -- broadcast -- and writes -- identical values -- the same words, so the single wavefront
+    // stays uniform), the NVEC optimiser vectors, the parameters X and the trial point Xt.  The state machine below
+    // stores a vector and reads it back a few lines later many times per tick: through global memory each of those is
+    // an L2 round trip plus a fence (~10 of them in the common path), in LDS ~100 cycles.
+    static_assert(NVEC * SFX_NVAR_MAX + 2 * SFX_NPAR_MAX <= 2048 && SFX_NPAR_MAX == 4 * 64, "s_work: 2048 floats");
+    float* vec = s_work;
+    float* X = s_work + NVEC * SFX_NVAR_MAX;
+    float* Xt = X + SFX_NPAR_MAX;
     const VarList& vl = vls[stage < 0 ? 0 : 1];
     int N = vl.n;
+    int idx3[NE3];           // this lane's parameter slots (vl.idx: 6 bytes per lane, once per tick)
+    {
+        Lane3 wv_[NVEC];
+#pragma unroll
+        for (int k = 0; k < NVEC; ++k) wv_[k] = ld3_raw(vecg, (unsigned)k * SFX_NVAR_MAX, lane);
+        const float4 x4 = reinterpret_cast<const float4*>(Xg)[lane], xt4 = reinterpret_cast<const float4*>(Xtg)[lane];
+#pragma unroll
+        for (int e = 0; e < NE3; ++e) idx3[e] = vl.idx[3 * lane + e];
+        if (lane == 0) s_state = gst->s;
+#pragma unroll
+        for (int k = 0; k < NVEC; ++k) st3_full(vec + k * SFX_NVAR_MAX, wv_[k], lane);
+        reinterpret_cast<float4*>(X)[lane] = x4; reinterpret_cast<float4*>(Xt)[lane] = xt4;
+    }
+    LB_SYNC();
+    OptScal& s = s_state;
     const double tol_change = 1e-9;
     const int max_iter = C.maxiters, max_eval = C.max_eval, max_ls = 25;
 
@@ -515,14 +535,14 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
     int glast_cached = 0;
     s.evals += 1; s.ref_evals += 1;
 
-    auto gather_x = [X, lane, N, &vl]() { Lane3 r;
-        for (int e = 0; e < NE3; ++e) { const int i = 3 * lane + e; r.v[e] = (i < N) ? X[vl.idx[i]] : 0.f; } return r; };
-    auto write_trial = [X, Xt, vec, lane, N, &vl](Sc t) {
+    auto gather_x = [X, lane, N, &idx3]() { Lane3 r;
+        for (int e = 0; e < NE3; ++e) { const int i = 3 * lane + e; r.v[e] = (i < N) ? X[idx3[e]] : 0.f; } return r; };
+    auto write_trial = [X, Xt, vec, lane, N, &idx3](Sc t) {
         const Lane3 xi = ld3(VEC(VEC_XINIT), lane, N), d = ld3(VEC(VEC_D), lane, N);
         const Lane3 xt = axpy3(xi, (float)t.v, d);
         for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xt[i] = X[i];
         LB_SYNC();
-        for (int e = 0; e < NE3; ++e) { const int i = 3 * lane + e; if (i < N) Xt[vl.idx[i]] = xt.v[e]; }
+        for (int e = 0; e < NE3; ++e) { const int i = 3 * lane + e; if (i < N) Xt[idx3[e]] = xt.v[e]; }
     };
 #define armijo_fail(f_new, t) sc_gt((f_new), sc_add(s.ls_f0, sc_mul(sc_mul(P(1e-4), (t)), s.ls_gtd0)))
 #define curv_ok(gtd_new) sc_le(sc_abs(gtd_new), sc_mul(P(-0.9), s.ls_gtd0))
@@ -709,7 +729,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
             st3(VEC(VEC_G), g, lane, N);
             const Lane3 xi = ld3(VEC(VEC_XINIT), lane, N), d = ld3(VEC(VEC_D), lane, N);
             const Lane3 xn = axpy3(xi, (float)t.v, d);
-            for (int e = 0; e < NE3; ++e) { const int i = 3 * lane + e; if (i < N) X[vl.idx[i]] = xn.v[e]; }
+            for (int e = 0; e < NE3; ++e) { const int i = 3 * lane + e; if (i < N) X[idx3[e]] = xn.v[e]; }
             s.cache_valid = 1;
             const bool opt_cond = sc_le(T(absmax3(g, lane, N)), P((double)1e-5));
             s.cur_evals += s.ls_evals; s.func_evals += s.ls_evals;
@@ -838,7 +858,12 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
     }
     TMARK(6);
     LB_SYNC();
-    if (lane == 0) gst->s = s_state;     // ro[] is written in place
+    // write the working set back
+#pragma unroll
+    for (int k = 0; k < NVEC; ++k) st3_full(vecg + k * SFX_NVAR_MAX, ld3_raw(vec, (unsigned)k * SFX_NVAR_MAX, lane), lane);
+    reinterpret_cast<float4*>(Xg)[lane] = reinterpret_cast<const float4*>(X)[lane];
+    reinterpret_cast<float4*>(Xtg)[lane] = reinterpret_cast<const float4*>(Xt)[lane];
+    if (lane == 0) gst->s = s_state;     // ro[] and the band tables are written in place
     TMARK(7);
 #undef TMARK
 #undef TRACE
@@ -849,10 +874,10 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
 template <int SETS>
 __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDev& D, const VarList* __restrict__ vls,
                                                 int first_stage, int last_stage, int init, int step_mode,
-                                                const int b, const int tid, float* s_al, OptScal& s_state,
+                                                const int b, const int tid, float* s_al, OptScal& s_state, float* s_work,
                                                 const float* f_src, const float* g_src) {
     if (tid >= 64) return;
-    lbfgs_tick_wave0<SETS>(M, D, vls, first_stage, last_stage, init, step_mode, b, tid, s_al, s_state, f_src, g_src);
+    lbfgs_tick_wave0<SETS>(M, D, vls, first_stage, last_stage, init, step_mode, b, tid, s_al, s_state, s_work, f_src, g_src);
 }
 
 
