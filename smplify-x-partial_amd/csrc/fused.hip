@@ -61,11 +61,17 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
         a.stage_override = -2; a.use_dense_verts = 1; a.reuse_fwd = 1;
         closure_body(S, M, D, vls, sws, a, b, gflat, &fval);
         __syncthreads();
+        const long long wc1 = D.dbg ? wall_clock64() : 0;
         // (one wavefront: sharing the dot products of the two-loop recursion between four was measured slower --
         //  a workgroup barrier per block of 8 history pairs costs more than the reductions it removes)
         if (threadIdx.x < 64)
             lbfgs_tick_body<(OCC == 1 ? 3 : 2)>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, S.T, &fval, gflat);      // (S.T: >= 2048 floats of closure scratch, dead between evaluations)
         __syncthreads();
+        if (D.dbg && threadIdx.x == 0) {       // debug: mean duration of the two segments over all workgroups (100 MHz ticks)
+            const long long wc2 = wall_clock64();
+            atomicAdd((unsigned long long*)&D.dbg[29], (unsigned long long)(wc1 - wc0));
+            atomicAdd((unsigned long long*)&D.dbg[30], (unsigned long long)(wc2 - wc1));
+        }
         if (D.dbg && b == 0 && threadIdx.x == 0 && D.dbg[62] <= D.dbg[61]) { D.dbg[25] = clock64(); for (int i = 0; i < 17; ++i) D.dbg[40 + i] = D.dbg[i]; }
         if (D.stage[b] > last_stage) return;
     }
