@@ -12,16 +12,15 @@
 // float32 whenever a tensor takes part.  `Sc` carries that distinction so that every
 // branch is decided on identically rounded numbers.  Compile with -ffp-contract=off: the
 // only fused multiply-adds are the explicit fmaf() of the axpy updates (ATen's
-// add_(alpha) vector path).
+// add_(alpha) vector path) and of the lane partials of the two-loop recursion's dot products
+// (a 64-lane summation tree that no ATen kernel shares anyway).
 #pragma once
 #include "sfx_internal.h"
 #include "wave_ops.h"
 // every multiply-add in this file is written out: no implicit contraction (see header comment)
 #pragma clang fp contract(off)
+#define LB_BS 8       // history pairs per block of the blocked two-loop recursion (one group of 8 lanes per member)
 // single-wavefront synchronisation: order LDS/global accesses of the 64 lanes
-#ifndef LB_BS
-#define LB_BS 8       // history pairs per block of the blocked two-loop recursion (LB_BS^2 = 64 band lanes)
-#endif
 #define LB_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 enum { PH_ENTRY = 0, PH_BRACKET = 1, PH_ZOOM = 2 };
@@ -155,37 +154,6 @@ __device__ __forceinline__ Lane3 ld3_raw(const float* base, unsigned row_off, in
 }
 __device__ __forceinline__ void st3_full(float* p, const Lane3& a, int lane) {
     *reinterpret_cast<float3*>(p + 3 * lane) = make_float3(a.v[0], a.v[1], a.v[2]);
-}
-// BS wavefront sums at once: the DPP steps of the BS independent reductions are issued
-// back to back, which also covers the VALU->DPP wait states
-template <int NB>
-__device__ __forceinline__ void wave_sum_multi(float (&x)[NB]) {
-    // written as DPP adds that update the register in place (rows masked off by row_mask keep
-    // their value, which is the "+0" of the scan), 6 instructions per value.  Inline asm is not
-    // seen by the hazard recogniser: the empty statements pin every producer before the s_nop,
-    // and consecutive DPP reads of one register are NB-1 >= 2 instructions apart.
-#pragma unroll
-    for (int c = 0; c < NB; ++c) asm volatile("" : "+v"(x[c]));
-    asm volatile("s_nop 1");
-#define LB_DPP_STEP(ctl)                                                                                   \
-    _Pragma("unroll") for (int c = 0; c < NB; ++c) asm volatile("v_add_f32_dpp %0, %0, %0 " ctl : "+v"(x[c])); \
-    if (NB < 3) asm volatile("s_nop 1");
-    LB_DPP_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-    LB_DPP_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-    LB_DPP_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-    LB_DPP_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-    LB_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-    LB_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
-#undef LB_DPP_STEP
-    asm volatile("s_nop 1");
-#pragma unroll
-    for (int c = 0; c < NB; ++c) x[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[c]), 63));
-}
-__device__ __forceinline__ float dot3_part(const Lane3& a, const Lane3& b) {
-    float p = a.v[0] * b.v[0];
-    p = p + a.v[1] * b.v[1];
-    p = p + a.v[2] * b.v[2];
-    return p;
 }
 __device__ __forceinline__ void st3(float* p, const Lane3& a, int lane, int N) {
 #pragma unroll
