@@ -395,6 +395,25 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
         }
         M.jk_type = m->mem.up(jt); M.jk_src = m->mem.up(js); M.jk_item0 = m->mem.up(ji0); M.jk_nitem = m->mem.up(jn);
         M.item_vid = m->mem.up(ivid); M.item_w = m->mem.up(iw); M.item_dyn = m->mem.up(idyn); M.item_k = m->mem.up(ik);
+        {   // template rows and packed skinning weights of the items, gathered per item: the per-frame kernels fetch them at
+            // entry in ONE round trip (through item_vid it took two, in every launch of the tick kernel)
+            const size_t ni = ivid.size();
+            std::vector<float> svt(ni * 3, 0.f), sww(ni * SFX_NW, 0.f); std::vector<int> swj(ni * SFX_NW, 0);
+            for (size_t i = 0; i < ni; ++i) {
+                const int v = ivid[i];
+                if (v < 0) continue;
+                for (int c = 0; c < 3; ++c) svt[i * 3 + c] = d->v_template[(size_t)v * 3 + c];
+                int n = 0;
+                for (int j = 0; j < SFX_J; ++j) {
+                    const float w = d->lbs_weights[(size_t)v * SFX_J + j];
+                    if (w == 0.f) continue;
+                    if (n < SFX_NW) { swj[i * SFX_NW + n] = j; sww[i * SFX_NW + n] = w; }
+                    ++n;
+                }
+                if (n > SFX_NW) swj[i * SFX_NW] = -1;      // (same flag as Wsp_j: the full row of lbs_weights is read instead)
+            }
+            M.item_vt = m->mem.up(svt); M.item_wj = m->mem.up(swj); M.item_ww = m->mem.up(sww);
+        }
         {   // distinct vertices of the static items: the dense GEMM hands their v_posed / T to the adjoint pass
             std::vector<int> vslot(M.Vpad, -1), uslot(ivid.size(), -1);
             int nu = 0, nstat = 0;
@@ -542,7 +561,7 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.f = b->mem.zeros<float>(B);
     D.g = b->mem.zeros<float>((size_t)B * SFX_NVAR_MAX);
     D.bodypose = b->mem.zeros<float>((size_t)B * 63);
-    D.featT = b->mem.zeros<float>((size_t)SFX_KD_PAD * D.Bpad);
+    D.featR = b->mem.zeros<float>((size_t)SFX_KD_PAD * D.Bpad);
     D.AT = b->mem.zeros<float>((size_t)12 * SFX_JPAD * D.Bpad);
     D.verts = b->mem.zeros<float>((size_t)B * m->M.V * 3);
     D.fwd = b->mem.zeros<float>((size_t)B * SFX_FWD_N);
@@ -731,10 +750,10 @@ extern "C" int sfx_batch_debug_read(sfx_batch* b, const char* name, float* out, 
         const size_t rows = k == "A" ? (size_t)12 * SFX_JPAD : SFX_KD_PAD, per = k == "A" ? (size_t)12 * SFX_J : SFX_KD_PAD;
         if ((int64_t)(per * B) != n_out) { sfx_set_error("'%s' holds %zu floats, caller asked for %lld", name, per * B, (long long)n_out); return -1; }
         std::vector<float> h(rows * D.Bpad);
-        SFX_CHECK(hipMemcpy(h.data(), k == "A" ? D.AT : D.featT, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+        SFX_CHECK(hipMemcpy(h.data(), k == "A" ? D.AT : D.featR, h.size() * sizeof(float), hipMemcpyDeviceToHost));
         for (int i = 0; i < B; ++i) {
             if (k == "A") { for (int e = 0; e < 12; ++e) for (int j = 0; j < SFX_J; ++j) out[((size_t)i * 12 + e) * SFX_J + j] = h[((size_t)e * SFX_JPAD + j) * D.Bpad + i]; }
-            else for (int q = 0; q < SFX_KD_PAD; ++q) out[(size_t)i * SFX_KD_PAD + q] = h[(size_t)q * D.Bpad + i];
+            else for (int q = 0; q < SFX_KD_PAD; ++q) out[(size_t)i * SFX_KD_PAD + q] = h[(size_t)i * SFX_KD_PAD + q];
         }
         return 0;
     }
@@ -1002,7 +1021,7 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
                     launch_tick_dense(M, Dn, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, s);
                 } else if ((D.nact + 31) / 32 != ((int)run.size() + 31) / 32) {
                     // queue dry and a 32-frame MFMA slice has emptied: compact.  The pending evaluation of every running
-                    // frame lives in column slot[f] of featT / AT, so re-export after remapping (queued behind the rounds
+                    // frame lives in column slot[f] of featR / AT, so re-export after remapping (queued behind the rounds
                     // already in flight, which still use the old mapping consistently).
                     int q = 0;
                     for (int f : run) col[f] = q++;
@@ -1051,7 +1070,7 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
         for (int i = 0; i < B; ++i) if (hp[i] <= last_stage) { done = false; break; }
         if (fused && dense && !done) {
             // compaction: finished frames give up their GEMM columns.  The pending evaluation of
-            // every active frame lives in column slot[b] of featT/AT, so re-export after remapping.
+            // every active frame lives in column slot[b] of featR / AT, so re-export after remapping.
             int n = 0;
             for (int i = 0; i < B; ++i) if (hp[i] <= last_stage) ++n;
             if ((b->D.nact + 31) / 32 != (n + 31) / 32) {      // a 32-frame MFMA tile became free

@@ -252,6 +252,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     const int stage = __builtin_amdgcn_readfirstlane((args.stage_override != -2) ? args.stage_override : D.stage[b]);
     if (stage >= C.n_stages && !args.forward_only) return;      // frame finished
     const bool cam_stage = (stage < 0);
+    const StageW sw = (cam_stage || args.forward_only) ? StageW{} : sws[stage];     // (11 scalars, requested here: the loss section is 20 k cycles away)
 
     MARK(0);
     // ------------------------------------------------------------------ load parameters
@@ -282,16 +283,9 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     // static items (vertex joints, static landmarks): vertex ids, weights, template rows, skinning weights, per-joint
     // adjoint lists -- none of it depends on the pose, so it is fetched here, next to the other tables (one overlapped
     // round trip at kernel entry; a persistent workgroup keeps it for the whole fit), not item by item inside the evaluation
-    for (int i = t; i < M.n_static_items; i += CT) {
-        const int vid = M.item_vid[i];
-        S.ivid[i] = vid; S.iw[i] = M.item_w[i];
-        S.vt[i * 3] = M.v_template[vid * 3]; S.vt[i * 3 + 1] = M.v_template[vid * 3 + 1]; S.vt[i * 3 + 2] = M.v_template[vid * 3 + 2];
-    }
-    for (int w = t; w < M.n_static_items * SFX_NW; w += CT) {
-        const int vid = M.item_vid[w / SFX_NW], q2 = w % SFX_NW;
-        S.wj[w] = M.Wsp_j[(size_t)vid * SFX_NW + q2];
-        S.ww[w] = M.Wsp_w[(size_t)vid * SFX_NW + q2];
-    }
+    for (int i = t; i < M.n_static_items; i += CT) { S.ivid[i] = M.item_vid[i]; S.iw[i] = M.item_w[i]; }
+    for (int w = t; w < M.n_static_items * 3; w += CT) S.vt[w] = M.item_vt[w];
+    for (int w = t; w < M.n_static_items * SFX_NW; w += CT) { S.wj[w] = M.item_wj[w]; S.ww[w] = M.item_ww[w]; }
     if (M.n_sj <= LDS::kMaxItems * SFX_NW) {
         for (int i = t; i <= SFX_J; i += CT) S.sjs[i] = M.sj_start[i];
         for (int i = t; i < M.n_sj; i += CT) { S.sji[i] = M.sj_item[i]; S.sjw[i] = M.sj_w[i]; }
@@ -460,11 +454,16 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     // ------------------------------------------------------------------ dense export
     if (args.export_dense) {
         const int slot = D.slot[b];      // column of this frame in the GEMM operands (compacted)
-        for (int k = t; k < M.KD; k += CT) D.featT[(size_t)k * D.Bpad + slot] = S.feat[k];
+        // coefficients of this frame: one contiguous 2-KiB row (entries >= KD are zero).  (As a COLUMN of a [K][frames]
+        // matrix -- what the GEMM's A operand looks like in LDS -- these were 506 scattered 4-byte writes per frame into
+        // lines shared by 32 frames: 10 k cycles of the launch; the GEMM transposes while staging instead.)
+        if (t < SFX_KD_PAD / 4) reinterpret_cast<float4*>(D.featR + (size_t)slot * SFX_KD_PAD)[t] = reinterpret_cast<const float4*>(S.feat)[t];
+        MARK(17);
         for (int i = t; i < SFX_J * 12; i += CT) {
             const int j = i / 12, e = i % 12;
             D.AT[((size_t)e * SFX_JPAD + j) * D.Bpad + slot] = S.A[i];
         }
+        MARK(18);
         if (args.forward_only == 2) {           // export pass only: keep the forward state for the adjoint pass
             if (fwd) {
                 const float* sp = reinterpret_cast<const float*>(&S);
@@ -480,6 +479,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
                     if (t < 64) vx[2 * VP_H + 128 + t] = S.V.body[t];
                 }
             }
+            MARK(19);
             return;
         }
     }
@@ -629,7 +629,6 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     const float* ct = S.x + L.cam_t;
     const float dw2 = dwt * dwt;
     const float rho2 = C.rho * C.rho;
-    const StageW sw = cam_stage ? StageW{} : sws[stage];
 
     MARK(20);
     float csum = 1.f;
@@ -869,6 +868,17 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     // because G_d = G_j . Rel(j->d).  Pass A forms M_d = loc_d . Gh_d^T (stored at the DFS
     // pre-order position of d), pass B sums contiguous pre-order ranges in fixed order (no
     // atomics -> deterministic), pass C applies Gh_j^-T.  Then dR, d(rel) (pass D) and dJ (pass E).
+    // (the 14 joint-regressor entries this thread needs for d(coefficients) below are requested here: they come from
+    //  global memory and have the whole chain adjoint to arrive)
+    float jdv[14];
+    {
+        const int l = t % 20, ch = t / 20;
+#pragma unroll
+        for (int i = 0; i < 14; ++i) {
+            const int row = ch * 14 + i;
+            jdv[i] = (ch < 12 && l < M.S && row < SFX_J * 3) ? M.J_dirs[(size_t)row * M.S + l] : 0.f;
+        }
+    }
     for (int w = t; w < SFX_J * 3; w += CT) {
         const int j = w / 3, r = w % 3;
         float acc = 0.f;
@@ -957,12 +967,10 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         S.dpose[3 * t] += dth[0]; S.dpose[3 * t + 1] += dth[1]; S.dpose[3 * t + 2] += dth[2];
     }
     {   // d(coefficients) = dfeat[0..S) + J_dirs^T dJ : 12 partial sums of 14 rows per coefficient
-        const int l = t % 20, ch = t / 20;
+        const int ch = t / 20;
         float acc = 0.f;
-        if (ch < 12 && l < M.S) {
-            const int i1 = (ch * 14 + 14 < SFX_J * 3) ? ch * 14 + 14 : SFX_J * 3;
-            for (int i = ch * 14; i < i1; ++i) acc += M.J_dirs[(size_t)i * M.S + l] * S.dJ[i];
-        }
+#pragma unroll
+        for (int i = 0; i < 14; ++i) { const int row = ch * 14 + i; acc += jdv[i] * S.dJ[row < SFX_J * 3 ? row : 0]; }      // (rows past the end: jdv = 0)
         S.red[t] = acc;
     }
     __syncthreads();

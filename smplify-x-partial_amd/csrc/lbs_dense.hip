@@ -6,8 +6,8 @@
 //     T       = lbs_weights . A                                                   (K = 55)
 //     verts   = T[:3,:3] v_posed + T[:3,3]
 // as two GEMMs sharing one output tile:  rows = frames (M), cols = vertices (N).
-//   A operand  featT[k][b]      (written per frame by the tick kernel's export pass; 512 rows,
-//                                rows >= 506 are zero)
+//   A operand  featR[b][k]      (one 2-KiB row per frame, written by the tick kernel's export pass; entries
+//                                >= 506 are zero); transposed to [k-chunk][frame] order while staged into LDS
 //   B operand  dirs[k][3*v + c] (the .npz posedirs layout [486, 3V]: 3 coords interleaved; rows
 //                                padded to 3*Vpad floats and to 512 rows)
 // Work unit = one wavefront = 16 vertices x 32 frames (two 16x16 MFMA tiles): 6 accumulators
@@ -33,12 +33,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define FB 128           // frames per workgroup
 #define VB 16            // vertices per workgroup
 #define NB3 (VB * 3)     // 48 floats of dirs per K row
-#define LDA (FB + 16)    // padded row stride: the K rows of one MFMA operand fetch hit distinct banks
+#define LDK (KC + 4)     // padded K stride of a frame's row in LDS: the 16 frames x 4 K rows of one MFMA operand fetch hit 64 distinct banks
 #define LDB NB3
 #define B4 (KC * NB3 / 4)      // float4 per dirs chunk (384)
 
 struct __align__(16) DenseLDS {
-    float a[2][KC][LDA];
+    float a[2][FB][LDK];     // [frame][k]: written as float4 along k (the global layout), read one (frame, k) per lane
     float b[2][KC][LDB];
 };
 
@@ -77,15 +77,15 @@ void k_lbs_dense(DevModel M, BatchDev D) {
 
     // staging: 1024 (feat) + 384 (dirs) float4 per chunk: slots tid + q*256; q = 0..3 -> feat rows,
     // slot 4 -> dirs, slot 5 (tid < 128) -> dirs
-    const float4* gA = reinterpret_cast<const float4*>(D.featT + fb0);
+    const float4* gA = reinterpret_cast<const float4*>(D.featR + (size_t)fb0 * SFX_KD_PAD);
     const float4* gB = reinterpret_cast<const float4*>(M.dirs + (size_t)v0 * 3);
-    const int Bp4 = (int)(Bp / 4), LD4 = (int)(LD / 4);
-    const int stepA = KC * Bp4, stepB = KC * LD4;
+    const int LD4 = (int)(LD / 4);
+    const int stepA = KC / 4, stepB = KC * LD4;
     int gA_off[4], lA_off[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = tid + q * DT, row = idx / (FB / 4), c4 = idx % (FB / 4);
-        gA_off[q] = row * Bp4 + c4; lA_off[q] = row * LDA + c4 * 4;
+    for (int q = 0; q < 4; ++q) {       // thread -> (frame, 4 consecutive k): 8 threads cover the 128 bytes a frame contributes to a chunk
+        const int idx = tid + q * DT, f = idx / (KC / 4), k4 = idx % (KC / 4);
+        gA_off[q] = f * (SFX_KD_PAD / 4) + k4; lA_off[q] = f * LDK + k4 * 4;
     }
     const int i4 = tid, i5 = tid + DT;
     const bool ok5 = i5 < B4;
@@ -122,11 +122,11 @@ void k_lbs_dense(DevModel M, BatchDev D) {
         const int cur = c & 1;
         if (c + 1 < NCHUNK) STAGE_LOAD(KCHUNK(c + 1));
         if (active) {
-            const float* sa = &S.a[cur][kq][wv * 32 + jl];
+            const float* sa = &S.a[cur][wv * 32 + jl][kq];
             const float* sb = &S.b[cur][kq][jl * 3];
 #pragma unroll
             for (int ks = 0; ks < KC / 4; ++ks) {
-                const float a0 = sa[ks * 4 * LDA], a1 = sa[ks * 4 * LDA + 16];
+                const float a0 = sa[ks * 4], a1 = sa[16 * LDK + ks * 4];
                 const float bx = sb[ks * 4 * LDB], by = sb[ks * 4 * LDB + 1], bz = sb[ks * 4 * LDB + 2];
                 ax0 = MFMA(a0, bx, ax0); ay0 = MFMA(a0, by, ay0); az0 = MFMA(a0, bz, az0);
                 ax1 = MFMA(a1, bx, ax1); ay1 = MFMA(a1, by, ay1); az1 = MFMA(a1, bz, az1);

@@ -110,6 +110,9 @@ struct DevModel {
     const int* item_uslot;     // [n_items] export index of a static item's vertex (-1: dynamic item)
     const int*   item_vid;     // [n_items] static vertex id (dynamic items: -1)
     const float* item_w;       // [n_items] static bary weight
+    const float* item_vt;      // [n_items][3] v_template row of the item's vertex     } gathered copies for the static items:
+    const int*   item_wj;      // [n_items][SFX_NW] = Wsp_j[item_vid]                  } one round trip at kernel entry
+    const float* item_ww;      // [n_items][SFX_NW] = Wsp_w[item_vid]                  }
     const int*   item_dyn;     // [n_items] -1, or (landmark*3 + corner) of the dynamic LUT
     const int*   item_k;       // [n_items] owning mapped joint
     const int*   src_k0;       // [J+1] CSR: mapped joints that read kinematic joint s
@@ -156,7 +159,7 @@ struct BatchDev {
     float* g;          // [B][NVAR_MAX] flat gradient at Xt
     float* bodypose;   // [B][63] decoded body pose (VPoser) scratch
     // dense path
-    float* featT;      // [KD_PAD][Bpad]
+    float* featR;      // [Bpad][KD_PAD]: one 2-KiB row of blend-shape coefficients per GEMM column (frame)
     float* AT;         // [12][JPAD][Bpad]
     float* verts;      // [B][V][3]
     float* joints;     // [B][K][3] (export)
@@ -212,9 +215,9 @@ void sfx_set_error(const char* fmt, ...);
 // kernel launchers (defined in the .hip files)
 struct ClosureArgs {
     int stage_override;     // -2: use per-frame stage[]; otherwise stage for all frames
-    int forward_only;       // 1: export joints / full_pose / featT / AT only
+    int forward_only;       // 1: export joints / full_pose / featR / AT only
     int use_dense_verts;    // 1: item vertices come from BatchDev.verts
-    int export_dense;       // 1: write featT / AT for the dense kernel
+    int export_dense;       // 1: write featR / AT for the dense kernel
     int from_X;             // 1: evaluate at X instead of Xt
     int from_scratch_items; // 1: dense mode, but evaluate the item rows here (the GEMM export belongs to another call)
     int keep_tables;        // 1: S.meta / S.fd are still valid from the previous evaluation of this workgroup

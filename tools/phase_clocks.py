@@ -37,6 +37,9 @@ for which in ('body','full'):
     post = np.diff(o[40:57]); pre = np.diff(o[0:9])
     print(which, 'dense tick kernel (last launch): total', int(o[26]-o[24]), 'post-closure+tick', int(o[25]-o[24]), 'pre/export', int(o[26]-o[25]))
     print('    post phases', post.astype(int).tolist()); print('    pre phases', pre.astype(int).tolist())
+    rel = lambda a: [int(x - o[24]) if 0 <= x - o[24] < 1e6 else None for x in a]
+    print('    marks of the loss/adjoint pass relative to kernel entry (cycles; None = not passed in this launch):', rel(o[40:57]))
+    print('    marks of the next-pose pass:', rel(o[0:5]), 'export (feat row, AT, state)', rel(o[17:20]), 'after tick', rel([o[25]]), 'exit', rel([o[26]]))
     print('    mean per workgroup: loss + adjoint %.1f us, optimiser tick %.1f us, rest (next pose / chain / export, entry, exit) %.1f us' % (
         o[29] * 0.01 / max(o[60], 1), o[30] * 0.01 / max(o[60], 1), (o[59] - o[29] - o[30]) * 0.01 / max(o[60], 1)))
     print('    per-workgroup duration of k_tick_dense over the fit: max %.1f us, mean %.1f us over %d workgroup launches' % (o[58] * 0.01, o[59] * 0.01 / max(o[60], 1), o[60]))
