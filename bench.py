@@ -606,7 +606,9 @@ def main():
                                         "note": "latency-bound by construction (one frame's serial L-BFGS chain per workgroup): the "
                                                 "figure to watch is avg_launch_us; bytes = needed-rows adjoint + full history + vectors"}
                 if os.path.exists(pmc):
-                    k = json.load(open(pmc)).get("k_tick_dense", {})
+                    # (a template instantiation: "void k_tick_dense<FrameLDSx<32, false>, 1>"; the variant with most launches)
+                    cands = [v for n, v in json.load(open(pmc)).items() if "k_tick_dense" in n and "hbm_read_bytes_per_launch" in v]
+                    k = max(cands, key=lambda v: v.get("FETCH_SIZE", {}).get("launches", 0)) if cands else {}
                     if "hbm_read_bytes_per_launch" in k:
                         out["roofline_tick"]["traffic"] = k["hbm_read_bytes_per_launch"] + k.get("hbm_write_bytes_per_launch", 0.0)
                         out["roofline_tick"]["traffic_source"] = "replayed: profiles/pmc_summary.json"
