@@ -311,8 +311,15 @@ def make_frame_truth(index, seed=0):
     return truth
 
 
-def make_frames(n, joints_fn, K, start=0, seed=0, focal=5000.0, H=600, W=800):
+def make_frames(n, joints_fn, K, start=0, seed=0, focal=5000.0, H=600, W=800, min_camera_keypoints=None,
+                camera_keypoints=(9, 12, 2, 5)):
     """Synthetic 2-D keypoint frames `start .. start+n-1`.
+
+    min_camera_keypoints: when given, the synthetic detector never loses more than len(camera_keypoints) - that many of
+    the camera-initialisation keypoints (cfg init_joints_idxs: shoulders and hips): the keypoints it would have dropped
+    beyond that are kept, highest index first.  bench.py asks for 3 of 4: a frame with two of them missing has an
+    under-determined camera -- the reference's own fp32 and fp64 runs end such a frame in different basins, with 2-3 x the
+    closure evaluations of a well-posed one -- and one such frame in a rank's share decides that rank's time.
 
     joints_fn(params) -> [n,K,3] mapped model joints for dict `params` of [n,.] float32
     arrays (global_orient, body_pose, betas; everything else zero) -- the caller supplies
@@ -333,6 +340,12 @@ def make_frames(n, joints_fn, K, start=0, seed=0, focal=5000.0, H=600, W=800):
     noise = np.stack([t["kp_noise"][:K] for t in tr])
     conf = np.stack([t["conf"][:K] for t in tr])
     drop = np.stack([t["conf_drop"][:K] for t in tr])
+    if min_camera_keypoints is not None:
+        ck = [int(j) for j in camera_keypoints if int(j) < K]
+        for i in range(n):
+            lost = [j for j in sorted(ck) if drop[i, j]]
+            while len(ck) - len(lost) < min(int(min_camera_keypoints), len(ck)):
+                drop[i, lost.pop()] = False
     kp = np.concatenate([uv + noise, conf[..., None]], -1)
     kp[drop] = 0.0
     reg_pose = np.stack([euler_xyz_from_matrix(rodrigues_np((t["body_pose"] + t["prior_noise"]).reshape(21, 3))).reshape(-1)

@@ -462,7 +462,8 @@ def _bench_task(task):
     cfg = H.load_cfg("fit_smplx_smplifyx.yaml", use_hands=False, use_face=False, use_vposer=False, use_cuda=False)
     cfg["use_camera_prior"] = False
     K = len(H.joint_map_for(cfg))
-    frames = synthetic.make_frames(1, H.oracle_joints_fn(model, cfg), K, start=i, focal=5000.0)
+    frames = synthetic.make_frames(1, H.oracle_joints_fn(model, cfg), K, start=i, focal=5000.0, min_camera_keypoints=3,
+                                   camera_keypoints=cfg.get("init_joints_idxs", (9, 12, 2, 5)))      # (= bench.MIN_CAMERA_KEYPOINTS)
     c = dict(cfg); c["regression_prior"] = "ExPose"
     bp = Rot.from_euler("XYZ", frames["reg_pose"][0].reshape(21, 3).astype(np.float64)).as_matrix().astype(np.float32)
     go = Rot.from_euler("XYZ", frames["reg_global"][0].astype(np.float64)[None]).as_matrix().astype(np.float32)
@@ -518,7 +519,11 @@ def gen_e2e_bench():
                 out[k] = g[k]
         for i in range(have):
             kp[i], rp[i], rg[i] = g["keypoints"][i], g["reg_pose"][i], g["reg_global"][i]
-    tasks = [(i, tag) for i in range(have, n) for tag in ("f32", "f64")]
+    redo = [int(x) for x in os.environ.get("SFX_GOLDEN_BENCH_REDO", "").split(",") if x.strip()]     # frames to fit again
+    for i in redo:
+        for k in [k for k in out if k.startswith("f%d_" % i)]:
+            del out[k]
+    tasks = [(i, tag) for i in list(range(have, n)) + [r for r in redo if r < have] for tag in ("f32", "f64")]
     with mp.get_context("fork").Pool(int(os.environ.get("SFX_GOLDEN_WORKERS", "6"))) as pool:
         results = pool.map(_bench_task, tasks, chunksize=1)
     for i, tag, k_, p_, g_, o in results:
