@@ -544,6 +544,8 @@ def main():
                                    ("configs[1]: %d synthetic frames/GPU, neutral SMPL-X-shaped synthetic model, "
                                     "body-only K=25, camera stage + 5-stage L-BFGS (fit_smplx_smplifyx.yaml weights, "
                                     "use_vposer=False, synthetic regression prior)" % B),
+                       "keypoints": "projected model joints + 1 px noise, confidences U(0.3, 1), 10 %% of the keypoints dropped, at least %d of the "
+                                    "4 camera-initialisation keypoints of a frame kept (a frame without them has no determined camera: DESIGN.md 3.2)" % MIN_CAMERA_KEYPOINTS,
                        "frames_per_gpu": B, "lbs_mode": args.lbs, "groups_per_gpu": args.groups,
                        "gemm_columns_per_gpu": (args.slots if (args.slots and args.lbs == "dense") else B),
                        "parallelism": "frames sharded, dp%d" % world,
