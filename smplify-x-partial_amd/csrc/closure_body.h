@@ -122,7 +122,6 @@ struct __align__(16) FrameLDSx {
     float dA[SFX_J * 12];
     float dG[SFX_J * 12];
     float drel[SFX_J * 3];
-    float dpj[SFX_J * 3];
     float dJ[SFX_J * 3];
     float dR[SFX_J * 9];
     float dfeat[SFX_KD_PAD];
@@ -879,18 +878,16 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
             jdv[i] = (ch < 12 && l < M.S && row < SFX_J * 3) ? M.J_dirs[(size_t)row * M.S + l] : 0.f;
         }
     }
-    for (int w = t; w < SFX_J * 3; w += CT) {
-        const int j = w / 3, r = w % 3;
-        float acc = 0.f;
-        for (int q2 = S.meta[MO_SK0 + j]; q2 < S.meta[MO_SK0 + j + 1]; ++q2) acc += S.dj[S.meta[MO_SKL + q2] * 3 + r];
-        S.dpj[w] = acc;
-    }
-    __syncthreads();
     float* Mpre = S.T;          // scratch: the item transforms are dead here
+    float* Ssub = S.T + 704;    // the subtree sums, before Gh_j^-T is applied (a second 660-float region of the same scratch)
     FOR_CT(w, SFX_J * 12) {
         const int d = w / 12, e = w % 12, r = e >> 2, k = e & 3;
         const float* dAd = &S.dA[d * 12 + r * 4];
-        const float l3 = dAd[3] + S.dpj[d * 3 + r];
+        // gradient on the joint's position from the keypoints mapped to it (a list of one or two entries: summed here by
+        // each of the four threads of the row rather than in a pass of its own)
+        float dpj = 0.f;
+        for (int q2 = S.meta[MO_SK0 + d]; q2 < S.meta[MO_SK0 + d + 1]; ++q2) dpj += S.dj[S.meta[MO_SKL + q2] * 3 + r];
+        const float l3 = dAd[3] + dpj;
         float v = l3;
         if (k < 3) {
             const float* Gk = &S.G[d * 12 + k * 4];
@@ -905,30 +902,18 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         const int q0 = S.meta[MO_PRE + j], n = S.meta[MO_SUB + j];
         float acc = 0.f;
         for (int q2 = 0; q2 < n; ++q2) acc += Mpre[(q0 + q2) * 12 + e];
-        S.dG[w] = acc;          // subtree sum, still in the basis of the world frame
+        Ssub[w] = acc;          // subtree sum, still in the basis of the world frame
     }
     __syncthreads();
-    {
-        static_assert(SFX_J * 12 <= 3 * CT, "three elements per thread");
-        float vv[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int w = t + i * CT;
-            vv[i] = 0.f;
-            if (w < SFX_J * 12) {
-                const int j = w / 12, e = w % 12, r = e >> 2, c = e & 3;
-                const float* Sj = &S.dG[j * 12 + r * 4];
-                float v = Sj[3];
-                if (c < 3) {
-                    const float* Gj = &S.G[j * 12];
-                    v = Gj[c] * (Sj[0] - Sj[3] * Gj[3]) + Gj[4 + c] * (Sj[1] - Sj[3] * Gj[7]) + Gj[8 + c] * (Sj[2] - Sj[3] * Gj[11]);
-                }
-                vv[i] = v;
-            }
+    FOR_CT(w, SFX_J * 12) {
+        const int j = w / 12, e = w % 12, r = e >> 2, c = e & 3;
+        const float* Sj = &Ssub[j * 12 + r * 4];
+        float v = Sj[3];
+        if (c < 3) {
+            const float* Gj = &S.G[j * 12];
+            v = Gj[c] * (Sj[0] - Sj[3] * Gj[3]) + Gj[4 + c] * (Sj[1] - Sj[3] * Gj[7]) + Gj[8 + c] * (Sj[2] - Sj[3] * Gj[11]);
         }
-        __syncthreads();        // every thread has read the sums it needs before they are overwritten
-#pragma unroll
-        for (int i = 0; i < 3; ++i) if (t + i * CT < SFX_J * 12) S.dG[t + i * CT] = vv[i];
+        S.dG[w] = v;
     }
     __syncthreads();
     FOR_CT(w, SFX_J * 12) {
