@@ -75,3 +75,25 @@ def test_record_widths_follow_the_configuration():
     u = sd.unpack_records(rec, fields)
     assert np.array_equal(u["frame"][:, 0], first + np.arange(B)) and np.all(u["evals"][:, 0] == 18_000_000)
     assert u["betas"].shape == (B, 16) and u["left_hand_pose"].shape == (B, 6) and np.array_equal(u["betas"], res["betas"])
+
+
+def test_benchmark_detector_keeps_three_camera_keypoints_and_matches_the_golden_set():
+    """synthetic.make_frames(min_camera_keypoints=3): no frame loses more than one of the camera-initialisation keypoints,
+    every other keypoint is what the raw detector gives, shards regenerate the same frames, and the first 64 frames are
+    the ones the reference fitted for tests/golden/e2e_bench.npz (bench.py's reference_parity leg relies on that)."""
+    from smplifyx_amd import synthetic
+    K, cam = 25, (9, 12, 2, 5)
+    joints_fn = lambda P: np.tile(np.linspace(-0.5, 0.5, K * 3).reshape(1, K, 3), (len(P["betas"]), 1, 1))   # (any fixed joints)
+    raw = synthetic.make_frames(300, joints_fn, K)
+    kept = synthetic.make_frames(300, joints_fn, K, min_camera_keypoints=BB.MIN_CAMERA_KEYPOINTS, camera_keypoints=cam)
+    present = (kept["keypoints"][:, list(cam), 2] > 0).sum(1)
+    assert present.min() >= 3 and (raw["keypoints"][:, list(cam), 2] > 0).sum(1).min() < 3
+    other = [j for j in range(K) if j not in cam]
+    assert np.array_equal(raw["keypoints"][:, other], kept["keypoints"][:, other])
+    changed = np.flatnonzero((raw["keypoints"] != kept["keypoints"]).any((1, 2)))
+    assert 0 < len(changed) < 30                                  # ~5 % of the frames
+    shard = synthetic.make_frames(40, joints_fn, K, start=100, min_camera_keypoints=3, camera_keypoints=cam)
+    assert np.array_equal(shard["keypoints"], kept["keypoints"][100:140])
+    g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_bench.npz"))
+    assert (g["keypoints"][:, list(cam), 2] > 0).sum(1).min() >= 3
+    assert np.array_equal(g["keypoints"][..., 2] > 0, kept["keypoints"][:64, :, 2] > 0)       # same dropout pattern, frame by frame
