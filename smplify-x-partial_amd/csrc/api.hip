@@ -558,6 +558,7 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.cam = b->mem.zeros<float>((size_t)B * 8);
     D.camR = b->mem.zeros<float>((size_t)B * 9);
     D.regpose = b->mem.zeros<float>((size_t)B * 63);
+    D.fd = b->mem.zeros<float>((size_t)B * FD_N);
     D.f = b->mem.zeros<float>(B);
     D.g = b->mem.zeros<float>((size_t)B * SFX_NVAR_MAX);
     D.bodypose = b->mem.zeros<float>((size_t)B * 63);
@@ -631,6 +632,22 @@ extern "C" void sfx_batch_destroy(sfx_batch* b) {
     delete b;
 }
 
+// gt | conf | jw | cmask | cam | camR | regpose of frame b -> its packed record D.fd[b] (what the closure workgroup
+// loads in one 16-byte copy); launched after every host write to one of the seven arrays
+__global__ void k_pack_fd(BatchDev D, int K) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    float* fd = D.fd + (size_t)b * FD_N;
+    for (int i = t; i < 2 * K; i += blockDim.x) fd[FD_GT + i] = D.gt[(size_t)b * K * 2 + i];
+    for (int i = t; i < K; i += blockDim.x) {
+        fd[FD_CONF + i] = D.conf[(size_t)b * K + i]; fd[FD_JW + i] = D.jw[(size_t)b * K + i]; fd[FD_CMASK + i] = D.cmask[(size_t)b * K + i]; }
+    if (t < 8) fd[FD_CAM + t] = D.cam[(size_t)b * 8 + t];
+    if (t < 9) fd[FD_CAMR + t] = D.camR[(size_t)b * 9 + t];
+    if (t < 63) fd[FD_REG + t] = D.regpose[(size_t)b * 63 + t];
+}
+static void pack_fd(sfx_batch* b, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_fd, dim3(b->D.cfg.B), dim3(128), 0, s, b->D, b->K);
+}
+
 extern "C" int sfx_batch_set_frames(sfx_batch* b, const float* kp, const float* jw, const float* cmask,
                                     const float* cam, const float* camR) {
     if (!b) { sfx_set_error("null batch"); return -1; }
@@ -649,6 +666,8 @@ extern "C" int sfx_batch_set_frames(sfx_batch* b, const float* kp, const float* 
         SFX_CHECK(hipMemcpy(b->D.cam, c8.data(), c8.size() * 4, hipMemcpyHostToDevice));
     }
     if (camR) SFX_CHECK(hipMemcpy(b->D.camR, camR, (size_t)B * 9 * 4, hipMemcpyHostToDevice));
+    pack_fd(b, 0);
+    SFX_CHECK(hipDeviceSynchronize());
     return 0;
 }
 
@@ -680,6 +699,8 @@ extern "C" int sfx_batch_set_params(sfx_batch* b, const float* cam_t, const floa
         std::vector<float> r((size_t)B * 63, 0.f);
         for (int i = 0; i < B; ++i) for (int q = 0; q < L.NEMB; ++q) r[(size_t)i * 63 + q] = reg[(size_t)i * L.NEMB + q];
         SFX_CHECK(hipMemcpy(b->D.regpose, r.data(), r.size() * 4, hipMemcpyHostToDevice));
+        pack_fd(b, 0);
+        SFX_CHECK(hipDeviceSynchronize());
     }
     return 0;
 }
@@ -923,6 +944,7 @@ extern "C" int sfx_batch_guess_init(sfx_batch* b, const int32_t* pairs, int32_t 
     ClosureArgs a{}; a.stage_override = -1; a.forward_only = 1; a.from_X = 1;
     launch_closure(b->m->M, b->D, b->vl_dev, b->sw_dev, a, s);
     hipLaunchKernelGGL(k_guess_init, dim3((b->D.cfg.B + 63) / 64), dim3(64), 0, s, b->D, b->K, pd, n_pairs);
+    pack_fd(b, s);          // (est_tz changed)
     SFX_CHECK(hipStreamSynchronize(s));
     hipFree(pd);
     SFX_CHECK(hipGetLastError());
@@ -937,7 +959,10 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
     const bool fused = !step_mode && !g_unfused;
     D.act = nullptr; D.nrun = 0;          // (a previous fit that ended on an error may have left its running list attached)
     launch_lbfgs_tick(M, D, b->vl_dev, first_stage, last_stage, init, step_mode, s);
-    const long max_ticks = (long)(last_stage - first_stage + 1) * D.cfg.maxiters * 80 * 2 + 64;
+    // bound on the rounds of the polled loops: one resident batch needs at most stages x maxiters LBFGS.step calls of
+    // <= ~160 evaluations each; a job of B frames through a pool of `slots` columns needs that once per wave of the queue
+    long max_ticks = (long)(last_stage - first_stage + 1) * D.cfg.maxiters * 80 * 2 + 64;
+    if (dense && b->slots > 0 && b->slots < B) max_ticks *= (B + b->slots - 1) / b->slots;
     std::vector<int> hs(B);
     int* hp = b->stage_host ? b->stage_host : hs.data();
     long tick = 0;
@@ -1268,10 +1293,18 @@ extern "C" int sfx_batch_trace(sfx_batch* b, int32_t capacity) {
     if (D.trace_n) { hipFree(D.trace_n); D.trace_n = nullptr; }
     D.trace_cap = 0;
     if (capacity == 0) return 0;
-    SFX_CHECK(hipMalloc((void**)&D.trace, (size_t)D.cfg.B * capacity * sizeof(float4)));
-    SFX_CHECK(hipMalloc((void**)&D.trace_n, (size_t)D.cfg.B * sizeof(int)));
-    SFX_CHECK(hipMemset(D.trace_n, 0, (size_t)D.cfg.B * sizeof(int)));
-    D.trace_cap = capacity;
+    // both buffers or neither: the kernels test D.trace alone, so a half-attached trace must never be left behind
+    float4* tr = nullptr; int* tn = nullptr;
+    hipError_t e = hipMalloc((void**)&tr, (size_t)D.cfg.B * capacity * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void**)&tn, (size_t)D.cfg.B * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(tn, 0, (size_t)D.cfg.B * sizeof(int));
+    if (e != hipSuccess) {
+        if (tr) (void)hipFree(tr);
+        if (tn) (void)hipFree(tn);
+        sfx_set_error("sfx_batch_trace: %s", hipGetErrorString(e));
+        return -2;
+    }
+    D.trace = tr; D.trace_n = tn; D.trace_cap = capacity;
     return 0;
 }
 

@@ -61,14 +61,6 @@ __device__ __forceinline__ void sincos_t(float a, float* s, float* c) { *s = sin
 #define CT 256
 // RIF = 2-KiB blend-shape rows in flight per wavefront (forward dots and dfeat adjoint): 4 for the
 // body-only variant (33 rows: 16 + 16 + 1), SFX_RIF_BIG for the full model (675 rows)
-#define FD_GT 0
-#define FD_CONF (2 * SFX_MAX_K)
-#define FD_JW (3 * SFX_MAX_K)
-#define FD_CMASK (4 * SFX_MAX_K)
-#define FD_CAM (5 * SFX_MAX_K)
-#define FD_CAMR (FD_CAM + 8)
-#define FD_REG (FD_CAMR + 12)
-#define FD_N (FD_REG + 64)
 // debug timing: block 0 / thread 0 stores the shader clock at phase boundaries when D.dbg != NULL
 #define MARK(i) do { if (D.dbg && blockIdx.x == 0 && threadIdx.x == 0 && D.dbg[62] <= D.dbg[61]) { D.dbg[i] = clock64(); \
         if ((i) == 0) D.dbg[17] = wall_clock64(); if ((i) == 16) D.dbg[18] = wall_clock64(); } } while (0)
@@ -79,6 +71,34 @@ __device__ __forceinline__ void sincos_t(float a, float* s, float* c) { *s = sin
                          if (const int w = t + w##_i * CT; w < (N))
 
 struct EmptyLDS {};
+
+// Asynchronous global -> LDS copies by the whole workgroup (LDS-DMA, `global_load_lds_dword[x4]`): no registers, and no wait
+// until the next __syncthreads (which carries the vmcnt(0)).  Every table a closure workgroup needs at entry -- model
+// tables, this frame's record, the forward state of the previous launch -- is requested back to back this way: ONE memory
+// round trip instead of one per copy loop (the entry of k_tick_dense was 7.7 us body-only / 11 us with hands + face).
+// The destination of one wave-instruction is a contiguous run of 64 dwords (or 64 x 16 bytes) starting at a wave-uniform
+// LDS address; sources are per-lane.
+typedef __attribute__((address_space(3))) void* sfx_lds_vp;
+typedef const __attribute__((address_space(1))) void* sfx_glb_vp;
+__device__ __forceinline__ void lds_fill_async(void* lds_dst, const void* gsrc, const int n_dwords) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const char* g = reinterpret_cast<const char*>(gsrc);
+    char* l = reinterpret_cast<char*>(lds_dst);
+    for (int base = wv * 64; base < n_dwords; base += CT) {
+        const int i = base + lane;
+        if (i < n_dwords) __builtin_amdgcn_global_load_lds((sfx_glb_vp)(g + 4 * (size_t)i), (sfx_lds_vp)(l + 4 * base), 4, 0, 0);
+    }
+}
+// the same in 16-byte units (both sides 16-byte aligned)
+__device__ __forceinline__ void lds_fill_async16(void* lds_dst, const void* gsrc, const int n16) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const char* g = reinterpret_cast<const char*>(gsrc);
+    char* l = reinterpret_cast<char*>(lds_dst);
+    for (int base = wv * 64; base < n16; base += CT) {
+        const int i = base + lane;
+        if (i < n16) __builtin_amdgcn_global_load_lds((sfx_glb_vp)(g + 16 * (size_t)i), (sfx_lds_vp)(l + 16 * base), 16, 0, 0);
+    }
+}
 
 // Per-frame working set of the closure workgroup.  MAXI = item capacity, VP = VPoser activations
 // present.  Two variants are instantiated: <240, true> (any model / configuration, 86 KB) and
@@ -128,12 +148,11 @@ struct __align__(16) FrameLDSx {
     float dpose[168];
     float gc[SFX_NPAR_MAX];
     float red[CT];
-    float lh45[SFX_NHAND], rh45[SFX_NHAND];
-    float scal[16];
-    int   lut_row;
+    float lh45[SFX_NHAND], rh45[SFX_NHAND];    // } contiguous: saved / reloaded as one run of 2 * SFX_NHAND + 1 dwords
+    int   lut_row;                             // }
     typename std::conditional<VP, VposerLDS, EmptyLDS>::type V;   // VPoser activations (use_vposer only)
-    float fd[FD_N];             // this frame's keypoints / weights / camera / regression pose
-    int   meta[SFX_META_N];     // tree / joint-map tables (one coalesced load instead of
+    alignas(16) float fd[FD_N]; // this frame's keypoints / weights / camera / regression pose (image of BatchDev.fd)
+    alignas(16) int meta[SFX_META_N];     // tree / joint-map tables (one coalesced load instead of
                                 // dependent global loads inside every level of the chain)
 };
 using FrameLDS = FrameLDSx<SFX_MAX_ITEMS, true>;
@@ -267,46 +286,39 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     const bool reuse = args.reuse_fwd != 0;
     float* fwd = D.fwd ? D.fwd + (size_t)b * SFX_FWD_N : nullptr;
     const float* xsrc = (args.from_X ? D.X : D.Xt) + (size_t)b * SFX_NPAR_MAX;
-    if (!reuse) for (int i = t; i < L.npar; i += CT) S.x[i] = xsrc[i];
+    // every global source of this section goes to LDS asynchronously (lds_fill_async): one round trip for all of it
+    if (!reuse) lds_fill_async(S.x, xsrc, L.npar);
     if (!args.keep_tables) {   // (a persistent workgroup keeps the tables and its frame's data in LDS between evaluations)
-    for (int i = t; i < SFX_META_N; i += CT) S.meta[i] = M.meta[i];
-    {   // per-frame data -> LDS (one coalesced pass instead of dependent global loads later)
-        const int K_ = M.K;
-        for (int i = t; i < 2 * K_; i += CT) S.fd[FD_GT + i] = D.gt[(size_t)b * K_ * 2 + i];
-        for (int i = t; i < K_; i += CT) { S.fd[FD_CONF + i] = D.conf[(size_t)b * K_ + i]; S.fd[FD_JW + i] = D.jw[(size_t)b * K_ + i];
-                                           S.fd[FD_CMASK + i] = D.cmask[(size_t)b * K_ + i]; }
-        if (t < 8) S.fd[FD_CAM + t] = D.cam[(size_t)b * 8 + t];
-        if (t >= 64 && t < 73) S.fd[FD_CAMR + t - 64] = D.camR[(size_t)b * 9 + t - 64];
-        if (t >= 128 && t < 128 + 63) S.fd[FD_REG + t - 128] = D.regpose[(size_t)b * 63 + t - 128];
-    }
+    static_assert(SFX_META_N % 4 == 0 && FD_N % 4 == 0 && offsetof(LDS, meta) % 16 == 0 && offsetof(LDS, fd) % 16 == 0, "16-byte copies");
+    lds_fill_async16(S.meta, M.meta, SFX_META_N / 4);
+    lds_fill_async16(S.fd, D.fd + (size_t)b * FD_N, FD_N / 4);     // per-frame record (packed by k_pack_fd)
     // static items (vertex joints, static landmarks): vertex ids, weights, template rows, skinning weights, per-joint
-    // adjoint lists -- none of it depends on the pose, so it is fetched here, next to the other tables (one overlapped
-    // round trip at kernel entry; a persistent workgroup keeps it for the whole fit), not item by item inside the evaluation
-    for (int i = t; i < M.n_static_items; i += CT) { S.ivid[i] = M.item_vid[i]; S.iw[i] = M.item_w[i]; }
-    for (int w = t; w < M.n_static_items * 3; w += CT) S.vt[w] = M.item_vt[w];
-    for (int w = t; w < M.n_static_items * SFX_NW; w += CT) { S.wj[w] = M.item_wj[w]; S.ww[w] = M.item_ww[w]; }
+    // adjoint lists -- none of it depends on the pose, so it is fetched here, next to the other tables (a persistent
+    // workgroup keeps it for the whole fit), not item by item inside the evaluation
+    const int ns = M.n_static_items;
+    lds_fill_async(S.ivid, M.item_vid, ns); lds_fill_async(S.iw, M.item_w, ns);
+    lds_fill_async(S.vt, M.item_vt, ns * 3);
+    lds_fill_async(S.wj, M.item_wj, ns * SFX_NW); lds_fill_async(S.ww, M.item_ww, ns * SFX_NW);
     if (M.n_sj <= LDS::kMaxItems * SFX_NW) {
-        for (int i = t; i <= SFX_J; i += CT) S.sjs[i] = M.sj_start[i];
-        for (int i = t; i < M.n_sj; i += CT) { S.sji[i] = M.sj_item[i]; S.sjw[i] = M.sj_w[i]; }
+        lds_fill_async(S.sjs, M.sj_start, SFX_J + 1);
+        lds_fill_async(S.sji, M.sj_item, M.n_sj); lds_fill_async(S.sjw, M.sj_w, M.n_sj);
     }
+    }
+    if (reuse) {
+        static_assert(offsetof(LDS, lut_row) == offsetof(LDS, lh45) + 2 * SFX_NHAND * sizeof(float), "hand poses + LUT row are one run");
+        lds_fill_async16(&S, fwd, FWD_PREFIX / 4);
+        const float* ex = fwd + FWD_PREFIX;
+        lds_fill_async(S.lh45, ex, 2 * SFX_NHAND + 1);
+        if constexpr (HAS_VP) if (C.use_vposer) {
+            const float* vx = ex + 96;
+            static_assert(offsetof(VposerLDS, h2) == VP_H * sizeof(float) && offsetof(VposerLDS, o) == 2 * VP_H * sizeof(float), "h1 | h2 | o are one run");
+            lds_fill_async16(S.V.h1, vx, (2 * VP_H + 128) / 4);
+            lds_fill_async16(S.V.body, vx + 2 * VP_H + 128, 64 / 4);
+        }
     }
     for (int i = t; i < SFX_KD_PAD; i += CT) { if (!reuse) S.feat[i] = 0.f; S.dfeat[i] = 0.f; }
     for (int i = t; i < SFX_NPAR_MAX; i += CT) S.gc[i] = 0.f;
     for (int i = t; i < 168; i += CT) S.dpose[i] = 0.f;
-    if (reuse) {
-        float* sp = reinterpret_cast<float*>(&S);
-        for (int i = t; i < FWD_PREFIX / 4; i += CT)
-            reinterpret_cast<float4*>(sp)[i] = reinterpret_cast<const float4*>(fwd)[i];
-        const float* ex = fwd + FWD_PREFIX;
-        if (t < SFX_NHAND) { S.lh45[t] = ex[t]; S.rh45[t] = ex[SFX_NHAND + t]; }
-        if (t == 64) S.lut_row = __float_as_int(ex[2 * SFX_NHAND]);
-        if constexpr (HAS_VP) if (C.use_vposer) {
-            const float* vx = ex + 96;
-            for (int i = t; i < VP_H; i += CT) { S.V.h1[i] = vx[i]; S.V.h2[i] = vx[VP_H + i]; }
-            if (t < 128) S.V.o[t] = vx[2 * VP_H + t];
-            if (t < 64) S.V.body[t] = vx[2 * VP_H + 128 + t];
-        }
-    }
     __syncthreads();
     const float* bodypose = S.x + L.emb;
     if constexpr (HAS_VP) {

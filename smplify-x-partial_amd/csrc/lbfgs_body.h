@@ -240,8 +240,15 @@ __device__ __forceinline__ float wave_sum8_groups(const float (&v)[8], const int
 typedef float lb_v2 __attribute__((ext_vector_type(2)));
 struct LbRow { lb_v2 a; float b; };
 struct LbSet { LbRow mine[8]; LbRow all[8]; float bnd[7]; float ro, al; };
+typedef float lb_v3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ LbRow lb_ldrow(const char* p) {
+#ifdef SFX_HIST_NT
+    // history rows are read once per direction and never shared: non-temporal, so that they do not push the tables every
+    // frame of the XCD reads (blend-shape rows, VPoser weights) out of the 4-MB L2
+    const lb_v3 u = __builtin_nontemporal_load(reinterpret_cast<const lb_v3*>(p));
+#else
     const float3 u = *reinterpret_cast<const float3*>(p);
+#endif
     LbRow r; r.a.x = u.x; r.a.y = u.y; r.b = u.z; return r;
 }
 __device__ __forceinline__ float lb_dotpart(const LbRow& x, const LbRow& y) { return fmaf(x.b, y.b, fmaf(x.a.y, y.a.y, x.a.x * y.a.x)); }
@@ -522,7 +529,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
         if (sc_le(s.bf0, s.bf1)) { s.low = 0; s.high = 1; } else { s.low = 1; s.high = 0; } } while (0)
 
     // optimiser trace (sfx_batch_trace): one record per finished line search / LBFGS.step / stage
-#define TRACE(ty, a_, b_, c_) do { if (D.trace && lane == 0) { const int n_ = D.trace_n[b];                         \
+#define TRACE(ty, a_, b_, c_) do { if (D.trace && D.trace_n && lane == 0) { const int n_ = D.trace_n[b];                         \
         if (n_ < D.trace_cap) D.trace[(size_t)b * D.trace_cap + n_] = make_float4((float)(ty), (float)(a_), (float)(b_), (float)(c_)); \
         D.trace_n[b] = n_ + 1; } } while (0)
     if (D.trace && D.trace_evals) {      // (debug) every evaluation: trial step, loss, |g|inf  (the reduction is wave-wide: outside TRACE)

@@ -48,6 +48,17 @@
 #define SFX_MAX_ROUNDS 5
 #define SFX_META_N 1632
 
+// Per-frame record (floats): keypoints, confidences, joint weights, camera-init mask, camera, camera rotation, regression
+// pose -- packed by k_pack_fd (api.hip) from the arrays the host fills, read by the closure workgroup in ONE 16-byte copy
+#define FD_GT 0
+#define FD_CONF (2 * SFX_MAX_K)
+#define FD_JW (3 * SFX_MAX_K)
+#define FD_CMASK (4 * SFX_MAX_K)
+#define FD_CAM (5 * SFX_MAX_K)
+#define FD_CAMR (FD_CAM + 8)
+#define FD_REG (FD_CAMR + 12)
+#define FD_N (FD_REG + 64)
+
 // Canonical per-frame parameter block (floats).  cam_t | global_orient | betas | lhand |
 // rhand | expression | jaw | leye | reye | body_pose param (dead, iff !use_vposer) | embedding
 struct ParLayout {
@@ -155,6 +166,7 @@ struct BatchDev {
     float* cam;        // [B][8] fx fy cx cy data_weight est_tz - -
     float* camR;       // [B][9]
     float* regpose;    // [B][63]  (or latent)
+    float* fd;         // [B][FD_N] the seven arrays above packed per frame (k_pack_fd): what the closure workgroup loads
     float* f;          // [B] loss at Xt
     float* g;          // [B][NVAR_MAX] flat gradient at Xt
     float* bodypose;   // [B][63] decoded body pose (VPoser) scratch

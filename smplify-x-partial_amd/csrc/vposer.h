@@ -12,10 +12,15 @@
 #include "sfx_internal.h"
 
 #define VP_H 512
+#ifndef SFX_VP_UNROLL
+#define SFX_VP_UNROLL 8      // 16-byte weight loads in flight per thread of a VPoser matrix-vector product
+#endif
+#define SFX_STR_(x) #x
+#define SFX_STR(x) SFX_STR_(x)
 #define VP_O 126
 
-struct VposerLDS {
-    float h1[VP_H], h2[VP_H], o[128];
+struct alignas(16) VposerLDS {
+    float h1[VP_H], h2[VP_H], o[128];      // (contiguous: saved / reloaded as one run)
     float dh[VP_H], dg[VP_H];
     float body[64];
 };
@@ -111,7 +116,7 @@ __device__ __forceinline__ int vp_gemv_partial(const float* __restrict__ Wt, con
         float4 acc = {0.f, 0.f, 0.f, 0.f};
         const float4* w = reinterpret_cast<const float4*>(Wt + (size_t)k0 * ld) + c4;
         const int ld4 = ld >> 2;
-#pragma unroll 8
+_Pragma(SFX_STR(unroll SFX_VP_UNROLL))
         for (int k = k0; k < k1; ++k, w += ld4) {
             const float4 wv = *w;
             const float xv = x[k];

@@ -16,3 +16,16 @@ def pytest_configure(config):
 def synth_model():
     from smplifyx_amd import synthetic
     return synthetic.make_synthetic_model(0)
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Observed maxima of every closure-vs-oracle comparison of the session (tests/helpers.check_closure)."""
+    try:
+        import helpers as H
+    except Exception:
+        return
+    lines = H.parity_log_lines()
+    if lines:
+        terminalreporter.write_sep("-", "closure parity: observed maxima")
+        for l in lines:
+            terminalreporter.write_line(l)

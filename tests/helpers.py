@@ -111,3 +111,40 @@ def engine_batch_from_frames(dm, cfg, frames, idx, lbs_mode="rows", reuse=False)
         fb.set_params(regression_pose=frames["reg_pose"][idx], global_orient=frames["reg_global"][idx],
                       pose_embedding=frames["reg_pose"][idx], cam_translation=np.zeros((B, 3), np.float32))
     return fb
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Closure-level parity bounds (loss 1e-5; north_star: 1e-4 on the gradient), shared by every
+# closure-vs-oracle comparison of the GPU suite, __graft_entry__.smoke() and bench.py's closure_parity object.
+# Every comparison is recorded in PARITY_LOG; conftest prints the observed maxima per (label, stage) at the end
+# of a test session, so the log of a run shows the measurement next to the bound that protects it.
+# Measured on MI355X (round 3, every closure test of the suite): loss <= 3.2e-7, gradient <= 5.2e-7.  The asserted bounds are
+# ~10 x those maxima -- far inside SURVEY 8(d)'s 1e-5 and north_star's 1e-4, which an assertion must not merely repeat.
+CLOSURE_LOSS_TOL = 4e-6
+CLOSURE_GRAD_TOL = 6e-6
+PARITY_LOG = {}
+
+
+def closure_errors(loss, lo, grad, go):
+    """(relative loss error, relative gradient error in the 2-norm) of one frame's closure result against the oracle's."""
+    le = abs(float(loss) - float(lo)) / max(abs(float(lo)), 1e-30)
+    ge = float(np.linalg.norm(np.asarray(grad, np.float64) - np.asarray(go, np.float64)) / max(np.linalg.norm(go), 1e-30))
+    return le, ge
+
+
+def check_closure(label, stage, loss, lo, grad, go, loss_tol=CLOSURE_LOSS_TOL, grad_tol=CLOSURE_GRAD_TOL):
+    """Record and assert one closure comparison (HIP result vs fp64 autograd of the oracle)."""
+    le, ge = closure_errors(loss, lo, grad, go)
+    e = PARITY_LOG.setdefault((label, int(stage)), [0.0, 0.0, 0, loss_tol, grad_tol])
+    e[0] = max(e[0], le); e[1] = max(e[1], ge); e[2] += 1
+    assert le <= loss_tol, ("closure loss", label, stage, float(loss), float(lo), le, loss_tol)
+    assert ge <= grad_tol, ("closure gradient", label, stage, ge, grad_tol)
+    return le, ge
+
+
+def parity_log_lines():
+    out = []
+    for (label, stage), (le, ge, n, lt, gt) in sorted(PARITY_LOG.items()):
+        out.append("closure parity %-28s stage %2d: loss rel err max %.2e (bound %.0e)  gradient rel err max %.2e (bound %.0e)  [%d frames]"
+                   % (label, stage, le, lt, ge, gt, n))
+    return out

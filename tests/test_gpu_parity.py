@@ -3,8 +3,8 @@ C ABI (ctypes), against the CPU oracle on identical seeded inputs.
 
 Tolerances (fp32 path; north_star asks 1e-4 relative):
   LBS vertices / joints     abs 5e-6 m on ~1 m geometry (vs oracle fp32), 1e-5 vs oracle fp64
-  closure loss              rel 2e-5
-  closure gradient          ||g - g_ref|| / ||g_ref|| < 2e-4 (vs oracle fp64 autograd)
+  closure loss              rel 1e-5  (helpers.CLOSURE_LOSS_TOL; observed maxima are printed at session end)
+  closure gradient          ||g - g_ref|| / ||g_ref|| < 1e-4 (helpers.CLOSURE_GRAD_TOL; vs oracle fp64 autograd)
   end-to-end stage losses   rel 2e-3 on well-posed synthetic frames (the reference's own
                             fp32-vs-fp64 spread on such frames is 6e-5 .. 1e-3)
 """
@@ -109,34 +109,50 @@ def _oracle_closure(model, cfg, frames, i, params, stage, dtype=torch.float64):
     return loss.item(), g.numpy()
 
 
-@pytest.mark.parametrize("which,mode", [("body", "rows"), ("body", "dense"), ("full", "rows"), ("full", "dense")])
-def test_closure_matches_oracle(gpu, synth_model, cfg_body, cfg_full, which, mode):
-    cfg = cfg_body if which == "body" else cfg_full
-    dm = _dm(synth_model, cfg)
-    B = 3
-    frames = synth_frames(synth_model, cfg, B)
+def closure_probe(model, cfg, mode, label, B=3, seed=11, stages=None, vposer=None, check=True):
+    """HIP closure (through the C ABI) against fp64 autograd of the oracle at B seeded random points of B synthetic
+    frames, camera stage + body stages.  Returns {stage: (max loss rel err, max gradient rel err)}; with check=True every
+    comparison also goes through helpers.check_closure (bounds 1e-5 / 1e-4).  Used by the tests below,
+    __graft_entry__.smoke() and bench.py's closure_parity object."""
+    dm = _dm(model, cfg, **({"vposer": vposer} if vposer is not None else {}))
+    frames = synth_frames(model, cfg, B)
     fb = H.engine_batch_from_frames(dm, cfg, frames, range(B), lbs_mode=mode)
-    rng = np.random.RandomState(11)
+    rng = np.random.RandomState(seed)
     P = H.random_params(rng, B, scale=0.5)
-    P["pose_embedding"] = frames["reg_pose"] + 0.1 * rng.normal(size=(B, 63)).astype(np.float32)
+    if vposer is not None:
+        P["pose_embedding"] = rng.normal(size=(B, fb.nemb)).astype(np.float32)
+    else:
+        P["pose_embedding"] = frames["reg_pose"] + 0.1 * rng.normal(size=(B, 63)).astype(np.float32)
     P["global_orient"] = frames["reg_global"] + 0.1 * rng.normal(size=(B, 3)).astype(np.float32)
     P["cam_translation"] = (frames["cam_t"] + 0.3 * rng.normal(size=(B, 3))).astype(np.float32)
     est = (frames["cam_t"][:, 2] + 1.0).astype(np.float32)
     fb.set_frames(frames["keypoints"], _jw(cfg, frames), _cmask(cfg, frames), frames["focal"],
                   np.tile([frames["W"] * 0.5, frames["H"] * 0.5], (B, 1)), 1000.0 / frames["H"], est_tz=est)
-    fb.set_params(regression_pose=frames["reg_pose"], **P)
+    if vposer is not None:
+        fb.set_params(**P)
+    else:
+        fb.set_params(regression_pose=frames["reg_pose"], **P)
     P["est_tz"] = est
-    n_stages = fb.n_stages
-    for stage in [-1] + list(range(n_stages)):
+    out = {}
+    for stage in ([-1] + list(range(fb.n_stages)) if stages is None else stages):
         loss, grad = fb.closure(stage)
+        le_max = ge_max = 0.0
         for i in range(B):
-            lo, go = _oracle_closure(synth_model, cfg, frames, i, P, stage)
-            assert abs(loss[i] - lo) <= 2e-5 * abs(lo), (stage, i, loss[i], lo)
-            err = np.linalg.norm(grad[i] - go) / max(np.linalg.norm(go), 1e-30)
-            assert err < 2e-4, (stage, i, err)
+            lo, go = _oracle_closure(model, cfg, frames, i, P, stage)
+            le, ge = H.check_closure(label, stage, loss[i], lo, grad[i], go) if check else H.closure_errors(loss[i], lo, grad[i], go)
+            le_max, ge_max = max(le_max, le), max(ge_max, ge)
             # the dead body_pose parameter receives no gradient (fit_single_frame.py:554-559)
             if stage >= 0 and not cfg["use_vposer"]:
                 assert np.all(grad[i][13:13 + 63] == 0)
+        out[stage] = (le_max, ge_max)
+    fb.close(); dm.close()
+    return out
+
+
+@pytest.mark.parametrize("which,mode", [("body", "rows"), ("body", "dense"), ("full", "rows"), ("full", "dense")])
+def test_closure_matches_oracle(gpu, synth_model, cfg_body, cfg_full, which, mode):
+    cfg = cfg_body if which == "body" else cfg_full
+    closure_probe(synth_model, cfg, mode, "%s-%s" % (which, mode))
 
 
 def _jw(cfg, frames):
@@ -498,9 +514,7 @@ def test_closure_with_vposer_matches_oracle(gpu, synth_model):
             loss, grad = fb.closure(stage)
             for i in range(B):
                 lo, go = _oracle_closure(synth_model, cfg, frames, i, Q, stage)
-                assert abs(loss[i] - lo) <= 2e-5 * abs(lo), (mode, stage, i, loss[i], lo)
-                err = np.linalg.norm(grad[i] - go) / max(np.linalg.norm(go), 1e-30)
-                assert err < 3e-4, (mode, stage, i, err)
+                H.check_closure("vposer-full-%s" % mode, stage, loss[i], lo, grad[i], go)
         # decoded body pose of the accepted latent
         bp = fb.get_params()["body_pose"]
         from oracle.vposer import VPoserRef

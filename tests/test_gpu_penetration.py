@@ -221,9 +221,8 @@ def test_closure_with_interpenetration_matches_oracle(synth_model):
         lo, go = oracle(i, stage, True)
         lo_np, _ = oracle(i, stage, False)
         assert lo - lo_np > 1e-3 * lo                                  # the term matters in this pose
-        assert abs(loss[i] - lo) <= 1e-4 * abs(lo), (stage, loss[i], lo, lo_np)
-        err = np.linalg.norm(grad[i] - go) / np.linalg.norm(go)
-        assert err < 2e-3, (stage, err)
+        # (looser than the keypoint terms' 1e-5 / 1e-4: the cone field amplifies the 1e-7 m between two fp32 skinnings)
+        H.check_closure("pen-body-dense", stage, loss[i], lo, grad[i], go, loss_tol=1e-4, grad_tol=2e-3)
         assert np.all(grad[i][13:13 + 63] == 0)                        # dead body_pose parameter
     fb.close()
 
