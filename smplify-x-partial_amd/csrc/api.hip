@@ -516,6 +516,14 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     if (D.cfg.pen && !(c->df_cone_height > 0.f)) { sfx_set_error("df_cone_height must be positive"); delete b; return -1; }
     if (c->side_view_thsh > 0.f && (c->left_shoulder_idx < 0 || c->left_shoulder_idx >= K || c->right_shoulder_idx < 0 || c->right_shoulder_idx >= K)) {
         sfx_set_error("shoulder indices out of range"); delete b; return -1; }
+    {   // keypoints (and their vertex items: ascending in keypoint order) that are live while the hand / face joint weights are zero
+        const int kl[3] = {std::min(K, c->num_body_joints), std::min(K, c->num_body_joints + 42), K};
+        for (int q = 0; q < 3; ++q) {
+            int n = 0;
+            for (int i = 0; i < m->M.n_items; ++i) if (m->meta_host[MO_IK + i] < kl[q]) ++n;
+            D.cfg.kl[q] = kl[q]; D.cfg.nil[q] = n;
+        }
+    }
     build_layout(D.L, m->NB, m->NE, m->NPCA, c->use_vposer, m->M.vp_latent);
     if (D.L.npar > SFX_NPAR_MAX) { sfx_set_error("parameter block too large"); delete b; return -1; }
     const ParLayout& L = D.L;

@@ -130,6 +130,8 @@ struct __align__(16) FrameLDSx {
     fwd_t jd[SFX_MAX_K * 3];      // mapped joints, fp64 (what the projection reads)
     float dvert[MAXI * 3];
     float dvp[MAXI * 3];
+    int   rl[MAXI * 3];            // compacted list of the blend-shape rows the adjoint streams (row = vertex * 3 + coordinate) ...
+    float rc[MAXI * 3];            // ... and their coefficients (d v_posed), nonzero entries only
     int   ivid[MAXI];
     float iw[MAXI];
     int   wj[MAXI * SFX_NW];       // sparse skinning weights of the items
@@ -271,6 +273,15 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     if (stage >= C.n_stages && !args.forward_only) return;      // frame finished
     const bool cam_stage = (stage < 0);
     const StageW sw = (cam_stage || args.forward_only) ? StageW{} : sws[stage];     // (11 scalars, requested here: the loss section is 20 k cycles away)
+
+    // Live keypoints of this evaluation.  Keypoints are ordered body | hands | face (+ contour) and the vertex items follow
+    // that order; a stage whose hand / face joint weight is zero (fit_single_frame.py:569-572: the first three of the five
+    // stages of fit_smplx_smplifyx.yaml) multiplies everything those keypoints produce by zero -- loss terms and gradients
+    // alike -- so their vertex rows, skinning, projection and adjoint lists are not walked at all (exact: the skipped terms
+    // are zeros).  Forward-only passes and the camera stage keep every keypoint.
+    const int cls = (cam_stage || args.forward_only) ? 2 : ((sw.face_jw != 0.f) ? 2 : ((sw.hand_jw != 0.f) ? 1 : 0));
+    const int KL = __builtin_amdgcn_readfirstlane(cls == 2 ? M.K : C.kl[cls]);             // keypoints < KL are live
+    const int NIL = __builtin_amdgcn_readfirstlane(cls == 2 ? M.n_items : C.nil[cls]);     // items < NIL belong to them
 
     MARK(0);
     // ------------------------------------------------------------------ load parameters
@@ -497,7 +508,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
 
     MARK(5);
     // ------------------------------------------------------------------ needed vertices
-    const int NI = M.n_items;
+    const int NI = NIL;
     for (int i = M.n_static_items + t; i < NI; i += CT) {       // dynamic contour items: their vertices follow the head pose
         const int dd = M.item_dyn[i];
         const int l = dd / 3, c = dd % 3;
@@ -520,23 +531,31 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         // in step: every CU of an XCD then asks one L2 channel for one 2-KiB row at the same moment.
         // Each workgroup therefore starts at its own rotation of the row list; the rows are
         // independent dot products, so the result is bit-identical.
+        // Row addresses are wave-uniform: lane u looks up row u of the pass (one LDS read for the whole pass), the
+        // row index travels through v_readlane into scalar registers and the loads use scalar base + lane offset --
+        // looked up one by one in front of each load, the passes were issue-bound (2 dependent LDS round trips per row).
         const int nrow = ni * 3, rb = ib * 3;
         const int rot = (int)((blockIdx.x * 40u) % (unsigned)nrow);
         for (int w0 = wv * RIF; w0 < nrow; w0 += (CT / 64) * RIF) {
-            float4 da[RIF], db[RIF]; int wr[RIF];
-#pragma unroll
-            for (int u = 0; u < RIF; ++u) {
+            float4 da[RIF], db[RIF];
+            int myw, myrow;
+            {
+                const int u = lane < RIF ? lane : 0;
                 int w = ((w0 + u < nrow) ? w0 + u : w0) + rot;
                 w = w >= nrow ? w - nrow : w;
                 w += rb;
-                wr[u] = w;
-                const int v = S.ivid[w / 3];
-                const float4* row = reinterpret_cast<const float4*>(M.dirsT + ((size_t)v * 3 + w % 3) * SFX_KD_PAD);
+                myw = w;
+                myrow = S.ivid[w / 3] * 3 + w % 3;
+            }
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) {
+                const int r = __builtin_amdgcn_readlane(myrow, u);
+                const float4* row = reinterpret_cast<const float4*>(M.dirsT + (size_t)r * SFX_KD_PAD);
                 da[u] = row[lane]; db[u] = row[64 + lane];
             }
 #pragma unroll
             for (int u = 0; u < RIF; ++u) {
-                const int w = wr[u];
+                const int w = __builtin_amdgcn_readlane(myw, u);
                 float acc = fa.x * da[u].x + fa.y * da[u].y + fa.z * da[u].z + fa.w * da[u].w +
                             fb.x * db[u].x + fb.y * db[u].y + fb.z * db[u].z + fb.w * db[u].w;
                 acc = wave_sum(acc);
@@ -577,7 +596,8 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         // of every static item vertex (lbs_dense.hip epilogue); only the dynamic contour items, whose
         // vertices depend on this frame's head pose, are evaluated here
         const size_t ub = (size_t)D.slot[b] * M.n_uniq;
-        for (int w = t; w < M.n_static_items * 3; w += CT) {
+        const int nst = NI < M.n_static_items ? NI : M.n_static_items;
+        for (int w = t; w < nst * 3; w += CT) {
             const float o = D.uvp[(ub + M.item_uslot[w / 3]) * 3 + w % 3];
             S.vpo[w] = o; S.vp[w] = S.vt[w] + o;
         }
@@ -612,7 +632,8 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     for (int w = t; w < K * 3; w += CT) {
         const int k = w / 3, r = w % 3;
         fwd_t v;
-        if (S.meta[MO_JT + k] == 0) v = S.Gt[S.meta[MO_JS + k] * 3 + r];
+        if (k >= KL) v = 0;                      // (not live in this stage: never read)
+        else if (S.meta[MO_JT + k] == 0) v = S.Gt[S.meta[MO_JS + k] * 3 + r];
         else {
             v = 0;
             const int i0 = S.meta[MO_JI0 + k], n = S.meta[MO_JN + k];
@@ -652,7 +673,8 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     float q[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) q[i] = 0.f;
-    if (t < K) {
+    if (t >= KL && t < K) { S.dj[t * 3 + 0] = 0.f; S.dj[t * 3 + 1] = 0.f; S.dj[t * 3 + 2] = 0.f; }
+    if (t < KL) {
         // camera.py:93-117 in proj_t (fp32, as the reference; see "forward precision" above) -- except in the camera
         // stage, always fp64: there the residuals are tens of pixels, so fp32 pixel rounding (3e-5 px) is +-3e-3 of loss
         // noise, enough to make a strong-Wolfe zoom on a badly scaled direction collapse to t = 0 twice and end the stage
@@ -818,9 +840,10 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
             const int* st = pass ? (M.dj_start + (size_t)S.lut_row * (SFX_J + 1)) : (sj_lds ? S.sjs : M.sj_start);
             const int* it = pass ? M.dj_item : (sj_lds ? S.sji : M.sj_item);
             const float* wt = pass ? M.dj_w : (sj_lds ? S.sjw : M.sj_w);
-            if (pass && M.n_dyn_items == 0) break;
+            if (pass && (M.n_dyn_items == 0 || NI <= M.n_static_items)) break;
             for (int q2 = st[j]; q2 < st[j + 1]; ++q2) {
                 const int i = it[q2];
+                if (i >= NI) break;              // (lists ascend by item: the rest belongs to keypoints that are not live)
                 const float dv = S.dvert[i * 3 + r];
                 if (dv != 0.f) acc += wt[q2] * (dv * (c < 3 ? S.vp[i * 3 + c] : 1.f));
             }
@@ -833,21 +856,48 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     // (RIF in flight), lane l keeps k = 4l..4l+3 and 256+4l..+3; the 4 per-wave partials are added
     // in wave order (fixed association -> deterministic)
     {
+        // 1. the rows that carry a nonzero coefficient, compacted in ascending (item, coordinate) order: thread t looks at
+        //    item t's three coordinates; positions from wave ballots + the 4 wave totals (a keypoint with zero weight or
+        //    confidence contributes nothing and costs nothing)
+        int nrows;
+        {
+            float c3[3] = {0.f, 0.f, 0.f};
+            if (t < ni) { c3[0] = S.dvp[t * 3]; c3[1] = S.dvp[t * 3 + 1]; c3[2] = S.dvp[t * 3 + 2]; }
+            const unsigned long long b0 = __ballot(c3[0] != 0.f), b1 = __ballot(c3[1] != 0.f), b2 = __ballot(c3[2] != 0.f);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            int pos = __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt);
+            if (lane == 0) S.red[wv] = __int_as_float(__popcll(b0) + __popcll(b1) + __popcll(b2));
+            __syncthreads();
+            int tot = 0;
+#pragma unroll
+            for (int q2 = 0; q2 < CT / 64; ++q2) { const int n = __float_as_int(S.red[q2]); if (q2 < wv) pos += n; tot += n; }
+            nrows = tot;
+            if (t < ni) {
+                const int v3 = S.ivid[t] * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) if (c3[c] != 0.f) { S.rl[pos] = v3 + c; S.rc[pos] = c3[c]; ++pos; }
+            }
+            __syncthreads();
+        }
+        // 2. stream them: lane u of a wavefront looks up entry u of the pass, v_readlane moves row index and coefficient
+        //    into scalar registers, the loads use scalar base + lane offset (all RIF rows of a pass are requested back to back)
         float4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
-        for (int w0 = wv * RIF; w0 < ni * 3; w0 += (CT / 64) * RIF) {
-            float4 da[RIF], db[RIF]; float dv[RIF];
+        for (int w0 = wv * RIF; w0 < nrows; w0 += (CT / 64) * RIF) {
+            float4 da[RIF], db[RIF];
+            const bool mine = lane < RIF && w0 + lane < nrows;
+            const int myrow = S.rl[mine ? w0 + lane : w0];
+            const float myc = mine ? S.rc[w0 + lane] : 0.f;      // (entries past the end: the first row again, coefficient 0)
 #pragma unroll
             for (int u = 0; u < RIF; ++u) {
-                const int w = (w0 + u < ni * 3) ? w0 + u : w0;
-                dv[u] = (w0 + u < ni * 3) ? S.dvp[w] : 0.f;
-                const float4* row = reinterpret_cast<const float4*>(M.dirsT + ((size_t)S.ivid[w / 3] * 3 + w % 3) * SFX_KD_PAD);
-                if (dv[u] != 0.f) { da[u] = row[lane]; db[u] = row[64 + lane]; }
-                else { da[u] = pa; db[u] = pa; dv[u] = 0.f; }
+                const int r = __builtin_amdgcn_readlane(myrow, u);
+                const float4* row = reinterpret_cast<const float4*>(M.dirsT + (size_t)r * SFX_KD_PAD);
+                da[u] = row[lane]; db[u] = row[64 + lane];
             }
 #pragma unroll
             for (int u = 0; u < RIF; ++u) {
-                pa.x += da[u].x * dv[u]; pa.y += da[u].y * dv[u]; pa.z += da[u].z * dv[u]; pa.w += da[u].w * dv[u];
-                pb.x += db[u].x * dv[u]; pb.y += db[u].y * dv[u]; pb.z += db[u].z * dv[u]; pb.w += db[u].w * dv[u];
+                const float dv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myc), u));
+                pa.x += da[u].x * dv; pa.y += da[u].y * dv; pa.z += da[u].z * dv; pa.w += da[u].w * dv;
+                pb.x += db[u].x * dv; pb.y += db[u].y * dv; pb.z += db[u].z * dv; pb.w += db[u].w * dv;
             }
         }
         float4* part = reinterpret_cast<float4*>(S.T);          // S.T is dead here: 4 x 512 floats of scratch

@@ -203,8 +203,98 @@ void k_lbs_dense(DevModel M, BatchDev D) {
     }
 }
 
+#ifdef MF32
+// DIAGNOSTIC build only (tools/build_variant.sh mf32 lbs_dense -DMF32 -DNO_T): the K loop of the blend-shape GEMM on
+// v_mfma_f32_32x32x2_f32 -- wavefront tile 32 vertices x 32 frames, 3 x 16 accumulator registers, per K step of two rows
+// 1 A read + 3 B reads for 3 MFMAs -- against the same loop of k_lbs_dense built with -DNO_T (no skinning epilogue, a
+// checksum store).  Measured and rejected: DESIGN.md 4.5.  A operand staged k-major ([k][frame], +1 pad) so that the 32
+// frames of an operand fetch hit 32 banks.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define VB2 32
+#define LDA2 (FB + 1)
+struct __align__(16) DenseLDS32 {
+    float a[2][KC][LDA2];
+    float b[2][KC][VB2 * 3];
+};
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+__global__ __launch_bounds__(DT, MINW)
+void k_lbs_dense32(DevModel M, BatchDev D) {
+    __shared__ DenseLDS32 S;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int tile, fblk, fpb;
+    {
+        const int ny = (D.nact + FB - 1) / FB, ntile = (M.V + VB2 - 1) / VB2;
+        const int tpx = (ntile + 7) / 8;
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        tile = xcd * tpx + slot / ny; fblk = slot % ny;
+        if (tile >= ntile) return;
+        fpb = 32 * (((D.nact + 31) / 32 + ny - 1) / ny);
+    }
+    const int v0 = tile * VB2, fb0 = fblk * fpb, b0 = fb0 + wv * 32;
+    const int il = lane & 31, kh = lane >> 5;
+    const int V = M.V, B = D.nact;
+    const size_t LD = (size_t)3 * M.Vpad;
+    const bool active = wv * 32 < fpb && b0 < B;
+    const float4* gA = reinterpret_cast<const float4*>(D.featR + (size_t)fb0 * SFX_KD_PAD);
+    const float4* gB = reinterpret_cast<const float4*>(M.dirs + (size_t)v0 * 3);
+    const int LD4 = (int)(LD / 4);
+    const int stepA = KC / 4, stepB = KC * LD4;
+    int gA_off[4], fA[4], kA[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int idx = tid + q * DT, f = idx / (KC / 4), k4 = idx % (KC / 4);
+        gA_off[q] = f * (SFX_KD_PAD / 4) + k4; fA[q] = f; kA[q] = k4 * 4;
+    }
+    // dirs chunk: KC rows x 96 floats = 24 float4 per row -> 768 float4: 3 per thread
+    int gBo[3], lBo[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const int idx = tid + q * DT; gBo[q] = (idx / 24) * LD4 + idx % 24; lBo[q] = (idx / 24) * (VB2 * 3) + (idx % 24) * 4; }
+    float4 s0, s1, s2, s3, t0, t1, t2;
+#define SL32(c) do { s0 = gA[gA_off[0] + (c) * stepA]; s1 = gA[gA_off[1] + (c) * stepA]; s2 = gA[gA_off[2] + (c) * stepA];   \
+        s3 = gA[gA_off[3] + (c) * stepA]; t0 = gB[gBo[0] + (c) * stepB]; t1 = gB[gBo[1] + (c) * stepB]; t2 = gB[gBo[2] + (c) * stepB]; } while (0)
+#define SWA(buf, q, sv) do { float* p_ = &S.a[buf][kA[q]][fA[q]]; p_[0] = sv.x; p_[LDA2] = sv.y; p_[2 * LDA2] = sv.z; p_[3 * LDA2] = sv.w; } while (0)
+#define SW32(buf) do { SWA(buf, 0, s0); SWA(buf, 1, s1); SWA(buf, 2, s2); SWA(buf, 3, s3);                                    \
+        *reinterpret_cast<float4*>(&S.b[buf][0][0] + lBo[0]) = t0; *reinterpret_cast<float4*>(&S.b[buf][0][0] + lBo[1]) = t1; \
+        *reinterpret_cast<float4*>(&S.b[buf][0][0] + lBo[2]) = t2; } while (0)
+    f32x16 ax = {0}, ay = {0}, az = {0};
+    constexpr int NCHUNK = SFX_KD_PAD / KC;
+    SL32(KCHUNK(0)); SW32(0);
+    __syncthreads();
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < NCHUNK) SL32(KCHUNK(c + 1));
+        if (active) {
+            const float* sa = &S.a[cur][kh][wv * 32 + il];
+            const float* sb = &S.b[cur][kh][il * 3];
+#pragma unroll
+            for (int ks = 0; ks < KC / 2; ++ks) {
+                const float a0 = sa[ks * 2 * LDA2];
+                const float bx = sb[ks * 2 * VB2 * 3], by = sb[ks * 2 * VB2 * 3 + 1], bz = sb[ks * 2 * VB2 * 3 + 2];
+                ax = MFMA32(a0, bx, ax); ay = MFMA32(a0, by, ay); az = MFMA32(a0, bz, az);
+            }
+        }
+        if (c + 1 < NCHUNK) SW32(cur ^ 1);
+        __syncthreads();
+    }
+    if (!active) return;
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += ax[r] + ay[r] + az[r];
+    const int vtx = v0 + il;
+    if (vtx < V && b0 < B) D.verts[((size_t)b0 * V + vtx) * 3 + kh] = sum;
+}
+#endif
+
 void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s) {
     if (D.nact <= 0) return;
+#ifdef MF32
+    {
+        const int ny = (D.nact + FB - 1) / FB, ntile = (M.V + VB2 - 1) / VB2;
+        dim3 grid(8 * ((ntile + 7) / 8) * ny);
+        hipLaunchKernelGGL(k_lbs_dense32, grid, dim3(DT), 0, s, M, D);
+        return;
+    }
+#endif
     const int ny = (D.nact + FB - 1) / FB, ntile = (M.V + VB - 1) / VB;
     dim3 grid(8 * ((ntile + 7) / 8) * ny);
     hipLaunchKernelGGL(k_lbs_dense, grid, dim3(DT), 0, s, M, D);

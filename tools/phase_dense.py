@@ -1,5 +1,5 @@
 """Cycle stamps of one mid-fit k_tick_dense launch (block 0) for the bench workloads: body / full (VPoser).
-usage: python tools/phase_dense.py [body|full|fullreg] [B]"""
+usage: python tools/phase_dense.py [body|full|fullreg] [B] [stage] [launch]"""
 import os, sys, ctypes as C; sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch, _frames as FR
 from smplifyx_amd import synthetic, _capi
@@ -15,12 +15,16 @@ idx = [i % 8 for i in range(B)]
 lib = _capi.load()
 o64 = (C.c_int64 * 64)()
 fb = FR.batch(dm, cfg, fr, idx, lbs_mode="dense")
-_capi.check(lib.sfx_debug_clocks(fb._h, 400, None))
-fb.fit(first_stage=-1, last_stage=0)
+stage = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # body stage whose launch number `launch` is stamped
+launch = int(sys.argv[4]) if len(sys.argv) > 4 else (400 if stage == 0 else 100)
+if stage > 0:
+    fb.fit(first_stage=-1, last_stage=stage - 1)
+_capi.check(lib.sfx_debug_clocks(fb._h, launch, None))
+fb.fit(first_stage=-1 if stage == 0 else stage, last_stage=stage)
 _capi.check(lib.sfx_debug_clocks(fb._h, 0, o64))
 o = np.array(list(o64), np.float64)
 rel = lambda a: [int(x - o[24]) if 0 <= x - o[24] < 1e7 else None for x in a]
-print(which, 'B', B, 'dense tick kernel (launch 400, block 0): total cycles', int(o[26] - o[24]), 'loss+adjoint+tick', int(o[25] - o[24]), 'next pose/export', int(o[26] - o[25]))
+print(which, 'B', B, 'stage', stage, 'dense tick kernel (launch %d, block 0): total cycles' % launch, int(o[26] - o[24]), 'loss+adjoint+tick', int(o[25] - o[24]), 'next pose/export', int(o[26] - o[25]))
 print('  marks 0..16 of the loss/adjoint pass rel. to entry:', rel(o[40:57]))
 print('  loss sub marks 20..23:', rel(o[20:24]), ' chain 27,28:', rel(o[27:29]))
 print('  next-pose marks 0..5:', rel(o[0:6]), 'export 17..19', rel(o[17:20]))

@@ -1,0 +1,28 @@
+"""Mean closure evaluations per stage of a bench workload (which stages the time goes to).  usage: stage_evals.py [body|full|pen] [B]"""
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from smplifyx_amd import engine, synthetic, utils as U, driver
+which = sys.argv[1] if len(sys.argv) > 1 else 'full'; B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+cfg = bench.build_cfg(which); full = which == 'full'; pen = which == 'pen'
+model = synthetic.make_synthetic_model(0, surface=pen)
+jm = U.smpl_to_annotation("smplx", use_hands=cfg["use_hands"], use_face=cfg["use_face"], use_face_contour=cfg["use_face_contour"], format=cfg["format"])
+dm = engine.DeviceModel(model, joint_map=jm, num_betas=cfg["num_betas"], num_expression_coeffs=cfg["num_expression_coeffs"],
+                        num_pca_comps=cfg["num_pca_comps"], use_face_contour=cfg["use_face_contour"], vposer=synthetic.make_synthetic_vposer(0) if full else None)
+if pen:
+    parts = synthetic.make_synthetic_parts(model); dm.set_parts(parts["segm"], parts["parents"], cfg["ign_part_pairs"])
+dev = torch.device("cuda")
+def joints_fn(P):
+    z = lambda n: torch.zeros([B, n], device=dev); t = lambda a: torch.tensor(a, device=dev)
+    _, j, _ = dm.lbs_forward(t(P["global_orient"]), t(P["body_pose"]), t(P["betas"]), z(10), z(3), z(3), z(3), z(12), z(12), return_verts=False, return_full_pose=False)
+    return j.cpu().numpy()
+fr = synthetic.make_frames(B, joints_fn, len(jm), focal=float(cfg.get("focal_length") or 5000.0))
+jw = np.ones(len(jm), np.float32); jw[cfg["joints_to_ign"]] = 0
+ct = cc = None
+if pen:
+    rng = np.random.RandomState(1000); ct = (fr["cam_t"] + 0.05 * rng.normal(size=fr["cam_t"].shape)).astype(np.float32)
+    cc = np.tile(np.array([fr["W"] * 0.5, fr["H"] * 0.5], np.float32), (B, 1))
+res = driver.fit_frames(dm, cfg, fr["keypoints"], jw, fr["H"], fr["W"], fr["focal"], reg_pose=None if full else fr["reg_pose"],
+                        reg_global=None if full else fr["reg_global"], cam_prior_t=ct, cam_prior_center=cc, lbs_mode="dense", reuse_entry_eval=True)
+ev = res["stage_evals"]
+print(which, "B", B, "mean evals per stage (camera, body stages...):", ev.mean(0).round(1).tolist(), "max per stage", ev.max(0).tolist(), "total mean", ev.sum(1).mean(), "max", ev.sum(1).max())
