@@ -392,6 +392,40 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
             }
             // 'build' used base 0 relative to the current size of di at call time -> already absolute
             M.dj_start = m->mem.up(ds); M.dj_item = m->mem.up(di); M.dj_w = m->mem.up(dw);
+            // the same per LUT row in fixed-size blocks, together with the row's vertices, barycentric weights, template
+            // rows and sparse skinning weights (closure_body fetches one block asynchronously)
+            const int nd = (int)dynitems.size(), rows = nd ? d->n_dyn_rows : 0;
+            if (nd > SFX_MAX_DYN) { sfx_set_error("too many dynamic-contour items (%d > %d)", nd, SFX_MAX_DYN); delete m; return -1; }
+            std::vector<int> pv((size_t)rows * nd), pwj((size_t)rows * nd * SFX_NW, 0), pjs((size_t)rows * (SFX_J + 1), 0), pji((size_t)rows * nd * SFX_NW, 0);
+            std::vector<float> pw((size_t)rows * nd), pvt((size_t)rows * nd * 3), pww((size_t)rows * nd * SFX_NW, 0.f), pjw((size_t)rows * nd * SFX_NW, 0.f);
+            for (int row = 0; row < rows; ++row) {
+                for (int q = 0; q < nd; ++q) {
+                    const int i = dynitems[q], l = idyn[i] / 3, c = idyn[i] % 3;
+                    const int f = d->dyn_lmk_faces_idx[(size_t)row * d->n_dyn + l];
+                    const int v = d->faces[(size_t)f * 3 + c];
+                    const size_t o = (size_t)row * nd + q;
+                    pv[o] = v; pw[o] = d->dyn_lmk_bary[((size_t)row * d->n_dyn + l) * 3 + c];
+                    for (int e = 0; e < 3; ++e) pvt[o * 3 + e] = d->v_template[(size_t)v * 3 + e];
+                    int n = 0;
+                    for (int j = 0; j < SFX_J; ++j) {
+                        const float w = d->lbs_weights[(size_t)v * SFX_J + j];
+                        if (w == 0.f) continue;
+                        if (n < SFX_NW) { pwj[o * SFX_NW + n] = j; pww[o * SFX_NW + n] = w; }
+                        ++n;
+                    }
+                    if (n > SFX_NW) pwj[o * SFX_NW] = -1;
+                }
+                const int* st = &ds[(size_t)row * (SFX_J + 1)];
+                const int n_row = st[SFX_J] - st[0];
+                if (n_row > nd * SFX_NW) {      // (> SFX_NW weights per vertex on average: the closure falls back to dj_*)
+                    pjs.clear(); break; }
+                for (int j = 0; j <= SFX_J; ++j) pjs[(size_t)row * (SFX_J + 1) + j] = st[j] - st[0];
+                for (int q = 0; q < n_row; ++q) { pji[(size_t)row * nd * SFX_NW + q] = di[st[0] + q]; pjw[(size_t)row * nd * SFX_NW + q] = dw[st[0] + q]; }
+            }
+            M.dynp_vid = m->mem.up(pv); M.dynp_w = m->mem.up(pw); M.dynp_vt = m->mem.up(pvt);
+            M.dynp_wj = m->mem.up(pwj); M.dynp_ww = m->mem.up(pww);
+            M.dynp_js = pjs.empty() ? nullptr : m->mem.up(pjs);
+            M.dynp_ji = m->mem.up(pji); M.dynp_jw = m->mem.up(pjw);
         }
         M.jk_type = m->mem.up(jt); M.jk_src = m->mem.up(js); M.jk_item0 = m->mem.up(ji0); M.jk_nitem = m->mem.up(jn);
         M.item_vid = m->mem.up(ivid); M.item_w = m->mem.up(iw); M.item_dyn = m->mem.up(idyn); M.item_k = m->mem.up(ik);

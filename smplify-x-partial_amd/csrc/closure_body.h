@@ -133,12 +133,17 @@ struct __align__(16) FrameLDSx {
     int   rl[MAXI * 3];            // compacted list of the blend-shape rows the adjoint streams (row = vertex * 3 + coordinate) ...
     float rc[MAXI * 3];            // ... and their coefficients (d v_posed), nonzero entries only
     int   ivid[MAXI];
+    int   uslot[MAXI];             // static items: index of the item's vertex in the dense GEMM's export (BatchDev.uvp)
     float iw[MAXI];
     int   wj[MAXI * SFX_NW];       // sparse skinning weights of the items
     float ww[MAXI * SFX_NW];
     int   sjs[SFX_J + 1];          // per-joint lists of the static items (adjoint of the skinning: dA), copied from the
     int   sji[MAXI * SFX_NW];      //   model's CSR when it fits (M.n_sj <= MAXI * SFX_NW): two dependent global round trips
     float sjw[MAXI * SFX_NW];      //   per evaluation otherwise
+    static constexpr int kMaxDyn = (MAXI > SFX_SMALL_ITEMS) ? SFX_MAX_DYN : 1;
+    int   djs[SFX_J + 1];          // the same for the dynamic-contour items of this frame's LUT row (DevModel.dynp_*)
+    int   dji[kMaxDyn * SFX_NW];
+    float djw[kMaxDyn * SFX_NW];
     float joints[SFX_MAX_K * 3];
     float dj[SFX_MAX_K * 3];
     float dA[SFX_J * 12];
@@ -161,6 +166,10 @@ using FrameLDS = FrameLDSx<SFX_MAX_ITEMS, true>;
 using FrameLDSSmall = FrameLDSx<SFX_SMALL_ITEMS, false>;
 
 __device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
+template <int CTRL>
+__device__ __forceinline__ float lb_quad(float x) {       // DPP quad permutation of x (all lanes of the quad active)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
 
 // fixed-order block reduction: DPP sum per wavefront, then the CT/64 partials in order
 // (2 barriers instead of a 9-barrier LDS tree); result in all threads
@@ -307,7 +316,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     // adjoint lists -- none of it depends on the pose, so it is fetched here, next to the other tables (a persistent
     // workgroup keeps it for the whole fit), not item by item inside the evaluation
     const int ns = M.n_static_items;
-    lds_fill_async(S.ivid, M.item_vid, ns); lds_fill_async(S.iw, M.item_w, ns);
+    lds_fill_async(S.ivid, M.item_vid, ns); lds_fill_async(S.iw, M.item_w, ns); lds_fill_async(S.uslot, M.item_uslot, ns);
     lds_fill_async(S.vt, M.item_vt, ns * 3);
     lds_fill_async(S.wj, M.item_wj, ns * SFX_NW); lds_fill_async(S.ww, M.item_ww, ns * SFX_NW);
     if (M.n_sj <= LDS::kMaxItems * SFX_NW) {
@@ -509,16 +518,23 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     MARK(5);
     // ------------------------------------------------------------------ needed vertices
     const int NI = NIL;
-    for (int i = M.n_static_items + t; i < NI; i += CT) {       // dynamic contour items: their vertices follow the head pose
-        const int dd = M.item_dyn[i];
-        const int l = dd / 3, c = dd % 3;
-        const int face = M.dyn_faces[S.lut_row * M.n_dyn + l];
-        const int vid = M.faces[face * 3 + c];
-        S.iw[i] = M.dyn_bary[(S.lut_row * M.n_dyn + l) * 3 + c];
-        S.ivid[i] = vid;
-        S.vt[i * 3] = M.v_template[vid * 3]; S.vt[i * 3 + 1] = M.v_template[vid * 3 + 1]; S.vt[i * 3 + 2] = M.v_template[vid * 3 + 2];
+    // dynamic contour items: their vertices follow the head pose -- everything that depends on the LUT row (vertex ids,
+    // barycentric weights, template rows, sparse skinning weights, per-joint adjoint lists) is one block of DevModel.dynp_*
+    const bool dyn_live = NI > M.n_static_items;
+    const bool dyn_lds = dyn_live && M.dynp_js != nullptr && M.n_dyn_items <= LDS::kMaxDyn;
+    if (dyn_live) {
+        const int ns = M.n_static_items, nd = M.n_dyn_items;
+        const size_t ro = (size_t)S.lut_row * nd;
+        lds_fill_async(S.ivid + ns, M.dynp_vid + ro, nd); lds_fill_async(S.iw + ns, M.dynp_w + ro, nd);
+        lds_fill_async(S.vt + ns * 3, M.dynp_vt + ro * 3, nd * 3);
+        lds_fill_async(S.wj + ns * SFX_NW, M.dynp_wj + ro * SFX_NW, nd * SFX_NW);
+        lds_fill_async(S.ww + ns * SFX_NW, M.dynp_ww + ro * SFX_NW, nd * SFX_NW);
+        if (dyn_lds) {
+            lds_fill_async(S.djs, M.dynp_js + (size_t)S.lut_row * (SFX_J + 1), SFX_J + 1);
+            lds_fill_async(S.dji, M.dynp_ji + ro * SFX_NW, nd * SFX_NW); lds_fill_async(S.djw, M.dynp_jw + ro * SFX_NW, nd * SFX_NW);
+        }
+        __syncthreads();
     }
-    if (NI > M.n_static_items) __syncthreads();
     // v_posed rows and skinning transforms of `ni` vertices listed in S.ivid (the model's items, or a
     // chunk of vertices that carry a penetration gradient)
     auto items_forward = [&](const int ib, const int ni) {       // items ib .. ib + ni - 1
@@ -568,12 +584,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     // (sparse rows of lbs_weights: <= SFX_NW nonzeros per vertex, ascending joint order, so the
     //  sum visits the same nonzero terms in the same order as the dense product)
     auto items_transforms = [&](const int ib, const int ni) {
-    for (int w = t + M.n_static_items * SFX_NW; w < (ib + ni) * SFX_NW; w += CT) {       // (static items: loaded with the tables)
-        const int i = w / SFX_NW, q2 = w % SFX_NW;
-        S.wj[w] = M.Wsp_j[(size_t)S.ivid[i] * SFX_NW + q2];
-        S.ww[w] = M.Wsp_w[(size_t)S.ivid[i] * SFX_NW + q2];
-    }
-    __syncthreads();
+    // (sparse weights: the static items' came with the tables, the dynamic items' with their LUT-row block)
     for (int w = t + ib * 12; w < (ib + ni) * 12; w += CT) {
         const int i = w / 12, e = w % 12;
         float acc = 0.f;
@@ -598,7 +609,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         const size_t ub = (size_t)D.slot[b] * M.n_uniq;
         const int nst = NI < M.n_static_items ? NI : M.n_static_items;
         for (int w = t; w < nst * 3; w += CT) {
-            const float o = D.uvp[(ub + M.item_uslot[w / 3]) * 3 + w % 3];
+            const float o = D.uvp[(ub + S.uslot[w / 3]) * 3 + w % 3];
             S.vpo[w] = o; S.vp[w] = S.vt[w] + o;
         }
         if (NI > M.n_static_items) items_forward(M.n_static_items, NI - M.n_static_items);
@@ -831,24 +842,34 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     items_dvp(NI);
     MARK(10);
     // dA[j][e] = sum_items W[v][j] * dT[e]: per-joint item lists (CSR built at model creation,
-    // one per dynamic-contour LUT row), visited in ascending item order -> deterministic
-    for (int w = t; w < SFX_J * 12; w += CT) {
+    // one per dynamic-contour LUT row), visited in ascending item order -> deterministic.  Four lanes share one (j, e):
+    // lane g takes entries g, g + 4, ... of the joint's lists and the four partial sums are added as (p0 + p1) + (p2 + p3)
+    // inside the quad -- the face landmarks hang on two or three joints whose lists hold ~150 entries each, walked by one
+    // lane they were 10 us of a full-model evaluation.
+    // (only when the face keypoints are live: with the body's or the hands' few items one lane per (j, e) is faster)
+    const int gsh = (cls == 2 && NI > 64) ? 2 : 0, gst = 1 << gsh;
+    for (int u = t; u < (SFX_J * 12) << gsh; u += CT) {
+        const int w = u >> gsh, g = u & (gst - 1);
         const int j = w / 12, e = w % 12, r = e >> 2, c = e & 3;
         float acc = 0.f;
         const bool sj_lds = M.n_sj <= LDS::kMaxItems * SFX_NW;
         for (int pass = 0; pass < 2; ++pass) {
-            const int* st = pass ? (M.dj_start + (size_t)S.lut_row * (SFX_J + 1)) : (sj_lds ? S.sjs : M.sj_start);
-            const int* it = pass ? M.dj_item : (sj_lds ? S.sji : M.sj_item);
-            const float* wt = pass ? M.dj_w : (sj_lds ? S.sjw : M.sj_w);
+            const int* st = pass ? (dyn_lds ? S.djs : M.dj_start + (size_t)S.lut_row * (SFX_J + 1)) : (sj_lds ? S.sjs : M.sj_start);
+            const int* it = pass ? (dyn_lds ? S.dji : M.dj_item) : (sj_lds ? S.sji : M.sj_item);
+            const float* wt = pass ? (dyn_lds ? S.djw : M.dj_w) : (sj_lds ? S.sjw : M.sj_w);
             if (pass && (M.n_dyn_items == 0 || NI <= M.n_static_items)) break;
-            for (int q2 = st[j]; q2 < st[j + 1]; ++q2) {
+            for (int q2 = st[j] + g; q2 < st[j + 1]; q2 += gst) {
                 const int i = it[q2];
                 if (i >= NI) break;              // (lists ascend by item: the rest belongs to keypoints that are not live)
                 const float dv = S.dvert[i * 3 + r];
                 if (dv != 0.f) acc += wt[q2] * (dv * (c < 3 ? S.vp[i * 3 + c] : 1.f));
             }
         }
-        S.dA[w] = acc;
+        if (gsh) {
+            acc = acc + lb_quad<0xB1>(acc);      // quad_perm [1,0,3,2]: p0 + p1 | p2 + p3
+            acc = acc + lb_quad<0x4E>(acc);      // quad_perm [2,3,0,1]: (p0 + p1) + (p2 + p3)
+        }
+        if (g == 0) S.dA[w] = acc;
     }
     MARK(11);
     auto items_dfeat = [&](const int ni, const bool accumulate) {

@@ -9,6 +9,7 @@
 #define SFX_MAX_K 144       // mapped joints
 #define SFX_MAX_ITEMS 240   // vertex items (21 + 68*3 = 225)
 #define SFX_SMALL_ITEMS 32  // item capacity of the small closure variant (body-only: 11 items)
+#define SFX_MAX_DYN 64      // dynamic-contour items (17 landmarks x 3 corners = 51)
 #ifndef SFX_RIF_BIG
 #define SFX_RIF_BIG 8        // 2-KiB blend-shape rows in flight per wavefront in the full-model closure (1 workgroup per CU:
 #endif                       // the loads of 4 wavefronts are all the memory parallelism a frame gets)
@@ -133,6 +134,16 @@ struct DevModel {
     const int *sj_start, *sj_item; const float* sj_w;      // [J+1], [..]
     const int *dj_start, *dj_item; const float* dj_w;      // [rows][J+1] (absolute offsets), [..]
     int n_dyn_items;
+    // everything about the dynamic-contour items that depends on the LUT row, packed per row (one asynchronous copy into
+    // the closure workgroup's LDS instead of four dependent global round trips): nd = n_dyn_items
+    const int*   dynp_vid;     // [rows][nd]      vertex of item (n_static_items + q)
+    const float* dynp_w;       // [rows][nd]      its barycentric weight
+    const float* dynp_vt;      // [rows][nd][3]   its v_template row
+    const int*   dynp_wj;      // [rows][nd][SFX_NW]  sparse skinning weights (Wsp_j / Wsp_w of the vertex)
+    const float* dynp_ww;      // [rows][nd][SFX_NW]
+    const int*   dynp_js;      // [rows][J+1]     per-joint adjoint lists of the row, offsets RELATIVE to the row's block ...
+    const int*   dynp_ji;      // [rows][nd*SFX_NW]   ... items (absolute item ids), padded to nd * SFX_NW entries per row
+    const float* dynp_jw;      // [rows][nd*SFX_NW]
     int n_sj;                  // entries of sj_item / sj_w
     const int*   meta;         // [SFX_META_N] packed copy of the tables above
     // VPoser decoder

@@ -104,7 +104,7 @@ __device__ __forceinline__ void vposer_joint(const float* a, float* aa, const fl
 // the k range and leave partial sums in `part` ([groups][nout], LDS); the caller adds them in group
 // order.  16 bytes per lane and 8 rows in flight per thread keep ~64 KB of weights in flight per
 // CU -- a scalar 4-byte-per-lane loop is latency bound at a tenth of the L2 bandwidth.
-template <int NT>
+template <int NT, int UNR = SFX_VP_UNROLL>
 __device__ __forceinline__ int vp_gemv_partial(const float* __restrict__ Wt, const int K, const int ld, const int nout,
                                                const float* x, float* part) {
     const int t = threadIdx.x;
@@ -116,7 +116,7 @@ __device__ __forceinline__ int vp_gemv_partial(const float* __restrict__ Wt, con
         float4 acc = {0.f, 0.f, 0.f, 0.f};
         const float4* w = reinterpret_cast<const float4*>(Wt + (size_t)k0 * ld) + c4;
         const int ld4 = ld >> 2;
-_Pragma(SFX_STR(unroll SFX_VP_UNROLL))
+#pragma unroll UNR
         for (int k = k0; k < k1; ++k, w += ld4) {
             const float4 wv = *w;
             const float xv = x[k];
@@ -132,7 +132,9 @@ template <int NT>
 __device__ __forceinline__ void vposer_forward(VposerLDS& V, const DevModel& M, const float* z) {
     const int t = threadIdx.x, L = M.vp_latent;
     float* part = V.dh;                         // dh, dg (2 x 512 floats, contiguous) are free during the forward
-    int G = vp_gemv_partial<NT>(M.vp_w1T, L, VP_H, VP_H, z, part);
+    // (16 weight loads in flight per thread in the forward products: 43 k -> 34 k cycles per decode at 256 frames; the
+    //  adjoint products, which follow a longer dependent prologue, measured slower with 16 than with 8: 78 k -> 87 k)
+    int G = vp_gemv_partial<NT, 16>(M.vp_w1T, L, VP_H, VP_H, z, part);
     __syncthreads();
     for (int o = t; o < VP_H; o += NT) {
         float acc = M.vp_b1[o];
@@ -140,7 +142,7 @@ __device__ __forceinline__ void vposer_forward(VposerLDS& V, const DevModel& M, 
         V.h1[o] = leaky(acc);
     }
     __syncthreads();
-    G = vp_gemv_partial<NT>(M.vp_w2T, VP_H, VP_H, VP_H, V.h1, part);
+    G = vp_gemv_partial<NT, 16>(M.vp_w2T, VP_H, VP_H, VP_H, V.h1, part);
     __syncthreads();
     for (int o = t; o < VP_H; o += NT) {
         float acc = M.vp_b2[o];
@@ -148,7 +150,7 @@ __device__ __forceinline__ void vposer_forward(VposerLDS& V, const DevModel& M, 
         V.h2[o] = leaky(acc);
     }
     __syncthreads();
-    G = vp_gemv_partial<NT>(M.vp_w3T, VP_H, 128, 128, V.h2, part);
+    G = vp_gemv_partial<NT, 16>(M.vp_w3T, VP_H, 128, 128, V.h2, part);
     __syncthreads();
     for (int o = t; o < VP_O; o += NT) {
         float acc = M.vp_b3[o];

@@ -26,3 +26,17 @@ res = driver.fit_frames(dm, cfg, fr["keypoints"], jw, fr["H"], fr["W"], fr["foca
                         reg_global=None if full else fr["reg_global"], cam_prior_t=ct, cam_prior_center=cc, lbs_mode="dense", reuse_entry_eval=True)
 ev = res["stage_evals"]
 print(which, "B", B, "mean evals per stage (camera, body stages...):", ev.mean(0).round(1).tolist(), "max per stage", ev.max(0).tolist(), "total mean", ev.sum(1).mean(), "max", ev.sum(1).max())
+
+# lock-step occupancy by stage: in round r frame f is in the stage its cumulative evaluation count has reached
+cum = np.cumsum(ev, 1)
+R = int(cum[:, -1].max())
+ns = ev.shape[1]
+any_in = np.zeros(ns, np.int64); frames_in = np.zeros(ns, np.float64); act = 0.0
+for r in range(R):
+    st = (cum <= r).sum(1)              # stage index of each frame in round r (ns = finished)
+    for q in range(ns):
+        n = int((st == q).sum())
+        any_in[q] += n > 0; frames_in[q] += n
+    act += (st < ns).sum()
+print("rounds", R, "mean active frames/round %.1f" % (act / R), "| rounds with >= 1 frame in stage q:", any_in.tolist(),
+      "| mean frames in stage q over those rounds:", [round(frames_in[q] / max(any_in[q], 1), 1) for q in range(ns)])
