@@ -743,6 +743,37 @@ def main():
                                "kernel_ms_total": ms_lb, "launches": n_lb,
                                "note": "latency-bound by construction: one workgroup walks one frame's serial "
                                        "L-BFGS chain; the meaningful figure is frames/s"}
+        if pen and prof["penetration"][1]:
+            # the interpenetration step of a round (csrc/collide.hip k_pen_* + the dense skinning adjoint, csrc/lbs_adjoint.hip), timed
+            # as ONE HIP-event scope per round.  Byte model per GEMM column whose stage carries a collision weight (F triangles, V
+            # vertices, E grid entries, P ordered pairs; E and P are read from the run): broad phase = vertices 12 V + faces 12 F +
+            # part labels 4 F read, boxes 24 F written and read back by the pair tests, entries 8 E written + (8 + 36) E read;
+            # narrow phase = pair list 8 P written and read, 2 x 36 B of geometry per pair read, 40 B per pair of per-pair results
+            # written and read, per-triangle sums 40 F, vertex gradient 12 V written; adjoint = d v_posed 12 V written and read by
+            # the fp32-MFMA GEMM (whose 63.7 MB of blend-shape rows are shared by the launch: not in the per-column figure).
+            ms_p, n_p, u_p = prof["penetration"]
+            V_, F_ = dm.V, dm.F
+            E_, P_ = 10000.0, 8000.0        # typical of the synthetic surface mesh in these fits (engine.FrameBatch.penetration_stats)
+            by_col = (12 * V_ + 12 * F_ + 4 * F_ + 2 * 24 * F_ + (8 + 8 + 36) * E_) + (2 * 8 * P_ + 72 * P_ + 2 * 40 * P_ + 40 * F_ + 12 * V_) + 2 * 12 * V_
+            t_p = 1e-3 * ms_p
+            out["roofline_pen"] = {"kernels": "k_pen_grid, k_pen_walk, k_pen_list, k_pen_rank, k_pen_eval, k_pen_facesum, k_pen_gather, k_adj_prep, "
+                                              "k_lbs_dense_adj, k_adj_reduce, k_adj_dA (one HIP-event scope per round)",
+                                   "bound": "hbm", "achieved": by_col * u_p / t_p / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                                   "frac": by_col * u_p / t_p / PEAK_HBM, "traffic": None, "bytes_per_column_launch": by_col,
+                                   "avg_scope_us": 1e6 * t_p / n_p, "launches": n_p, "columns_per_launch": u_p / n_p,
+                                   "share_of_step": ms_p * args.prof_every / (1e3 * dt),
+                                   "note": "latency-bound: eleven dependent kernels per round whose per-frame chains (counting sort of one "
+                                           "frame's triangles by one 1024-lane workgroup, bucket walks, list ranking) expose little "
+                                           "parallelism per frame; per-kernel times and counters: profiles/r03_pen_*"}
+            pmc_ok, pmc_note = pmc_is_current(os.path.join(ROOT, "profiles", "pmc_summary_pen.json"))
+            if pmc_ok:
+                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary_pen.json")))
+                tr = sum(v.get("hbm_read_bytes_per_launch", 0.0) + v.get("hbm_write_bytes_per_launch", 0.0) for k, v in pj.items()
+                         if k.startswith(("k_pen_", "k_adj_", "k_lbs_dense_adj")))
+                out["roofline_pen"]["traffic"] = tr
+                out["roofline_pen"]["traffic_source"] = "replayed: profiles/pmc_summary_pen.json (sum over the scope's kernels, FETCH_SIZE x 2 + WRITE_SIZE)"
+            else:
+                out["roofline_pen"]["traffic_note"] = pmc_note
         if alt is not None:
             out["alt"] = alt
         if not args.no_parity and not full and not pen and world == 1:

@@ -247,7 +247,8 @@ void sfx_pen_destroy(sfx_pen* h);
 int  sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
                   float* loss_dev, float* dverts_dev, void* stream);
 /* per frame (HOST [B][4]): ordered pairs kept, partners dropped by max_collisions / the pair list's capacity, grid entries
- * when they overflowed the buffer (0 = fine; then the frame reports no pairs), grid cells.       */
+ * when they overflowed the buffer (0 = fine; then the frame reports no pairs), bucket walks cut short (0 on a sane mesh:
+ * an entry looks at most 2048 entries ahead in its bucket; a mesh folded into a few cells by a diverged fit hits that). */
 int  sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host);
 /* debug: elapsed 100 MHz wall-clock ticks at the end of k_pen_grid's seven steps (triangle boxes,
  * frame box, part boxes, part culling, grid histogram, scan, scatter; [7..9] unused) of the most

@@ -612,9 +612,12 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     if (D.cfg.pen) {
         const int F = (int)(m->faces_host.size() / 3);
         const bool parts = !m->segm_host.empty();
+        // collision buffers (partner lists, grid entries, pair list: ~45 MB per mesh at max_collisions 128) are indexed by
+        // GEMM column, not by frame: a job that runs B frames through a pool of `slots` columns holds `slots` of them
+        const int pen_cols = (c->slots > 0 && c->slots < B && c->lbs_mode == 1) ? std::min(B, ((c->slots + 31) / 32) * 32) : B;
         int rc = sfx_pen_create(m->M.V, F, m->faces_host.data(), parts ? m->segm_host.data() : nullptr,
                                 parts ? m->parents_host.data() : nullptr, m->ign_host.empty() ? nullptr : m->ign_host.data(),
-                                (int)(m->ign_host.size() / 2), std::max(1, c->max_collisions), B, &b->pen);
+                                (int)(m->ign_host.size() / 2), std::max(1, c->max_collisions), pen_cols, &b->pen);
         if (rc) { b->mem.free_all(); delete b; return rc; }
         b->pen_sigma = c->df_cone_height; b->pen_outside = c->penalize_outside ? 1 : 0;
         D.pen_loss = b->mem.zeros<float>(B);

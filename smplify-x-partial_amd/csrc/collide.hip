@@ -44,6 +44,10 @@
 #define PEN_SPAN 8              // cells per axis one triangle may be entered in (a sane triangle spans 1-3; an exploded
                                 // mesh -- diverged fit, NaN / huge coordinates -- must not turn into 10^9 cell visits)
 #define PEN_STATS 16
+#define PEN_MAX_WALK 2048        // entries an entry looks ahead in its bucket before it gives up (crowded cells of a sane mesh hold hundreds:
+                                // 418 on the synthetic surface).  A diverged fit folds the mesh into a few cells of 10^4 entries; walking
+                                // them out took 7-8 ms per evaluation and held up the whole batch (3 % of the launches of a 256-frame fit,
+                                // half of this kernel's total time).  The reference's BVH bounds a query by max_collisions hits instead.
 #define PEN_WALK_BLOCKS 32      // workgroups (of 4 wavefronts) per frame of the pair tests: a frame whose limbs are pushed
                                 // through each other has 100x the candidates of a clean one, and must not hold up the launch
 #define PEN_EVAL_BLOCKS 32      // workgroups per frame of the pair evaluation (grid-stride over the pair list)
@@ -62,6 +66,7 @@ struct PenDev {
     float* aabb;               // [B][F][6]
     int* entries;              // [B][ent_cap] triangle | part << 24, sorted by bucket
     int* ent_cell;             // [B][ent_cap] packed cell coordinates the entry was made for
+    int2* tcell;               // [B][F] per triangle: packed cell range + part + alive bit (k_pen_grid's passes)
     int ent_cap;
     int* partners;             // [B][F][pcap]
     int* pavail;               // [B][F] partners held: min(found, pcap)
@@ -180,6 +185,10 @@ __device__ __forceinline__ int block_excl_scan(const int v, int* wsum /* [PEN_T 
     return base + inc - v;
 }
 
+// Triangles per lane whose loads are issued together in the passes of k_pen_grid: every pass walks the lane's 21
+// triangles (f = t, t + 1024, ...); one triangle at a time each pass was a chain of 21 x 2 dependent global round trips
+// (face -> vertex ids -> coordinates; AABB re-read from global) -- 100 + 65 + 67 + 75 us of a 350-us kernel.
+#define PEN_U 4
 __global__ __launch_bounds__(PEN_T)
 void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __restrict__ want) {
     extern __shared__ int cell_cnt[];           // [ncell + 1]: histogram, then start offsets, then cursors
@@ -196,46 +205,77 @@ void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __r
 #define PEN_CLK(i) if (t == 0) st[4 + (i)] = (int)(wall_clock64() - clk0)
     const float* vb = verts + (size_t)b * P.V * 3;
     float* aabb = P.aabb + (size_t)b * P.F * 6;
+    int2* tcell = P.tcell + (size_t)b * P.F;
     const int F = P.F;
 
     // per-part masks of the parts a triangle never collides with (parts < 64)
     __shared__ unsigned long long s_mask[64];
+    __shared__ int s_pbox[64][6];
+    auto ford = [](float x) { int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); };      // order-preserving
     if (t < 64) {
         unsigned long long m = 0;
         if (t < P.n_parts) for (int q = 0; q < P.n_parts; ++q) m |= (unsigned long long)(P.skip[(size_t)t * P.n_parts + q] != 0) << q;
         s_mask[t] = m;
+        for (int e = 0; e < 3; ++e) { s_pbox[t][e] = 0x7fffffff; s_pbox[t][3 + e] = (int)0x80000000; }
     }
     for (int f = t; f < P.F; f += PEN_T) P.pcount[(size_t)b * P.F + f] = 0;
-    // ---- AABBs, frame bounding box, mean triangle extent
+    __syncthreads();
+    // ---- pass 1: AABBs, frame bounding box, mean triangle extent, bounding box of every part
     float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f}, ext_sum = 0.f;
-    for (int f = t; f < F; f += PEN_T) {
-        float a[3] = {3e38f, 3e38f, 3e38f}, c[3] = {-3e38f, -3e38f, -3e38f};
-        for (int k = 0; k < 3; ++k) {
-            const float* p = vb + (size_t)P.faces[f * 3 + k] * 3;
-            for (int e = 0; e < 3; ++e) { a[e] = fminf(a[e], p[e]); c[e] = fmaxf(c[e], p[e]); }
+    for (int f0 = t; f0 < F; f0 += PEN_T * PEN_U) {
+        int vid[PEN_U][3], seg[PEN_U];
+#pragma unroll
+        for (int u = 0; u < PEN_U; ++u) {
+            const int f = f0 + u * PEN_T, ff = f < F ? f : 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) vid[u][k] = P.faces[ff * 3 + k];
+            seg[u] = P.segm[ff];
         }
-        for (int e = 0; e < 3; ++e) { aabb[f * 6 + e] = a[e]; aabb[f * 6 + 3 + e] = c[e];
-                                      lo[e] = fminf(lo[e], a[e]); hi[e] = fmaxf(hi[e], c[e]); }
-        ext_sum += fmaxf(fmaxf(c[0] - a[0], c[1] - a[1]), c[2] - a[2]);
+        float px[PEN_U][9];
+#pragma unroll
+        for (int u = 0; u < PEN_U; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float* p = vb + (size_t)vid[u][k] * 3;
+                px[u][k * 3] = p[0]; px[u][k * 3 + 1] = p[1]; px[u][k * 3 + 2] = p[2];
+            }
+#pragma unroll
+        for (int u = 0; u < PEN_U; ++u) {
+            const int f = f0 + u * PEN_T;
+            if (f >= F) continue;
+            float a[3], c[3];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                a[e] = fminf(fminf(px[u][e], px[u][3 + e]), px[u][6 + e]); c[e] = fmaxf(fmaxf(px[u][e], px[u][3 + e]), px[u][6 + e]);
+                aabb[f * 6 + e] = a[e]; aabb[f * 6 + 3 + e] = c[e];
+                lo[e] = fminf(lo[e], a[e]); hi[e] = fmaxf(hi[e], c[e]);
+            }
+            ext_sum += fmaxf(fmaxf(c[0] - a[0], c[1] - a[1]), c[2] - a[2]);
+            // part boxes.  Consecutive triangles mostly belong to one part: when the whole wavefront does (and is complete),
+            // its 64 boxes are reduced on DPP and ONE lane updates the part's box -- 125 k same-address LDS atomics per frame
+            // were 50 us of this kernel.  (min / max: the result does not depend on the order.)
+            const int s0 = __builtin_amdgcn_readfirstlane(seg[u]);
+            if (__ballot(seg[u] == s0) == ~0ull) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const float wl = -wave_max_dpp(-a[e]), wh = wave_max_dpp(c[e]);
+                    if ((t & 63) == 0) { atomicMin(&s_pbox[s0][e], ford(wl)); atomicMax(&s_pbox[s0][3 + e], ford(wh)); }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) { atomicMin(&s_pbox[seg[u]][e], ford(a[e])); atomicMax(&s_pbox[seg[u]][3 + e], ford(c[e])); }
+            }
+        }
     }
     PEN_CLK(0);
     float glo[3], ghi[3];
     for (int e = 0; e < 3; ++e) { glo[e] = block_min(lo[e], red); ghi[e] = block_max(hi[e], red); }
     PEN_CLK(1);
-    // ---- part-level broad phase: bounding box of every part; a triangle whose box meets the box of
-    // no part it may collide with cannot have a partner and never enters the grid (at rest and in most
-    // poses that is nearly every triangle: the grid only sees the regions where unrelated parts meet)
-    __shared__ int s_pbox[64][6];
-    auto ford = [](float x) { int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); };      // order-preserving
-    if (t < 64) { for (int e = 0; e < 3; ++e) { s_pbox[t][e] = 0x7fffffff; s_pbox[t][3 + e] = (int)0x80000000; } }
-    __syncthreads();
-    for (int f = t; f < F; f += PEN_T) {
-        const int pf = P.segm[f];
-        for (int e = 0; e < 3; ++e) { atomicMin(&s_pbox[pf][e], ford(aabb[f * 6 + e])); atomicMax(&s_pbox[pf][3 + e], ford(aabb[f * 6 + 3 + e])); }
-    }
+    // ---- part-level broad phase: a triangle whose box meets the box of no part it may collide with cannot
+    // have a partner and never enters the grid (at rest and in most poses that is nearly every triangle: the
+    // grid only sees the regions where unrelated parts meet)
     __syncthreads();
     PEN_CLK(2);
-    unsigned char* alive = reinterpret_cast<unsigned char*>(P.ent_cell + (size_t)b * P.ent_cap + P.ent_cap - (F + 3) / 4);   // tail of the entry buffer
     // parts whose boxes meet and that may collide, as one 64-bit word per part
     __shared__ unsigned long long s_near[64];
     if (t < 64) {
@@ -250,25 +290,7 @@ void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __r
         }
         s_near[t] = m;
     }
-    __syncthreads();
-    for (int f = t; f < F; f += PEN_T) {
-        unsigned long long nm = s_near[P.segm[f]];
-        bool any = false;
-        if (nm) {
-            int a6[6];
-            for (int e = 0; e < 3; ++e) { a6[e] = ford(aabb[f * 6 + e]); a6[3 + e] = ford(aabb[f * 6 + 3 + e]); }
-            while (nm && !any) {
-                const int q = __ffsll((long long)nm) - 1;
-                nm &= nm - 1;
-                any = a6[0] <= s_pbox[q][3] && s_pbox[q][0] <= a6[3] && a6[1] <= s_pbox[q][4] && s_pbox[q][1] <= a6[4] &&
-                      a6[2] <= s_pbox[q][5] && s_pbox[q][2] <= a6[5];
-            }
-        }
-        alive[f] = any ? 1 : 0;
-    }
-    __syncthreads();
-    PEN_CLK(3);
-    const float mean_ext = block_sum_fixed(ext_sum, red) / (float)F;
+    const float mean_ext = block_sum_fixed(ext_sum, red) / (float)F;      // (its barriers also publish s_near)
     // cell size: twice the mean triangle extent; cells are addressed by integer coordinates from
     // the low corner of the frame's bounding box and hashed into PEN_CELLS buckets (a bucket that
     // mixes cells only adds candidates the AABB test rejects)
@@ -293,24 +315,69 @@ void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __r
     for (int c = t; c <= ncell; c += PEN_T) cell_cnt[c] = 0;
     for (int c = t; c < ncell; c += PEN_T) pmask[c] = 0u;
     __syncthreads();
-    for (int f = t; f < F; f += PEN_T) {
-        if (!alive[f]) continue;
-        const unsigned bit = 1u << (P.segm[f] & 31);
-        int c0[3], c1[3];
-        for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = min(cell_of(aabb[f * 6 + 3 + e], e), c0[e] + PEN_SPAN - 1); }
-        for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x)
-            atomicOr(&pmask[bucket(x & 1023, y & 1023, z & 1023)], bit);
+    // ---- pass 2: part culling, the cell range of every surviving triangle (packed: low cell coordinates mod 1024, spans,
+    // part, alive bit -- ONE coalesced 8-byte load per triangle in the two passes that follow), part masks of the buckets
+    for (int f0 = t; f0 < F; f0 += PEN_T * PEN_U) {
+        float bx[PEN_U][6]; int seg[PEN_U];
+#pragma unroll
+        for (int u = 0; u < PEN_U; ++u) {
+            const int f = f0 + u * PEN_T, ff = f < F ? f : 0;
+            seg[u] = P.segm[ff];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) bx[u][e] = aabb[ff * 6 + e];          // (written by this lane in pass 1)
+        }
+#pragma unroll
+        for (int u = 0; u < PEN_U; ++u) {
+            const int f = f0 + u * PEN_T;
+            if (f >= F) continue;
+            unsigned long long nm = s_near[seg[u]];
+            bool any = false;
+            if (nm) {
+                int a6[6];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) a6[e] = ford(bx[u][e]);
+                while (nm && !any) {
+                    const int q = __ffsll((long long)nm) - 1;
+                    nm &= nm - 1;
+                    any = a6[0] <= s_pbox[q][3] && s_pbox[q][0] <= a6[3] && a6[1] <= s_pbox[q][4] && s_pbox[q][1] <= a6[4] &&
+                          a6[2] <= s_pbox[q][5] && s_pbox[q][2] <= a6[5];
+                }
+            }
+            int2 pk = make_int2(0, 0);
+            if (any) {
+                int c0[3], sp[3];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) { c0[e] = cell_of(bx[u][e], e); sp[e] = min(cell_of(bx[u][3 + e], e), c0[e] + PEN_SPAN - 1) - c0[e]; }
+                pk.x = (c0[0] & 1023) | ((c0[1] & 1023) << 10) | ((c0[2] & 1023) << 20) | (int)0x80000000;
+                pk.y = sp[0] | (sp[1] << 3) | (sp[2] << 6) | (seg[u] << 9);
+                const unsigned bit = 1u << (seg[u] & 31);
+                for (int dz = 0; dz <= sp[2]; ++dz) for (int dy = 0; dy <= sp[1]; ++dy) for (int dx = 0; dx <= sp[0]; ++dx)
+                    atomicOr(&pmask[bucket((c0[0] + dx) & 1023, (c0[1] + dy) & 1023, (c0[2] + dz) & 1023)], bit);
+            }
+            tcell[f] = pk;
+        }
     }
     __syncthreads();
-    // ---- counting sort of (cell, triangle) entries
-    for (int f = t; f < F; f += PEN_T) {
-        if (!alive[f]) continue;
-        const unsigned want32 = s_coll32[P.segm[f]];
-        int c0[3], c1[3];
-        for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = min(cell_of(aabb[f * 6 + 3 + e], e), c0[e] + PEN_SPAN - 1); }
-        for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x) {
-            const int bk = bucket(x & 1023, y & 1023, z & 1023);
-            if (pmask[bk] & want32) atomicAdd(&cell_cnt[bk], 1);
+    PEN_CLK(3);
+    // ---- pass 3: counting sort of (cell, triangle) entries: histogram
+    auto for_cells = [&](const int2 pk, auto&& fn) {      // fn(bucket, packed cell key) for every cell of a packed range
+        const int x0 = pk.x & 1023, y0 = (pk.x >> 10) & 1023, z0 = (pk.x >> 20) & 1023;
+        const int sx = pk.y & 7, sy = (pk.y >> 3) & 7, sz = (pk.y >> 6) & 7;
+        for (int dz = 0; dz <= sz; ++dz) for (int dy = 0; dy <= sy; ++dy) for (int dx = 0; dx <= sx; ++dx) {
+            const int x = (x0 + dx) & 1023, y = (y0 + dy) & 1023, z = (z0 + dz) & 1023;
+            fn(bucket(x, y, z), x | (y << 10) | (z << 20));
+        }
+    };
+    constexpr int U2 = 7;
+    for (int f0 = t; f0 < F; f0 += PEN_T * U2) {
+        int2 pk[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) { const int f = f0 + u * PEN_T; pk[u] = f < F ? tcell[f] : make_int2(0, 0); }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            if (pk[u].x >= 0) continue;                    // (alive bit = sign bit)
+            const unsigned want32 = s_coll32[(pk[u].y >> 9) & 63];
+            for_cells(pk[u], [&](int bk, int) { if (pmask[bk] & want32) atomicAdd(&cell_cnt[bk], 1); });
         }
     }
     __syncthreads();
@@ -319,10 +386,10 @@ void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __r
     {
         const int per = (ncell + PEN_T - 1) / PEN_T;
         const int c0 = min(ncell, t * per), c1 = min(ncell, c0 + per);
-        int s = 0;
-        for (int c = c0; c < c1; ++c) s += cell_cnt[c];
+        int sm = 0;
+        for (int c = c0; c < c1; ++c) sm += cell_cnt[c];
         int tot;
-        int acc = block_excl_scan(s, slice, &tot);
+        int acc = block_excl_scan(sm, slice, &tot);
         for (int c = c0; c < c1; ++c) { const int v = cell_cnt[c]; cell_cnt[c] = acc; acc += v; }
         if (t == 0) { cell_cnt[ncell] = tot; s_total = tot; }
         __syncthreads();
@@ -333,27 +400,30 @@ void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __r
     int* entc = P.ent_cell + (size_t)b * P.ent_cap;
     // a bucket may mix several cells (and one triangle may sit in it twice, once per cell): entries
     // carry the cell they were made for, and a scan only looks at those of its own cell
-    auto cell_key = [](int x, int y, int z) { return (x & 1023) | ((y & 1023) << 10) | ((z & 1023) << 20); };
-    const bool ent_ok = s_total <= P.ent_cap - (F + 3) / 4 - 4;
-    if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = ncell; st[14] = s_total; st[15] = 0; }
+    const bool ent_ok = s_total <= P.ent_cap - 4;
+    if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = ncell; st[13] = 0; st[14] = s_total; st[15] = 0; }
     if (!ent_ok) {       // grid too crowded for the entry buffer: report, produce no pairs
         for (int f = t; f < F; f += PEN_T) P.pcount[(size_t)b * F + f] = 0;
         if (t == 0) { st[0] = 0; st[1] = 0; P.ptotal[b] = 0; P.cells[(size_t)b * (PEN_CELLS + 1) + PEN_CELLS] = 0; }
         return;
     }
-    // scatter: the start offsets double as cursors, so bucket c ends up holding its END offset
+    // ---- pass 4: scatter: the start offsets double as cursors, so bucket c ends up holding its END offset
     // (= the start of bucket c + 1); a bucket's entries are [c ? cell_cnt[c - 1] : 0, cell_cnt[c])
-    for (int f = t; f < F; f += PEN_T) {
-        if (!alive[f]) continue;
-        const unsigned want32 = s_coll32[P.segm[f]];
-        int c0[3], c1[3];
-        for (int e = 0; e < 3; ++e) { c0[e] = cell_of(aabb[f * 6 + e], e); c1[e] = min(cell_of(aabb[f * 6 + 3 + e], e), c0[e] + PEN_SPAN - 1); }
-        for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x) {
-            const int bk = bucket(x & 1023, y & 1023, z & 1023);
-            if (!(pmask[bk] & want32)) continue;
-            const int q = atomicAdd(&cell_cnt[bk], 1);
-            ent[q] = f | (P.segm[f] << 24);     // triangle | part << 24
-            entc[q] = cell_key(x, y, z);
+    for (int f0 = t; f0 < F; f0 += PEN_T * U2) {
+        int2 pk[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) { const int f = f0 + u * PEN_T; pk[u] = f < F ? tcell[f] : make_int2(0, 0); }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            if (pk[u].x >= 0) continue;
+            const int f = f0 + u * PEN_T, pf = (pk[u].y >> 9) & 63;
+            const unsigned want32 = s_coll32[pf];
+            for_cells(pk[u], [&](int bk, int key) {
+                if (!(pmask[bk] & want32)) return;
+                const int q = atomicAdd(&cell_cnt[bk], 1);
+                ent[q] = f | (pf << 24);            // triangle | part << 24
+                entc[q] = key;
+            });
         }
     }
     __threadfence_block();
@@ -456,6 +526,10 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
             const int k = qi + d;
             const bool act = k < bend;
             if (!__ballot(act)) break;
+            if (d > PEN_MAX_WALK) {                    // a bucket of thousands of entries: a mesh that has collapsed into a few cells
+                if (lane == 0) atomicAdd(&P.stats[b * PEN_STATS + 13], 1);      // (reported: sfx_pen_stats, "walks cut short")
+                break;
+            }
             if (63 + d >= staged) {                    // wave-uniform: the window's leading edge reaches the next half
                 int hn[12];
                 const int qn_ = i0 + staged + lane;
@@ -527,6 +601,7 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
         const int per = (F + PEN_T - 1) / PEN_T;
         const int f0 = min(F, t * per), f1 = min(F, f0 + per);
         int sum = 0, n_over = 0;
+#pragma unroll 8
         for (int f = f0; f < f1; ++f) { const int cnt = pc[f]; n_over += max(cnt - P.cap, 0); sum += min(cnt, P.cap); }
         int ptot;
         int acc = block_excl_scan(sum, slice, &ptot);
@@ -778,10 +853,22 @@ void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss
         float g[3] = {0.f, 0.f, 0.f};
         if (total > 0) {
             const float* tg = P.tgrad + (size_t)b * P.F * 9;
-            for (int q = P.vf_start[v]; q < P.vf_start[v + 1]; ++q) {
-                const int fc = P.vf_list[q], face = fc / 3;
-                if (pc[face] > 0 && poff[face] < P.pair_cap)
-                    for (int e = 0; e < 3; ++e) g[e] += tg[(size_t)fc * 3 + e];      // fc = face * 3 + corner -> [face][corner][3]
+            // (the incident corners in batches of 8 -- a vertex of a closed mesh has ~6 -- so that the three dependent
+            //  loads per corner overlap across the corners instead of forming one chain per corner; same summation order)
+            const int q0 = P.vf_start[v], q1 = P.vf_start[v + 1];
+            for (int qb = q0; qb < q1; qb += 8) {
+                int fc[8]; bool use[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) fc[u] = qb + u < q1 ? P.vf_list[qb + u] : -1;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int face = fc[u] >= 0 ? fc[u] / 3 : 0; use[u] = fc[u] >= 0 && pc[face] > 0 && poff[face] < P.pair_cap; }
+                float tv[8][3];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) tv[u][e] = use[u] ? tg[(size_t)fc[u] * 3 + e] : 0.f;      // fc = face * 3 + corner -> [face][corner][3]
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (use[u]) { g[0] += tv[u][0]; g[1] += tv[u][1]; g[2] += tv[u][2]; }
             }
         }
         for (int e = 0; e < 3; ++e) dverts[((size_t)b * P.V + v) * 3 + e] = g[e];
@@ -855,13 +942,14 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     const size_t B = max_batch;
     P.ent_cap = F * 32;
     P.aabb = h->zeros<float>(B * F * 6); P.entries = h->zeros<int>(B * P.ent_cap); P.ent_cell = h->zeros<int>(B * P.ent_cap);
+    P.tcell = h->zeros<int2>(B * F);
     P.partners = h->zeros<int>(B * F * P.pcap); P.pcount = h->zeros<int>(B * F); P.pavail = h->zeros<int>(B * F);
     P.pair_cap = (int)std::min<size_t>((size_t)F * P.cap, std::max<size_t>(65536, (size_t)16 * F));
     P.poff = h->zeros<int>(B * F); P.pown = h->zeros<int>(B * P.pair_cap); P.plist = h->zeros<int>(B * P.pair_cap);
     P.pout = h->zeros<float>(B * 10 * P.pair_cap); P.ptotal = h->zeros<int>(B); P.stats = h->zeros<int>(B * PEN_STATS);
     P.cells = h->zeros<int>(B * (PEN_CELLS + 1)); P.gridp = h->zeros<float>(B * 4);
     P.tgrad = h->zeros<float>(B * F * 9); P.tloss = h->zeros<float>(B * F);
-    if (!P.cells || !P.gridp || !P.tgrad || !P.tloss) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
+    if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tcell || !P.aabb || !P.entries || !P.ent_cell) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.pavail || !P.ptotal) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     *out = h;
     return 0;
@@ -931,7 +1019,7 @@ extern "C" int sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host /* [B][4
         // r[15]: ordered pairs in the list that only one of the two triangles kept (max_collisions cut the other's list):
         // they contribute nothing and count as dropped
         stats_host[i * 4 + 0] = r[0] - r[15]; stats_host[i * 4 + 1] = r[1] + r[15];
-        stats_host[i * 4 + 2] = r[2]; stats_host[i * 4 + 3] = r[3];
+        stats_host[i * 4 + 2] = r[2]; stats_host[i * 4 + 3] = r[13];      // [3]: walks cut short at PEN_MAX_WALK entries (0 on a sane mesh)
     }
     return 0;
 }

@@ -446,7 +446,7 @@ class Penetration(object):
     def stats(self, B):
         out = np.zeros((B, 4), np.int32)
         capi.check(self._lib.sfx_pen_stats(self._h, int(B), capi.iptr(out)))
-        return dict(pairs=out[:, 0].copy(), dropped=out[:, 1].copy(), entry_overflow=out[:, 2].copy(), cells=out[:, 3].copy())
+        return dict(pairs=out[:, 0].copy(), dropped=out[:, 1].copy(), entry_overflow=out[:, 2].copy(), walks_cut=out[:, 3].copy())
 
     def phase_clocks(self, B):
         """Debug: microseconds at the end of the broad phase's ten steps, grid entries (see sfx_pen_phase_clocks)."""

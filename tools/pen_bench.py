@@ -13,5 +13,5 @@ for B in (1, 64, 256):
     for _ in range(10): pen.eval(vb, 1e-4)
     torch.cuda.synchronize(); dt=(time.time()-t0)/10
     st = pen.stats(B)
-    print("B=%d  %.1f us per eval, pairs/frame %d, cells %d" % (B, dt*1e6, st["pairs"][0], st["cells"][0]))
+    print("B=%d  %.1f us per eval, pairs/frame %d, walks cut %d" % (B, dt*1e6, st["pairs"][0], st["walks_cut"][0]))
     pen.close()
