@@ -132,6 +132,10 @@ typedef struct sfx_batch_cfg {
                                        that finish (continuous batching): the reference's loop over frames
                                        (main.py:207) for jobs larger than one GEMM batch.  A frame's result does
                                        not depend on when it is admitted or which column it gets              */
+    int32_t high_precision;         /* cfg float_dtype: float64 (main.py:99-105): besides the keypoint forward (always fp64) the
+                                       projection up to the pixel residual is carried in fp64 in every stage -- gradient noise
+                                       0.13 x torch fp32's, the fits behave like the reference's float64 run;
+                                       parameters, reverse sweep and optimiser stay fp32                          */
 } sfx_batch_cfg;
 
 int  sfx_batch_create(sfx_model* m, const sfx_batch_cfg* cfg,
@@ -225,6 +229,11 @@ int  sfx_batch_get_trace(sfx_batch* b, float* records, int32_t* counts);
  * means [M][D], precisions [M][D][D], nll_weights [M] = the module's buffers; D = 63, M <= 8 (HOST). */
 int  sfx_batch_set_gmm(sfx_batch* b, int32_t M, int32_t D, const float* means, const float* precisions,
                        const float* nll_weights);
+/* The same prior in its per-component form (MaxMixturePrior(use_merged=False), prior.py:203-225):
+ *   m* = argmin_m [ d_m^T P_m d_m + comp_const_m ],  value = d^T P d + comp_const (at m*) - log nll_weights_m*
+ * comp_const [M] = 0.5 (log(det cov_m + epsilon) + D log 2 pi) (HOST); comp_const NULL = the merged form above.   */
+int  sfx_batch_set_gmm_form(sfx_batch* b, int32_t M, int32_t D, const float* means, const float* precisions,
+                            const float* nll_weights, const float* comp_const);
 
 /* Final meshes / joints at the current parameters (dense LBS; DEVICE pointers, may be NULL). */
 int  sfx_batch_forward(sfx_batch* b, float* vertices_out_dev /* [B][V][3] */,

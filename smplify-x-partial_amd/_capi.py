@@ -52,7 +52,7 @@ class BatchCfg(C.Structure):
         ("lbs_mode", C.c_int32), ("reuse_entry_eval", C.c_int32),
         ("side_view_thsh", C.c_float), ("left_shoulder_idx", C.c_int32), ("right_shoulder_idx", C.c_int32),
         ("interpenetration", C.c_int32), ("max_collisions", C.c_int32), ("df_cone_height", C.c_float),
-        ("penalize_outside", C.c_int32), ("slots", C.c_int32),
+        ("penalize_outside", C.c_int32), ("slots", C.c_int32), ("high_precision", C.c_int32),
     ]
 
 
@@ -91,6 +91,7 @@ SYMBOLS = {
     "sfx_pen_phase_clocks": (C.c_int, [C.c_void_p, C.c_int32, i32p]),
     "sfx_debug_clocks": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "sfx_batch_set_gmm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, f32p, f32p]),
+    "sfx_batch_set_gmm_form": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, f32p, f32p, f32p]),
     "sfx_batch_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, f32p, C.c_int64]),
     "sfx_prof_enable": (C.c_int, [C.c_int32]),
     "sfx_prof_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

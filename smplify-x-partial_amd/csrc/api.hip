@@ -545,6 +545,7 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.cfg.reuse = c->reuse_entry_eval;
     D.cfg.side_thsh = c->side_view_thsh; D.cfg.lsh = c->left_shoulder_idx; D.cfg.rsh = c->right_shoulder_idx;
     D.cfg.pen = c->interpenetration ? 1 : 0;
+    D.cfg.proj64 = c->high_precision ? 1 : 0;
     if (D.cfg.pen && c->lbs_mode != 1) {
         sfx_set_error("interpenetration needs lbs_mode = 1 (the term reads every vertex)"); delete b; return -1; }
     if (D.cfg.pen && !(c->df_cone_height > 0.f)) { sfx_set_error("df_cone_height must be positive"); delete b; return -1; }
@@ -565,7 +566,11 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     add_group(cam, L.cam_t, 3, 1); add_group(cam, L.go, 3, 1);
     // order of smplx.SMPLX.parameters() then pose_embedding (fit_single_frame.py:554-559)
     add_group(body, L.betas, L.NB, 1); add_group(body, L.go, 3, 1);
-    if (L.has_bodyp) add_group(body, L.bodyp, 63, 0);
+    // the dead body_pose parameter (zero gradient, never moves: SURVEY 7 quirk) takes 63 slots of the optimiser's vectors; with
+    // all 45 + 45 hand variables (use_pca=False) the list would not fit, so it is left out there -- entries that are identically
+    // zero in x, g, d, s and y contribute nothing to any dot product or norm of LBFGS.step / _strong_Wolfe
+    const int n_live = L.NB + 3 + 2 * L.NPCA + 9 + L.NE + L.NEMB;
+    if (L.has_bodyp && n_live + 63 <= SFX_NVAR_MAX) add_group(body, L.bodyp, 63, 0);
     add_group(body, L.lh, L.NPCA, 1); add_group(body, L.rh, L.NPCA, 1);
     add_group(body, L.jaw, 3, 1); add_group(body, L.leye, 3, 1); add_group(body, L.reye, 3, 1);
     add_group(body, L.expr, L.NE, 1); add_group(body, L.emb, L.NEMB, 1);
@@ -1286,8 +1291,14 @@ extern "C" int sfx_batch_step(sfx_batch* b, int32_t stage, int32_t resume, float
 
 // body_pose_prior = MaxMixturePrior (prior.py:100-231) for use_vposer=False fits without a regression
 // prior (fitting.py:399-401).  means [M][D], precisions [M][D][D], nll_weights [M] (as the module's buffers)
+extern "C" int sfx_batch_set_gmm_form(sfx_batch* b, int32_t M, int32_t Dm, const float* means, const float* precisions,
+                                      const float* nll_weights, const float* comp_const);
 extern "C" int sfx_batch_set_gmm(sfx_batch* b, int32_t M, int32_t Dm, const float* means, const float* precisions,
                                  const float* nll_weights) {
+    return sfx_batch_set_gmm_form(b, M, Dm, means, precisions, nll_weights, nullptr);
+}
+extern "C" int sfx_batch_set_gmm_form(sfx_batch* b, int32_t M, int32_t Dm, const float* means, const float* precisions,
+                                      const float* nll_weights, const float* comp_const) {
     if (!b || !means || !precisions || !nll_weights) { sfx_set_error("null argument"); return -1; }
     if (M < 1 || M > 2 * (256 / 64)) { sfx_set_error("1..8 mixture components supported, got %d", M); return -1; }
     if (b->D.cfg.use_vposer) { sfx_set_error("the mixture prior acts on body_pose: use_vposer must be off"); return -1; }
@@ -1302,8 +1313,12 @@ extern "C" int sfx_batch_set_gmm(sfx_batch* b, int32_t M, int32_t Dm, const floa
                 P[((size_t)m * 64 + j) * 64 + i] = 0.5f * (precisions[((size_t)m * Dm + i) * Dm + j] + precisions[((size_t)m * Dm + j) * Dm + i]);
         }
     }
+    // merged form (prior.py:186-201): min_m [0.5 q_m - log w_m]; per-component form (:203-225): argmin_m [q_m + c_m], value + (-log w_m*)
+    std::vector<float> csel(M), cadd(M);
+    for (int m = 0; m < M; ++m) { csel[m] = comp_const ? comp_const[m] : -lw[m]; cadd[m] = comp_const ? -lw[m] : 0.f; }
     b->D.gmm_mean = b->mem.up(mu); b->D.gmm_prec = b->mem.up(P); b->D.gmm_lognw = b->mem.up(lw);
-    if (!b->D.gmm_mean || !b->D.gmm_prec || !b->D.gmm_lognw) { sfx_set_error("out of device memory"); return -2; }
+    b->D.gmm_csel = b->mem.up(csel); b->D.gmm_cadd = b->mem.up(cadd); b->D.gmm_scale = comp_const ? 1.f : 0.5f;
+    if (!b->D.gmm_mean || !b->D.gmm_prec || !b->D.gmm_lognw || !b->D.gmm_csel || !b->D.gmm_cadd) { sfx_set_error("out of device memory"); return -2; }
     b->D.gmm_M = M;
     return 0;
 }

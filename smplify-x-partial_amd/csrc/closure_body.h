@@ -694,6 +694,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         // its ~45 evaluations of K = 4 joints cost nothing.
         float pcx, pcy, pcz, rx, ry;
         if (cam_stage) project_residual<double>(&S.jd[t * 3], Rc, ct, fx, fy, cx, cy, fd[FD_GT + 2 * t], fd[FD_GT + 2 * t + 1], pcx, pcy, pcz, rx, ry);
+        else if (C.proj64) project_residual<double>(&S.jd[t * 3], Rc, ct, fx, fy, cx, cy, fd[FD_GT + 2 * t], fd[FD_GT + 2 * t + 1], pcx, pcy, pcz, rx, ry);      // (cfg float_dtype: float64)
         else project_residual<proj_t>(&S.jd[t * 3], Rc, ct, fx, fy, cx, cy, fd[FD_GT + 2 * t], fd[FD_GT + 2 * t + 1], pcx, pcy, pcz, rx, ry);
         float du, dv;       // dL/du, dL/dv
         if (cam_stage) {
@@ -745,7 +746,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
                     contrib = y * (S.x[L.emb + lane] - mu[lane]);
                 }
                 const float quad = wave_sum_dpp(contrib);
-                if (lane == 0 && m < D.gmm_M) S.red[m] = 0.5f * quad - D.gmm_lognw[m];
+                if (lane == 0 && m < D.gmm_M) S.red[m] = D.gmm_scale * quad + D.gmm_csel[m];      // (merged: 0.5 q - log nll_w; per component: q + const)
             }
             __syncthreads();
             int best = 0; float bl = S.red[0];
@@ -753,8 +754,8 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
             __syncthreads();
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
-                if (wv + mi * (CT / 64) == best && lane < L.NEMB) S.gc[L.emb + lane] = gy[mi] * bpw2;
-            if (t == 0) q[Q_PP] = bl;
+                if (wv + mi * (CT / 64) == best && lane < L.NEMB) S.gc[L.emb + lane] = (2.f * D.gmm_scale) * gy[mi] * bpw2;
+            if (t == 0) q[Q_PP] = bl + D.gmm_cadd[best];
         } else if (t < L.NEMB) {       // pose prior on the embedding (fitting.py:390-401)
             const float e = S.x[L.emb + t];
             const float dlt = latent_reg ? (e - fd[FD_REG + t]) : e;

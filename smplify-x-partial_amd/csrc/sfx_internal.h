@@ -163,6 +163,7 @@ struct BatchCfgDev {
     float side_thsh; int lsh, rsh;     // side-view test: 2-D shoulder distance threshold, indices
     int pen;                           // interpenetration term enabled (dense mode)
     int kl[3], nil[3];                 // live keypoints / vertex items by stage class: body only, + hands, all (closure_body)
+    int proj64;                        // projection in fp64 in every stage (cfg float_dtype float64; the camera stage always is)
 };
 
 // Per-frame data pointers (all device).
@@ -214,6 +215,9 @@ struct BatchDev {
     const float* gmm_mean;  // [M][64]
     const float* gmm_prec;  // [M][64][64] symmetrised precisions, rows padded
     const float* gmm_lognw; // [M] log nll_weights
+    const float* gmm_csel;  // [M] constant of a component in the selection: -log nll_weights (merged form) | comp_const (per-component form)
+    const float* gmm_cadd;  // [M] added to the selected component's value: 0 | -log nll_weights
+    float gmm_scale;        // factor of the quadratic form: 0.5 | 1
     float* vposed;          // [B][V][3] (slot-indexed) v_posed of every vertex, written by the dense GEMM when the term is on
     float* adj_G;           // [Bpad][3*Vpad] (slot-indexed) d v_posed = T^T d verts: operand of the adjoint GEMM
     float* adj_part;        // [slices][KD_PAD][Bpad] its per-slice partial sums

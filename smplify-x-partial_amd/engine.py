@@ -71,8 +71,13 @@ class DeviceModel(object):
 
     def __init__(self, model, joint_map=None, num_betas=10, num_expression_coeffs=10,
                  num_pca_comps=12, flat_hand_mean=False, use_face_contour=True,
-                 extra_vertex_ids=None, vposer=None):
+                 extra_vertex_ids=None, vposer=None, use_pca=True):
+        """use_pca=False (cmd_parser.py:127, smplx.SMPLX): the hand pose parameters are the 45 axis-angle values
+        themselves -- the same kernels with identity 'components'."""
         lib = capi.load()
+        self.use_pca = bool(use_pca)
+        if not self.use_pca:
+            num_pca_comps = 45
         sd = np.asarray(model["shapedirs"])
         es = 300 if sd.shape[-1] >= 400 else 10
         sdirs = np.concatenate([sd[:, :, :num_betas], sd[:, :, es:es + num_expression_coeffs]], -1)
@@ -99,8 +104,8 @@ class DeviceModel(object):
             v_template=capi.f32(model["v_template"]), shapedirs=capi.f32(sdirs),
             posedirs=capi.f32(model["posedirs"]), J_regressor=capi.f32(model["J_regressor"]),
             lbs_weights=capi.f32(model["weights"]), parents=capi.i32(parents),
-            hands_comp_l=capi.f32(np.asarray(model["hands_componentsl"])[:num_pca_comps]),
-            hands_comp_r=capi.f32(np.asarray(model["hands_componentsr"])[:num_pca_comps]),
+            hands_comp_l=capi.f32(np.asarray(model["hands_componentsl"])[:num_pca_comps] if self.use_pca else np.eye(45)),
+            hands_comp_r=capi.f32(np.asarray(model["hands_componentsr"])[:num_pca_comps] if self.use_pca else np.eye(45)),
             pose_mean=capi.f32(pose_mean), faces=faces,
             extra=capi.i32(extra_vertex_ids), lmk_f=capi.i32(model["lmk_faces_idx"]),
             lmk_b=capi.f32(model["lmk_bary_coords"]), dyn_f=capi.i32(dyn_f),
@@ -221,6 +226,8 @@ class FrameBatch(object):
         c.df_cone_height = float(cfg.get("df_cone_height", 0.5))
         c.penalize_outside = int(bool(cfg.get("penalize_outside", True)))
         c.slots = int(slots or 0)
+        # cfg float_dtype: float64 (main.py:99-105) -> the engine's high-precision mode (include/sfx.h sfx_batch_cfg.high_precision)
+        c.high_precision = int(str(cfg.get("float_dtype", "float32")) == "float64" or bool(cfg.get("high_precision", False)))
         if c.interpenetration and lbs_mode != "dense":
             raise ValueError("interpenetration=True needs lbs_mode='dense' (the term reads every vertex)")
         self.use_vposer = bool(c.use_vposer)
@@ -230,6 +237,7 @@ class FrameBatch(object):
         capi.check(self._lib.sfx_batch_create(model._h, C.byref(c), arr, C.byref(h)))
         self._h = h
         self.K = model.K
+        self._trace_cap = 0
 
     # ---- data ------------------------------------------------------------------------------
     def set_frames(self, keypoints, joint_weights, cam_init_mask, focal, center, data_weight, est_tz=None,
@@ -302,12 +310,17 @@ class FrameBatch(object):
     def set_gmm(self, prior):
         """Body pose prior = prior.MaxMixturePrior (body_prior_type 'gmm'): used by the closure when
         use_vposer is off and the batch has no regression pose (fitting.py:399-401)."""
-        if not getattr(prior, "use_merged", True):
-            raise NotImplementedError("MaxMixturePrior(use_merged=False): only the merged form (the reference's default) is on the device")
         mu = np.ascontiguousarray(prior.means.detach().cpu().numpy(), np.float32)
         P = np.ascontiguousarray(prior.precisions.detach().cpu().numpy(), np.float32)
         nw = np.ascontiguousarray(prior.nll_weights.detach().cpu().numpy().reshape(-1), np.float32)
-        capi.check(self._lib.sfx_batch_set_gmm(self._h, mu.shape[0], mu.shape[1], capi.fptr(mu), capi.fptr(P), capi.fptr(nw)))
+        cc = None
+        if not getattr(prior, "use_merged", True):
+            # MaxMixturePrior.log_likelihood (prior.py:203-225): d^T P d + 0.5 (log(det cov + eps) + D log 2 pi) per component
+            import torch
+            cov_term = torch.log(torch.det(prior.covs) + prior.epsilon)
+            cc = np.ascontiguousarray((0.5 * (cov_term + prior.random_var_dim * prior.pi_term)).detach().cpu().numpy().reshape(-1), np.float32)
+        capi.check(self._lib.sfx_batch_set_gmm_form(self._h, mu.shape[0], mu.shape[1], capi.fptr(mu), capi.fptr(P), capi.fptr(nw),
+                                                    capi.fptr(cc) if cc is not None else None))
 
     _DEBUG_PER_FRAME = dict(verts="V3", vposed="V3", pen_dverts="V3", pen_dfeat=512, feat=512, pen_dA=55 * 12, A=12 * 55,
                             pen_loss=1)

@@ -3,7 +3,7 @@ create_loss / SMPLifyLoss / SMPLifyCameraInitLoss (:278-520).
 
 The objects keep the reference's constructor kwargs, attributes and call conventions, but the
 arithmetic of the closure (LBS, projection, losses, adjoint) and of the optimiser runs in
-libsfx.so: `create_fitting_closure` binds a one-frame `engine.FrameBatch` to the caller's
+libsfx.so (the loss modules' stand-alone forward evaluates the same device objective without backward): `create_fitting_closure` binds a one-frame `engine.FrameBatch` to the caller's
 tensors; the closure it returns evaluates loss + gradients on the GPU and stores them in the
 parameters' `.grad`; `run_fitting` executes the whole step loop on device.  There is no
 autograd graph and no CPU fallback.
@@ -88,9 +88,14 @@ class SMPLifyLoss(nn.Module):
                     new = torch.tensor(v, dtype=cur.dtype, device=cur.device)
                 setattr(self, key, new)
 
-    def forward(self, *args, **kwargs):
-        raise RuntimeError("SMPLifyLoss is evaluated inside the closure returned by "
-                           "FittingMonitor.create_fitting_closure (HIP path); it has no stand-alone CPU forward")
+    def forward(self, body_model_output, camera, gt_joints, joints_conf, body_model_faces=None, joint_weights=None,
+                use_vposer=False, pose_embedding=None, stage=0, **kwargs):
+        """Stand-alone evaluation (fitting.py:375-461; keyword set of :251-259): the total loss of the DEVICE objective
+        (csrc/closure_body.h, no backward) at the parameters `body_model_output` was made from -- a ModelOutput of this
+        package's SMPLX.forward, which remembers them.  `stage` matters only for the latent regression prior
+        (fitting.py:391-395: last stage).  Returns a 0-d tensor like the reference; it carries no autograd graph."""
+        return _standalone_loss(self, body_model_output, camera, gt_joints, joints_conf, joint_weights, use_vposer,
+                                pose_embedding, stage)
 
 
 class SMPLifyCameraInitLoss(nn.Module):
@@ -116,12 +121,37 @@ class SMPLifyCameraInitLoss(nn.Module):
                 cur = getattr(self, key)
                 setattr(self, key, torch.tensor(loss_weight_dict[key], dtype=cur.dtype, device=cur.device))
 
-    def forward(self, *args, **kwargs):
-        raise RuntimeError("SMPLifyCameraInitLoss is evaluated inside the fitting closure (HIP path)")
+    def forward(self, body_model_output, camera, gt_joints, body_model=None, **kwargs):
+        """Stand-alone evaluation (fitting.py:499-520) of the device camera-initialisation loss at the parameters
+        `body_model_output` was made from (see SMPLifyLoss.forward)."""
+        return _standalone_loss(self, body_model_output, camera, gt_joints, None, None, False,
+                                kwargs.get("pose_embedding"), 0)
 
 
 def _np(t):
     return t.detach().to("cpu", torch.float32).numpy()
+
+
+class _NoMonitor(object):
+    """Tolerances of a closure that is only evaluated (stand-alone loss): never used by an optimiser."""
+    maxiters, ftol, gtol, steps = 1, 0.0, 0.0, 0
+
+
+def _standalone_loss(loss, out, camera, gt_joints, joints_conf, joint_weights, use_vposer, pose_embedding, stage):
+    bm, inputs = getattr(out, "_model", None), getattr(out, "_inputs", None)
+    if bm is None or inputs is None:
+        raise RuntimeError("the stand-alone loss evaluates the device objective at the PARAMETERS a ModelOutput was made "
+                           "from: pass the output of this package's SMPLX.forward (it remembers them); there is no CPU forward")
+    if joint_weights is None:
+        joint_weights = torch.ones_like(gt_joints[..., 0])
+    pe = pose_embedding if pose_embedding is not None else inputs["body_pose"]
+    c = EngineClosure(_NoMonitor(), None, bm, camera, gt_joints, loss, joints_conf, joint_weights, bool(use_vposer), None,
+                      pe, return_verts=True)
+    try:
+        return c(stage=stage, backward=False, inputs=inputs)
+    finally:
+        if c._fb is not None:
+            c._fb.close()
 
 
 class EngineClosure(object):
@@ -175,6 +205,7 @@ class EngineClosure(object):
         cfg = dict(use_vposer=self.use_vposer, use_hands=use_hands, use_face=use_face,
                    use_joints_conf=bool(getattr(loss, "use_joints_conf", False)),
                    use_conf_for_camera_init=bool(getattr(loss, "use_conf", False)),
+                   high_precision=getattr(bm, "dtype", torch.float32) == torch.float64,
                    maxiters=self.monitor.maxiters, ftol=self.monitor.ftol, gtol=self.monitor.gtol,
                    lr=getattr(opt, "lr", 1.0), rho=getattr(loss, "rho", 100),
                    depth_loss_weight=(float(getattr(loss, "depth_loss_weight", 0.0))
@@ -203,9 +234,12 @@ class EngineClosure(object):
         self._stepped = False
         return fb
 
-    def _push(self, fb):
+    def _push(self, fb, inputs=None):
         bm = self.body_model
-        g = lambda n: _np(getattr(bm, n)) if hasattr(bm, n) else None
+        if inputs is not None:      # stand-alone loss: the tensors a ModelOutput was made from
+            g = lambda n: _np(inputs[n]) if inputs.get(n) is not None else None
+        else:
+            g = lambda n: _np(getattr(bm, n)) if hasattr(bm, n) else None
         reg = None
         if not self.is_camera and self.loss.regression_pose is not None:
             reg = _np(self.loss.regression_pose)
@@ -244,9 +278,9 @@ class EngineClosure(object):
                                       "or body_model.parameters() + [pose_embedding] (body stages); got another set")
 
     # ---- the reference's fitting_func(stage=0, backward=True) ------------------------------------
-    def __call__(self, stage=0, backward=True):
+    def __call__(self, stage=0, backward=True, inputs=None):
         fb = self._batch(stage)
-        self._push(fb)
+        self._push(fb, inputs)
         loss, grad = fb.closure(-1 if self.is_camera else 0)
         if backward:
             self._set_grads(grad)
@@ -256,10 +290,16 @@ class EngineClosure(object):
 
     def _set_grads(self, grad):
         o = 0
-        for p in self._var_params():
+        ps = self._var_params()
+        # (the device leaves the dead body_pose parameter out of its variable vector when it would not fit: use_pca=False)
+        dead_on_device = sum(p.numel() for p in ps) == grad.shape[1]
+        for p in ps:
             n = p.numel()
-            gsl = torch.as_tensor(grad[0, o:o + n]).reshape(p.shape).to(p)
-            p.grad = gsl if not (self._is_dead(p)) else None
+            if self._is_dead(p):
+                p.grad = None
+                o += n if dead_on_device else 0
+                continue
+            p.grad = torch.as_tensor(grad[0, o:o + n]).reshape(p.shape).to(p)
             o += n
 
     def _is_dead(self, p):

@@ -86,8 +86,12 @@ def main(**args):
     mesh_folder = osp.join(output_folder, args.pop("mesh_folder", "meshes"))
     for d in (result_folder, mesh_folder, osp.join(output_folder, "images")):
         os.makedirs(d, exist_ok=True)
-    if args.get("float_dtype", "float32") != "float32":
-        raise ValueError("the MI355X engine computes in float32 (cfg float_dtype: float32)")
+    if args.get("float_dtype", "float32") not in ("float32", "float64"):
+        raise ValueError("Unknown float type {}, exiting!".format(args.get("float_dtype")))      # main.py:99-105
+    if args.get("float_dtype", "float32") == "float64":
+        warnings.warn("float_dtype: float64 selects the engine's high-precision mode (keypoint forward AND projection in fp64; "
+                      "parameters, reverse sweep and optimiser stay fp32): the fits behave like the reference's float64 run "
+                      "(DESIGN.md 3.1), they are not an end-to-end float64 evaluation")
     if args.get("use_cuda", True) and not torch.cuda.is_available():
         print("CUDA is not available, exiting!")
         sys.exit(-1)

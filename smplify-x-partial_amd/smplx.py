@@ -17,10 +17,17 @@ import torch.nn as nn
 from . import engine
 from .synthetic import SMPLX_EXTRA_VERTEX_IDS
 
-ModelOutput = namedtuple("ModelOutput",
-                         ["vertices", "joints", "full_pose", "betas", "global_orient", "body_pose",
-                          "expression", "left_hand_pose", "right_hand_pose", "jaw_pose"])
-ModelOutput.__new__.__defaults__ = (None,) * len(ModelOutput._fields)
+_ModelOutput = namedtuple("ModelOutput",
+                          ["vertices", "joints", "full_pose", "betas", "global_orient", "body_pose",
+                           "expression", "left_hand_pose", "right_hand_pose", "jaw_pose"])
+_ModelOutput.__new__.__defaults__ = (None,) * len(_ModelOutput._fields)
+
+
+class ModelOutput(_ModelOutput):
+    """smplx.ModelOutput (a namedtuple).  Outputs of SMPLX.forward below also remember the model and the exact parameter
+    tensors they were made from (`_model`, `_inputs`): the stand-alone SMPLifyLoss.forward evaluates the device objective there."""
+
+
 SMPLXOutput = ModelOutput
 
 
@@ -44,10 +51,13 @@ class SMPLX(nn.Module):
                  flat_hand_mean=False, num_betas=10, num_expression_coeffs=10, use_face_contour=False,
                  gender="neutral", ext="npz", vposer=None, **kwargs):
         super().__init__()
-        if dtype != torch.float32:
-            raise ValueError("the MI355X engine computes in float32 (cfg float_dtype: float32)")
+        if dtype not in (torch.float32, torch.float64):
+            raise ValueError("Unknown float type {}".format(dtype))
+        # dtype float64 (cfg float_dtype, main.py:99-105): parameters and outputs are float64 CONTAINERS; the engine's
+        # arithmetic is its own (fp32 parameters / reverse sweep / optimiser, fp64 keypoint forward, and -- in batches created
+        # with float_dtype float64 -- fp64 projection as well: sfx_batch_cfg.high_precision)
         if not use_pca:
-            raise NotImplementedError("use_pca=False (45-D hand pose) is not on the supported path")
+            num_pca_comps = 45          # the hand pose parameters are the 45 axis-angle values (cmd_parser.py:127)
         if create_transl:
             raise NotImplementedError("create_transl=True is not used by the reference (main.py:120)")
         if isinstance(model_path, dict):
@@ -69,7 +79,7 @@ class SMPLX(nn.Module):
             jm = joint_mapper.joint_maps.detach().cpu().numpy()
         self._cfg = dict(joint_map=jm, num_betas=num_betas, num_expression_coeffs=num_expression_coeffs,
                          num_pca_comps=num_pca_comps, flat_hand_mean=flat_hand_mean, use_face_contour=use_face_contour,
-                         extra_vertex_ids=data.get("extra_vertex_ids", SMPLX_EXTRA_VERTEX_IDS), vposer=vposer)
+                         extra_vertex_ids=data.get("extra_vertex_ids", SMPLX_EXTRA_VERTEX_IDS), vposer=vposer, use_pca=use_pca)
         self._dm = None
         self.faces = np.asarray(data["f"]).astype(np.int64)
         self.register_buffer("faces_tensor", torch.as_tensor(self.faces, dtype=torch.long))
@@ -127,12 +137,19 @@ class SMPLX(nn.Module):
         rh = pick(right_hand_pose, "right_hand_pose", self.num_pca_comps)
         verts, joints, full_pose = dm.lbs_forward(go, bp, be, ex, jw, le, re, lh, rh, return_verts=return_verts,
                                                   return_full_pose=True)
-        return ModelOutput(vertices=verts if return_verts else None, joints=joints,
+        if self.dtype != torch.float32:         # float64 containers
+            cast = lambda x: x.to(self.dtype) if x is not None else None
+            verts, joints, full_pose, be, go, bp, ex, jw = (cast(x) for x in (verts, joints, full_pose, be, go, bp, ex, jw))
+        inputs = dict(global_orient=go, body_pose=bp, betas=be, expression=ex, jaw_pose=jw, leye_pose=le, reye_pose=re,
+                      left_hand_pose=lh, right_hand_pose=rh)
+        out = ModelOutput(vertices=verts if return_verts else None, joints=joints,
                            full_pose=full_pose if return_full_pose else None, betas=be, global_orient=go,
                            body_pose=bp, expression=ex,
-                           left_hand_pose=full_pose[:, 75:120] - torch.as_tensor(dm_pose_mean(self, 75), device=dev),
-                           right_hand_pose=full_pose[:, 120:165] - torch.as_tensor(dm_pose_mean(self, 120), device=dev),
+                           left_hand_pose=full_pose[:, 75:120] - torch.as_tensor(dm_pose_mean(self, 75), device=dev, dtype=full_pose.dtype),
+                           right_hand_pose=full_pose[:, 120:165] - torch.as_tensor(dm_pose_mean(self, 120), device=dev, dtype=full_pose.dtype),
                            jaw_pose=jw)
+        out._model, out._inputs = self, inputs
+        return out
 
 
 def dm_pose_mean(model, start):

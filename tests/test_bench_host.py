@@ -97,3 +97,17 @@ def test_benchmark_detector_keeps_three_camera_keypoints_and_matches_the_golden_
     g = np.load(os.path.join(ROOT, "tests", "golden", "e2e_bench.npz"))
     assert (g["keypoints"][:, list(cam), 2] > 0).sum(1).min() >= 3
     assert np.array_equal(g["keypoints"][..., 2] > 0, kept["keypoints"][:64, :, 2] > 0)       # same dropout pattern, frame by frame
+
+
+def test_raw_sequence_golden_is_the_filtered_one_with_two_frames_replaced():
+    """bench.load_bench_golden(raw=True): frames 23 and 51 (two camera-initialisation keypoints dropped on the SURVEY 8(d)
+    sequence) carry their raw keypoints and the reference's fits of THOSE; the other 62 frames are shared."""
+    import bench
+    from smplifyx_amd import synthetic
+    f, r = bench.load_bench_golden(False), bench.load_bench_golden(True)
+    d = np.abs(f["keypoints"] - r["keypoints"]).reshape(64, -1).max(1)
+    assert np.flatnonzero(d > 0).tolist() == [23, 51]
+    for i in (23, 51):
+        assert not np.array_equal(f["f%d_f32_losses" % i], r["f%d_f32_losses" % i])
+        assert (r["keypoints"][i][[9, 12, 2, 5], 2] == 0).sum() == 2      # two of the four camera keypoints missing
+    assert np.array_equal(f["f7_f32_losses"], r["f7_f32_losses"])

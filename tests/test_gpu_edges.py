@@ -230,3 +230,151 @@ def test_vertices_with_many_skinning_weights(synth_model, cfg_body, mode):
         for i in range(B):
             lo, go = T._oracle_closure(model, cfg, frames, i, P, stage)
             H.check_closure("12-weights-%s" % mode, stage, loss[i], lo, grad[i], go)
+
+
+@pytest.mark.parametrize("mode", ["rows", "dense"])
+def test_use_pca_false_closure_matches_oracle(synth_model, mode):
+    """use_pca=False (cmd_parser.py:127; smplx.SMPLX): 45 + 45 hand pose variables.  248 optimisation variables with the dead
+    body_pose parameter, which the device leaves out of its 192-wide vectors (185): closure against the oracle built with
+    use_pca=False, gradient compared on the live variables."""
+    from oracle.body_model import SMPLXRef
+    cfg = H.load_cfg("fit_smplx_combined_coco25.yaml")
+    cfg["use_camera_prior"] = False
+    from smplifyx_amd import engine
+    dm = engine.DeviceModel(synth_model, joint_map=H.joint_map_for(cfg), num_betas=10, num_expression_coeffs=10,
+                            use_face_contour=cfg["use_face_contour"], use_pca=False)
+    assert dm.num_pca == 45
+    B = 2
+    frames = T.synth_frames(synth_model, cfg, 3)
+    frames = {k: (v[:B] if isinstance(v, np.ndarray) else v) for k, v in frames.items()}
+    fb = H.engine_batch_from_frames(dm, cfg, frames, range(B), lbs_mode=mode)
+    assert fb.num_vars(0) == 248 - 63
+    rng = np.random.RandomState(21)
+    P = H.random_params(rng, B, scale=0.5, npca=45)
+    P["left_hand_pose"] *= 0.2; P["right_hand_pose"] *= 0.2
+    P["pose_embedding"] = frames["reg_pose"] + 0.1 * rng.normal(size=(B, 63)).astype(np.float32)
+    P["global_orient"] = frames["reg_global"] + 0.1 * rng.normal(size=(B, 3)).astype(np.float32)
+    P["cam_translation"] = (frames["cam_t"] + 0.3 * rng.normal(size=(B, 3))).astype(np.float32)
+    est = (frames["cam_t"][:, 2] + 1.0).astype(np.float32)
+    fb.set_frames(frames["keypoints"], T._jw(cfg, frames), T._cmask(cfg, frames), frames["focal"],
+                  np.tile([frames["W"] * 0.5, frames["H"] * 0.5], (B, 1)), 1000.0 / frames["H"], est_tz=est)
+    fb.set_params(regression_pose=frames["reg_pose"], **P)
+    P["est_tz"] = est
+    orig = H.oracle_model
+    H.oracle_model = lambda model, cfg_, dtype=torch.float32: SMPLXRef(
+        model, joint_map=H.joint_map_for(cfg_), num_betas=cfg_["num_betas"], num_expression_coeffs=cfg_["num_expression_coeffs"],
+        use_pca=False, use_face_contour=cfg_["use_face_contour"], create_body_pose=True, dtype=dtype)
+    try:
+        for stage in (-1, 0, 2):
+            loss, grad = fb.closure(stage)
+            for i in range(B):
+                lo, go = T._oracle_closure(synth_model, cfg, frames, i, P, stage)
+                if stage >= 0:
+                    assert go.size == 248 and np.all(go[13:76] == 0)
+                    go = np.concatenate([go[:13], go[76:]])          # (the dead body_pose parameter is not a device variable here)
+                H.check_closure("pca-off-full-%s" % mode, stage, loss[i], lo, grad[i], go)
+    finally:
+        H.oracle_model = orig
+
+
+def test_high_precision_mode_closure_matches_oracle(synth_model):
+    """cfg float_dtype: float64 -> sfx_batch_cfg.high_precision: projection in fp64 in every stage.  Same objective, so the
+    same bounds against fp64 autograd of the oracle; and the loss moves by less than fp32 pixel rounding allows."""
+    cfg = H.load_cfg("fit_smplx_combined_coco25.yaml", use_hands=False, use_face=False)
+    cfg["use_camera_prior"] = False
+    cfg64 = dict(cfg, float_dtype="float64")
+    out = {}
+    for tag, c in (("f32", cfg), ("hp", cfg64)):
+        out[tag] = T.closure_probe(synth_model, c, "dense", "high-precision-" + tag)
+    for st in out["hp"]:
+        assert out["hp"][st][0] <= 2e-6 and out["hp"][st][1] <= 6e-6
+
+
+def test_standalone_loss_forward_matches_the_closure(synth_model):
+    """SMPLifyLoss.forward(body_model_output, camera=..., gt_joints=..., ...) and SMPLifyCameraInitLoss.forward, called the
+    way fitting.py:248-259 calls them, return the device objective at the parameters the ModelOutput was made from:
+    equal to the fitting closure's value bit for bit, and to the oracle within the closure bounds."""
+    import test_gpu_dropin as DI
+    from smplifyx_amd import fitting, prior
+    cfg = H.load_cfg("fit_smplx_combined_coco25.yaml", use_hands=False, use_face=False)
+    cfg["use_camera_prior"] = False
+    bm, camera = DI._setup(synth_model, cfg)
+    dev = torch.device("cuda")
+    frames = T.synth_frames(synth_model, cfg, 3)
+    i = 1
+    kd = torch.tensor(frames["keypoints"][i:i + 1], device=dev)
+    gt_joints, joints_conf = kd[:, :, :2], kd[:, :, 2].reshape(1, -1)
+    joint_weights = torch.tensor(T._jw(cfg, frames)[i:i + 1], device=dev)
+    pose_embedding = torch.tensor(frames["reg_pose"][i:i + 1] + 0.05, device=dev, requires_grad=True)
+    rng = np.random.RandomState(5)
+    bm.reset_params(global_orient=frames["reg_global"][i:i + 1], body_pose=pose_embedding.detach(),
+                    betas=0.5 * rng.normal(size=(1, 10)).astype(np.float32))
+    with torch.no_grad():
+        camera.translation[:] = torch.tensor(frames["cam_t"][i:i + 1] + 0.1, device=dev)
+        camera.center[:] = torch.tensor([frames["W"] * 0.5, frames["H"] * 0.5], device=dev)
+    mk = lambda t: prior.create_prior(prior_type=t, dtype=torch.float32)
+    loss = fitting.create_loss(loss_type="smplify", joint_weights=joint_weights, rho=cfg["rho"], use_joints_conf=True,
+                               use_face=False, use_hands=False, body_pose_prior=mk("l2"), shape_prior=mk("l2"),
+                               angle_prior=mk("angle"), interpenetration=False, dtype=torch.float32,
+                               regression_pose=torch.tensor(frames["reg_pose"][i:i + 1], device=dev), num_stages=3).to(dev)
+    w = {"data_weight": 1000.0 / frames["H"], "body_pose_weight": torch.tensor(cfg["body_pose_prior_weights"][1], device=dev),
+         "shape_weight": torch.tensor(cfg["shape_weights"][1], device=dev)}
+    w["bending_prior_weight"] = 3.17 * w["body_pose_weight"]
+    loss.reset_loss_weights(w)
+    out = bm(return_verts=True, body_pose=pose_embedding, return_full_pose=True)
+    total = loss(out, camera=camera, gt_joints=gt_joints, body_model_faces=bm.faces_tensor, joints_conf=joints_conf,
+                 joint_weights=joint_weights, pose_embedding=pose_embedding, use_vposer=False)
+    assert total.dim() == 0 and torch.isfinite(total)
+    with fitting.FittingMonitor(**cfg) as monitor:
+        closure = monitor.create_fitting_closure(None, bm, camera=camera, gt_joints=gt_joints, joints_conf=joints_conf,
+                                                 joint_weights=joint_weights, loss=loss, use_vposer=False,
+                                                 pose_embedding=pose_embedding, return_verts=True, return_full_pose=True)
+        via_closure = closure(stage=1, backward=False)
+    assert float(total) == float(via_closure)
+    P = dict(global_orient=frames["reg_global"], pose_embedding=np.tile(pose_embedding.detach().cpu().numpy(), (3, 1)),
+             betas=np.tile(bm.betas.detach().cpu().numpy(), (3, 1)), cam_translation=np.tile(camera.translation.detach().cpu().numpy(), (3, 1)),
+             est_tz=np.zeros(3, np.float32))
+    for k in ("expression", "jaw_pose", "leye_pose", "reye_pose", "left_hand_pose", "right_hand_pose"):
+        P[k] = np.tile(getattr(bm, k).detach().cpu().numpy(), (3, 1))
+    lo, _ = T._oracle_closure(synth_model, cfg, frames, i, P, 1)
+    assert abs(float(total) - lo) <= H.CLOSURE_LOSS_TOL * abs(lo), (float(total), lo)
+    # camera-initialisation loss (fitting.py:499-520)
+    init_idxs = [k for k in cfg["init_joints_idxs"] if float(gt_joints[0, k, 0]) != 0]
+    closs = fitting.create_loss("camera_init", joints_conf=joints_conf, use_conf=False, trans_estimation=camera.translation.detach().clone(),
+                                init_joints_idxs=torch.tensor(init_idxs, device=dev), depth_loss_weight=1e2, dtype=torch.float32).to(dev)
+    closs.reset_loss_weights({"data_weight": 1000.0 / frames["H"]})
+    cval = closs(out, camera=camera, gt_joints=gt_joints, body_model=bm)
+    assert cval.dim() == 0 and torch.isfinite(cval) and float(cval) >= 0
+    with pytest.raises(RuntimeError):
+        from smplifyx_amd.smplx import ModelOutput
+        loss(ModelOutput(joints=out.joints), camera=camera, gt_joints=gt_joints, joints_conf=joints_conf, joint_weights=joint_weights)
+
+
+def test_long_queue_through_a_small_column_pool(synth_model):
+    """cfg.slots with a queue 16 waves deep (B / slots = 16): the bound on the polled rounds scales with the queue, and
+    the pooled job equals the resident one frame for frame (camera stage only: cheap)."""
+    cfg = H.load_cfg("fit_smplx_combined_coco25.yaml", use_hands=False, use_face=False)
+    cfg["use_camera_prior"] = False
+    cfg["maxiters"] = 4
+    from smplifyx_amd import engine
+    dm = T._dm(synth_model, cfg)
+    B = 512
+    frames = T.synth_frames(synth_model, cfg, 3)
+    idx = [i % 3 for i in range(B)]
+    res = {}
+    for slots in (0, 32):
+        fb = H.engine_batch_from_frames(dm, cfg, frames, idx, lbs_mode="dense")
+        fb.close()
+        kp = frames["keypoints"][idx]
+        fb = engine.FrameBatch(dm, B, cfg, lbs_mode="dense", reuse_entry_eval=True, has_regression_pose=True, slots=slots)
+        K = kp.shape[1]
+        jw = np.tile(H.base_joint_weights(cfg, K), (B, 1))
+        cm = np.zeros((B, K), np.float32); cm[:, cfg["init_joints_idxs"]] = 1
+        fb.set_frames(kp, jw, cm, frames["focal"], np.tile([frames["W"] * 0.5, frames["H"] * 0.5], (B, 1)), 1000.0 / frames["H"])
+        fb.set_params(regression_pose=frames["reg_pose"][idx], global_orient=frames["reg_global"][idx],
+                      pose_embedding=frames["reg_pose"][idx], cam_translation=np.zeros((B, 3), np.float32))
+        fb.guess_init(cfg["body_tri_idxs"])
+        fb.fit(first_stage=-1, last_stage=0)
+        res[slots] = fb.stats()["stage_loss"][:, :2].copy()
+        fb.close()
+    assert np.all(np.isfinite(res[32])) and np.array_equal(res[0], res[32])

@@ -57,6 +57,21 @@ def test_product_mixture_prior_module_matches_reference(g, tmp_path, tag, dtype,
         prior.create_prior("gmm", prior_folder=str(tmp_path / "nope"), num_gaussians=8)
 
 
+@pytest.mark.parametrize("tag,dtype,tol", [("f32", torch.float32, 2e-5), ("f64", torch.float64, 1e-10)])
+def test_per_component_form_matches_reference(g, tag, dtype, tol):
+    """MaxMixturePrior(use_merged=False) (prior.py:203-231) against tests/golden/gmm_unmerged.npz: the REAL reference's
+    module on the same mixture and poses (tools/make_goldens.py gmm_unmerged), one pose at a time like the reference runs."""
+    from smplifyx_amd import prior
+    u = np.load(os.path.join(os.path.dirname(GOLD), "gmm_unmerged.npz"))
+    pr = prior.MaxMixturePrior(gmm=_mixture(g), num_gaussians=8, dtype=dtype, use_merged=False)
+    for i in range(u["poses"].shape[0]):
+        x = torch.tensor(u["poses"][i:i + 1], dtype=dtype, requires_grad=True)
+        v = pr(x, None)
+        v.sum().backward()
+        assert abs(float(v.reshape(-1)[0]) - u["val_" + tag][i]) <= tol * abs(u["val_" + tag][i])
+        assert np.linalg.norm(x.grad.numpy()[0] - u["grad_" + tag][i]) <= tol * np.linalg.norm(u["grad_" + tag][i])
+
+
 def _cfg():
     cfg = H.load_cfg("fit_smplx_combined_coco25.yaml", use_hands=False, use_face=False, use_vposer=False,
                      body_prior_type="gmm")
@@ -226,3 +241,45 @@ def test_drop_in_modules_with_mixture_prior(g, synth_model, tmp_path):
         assert l0 > pr > 0
         lf = monitor.run_fitting(body_opt, closure, final_params, bm, 0, pose_embedding=pose_embedding, use_vposer=False)
         assert lf < l0
+
+
+@pytest.mark.gpu
+def test_closure_with_per_component_mixture_prior_matches_reference_values(g, synth_model):
+    """MaxMixturePrior(use_merged=False) on the device (sfx_batch_set_gmm_form): the closure's loss and embedding gradient
+    change, relative to the merged form, by exactly what the reference's two forms differ by at the same pose
+    (tests/golden/gmm.npz / gmm_unmerged.npz: values and gradients of the REAL reference), scaled by body_pose_weight^2."""
+    import test_gpu_parity as T
+    from smplifyx_amd import engine, prior, synthetic
+    cfg = _cfg()
+    dm = T._dm(synth_model, cfg)
+    u = np.load(os.path.join(os.path.dirname(GOLD), "gmm_unmerged.npz"))
+    idx = [2, 9, 17, 21]
+    B = len(idx)
+    K = len(H.joint_map_for(cfg))
+    frames = synthetic.make_frames(B, H.oracle_joints_fn(synth_model, cfg), K, focal=5000.0)
+    P = H.random_params(np.random.RandomState(4), B, scale=0.4)
+    P["pose_embedding"] = u["poses"][idx].astype(np.float32)
+    P["cam_translation"] = frames["cam_t"].astype(np.float32)
+    est = (frames["cam_t"][:, 2] + 1.0).astype(np.float32)
+    jw = np.tile(H.base_joint_weights(cfg, K), (B, 1))
+    res = {}
+    for merged in (True, False):
+        pr = prior.MaxMixturePrior(gmm=_mixture(g), num_gaussians=8, use_merged=merged)
+        fb = engine.FrameBatch(dm, B, cfg, lbs_mode="rows", reuse_entry_eval=False, has_regression_pose=False)
+        fb.set_gmm(pr)
+        fb.set_frames(frames["keypoints"], jw, np.zeros((B, K), np.float32), frames["focal"],
+                      np.tile([frames["W"] * 0.5, frames["H"] * 0.5], (B, 1)), 1000.0 / frames["H"], est_tz=est)
+        fb.set_params(**P)
+        res[merged] = fb.closure(1)
+        fb.close()
+    bpw2 = float(cfg["body_pose_prior_weights"][1]) ** 2
+    n_emb0 = 10 + 3 + 63 + 12 + 12 + 9 + 10             # embedding = last 63 entries of the 182 variables
+    for q, i in enumerate(idx):
+        # float32 poses: compare with the reference's fp64 values at the fp64 poses to 1e-4 (the poses were rounded to fp32)
+        dv = (u["val_f64"][i] - g["val_f64"][i]) * bpw2
+        dg = (u["grad_f64"][i] - g["grad_f64"][i]) * bpw2
+        got_v = float(res[False][0][q]) - float(res[True][0][q])
+        got_g = res[False][1][q][n_emb0:] - res[True][1][q][n_emb0:]
+        scale = abs(u["val_f64"][i] * bpw2)
+        assert abs(got_v - dv) <= 2e-4 * scale, (i, got_v, dv, scale)
+        assert np.linalg.norm(got_g - dg) <= 2e-4 * np.linalg.norm(u["grad_f64"][i] * bpw2), (i,)

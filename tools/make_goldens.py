@@ -2,7 +2,7 @@
 """Generate tests/golden/*.npz by running the REAL reference (imported from
 /root/reference, this container only) on seeded inputs.  The reference Python never
 ships; only these numeric arrays do.  Re-run: `python tools/make_goldens.py [what ...]`
-with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_full_set, e2e_vposer_set, e2e_side, e2e_bench}.
+with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_full_set, e2e_vposer_set, e2e_side, e2e_bench, gmm_unmerged, e2e_bench_raw_delta}.
 
 The LBS itself has no reference implementation here (external `smplx`, absent): wherever a
 body model is needed the reference drives oracle.body_model.SMPLXRef built from
@@ -462,8 +462,9 @@ def _bench_task(task):
     cfg = H.load_cfg("fit_smplx_smplifyx.yaml", use_hands=False, use_face=False, use_vposer=False, use_cuda=False)
     cfg["use_camera_prior"] = False
     K = len(H.joint_map_for(cfg))
-    frames = synthetic.make_frames(1, H.oracle_joints_fn(model, cfg), K, start=i, focal=5000.0, min_camera_keypoints=3,
-                                   camera_keypoints=cfg.get("init_joints_idxs", (9, 12, 2, 5)))      # (= bench.MIN_CAMERA_KEYPOINTS)
+    frames = synthetic.make_frames(1, H.oracle_joints_fn(model, cfg), K, start=i, focal=5000.0,
+                                   min_camera_keypoints=None if _BENCH_RAW else 3,      # (3 = bench.MIN_CAMERA_KEYPOINTS)
+                                   camera_keypoints=cfg.get("init_joints_idxs", (9, 12, 2, 5)))
     c = dict(cfg); c["regression_prior"] = "ExPose"
     bp = Rot.from_euler("XYZ", frames["reg_pose"][0].reshape(21, 3).astype(np.float64)).as_matrix().astype(np.float32)
     go = Rot.from_euler("XYZ", frames["reg_global"][0].astype(np.float64)[None]).as_matrix().astype(np.float32)
@@ -619,6 +620,64 @@ def gen_gmm():
     _save("gmm", **out)
 
 
+def gen_gmm_unmerged():
+    """MaxMixturePrior(use_merged=False) (prior.py:203-231: the per-component form) of the reference on the same
+    synthetic mixture and poses as gen_gmm: values and autograd gradients, one pose at a time (the reference's indexing
+    `nll_weights[:, min_idx]` is only meaningful for batch size 1, the size the reference runs at), fp32 / fp64."""
+    from smplifyx_amd import synthetic
+    gmm = synthetic.make_synthetic_gmm(0)
+    g = np.load(os.path.join(GOLD, "gmm.npz"))
+    poses = g["poses"]
+    out = dict(poses=poses)
+    for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        d = tempfile.mkdtemp()
+        with open(os.path.join(d, "gmm_08.pkl"), "wb") as fh:
+            pickle.dump(gmm, fh)
+        with contextlib.redirect_stdout(io.StringIO()):
+            pr = ref.prior.MaxMixturePrior(prior_folder=d, num_gaussians=8, dtype=dtype, use_merged=False)
+        vals, grads = [], []
+        for i in range(poses.shape[0]):
+            x = torch.tensor(poses[i:i + 1], dtype=dtype, requires_grad=True)
+            v = pr(x, None)
+            v.sum().backward()
+            vals.append(float(v.reshape(-1)[0])); grads.append(x.grad.numpy()[0].astype(np.float64))
+        out["val_" + tag] = np.array(vals, np.float64)
+        out["grad_" + tag] = np.stack(grads)
+    _save("gmm_unmerged", **out)
+
+
+def gen_e2e_bench_raw_delta():
+    """The benchmark's RAW SURVEY 8(d) sequence (no minimum of camera-initialisation keypoints) differs from the sequence
+    e2e_bench.npz holds in the frames that lose two of those keypoints (23 and 51 of the first 64): their raw keypoints
+    and reference fits (fp32 / fp64), so that bench.py can score its raw headline against the reference as well."""
+    import helpers as H
+    from smplifyx_amd import synthetic
+    g = np.load(os.path.join(GOLD, "e2e_bench.npz"))
+    n = g["keypoints"].shape[0]
+    model = synthetic.make_synthetic_model(0)
+    cfg = H.load_cfg("fit_smplx_smplifyx.yaml", use_hands=False, use_face=False, use_vposer=False, use_cuda=False)
+    K = len(H.joint_map_for(cfg))
+    raw = synthetic.make_frames(n, H.oracle_joints_fn(model, cfg), K, focal=5000.0)
+    differ = [i for i in range(n) if np.abs(raw["keypoints"][i] - g["keypoints"][i]).max() > 0]
+    out = {"frames": np.array(differ)}
+    import multiprocessing as mp
+    global _BENCH_RAW
+    _BENCH_RAW = True
+    with mp.get_context("fork").Pool(4) as pool:
+        results = pool.map(_bench_task, [(i, tag) for i in differ for tag in ("f32", "f64")], chunksize=1)
+    kp = {}; rp = {}; rg = {}
+    for i, tag, k_, p_, g_, o in results:
+        kp[i], rp[i], rg[i] = k_, p_, g_
+        for key, v in o.items():
+            out["f%d_%s_%s" % (i, tag, key)] = v
+    out.update(keypoints=np.stack([kp[i] for i in differ]), reg_pose=np.stack([rp[i] for i in differ]),
+               reg_global=np.stack([rg[i] for i in differ]))
+    _save("e2e_bench_raw_delta", **out)
+
+
+_BENCH_RAW = False
+
+
 def gen_eval():
     """utils.ProcrustesAlignment / ScaleAlignment / PelvisAlignment(+MPJPE) / mpjpe / v2v of the
     reference on seeded point sets (fscore thresholds None: open3d is absent)."""
@@ -681,4 +740,5 @@ if __name__ == "__main__":
     for w in todo:
         {"objective": gen_objective, "lbfgs": gen_lbfgs, "euler": gen_euler, "tables": gen_tables,
          "e2e": gen_e2e, "demo": gen_demo, "e2e_vposer": gen_e2e_vposer, "parser": gen_parser, "eval": gen_eval,
-         "gmm": gen_gmm, "e2e_full": gen_e2e_full, "e2e_full_set": gen_e2e_full_set, "e2e_vposer_set": gen_e2e_vposer_set, "e2e_side": gen_e2e_side, "e2e_bench": gen_e2e_bench}[w]()
+         "gmm": gen_gmm, "e2e_full": gen_e2e_full, "e2e_full_set": gen_e2e_full_set, "e2e_vposer_set": gen_e2e_vposer_set, "e2e_side": gen_e2e_side, "e2e_bench": gen_e2e_bench,
+         "gmm_unmerged": gen_gmm_unmerged, "e2e_bench_raw_delta": gen_e2e_bench_raw_delta}[w]()
