@@ -132,6 +132,11 @@ typedef struct sfx_batch_cfg {
                                        that finish (continuous batching): the reference's loop over frames
                                        (main.py:207) for jobs larger than one GEMM batch.  A frame's result does
                                        not depend on when it is admitted or which column it gets              */
+    /* hyper-parameters of optimizers/lbfgs_ls.py's LBFGS that optim_factory.py:27-65 leaves at their defaults; 0 = default */
+    double  lbfgs_tolerance_grad;   /* 1e-5                                                          */
+    double  lbfgs_tolerance_change; /* 1e-9                                                          */
+    int32_t lbfgs_max_eval;         /* maxiters * 5 / 4                                              */
+    int32_t lbfgs_history_size;     /* 100 (larger values are refused: the ring holds 100 pairs)     */
     int32_t high_precision;         /* cfg float_dtype: float64 (main.py:99-105): besides the keypoint forward (always fp64) the
                                        projection up to the pixel residual is carried in fp64 in every stage -- gradient noise
                                        0.13 x torch fp32's, the fits behave like the reference's float64 run;

@@ -103,7 +103,7 @@ class StageMachine(object):
     """run_fitting + LBFGS('lbfgsls') for one frame and one stage on a flat vector."""
 
     def __init__(self, x0, groups=None, maxiters=30, ftol=1e-9, gtol=1e-9, lr=1.0,
-                 max_iter=None, history=100, tol_grad=1e-5, tol_change=1e-9,
+                 max_iter=None, max_eval=None, history=100, tol_grad=1e-5, tol_change=1e-9,
                  c1=1e-4, c2=0.9, max_ls=25, dtype=np.float32, reuse_entry_eval=False,
                  fma=True):
         self.dt = dtype
@@ -115,7 +115,7 @@ class StageMachine(object):
         self.maxiters = maxiters
         self.ftol, self.gtol, self.lr = ftol, gtol, lr
         self.max_iter = maxiters if max_iter is None else max_iter
-        self.max_eval = self.max_iter * 5 // 4
+        self.max_eval = self.max_iter * 5 // 4 if max_eval is None else max_eval      # lbfgs_ls.py:262
         self.history = history
         self.tol_grad, self.tol_change = tol_grad, tol_change
         self.c1, self.c2, self.max_ls = c1, c2, max_ls

@@ -52,7 +52,9 @@ class BatchCfg(C.Structure):
         ("lbs_mode", C.c_int32), ("reuse_entry_eval", C.c_int32),
         ("side_view_thsh", C.c_float), ("left_shoulder_idx", C.c_int32), ("right_shoulder_idx", C.c_int32),
         ("interpenetration", C.c_int32), ("max_collisions", C.c_int32), ("df_cone_height", C.c_float),
-        ("penalize_outside", C.c_int32), ("slots", C.c_int32), ("high_precision", C.c_int32),
+        ("penalize_outside", C.c_int32), ("slots", C.c_int32),
+        ("lbfgs_tolerance_grad", C.c_double), ("lbfgs_tolerance_change", C.c_double),
+        ("lbfgs_max_eval", C.c_int32), ("lbfgs_history_size", C.c_int32), ("high_precision", C.c_int32),
     ]
 
 

@@ -546,6 +546,11 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.cfg.side_thsh = c->side_view_thsh; D.cfg.lsh = c->left_shoulder_idx; D.cfg.rsh = c->right_shoulder_idx;
     D.cfg.pen = c->interpenetration ? 1 : 0;
     D.cfg.proj64 = c->high_precision ? 1 : 0;
+    D.cfg.tol_grad = c->lbfgs_tolerance_grad > 0 ? c->lbfgs_tolerance_grad : 1e-5;
+    D.cfg.tol_change = c->lbfgs_tolerance_change > 0 ? c->lbfgs_tolerance_change : 1e-9;
+    if (c->lbfgs_max_eval > 0) D.cfg.max_eval = c->lbfgs_max_eval;
+    if (c->lbfgs_history_size > SFX_HIST) { sfx_set_error("history_size %d > %d", c->lbfgs_history_size, SFX_HIST); delete b; return -1; }
+    D.cfg.hist_cap = c->lbfgs_history_size > 0 ? c->lbfgs_history_size : SFX_HIST;
     if (D.cfg.pen && c->lbs_mode != 1) {
         sfx_set_error("interpenetration needs lbs_mode = 1 (the term reads every vertex)"); delete b; return -1; }
     if (D.cfg.pen && !(c->df_cone_height > 0.f)) { sfx_set_error("df_cone_height must be positive"); delete b; return -1; }

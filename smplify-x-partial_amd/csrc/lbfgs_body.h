@@ -290,8 +290,8 @@ __device__ __forceinline__ void lb_load(LbSet& X, const int base, const int n, c
 // recursion keeps per pair: ro, the band entries s_(k-th predecessor) . y_new -- the syt row of the new pair and entry k
 // of the k-th predecessor's syb row -- and the mirror of slots 0..7 behind the ring.
 __device__ __forceinline__ void lb_push_pair(float* hY, float* hS, OptState* gst, int& hist_n, int& hist_head, const Lane3& y,
-                                             const Lane3& sv, const float ys, const int lane) {
-    if (hist_n == SFX_HIST) { hist_head = (hist_head + 1) % SFX_HIST; hist_n -= 1; }
+                                             const Lane3& sv, const float ys, const int lane, const int hist_cap = SFX_HIST) {
+    if (hist_n >= hist_cap) { hist_head = (hist_head + 1) % SFX_HIST; hist_n -= 1; }      // (history_size <= SFX_HIST: the ring keeps its 100 slots)
     const int ph = (hist_head + hist_n) % SFX_HIST;
     st3_full(hY + (size_t)ph * SFX_NVAR_MAX, y, lane);
     st3_full(hS + (size_t)ph * SFX_NVAR_MAX, sv, lane);
@@ -501,7 +501,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
     }
     LB_SYNC();
     OptScal& s = s_state;
-    const double tol_change = 1e-9;
+    const double tol_change = C.tol_change, tol_grad = C.tol_grad;      // (LBFGS defaults 1e-9 / 1e-5: optim_factory.py:27-65 never changes them)
     const int max_iter = C.maxiters, max_eval = C.max_eval, max_ls = 25;
 
     // incoming evaluation
@@ -608,7 +608,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
             s.orig_loss = s.loss;
             s.cur_evals = 1; s.n_iter = 0;
             const Lane3 g = ld3(VEC(VEC_G), lane, N);
-            if (sc_le(T(absmax3(g, lane, N)), P((double)1e-5))) act = A_END_STEP;
+            if (sc_le(T(absmax3(g, lane, N)), P(tol_grad))) act = A_END_STEP;
             else act = A_ITER_HEAD;
             break;
         }
@@ -628,7 +628,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
                 const float ys = dot3(y, sv);
                 if (ys > 1e-10f) {
                     int hn = s.hist_n, hh = s.hist_head;
-                    lb_push_pair(hY, hS, gst, hn, hh, y, sv, ys, lane);
+                    lb_push_pair(hY, hS, gst, hn, hh, y, sv, ys, lane, C.hist_cap);
                     s.hist_n = hn; s.hist_head = hh;
                     s.H_diag = T(ys / dot3(y, y));
                 }
@@ -706,7 +706,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
             const Lane3 xn = axpy3(xi, (float)t.v, d);
             for (int e = 0; e < NE3; ++e) { const int i = 3 * lane + e; if (i < N) X[idx3[e]] = xn.v[e]; }
             s.cache_valid = 1;
-            const bool opt_cond = sc_le(T(absmax3(g, lane, N)), P((double)1e-5));
+            const bool opt_cond = sc_le(T(absmax3(g, lane, N)), P(tol_grad));
             s.cur_evals += s.ls_evals; s.func_evals += s.ls_evals;
             TRACE(0, t.v, s.loss.v, s.ls_evals);
             if (s.n_iter == max_iter) { act = A_END_STEP; break; }

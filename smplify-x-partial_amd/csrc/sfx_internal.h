@@ -163,6 +163,8 @@ struct BatchCfgDev {
     float side_thsh; int lsh, rsh;     // side-view test: 2-D shoulder distance threshold, indices
     int pen;                           // interpenetration term enabled (dense mode)
     int kl[3], nil[3];                 // live keypoints / vertex items by stage class: body only, + hands, all (closure_body)
+    double tol_grad, tol_change;       // LBFGS tolerance_grad / tolerance_change (lbfgs_ls.py defaults 1e-5 / 1e-9)
+    int hist_cap;                      // LBFGS history_size (<= SFX_HIST)
     int proj64;                        // projection in fp64 in every stage (cfg float_dtype float64; the camera stage always is)
 };
 

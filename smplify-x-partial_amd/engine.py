@@ -226,6 +226,11 @@ class FrameBatch(object):
         c.df_cone_height = float(cfg.get("df_cone_height", 0.5))
         c.penalize_outside = int(bool(cfg.get("penalize_outside", True)))
         c.slots = int(slots or 0)
+        # LBFGS hyper-parameters (optimizers/lbfgs_ls.py); the cfg files never set them: 0 = the reference's defaults
+        c.lbfgs_tolerance_grad = float(cfg.get("lbfgs_tolerance_grad", 0.0) or 0.0)
+        c.lbfgs_tolerance_change = float(cfg.get("lbfgs_tolerance_change", 0.0) or 0.0)
+        c.lbfgs_max_eval = int(cfg.get("lbfgs_max_eval", 0) or 0)
+        c.lbfgs_history_size = int(cfg.get("lbfgs_history_size", 0) or 0)
         # cfg float_dtype: float64 (main.py:99-105) -> the engine's high-precision mode (include/sfx.h sfx_batch_cfg.high_precision)
         c.high_precision = int(str(cfg.get("float_dtype", "float32")) == "float64" or bool(cfg.get("high_precision", False)))
         if c.interpenetration and lbs_mode != "dense":

@@ -59,6 +59,8 @@ class SMPLifyLoss(nn.Module):
         self.use_joints_conf, self.rho = use_joints_conf, rho
         self.angle_prior, self.body_pose_prior, self.shape_prior = angle_prior, body_pose_prior, shape_prior
         self.interpenetration = interpenetration
+        # fit_single_frame.py:300-328: BVH / DistanceFieldPenetrationLoss / FilterFaces (smplifyx_amd.mesh_intersection holders)
+        self.search_tree, self.pen_distance, self.tri_filtering_module = search_tree, pen_distance, tri_filtering_module
         self.use_hands = use_hands
         if use_hands:
             self.left_hand_prior, self.right_hand_prior = left_hand_prior, right_hand_prior
@@ -182,6 +184,7 @@ class EngineClosure(object):
         if maxiters != self.monitor.maxiters:
             raise NotImplementedError("LBFGS max_iter != FittingMonitor maxiters (the reference passes one value to both)")
         w = capi.StageWeights()
+        pen_cfg = {}
         has_reg = False
         use_hands = use_face = False
         if not self.is_camera:
@@ -197,19 +200,32 @@ class EngineClosure(object):
             for q in range(3):
                 w.jaw_prior_weight[q] = float(jw[q])
             if getattr(loss, "interpenetration", False) and float(getattr(loss, "coll_loss_weight", 0.0)) > 0:
-                raise NotImplementedError("interpenetration through create_loss(search_tree=..., pen_distance=...) needs the "
-                                          "external mesh_intersection objects; use fit_single_frame / main / "
-                                          "driver.fit_frames with interpenetration=True (csrc/collide.hip)")
+                # fitting.py:437-455 with the objects of fit_single_frame.py:300-328 (smplifyx_amd.mesh_intersection)
+                st, pd, tf = loss.search_tree, loss.pen_distance, loss.tri_filtering_module
+                if not (hasattr(st, "max_collisions") and hasattr(pd, "sigma")):
+                    raise TypeError("create_loss(search_tree=, pen_distance=): pass smplifyx_amd.mesh_intersection's BVH and "
+                                    "DistanceFieldPenetrationLoss (the external CUDA package's objects cannot run here)")
+                if not self.return_verts:
+                    raise ValueError("the interpenetration term reads every vertex: create_fitting_closure(return_verts=True)")
+                pen_cfg = dict(interpenetration=True, max_collisions=st.max_collisions, df_cone_height=pd.sigma,
+                               penalize_outside=pd.penalize_outside)
+                w.coll_loss_weight = float(loss.coll_loss_weight)
+                if tf is not None and getattr(dm, "_parts_from", None) is not tf:
+                    dm.set_parts(tf.faces_segm, tf.faces_parents, tf.ign_part_pairs)
+                    dm._parts_from = tf
             reg = loss.regression_pose
             has_reg = reg is not None and (not self.use_vposer or stage + 1 == loss.num_stages)
         cfg = dict(use_vposer=self.use_vposer, use_hands=use_hands, use_face=use_face,
                    use_joints_conf=bool(getattr(loss, "use_joints_conf", False)),
                    use_conf_for_camera_init=bool(getattr(loss, "use_conf", False)),
                    high_precision=getattr(bm, "dtype", torch.float32) == torch.float64,
+                   lbfgs_tolerance_grad=getattr(opt, "tolerance_grad", 0.0), lbfgs_tolerance_change=getattr(opt, "tolerance_change", 0.0),
+                   lbfgs_max_eval=getattr(opt, "max_eval", 0), lbfgs_history_size=getattr(opt, "history_size", 0),
                    maxiters=self.monitor.maxiters, ftol=self.monitor.ftol, gtol=self.monitor.gtol,
                    lr=getattr(opt, "lr", 1.0), rho=getattr(loss, "rho", 100),
                    depth_loss_weight=(float(getattr(loss, "depth_loss_weight", 0.0))
                                       if getattr(loss, "trans_estimation", None) is not None else 0.0))
+        cfg.update(pen_cfg)
         fb = engine.FrameBatch(dm, 1, cfg, lbs_mode="dense" if self.return_verts else "rows",
                                reuse_entry_eval=False, has_regression_pose=has_reg, stages=[w], num_body_joints=K)
         if (not self.is_camera and not self.use_vposer and not has_reg

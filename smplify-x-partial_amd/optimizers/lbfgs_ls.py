@@ -10,14 +10,12 @@ class LBFGS(object):
                  history_size=100, line_search_fn=None):
         if line_search_fn != "strong_Wolfe":
             raise RuntimeError("only 'strong_Wolfe' is supported")
-        if (tolerance_grad, tolerance_change, history_size) != (1e-5, 1e-9, 100):
-            raise NotImplementedError("the device optimiser is built for the defaults the reference uses "
-                                      "(tolerance_grad 1e-5, tolerance_change 1e-9, history 100)")
+        if history_size > 100 or history_size < 1:
+            raise NotImplementedError("history_size must be 1..100 (the device keeps a ring of 100 curvature pairs)")
         self._params = list(params)
         self.lr, self.max_iter = lr, max_iter
         self.max_eval = max_iter * 5 // 4 if max_eval is None else max_eval
-        if self.max_eval != max_iter * 5 // 4:
-            raise NotImplementedError("max_eval other than max_iter * 5 // 4")
+        self.tolerance_grad, self.tolerance_change, self.history_size = tolerance_grad, tolerance_change, history_size
         self.param_groups = [dict(params=self._params, lr=lr, max_iter=max_iter, max_eval=self.max_eval,
                                   tolerance_grad=tolerance_grad, tolerance_change=tolerance_change,
                                   history_size=history_size, line_search_fn=line_search_fn)]

@@ -403,3 +403,70 @@ def test_main_runs_every_shipped_cfg_unmodified(tmp_path, yaml_):
         assert res["left_hand_pose"].shape == (1, 12) and res["expression"].shape == (1, 10) and res["body_pose"].shape == (1, 63)
         assert all(np.all(np.isfinite(np.asarray(v, np.float64))) for v in res.values())
         assert os.path.getsize(out / "results" / nme / "vertices.ply") > 10475 * 12
+
+
+def test_create_loss_with_interpenetration_objects(synth_model):
+    """fit_single_frame.py:300-328 + fitting.py:437-455: create_loss(search_tree=BVH(...), pen_distance=
+    DistanceFieldPenetrationLoss(...), tri_filtering_module=FilterFaces(...), interpenetration=True) through the fitting
+    closure: the value and gradients equal those of the engine batch built from the cfg keys (the route fit_single_frame /
+    main take), and the term is really in (coll_loss_weight 0 gives a smaller loss)."""
+    from smplifyx_amd import fitting, prior, synthetic, engine
+    from smplifyx_amd.mesh_intersection.bvh_search_tree import BVH
+    import smplifyx_amd.mesh_intersection.loss as collisions_loss
+    from smplifyx_amd.mesh_intersection.filter_faces import FilterFaces
+    import test_gpu_parity as T
+    cfg = H.load_cfg("fit_smplx_combined_halpe.yaml", use_hands=False, use_face=False, interpenetration=True)
+    cfg["use_camera_prior"] = False
+    cfg["df_cone_height"] = 1e-2
+    model = synthetic.make_synthetic_model(0, surface=True)
+    parts = synthetic.make_synthetic_parts(model)
+    bm, camera = _setup(model, cfg)
+    dev = torch.device("cuda")
+    K = len(H.joint_map_for(cfg))
+    frames = synthetic.make_frames(1, H.oracle_joints_fn(model, cfg), K, focal=5000.0)
+    kd = torch.tensor(frames["keypoints"][:1], device=dev)
+    gt_joints, joints_conf = kd[:, :, :2], kd[:, :, 2].reshape(1, -1)
+    joint_weights = torch.tensor(H.base_joint_weights(cfg, K), device=dev).unsqueeze(0)
+    rng = np.random.RandomState(3)
+    pose = (frames["reg_pose"][:1] + 0.3 * rng.normal(size=(1, 63))).astype(np.float32)      # bent enough to collide
+    pose_embedding = torch.tensor(pose, device=dev, requires_grad=True)
+    bm.reset_params(global_orient=frames["reg_global"][:1], body_pose=pose_embedding.detach())
+    with torch.no_grad():
+        camera.translation[:] = torch.tensor(frames["cam_t"][:1], device=dev)
+        camera.center[:] = torch.tensor([frames["W"] * 0.5, frames["H"] * 0.5], device=dev)
+    search_tree = BVH(max_collisions=cfg["max_collisions"])
+    pen_distance = collisions_loss.DistanceFieldPenetrationLoss(sigma=cfg["df_cone_height"], point2plane=False, vectorized=True,
+                                                                penalize_outside=cfg["penalize_outside"])
+    filter_faces = FilterFaces(faces_segm=parts["segm"], faces_parents=parts["parents"], ign_part_pairs=cfg["ign_part_pairs"]).to(dev)
+    with pytest.raises(NotImplementedError):
+        collisions_loss.DistanceFieldPenetrationLoss(sigma=0.5, point2plane=True)
+    mk = lambda t: prior.create_prior(prior_type=t, dtype=torch.float32)
+    vals = {}
+    for cw in (1.0, 0.0):
+        loss = fitting.create_loss(loss_type="smplify", joint_weights=joint_weights, rho=cfg["rho"], use_joints_conf=True,
+                                   use_face=False, use_hands=False, body_pose_prior=mk("l2"), shape_prior=mk("l2"),
+                                   angle_prior=mk("angle"), interpenetration=True, search_tree=search_tree,
+                                   pen_distance=pen_distance, tri_filtering_module=filter_faces, dtype=torch.float32,
+                                   regression_pose=torch.tensor(frames["reg_pose"][:1], device=dev), num_stages=3).to(dev)
+        w = {"data_weight": 1000.0 / frames["H"], "body_pose_weight": torch.tensor(cfg["body_pose_prior_weights"][2], device=dev),
+             "shape_weight": torch.tensor(cfg["shape_weights"][2], device=dev), "coll_loss_weight": torch.tensor(cw, device=dev)}
+        w["bending_prior_weight"] = 3.17 * w["body_pose_weight"]
+        loss.reset_loss_weights(w)
+        with fitting.FittingMonitor(**cfg) as monitor:
+            closure = monitor.create_fitting_closure(None, bm, camera=camera, gt_joints=gt_joints, joints_conf=joints_conf,
+                                                     joint_weights=joint_weights, loss=loss, use_vposer=False,
+                                                     pose_embedding=pose_embedding, return_verts=True, return_full_pose=True)
+            vals[cw] = (float(closure(stage=2)), pose_embedding.grad.detach().cpu().numpy().copy())
+            if closure._fb is not None:
+                closure._fb.close()
+    assert vals[1.0][0] > vals[0.0][0] * (1 + 1e-6), vals         # the term is in
+    # the same through the engine batch of the cfg route
+    dm = bm.device_model
+    fb = H.engine_batch_from_frames(dm, cfg, frames, [0], lbs_mode="dense")
+    fb.set_frames(frames["keypoints"][:1], joint_weights.cpu().numpy(), np.zeros((1, K), np.float32), frames["focal"],
+                  np.array([[frames["W"] * 0.5, frames["H"] * 0.5]]), 1000.0 / frames["H"])
+    fb.set_params(regression_pose=frames["reg_pose"][:1], global_orient=frames["reg_global"][:1], pose_embedding=pose,
+                  cam_translation=frames["cam_t"][:1].astype(np.float32))
+    l2, g2 = fb.closure(2)
+    assert float(l2[0]) == vals[1.0][0]
+    assert np.array_equal(g2[0][-63:], vals[1.0][1].reshape(-1))
