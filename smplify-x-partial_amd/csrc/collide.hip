@@ -9,7 +9,7 @@
 // (the package's source is absent: parity unpinned).
 //
 // MI355X design (not the package's LBVH; DESIGN.md 4.6 has the table):
-//   k_pen_grid    (1 x 1024 lanes per frame) triangle AABBs -> bounding box per body part: a triangle
+//   k_pen_g1..g5  (8 x 1024 lanes per frame, five launches) triangle AABBs -> bounding box per body part: a triangle
 //                 whose box meets the box of no part it may collide with is dropped -> the rest enters a
 //                 uniform grid (cell = twice the mean triangle extent, every cell the AABB touches)
 //                 hashed into 16384 LDS buckets by a counting sort.
@@ -66,12 +66,16 @@ struct PenDev {
     float* aabb;               // [B][F][6]
     int* entries;              // [B][ent_cap] triangle | part << 24, sorted by bucket
     int* ent_cell;             // [B][ent_cap] packed cell coordinates the entry was made for
-    int2* tcell;               // [B][F] per triangle: packed cell range + part + alive bit (k_pen_grid's passes)
+    int2* tcell;               // [B][F] per triangle: packed cell range + part + alive bit (k_pen_g2 -> g3 / g5)
+    int* pbox;                 // [B][64][6] bounding box of every part, order-preserving ints (k_pen_g1; reset per evaluation)
+    float* gpart;              // [B][PEN_GW][8] per workgroup of k_pen_g1: frame box lo / hi, extent sum
     int ent_cap;
     int* partners;             // [B][F][pcap]
     int* pavail;               // [B][F] partners held: min(found, pcap)
     int* pcount;               // [B][F]
     int* poff;                 // [B][F] start of the triangle's partner range in the frame's pair list
+    unsigned* hasp;            // [B][hasp_words] bit f: triangle f has pairs in the list (k_pen_list -> k_pen_gather)
+    int hasp_words;            // (F + 31) / 32
     int* pown;                 // [B][pair_cap] pair list: receiving triangle (ascending) ...
     int* plist;                // [B][pair_cap] ... and its partner (ascending within the triangle)
     int pair_cap;
@@ -185,63 +189,63 @@ __device__ __forceinline__ int block_excl_scan(const int v, int* wsum /* [PEN_T 
     return base + inc - v;
 }
 
-// Triangles per lane whose loads are issued together in the passes of k_pen_grid: every pass walks the lane's 21
-// triangles (f = t, t + 1024, ...); one triangle at a time each pass was a chain of 21 x 2 dependent global round trips
-// (face -> vertex ids -> coordinates; AABB re-read from global) -- 100 + 65 + 67 + 75 us of a 350-us kernel.
-#define PEN_U 4
+// ---------------------------------------------------------------------------------------------
+// The uniform grid of a frame in three launches (one 1024-lane workgroup per frame walked its 21 triangles per lane through
+// four dependent passes: 230-290 us on ONE compute unit per frame; its first pass alone -- 188 k scattered 4-byte vertex
+// gathers through one compute unit's address unit -- took 100 us):
+//   k_pen_g1  (PEN_GW workgroups per frame) triangle boxes, per-workgroup partial frame box / extent sum, part boxes (LDS
+//             atomics per workgroup, merged with a few hundred global atomicMin / Max)
+//   k_pen_g2  (PEN_GW workgroups per frame) frame box + cell size from the partials (every workgroup, same fixed order),
+//             part culling, packed cell range of every surviving triangle
+//   k_pen_g3  (one workgroup per frame) bucket part masks, histogram, scan, scatter on LDS atomics
+// Cross-workgroup results are order-independent (min / max) or combined in index order (extent sum).
+#define PEN_GW 8                // workgroups per frame in k_pen_g1 / g2
+#define PEN_GU 3                // triangles per lane of those kernels: ceil(F / (PEN_GW * PEN_T)) for F <= 24576; more loop
+__device__ __forceinline__ int pen_ford(float x) { int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); }      // order-preserving
+__device__ __forceinline__ int pen_bucket(int x, int y, int z) {
+    return (int)(((unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u) & (PEN_CELLS - 1)); }
+
+__global__ __launch_bounds__(256)
+void k_pen_reset(PenDev P, const int* __restrict__ want) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (want && !want[b]) return;
+    if (i < 64 * 6) P.pbox[(size_t)b * 64 * 6 + i] = (i % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+}
+
 __global__ __launch_bounds__(PEN_T)
-void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __restrict__ want) {
-    extern __shared__ int cell_cnt[];           // [ncell + 1]: histogram, then start offsets, then cursors
+void k_pen_g1(PenDev P, const float* __restrict__ verts, const int* __restrict__ want) {
     __shared__ float red[PEN_T / 64];
-    __shared__ int s_total;
-    __shared__ int slice[PEN_T];
-    const int b = blockIdx.x, t = threadIdx.x;
-    int* st = P.stats + b * PEN_STATS;
-    if (want && !want[b]) {                     // the frame's stage carries no collision weight: nothing to do
-        if (t == 0) { P.ptotal[b] = 0; P.cells[(size_t)b * (PEN_CELLS + 1) + PEN_CELLS] = 0; st[0] = st[1] = st[2] = st[3] = 0; st[15] = 0; }
-        return;
-    }
-    const long long clk0 = wall_clock64();
-#define PEN_CLK(i) if (t == 0) st[4 + (i)] = (int)(wall_clock64() - clk0)
+    __shared__ int pbox[64 * 6];               // this workgroup's part boxes (LDS atomics), merged into the frame's afterwards: atomics
+                                               // straight to the frame's 12 cache lines serialise in L2 (measured: 0.4-1.5 ms)
+    const int b = blockIdx.y, t = threadIdx.x, w = blockIdx.x;
+    if (want && !want[b]) return;
     const float* vb = verts + (size_t)b * P.V * 3;
     float* aabb = P.aabb + (size_t)b * P.F * 6;
-    int2* tcell = P.tcell + (size_t)b * P.F;
     const int F = P.F;
-
-    // per-part masks of the parts a triangle never collides with (parts < 64)
-    __shared__ unsigned long long s_mask[64];
-    __shared__ int s_pbox[64][6];
-    auto ford = [](float x) { int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); };      // order-preserving
-    if (t < 64) {
-        unsigned long long m = 0;
-        if (t < P.n_parts) for (int q = 0; q < P.n_parts; ++q) m |= (unsigned long long)(P.skip[(size_t)t * P.n_parts + q] != 0) << q;
-        s_mask[t] = m;
-        for (int e = 0; e < 3; ++e) { s_pbox[t][e] = 0x7fffffff; s_pbox[t][3 + e] = (int)0x80000000; }
-    }
-    for (int f = t; f < P.F; f += PEN_T) P.pcount[(size_t)b * P.F + f] = 0;
+    if (t < 64 * 6) pbox[t] = (t % 6) < 3 ? 0x7fffffff : (int)0x80000000;
     __syncthreads();
-    // ---- pass 1: AABBs, frame bounding box, mean triangle extent, bounding box of every part
     float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f}, ext_sum = 0.f;
-    for (int f0 = t; f0 < F; f0 += PEN_T * PEN_U) {
-        int vid[PEN_U][3], seg[PEN_U];
+    for (int f0 = w * PEN_T + t; f0 < F; f0 += PEN_GW * PEN_T * PEN_GU) {
+        int vid[PEN_GU][3], seg[PEN_GU];
 #pragma unroll
-        for (int u = 0; u < PEN_U; ++u) {
-            const int f = f0 + u * PEN_T, ff = f < F ? f : 0;
+        for (int u = 0; u < PEN_GU; ++u) {
+            const int f = f0 + u * PEN_GW * PEN_T, ff = f < F ? f : 0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) vid[u][k] = P.faces[ff * 3 + k];
             seg[u] = P.segm[ff];
+            if (f < F) P.pcount[(size_t)b * F + f] = 0;
         }
-        float px[PEN_U][9];
+        float px[PEN_GU][9];
 #pragma unroll
-        for (int u = 0; u < PEN_U; ++u)
+        for (int u = 0; u < PEN_GU; ++u)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float* p = vb + (size_t)vid[u][k] * 3;
                 px[u][k * 3] = p[0]; px[u][k * 3 + 1] = p[1]; px[u][k * 3 + 2] = p[2];
             }
 #pragma unroll
-        for (int u = 0; u < PEN_U; ++u) {
-            const int f = f0 + u * PEN_T;
+        for (int u = 0; u < PEN_GU; ++u) {
+            const int f = f0 + u * PEN_GW * PEN_T;
             if (f >= F) continue;
             float a[3], c[3];
 #pragma unroll
@@ -251,34 +255,69 @@ void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __r
                 lo[e] = fminf(lo[e], a[e]); hi[e] = fmaxf(hi[e], c[e]);
             }
             ext_sum += fmaxf(fmaxf(c[0] - a[0], c[1] - a[1]), c[2] - a[2]);
-            // part boxes.  Consecutive triangles mostly belong to one part: when the whole wavefront does (and is complete),
-            // its 64 boxes are reduced on DPP and ONE lane updates the part's box -- 125 k same-address LDS atomics per frame
-            // were 50 us of this kernel.  (min / max: the result does not depend on the order.)
+            // part boxes: consecutive triangles mostly belong to one part -- a complete wavefront of one part reduces its 64
+            // boxes on DPP and one lane updates the part's box
             const int s0 = __builtin_amdgcn_readfirstlane(seg[u]);
             if (__ballot(seg[u] == s0) == ~0ull) {
 #pragma unroll
                 for (int e = 0; e < 3; ++e) {
                     const float wl = -wave_max_dpp(-a[e]), wh = wave_max_dpp(c[e]);
-                    if ((t & 63) == 0) { atomicMin(&s_pbox[s0][e], ford(wl)); atomicMax(&s_pbox[s0][3 + e], ford(wh)); }
+                    if ((t & 63) == 0) { atomicMin(&pbox[s0 * 6 + e], pen_ford(wl)); atomicMax(&pbox[s0 * 6 + 3 + e], pen_ford(wh)); }
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 3; ++e) { atomicMin(&s_pbox[seg[u]][e], ford(a[e])); atomicMax(&s_pbox[seg[u]][3 + e], ford(c[e])); }
+                for (int e = 0; e < 3; ++e) { atomicMin(&pbox[seg[u] * 6 + e], pen_ford(a[e])); atomicMax(&pbox[seg[u] * 6 + 3 + e], pen_ford(c[e])); }
             }
         }
     }
-    PEN_CLK(0);
-    float glo[3], ghi[3];
-    for (int e = 0; e < 3; ++e) { glo[e] = block_min(lo[e], red); ghi[e] = block_max(hi[e], red); }
-    PEN_CLK(1);
-    // ---- part-level broad phase: a triangle whose box meets the box of no part it may collide with cannot
-    // have a partner and never enters the grid (at rest and in most poses that is nearly every triangle: the
-    // grid only sees the regions where unrelated parts meet)
     __syncthreads();
-    PEN_CLK(2);
-    // parts whose boxes meet and that may collide, as one 64-bit word per part
-    __shared__ unsigned long long s_near[64];
+    if (t < 64 * 6) {
+        const int v = pbox[t];
+        int* g = P.pbox + (size_t)b * 64 * 6 + t;
+        if ((t % 6) < 3) { if (v != 0x7fffffff) atomicMin(g, v); } else if (v != (int)0x80000000) atomicMax(g, v);
+    }
+    float r[7];
+    for (int e = 0; e < 3; ++e) { r[e] = block_min(lo[e], red); r[3 + e] = block_max(hi[e], red); }
+    r[6] = block_sum_fixed(ext_sum, red);
+    if (t < 7) P.gpart[((size_t)b * PEN_GW + w) * 8 + t] = r[t];
+}
+
+// frame box, cell size, skip / near masks: what every workgroup of g2 / g3 / g5 needs (recomputed per workgroup, fixed order)
+struct PenGridCtx { float glo[3], ih; };
+__device__ __forceinline__ PenGridCtx pen_grid_ctx(const PenDev& P, const int b) {
+    PenGridCtx c;
+    float lo[3] = {3e38f, 3e38f, 3e38f}, ext = 0.f;
+    for (int w = 0; w < PEN_GW; ++w) {
+        const float* g = P.gpart + ((size_t)b * PEN_GW + w) * 8;
+        for (int e = 0; e < 3; ++e) lo[e] = fminf(lo[e], g[e]);
+        ext += g[6];
+    }
+    const float h = fmaxf(2.f * (ext / (float)P.F), 1e-6f);
+    for (int e = 0; e < 3; ++e) c.glo[e] = lo[e];
+    c.ih = 1.f / h;
+    return c;
+}
+__device__ __forceinline__ int pen_cell_of(const PenGridCtx& c, float x, int e) { return min(1 << 20, max(0, (int)fminf((x - c.glo[e]) * c.ih, 1048576.f))); }
+
+__global__ __launch_bounds__(PEN_T)
+void k_pen_g2(PenDev P, const int* __restrict__ want) {
+    __shared__ unsigned long long s_mask[64], s_near[64];
+    __shared__ int s_pbox[64][6];
+    const int b = blockIdx.y, t = threadIdx.x, w = blockIdx.x;
+    if (want && !want[b]) return;
+    const int F = P.F;
+    const float* aabb = P.aabb + (size_t)b * F * 6;
+    int2* tcell = P.tcell + (size_t)b * F;
+    const PenGridCtx C = pen_grid_ctx(P, b);
+    if (w == 0 && t == 0) { float* gp = P.gridp + b * 4; gp[0] = C.glo[0]; gp[1] = C.glo[1]; gp[2] = C.glo[2]; gp[3] = C.ih; }
     if (t < 64) {
+        unsigned long long m = 0;
+        if (t < P.n_parts) for (int q = 0; q < P.n_parts; ++q) m |= (unsigned long long)(P.skip[(size_t)t * P.n_parts + q] != 0) << q;
+        s_mask[t] = m;
+        for (int e = 0; e < 6; ++e) s_pbox[t][e] = P.pbox[((size_t)b * 64 + t) * 6 + e];
+    }
+    __syncthreads();
+    if (t < 64) {       // parts whose boxes meet and that may collide, as one 64-bit word per part
         unsigned long long m = 0;
         if (t < P.n_parts && s_pbox[t][0] <= s_pbox[t][3]) {
             const unsigned long long sk = s_mask[t];
@@ -290,52 +329,28 @@ void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __r
         }
         s_near[t] = m;
     }
-    const float mean_ext = block_sum_fixed(ext_sum, red) / (float)F;      // (its barriers also publish s_near)
-    // cell size: twice the mean triangle extent; cells are addressed by integer coordinates from
-    // the low corner of the frame's bounding box and hashed into PEN_CELLS buckets (a bucket that
-    // mixes cells only adds candidates the AABB test rejects)
-    const float h = fmaxf(2.f * mean_ext, 1e-6f);
-    const float ih = 1.f / h;
-    const int ncell = PEN_CELLS;
-    auto cell_of = [&](float x, int e) { return min(1 << 20, max(0, (int)fminf((x - glo[e]) * ih, 1048576.f))); };
-    auto bucket = [](int x, int y, int z) { return (int)(((unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u) & (PEN_CELLS - 1)); };
-    (void)ghi;
-    // ---- which parts are present in each bucket (folded to 32 bits; the wavefront tiles are not in
-    // use yet and lend their 64 KB): a triangle only enters a cell that also holds a part it may
-    // collide with -- the crowded interior of a limb, and joints where only parent and child meet,
-    // never reach the pair tests
-    static_assert((PEN_T / 64) * (64 * 12 + 256) >= PEN_CELLS, "part masks borrow the tile / queue area");
-    unsigned* pmask = reinterpret_cast<unsigned*>(cell_cnt + PEN_GRID_INTS);
-    __shared__ unsigned s_coll32[64];
-    if (t < 64) {
-        unsigned m = 0;
-        if (t < P.n_parts) for (int q = 0; q < P.n_parts; ++q) if (!((s_mask[t] >> q) & 1ull)) m |= 1u << (q & 31);
-        s_coll32[t] = m;
-    }
-    for (int c = t; c <= ncell; c += PEN_T) cell_cnt[c] = 0;
-    for (int c = t; c < ncell; c += PEN_T) pmask[c] = 0u;
     __syncthreads();
-    // ---- pass 2: part culling, the cell range of every surviving triangle (packed: low cell coordinates mod 1024, spans,
-    // part, alive bit -- ONE coalesced 8-byte load per triangle in the two passes that follow), part masks of the buckets
-    for (int f0 = t; f0 < F; f0 += PEN_T * PEN_U) {
-        float bx[PEN_U][6]; int seg[PEN_U];
+    // part culling (a triangle whose box meets the box of no part it may collide with cannot have a partner and never
+    // enters the grid), packed cell range of the survivors, part masks of the buckets (folded to 32 bits)
+    for (int f0 = w * PEN_T + t; f0 < F; f0 += PEN_GW * PEN_T * PEN_GU) {
+        float bx[PEN_GU][6]; int seg[PEN_GU];
 #pragma unroll
-        for (int u = 0; u < PEN_U; ++u) {
-            const int f = f0 + u * PEN_T, ff = f < F ? f : 0;
+        for (int u = 0; u < PEN_GU; ++u) {
+            const int f = f0 + u * PEN_GW * PEN_T, ff = f < F ? f : 0;
             seg[u] = P.segm[ff];
 #pragma unroll
-            for (int e = 0; e < 6; ++e) bx[u][e] = aabb[ff * 6 + e];          // (written by this lane in pass 1)
+            for (int e = 0; e < 6; ++e) bx[u][e] = aabb[ff * 6 + e];
         }
 #pragma unroll
-        for (int u = 0; u < PEN_U; ++u) {
-            const int f = f0 + u * PEN_T;
+        for (int u = 0; u < PEN_GU; ++u) {
+            const int f = f0 + u * PEN_GW * PEN_T;
             if (f >= F) continue;
             unsigned long long nm = s_near[seg[u]];
             bool any = false;
             if (nm) {
                 int a6[6];
 #pragma unroll
-                for (int e = 0; e < 6; ++e) a6[e] = ford(bx[u][e]);
+                for (int e = 0; e < 6; ++e) a6[e] = pen_ford(bx[u][e]);
                 while (nm && !any) {
                     const int q = __ffsll((long long)nm) - 1;
                     nm &= nm - 1;
@@ -347,28 +362,61 @@ void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __r
             if (any) {
                 int c0[3], sp[3];
 #pragma unroll
-                for (int e = 0; e < 3; ++e) { c0[e] = cell_of(bx[u][e], e); sp[e] = min(cell_of(bx[u][3 + e], e), c0[e] + PEN_SPAN - 1) - c0[e]; }
+                for (int e = 0; e < 3; ++e) { c0[e] = pen_cell_of(C, bx[u][e], e); sp[e] = min(pen_cell_of(C, bx[u][3 + e], e), c0[e] + PEN_SPAN - 1) - c0[e]; }
                 pk.x = (c0[0] & 1023) | ((c0[1] & 1023) << 10) | ((c0[2] & 1023) << 20) | (int)0x80000000;
                 pk.y = sp[0] | (sp[1] << 3) | (sp[2] << 6) | (seg[u] << 9);
-                const unsigned bit = 1u << (seg[u] & 31);
-                for (int dz = 0; dz <= sp[2]; ++dz) for (int dy = 0; dy <= sp[1]; ++dy) for (int dx = 0; dx <= sp[0]; ++dx)
-                    atomicOr(&pmask[bucket((c0[0] + dx) & 1023, (c0[1] + dy) & 1023, (c0[2] + dz) & 1023)], bit);
             }
             tcell[f] = pk;
         }
     }
+}
+
+// fn(bucket, packed cell key) for every cell of a packed range
+template <class FN>
+__device__ __forceinline__ void pen_for_cells(const int2 pk, FN&& fn) {
+    const int x0 = pk.x & 1023, y0 = (pk.x >> 10) & 1023, z0 = (pk.x >> 20) & 1023;
+    const int sx = pk.y & 7, sy = (pk.y >> 3) & 7, sz = (pk.y >> 6) & 7;
+    for (int dz = 0; dz <= sz; ++dz) for (int dy = 0; dy <= sy; ++dy) for (int dx = 0; dx <= sx; ++dx) {
+        const int x = (x0 + dx) & 1023, y = (y0 + dy) & 1023, z = (z0 + dz) & 1023;
+        fn(pen_bucket(x, y, z), x | (y << 10) | (z << 20));
+    }
+}
+// parts a triangle of part p may collide with, folded to 32 bits (a triangle only enters a cell that also holds such a
+// part: the crowded interior of a limb, and joints where only parent and child meet, never reach the pair tests)
+__device__ __forceinline__ void pen_coll32(const PenDev& P, unsigned* s_coll32) {
+    const int t = threadIdx.x;
+    if (t < 64) {
+        unsigned m = 0;
+        if (t < P.n_parts) for (int q = 0; q < P.n_parts; ++q) if (!P.skip[(size_t)t * P.n_parts + q]) m |= 1u << (q & 31);
+        s_coll32[t] = m;
+    }
     __syncthreads();
-    PEN_CLK(3);
-    // ---- pass 3: counting sort of (cell, triangle) entries: histogram
-    auto for_cells = [&](const int2 pk, auto&& fn) {      // fn(bucket, packed cell key) for every cell of a packed range
-        const int x0 = pk.x & 1023, y0 = (pk.x >> 10) & 1023, z0 = (pk.x >> 20) & 1023;
-        const int sx = pk.y & 7, sy = (pk.y >> 3) & 7, sz = (pk.y >> 6) & 7;
-        for (int dz = 0; dz <= sz; ++dz) for (int dy = 0; dy <= sy; ++dy) for (int dx = 0; dx <= sx; ++dx) {
-            const int x = (x0 + dx) & 1023, y = (y0 + dy) & 1023, z = (z0 + dz) & 1023;
-            fn(bucket(x, y, z), x | (y << 10) | (z << 20));
-        }
-    };
+}
+
+// One workgroup per frame: bucket part masks, histogram, scan and scatter of the (cell, triangle) entries, all on LDS atomics
+// (the same passes on global atomics -- eight workgroups per frame -- measured slower: 60-90 us each).  Every pass reads one
+// coalesced 8-byte word per triangle (k_pen_g2's packed cell range), 7 of them in flight per lane.
+__global__ __launch_bounds__(PEN_T)
+void k_pen_g3(PenDev P, const int* __restrict__ want) {
+    extern __shared__ int cell_cnt[];           // [PEN_CELLS + 1] histogram, then start offsets, then cursors | [PEN_CELLS] part masks
+    __shared__ int slice[PEN_T];
+    __shared__ int s_total;
+    __shared__ unsigned s_coll32[64];
+    const int b = blockIdx.x, t = threadIdx.x;
+    int* st = P.stats + b * PEN_STATS;
+    int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
+    if (want && !want[b]) {                     // the frame's stage carries no collision weight: nothing to do
+        if (t == 0) { P.ptotal[b] = 0; cells[PEN_CELLS] = 0; st[0] = st[1] = st[2] = st[3] = 0; st[13] = 0; st[15] = 0; }
+        return;
+    }
+    const int F = P.F;
+    const int2* tcell = P.tcell + (size_t)b * F;
+    unsigned* pmask = reinterpret_cast<unsigned*>(cell_cnt + PEN_GRID_INTS);
+    for (int c = t; c <= PEN_CELLS; c += PEN_T) cell_cnt[c] = 0;
+    for (int c = t; c < PEN_CELLS; c += PEN_T) pmask[c] = 0u;
+    pen_coll32(P, s_coll32);                    // (ends with a barrier)
     constexpr int U2 = 7;
+    // which parts are present in each bucket (folded to 32 bits)
     for (int f0 = t; f0 < F; f0 += PEN_T * U2) {
         int2 pk[U2];
 #pragma unroll
@@ -376,38 +424,44 @@ void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __r
 #pragma unroll
         for (int u = 0; u < U2; ++u) {
             if (pk[u].x >= 0) continue;                    // (alive bit = sign bit)
-            const unsigned want32 = s_coll32[(pk[u].y >> 9) & 63];
-            for_cells(pk[u], [&](int bk, int) { if (pmask[bk] & want32) atomicAdd(&cell_cnt[bk], 1); });
+            const unsigned bit = 1u << ((pk[u].y >> 9) & 31);
+            pen_for_cells(pk[u], [&](int bk, int) { atomicOr(&pmask[bk], bit); });
         }
     }
     __syncthreads();
-    PEN_CLK(4);
-    // exclusive scan over the cells: each lane owns a contiguous slice
-    {
-        const int per = (ncell + PEN_T - 1) / PEN_T;
-        const int c0 = min(ncell, t * per), c1 = min(ncell, c0 + per);
-        int sm = 0;
-        for (int c = c0; c < c1; ++c) sm += cell_cnt[c];
-        int tot;
-        int acc = block_excl_scan(sm, slice, &tot);
-        for (int c = c0; c < c1; ++c) { const int v = cell_cnt[c]; cell_cnt[c] = acc; acc += v; }
-        if (t == 0) { cell_cnt[ncell] = tot; s_total = tot; }
-        __syncthreads();
+    // histogram
+    for (int f0 = t; f0 < F; f0 += PEN_T * U2) {
+        int2 pk[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) { const int f = f0 + u * PEN_T; pk[u] = f < F ? tcell[f] : make_int2(0, 0); }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            if (pk[u].x >= 0) continue;
+            const unsigned want32 = s_coll32[(pk[u].y >> 9) & 63];
+            pen_for_cells(pk[u], [&](int bk, int) { if (pmask[bk] & want32) atomicAdd(&cell_cnt[bk], 1); });
+        }
     }
     __syncthreads();
-    PEN_CLK(5);
+    {   // exclusive scan over the buckets: each lane owns a contiguous slice
+        constexpr int per = PEN_CELLS / PEN_T;
+        const int c0 = t * per;
+        int sm = 0;
+        for (int c = c0; c < c0 + per; ++c) sm += cell_cnt[c];
+        int tot;
+        int acc = block_excl_scan(sm, slice, &tot);
+        for (int c = c0; c < c0 + per; ++c) { const int v = cell_cnt[c]; cell_cnt[c] = acc; acc += v; }
+        if (t == 0) { cell_cnt[PEN_CELLS] = tot; s_total = tot; }
+        __syncthreads();
+    }
     int* ent = P.entries + (size_t)b * P.ent_cap;
     int* entc = P.ent_cell + (size_t)b * P.ent_cap;
-    // a bucket may mix several cells (and one triangle may sit in it twice, once per cell): entries
-    // carry the cell they were made for, and a scan only looks at those of its own cell
     const bool ent_ok = s_total <= P.ent_cap - 4;
-    if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = ncell; st[13] = 0; st[14] = s_total; st[15] = 0; }
+    if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = PEN_CELLS; st[13] = 0; st[14] = s_total; st[15] = 0; for (int q = 4; q < 13; ++q) st[q] = 0; }
     if (!ent_ok) {       // grid too crowded for the entry buffer: report, produce no pairs
-        for (int f = t; f < F; f += PEN_T) P.pcount[(size_t)b * F + f] = 0;
-        if (t == 0) { st[0] = 0; st[1] = 0; P.ptotal[b] = 0; P.cells[(size_t)b * (PEN_CELLS + 1) + PEN_CELLS] = 0; }
+        if (t == 0) { st[0] = 0; st[1] = 0; P.ptotal[b] = 0; cells[PEN_CELLS] = 0; }
         return;
     }
-    // ---- pass 4: scatter: the start offsets double as cursors, so bucket c ends up holding its END offset
+    // scatter: the start offsets double as cursors, so bucket c ends up holding its END offset
     // (= the start of bucket c + 1); a bucket's entries are [c ? cell_cnt[c - 1] : 0, cell_cnt[c])
     for (int f0 = t; f0 < F; f0 += PEN_T * U2) {
         int2 pk[U2];
@@ -418,7 +472,7 @@ void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __r
             if (pk[u].x >= 0) continue;
             const int f = f0 + u * PEN_T, pf = (pk[u].y >> 9) & 63;
             const unsigned want32 = s_coll32[pf];
-            for_cells(pk[u], [&](int bk, int key) {
+            pen_for_cells(pk[u], [&](int bk, int key) {
                 if (!(pmask[bk] & want32)) return;
                 const int q = atomicAdd(&cell_cnt[bk], 1);
                 ent[q] = f | (pf << 24);            // triangle | part << 24
@@ -428,12 +482,7 @@ void k_pen_grid(PenDev P, const float* __restrict__ verts, int B, const int* __r
     }
     __threadfence_block();
     __syncthreads();
-    PEN_CLK(6);
-    // hand the grid to the pair tests (k_pen_walk, several workgroups per frame)
-    int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
-    for (int c = t; c <= ncell; c += PEN_T) cells[c] = cell_cnt[c];
-    if (t == 0) { float* gp = P.gridp + b * 4; gp[0] = glo[0]; gp[1] = glo[1]; gp[2] = glo[2]; gp[3] = ih; }
-#undef PEN_CLK
+    for (int c = t; c <= PEN_CELLS; c += PEN_T) cells[c] = cell_cnt[c];
 }
 
 
@@ -580,11 +629,16 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
 // offsets of the triangles' partner ranges in the frame's pair list (k_pen_rank fills the list)
 __global__ __launch_bounds__(PEN_T)
 void k_pen_list(PenDev P, const int* __restrict__ want) {
+    extern __shared__ int s_cnt[];             // [F] partner counts of the frame, then [hasp_words] bitmask
     __shared__ float red[PEN_T / 64];
     __shared__ int slice[PEN_T];
     const int b = blockIdx.x, t = threadIdx.x;
     int* st = P.stats + b * PEN_STATS;
-    if ((want && !want[b]) || st[2] != 0) return;          // skipped frame / grid overflow: k_pen_grid has zeroed the totals
+    unsigned* hasp = P.hasp + (size_t)b * P.hasp_words;
+    if ((want && !want[b]) || st[2] != 0) {          // skipped frame / grid overflow: k_pen_grid has zeroed the totals
+        for (int w = t; w < P.hasp_words; w += PEN_T) hasp[w] = 0u;
+        return;
+    }
     const int F = P.F;
     int* pc = P.pcount + (size_t)b * F;
 
@@ -597,25 +651,34 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
     // left to arrival order.  Cut partners, and pairs beyond pair_cap, are counted.
     int* poff = P.poff + (size_t)b * F;
     int* pav = P.pavail + (size_t)b * F;
+    unsigned* s_has = reinterpret_cast<unsigned*>(s_cnt + F);
+    // (every lane owns a contiguous run of triangles for the scan; read straight from global memory those runs are 84-byte
+    //  strides across the lanes and two chains of 21 dependent loads -- the counts are staged through LDS coalesced instead)
+    for (int f = t; f < F; f += PEN_T) s_cnt[f] = pc[f];
+    for (int w = t; w < P.hasp_words; w += PEN_T) s_has[w] = 0u;
+    __syncthreads();
     {
         const int per = (F + PEN_T - 1) / PEN_T;
         const int f0 = min(F, t * per), f1 = min(F, f0 + per);
         int sum = 0, n_over = 0;
-#pragma unroll 8
-        for (int f = f0; f < f1; ++f) { const int cnt = pc[f]; n_over += max(cnt - P.cap, 0); sum += min(cnt, P.cap); }
+        for (int f = f0; f < f1; ++f) { const int cnt = s_cnt[f]; n_over += max(cnt - P.cap, 0); sum += min(cnt, P.cap); }
         int ptot;
         int acc = block_excl_scan(sum, slice, &ptot);
         for (int f = f0; f < f1; ++f) {
-            const int c = min(pc[f], P.cap);
+            const int raw = s_cnt[f];
+            const int c = min(raw, P.cap);
             const int keep = max(0, min(c, P.pair_cap - acc));
             n_over += c - keep;
-            pav[f] = min(pc[f], P.pcap);
+            pav[f] = min(raw, P.pcap);
             poff[f] = acc; pc[f] = c;            // readers cut at pair_cap: kept = clamp(pair_cap - poff, 0, pcount)
+            if (c > 0 && acc < P.pair_cap) atomicOr(&s_has[f >> 5], 1u << (f & 31));
             acc += c;
         }
         const float to = block_sum_fixed((float)n_over, red);
         if (t == 0) { const int tot = min(ptot, P.pair_cap); P.ptotal[b] = tot; st[0] = tot; st[1] = (int)to; }
     }
+    __syncthreads();
+    for (int w = t; w < P.hasp_words; w += PEN_T) hasp[w] = s_has[w];
 }
 
 // ranks every triangle's partner list into the frame's pair list; PEN_RANK_BLOCKS workgroups per frame
@@ -843,12 +906,14 @@ void k_pen_facesum(PenDev P) {
 __global__ __launch_bounds__(256)
 void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss_out, const int* __restrict__ want) {
     __shared__ float red[4];
+    extern __shared__ unsigned s_hasp[];        // [hasp_words] triangles of this frame that have pairs
     const int b = blockIdx.y;
     if (want && !want[b]) { if (blockIdx.x == 0 && threadIdx.x == 0) loss_out[b] = 0.f; return; }
     const int v = blockIdx.x * 256 + threadIdx.x;
     const int total = P.ptotal[b];
-    const int* poff = P.poff + (size_t)b * P.F;
-    const int* pc = P.pcount + (size_t)b * P.F;
+    for (int w = threadIdx.x; w < P.hasp_words; w += 256) s_hasp[w] = P.hasp[(size_t)b * P.hasp_words + w];
+    __syncthreads();
+    auto has = [&](int face) { return (s_hasp[face >> 5] >> (face & 31)) & 1u; };
     if (v < P.V) {
         float g[3] = {0.f, 0.f, 0.f};
         if (total > 0) {
@@ -861,7 +926,7 @@ void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss
 #pragma unroll
                 for (int u = 0; u < 8; ++u) fc[u] = qb + u < q1 ? P.vf_list[qb + u] : -1;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int face = fc[u] >= 0 ? fc[u] / 3 : 0; use[u] = fc[u] >= 0 && pc[face] > 0 && poff[face] < P.pair_cap; }
+                for (int u = 0; u < 8; ++u) use[u] = fc[u] >= 0 && has(fc[u] / 3);      // (2.6 KB of bits in LDS instead of two gathers per corner)
                 float tv[8][3];
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
@@ -876,7 +941,7 @@ void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss
     if (blockIdx.x == 0) {
         float s = 0.f;
         if (total > 0) for (int f = threadIdx.x; f < P.F; f += 256)
-            if (pc[f] > 0 && poff[f] < P.pair_cap) s += P.tloss[(size_t)b * P.F + f];
+            if (has(f)) s += P.tloss[(size_t)b * P.F + f];
         s = wave_sum_dpp(s);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         __syncthreads();
@@ -943,13 +1008,15 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     P.ent_cap = F * 32;
     P.aabb = h->zeros<float>(B * F * 6); P.entries = h->zeros<int>(B * P.ent_cap); P.ent_cell = h->zeros<int>(B * P.ent_cap);
     P.tcell = h->zeros<int2>(B * F);
+    P.pbox = h->zeros<int>(B * 64 * 6); P.gpart = h->zeros<float>(B * PEN_GW * 8);
     P.partners = h->zeros<int>(B * F * P.pcap); P.pcount = h->zeros<int>(B * F); P.pavail = h->zeros<int>(B * F);
     P.pair_cap = (int)std::min<size_t>((size_t)F * P.cap, std::max<size_t>(65536, (size_t)16 * F));
+    P.hasp_words = (F + 31) / 32; P.hasp = h->zeros<unsigned>(B * P.hasp_words);
     P.poff = h->zeros<int>(B * F); P.pown = h->zeros<int>(B * P.pair_cap); P.plist = h->zeros<int>(B * P.pair_cap);
     P.pout = h->zeros<float>(B * 10 * P.pair_cap); P.ptotal = h->zeros<int>(B); P.stats = h->zeros<int>(B * PEN_STATS);
     P.cells = h->zeros<int>(B * (PEN_CELLS + 1)); P.gridp = h->zeros<float>(B * 4);
     P.tgrad = h->zeros<float>(B * F * 9); P.tloss = h->zeros<float>(B * F);
-    if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tcell || !P.aabb || !P.entries || !P.ent_cell) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
+    if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tcell || !P.pbox || !P.gpart || !P.aabb || !P.entries || !P.ent_cell) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.pavail || !P.ptotal) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     *out = h;
     return 0;
@@ -967,23 +1034,29 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
     if (B < 1 || B > h->Bmax) { sfx_set_error("batch %d exceeds the capacity %d given to sfx_pen_create", B, h->Bmax); return -1; }
     if (!(sigma > 0.f)) { sfx_set_error("df_cone_height must be positive"); return -1; }
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)(PEN_GRID_INTS + (PEN_T / 64) * (64 * 12 + 256)) * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_pen_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            sfx_set_error("cannot reserve %zu bytes of LDS", lds); return -2; }
+        if (hipFuncSetAttribute((const void*)k_pen_list, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_pen_g3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((PEN_GRID_INTS + PEN_CELLS) * sizeof(int))) != hipSuccess) {
+            sfx_set_error("cannot reserve LDS for k_pen_list / k_pen_g3"); return -2; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_pen_grid, dim3(B), dim3(PEN_T), lds, s, h->P, verts_dev, B, want_dev);
+    if ((size_t)(h->P.F + h->P.hasp_words) * sizeof(int) > 160 * 1024 - 8192) { sfx_set_error("mesh of %d faces: k_pen_list stages the counts in LDS (<= 38 k faces)", h->P.F); return -1; }
+    // grid build: reset the cross-workgroup accumulators (part boxes to empty = 0x7f.. / 0x80.. patterns, masks and counts to 0)
+    hipLaunchKernelGGL(k_pen_reset, dim3(2, B), dim3(256), 0, s, h->P, want_dev);
+    hipLaunchKernelGGL(k_pen_g1, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, verts_dev, want_dev);
+    hipLaunchKernelGGL(k_pen_g2, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, want_dev);
+    hipLaunchKernelGGL(k_pen_g3, dim3(B), dim3(PEN_T), (size_t)(PEN_GRID_INTS + PEN_CELLS) * sizeof(int), s, h->P, want_dev);
     hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, h->P, want_dev);
-    hipLaunchKernelGGL(k_pen_list, dim3(B), dim3(PEN_T), 0, s, h->P, want_dev);
+    hipLaunchKernelGGL(k_pen_list, dim3(B), dim3(PEN_T), (size_t)(h->P.F + h->P.hasp_words) * sizeof(int), s, h->P, want_dev);
     int cap_pad = 64;
     while (cap_pad < h->P.pcap) cap_pad <<= 1;
     hipLaunchKernelGGL(k_pen_rank, dim3(PEN_RANK_BLOCKS, B), dim3(256), (size_t)4 * std::min(std::max(cap_pad, 64), 2048) * sizeof(int), s,
                        h->P, want_dev, cap_pad);
     hipLaunchKernelGGL(k_pen_eval, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside);
     hipLaunchKernelGGL(k_pen_facesum, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P);
-    hipLaunchKernelGGL(k_pen_gather, dim3((std::max(h->P.V, 1) + 255) / 256, B), dim3(256), 0, s, h->P, dverts_dev, loss_dev, want_dev);
+    hipLaunchKernelGGL(k_pen_gather, dim3((std::max(h->P.V, 1) + 255) / 256, B), dim3(256), (size_t)h->P.hasp_words * sizeof(unsigned), s,
+                       h->P, dverts_dev, loss_dev, want_dev);
     if (hipGetLastError() != hipSuccess) { sfx_set_error("penetration kernels failed to launch"); return -4; }
     return 0;
 }
