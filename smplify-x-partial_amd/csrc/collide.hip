@@ -43,7 +43,11 @@
 #define PEN_GRID_INTS ((((PEN_CELLS + 1) + 3) / 4) * 4)
 #define PEN_SPAN 8              // cells per axis one triangle may be entered in (a sane triangle spans 1-3; an exploded
                                 // mesh -- diverged fit, NaN / huge coordinates -- must not turn into 10^9 cell visits)
+#ifdef PEN_COUNT
+#define PEN_STATS 32      // diagnostic build: room for the walk counters
+#else
 #define PEN_STATS 16
+#endif
 #define PEN_MAX_WALK 2048        // entries an entry looks ahead in its bucket before it gives up (crowded cells of a sane mesh hold hundreds:
                                 // 418 on the synthetic surface).  A diverged fit folds the mesh into a few cells of 10^4 entries; walking
                                 // them out took 7-8 ms per evaluation and held up the whole batch (3 % of the launches of a 256-frame fit,
@@ -420,7 +424,7 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     for (int f0 = t; f0 < F; f0 += PEN_T * U2) {
         int2 pk[U2];
 #pragma unroll
-        for (int u = 0; u < U2; ++u) { const int f = f0 + u * PEN_T; pk[u] = f < F ? tcell[f] : make_int2(0, 0); }
+        for (int u = 0; u < U2; ++u) { const int f = f0 + u * PEN_T; const int2 tc_ = tcell[f < F ? f : 0]; pk[u] = f < F ? tc_ : make_int2(0, 0); }
 #pragma unroll
         for (int u = 0; u < U2; ++u) {
             if (pk[u].x >= 0) continue;                    // (alive bit = sign bit)
@@ -433,7 +437,7 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     for (int f0 = t; f0 < F; f0 += PEN_T * U2) {
         int2 pk[U2];
 #pragma unroll
-        for (int u = 0; u < U2; ++u) { const int f = f0 + u * PEN_T; pk[u] = f < F ? tcell[f] : make_int2(0, 0); }
+        for (int u = 0; u < U2; ++u) { const int f = f0 + u * PEN_T; const int2 tc_ = tcell[f < F ? f : 0]; pk[u] = f < F ? tc_ : make_int2(0, 0); }
 #pragma unroll
         for (int u = 0; u < U2; ++u) {
             if (pk[u].x >= 0) continue;
@@ -456,7 +460,8 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     int* ent = P.entries + (size_t)b * P.ent_cap;
     int* entc = P.ent_cell + (size_t)b * P.ent_cap;
     const bool ent_ok = s_total <= P.ent_cap - 4;
-    if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = PEN_CELLS; st[13] = 0; st[14] = s_total; st[15] = 0; for (int q = 4; q < 13; ++q) st[q] = 0; }
+    if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = PEN_CELLS; st[13] = 0; st[14] = s_total; st[15] = 0; for (int q = 4; q < 13; ++q) st[q] = 0;
+                  for (int q = 16; q < PEN_STATS; ++q) st[q] = 0; }
     if (!ent_ok) {       // grid too crowded for the entry buffer: report, produce no pairs
         if (t == 0) { st[0] = 0; st[1] = 0; P.ptotal[b] = 0; cells[PEN_CELLS] = 0; }
         return;
@@ -466,7 +471,7 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     for (int f0 = t; f0 < F; f0 += PEN_T * U2) {
         int2 pk[U2];
 #pragma unroll
-        for (int u = 0; u < U2; ++u) { const int f = f0 + u * PEN_T; pk[u] = f < F ? tcell[f] : make_int2(0, 0); }
+        for (int u = 0; u < U2; ++u) { const int f = f0 + u * PEN_T; const int2 tc_ = tcell[f < F ? f : 0]; pk[u] = f < F ? tc_ : make_int2(0, 0); }
 #pragma unroll
         for (int u = 0; u < U2; ++u) {
             if (pk[u].x >= 0) continue;
@@ -522,13 +527,23 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
     int* tile = s_tile + wv * 128 * 12;
     int* pc = P.pcount + (size_t)b * F;
     int* part = P.partners + (size_t)b * F * P.pcap;
+    // (every load unconditional, from a clamped index: written as `ok ? p[i] : 0` each of the eleven loads became its own
+    //  exec-masked branch with a full s_waitcnt behind it -- eleven serial round trips per header, two headers per block of 64
+    //  entries: that chain, not the pair tests, was most of this kernel's time)
     auto load_hdr = [&](int q, bool ok, int (&hd)[12]) {
-        hd[0] = ok ? ent[q] : 0; hd[1] = ok ? entc[q] : -1;
-        const int f = hd[0] & 0xffffff;
+        const int qs = ok ? q : 0;
+        const int e0 = ent[qs], e1 = entc[qs];
+        const int f = e0 & 0xffffff;
+        int bx[6], vd[3];
 #pragma unroll
-        for (int e = 0; e < 6; ++e) hd[2 + e] = ok ? __float_as_int(aabb[f * 6 + e]) : 0;
+        for (int e = 0; e < 6; ++e) bx[e] = __float_as_int(aabb[f * 6 + e]);
 #pragma unroll
-        for (int e = 0; e < 3; ++e) hd[8 + e] = ok ? P.faces[f * 3 + e] : -1 - e;
+        for (int e = 0; e < 3; ++e) vd[e] = P.faces[f * 3 + e];
+        hd[0] = ok ? e0 : 0; hd[1] = ok ? e1 : -1;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) hd[2 + e] = ok ? bx[e] : 0;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) hd[8 + e] = ok ? vd[e] : -1 - e;
         hd[11] = 0;
     };
     // (blocks of 64 entries, NOT whole buckets: a crowded bucket is shared by many wavefronts; the
@@ -601,7 +616,8 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
                 const bool c1 = act && h0.y == ck;
                 const bool c2 = ai[0] <= kh0 && kl0 <= ai[3] && ai[1] <= kh1 && kl1 <= ai[4] && ai[2] <= kh2 && kl2 <= ai[5];
                 const unsigned long long m0 = __ballot(act), m1 = __ballot(c1), m2 = __ballot(pass), m3 = __ballot(pass && c2);
-                if (lane == 0) { atomicAdd(&st[16], __popcll(m0)); atomicAdd(&st[17], __popcll(m1)); atomicAdd(&st[18], __popcll(m2)); atomicAdd(&st[19], __popcll(m3)); }
+                if (lane == 0) { atomicAdd(&st[16], __popcll(m0)); atomicAdd(&st[17], __popcll(m1)); atomicAdd(&st[18], __popcll(m2)); atomicAdd(&st[19], __popcll(m3));
+                                 atomicAdd(&st[20], 1); }      // [20] wavefront steps
             }
 #endif
             pass = pass && ai[0] <= kh0 && kl0 <= ai[3] && ai[1] <= kh1 && kl1 <= ai[4] && ai[2] <= kh2 && kl2 <= ai[5];
@@ -707,8 +723,10 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
     for (int fw = gw * fper; fw < flim; fw += 64) {
         const int f = fw + lane;
         const bool inr = f < flim;
-        const int c_l = inr ? pc[f] : 0, off_l = inr ? poff[f] : 0x3fffffff;
-        const int a_l = inr ? pav[f] : 0;              // partners held (> c_l: the list is cut to its c_l lowest ids)
+        const int fs = inr ? f : 0;                    // (unconditional loads from a clamped index: three loads in flight, not three round trips)
+        const int c_ld = pc[fs], o_ld = poff[fs], a_ld = pav[fs];
+        const int c_l = inr ? c_ld : 0, off_l = inr ? o_ld : 0x3fffffff;
+        const int a_l = inr ? a_ld : 0;                // partners held (> c_l: the list is cut to its c_l lowest ids)
         const int base = __builtin_amdgcn_readfirstlane(off_l);
         const int lastv = min(63, flim - 1 - fw);
         const int E = __builtin_amdgcn_readlane(off_l + c_l, lastv) - base;
@@ -798,7 +816,9 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
     for (int i0 = blockIdx.x * 256 + (threadIdx.x & ~63); i0 < total; i0 += gridDim.x * 256) {      // wave-uniform trip count
         const int i = i0 + lane;
         const bool valid = i < total;
-        const int f = valid ? pown[i] : 0, g = valid ? plist[i] : 0;
+        const int is_ = valid ? i : 0;
+        const int f_ld = pown[is_], g_ld = plist[is_];
+        const int f = valid ? f_ld : 0, g = valid ? g_ld : 0;
         float p[9], qv[9];
         for (int k = 0; k < 3; ++k) for (int e = 0; e < 3; ++e) {
             p[k * 3 + e] = vb[(size_t)P.faces[f * 3 + k] * 3 + e];
@@ -924,7 +944,7 @@ void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss
             for (int qb = q0; qb < q1; qb += 8) {
                 int fc[8]; bool use[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) fc[u] = qb + u < q1 ? P.vf_list[qb + u] : -1;
+                for (int u = 0; u < 8; ++u) { const int l_ = P.vf_list[min(qb + u, q1 - 1)]; fc[u] = qb + u < q1 ? l_ : -1; }      // (unconditional loads)
 #pragma unroll
                 for (int u = 0; u < 8; ++u) use[u] = fc[u] >= 0 && has(fc[u] / 3);      // (2.6 KB of bits in LDS instead of two gathers per corner)
                 float tv[8][3];
@@ -1075,9 +1095,17 @@ extern "C" int sfx_pen_phase_clocks(sfx_pen* h, int32_t B, int32_t* out) {
     hipMemcpy(st.data(), h->P.stats, st.size() * sizeof(int), hipMemcpyDeviceToHost);
     for (int i = 0; i < B; ++i) for (int k = 0; k < 11; ++k) out[i * 11 + k] = st[(size_t)i * PEN_STATS + 4 + k];
 #ifdef PEN_COUNT
-    for (int i = 0; i < std::min(B, 4); ++i)
-        fprintf(stderr, "[pen count] frame %d: walked %d, same cell %d, part mask passed %d, boxes overlap %d\n", i,
-                st[(size_t)i * PEN_STATS + 16], st[(size_t)i * PEN_STATS + 17], st[(size_t)i * PEN_STATS + 18], st[(size_t)i * PEN_STATS + 19]);
+    {   // per frame: grid entries, candidates by the test they die on, wavefront steps of the walk -- and how unevenly the frames carry them
+        long tot[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < B; ++i) {
+            const int* r = &st[(size_t)i * PEN_STATS];
+            const long v[6] = {r[14], r[16], r[17], r[18], r[19], r[20]};
+            for (int q = 0; q < 6; ++q) { tot[q] += v[q]; mx[q] = std::max(mx[q], v[q]); }
+        }
+        fprintf(stderr, "[pen count] %d frames, mean / max per frame: entries %ld / %ld; walked %ld / %ld, same cell %ld / %ld, part mask passed %ld / %ld, "
+                "boxes overlap %ld / %ld; wavefront steps %ld / %ld\n", B, tot[0] / B, mx[0], tot[1] / B, mx[1], tot[2] / B, mx[2], tot[3] / B, mx[3],
+                tot[4] / B, mx[4], tot[5] / B, mx[5]);
+    }
 #endif
     return 0;
 }
