@@ -20,6 +20,7 @@
 // Algorithmic traffic per launch:
 //     66.0 MB of constants (dirs 61.1+2.5, W 2.3, template 0.1) + B * 125.7 KB of vertices.
 #include "sfx_internal.h"
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -203,6 +204,150 @@ void k_lbs_dense(DevModel M, BatchDev D) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_lbs_dense16: the same kernel with 16 instead of 32 frames per wavefront (one 16 x 16 MFMA tile per coordinate): work
+// units of 434 instead of 870 MFMAs, 64 frames per workgroup, 90 registers.  Every (vertex, frame) goes through exactly the
+// chain of fp32 operations it goes through in k_lbs_dense (rows of an MFMA tile are independent; same K order, same
+// skinning), so the two kernels are interchangeable bit for bit and the launcher picks by the number of active frames:
+// this one where the batch is small or fills k_lbs_dense's 128-frame blocks badly (<= 64 frames: the launch floor, set by one
+// wavefront's MFMA chain, drops from 29 to ~20 us; 129-192 frames: 74 instead of 91 us), k_lbs_dense where its fewer LDS
+// operand reads per MFMA pay (it reads 5 operands per 6 MFMAs, this kernel 4 per 3).
+// (Measured and dropped on the way: a K-split pair of wavefronts per 16 x 32 tile -- halves of the K range summed as
+//  (half 0) + (half 1) after an exchange through LDS: faster below 64 and at 129-192 frames, 4-8 % slower at 256-1024, and NOT
+//  interchangeable with k_lbs_dense bit for bit, so it could not be used for part of the batch sizes only.)
+#define FB3 64            // frames per workgroup
+struct __align__(16) DenseLDS16 {
+    float a[2][FB3][LDK];
+    float b[2][KC][LDB];
+};
+#ifndef MINW16
+#define MINW16 4
+#endif
+__global__ __launch_bounds__(DT, MINW16)
+void k_lbs_dense16(DevModel M, BatchDev D) {
+    __shared__ DenseLDS16 S;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    int tile, fblk, fpb;
+    {
+        const int ny = (D.nact + FB3 - 1) / FB3, ntile = (M.V + VB - 1) / VB;
+        const int tpx = (ntile + 7) / 8;                        // tiles per XCD
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        tile = xcd * tpx + slot / ny; fblk = slot % ny;
+        if (tile >= ntile) return;
+        fpb = 16 * (((D.nact + 15) / 16 + ny - 1) / ny);        // frames dealt evenly to the frame blocks in 16-frame slices
+    }
+    const int v0 = tile * VB;
+    const int fb0 = fblk * fpb;
+    const int b0 = fb0 + wv * 16;
+    const int jl = lane & 15, kq = lane >> 4;
+    const int V = M.V, B = D.nact;
+    const int vtx = v0 + jl;
+    const int v = vtx < V ? vtx : V - 1;
+    const size_t Bp = (size_t)D.Bpad;
+    const size_t LD = (size_t)3 * M.Vpad;
+    const bool active = wv * 16 < fpb && b0 < B;
+    // staging: 512 (feat) + 384 (dirs) float4 per chunk
+    const float4* gA = reinterpret_cast<const float4*>(D.featR + (size_t)fb0 * SFX_KD_PAD);
+    const float4* gB = reinterpret_cast<const float4*>(M.dirs + (size_t)v0 * 3);
+    const int LD4 = (int)(LD / 4);
+    const int stepA = KC / 4, stepB = KC * LD4;
+    int gA_off[2], lA_off[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int idx = tid + q * DT, f = idx / (KC / 4), k4 = idx % (KC / 4);
+        gA_off[q] = f * (SFX_KD_PAD / 4) + k4; lA_off[q] = f * LDK + k4 * 4;
+    }
+    const int i4 = tid, i5 = tid + DT;
+    const bool ok5 = i5 < B4;
+    const int gB4 = (i4 / (NB3 / 4)) * LD4 + i4 % (NB3 / 4), lB4 = (i4 / (NB3 / 4)) * LDB + (i4 % (NB3 / 4)) * 4;
+    const int j5 = ok5 ? i5 : 0;
+    const int gB5 = (j5 / (NB3 / 4)) * LD4 + j5 % (NB3 / 4), lB5 = (j5 / (NB3 / 4)) * LDB + (j5 % (NB3 / 4)) * 4;
+    float4 s0, s1, s4, s5;
+#define ST3_LOAD(c) do { s0 = gA[gA_off[0] + (c) * stepA]; s1 = gA[gA_off[1] + (c) * stepA];            \
+        s4 = gB[gB4 + (c) * stepB]; s5 = gB[gB5 + (c) * stepB]; } while (0)
+#define ST3_WRITE(buf) do {                                                                            \
+        *reinterpret_cast<float4*>(&S.a[buf][0][0] + lA_off[0]) = s0;                                  \
+        *reinterpret_cast<float4*>(&S.a[buf][0][0] + lA_off[1]) = s1;                                  \
+        *reinterpret_cast<float4*>(&S.b[buf][0][0] + lB4) = s4;                                        \
+        if (ok5) *reinterpret_cast<float4*>(&S.b[buf][0][0] + lB5) = s5; } while (0)
+    f32x4 ax0 = {0, 0, 0, 0}, ay0 = ax0, az0 = ax0;
+    const float tx = M.v_template[v * 3], ty = M.v_template[v * 3 + 1], tz = M.v_template[v * 3 + 2];
+    constexpr int NCHUNK = SFX_KD_PAD / KC;
+    ST3_LOAD(KCHUNK(0));
+    ST3_WRITE(0);
+    __syncthreads();
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < NCHUNK) ST3_LOAD(KCHUNK(c + 1));
+        if (active) {
+            const float* sa = &S.a[cur][wv * 16 + jl][kq];
+            const float* sb = &S.b[cur][kq][jl * 3];
+#pragma unroll
+            for (int ks = 0; ks < KC / 4; ++ks) {
+                const float a0 = sa[ks * 4];
+                const float bx = sb[ks * 4 * LDB], by = sb[ks * 4 * LDB + 1], bz = sb[ks * 4 * LDB + 2];
+                ax0 = MFMA(a0, bx, ax0); ay0 = MFMA(a0, by, ay0); az0 = MFMA(a0, bz, az0);
+            }
+        }
+        if (c + 1 < NCHUNK) ST3_WRITE(cur ^ 1);
+        __syncthreads();
+    }
+#undef ST3_LOAD
+#undef ST3_WRITE
+    if (!active) return;
+    const bool vok = vtx < V;
+    const int us = vok ? M.vslot[vtx] : -1;      // export index of an item vertex
+    if (us >= 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f0 = b0 + kq * 4 + r;
+            if (f0 < B) { float* o = D.uvp + ((size_t)f0 * M.n_uniq + us) * 3; o[0] = ax0[r]; o[1] = ay0[r]; o[2] = az0[r]; }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ax0[r] += tx; ay0[r] += ty; az0[r] += tz; }
+    const int njs = M.tj_n[tile] >> 2;
+    const int* jl4 = M.tj_list + (size_t)tile * SFX_JPAD + kq;
+    const float* wl = M.tj_w + ((size_t)tile * SFX_JPAD + kq) * 16 + jl;
+    const float* atb = D.AT + b0 + jl;
+    const size_t estep = (size_t)SFX_JPAD * Bp;
+    float P0, P1, P2, P3, N0, N1, N2, N3, wc, wn;
+#define AT3_LOAD(p0, p1, p2, p3, ww, rr, js) do {                                                            \
+        const float* at_ = atb + ((size_t)((rr) * 4) * SFX_JPAD + jl4[(js) * 4]) * Bp;                        \
+        p0 = at_[0]; p1 = at_[estep]; p2 = at_[2 * estep]; p3 = at_[3 * estep];                               \
+        ww = wl[(js) * 64]; } while (0)
+    float o0[4][3];
+    AT3_LOAD(P0, P1, P2, P3, wc, 0, 0);
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        f32x4 t00 = {0, 0, 0, 0}, t01 = t00, t02 = t00, t03 = t00;
+        for (int js = 0; js < njs; ++js) {
+            if (js + 1 < njs) AT3_LOAD(N0, N1, N2, N3, wn, rr, js + 1);
+            else if (rr < 2) AT3_LOAD(N0, N1, N2, N3, wn, rr + 1, 0);
+            t00 = MFMA(P0, wc, t00); t01 = MFMA(P1, wc, t01); t02 = MFMA(P2, wc, t02); t03 = MFMA(P3, wc, t03);
+            P0 = N0; P1 = N1; P2 = N2; P3 = N3; wc = wn;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o0[r][rr] = t00[r] * ax0[r] + t01[r] * ay0[r] + t02[r] * az0[r] + t03[r];
+    }
+#undef AT3_LOAD
+    if (vok && D.vposed) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f0 = b0 + kq * 4 + r;
+            if (f0 < B) { float* o = D.vposed + ((size_t)f0 * V + vtx) * 3; o[0] = ax0[r]; o[1] = ay0[r]; o[2] = az0[r]; }
+        }
+    }
+    if (vok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f0 = b0 + kq * 4 + r;
+            if (f0 < B) { float* o = D.verts + ((size_t)f0 * V + vtx) * 3; o[0] = o0[r][0]; o[1] = o0[r][1]; o[2] = o0[r][2]; }
+        }
+    }
+}
+
 #ifdef MF32
 // DIAGNOSTIC build only (tools/build_variant.sh mf32 lbs_dense -DMF32 -DNO_T): the K loop of the blend-shape GEMM on
 // v_mfma_f32_32x32x2_f32 -- wavefront tile 32 vertices x 32 frames, 3 x 16 accumulator registers, per K step of two rows
@@ -295,6 +440,15 @@ void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s) {
         return;
     }
 #endif
+    // which of the two (bit-for-bit interchangeable) kernels: SFX_LBS_DENSE = 32 | 16 forces one (A/B measurements)
+    static const int force = [] { const char* e = getenv("SFX_LBS_DENSE"); return e ? atoi(e) : 0; }();
+    const bool use16 = force ? force == 16 : !(D.nact > 96 && D.nact <= 128);      // (measured, tools/bench_dense.py: the 32-frame form only wins at 97-128 frames)
+    if (use16) {
+        const int ny = (D.nact + FB3 - 1) / FB3, ntile = (M.V + VB - 1) / VB;
+        dim3 grid(8 * ((ntile + 7) / 8) * ny);
+        hipLaunchKernelGGL(k_lbs_dense16, grid, dim3(DT), 0, s, M, D);
+        return;
+    }
     const int ny = (D.nact + FB - 1) / FB, ntile = (M.V + VB - 1) / VB;
     dim3 grid(8 * ((ntile + 7) / 8) * ny);
     hipLaunchKernelGGL(k_lbs_dense, grid, dim3(DT), 0, s, M, D);

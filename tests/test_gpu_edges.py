@@ -15,10 +15,11 @@ def cfg_body():
     return H.load_cfg("fit_smplx_combined_coco25.yaml", use_hands=False, use_face=False)
 
 
-@pytest.mark.parametrize("B", [1, 33, 130])
+@pytest.mark.parametrize("B", [33, 100, 130, 250])
 def test_dense_path_is_batch_composition_independent(synth_model, cfg_body, B):
-    """Column position in the GEMM operands, frame-block split (1 / 2 blocks, partial slices) and
-    compaction must not change a frame's numbers: frame 2 alone == frame 2 as the LAST of B."""
+    """Column position in the GEMM operands, frame-block split (1 / 2 blocks, partial slices), compaction AND which of the
+    two dense kernels a batch size selects (k_lbs_dense16 for <= 64 and 129-192 active frames, k_lbs_dense otherwise: the fit
+    of a batch walks through both as frames finish) must not change a frame's numbers: frame 2 alone == frame 2 as the LAST of B."""
     cfg = dict(cfg_body); cfg["use_camera_prior"] = False
     dm = T._dm(synth_model, cfg)
     frames = T.synth_frames(synth_model, cfg, 3)
