@@ -16,7 +16,7 @@ records at the end of every step (RCCL over xGMI when N > 1).
 launcher's world size is N.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
-  roofline          the dense LBS GEMM (k_lbs_dense): algorithmic flops / HIP-event duration (MFMA bound)
+  roofline          the dense LBS GEMM (k_lbs_dense16): algorithmic flops / HIP-event duration (MFMA bound)
   roofline_tick     the per-frame loss / adjoint / L-BFGS kernel (k_tick_dense): algorithmic bytes / duration
   cpu_baseline      the oracle (port of the reference path) timed on ALL host cores: latency mode
                     (1 process x all threads) and throughput mode (one single-threaded process per core)
@@ -677,7 +677,7 @@ def main():
             fpl = u_dense / n_dense                       # mean frames per launch
             fl = u_dense * lbs_flops_per_frame(dm.V)
             by = n_dense * lbs_bytes_per_launch(0, dm.V) + u_dense * (lbs_bytes_per_launch(1, dm.V) - lbs_bytes_per_launch(0, dm.V))
-            out["roofline"] = {"kernel": "k_lbs_dense", "bound": "mfma", "achieved": fl / t_tot / 1e12,
+            out["roofline"] = {"kernel": "k_lbs_dense16", "bound": "mfma", "achieved": fl / t_tot / 1e12,
                                "peak": PEAK_MFMA_F32 / 1e12, "unit": "TFLOP/s", "frac": fl / t_tot / PEAK_MFMA_F32,
                                "traffic": None, "flops_per_launch": fl / n_dense, "bytes_per_launch": by / n_dense,
                                "hbm_GBps": by / t_tot / 1e9, "hbm_frac": by / t_tot / PEAK_HBM,
@@ -698,7 +698,7 @@ def main():
                 out["roofline"]["traffic_note"] = pmc_note
             if pmc_ok:     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/run_prof.sh)
                 pj = json.load(open(pmc))
-                k = pj.get("k_lbs_dense", {})
+                k = pj.get("k_lbs_dense16", {})
                 if "hbm_read_bytes_per_launch" in k and "hbm_write_bytes_per_launch" in k:
                     out["roofline"]["traffic"] = k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"]
                     out["roofline"]["traffic_detail"] = {
@@ -756,15 +756,17 @@ def main():
             E_, P_ = 10000.0, 8000.0        # typical of the synthetic surface mesh in these fits (engine.FrameBatch.penetration_stats)
             by_col = (12 * V_ + 12 * F_ + 4 * F_ + 2 * 24 * F_ + (8 + 8 + 36) * E_) + (2 * 8 * P_ + 72 * P_ + 2 * 40 * P_ + 40 * F_ + 12 * V_) + 2 * 12 * V_
             t_p = 1e-3 * ms_p
-            out["roofline_pen"] = {"kernels": "k_pen_grid, k_pen_walk, k_pen_list, k_pen_rank, k_pen_eval, k_pen_facesum, k_pen_gather, k_adj_prep, "
+            out["roofline_pen"] = {"kernels": "k_pen_want, k_pen_reset, k_pen_g1, k_pen_g2, k_pen_g3, k_pen_walk, k_pen_list, k_pen_rank, k_pen_eval, k_pen_facesum, k_pen_gather, k_adj_prep, "
                                               "k_lbs_dense_adj, k_adj_reduce, k_adj_dA (one HIP-event scope per round)",
                                    "bound": "hbm", "achieved": by_col * u_p / t_p / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                                    "frac": by_col * u_p / t_p / PEAK_HBM, "traffic": None, "bytes_per_column_launch": by_col,
                                    "avg_scope_us": 1e6 * t_p / n_p, "launches": n_p, "columns_per_launch": u_p / n_p,
                                    "share_of_step": ms_p * args.prof_every / (1e3 * dt),
-                                   "note": "latency-bound: eleven dependent kernels per round whose per-frame chains (counting sort of one "
-                                           "frame's triangles by one 1024-lane workgroup, bucket walks, list ranking) expose little "
-                                           "parallelism per frame; per-kernel times and counters: profiles/r03_pen_*"}
+                                   "bytes_per_launch": by_col * u_p / n_p,
+                                   "note": "latency- and issue-bound: fifteen dependent kernels per round whose per-frame chains (counting sort "
+                                           "of one frame's grid entries by one 1024-lane workgroup in k_pen_g3, bucket walks at ~70 VALU "
+                                           "instructions per candidate, list ranking) expose little parallelism per frame; per-kernel "
+                                           "times and counters: profiles/r03_pen_*"}
             pmc_ok, pmc_note = pmc_is_current(os.path.join(ROOT, "profiles", "pmc_summary_pen.json"))
             if pmc_ok:
                 pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary_pen.json")))

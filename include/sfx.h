@@ -282,6 +282,11 @@ void sfx_prof_reset(void);
 /* Debug: shader-clock stamps at the phase boundaries of one closure launch (block 0). */
 int  sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out /* [32] */);
 
+/* Debug / A-B measurements: which dense LBS kernel the rounds launch -- 16 = k_lbs_dense16 (16 frames per wavefront: the
+ * product kernel), 32 = k_lbs_dense (32 frames per wavefront; the same chain of fp32 operations per vertex and frame, so
+ * the same bits).  Process-wide; any other value only queries.  Returns the previous setting.                          */
+int  sfx_debug_lbs_dense_form(int32_t form);
+
 /* Experiment (timing only): `rounds` rounds of the dense loop; mode 0 serial (GEMM -> tick), mode 1 GEMM and tick of a
  * round launched together on two streams.  out_ms = elapsed time.  The batch's results are meaningless afterwards.     */
 int  sfx_debug_overlap_test(sfx_batch* b, int32_t rounds, int32_t mode, double* out_ms);

@@ -852,6 +852,12 @@ extern "C" int sfx_debug_two_loop(const float* S, const float* Y, int32_t count,
 // Experiment (timing only, results are not meaningful): `rounds` rounds of the dense fit loop with the GEMM on a second
 // stream.  mode 0: serial as in sfx_batch_fit (GEMM -> tick); mode 1: GEMM(i) and tick(i) launched together (what a loop
 // whose loss pass does not wait for the GEMM would cost); out_ms = elapsed wall time of the rounds.
+extern "C" int sfx_debug_lbs_dense_form(int32_t form) {
+    const int prev = g_lbs_dense_form;
+    if (form == 16 || form == 32) g_lbs_dense_form = form;
+    return prev;
+}
+
 extern "C" int sfx_debug_overlap_test(sfx_batch* b, int32_t rounds, int32_t mode, double* out_ms) {
     if (!b || b->D.cfg.lbs_mode != 1) { sfx_set_error("dense batch needed"); return -1; }
     BatchDev& D = b->D; const DevModel& M = b->m->M;

@@ -430,6 +430,8 @@ void k_lbs_dense32(DevModel M, BatchDev D) {
 }
 #endif
 
+int g_lbs_dense_form = [] { const char* e = getenv("SFX_LBS_DENSE"); return e ? atoi(e) : 16; }();
+
 void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s) {
     if (D.nact <= 0) return;
 #ifdef MF32
@@ -440,9 +442,10 @@ void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s) {
         return;
     }
 #endif
-    // which of the two (bit-for-bit interchangeable) kernels: SFX_LBS_DENSE = 32 | 16 forces one (A/B measurements)
-    static const int force = [] { const char* e = getenv("SFX_LBS_DENSE"); return e ? atoi(e) : 0; }();
-    const bool use16 = force ? force == 16 : !(D.nact > 96 && D.nact <= 128);      // (measured, tools/bench_dense.py: the 32-frame form only wins at 97-128 frames)
+    // k_lbs_dense16 is the product kernel; k_lbs_dense (32 frames per wavefront, bit-for-bit the same results, within 2 % at
+    // 97-128 active frames and slower everywhere else: tools/bench_dense.py) stays for A/B measurements and the
+    // interchangeability test: SFX_LBS_DENSE=32 in the environment or sfx_debug_lbs_dense_form(32).
+    const bool use16 = g_lbs_dense_form != 32;
     if (use16) {
         const int ny = (D.nact + FB3 - 1) / FB3, ntile = (M.V + VB - 1) / VB;
         dim3 grid(8 * ((ntile + 7) / 8) * ny);

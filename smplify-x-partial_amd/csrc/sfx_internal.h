@@ -263,6 +263,7 @@ void launch_closure(const DevModel& M, const BatchDev& D, const VarList* vl_dev,
 void launch_pen_adjoint(const DevModel& M, const BatchDev& D, hipStream_t s);
 int sfx_adj_slices(const DevModel& M);
 void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s);
+extern int g_lbs_dense_form;          // 16 (k_lbs_dense16, default) | 32 (k_lbs_dense)
 void launch_lbfgs_tick(const DevModel& M, const BatchDev& D, const VarList* vl_dev, int first_stage,
                        int last_stage, int init, int step_mode, hipStream_t s);
 size_t sfx_optstate_size();

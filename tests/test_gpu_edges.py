@@ -17,9 +17,8 @@ def cfg_body():
 
 @pytest.mark.parametrize("B", [33, 100, 130, 250])
 def test_dense_path_is_batch_composition_independent(synth_model, cfg_body, B):
-    """Column position in the GEMM operands, frame-block split (1 / 2 blocks, partial slices), compaction AND which of the
-    two dense kernels a batch size selects (k_lbs_dense16 for <= 64 and 129-192 active frames, k_lbs_dense otherwise: the fit
-    of a batch walks through both as frames finish) must not change a frame's numbers: frame 2 alone == frame 2 as the LAST of B."""
+    """Column position in the GEMM operands, frame-block split (1 .. 4 blocks of 64 frames, partial slices) and compaction
+    must not change a frame's numbers: frame 2 alone == frame 2 as the LAST of B."""
     cfg = dict(cfg_body); cfg["use_camera_prior"] = False
     dm = T._dm(synth_model, cfg)
     frames = T.synth_frames(synth_model, cfg, 3)
@@ -36,6 +35,38 @@ def test_dense_path_is_batch_composition_independent(synth_model, cfg_body, B):
     for k in out[0][2]:
         assert np.array_equal(out[0][2][k], out[1][2][k]), k
     assert np.array_equal(out[0][3]["stage_evals"][-1], out[1][3]["stage_evals"][-1])
+
+
+def test_the_two_dense_kernels_are_interchangeable_bit_for_bit(synth_model, cfg_body):
+    """k_lbs_dense16 (16 frames per wavefront, the product kernel) and k_lbs_dense (32 per wavefront, kept for A/B
+    measurements) put every (vertex, frame) through the same chain of fp32 operations: all vertices of a 100-frame launch
+    and a whole two-stage fit must agree bit for bit."""
+    from smplifyx_amd import _capi
+    lib = _capi.load()
+    cfg = dict(cfg_body); cfg["use_camera_prior"] = False
+    dm = T._dm(synth_model, cfg)
+    frames = T.synth_frames(synth_model, cfg, 3)
+    idx = [i % 3 for i in range(100)]
+    out = []
+    prev = lib.sfx_debug_lbs_dense_form(0)
+    try:
+        for form in (16, 32):
+            lib.sfx_debug_lbs_dense_form(form)
+            assert lib.sfx_debug_lbs_dense_form(0) == form
+            fb = H.engine_batch_from_frames(dm, cfg, frames, idx, lbs_mode="dense", reuse=True)
+            fb.guess_init(cfg["body_tri_idxs"])
+            l, g = fb.closure(0)
+            verts = fb.debug_read("verts").copy()
+            fb.fit(first_stage=-1, last_stage=1)
+            out.append((l.copy(), g.copy(), verts, {k: v.copy() for k, v in fb.get_params().items()}, fb.stats()["stage_evals"].copy()))
+            fb.close()
+    finally:
+        lib.sfx_debug_lbs_dense_form(prev)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert np.abs(out[0][2]).max() > 0.1
+    for k in out[0][3]:
+        assert np.array_equal(out[0][3][k], out[1][3][k]), k
+    assert np.array_equal(out[0][4], out[1][4])
 
 
 def test_dense_and_rows_agree_per_closure(synth_model, cfg_body):
@@ -182,7 +213,7 @@ def test_bench_line_contract(workload):
     assert d["unit"] == "frames/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
-    assert r["kernel"] == "k_lbs_dense" and r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["kernel"] == "k_lbs_dense16" and r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert np.isfinite(d["config"]["final_loss_mean"])
     if workload == "body":
         rp = d["reference_parity"]
