@@ -52,9 +52,13 @@
                                 // 418 on the synthetic surface).  A diverged fit folds the mesh into a few cells of 10^4 entries; walking
                                 // them out took 7-8 ms per evaluation and held up the whole batch (3 % of the launches of a 256-frame fit,
                                 // half of this kernel's total time).  The reference's BVH bounds a query by max_collisions hits instead.
-#define PEN_WALK_BLOCKS 32      // workgroups (of 4 wavefronts) per frame of the pair tests: a frame whose limbs are pushed
+#ifndef PEN_WALK_BLOCKS
+#define PEN_WALK_BLOCKS 128     // workgroups (of 4 wavefronts) per frame of the pair tests: a frame whose limbs are pushed
                                 // through each other has 100x the candidates of a clean one, and must not hold up the launch
-#define PEN_EVAL_BLOCKS 32      // workgroups per frame of the pair evaluation (grid-stride over the pair list)
+#endif
+#ifndef PEN_EVAL_BLOCKS
+#define PEN_EVAL_BLOCKS 128     // workgroups per frame of the pair evaluation (grid-stride over the pair list)
+#endif
 #define PEN_CELLS 16384         // hash buckets of the grid: one 64-KB LDS array serves as histogram, start offsets and
                                 // scatter cursors (+ 48 KB of wavefront tiles, 16 KB of pair queues)
 
@@ -64,12 +68,12 @@ struct PenDev {
     const int* faces;          // [F][3]
     const int* segm;           // [F]
     const unsigned char* skip; // [n_parts][n_parts] 1 = pair of parts never collides
+    const unsigned long long* skipmask;   // [64] the same table as one 64-bit word per part (bit q: never collides with part q)
     const int* vf_start;       // [V+1] CSR: incident (face * 3 + corner)
     const int* vf_list;
     // per batch (capacity Bmax)
     float* aabb;               // [B][F][6]
-    int* entries;              // [B][ent_cap] triangle | part << 24, sorted by bucket
-    int* ent_cell;             // [B][ent_cap] packed cell coordinates the entry was made for
+    int2* entries;             // [B][ent_cap] (triangle | part << 24, packed cell coordinates the entry was made for), sorted by bucket
     int2* tcell;               // [B][F] per triangle: packed cell range + part + alive bit (k_pen_g2 -> g3 / g5)
     int* pbox;                 // [B][64][6] bounding box of every part, order-preserving ints (k_pen_g1; reset per evaluation)
     float* gpart;              // [B][PEN_GW][8] per workgroup of k_pen_g1: frame box lo / hi, extent sum
@@ -316,7 +320,7 @@ void k_pen_g2(PenDev P, const int* __restrict__ want) {
     if (w == 0 && t == 0) { float* gp = P.gridp + b * 4; gp[0] = C.glo[0]; gp[1] = C.glo[1]; gp[2] = C.glo[2]; gp[3] = C.ih; }
     if (t < 64) {
         unsigned long long m = 0;
-        if (t < P.n_parts) for (int q = 0; q < P.n_parts; ++q) m |= (unsigned long long)(P.skip[(size_t)t * P.n_parts + q] != 0) << q;
+        m = P.skipmask[t];
         s_mask[t] = m;
         for (int e = 0; e < 6; ++e) s_pbox[t][e] = P.pbox[((size_t)b * 64 + t) * 6 + e];
     }
@@ -391,7 +395,7 @@ __device__ __forceinline__ void pen_coll32(const PenDev& P, unsigned* s_coll32) 
     const int t = threadIdx.x;
     if (t < 64) {
         unsigned m = 0;
-        if (t < P.n_parts) for (int q = 0; q < P.n_parts; ++q) if (!P.skip[(size_t)t * P.n_parts + q]) m |= 1u << (q & 31);
+        if (t < P.n_parts) { const unsigned long long c = ~P.skipmask[t] & (P.n_parts >= 64 ? ~0ull : (1ull << P.n_parts) - 1ull); m = (unsigned)c | (unsigned)(c >> 32); }
         s_coll32[t] = m;
     }
     __syncthreads();
@@ -416,9 +420,17 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     const int F = P.F;
     const int2* tcell = P.tcell + (size_t)b * F;
     unsigned* pmask = reinterpret_cast<unsigned*>(cell_cnt + PEN_GRID_INTS);
+#ifdef PEN_COUNT    // diagnostic build: shader clocks at the phase boundaries -> stats[24..30] (cycles per phase, thread 0)
+    long long g3c[8]; int g3n = 0;
+#define G3MARK() do { g3c[g3n++] = clock64(); } while (0)
+#else
+#define G3MARK() do { } while (0)
+#endif
+    G3MARK();
     for (int c = t; c <= PEN_CELLS; c += PEN_T) cell_cnt[c] = 0;
     for (int c = t; c < PEN_CELLS; c += PEN_T) pmask[c] = 0u;
     pen_coll32(P, s_coll32);                    // (ends with a barrier)
+    G3MARK();
     constexpr int U2 = 7;
     // which parts are present in each bucket (folded to 32 bits)
     for (int f0 = t; f0 < F; f0 += PEN_T * U2) {
@@ -433,6 +445,7 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
         }
     }
     __syncthreads();
+    G3MARK();
     // histogram
     for (int f0 = t; f0 < F; f0 += PEN_T * U2) {
         int2 pk[U2];
@@ -446,19 +459,36 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
         }
     }
     __syncthreads();
+    G3MARK();
     {   // exclusive scan over the buckets: each lane owns a contiguous slice
+        // (wavefront w owns buckets [w * 1024, (w + 1) * 1024) in 16 rows of 64: lane l reads bucket row * 64 + l -- conflict-free;
+        //  a lane that owned 16 CONSECUTIVE buckets read them at a stride of 16 words, a 16-way bank conflict on every access:
+        //  26 k of this kernel's 180 k cycles)
         constexpr int per = PEN_CELLS / PEN_T;
-        const int c0 = t * per;
-        int sm = 0;
-        for (int c = c0; c < c0 + per; ++c) sm += cell_cnt[c];
-        int tot;
-        int acc = block_excl_scan(sm, slice, &tot);
-        for (int c = c0; c < c0 + per; ++c) { const int v = cell_cnt[c]; cell_cnt[c] = acc; acc += v; }
+        static_assert(PEN_CELLS == PEN_T * per && PEN_T / 64 * 64 * per == PEN_CELLS, "scan layout");
+        const int lane = t & 63, wv = t >> 6;
+        int* row0 = cell_cnt + wv * (64 * per) + lane;
+        int ex[per], carry = 0;
+#pragma unroll
+        for (int i = 0; i < per; ++i) {
+            const int v = row0[i * 64];
+            int inc = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+            ex[i] = carry + inc - v;
+            carry += __shfl(inc, 63);
+        }
+        if (lane == 0) slice[wv] = carry;
+        __syncthreads();
+        int base = 0, tot = 0;
+        for (int i = 0; i < PEN_T / 64; ++i) { const int x = slice[i]; if (i < wv) base += x; tot += x; }
+#pragma unroll
+        for (int i = 0; i < per; ++i) row0[i * 64] = base + ex[i];
         if (t == 0) { cell_cnt[PEN_CELLS] = tot; s_total = tot; }
         __syncthreads();
     }
-    int* ent = P.entries + (size_t)b * P.ent_cap;
-    int* entc = P.ent_cell + (size_t)b * P.ent_cap;
+    G3MARK();
+    int2* ent = P.entries + (size_t)b * P.ent_cap;
     const bool ent_ok = s_total <= P.ent_cap - 4;
     if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = PEN_CELLS; st[13] = 0; st[14] = s_total; st[15] = 0; for (int q = 4; q < 13; ++q) st[q] = 0;
                   for (int q = 16; q < PEN_STATS; ++q) st[q] = 0; }
@@ -480,14 +510,19 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
             pen_for_cells(pk[u], [&](int bk, int key) {
                 if (!(pmask[bk] & want32)) return;
                 const int q = atomicAdd(&cell_cnt[bk], 1);
-                ent[q] = f | (pf << 24);            // triangle | part << 24
-                entc[q] = key;
+                ent[q] = make_int2(f | (pf << 24), key);            // (triangle | part << 24, cell): one 8-byte store
             });
         }
     }
     __threadfence_block();
     __syncthreads();
+    G3MARK();
     for (int c = t; c <= PEN_CELLS; c += PEN_T) cells[c] = cell_cnt[c];
+    G3MARK();
+#ifdef PEN_COUNT
+    if (t == 0) for (int q = 1; q < g3n; ++q) st[23 + q] = (int)(g3c[q] - g3c[q - 1]);      // [24] init, [25] part masks, [26] histogram, [27] scan, [28] scatter, [29] copy
+#endif
+#undef G3MARK
 }
 
 
@@ -503,11 +538,10 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
     if ((want && !want[b]) || blockIdx.x * 256 >= s_total) return;
     const int F = P.F;
     const float* aabb = P.aabb + (size_t)b * F * 6;
-    const int* ent = P.entries + (size_t)b * P.ent_cap;
-    const int* entc = P.ent_cell + (size_t)b * P.ent_cap;
+    const int2* ent = P.entries + (size_t)b * P.ent_cap;
     if (t < 64) {
         unsigned long long m = 0;
-        if (t < P.n_parts) for (int q = 0; q < P.n_parts; ++q) m |= (unsigned long long)(P.skip[(size_t)t * P.n_parts + q] != 0) << q;
+        m = P.skipmask[t];
         s_mask[t] = m;
     }
     __syncthreads();
@@ -532,7 +566,8 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
     //  entries: that chain, not the pair tests, was most of this kernel's time)
     auto load_hdr = [&](int q, bool ok, int (&hd)[12]) {
         const int qs = ok ? q : 0;
-        const int e0 = ent[qs], e1 = entc[qs];
+        const int2 e01 = ent[qs];
+        const int e0 = e01.x, e1 = e01.y;
         const int f = e0 & 0xffffff;
         int bx[6], vd[3];
 #pragma unroll
@@ -698,7 +733,9 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
 }
 
 // ranks every triangle's partner list into the frame's pair list; PEN_RANK_BLOCKS workgroups per frame
-#define PEN_RANK_BLOCKS 16
+#ifndef PEN_RANK_BLOCKS
+#define PEN_RANK_BLOCKS 64
+#endif
 #define PEN_SHORT 16            // lists up to this length are ranked element-wise, longer ones sorted by a wavefront
 __global__ __launch_bounds__(256)
 void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
@@ -718,9 +755,10 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
     // lanes (owner found by bisection of the 64 offsets in LDS), each lane ranks its element within its
     // list.  Long lists: bitonic sort by the whole wavefront in LDS.
     const int nw = gridDim.x * 4, gw = blockIdx.x * 4 + wv;
-    const int fper = (((F + nw - 1) / nw + 63) / 64) * 64;
-    const int flim = min(F, (gw + 1) * fper);
-    for (int fw = gw * fper; fw < flim; fw += 64) {
+    // (blocks of 64 triangles dealt round-robin to the frame's wavefronts: crowded triangles are neighbours in the index too,
+    //  a contiguous range per wavefront gave one wavefront all the long lists)
+    const int flim = F;
+    for (int fw = gw * 64; fw < flim; fw += nw * 64) {
         const int f = fw + lane;
         const bool inr = f < flim;
         const int fs = inr ? f : 0;                    // (unconditional loads from a clamped index: three loads in flight, not three round trips)
@@ -1023,10 +1061,13 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     }
     for (int v = 0; v < V; ++v) vs[v + 1] += vs[v];
     { std::vector<int> cur(vs.begin(), vs.end() - 1); for (size_t i = 0; i < fv.size(); ++i) vl[cur[fv[i]]++] = (int)i; }
+    std::vector<unsigned long long> skm(64, 0ull);
+    for (int a = 0; a < np; ++a) for (int b2 = 0; b2 < np; ++b2) if (skip[(size_t)a * np + b2]) skm[a] |= 1ull << b2;
+    P.skipmask = h->up(skm);
     P.faces = h->up(fv); P.segm = h->up(sg); P.skip = h->up(skip); P.vf_start = h->up(vs); P.vf_list = h->up(vl);
     const size_t B = max_batch;
     P.ent_cap = F * 32;
-    P.aabb = h->zeros<float>(B * F * 6); P.entries = h->zeros<int>(B * P.ent_cap); P.ent_cell = h->zeros<int>(B * P.ent_cap);
+    P.aabb = h->zeros<float>(B * F * 6); P.entries = h->zeros<int2>(B * P.ent_cap);
     P.tcell = h->zeros<int2>(B * F);
     P.pbox = h->zeros<int>(B * 64 * 6); P.gpart = h->zeros<float>(B * PEN_GW * 8);
     P.partners = h->zeros<int>(B * F * P.pcap); P.pcount = h->zeros<int>(B * F); P.pavail = h->zeros<int>(B * F);
@@ -1036,7 +1077,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     P.pout = h->zeros<float>(B * 10 * P.pair_cap); P.ptotal = h->zeros<int>(B); P.stats = h->zeros<int>(B * PEN_STATS);
     P.cells = h->zeros<int>(B * (PEN_CELLS + 1)); P.gridp = h->zeros<float>(B * 4);
     P.tgrad = h->zeros<float>(B * F * 9); P.tloss = h->zeros<float>(B * F);
-    if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tcell || !P.pbox || !P.gpart || !P.aabb || !P.entries || !P.ent_cell) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
+    if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tcell || !P.pbox || !P.gpart || !P.aabb || !P.entries) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.pavail || !P.ptotal) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     *out = h;
     return 0;
@@ -1102,6 +1143,10 @@ extern "C" int sfx_pen_phase_clocks(sfx_pen* h, int32_t B, int32_t* out) {
             const long v[6] = {r[14], r[16], r[17], r[18], r[19], r[20]};
             for (int q = 0; q < 6; ++q) { tot[q] += v[q]; mx[q] = std::max(mx[q], v[q]); }
         }
+        long ph[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < B; ++i) for (int q = 0; q < 6; ++q) ph[q] += st[(size_t)i * PEN_STATS + 24 + q];
+        fprintf(stderr, "[pen count] k_pen_g3 mean shader cycles per phase: init %ld, part masks %ld, histogram %ld, scan %ld, scatter %ld, copy %ld\n",
+                ph[0] / B, ph[1] / B, ph[2] / B, ph[3] / B, ph[4] / B, ph[5] / B);
         fprintf(stderr, "[pen count] %d frames, mean / max per frame: entries %ld / %ld; walked %ld / %ld, same cell %ld / %ld, part mask passed %ld / %ld, "
                 "boxes overlap %ld / %ld; wavefront steps %ld / %ld\n", B, tot[0] / B, mx[0], tot[1] / B, mx[1], tot[2] / B, mx[2], tot[3] / B, mx[3],
                 tot[4] / B, mx[4], tot[5] / B, mx[5]);

@@ -30,3 +30,6 @@ print('  loss sub marks 20..23:', rel(o[20:24]), ' chain 27,28:', rel(o[27:29]))
 print('  next-pose marks 0..5:', rel(o[0:6]), 'export 17..19', rel(o[17:20]))
 print('  mean per workgroup: loss+adjoint %.1f us, tick %.1f us, rest %.1f us; wg duration max %.1f mean %.1f us over %d' % (
     o[29] * 0.01 / max(o[60], 1), o[30] * 0.01 / max(o[60], 1), (o[59] - o[29] - o[30]) * 0.01 / max(o[60], 1), o[58] * 0.01, o[59] * 0.01 / max(o[60], 1), o[60]))
+nt = max(o[63], 1)
+print('  optimiser tick of frame 0, mean cycles between marks over %d ticks: fetch %.0f  consume %.0f  line-search end + iteration head + pair push %.0f  two-loop %.0f  rest-of-machine %.0f  write-back %.0f' % (
+    nt, o[33] / nt, o[34] / nt, o[35] / nt, o[37] / nt, o[38] / nt, o[39] / nt))

@@ -19,5 +19,6 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tm
 timeout 600 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d /tmp/pmc_c -o p -- $PM > /dev/null 2> $O/pmc_c.log
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_s -o p -- $PM > /dev/null 2> $O/pmc_s.log
 python tools/pmc_summary.py $O/pmc_summary.json /tmp/pmc_f /tmp/pmc_w /tmp/pmc_c /tmp/pmc_s > $O/pmc_brief.json
-rm -f $O/*/p_kernel_trace.csv $O/*/*.db
+for f in $(find $O/kt -name "*kernel_trace.csv"); do python tools/kt_percentiles.py $f > $O/kernel_percentiles.txt; done
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
 tail -c 400 $O/kt.log; head -12 $O/kt/p_kernel_stats.csv; tail -2 $O/pmc_c.log; cat $O/pmc_brief.json | head -c 3000
