@@ -68,6 +68,7 @@ struct PenDev {
     const int* faces;          // [F][3]
     const int* segm;           // [F]
     const unsigned char* skip; // [n_parts][n_parts] 1 = pair of parts never collides
+    const int4* faces4;        // [F] the faces padded to 16-byte rows (one load per header in the pair tests)
     const unsigned long long* skipmask;   // [64] the same table as one 64-bit word per part (bit q: never collides with part q)
     const int* vf_start;       // [V+1] CSR: incident (face * 3 + corner)
     const int* vf_list;
@@ -568,18 +569,26 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
         const int qs = ok ? q : 0;
         const int2 e01 = ent[qs];
         const int e0 = e01.x, e1 = e01.y;
-        const int f = e0 & 0xffffff;
+        // (the mask goes through inline assembly: from `e0 & 0xffffff` the compiler forms a 24-bit multiply -- which masks
+        //  implicitly -- and, once the wide loads below make the row address 64-bit, turns it into v_mad_u64_u32 on the UNMASKED
+        //  word: rows 2^24 x part id beyond the array, a memory fault with ROCm 7.2's compiler)
+        int f;
+        asm("v_and_b32 %0, 0xffffff, %1" : "=v"(f) : "v"(e0));
         int bx[6], vd[3];
-#pragma unroll
-        for (int e = 0; e < 6; ++e) bx[e] = __float_as_int(aabb[f * 6 + e]);
-#pragma unroll
-        for (int e = 0; e < 3; ++e) vd[e] = P.faces[f * 3 + e];
+        {   // four gathers per header: the box as three 8-byte loads (rows of 24 bytes), the vertex ids as one 16-byte row
+            const int2* bp = reinterpret_cast<const int2*>(aabb) + (size_t)f * 3;
+            const int2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
+            bx[0] = b0.x; bx[1] = b0.y; bx[2] = b1.x; bx[3] = b1.y; bx[4] = b2.x; bx[5] = b2.y;
+            const int4 fv4 = P.faces4[f];
+            vd[0] = fv4.x; vd[1] = fv4.y; vd[2] = fv4.z;
+        }
         hd[0] = ok ? e0 : 0; hd[1] = ok ? e1 : -1;
 #pragma unroll
         for (int e = 0; e < 6; ++e) hd[2 + e] = ok ? bx[e] : 0;
 #pragma unroll
         for (int e = 0; e < 3; ++e) hd[8 + e] = ok ? vd[e] : -1 - e;
-        hd[11] = 0;
+        // the cell of the box's low corner (wrapped like the entries' keys): the ownership test below works on these
+        hd[11] = cell_key(cell_of(__int_as_float(bx[0]), 0), cell_of(__int_as_float(bx[1]), 1), cell_of(__int_as_float(bx[2]), 2));
     };
     // (blocks of 64 entries, NOT whole buckets: a crowded bucket is shared by many wavefronts; the
     // cell key comparison keeps different cells of one bucket apart)
@@ -619,7 +628,14 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
         const int bend_max = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)bend));      // entries < 2^24: exact
         tA[lane] = make_int4(hi_[0], hi_[1], hi_[2], hi_[3]);
         tB[lane] = make_int4(hi_[4], hi_[5], hi_[6], hi_[7]);
-        tC[lane] = make_int4(hi_[8], hi_[9], hi_[10], 0);
+        tC[lane] = make_int4(hi_[8], hi_[9], hi_[10], hi_[11]);
+        // Ownership: a pair is accepted in the cell that holds the low corner of the boxes' intersection.  Both triangles are
+        // entered in THIS cell, so on every axis the cells of both low corners are <= this cell's coordinate, and (the cell
+        // function is monotone) cell(max(a, k)) == c  <=>  cell(a) == c or cell(k) == c.  own_m has an axis' 10 key bits SET
+        // where this lane's own low corner is NOT in cell c: there the partner's must be -- ((kcell ^ ck) & own_m) == 0.
+        // (two AND / compare instructions per candidate instead of three cell computations under a branch nearly every step takes)
+        const int own_x = hi_[11] ^ ck;
+        const int own_m = ((own_x & 0x3ff) ? 0x3ff : 0) | ((own_x & 0xffc00) ? 0xffc00 : 0) | ((own_x & 0x3ff00000) ? 0x3ff00000 : 0);
         int staged = 64;                               // entries i0 .. i0 + staged - 1 are (or were) in the window
         for (int d = 1; ; ++d) {
             const int k = qi + d;
@@ -636,7 +652,7 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
                 const int sl = (staged + lane) & 127;
                 tA[sl] = make_int4(hn[0], hn[1], hn[2], hn[3]);
                 tB[sl] = make_int4(hn[4], hn[5], hn[6], hn[7]);
-                tC[sl] = make_int4(hn[8], hn[9], hn[10], 0);
+                tC[sl] = make_int4(hn[8], hn[9], hn[10], hn[11]);
                 staged += 64;
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();     // (d = 1 always refills: covers the first half too)
             }
@@ -656,10 +672,10 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
             }
 #endif
             pass = pass && ai[0] <= kh0 && kl0 <= ai[3] && ai[1] <= kh1 && kl1 <= ai[4] && ai[2] <= kh2 && kl2 <= ai[5];
+            pass = pass && ((h2.w ^ ck) & own_m) == 0;
             if (pass) {
-                pass = cell_key(cell_of(fmaxf(ai[0], kl0), 0), cell_of(fmaxf(ai[1], kl1), 1), cell_of(fmaxf(ai[2], kl2), 2)) == ck;
                 const int g0 = h2.x, g1 = h2.y, g2 = h2.z;
-                pass = pass && !(g0 == hi_[8] || g0 == hi_[9] || g0 == hi_[10] || g1 == hi_[8] || g1 == hi_[9] || g1 == hi_[10] ||
+                pass = !(g0 == hi_[8] || g0 == hi_[9] || g0 == hi_[10] || g1 == hi_[8] || g1 == hi_[9] || g1 == hi_[10] ||
                                  g2 == hi_[8] || g2 == hi_[9] || g2 == hi_[10]);
             }
             // accepted pairs go to a wavefront-private queue and are appended to the partner lists
@@ -1064,6 +1080,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     std::vector<unsigned long long> skm(64, 0ull);
     for (int a = 0; a < np; ++a) for (int b2 = 0; b2 < np; ++b2) if (skip[(size_t)a * np + b2]) skm[a] |= 1ull << b2;
     P.skipmask = h->up(skm);
+    { std::vector<int4> f4(F); for (int f = 0; f < F; ++f) f4[f] = make_int4(fv[(size_t)f * 3], fv[(size_t)f * 3 + 1], fv[(size_t)f * 3 + 2], 0); P.faces4 = h->up(f4); }
     P.faces = h->up(fv); P.segm = h->up(sg); P.skip = h->up(skip); P.vf_start = h->up(vs); P.vf_list = h->up(vl);
     const size_t B = max_batch;
     P.ent_cap = F * 32;
