@@ -75,7 +75,8 @@ struct PenDev {
     // per batch (capacity Bmax)
     float* aabb;               // [B][F][6]
     int2* entries;             // [B][ent_cap] (triangle | part << 24, packed cell coordinates the entry was made for), sorted by bucket
-    int2* tcell;               // [B][F] per triangle: packed cell range + part + alive bit (k_pen_g2 -> g3 / g5)
+    int4* tlist;               // [B][F] the triangles that survive the part culling, compacted (any order): packed cell range, spans + part, triangle
+    int* tcount;               // [B][16] (one cache line each) number of survivors (k_pen_reset -> 0, k_pen_g2 reserves ranges)
     int* pbox;                 // [B][64][6] bounding box of every part, order-preserving ints (k_pen_g1; reset per evaluation)
     float* gpart;              // [B][PEN_GW][8] per workgroup of k_pen_g1: frame box lo / hi, extent sum
     int ent_cap;
@@ -219,6 +220,7 @@ void k_pen_reset(PenDev P, const int* __restrict__ want) {
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (want && !want[b]) return;
     if (i < 64 * 6) P.pbox[(size_t)b * 64 * 6 + i] = (i % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+    if (i == 0) P.tcount[b * 16] = 0;
 }
 
 __global__ __launch_bounds__(PEN_T)
@@ -312,11 +314,12 @@ __global__ __launch_bounds__(PEN_T)
 void k_pen_g2(PenDev P, const int* __restrict__ want) {
     __shared__ unsigned long long s_mask[64], s_near[64];
     __shared__ int s_pbox[64][6];
-    const int b = blockIdx.y, t = threadIdx.x, w = blockIdx.x;
+    __shared__ int s_cnt, s_base;
+    const int b = blockIdx.y, t = threadIdx.x, w = blockIdx.x, lane = t & 63;
     if (want && !want[b]) return;
     const int F = P.F;
     const float* aabb = P.aabb + (size_t)b * F * 6;
-    int2* tcell = P.tcell + (size_t)b * F;
+    int4* tlist = P.tlist + (size_t)b * F;
     const PenGridCtx C = pen_grid_ctx(P, b);
     if (w == 0 && t == 0) { float* gp = P.gridp + b * 4; gp[0] = C.glo[0]; gp[1] = C.glo[1]; gp[2] = C.glo[2]; gp[3] = C.ih; }
     if (t < 64) {
@@ -341,7 +344,12 @@ void k_pen_g2(PenDev P, const int* __restrict__ want) {
     __syncthreads();
     // part culling (a triangle whose box meets the box of no part it may collide with cannot have a partner and never
     // enters the grid), packed cell range of the survivors, part masks of the buckets (folded to 32 bits)
-    for (int f0 = w * PEN_T + t; f0 < F; f0 += PEN_GW * PEN_T * PEN_GU) {
+    // The survivors are COMPACTED into the frame's list (k_pen_g3 makes three passes over them and a wavefront's pass lasts as
+    // long as its widest triangle: dead lanes between live ones cost as much as live ones): a wavefront reserves its share of
+    // the workgroup's range with one LDS atomic per batch, the workgroup its range of the frame's list with one global atomic.
+    // The order of the list is immaterial (the buckets are filled through atomics anyway; the pair set does not depend on it).
+    for (int fb = 0; fb < F; fb += PEN_GW * PEN_T * PEN_GU) {        // (uniform trip count: barriers inside)
+        const int f0 = fb + w * PEN_T + t;
         float bx[PEN_GU][6]; int seg[PEN_GU];
 #pragma unroll
         for (int u = 0; u < PEN_GU; ++u) {
@@ -350,12 +358,14 @@ void k_pen_g2(PenDev P, const int* __restrict__ want) {
 #pragma unroll
             for (int e = 0; e < 6; ++e) bx[u][e] = aabb[ff * 6 + e];
         }
+        if (t == 0) s_cnt = 0;
+        __syncthreads();
+        int2 pk[PEN_GU]; int off[PEN_GU];
 #pragma unroll
         for (int u = 0; u < PEN_GU; ++u) {
             const int f = f0 + u * PEN_GW * PEN_T;
-            if (f >= F) continue;
-            unsigned long long nm = s_near[seg[u]];
             bool any = false;
+            unsigned long long nm = f < F ? s_near[seg[u]] : 0ull;
             if (nm) {
                 int a6[6];
 #pragma unroll
@@ -367,16 +377,27 @@ void k_pen_g2(PenDev P, const int* __restrict__ want) {
                           a6[2] <= s_pbox[q][5] && s_pbox[q][2] <= a6[5];
                 }
             }
-            int2 pk = make_int2(0, 0);
+            pk[u] = make_int2(0, 0);
             if (any) {
                 int c0[3], sp[3];
 #pragma unroll
                 for (int e = 0; e < 3; ++e) { c0[e] = pen_cell_of(C, bx[u][e], e); sp[e] = min(pen_cell_of(C, bx[u][3 + e], e), c0[e] + PEN_SPAN - 1) - c0[e]; }
-                pk.x = (c0[0] & 1023) | ((c0[1] & 1023) << 10) | ((c0[2] & 1023) << 20) | (int)0x80000000;
-                pk.y = sp[0] | (sp[1] << 3) | (sp[2] << 6) | (seg[u] << 9);
+                pk[u].x = (c0[0] & 1023) | ((c0[1] & 1023) << 10) | ((c0[2] & 1023) << 20) | (int)0x80000000;
+                pk[u].y = sp[0] | (sp[1] << 3) | (sp[2] << 6) | (seg[u] << 9);
             }
-            tcell[f] = pk;
+            const unsigned long long m = __ballot(any);
+            int wo = 0;
+            if (lane == 0 && m) wo = atomicAdd(&s_cnt, __popcll(m));
+            off[u] = __builtin_amdgcn_readfirstlane(wo) + __popcll(m & ((1ull << lane) - 1ull));
         }
+        __syncthreads();
+        if (t == 0) s_base = s_cnt ? atomicAdd(&P.tcount[b * 16], s_cnt) : 0;
+        __syncthreads();
+        const int base = s_base;
+#pragma unroll
+        for (int u = 0; u < PEN_GU; ++u)
+            if (pk[u].x < 0) tlist[base + off[u]] = make_int4(pk[u].x, pk[u].y, f0 + u * PEN_GW * PEN_T, 0);
+        __syncthreads();        // (s_cnt is reset by the next batch)
     }
 }
 
@@ -419,7 +440,8 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
         return;
     }
     const int F = P.F;
-    const int2* tcell = P.tcell + (size_t)b * F;
+    const int4* tlist = P.tlist + (size_t)b * F;
+    const int NT = min(P.tcount[b * 16], F);      // triangles that survived the part culling
     unsigned* pmask = reinterpret_cast<unsigned*>(cell_cnt + PEN_GRID_INTS);
 #ifdef PEN_COUNT    // diagnostic build: shader clocks at the phase boundaries -> stats[24..30] (cycles per phase, thread 0)
     long long g3c[8]; int g3n = 0;
@@ -434,29 +456,29 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     G3MARK();
     constexpr int U2 = 7;
     // which parts are present in each bucket (folded to 32 bits)
-    for (int f0 = t; f0 < F; f0 += PEN_T * U2) {
-        int2 pk[U2];
+    for (int f0 = t; f0 < NT; f0 += PEN_T * U2) {
+        int4 pk[U2];
 #pragma unroll
-        for (int u = 0; u < U2; ++u) { const int f = f0 + u * PEN_T; const int2 tc_ = tcell[f < F ? f : 0]; pk[u] = f < F ? tc_ : make_int2(0, 0); }
+        for (int u = 0; u < U2; ++u) { const int i = f0 + u * PEN_T; const int4 tc_ = tlist[i < NT ? i : 0]; pk[u] = i < NT ? tc_ : make_int4(0, 0, 0, 0); }
 #pragma unroll
         for (int u = 0; u < U2; ++u) {
-            if (pk[u].x >= 0) continue;                    // (alive bit = sign bit)
+            if (pk[u].x >= 0) continue;                    // (alive bit = sign bit: entries past the end of the list)
             const unsigned bit = 1u << ((pk[u].y >> 9) & 31);
-            pen_for_cells(pk[u], [&](int bk, int) { atomicOr(&pmask[bk], bit); });
+            pen_for_cells(make_int2(pk[u].x, pk[u].y), [&](int bk, int) { atomicOr(&pmask[bk], bit); });
         }
     }
     __syncthreads();
     G3MARK();
     // histogram
-    for (int f0 = t; f0 < F; f0 += PEN_T * U2) {
-        int2 pk[U2];
+    for (int f0 = t; f0 < NT; f0 += PEN_T * U2) {
+        int4 pk[U2];
 #pragma unroll
-        for (int u = 0; u < U2; ++u) { const int f = f0 + u * PEN_T; const int2 tc_ = tcell[f < F ? f : 0]; pk[u] = f < F ? tc_ : make_int2(0, 0); }
+        for (int u = 0; u < U2; ++u) { const int i = f0 + u * PEN_T; const int4 tc_ = tlist[i < NT ? i : 0]; pk[u] = i < NT ? tc_ : make_int4(0, 0, 0, 0); }
 #pragma unroll
         for (int u = 0; u < U2; ++u) {
             if (pk[u].x >= 0) continue;
             const unsigned want32 = s_coll32[(pk[u].y >> 9) & 63];
-            pen_for_cells(pk[u], [&](int bk, int) { if (pmask[bk] & want32) atomicAdd(&cell_cnt[bk], 1); });
+            pen_for_cells(make_int2(pk[u].x, pk[u].y), [&](int bk, int) { if (pmask[bk] & want32) atomicAdd(&cell_cnt[bk], 1); });
         }
     }
     __syncthreads();
@@ -499,16 +521,16 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     }
     // scatter: the start offsets double as cursors, so bucket c ends up holding its END offset
     // (= the start of bucket c + 1); a bucket's entries are [c ? cell_cnt[c - 1] : 0, cell_cnt[c])
-    for (int f0 = t; f0 < F; f0 += PEN_T * U2) {
-        int2 pk[U2];
+    for (int f0 = t; f0 < NT; f0 += PEN_T * U2) {
+        int4 pk[U2];
 #pragma unroll
-        for (int u = 0; u < U2; ++u) { const int f = f0 + u * PEN_T; const int2 tc_ = tcell[f < F ? f : 0]; pk[u] = f < F ? tc_ : make_int2(0, 0); }
+        for (int u = 0; u < U2; ++u) { const int i = f0 + u * PEN_T; const int4 tc_ = tlist[i < NT ? i : 0]; pk[u] = i < NT ? tc_ : make_int4(0, 0, 0, 0); }
 #pragma unroll
         for (int u = 0; u < U2; ++u) {
             if (pk[u].x >= 0) continue;
-            const int f = f0 + u * PEN_T, pf = (pk[u].y >> 9) & 63;
+            const int f = pk[u].z, pf = (pk[u].y >> 9) & 63;
             const unsigned want32 = s_coll32[pf];
-            pen_for_cells(pk[u], [&](int bk, int key) {
+            pen_for_cells(make_int2(pk[u].x, pk[u].y), [&](int bk, int key) {
                 if (!(pmask[bk] & want32)) return;
                 const int q = atomicAdd(&cell_cnt[bk], 1);
                 ent[q] = make_int2(f | (pf << 24), key);            // (triangle | part << 24, cell): one 8-byte store
@@ -1085,7 +1107,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     const size_t B = max_batch;
     P.ent_cap = F * 32;
     P.aabb = h->zeros<float>(B * F * 6); P.entries = h->zeros<int2>(B * P.ent_cap);
-    P.tcell = h->zeros<int2>(B * F);
+    P.tlist = h->zeros<int4>(B * F); P.tcount = h->zeros<int>(B * 16);
     P.pbox = h->zeros<int>(B * 64 * 6); P.gpart = h->zeros<float>(B * PEN_GW * 8);
     P.partners = h->zeros<int>(B * F * P.pcap); P.pcount = h->zeros<int>(B * F); P.pavail = h->zeros<int>(B * F);
     P.pair_cap = (int)std::min<size_t>((size_t)F * P.cap, std::max<size_t>(65536, (size_t)16 * F));
@@ -1094,7 +1116,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     P.pout = h->zeros<float>(B * 10 * P.pair_cap); P.ptotal = h->zeros<int>(B); P.stats = h->zeros<int>(B * PEN_STATS);
     P.cells = h->zeros<int>(B * (PEN_CELLS + 1)); P.gridp = h->zeros<float>(B * 4);
     P.tgrad = h->zeros<float>(B * F * 9); P.tloss = h->zeros<float>(B * F);
-    if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tcell || !P.pbox || !P.gpart || !P.aabb || !P.entries) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
+    if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tlist || !P.tcount || !P.pbox || !P.gpart || !P.aabb || !P.entries) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.pavail || !P.ptotal) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     *out = h;
     return 0;
