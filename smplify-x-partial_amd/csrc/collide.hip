@@ -659,27 +659,8 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
         const int own_x = hi_[11] ^ ck;
         const int own_m = ((own_x & 0x3ff) ? 0x3ff : 0) | ((own_x & 0xffc00) ? 0xffc00 : 0) | ((own_x & 0x3ff00000) ? 0x3ff00000 : 0);
         int staged = 64;                               // entries i0 .. i0 + staged - 1 are (or were) in the window
-        for (int d = 1; ; ++d) {
-            const int k = qi + d;
-            const bool act = k < bend;
-            if (!__ballot(act)) break;
-            if (d > PEN_MAX_WALK) {                    // a bucket of thousands of entries: a mesh that has collapsed into a few cells
-                if (lane == 0) atomicAdd(&P.stats[b * PEN_STATS + 13], 1);      // (reported: sfx_pen_stats, "walks cut short")
-                break;
-            }
-            if (63 + d >= staged) {                    // wave-uniform: the window's leading edge reaches the next half
-                int hn[12];
-                const int qn_ = i0 + staged + lane;
-                load_hdr(qn_, qn_ < bend_max, hn);
-                const int sl = (staged + lane) & 127;
-                tA[sl] = make_int4(hn[0], hn[1], hn[2], hn[3]);
-                tB[sl] = make_int4(hn[4], hn[5], hn[6], hn[7]);
-                tC[sl] = make_int4(hn[8], hn[9], hn[10], hn[11]);
-                staged += 64;
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();     // (d = 1 always refills: covers the first half too)
-            }
-            const int kl = (lane + d) & 127;
-            const int4 h0 = tA[kl], h1 = tB[kl], h2 = tC[kl];
+        // one candidate of this lane: entry (lane + dd) of the window
+        auto test = [&](const bool act, const int4 h0, const int4 h1, const int4 h2) {
             bool pass = act && h0.y == ck && !((skip_i >> (h0.x >> 24)) & 1ull);
             const float kl0 = __int_as_float(h0.z), kl1 = __int_as_float(h0.w), kl2 = __int_as_float(h1.x);
             const float kh0 = __int_as_float(h1.y), kh1 = __int_as_float(h1.z), kh2 = __int_as_float(h1.w);
@@ -695,20 +676,56 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
 #endif
             pass = pass && ai[0] <= kh0 && kl0 <= ai[3] && ai[1] <= kh1 && kl1 <= ai[4] && ai[2] <= kh2 && kl2 <= ai[5];
             pass = pass && ((h2.w ^ ck) & own_m) == 0;
-            if (pass) {
-                const int g0 = h2.x, g1 = h2.y, g2 = h2.z;
-                pass = !(g0 == hi_[8] || g0 == hi_[9] || g0 == hi_[10] || g1 == hi_[8] || g1 == hi_[9] || g1 == hi_[10] ||
-                                 g2 == hi_[8] || g2 == hi_[9] || g2 == hi_[10]);
-            }
-            // accepted pairs go to a wavefront-private queue and are appended to the partner lists
-            // 64 at a time: the list cursors are returning atomics, one memory round trip each
+            const int g0 = h2.x, g1 = h2.y, g2 = h2.z;
+            return pass && !(g0 == hi_[8] || g0 == hi_[9] || g0 == hi_[10] || g1 == hi_[8] || g1 == hi_[9] || g1 == hi_[10] ||
+                             g2 == hi_[8] || g2 == hi_[9] || g2 == hi_[10]);
+        };
+        // accepted pairs go to a wavefront-private queue and are appended to the partner lists
+        // 64 at a time: the list cursors are returning atomics, one memory round trip each
+        auto push = [&](const bool pass, const int other) {
             const unsigned long long m = __ballot(pass);
             if (m) {
                 const int pos = qn + __popcll(m & ((1ull << lane) - 1ull));
-                if (pass) { queue[2 * pos] = fi; queue[2 * pos + 1] = h0.x & 0xffffff; }
+                if (pass) { queue[2 * pos] = fi; queue[2 * pos + 1] = other & 0xffffff; }
                 qn += __popcll(m);
                 if (qn >= 64) { flush_queue(qn); qn = 0; }
             }
+        };
+        // TWO candidates per lane and iteration (entries lane + d and lane + d + 1): their tests are independent instruction
+        // streams, which is what a wavefront needs to cover its own LDS and compare latencies -- one candidate per iteration kept
+        // the SIMDs a third busy with five wavefronts each
+#ifndef PEN_NC
+#define PEN_NC 2
+#endif
+        // (not more: a refill overwrites entries staged - 128 .. staged - 65 of the 128-entry window; it is triggered by the leading
+        //  edge 63 + d + PEN_NC - 1 reaching `staged`, i.e. at some d >= staged - 62 - PEN_NC, and lane 0 still needs entry d)
+        static_assert(PEN_NC >= 1 && PEN_NC <= 2, "window of 128 entries, refills of 64");
+        for (int d = 1; ; d += PEN_NC) {
+            const bool act0 = qi + d < bend;
+            if (!__ballot(act0)) break;
+            if (d > PEN_MAX_WALK) {                    // a bucket of thousands of entries: a mesh that has collapsed into a few cells
+                if (lane == 0) atomicAdd(&P.stats[b * PEN_STATS + 13], 1);      // (reported: sfx_pen_stats, "walks cut short")
+                break;
+            }
+            if (62 + PEN_NC + d >= staged) {           // wave-uniform: the window's leading edge (entry 63 + d + PEN_NC - 1) reaches the next half
+                int hn[12];
+                const int qn_ = i0 + staged + lane;
+                load_hdr(qn_, qn_ < bend_max, hn);
+                const int sl = (staged + lane) & 127;
+                tA[sl] = make_int4(hn[0], hn[1], hn[2], hn[3]);
+                tB[sl] = make_int4(hn[4], hn[5], hn[6], hn[7]);
+                tC[sl] = make_int4(hn[8], hn[9], hn[10], hn[11]);
+                staged += 64;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();     // (d = 1 always refills: covers the first half too)
+            }
+            int4 hA[PEN_NC], hB[PEN_NC], hC[PEN_NC];
+#pragma unroll
+            for (int c = 0; c < PEN_NC; ++c) { const int kk = (lane + d + c) & 127; hA[c] = tA[kk]; hB[c] = tB[kk]; hC[c] = tC[kk]; }
+            bool ps[PEN_NC];
+#pragma unroll
+            for (int c = 0; c < PEN_NC; ++c) ps[c] = test(qi + d + c < bend, hA[c], hB[c], hC[c]);
+#pragma unroll
+            for (int c = 0; c < PEN_NC; ++c) push(ps[c], hA[c].x);
         }
         __builtin_amdgcn_wave_barrier();
     }
