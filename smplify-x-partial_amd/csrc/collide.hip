@@ -9,17 +9,18 @@
 // (the package's source is absent: parity unpinned).
 //
 // MI355X design (not the package's LBVH; DESIGN.md 4.6 has the table):
-//   k_pen_g1..g5  (8 x 1024 lanes per frame, five launches) triangle AABBs -> bounding box per body part: a triangle
-//                 whose box meets the box of no part it may collide with is dropped -> the rest enters a
-//                 uniform grid (cell = twice the mean triangle extent, every cell the AABB touches)
-//                 hashed into 16384 LDS buckets by a counting sort.
-//   k_pen_walk    (32 x 256 lanes per frame) pair tests over blocks of 64 consecutive entries of the
-//                 bucket-sorted list: each lane holds one entry (AABB, vertex ids, part, cell), the same
-//                 64 headers sit in a wavefront-private LDS tile, and lane i walks the entries after it
-//                 in its bucket, so memory is touched once per ENTRY, not per pair.  Tests in order: same
-//                 cell, part mask (one 64-bit word), AABB overlap, ownership by the cell of the
-//                 intersection's low corner, shared vertices.  Accepted pairs are queued per wavefront
-//                 and appended to both triangles' partner lists 64 at a time.
+//   k_pen_reset / g1 / g2 / g3   triangle AABBs (8 x 1024 lanes per frame) -> bounding box per body part: a triangle
+//                 whose box meets the box of no part it may collide with is dropped, the survivors are
+//                 compacted (8 x 1024) -> they enter a uniform grid (cell = twice the mean triangle extent,
+//                 every cell the AABB touches) hashed into 16384 LDS buckets by a counting sort (1 x 1024).
+//   k_pen_walk    (128 x 256 lanes per frame) pair tests over blocks of 64 consecutive entries of the
+//                 bucket-sorted list: each lane holds one entry (AABB, vertex ids, part, cell), the
+//                 headers sit in a wavefront-private LDS window, and lane i walks the entries after it
+//                 in its bucket, two per iteration, so memory is touched once per ENTRY, not per pair.
+//                 Tests in order: same cell, part mask (one 64-bit word), AABB overlap, ownership by the
+//                 cell of the intersection's low corner (a mask test on cell keys), shared vertices.
+//                 Accepted pairs are queued per wavefront and appended to both triangles' partner lists
+//                 64 at a time.
 //   k_pen_list /  offsets and ranks turn the partner lists (appended in scheduling order) into the
 //   k_pen_rank    frame's pair list -- triangles ascending, partners ascending -- which fixes every
 //                 later summation order.
