@@ -358,6 +358,7 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
         for (int k = 0; k < K; ++k) { m->meta_host[MO_JT + k] = jt[k]; m->meta_host[MO_JS + k] = js[k];
                                       m->meta_host[MO_JI0 + k] = ji0[k]; m->meta_host[MO_JN + k] = jn[k]; }
         for (size_t q = 0; q < ik.size(); ++q) m->meta_host[MO_IK + q] = ik[q];
+        std::vector<int> dyn_pv;        // [rows][nd] vertices of the dynamic-contour items (filled below; the export table needs them)
         // by-joint adjoint lists
         {
             auto build = [&](const std::vector<int>& vids, const std::vector<int>& items, std::vector<int>& start,
@@ -422,6 +423,7 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
                 for (int j = 0; j <= SFX_J; ++j) pjs[(size_t)row * (SFX_J + 1) + j] = st[j] - st[0];
                 for (int q = 0; q < n_row; ++q) { pji[(size_t)row * nd * SFX_NW + q] = di[st[0] + q]; pjw[(size_t)row * nd * SFX_NW + q] = dw[st[0] + q]; }
             }
+            dyn_pv = pv;
             M.dynp_vid = m->mem.up(pv); M.dynp_w = m->mem.up(pw); M.dynp_vt = m->mem.up(pvt);
             M.dynp_wj = m->mem.up(pwj); M.dynp_ww = m->mem.up(pww);
             M.dynp_js = pjs.empty() ? nullptr : m->mem.up(pjs);
@@ -448,7 +450,8 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
             }
             M.item_vt = m->mem.up(svt); M.item_wj = m->mem.up(swj); M.item_ww = m->mem.up(sww);
         }
-        {   // distinct vertices of the static items: the dense GEMM hands their v_posed / T to the adjoint pass
+        {   // distinct vertices of the static items -- and of every vertex a dynamic-contour item can land on (all LUT rows):
+            // the dense GEMM hands their blend offsets to the per-frame kernel, which then streams no blend-shape row forward
             std::vector<int> vslot(M.Vpad, -1), uslot(ivid.size(), -1);
             int nu = 0, nstat = 0;
             for (size_t i = 0; i < ivid.size(); ++i) {
@@ -459,6 +462,13 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
             }
             for (size_t i = 0; i + 1 < ivid.size(); ++i)
                 if (idyn[i] >= 0 && idyn[i + 1] < 0) { sfx_set_error("internal: dynamic items must trail the static ones"); delete m; return -1; }
+            std::vector<int> pus(dyn_pv.size(), -1);
+            for (size_t o = 0; o < dyn_pv.size(); ++o) {
+                const int v = dyn_pv[o];
+                if (vslot[v] < 0) vslot[v] = nu++;
+                pus[o] = vslot[v];
+            }
+            M.dynp_us = pus.empty() ? nullptr : m->mem.up(pus);
             M.n_uniq = nu; M.n_static_items = nstat;
             M.vslot = m->mem.up(vslot); M.item_uslot = m->mem.up(uslot);
         }

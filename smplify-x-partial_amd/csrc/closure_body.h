@@ -527,6 +527,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         const size_t ro = (size_t)S.lut_row * nd;
         lds_fill_async(S.ivid + ns, M.dynp_vid + ro, nd); lds_fill_async(S.iw + ns, M.dynp_w + ro, nd);
         lds_fill_async(S.vt + ns * 3, M.dynp_vt + ro * 3, nd * 3);
+        if (M.dynp_us) lds_fill_async(S.uslot + ns, M.dynp_us + ro, nd);
         lds_fill_async(S.wj + ns * SFX_NW, M.dynp_wj + ro * SFX_NW, nd * SFX_NW);
         lds_fill_async(S.ww + ns * SFX_NW, M.dynp_ww + ro * SFX_NW, nd * SFX_NW);
         if (dyn_lds) {
@@ -603,16 +604,16 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     __syncthreads();
     };
     if (args.use_dense_verts && !args.from_scratch_items) {
-        // dense path: the GEMM that produced the vertices also left the blend offsets (v_posed - v_template)
-        // of every static item vertex (lbs_dense.hip epilogue); only the dynamic contour items, whose
-        // vertices depend on this frame's head pose, are evaluated here
+        // dense path: the GEMM that produced the vertices also left the blend offsets (v_posed - v_template) of every item
+        // vertex (lbs_dense.hip epilogue) -- of the static items and of every vertex a dynamic-contour item can land on,
+        // whichever LUT row this frame's head pose selects: no blend-shape row is streamed forward here
         const size_t ub = (size_t)D.slot[b] * M.n_uniq;
-        const int nst = NI < M.n_static_items ? NI : M.n_static_items;
+        const int nst = (M.dynp_us || NI < M.n_static_items) ? NI : M.n_static_items;
         for (int w = t; w < nst * 3; w += CT) {
             const float o = D.uvp[(ub + S.uslot[w / 3]) * 3 + w % 3];
             S.vpo[w] = o; S.vp[w] = S.vt[w] + o;
         }
-        if (NI > M.n_static_items) items_forward(M.n_static_items, NI - M.n_static_items);
+        if (NI > nst) items_forward(nst, NI - nst);
     } else items_forward(0, NI);
     items_transforms(0, NI);
     MARK(6);

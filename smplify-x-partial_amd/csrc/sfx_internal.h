@@ -119,7 +119,7 @@ struct DevModel {
     int n_items, n_static_items;
     int n_uniq;                // distinct vertices of the static items: the dense GEMM exports their v_posed and T
     const int* vslot;          // [Vpad] vertex -> index into the export arrays, or -1
-    const int* item_uslot;     // [n_items] export index of a static item's vertex (-1: dynamic item)
+    const int* item_uslot;     // [n_items] export index of a static item's vertex (-1: dynamic item, whose index comes with its LUT-row block: dynp_us)
     const int*   item_vid;     // [n_items] static vertex id (dynamic items: -1)
     const float* item_w;       // [n_items] static bary weight
     const float* item_vt;      // [n_items][3] v_template row of the item's vertex     } gathered copies for the static items:
@@ -144,6 +144,7 @@ struct DevModel {
     const int*   dynp_js;      // [rows][J+1]     per-joint adjoint lists of the row, offsets RELATIVE to the row's block ...
     const int*   dynp_ji;      // [rows][nd*SFX_NW]   ... items (absolute item ids), padded to nd * SFX_NW entries per row
     const float* dynp_jw;      // [rows][nd*SFX_NW]
+    const int*   dynp_us;      // [rows][nd]      export index of the item's vertex in the dense GEMM's uvp (nullptr: no dynamic items)
     int n_sj;                  // entries of sj_item / sj_w
     const int*   meta;         // [SFX_META_N] packed copy of the tables above
     // VPoser decoder
