@@ -225,17 +225,18 @@ def csrc_sha():
 def pmc_is_current(path):
     """Counter traffic is REPLAYED from profiles/pmc_summary.json (counters cannot be read inside an un-profiled run);
     it is only valid for the kernels it was taken with: the summary carries the hash of csrc/ at profiling time."""
+    name = "profiles/" + os.path.basename(path)
     if not os.path.exists(path):
-        return False, "no profiles/pmc_summary.json"
+        return False, "no " + name
     try:
         sha = json.load(open(path)).get("_meta", {}).get("csrc_sha")
     except Exception as e:
         return False, "unreadable pmc summary: %r" % e
     if sha is None:
-        return False, "profiles/pmc_summary.json carries no csrc hash (taken before round 3): traffic not replayed"
+        return False, name + " carries no csrc hash (taken before round 3): traffic not replayed"
     cur = csrc_sha()
     if sha != cur:
-        return False, "profiles/pmc_summary.json was taken with csrc %s, this build is %s: traffic not replayed (stale)" % (sha, cur)
+        return False, name + " was taken with csrc %s, this build is %s: traffic not replayed (stale)" % (sha, cur)
     return True, None
 
 
@@ -561,7 +562,10 @@ def main():
 
     for _ in range(args.warmup):
         one_fit()
-    engine.prof_enable(True, every=args.prof_every)
+    # (the persistent needed-rows kernel is launched a few dozen times per step: every launch is timed; the dense loop's
+    #  thousands of launches are sampled)
+    prof_every = 1 if args.lbs == "rows" else args.prof_every
+    engine.prof_enable(True, every=prof_every)
     engine.prof_reset()
     sync()
     t0 = time.time()
@@ -692,8 +696,12 @@ def main():
                                             "MFLOP/frame) / kernel time; achieved_executed counts only issued MFMA work "
                                             "(K padded to 512, skinning restricted to the %.1f joints per 16-vertex tile that "
                                             "carry weight)" % tj})
-            pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+            # (one summary per workload: the body-only headline, --workload full, --workload pen -- tools/run_prof.sh TAG)
+            pmc_name = "pmc_summary_full.json" if full else "pmc_summary_pen.json" if pen else "pmc_summary.json"
+            pmc = os.path.join(ROOT, "profiles", pmc_name)
             pmc_ok, pmc_note = pmc_is_current(pmc)
+            if pmc_ok and B != 256:     # (the counter passes run the default 256 frames per GPU: per-launch traffic of another job size is not theirs)
+                pmc_ok, pmc_note = False, "profiles/%s was taken at 256 frames per GPU, this run has %d: traffic not replayed" % (pmc_name, B)
             if not pmc_ok:
                 out["roofline"]["traffic_note"] = pmc_note
             if pmc_ok:     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/run_prof.sh)
@@ -704,7 +712,7 @@ def main():
                     out["roofline"]["traffic_detail"] = {
                         "read_bytes_per_launch": k["hbm_read_bytes_per_launch"],
                         "write_bytes_per_launch": k["hbm_write_bytes_per_launch"],
-                        "source": "replayed: profiles/pmc_summary.json, the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                        "source": "replayed: profiles/" + pmc_name + ", the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                   "command (tools/run_prof.sh; counters cannot be read inside an un-profiled run), FETCH_SIZE x2 "
                                   "per the gfx950 correction"}
             # the other half of the step: loss + adjoint + L-BFGS tick + next pose / chain, one workgroup per frame.
@@ -729,7 +737,7 @@ def main():
                     k = max(cands, key=lambda v: v.get("FETCH_SIZE", {}).get("launches", 0)) if cands else {}
                     if "hbm_read_bytes_per_launch" in k:
                         out["roofline_tick"]["traffic"] = k["hbm_read_bytes_per_launch"] + k.get("hbm_write_bytes_per_launch", 0.0)
-                        out["roofline_tick"]["traffic_source"] = "replayed: profiles/pmc_summary.json"
+                        out["roofline_tick"]["traffic_source"] = "replayed: profiles/" + pmc_name
         else:
             # persistent per-frame kernel: bytes the needed-rows closure must move per evaluation
             # (11 vertex rows x (3 x 506 blend-shape + 8 skinning entries), forward and adjoint)
@@ -740,9 +748,21 @@ def main():
             out["roofline"] = {"kernel": "k_fit_rows", "bound": "hbm", "achieved": by_eval * total_evals / max(t_tot, 1e-12) / 1e9,
                                "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": by_eval * total_evals / max(t_tot, 1e-12) / PEAK_HBM,
                                "traffic": None, "bytes_per_eval": by_eval, "evals": total_evals,
-                               "kernel_ms_total": ms_lb, "launches": n_lb,
+                               "kernel_ms_total": ms_lb, "launches": n_lb, "bytes_per_launch": by_eval * total_evals / max(n_lb, 1),
                                "note": "latency-bound by construction: one workgroup walks one frame's serial "
                                        "L-BFGS chain; the meaningful figure is frames/s"}
+            pmc_rows = os.path.join(ROOT, "profiles", "pmc_summary_rows.json")
+            pmc_ok, pmc_note = pmc_is_current(pmc_rows)
+            if pmc_ok and B != 256:
+                pmc_ok, pmc_note = False, "profiles/pmc_summary_rows.json was taken at 256 frames per GPU, this run has %d: traffic not replayed" % B
+            if pmc_ok:      # per LAUNCH of the persistent kernel (one launch = the whole fit of a batch stage range)
+                cands = [v for n, v in json.load(open(pmc_rows)).items() if "k_fit_rows" in n and "hbm_read_bytes_per_launch" in v]
+                if cands:
+                    k = max(cands, key=lambda v: v.get("FETCH_SIZE", {}).get("launches", 0))
+                    out["roofline"]["traffic"] = k["hbm_read_bytes_per_launch"] + k.get("hbm_write_bytes_per_launch", 0.0)
+                    out["roofline"]["traffic_source"] = "replayed: profiles/pmc_summary_rows.json (per launch of k_fit_rows)"
+            else:
+                out["roofline"]["traffic_note"] = pmc_note
         if pen and prof["penetration"][1]:
             # the interpenetration step of a round (csrc/collide.hip k_pen_* + the dense skinning adjoint, csrc/lbs_adjoint.hip), timed
             # as ONE HIP-event scope per round.  Byte model per GEMM column whose stage carries a collision weight (F triangles, V
@@ -768,6 +788,8 @@ def main():
                                            "instructions per candidate, list ranking) expose little parallelism per frame; per-kernel "
                                            "times and counters: profiles/r03_pen_*"}
             pmc_ok, pmc_note = pmc_is_current(os.path.join(ROOT, "profiles", "pmc_summary_pen.json"))
+            if pmc_ok and B != 256:
+                pmc_ok, pmc_note = False, "profiles/pmc_summary_pen.json was taken at 256 frames per GPU, this run has %d: traffic not replayed" % B
             if pmc_ok:
                 pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary_pen.json")))
                 tr = sum(v.get("hbm_read_bytes_per_launch", 0.0) + v.get("hbm_write_bytes_per_launch", 0.0) for k, v in pj.items()
