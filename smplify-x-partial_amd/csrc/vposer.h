@@ -13,7 +13,7 @@
 
 #define VP_H 512
 #ifndef SFX_VP_UNROLL
-#define SFX_VP_UNROLL 8      // 16-byte weight loads in flight per thread of a VPoser matrix-vector product
+#define SFX_VP_UNROLL 12     // 16-byte weight loads in flight per thread of a VPoser matrix-vector product
 #endif
 #define SFX_STR_(x) #x
 #define SFX_STR(x) SFX_STR_(x)
@@ -133,7 +133,8 @@ __device__ __forceinline__ void vposer_forward(VposerLDS& V, const DevModel& M, 
     const int t = threadIdx.x, L = M.vp_latent;
     float* part = V.dh;                         // dh, dg (2 x 512 floats, contiguous) are free during the forward
     // (16 weight loads in flight per thread in the forward products: 43 k -> 34 k cycles per decode at 256 frames; the
-    //  adjoint products, which follow a longer dependent prologue, measured slower with 16 than with 8: 78 k -> 87 k)
+    //  transposed products, which follow a longer dependent prologue, are fastest with 12 -- 8 / 12 / 16: 51.8 k / 44.8 k /
+    //  51.5 k cycles per backward at 256 frames, shader clocks of tools/phase_dense.py)
     int G = vp_gemv_partial<NT, 16>(M.vp_w1T, L, VP_H, VP_H, z, part);
     __syncthreads();
     for (int o = t; o < VP_H; o += NT) {
