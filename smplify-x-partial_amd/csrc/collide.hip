@@ -75,7 +75,8 @@ struct PenDev {
     const int* vf_list;
     // per batch (capacity Bmax)
     float* aabb;               // [B][F][6]
-    int2* entries;             // [B][ent_cap] (triangle | part << 24, packed cell coordinates the entry was made for), sorted by bucket
+    int2* entries;             // [B][ent_cap] (triangle | part << 24 | lz << 30, packed cell coordinates | lx << 30 | ly << 31), sorted by bucket;
+                               //              lx, ly, lz: the cell holds the low corner of the triangle's box on that axis
     int4* tlist;               // [B][F] the triangles that survive the part culling, compacted (any order): packed cell range, spans + part, triangle
     int* tcount;               // [B][16] (one cache line each) number of survivors (k_pen_reset -> 0, k_pen_g2 reserves ranges)
     int* pbox;                 // [B][64][6] bounding box of every part, order-preserving ints (k_pen_g1; reset per evaluation)
@@ -407,9 +408,11 @@ template <class FN>
 __device__ __forceinline__ void pen_for_cells(const int2 pk, FN&& fn) {
     const int x0 = pk.x & 1023, y0 = (pk.x >> 10) & 1023, z0 = (pk.x >> 20) & 1023;
     const int sx = pk.y & 7, sy = (pk.y >> 3) & 7, sz = (pk.y >> 6) & 7;
+    // (the key's two spare bits, and bit 0 of the third argument, say on which axes -- x, y, z -- this cell is the one that
+    //  holds the LOW corner of the triangle's box: the pair tests decide ownership of a pair on these bits)
     for (int dz = 0; dz <= sz; ++dz) for (int dy = 0; dy <= sy; ++dy) for (int dx = 0; dx <= sx; ++dx) {
         const int x = (x0 + dx) & 1023, y = (y0 + dy) & 1023, z = (z0 + dz) & 1023;
-        fn(pen_bucket(x, y, z), x | (y << 10) | (z << 20));
+        fn(pen_bucket(x, y, z), x | (y << 10) | (z << 20) | ((dx == 0) << 30) | ((dy == 0) << 31), dz == 0);
     }
 }
 // parts a triangle of part p may collide with, folded to 32 bits (a triangle only enters a cell that also holds such a
@@ -465,7 +468,7 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
         for (int u = 0; u < U2; ++u) {
             if (pk[u].x >= 0) continue;                    // (alive bit = sign bit: entries past the end of the list)
             const unsigned bit = 1u << ((pk[u].y >> 9) & 31);
-            pen_for_cells(make_int2(pk[u].x, pk[u].y), [&](int bk, int) { atomicOr(&pmask[bk], bit); });
+            pen_for_cells(make_int2(pk[u].x, pk[u].y), [&](int bk, int, int) { atomicOr(&pmask[bk], bit); });
         }
     }
     __syncthreads();
@@ -479,7 +482,7 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
         for (int u = 0; u < U2; ++u) {
             if (pk[u].x >= 0) continue;
             const unsigned want32 = s_coll32[(pk[u].y >> 9) & 63];
-            pen_for_cells(make_int2(pk[u].x, pk[u].y), [&](int bk, int) { if (pmask[bk] & want32) atomicAdd(&cell_cnt[bk], 1); });
+            pen_for_cells(make_int2(pk[u].x, pk[u].y), [&](int bk, int, int) { if (pmask[bk] & want32) atomicAdd(&cell_cnt[bk], 1); });
         }
     }
     __syncthreads();
@@ -531,10 +534,10 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
             if (pk[u].x >= 0) continue;
             const int f = pk[u].z, pf = (pk[u].y >> 9) & 63;
             const unsigned want32 = s_coll32[pf];
-            pen_for_cells(make_int2(pk[u].x, pk[u].y), [&](int bk, int key) {
+            pen_for_cells(make_int2(pk[u].x, pk[u].y), [&](int bk, int key, int lowz) {
                 if (!(pmask[bk] & want32)) return;
                 const int q = atomicAdd(&cell_cnt[bk], 1);
-                ent[q] = make_int2(f | (pf << 24), key);            // (triangle | part << 24, cell): one 8-byte store
+                ent[q] = make_int2(f | (pf << 24) | (lowz << 30), key);     // (triangle | part << 24 | low-corner bit z << 30, cell | low-corner bits x, y << 30): one 8-byte store
             });
         }
     }
@@ -553,7 +556,7 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
 // pair tests over the bucket-sorted entries of k_pen_grid; PEN_WALK_BLOCKS workgroups per frame
 __global__ __launch_bounds__(256)
 void k_pen_walk(PenDev P, const int* __restrict__ want) {
-    __shared__ __align__(16) int s_tile[4 * 128 * 12];       // per wavefront: a sliding window of 128 entry headers
+    __shared__ __align__(16) int s_tile[4 * 128 * 8];        // per wavefront: a sliding window of 128 entry headers (32 bytes each)
     __shared__ int s_queue[4 * 256];
     __shared__ unsigned long long s_mask[64];
     const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -569,26 +572,24 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
         s_mask[t] = m;
     }
     __syncthreads();
-    const float glo[3] = {P.gridp[b * 4], P.gridp[b * 4 + 1], P.gridp[b * 4 + 2]};
-    const float ih = P.gridp[b * 4 + 3];
-    auto cell_of = [&](float x, int e) { return min(1 << 20, max(0, (int)fminf((x - glo[e]) * ih, 1048576.f))); };
     auto bucket = [](int x, int y, int z) { return (int)(((unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u) & (PEN_CELLS - 1)); };
-    auto cell_key = [](int x, int y, int z) { return (x & 1023) | ((y & 1023) << 10) | ((z & 1023) << 20); };
 
     // ---- pairs.  A wavefront takes 64 consecutive entries of the bucket-sorted list: its lanes hold
-    // one entry each (header = AABB, vertex ids, part, cell) and the same 64 headers sit in a
-    // wavefront-private LDS tile (three int4 arrays: lane i reading entry i + d is conflict-free);
+    // one entry each (header = entry record + AABB: 32 bytes) and the same headers sit in a
+    // wavefront-private LDS window (two int4 arrays: lane i reading entry i + d is conflict-free);
     // lane i tests itself against the entries after it in its bucket.  All memory traffic is one
     // gather per ENTRY; the pair tests run on registers and LDS.  A pair is accepted in the cell that
     // holds the low corner of the AABB intersection (both triangles are entered there), and appended
-    // to both triangles' partner lists.
-    int* tile = s_tile + wv * 128 * 12;
+    // to both triangles' partner lists -- unless the triangles share a vertex, which is looked at when the
+    // queue of accepted pairs is flushed (neighbours are almost always of one part or of parent and child,
+    // which the part mask has already turned away: the vertex ids are not worth 16 bytes of every header).
+    int* tile = s_tile + wv * 128 * 8;
     int* pc = P.pcount + (size_t)b * F;
     int* part = P.partners + (size_t)b * F * P.pcap;
-    // (every load unconditional, from a clamped index: written as `ok ? p[i] : 0` each of the eleven loads became its own
-    //  exec-masked branch with a full s_waitcnt behind it -- eleven serial round trips per header, two headers per block of 64
+    // (every load unconditional, from a clamped index: written as `ok ? p[i] : 0` each of the loads became its own
+    //  exec-masked branch with a full s_waitcnt behind it -- serial round trips per header, two headers per block of 64
     //  entries: that chain, not the pair tests, was most of this kernel's time)
-    auto load_hdr = [&](int q, bool ok, int (&hd)[12]) {
+    auto load_hdr = [&](int q, bool ok, int (&hd)[8]) {
         const int qs = ok ? q : 0;
         const int2 e01 = ent[qs];
         const int e0 = e01.x, e1 = e01.y;
@@ -597,21 +598,10 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
         //  word: rows 2^24 x part id beyond the array, a memory fault with ROCm 7.2's compiler)
         int f;
         asm("v_and_b32 %0, 0xffffff, %1" : "=v"(f) : "v"(e0));
-        int bx[6], vd[3];
-        {   // four gathers per header: the box as three 8-byte loads (rows of 24 bytes), the vertex ids as one 16-byte row
-            const int2* bp = reinterpret_cast<const int2*>(aabb) + (size_t)f * 3;
-            const int2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
-            bx[0] = b0.x; bx[1] = b0.y; bx[2] = b1.x; bx[3] = b1.y; bx[4] = b2.x; bx[5] = b2.y;
-            const int4 fv4 = P.faces4[f];
-            vd[0] = fv4.x; vd[1] = fv4.y; vd[2] = fv4.z;
-        }
-        hd[0] = ok ? e0 : 0; hd[1] = ok ? e1 : -1;
-#pragma unroll
-        for (int e = 0; e < 6; ++e) hd[2 + e] = ok ? bx[e] : 0;
-#pragma unroll
-        for (int e = 0; e < 3; ++e) hd[8 + e] = ok ? vd[e] : -1 - e;
-        // the cell of the box's low corner (wrapped like the entries' keys): the ownership test below works on these
-        hd[11] = cell_key(cell_of(__int_as_float(bx[0]), 0), cell_of(__int_as_float(bx[1]), 1), cell_of(__int_as_float(bx[2]), 2));
+        const int2* bp = reinterpret_cast<const int2*>(aabb) + (size_t)f * 3;      // the box as three 8-byte loads (rows of 24 bytes)
+        const int2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
+        hd[0] = ok ? e0 : 0; hd[1] = ok ? e1 : 0x3fffffff;      // (no cell has the key 0x3fffffff with the low-corner bits clear... any key: `act` is false for such lanes)
+        hd[2] = ok ? b0.x : 0; hd[3] = ok ? b0.y : 0; hd[4] = ok ? b1.x : 0; hd[5] = ok ? b1.y : 0; hd[6] = ok ? b2.x : 0; hd[7] = ok ? b2.y : 0;
     };
     // (blocks of 64 entries, NOT whole buckets: a crowded bucket is shared by many wavefronts; the
     // cell key comparison keeps different cells of one bucket apart)
@@ -621,6 +611,10 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
         for (int q = lane; q < n; q += 64) {
             const int fa = queue[2 * q], fb = queue[2 * q + 1];
+            const int4 va = P.faces4[fa], vb = P.faces4[fb];      // triangles that share a vertex do not collide
+            const bool shared = va.x == vb.x || va.x == vb.y || va.x == vb.z || va.y == vb.x || va.y == vb.y || va.y == vb.z ||
+                                va.z == vb.x || va.z == vb.y || va.z == vb.z;
+            if (shared) continue;
             const int pa = atomicAdd(&pc[fa], 1), pb = atomicAdd(&pc[fb], 1);
             if (pa < P.pcap) part[(size_t)fa * P.pcap + pa] = fb;
             if (pb < P.pcap) part[(size_t)fb * P.pcap + pb] = fa;
@@ -629,20 +623,19 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
     };
     int4* tA = reinterpret_cast<int4*>(tile);        // [128] entry | cell | lo.x | lo.y
     int4* tB = tA + 128;                             // [128] lo.z | hi.x | hi.y | hi.z
-    int4* tC = tA + 256;                             // [128] vertex ids
     for (int i0 = (blockIdx.x * 4 + wv) * 64; i0 < s_total; i0 += gridDim.x * 256) {
         const int qi = i0 + lane;
         const bool vi = qi < s_total;
-        int hi_[12];
+        int hi_[8];
         load_hdr(qi, vi, hi_);
         const int fi = hi_[0] & 0xffffff;
-        const unsigned long long skip_i = vi ? s_mask[hi_[0] >> 24] : ~0ull;
+        const unsigned long long skip_i = vi ? s_mask[(hi_[0] >> 24) & 63] : ~0ull;
         float ai[6];
 #pragma unroll
         for (int e = 0; e < 6; ++e) ai[e] = __int_as_float(hi_[2 + e]);
         // partners of an entry: the entries after it up to the end of ITS bucket (buckets hold a few
         // entries, so this per-lane walk takes as many steps as the fullest bucket of the block)
-        const int ck = hi_[1];
+        const int ck = hi_[1] & 0x3fffffff;
         const int bend = vi ? cells[bucket(ck & 1023, (ck >> 10) & 1023, (ck >> 20) & 1023)] : 0;
         // the walk of all lanes advances in lockstep (lane i looks at entry i + d), so the headers it needs
         // form a window of 64 entries sliding over the list: two 64-entry halves in LDS, the next half
@@ -651,35 +644,34 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
         const int bend_max = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)bend));      // entries < 2^24: exact
         tA[lane] = make_int4(hi_[0], hi_[1], hi_[2], hi_[3]);
         tB[lane] = make_int4(hi_[4], hi_[5], hi_[6], hi_[7]);
-        tC[lane] = make_int4(hi_[8], hi_[9], hi_[10], hi_[11]);
         // Ownership: a pair is accepted in the cell that holds the low corner of the boxes' intersection.  Both triangles are
         // entered in THIS cell, so on every axis the cells of both low corners are <= this cell's coordinate, and (the cell
-        // function is monotone) cell(max(a, k)) == c  <=>  cell(a) == c or cell(k) == c.  own_m has an axis' 10 key bits SET
-        // where this lane's own low corner is NOT in cell c: there the partner's must be -- ((kcell ^ ck) & own_m) == 0.
-        // (two AND / compare instructions per candidate instead of three cell computations under a branch nearly every step takes)
-        const int own_x = hi_[11] ^ ck;
-        const int own_m = ((own_x & 0x3ff) ? 0x3ff : 0) | ((own_x & 0xffc00) ? 0xffc00 : 0) | ((own_x & 0x3ff00000) ? 0x3ff00000 : 0);
+        // function is monotone) cell(max(a, k)) == c  <=>  cell(a) == c or cell(k) == c.  Whether an entry's cell holds its
+        // box's low corner on an axis is a bit of the entry record (k_pen_g3: bits 30, 31 of the key, bit 30 of the triangle
+        // word): `need` has the axes where this lane's own corner is elsewhere -- there the partner's must be here.
+        const unsigned lowb = ((unsigned)hi_[1] >> 30) | (((unsigned)hi_[0] >> 28) & 4u);      // x | y << 1 | z << 2
+        const unsigned need = ~lowb & 7u;
         int staged = 64;                               // entries i0 .. i0 + staged - 1 are (or were) in the window
         // one candidate of this lane: entry (lane + dd) of the window
-        auto test = [&](const bool act, const int4 h0, const int4 h1, const int4 h2) {
-            bool pass = act && h0.y == ck && !((skip_i >> (h0.x >> 24)) & 1ull);
+        auto test = [&](const bool act, const int4 h0, const int4 h1) {
+            // (every test is evaluated, the results are combined with `&`: written with `&&` the compiler nests one exec-masked
+            //  branch per condition -- five s_and_saveexec / s_cbranch_execz pairs per candidate, the second LDS read inside them)
             const float kl0 = __int_as_float(h0.z), kl1 = __int_as_float(h0.w), kl2 = __int_as_float(h1.x);
             const float kh0 = __int_as_float(h1.y), kh1 = __int_as_float(h1.z), kh2 = __int_as_float(h1.w);
+            const bool same = ((h0.y ^ ck) & 0x3fffffff) == 0;
+            const bool coll = ((unsigned)(skip_i >> ((h0.x >> 24) & 63)) & 1u) == 0u;
+            const bool box = (ai[0] <= kh0) & (kl0 <= ai[3]) & (ai[1] <= kh1) & (kl1 <= ai[4]) & (ai[2] <= kh2) & (kl2 <= ai[5]);
+            const unsigned klow = ((unsigned)h0.y >> 30) | (((unsigned)h0.x >> 28) & 4u);
+            const bool own = (need & ~klow) == 0u;
 #ifdef PEN_COUNT    // diagnostic build: where do the candidates die?  stats[16..19] = walked, same cell, part mask passed, boxes overlap
             {
                 int* st = P.stats + b * PEN_STATS;
-                const bool c1 = act && h0.y == ck;
-                const bool c2 = ai[0] <= kh0 && kl0 <= ai[3] && ai[1] <= kh1 && kl1 <= ai[4] && ai[2] <= kh2 && kl2 <= ai[5];
-                const unsigned long long m0 = __ballot(act), m1 = __ballot(c1), m2 = __ballot(pass), m3 = __ballot(pass && c2);
+                const unsigned long long m0 = __ballot(act), m1 = __ballot(act & same), m2 = __ballot(act & same & coll), m3 = __ballot(act & same & coll & box);
                 if (lane == 0) { atomicAdd(&st[16], __popcll(m0)); atomicAdd(&st[17], __popcll(m1)); atomicAdd(&st[18], __popcll(m2)); atomicAdd(&st[19], __popcll(m3));
                                  atomicAdd(&st[20], 1); }      // [20] wavefront steps
             }
 #endif
-            pass = pass && ai[0] <= kh0 && kl0 <= ai[3] && ai[1] <= kh1 && kl1 <= ai[4] && ai[2] <= kh2 && kl2 <= ai[5];
-            pass = pass && ((h2.w ^ ck) & own_m) == 0;
-            const int g0 = h2.x, g1 = h2.y, g2 = h2.z;
-            return pass && !(g0 == hi_[8] || g0 == hi_[9] || g0 == hi_[10] || g1 == hi_[8] || g1 == hi_[9] || g1 == hi_[10] ||
-                             g2 == hi_[8] || g2 == hi_[9] || g2 == hi_[10]);
+            return act & same & coll & box & own;
         };
         // accepted pairs go to a wavefront-private queue and are appended to the partner lists
         // 64 at a time: the list cursors are returning atomics, one memory round trip each
@@ -709,22 +701,21 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
                 break;
             }
             if (62 + PEN_NC + d >= staged) {           // wave-uniform: the window's leading edge (entry 63 + d + PEN_NC - 1) reaches the next half
-                int hn[12];
+                int hn[8];
                 const int qn_ = i0 + staged + lane;
                 load_hdr(qn_, qn_ < bend_max, hn);
                 const int sl = (staged + lane) & 127;
                 tA[sl] = make_int4(hn[0], hn[1], hn[2], hn[3]);
                 tB[sl] = make_int4(hn[4], hn[5], hn[6], hn[7]);
-                tC[sl] = make_int4(hn[8], hn[9], hn[10], hn[11]);
                 staged += 64;
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();     // (d = 1 always refills: covers the first half too)
             }
-            int4 hA[PEN_NC], hB[PEN_NC], hC[PEN_NC];
+            int4 hA[PEN_NC], hB[PEN_NC];
 #pragma unroll
-            for (int c = 0; c < PEN_NC; ++c) { const int kk = (lane + d + c) & 127; hA[c] = tA[kk]; hB[c] = tB[kk]; hC[c] = tC[kk]; }
+            for (int c = 0; c < PEN_NC; ++c) { const int kk = (lane + d + c) & 127; hA[c] = tA[kk]; hB[c] = tB[kk]; }
             bool ps[PEN_NC];
 #pragma unroll
-            for (int c = 0; c < PEN_NC; ++c) ps[c] = test(qi + d + c < bend, hA[c], hB[c], hC[c]);
+            for (int c = 0; c < PEN_NC; ++c) ps[c] = test(qi + d + c < bend, hA[c], hB[c]);
 #pragma unroll
             for (int c = 0; c < PEN_NC; ++c) push(ps[c], hA[c].x);
         }
