@@ -375,8 +375,8 @@ void k_pen_g2(PenDev P, const int* __restrict__ want) {
                 while (nm && !any) {
                     const int q = __ffsll((long long)nm) - 1;
                     nm &= nm - 1;
-                    any = a6[0] <= s_pbox[q][3] && s_pbox[q][0] <= a6[3] && a6[1] <= s_pbox[q][4] && s_pbox[q][1] <= a6[4] &&
-                          a6[2] <= s_pbox[q][5] && s_pbox[q][2] <= a6[5];
+                    const int* pb = s_pbox[q];      // (all six comparisons, combined with `&`: `&&` compiles to a branch per condition)
+                    any = (a6[0] <= pb[3]) & (pb[0] <= a6[3]) & (a6[1] <= pb[4]) & (pb[1] <= a6[4]) & (a6[2] <= pb[5]) & (pb[2] <= a6[5]);
                 }
             }
             pk[u] = make_int2(0, 0);
@@ -556,7 +556,10 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
 // pair tests over the bucket-sorted entries of k_pen_grid; PEN_WALK_BLOCKS workgroups per frame
 __global__ __launch_bounds__(256)
 void k_pen_walk(PenDev P, const int* __restrict__ want) {
-    __shared__ __align__(16) int s_tile[4 * 128 * 8];        // per wavefront: a sliding window of 128 entry headers (32 bytes each)
+#ifndef PEN_WIN
+#define PEN_WIN 128
+#endif
+    __shared__ __align__(16) int s_tile[4 * PEN_WIN * 8];    // per wavefront: a sliding window of PEN_WIN entry headers (32 bytes each)
     __shared__ int s_queue[4 * 256];
     __shared__ unsigned long long s_mask[64];
     const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -583,7 +586,7 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
     // to both triangles' partner lists -- unless the triangles share a vertex, which is looked at when the
     // queue of accepted pairs is flushed (neighbours are almost always of one part or of parent and child,
     // which the part mask has already turned away: the vertex ids are not worth 16 bytes of every header).
-    int* tile = s_tile + wv * 128 * 8;
+    int* tile = s_tile + wv * PEN_WIN * 8;
     int* pc = P.pcount + (size_t)b * F;
     int* part = P.partners + (size_t)b * F * P.pcap;
     // (every load unconditional, from a clamped index: written as `ok ? p[i] : 0` each of the loads became its own
@@ -622,7 +625,7 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
         __builtin_amdgcn_wave_barrier();
     };
     int4* tA = reinterpret_cast<int4*>(tile);        // [128] entry | cell | lo.x | lo.y
-    int4* tB = tA + 128;                             // [128] lo.z | hi.x | hi.y | hi.z
+    int4* tB = tA + PEN_WIN;                         // [PEN_WIN] lo.z | hi.x | hi.y | hi.z
     for (int i0 = (blockIdx.x * 4 + wv) * 64; i0 < s_total; i0 += gridDim.x * 256) {
         const int qi = i0 + lane;
         const bool vi = qi < s_total;
@@ -692,7 +695,7 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
 #endif
         // (not more: a refill overwrites entries staged - 128 .. staged - 65 of the 128-entry window; it is triggered by the leading
         //  edge 63 + d + PEN_NC - 1 reaching `staged`, i.e. at some d >= staged - 62 - PEN_NC, and lane 0 still needs entry d)
-        static_assert(PEN_NC >= 1 && PEN_NC <= 2, "window of 128 entries, refills of 64");
+        static_assert(PEN_NC >= 1 && PEN_NC <= PEN_WIN - 126, "window of PEN_WIN entries, refills of 64");
         for (int d = 1; ; d += PEN_NC) {
             const bool act0 = qi + d < bend;
             if (!__ballot(act0)) break;
@@ -704,7 +707,7 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
                 int hn[8];
                 const int qn_ = i0 + staged + lane;
                 load_hdr(qn_, qn_ < bend_max, hn);
-                const int sl = (staged + lane) & 127;
+                const int sl = (staged + lane) & (PEN_WIN - 1);
                 tA[sl] = make_int4(hn[0], hn[1], hn[2], hn[3]);
                 tB[sl] = make_int4(hn[4], hn[5], hn[6], hn[7]);
                 staged += 64;
@@ -712,7 +715,7 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
             }
             int4 hA[PEN_NC], hB[PEN_NC];
 #pragma unroll
-            for (int c = 0; c < PEN_NC; ++c) { const int kk = (lane + d + c) & 127; hA[c] = tA[kk]; hB[c] = tB[kk]; }
+            for (int c = 0; c < PEN_NC; ++c) { const int kk = (lane + d + c) & (PEN_WIN - 1); hA[c] = tA[kk]; hB[c] = tB[kk]; }
             bool ps[PEN_NC];
 #pragma unroll
             for (int c = 0; c < PEN_NC; ++c) ps[c] = test(qi + d + c < bend, hA[c], hB[c]);
@@ -829,7 +832,7 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
             const int* mine = part + (size_t)ff * P.pcap;
             const int x = mine[slot];
             int rank = 0;
-            for (int r = 0; r < cc; ++r) { const int y = mine[r]; rank += (y < x) || (y == x && r < slot); }
+            for (int r = 0; r < cc; ++r) { const int y = mine[r]; rank += (int)((y < x) | ((y == x) & (r < slot))); }
             if (off + rank < P.pair_cap) { plist[off + rank] = x; pown[off + rank] = ff; }
         }
         __builtin_amdgcn_wave_barrier();
