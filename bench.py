@@ -784,8 +784,8 @@ def main():
                                    "share_of_step": ms_p * args.prof_every / (1e3 * dt),
                                    "bytes_per_launch": by_col * u_p / n_p,
                                    "note": "latency- and issue-bound: fifteen dependent kernels per round whose per-frame chains (counting sort "
-                                           "of one frame's grid entries by one 1024-lane workgroup in k_pen_g3, bucket walks at ~70 VALU "
-                                           "instructions per candidate, list ranking) expose little parallelism per frame; per-kernel "
+                                           "of one frame's grid entries by one 1024-lane workgroup in k_pen_g3, bucket walks at ~25 vector + "
+                                           "~20 scalar instructions per candidate, list ranking) expose little parallelism per frame; per-kernel "
                                            "times and counters: profiles/r03_pen_*"}
             pmc_ok, pmc_note = pmc_is_current(os.path.join(ROOT, "profiles", "pmc_summary_pen.json"))
             if pmc_ok and B != 256:
