@@ -180,6 +180,14 @@ extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
             }
         M.dirs = m->mem.up(dirs);
         M.dirsT = m->mem.up(dirsT);
+        {   // tile-major copy for the forward GEMM: [tile][k][16 vertices x 3 coordinates]
+            const int ntile = M.Vpad / 16;
+            std::vector<float> dt((size_t)ntile * SFX_KD_PAD * 48, 0.f);
+            for (int tl = 0; tl < ntile; ++tl)
+                for (int k = 0; k < SFX_KD_PAD; ++k)
+                    std::memcpy(&dt[((size_t)tl * SFX_KD_PAD + k) * 48], &dirs[(size_t)k * LD + (size_t)tl * 48], 48 * sizeof(float));
+            M.dirs_tiled = m->mem.up(dt);
+        }
     }
     {
         std::vector<float> W(d->lbs_weights, d->lbs_weights + (size_t)V * SFX_J);

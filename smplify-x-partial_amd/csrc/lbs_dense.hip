@@ -79,9 +79,10 @@ void k_lbs_dense(DevModel M, BatchDev D) {
     // staging: 1024 (feat) + 384 (dirs) float4 per chunk: slots tid + q*256; q = 0..3 -> feat rows,
     // slot 4 -> dirs, slot 5 (tid < 128) -> dirs
     const float4* gA = reinterpret_cast<const float4*>(D.featR + (size_t)fb0 * SFX_KD_PAD);
-    const float4* gB = reinterpret_cast<const float4*>(M.dirs + (size_t)v0 * 3);
-    const int LD4 = (int)(LD / 4);
-    const int stepA = KC / 4, stepB = KC * LD4;
+    // dirs tile-major ([tile of 16 vertices][k][48]: the 98 KB a workgroup streams are ONE contiguous block and a chunk is
+    // 6 KB of consecutive float4 -- out of the k-major matrix it was 32 separate 192-byte pieces 240 KB apart per chunk)
+    const float4* gB = reinterpret_cast<const float4*>(M.dirs_tiled + (size_t)tile * SFX_KD_PAD * NB3);
+    const int stepA = KC / 4, stepB = KC * (NB3 / 4);
     int gA_off[4], lA_off[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {       // thread -> (frame, 4 consecutive k): 8 threads cover the 128 bytes a frame contributes to a chunk
@@ -90,9 +91,9 @@ void k_lbs_dense(DevModel M, BatchDev D) {
     }
     const int i4 = tid, i5 = tid + DT;
     const bool ok5 = i5 < B4;
-    const int gB4 = (i4 / (NB3 / 4)) * LD4 + i4 % (NB3 / 4), lB4 = (i4 / (NB3 / 4)) * LDB + (i4 % (NB3 / 4)) * 4;
+    const int gB4 = i4, lB4 = (i4 / (NB3 / 4)) * LDB + (i4 % (NB3 / 4)) * 4;
     const int j5 = ok5 ? i5 : 0;
-    const int gB5 = (j5 / (NB3 / 4)) * LD4 + j5 % (NB3 / 4), lB5 = (j5 / (NB3 / 4)) * LDB + (j5 % (NB3 / 4)) * 4;
+    const int gB5 = j5, lB5 = (j5 / (NB3 / 4)) * LDB + (j5 % (NB3 / 4)) * 4;
     float4 s0, s1, s2, s3, s4, s5;
 #define STAGE_LOAD(c) do { s0 = gA[gA_off[0] + (c) * stepA]; s1 = gA[gA_off[1] + (c) * stepA];         \
         s2 = gA[gA_off[2] + (c) * stepA]; s3 = gA[gA_off[3] + (c) * stepA];                            \
@@ -249,9 +250,10 @@ void k_lbs_dense16(DevModel M, BatchDev D) {
     const bool active = wv * 16 < fpb && b0 < B;
     // staging: 512 (feat) + 384 (dirs) float4 per chunk
     const float4* gA = reinterpret_cast<const float4*>(D.featR + (size_t)fb0 * SFX_KD_PAD);
-    const float4* gB = reinterpret_cast<const float4*>(M.dirs + (size_t)v0 * 3);
-    const int LD4 = (int)(LD / 4);
-    const int stepA = KC / 4, stepB = KC * LD4;
+    // dirs tile-major ([tile of 16 vertices][k][48]: the 98 KB a workgroup streams are ONE contiguous block and a chunk is
+    // 6 KB of consecutive float4 -- out of the k-major matrix it was 32 separate 192-byte pieces 240 KB apart per chunk)
+    const float4* gB = reinterpret_cast<const float4*>(M.dirs_tiled + (size_t)tile * SFX_KD_PAD * NB3);
+    const int stepA = KC / 4, stepB = KC * (NB3 / 4);
     int gA_off[2], lA_off[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -260,9 +262,9 @@ void k_lbs_dense16(DevModel M, BatchDev D) {
     }
     const int i4 = tid, i5 = tid + DT;
     const bool ok5 = i5 < B4;
-    const int gB4 = (i4 / (NB3 / 4)) * LD4 + i4 % (NB3 / 4), lB4 = (i4 / (NB3 / 4)) * LDB + (i4 % (NB3 / 4)) * 4;
+    const int gB4 = i4, lB4 = (i4 / (NB3 / 4)) * LDB + (i4 % (NB3 / 4)) * 4;
     const int j5 = ok5 ? i5 : 0;
-    const int gB5 = (j5 / (NB3 / 4)) * LD4 + j5 % (NB3 / 4), lB5 = (j5 / (NB3 / 4)) * LDB + (j5 % (NB3 / 4)) * 4;
+    const int gB5 = j5, lB5 = (j5 / (NB3 / 4)) * LDB + (j5 % (NB3 / 4)) * 4;
     float4 s0, s1, s4, s5;
 #define ST3_LOAD(c) do { s0 = gA[gA_off[0] + (c) * stepA]; s1 = gA[gA_off[1] + (c) * stepA];            \
         s4 = gB[gB4 + (c) * stepB]; s5 = gB[gB5 + (c) * stepB]; } while (0)

@@ -86,7 +86,8 @@ struct DevModel {
     int level_start[SFX_MAX_LEVELS + 1];
     // constants
     const float* v_template;   // [V][3]
-    const float* dirs;         // [KD][3*Vpad]  k-major, coords interleaved (dense GEMM B operand)
+    const float* dirs;         // [KD_PAD][3*Vpad]  k-major, coords interleaved (the adjoint GEMM's operand)
+    const float* dirs_tiled;   // [Vpad/16][KD_PAD][48]  the same matrix, one contiguous block per 16-vertex tile (dense GEMM B operand)
     const float* dirsT;        // [V][3][KD_PAD] vertex-major (needed-rows path)
     const float* W;            // [V][J]
     const float* WT;           // [JPAD][Vpad]   (dense skinning GEMM B operand)
