@@ -40,6 +40,130 @@ PEAK_MFMA_F32 = 157.3e12      # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector pea
 PEAK_HBM = 8.0e12
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# The ONE line of the contract carries numbers and short tags only (< LINE_LIMIT bytes, strict JSON: the driver keeps the
+# last 8 000 bytes of stdout and parses the line from there -- round 3's 20-KB line was cut and counted as unmeasured);
+# everything else -- per-frame arrays, per-stage lists, the prose that explains a figure -- goes to the detail file
+# (gpurun_out/bench_detail_<tag>.json, copied into profiles/ for the rounds' records) and to stderr.
+LINE_LIMIT = 4096
+
+
+def _num(v, sig=6):
+    """JSON-safe scalar: floats rounded to `sig` significant digits, NaN / inf -> None, numpy scalars -> python."""
+    if v is None or isinstance(v, (bool, str)):
+        return v
+    if isinstance(v, (int, np.integer)):
+        return int(v)
+    v = float(v)
+    if not np.isfinite(v):
+        return None
+    return float("%.*g" % (sig, v))
+
+
+def _pick(d, keys, sig=6):
+    return {k: _num(d[k], sig) for k in keys if d is not None and k in d and not isinstance(d[k], (list, dict, tuple))}
+
+
+def sanitize(o):
+    """Deep copy of a report with every NaN / inf replaced by None and numpy types unwrapped (strict JSON)."""
+    if isinstance(o, dict):
+        return {str(k): sanitize(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [sanitize(v) for v in o]
+    if isinstance(o, np.ndarray):
+        return sanitize(o.tolist())
+    if isinstance(o, (np.floating, float)):
+        return float(o) if np.isfinite(o) else None
+    if isinstance(o, np.integer):
+        return int(o)
+    return o
+
+
+ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "frac_executed", "mfma_busy_frac",
+                 "avg_launch_us", "launches", "frames_per_launch", "share_of_step", "hbm_frac", "bytes_per_launch",
+                 "bytes_per_frame_launch", "rows_per_frame_launch", "columns_per_launch", "bytes_per_column_launch",
+                 "grid_entries_per_column", "pairs_per_column", "launches_per_round")
+
+
+def compact_line(full):
+    """The contract line from the full report: contract keys verbatim, every object reduced to its scalar figures."""
+    line = {k: _num(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                           "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = full.get("config", {})
+    line["config"] = _pick(cfg, ("workload", "frames_per_gpu", "lbs_mode", "gemm_columns_per_gpu", "parallelism",
+                                 "closure_evals_per_frame_mean", "closure_evals_per_frame_max", "closure_evals_per_s",
+                                 "reference_equiv_evals_per_frame_mean", "final_loss_mean", "final_loss_median", "non_finite",
+                                 "single_gpu_same_job_frames_per_s", "per_gpu_frames_per_s_min", "per_gpu_frames_per_s_mean",
+                                 "per_gpu_closure_evals_max", "gather_ms_max"))
+    for name in ("roofline", "roofline_tick", "roofline_pen"):
+        if name in full:
+            line[name] = _pick(full[name], ROOFLINE_KEYS)
+            line[name].setdefault("traffic", None)
+    cb = full.get("cpu_baseline")
+    if cb is not None:
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "mode", "closure_evals_per_s", "cpu_model", "error"))
+    rp = full.get("reference_parity")
+    if rp is not None:      # second half of BASELINE's metric: final-loss delta vs the reference's own fits
+        line["reference_parity"] = _pick(rp, ("frames", "final_loss_rel_delta_mean", "final_loss_rel_delta_median",
+                                              "final_loss_rel_delta_signed_mean", "reference_f32_vs_f64_rel_delta_mean",
+                                              "reference_f32_vs_f64_rel_delta_median", "camera_stage_loss_rel_delta_max",
+                                              "closure_evals_mean", "reference_closure_evals_f32_mean", "error"), sig=4)
+    cp = full.get("closure_parity")
+    if cp is not None:
+        line["closure_parity"] = _pick(cp, ("loss_rel_err_max", "grad_rel_err_max", "error"), sig=3)
+    if "value_min3_camera_keypoints" in full:
+        line["value_min3_camera_keypoints"] = _num(full["value_min3_camera_keypoints"])
+    if isinstance(full.get("alt"), dict):
+        line["alt"] = _pick(full["alt"], ("lbs_mode", "value", "unit", "ms_per_step", "closure_evals_per_frame_mean", "final_loss_median"))
+    if "kernels_ms_avg" in full:
+        line["kernels_ms_avg"] = _pick(full["kernels_ms_avg"], ("lbs_dense", "tick_dense", "fit_rows", "penetration"))
+    if "detail" in full:
+        line["detail"] = full["detail"]
+    # strings are tags: anything longer than 160 characters is prose and belongs to the detail file
+    def clip(o):
+        if isinstance(o, dict):
+            return {k: clip(v) for k, v in o.items()}
+        return o[:160] if isinstance(o, str) else o
+    line = clip(line)
+    # never exceed the limit: shed the optional objects, least essential first
+    for drop in ("kernels_ms_avg", "alt", "closure_parity", "roofline_pen", "roofline_tick", "reference_parity"):
+        if len(json.dumps(line, allow_nan=False)) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+    return line
+
+
+def write_detail(full, tag):
+    """The long form of the report: gpurun_out/bench_detail_<tag>.json (merged back from the GPU box; the rounds' records
+    are copied into profiles/).  Returns the path relative to the repository root, or None if it could not be written."""
+    rel = os.path.join("gpurun_out", "bench_detail_%s.json" % tag)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, rel), "w") as f:
+            json.dump(sanitize(full), f, indent=1, allow_nan=False)
+        return rel
+    except Exception as e:          # a read-only tree must not cost the measurement
+        print("[bench] detail file not written: %r" % e, file=sys.stderr)
+        return None
+
+
+def item_rows_by_class(joint_map, n_extra, n_lmk, nbj):
+    """Vertex items (blend-shape row triples) under the live keypoints of the three stage classes -- body only | + hands |
+    all -- for a joint map (SFX model source indices: < 55 kinematic joint, then extra vertices (1 item), static landmarks
+    (3 items: face corners), dynamic contour landmarks (3 items)); keypoints are ordered body | hands (42) | face."""
+    per_k = [0 if s < 55 else (1 if s < 55 + n_extra else 3) for s in np.asarray(joint_map).tolist()]
+    K = len(per_k)
+    return [int(sum(per_k[:min(K, nbj)])), int(sum(per_k[:min(K, nbj + 42)])), int(sum(per_k))]
+
+
+def tick_bytes_per_frame_launch(rows_live, n_var_live, use_vposer, vposer_bytes=0.0, kd=506, hist=100):
+    """Algorithmic bytes one frame's pass through k_tick_dense must move per launch: the adjoint streams 3 blend-shape
+    rows (kd floats + 16 B of skinning) per live vertex item (forward offsets come from the GEMM); the two-loop
+    recursion reads 2 x hist history rows of the live optimiser variables; 8 work vectors; with VPoser the decoder's
+    weights forward (next pose) and transposed (gradient)."""
+    return rows_live * (3 * kd + 16) * 4.0 + 2.0 * hist * n_var_live * 4.0 + 8 * n_var_live * 4.0 + (2.0 * vposer_bytes if use_vposer else 0.0)
+
+
 # The headline (`value`) is measured on SURVEY.md 8(d)'s generator VERBATIM: confidences U(0.3, 1), 10 % of the keypoints
 # dropped, nothing else -- the sequence rounds 1 and 2 (first half) were measured on.  About 5 % of those frames lose two
 # of the four camera-initialisation keypoints; their camera is under-determined (the reference's own fp32 / fp64 runs
@@ -203,12 +327,14 @@ def cpu_baseline_report(m, ref_evals_per_frame):
             "latency": {"value": lat, "processes": 1, "threads": m["latency_threads"], "closure_evals_per_s": m["latency_evals_per_s"]},
             "throughput": {"value": thr, "processes": m["throughput_processes"], "threads_per_process": 1,
                            "closure_evals_per_s": m["throughput_evals_per_s"]},
-            "sample": "oracle frame driver (torch fp32; dense LBS forward + autograd backward per closure evaluation) on this "
-                      "benchmark's frames: latency mode 1 process x %d threads on frame 0 for %.0f s = %d evaluations; throughput "
-                      "mode %d single-threaded processes on frames 0..%d for %.0f s = %d evaluations; frames/s = evaluations/s / "
-                      "%.0f reference-equivalent evaluations per fitted frame" % (
-                          m["latency_threads"], m["latency_s"], m["latency_evals"], m["throughput_processes"],
-                          m["throughput_processes"] - 1, m["throughput_s"], m["throughput_evals"], per)}
+            "closure_evals_per_s": max(m["latency_evals_per_s"], m["throughput_evals_per_s"]),
+            "sample": "oracle fit (torch fp32) of this job's frames 0..%d: %d procs x 1 thread x %.0f s = %d closure evals; / %.0f evals per frame" % (
+                m["throughput_processes"] - 1, m["throughput_processes"], m["throughput_s"], m["throughput_evals"], per),
+            "sample_detail": {"latency_mode": "1 process x %d threads on frame 0 for %.0f s = %d evaluations" % (m["latency_threads"], m["latency_s"], m["latency_evals"]),
+                              "throughput_mode": "%d single-threaded processes on frames 0..%d for %.0f s = %d evaluations" % (
+                                  m["throughput_processes"], m["throughput_processes"] - 1, m["throughput_s"], m["throughput_evals"]),
+                              "closure": "dense LBS forward + autograd backward per evaluation",
+                              "evals_per_fitted_frame": per}}
 
 
 def csrc_sha():
@@ -567,6 +693,8 @@ def main():
     prof_every = 1 if args.lbs == "rows" else args.prof_every
     engine.prof_enable(True, every=prof_every)
     engine.prof_reset()
+    if pen:
+        engine.pen_work_reset()
     sync()
     t0 = time.time()
     for _ in range(args.steps):
@@ -578,6 +706,7 @@ def main():
     engine.prof_enable(False)
     # per-kernel HIP-event figures of the headline region (read before the side runs add their launches)
     prof = {k: engine.prof_get(k) for k in ("lbs_dense", "tick", "fit_rows", "penetration")}
+    pen_work = engine.pen_work_get() if pen else None      # device counts over the timed region: grid entries, ordered pairs, columns
     # side key: the same job on the detector that keeps >= 3 of the 4 camera-initialisation keypoints (round 2's headline)
     side_min3 = None
     if not (full or pen) and not args.no_side:
@@ -630,24 +759,17 @@ def main():
         ms_dense, n_dense, u_dense = prof["lbs_dense"]
         ms_clo, n_clo, u_clo = prof["tick"]
         ms_lb, n_lb, _ = prof["fit_rows"]
+        tag = {"body": "configs[1]" if world == 1 else "configs[3]", "full": "configs[2]", "pen": "configs[4]"}[args.workload]
+        what = {"body": "body-only K=25, camera + 5-stage L-BFGS (fit_smplx_smplifyx.yaml weights, use_vposer=False, synthetic regression prior)",
+                "full": "hands+face+contour K=135, VPoser decode in the loop (z0=0), camera + 5-stage L-BFGS (fit_smplx_smplifyx.yaml)",
+                "pen": "fit_smplx_combined_halpe.yaml verbatim: K=136, combined prior + camera prior, interpenetration (128 / 1e-4), camera + 3 stages"}[args.workload]
         out = {
             "metric": "fitted frames/sec", "value": world * B * args.steps / dt, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("configs[4]: %d synthetic frames/GPU, neutral SMPL-X-shaped synthetic model (surface-like mesh, "
-                                    "synthetic part labels), cfg_files/fit_smplx_combined_halpe.yaml verbatim: hands + face + contour "
-                                    "halpe keypoints K=136, synthetic combined regression prior + camera prior, interpenetration "
-                                    "term (max_collisions 128, df_cone_height 1e-4, coll_loss_weights [0, 0.1, 1]), camera stage + "
-                                    "3-stage L-BFGS" % B) if pen else
-                                   ("configs[2]: %d synthetic frames/GPU, neutral SMPL-X-shaped synthetic model, hands + face + "
-                                    "contour K=135, synthetic VPoser decoded in the loop (latent 32, z0 = 0), camera stage + "
-                                    "5-stage L-BFGS (fit_smplx_smplifyx.yaml)" % B) if full else
-                                   ("configs[%d]: %d synthetic frames/GPU%s, neutral SMPL-X-shaped synthetic model, "
-                                    "body-only K=25, camera stage + 5-stage L-BFGS (fit_smplx_smplifyx.yaml weights, "
-                                    "use_vposer=False, synthetic regression prior)%s" % (
-                                        1 if world == 1 else 3, B, "" if world == 1 else " = %d frames sharded over %d GPUs" % (world * B, world),
-                                        "" if world == 1 else ", one RCCL all_gather of the fitted-parameter records per step")),
+            "config": {"workload": "%s: %d synthetic frames/GPU%s, synthetic SMPL-X, %s" % (
+                           tag, B, "" if world == 1 else " x %d GPUs, 1 RCCL all_gather/step" % world, what),
                        "keypoints": "SURVEY 8(d) verbatim: projected model joints + 1 px noise, confidences U(0.3, 1), 10 % of the keypoints "
                                     "dropped (the sequence of rounds 1-2a; `value_min3_camera_keypoints` = the same job when the detector "
                                     "keeps at least 3 of the 4 camera-initialisation keypoints, round 2's headline sequence)",
@@ -665,6 +787,7 @@ def main():
                                      "to fp32 before the projection"},
             "kernels_ms_avg": {"lbs_dense": ms_dense / max(n_dense, 1), "tick_dense": ms_clo / max(n_clo, 1),
                                "fit_rows": ms_lb / max(n_lb, 1),
+                               "penetration": prof["penetration"][0] / max(prof["penetration"][1], 1),
                                "timed_launches_per_step": (n_dense + n_clo + n_lb) / max(args.steps, 1)},
         }
         out["config"].update(loss_distribution(st["stage_loss"][:, -1]))
@@ -674,6 +797,27 @@ def main():
         if ranks is not None:
             out["ranks"] = ranks
             out["config"]["closure_evals_per_s"] = float(sum(r["closure_evals_total"] for r in ranks) * args.steps / dt)
+            # the per-GPU rate of THIS job size: a rank's own B frames over its own time, before it waits for the others.
+            # rank 0's is a single-GPU run of the same job (frames are independent, no data-path collective), so scaling
+            # efficiency on equal jobs is value / (n_gpus x single_gpu_same_job); the driver's N=1 line is configs[1]'s
+            # smaller job (256 frames) and is not the denominator
+            rates = [r["frames_per_s"] for r in ranks]
+            out["config"].update(per_gpu_frames_per_s_min=min(rates), per_gpu_frames_per_s_mean=float(np.mean(rates)),
+                                 single_gpu_same_job_frames_per_s=rates[0],
+                                 per_gpu_closure_evals_max=max(r["closure_evals_per_frame_max"] for r in ranks),
+                                 gather_ms_max=max(r["gather_ms_last_step"] for r in ranks))
+        # counter-derived figures are REPLAYED from the profile of the same command (one summary per workload: tools/run_prof.sh)
+        pmc_name = "pmc_summary_full.json" if full else "pmc_summary_pen.json" if pen else "pmc_summary.json"
+        pmc = os.path.join(ROOT, "profiles", pmc_name)
+        pmc_ok, pmc_note = pmc_is_current(pmc)
+        if pmc_ok and B != 256:     # (the counter passes run the default 256 frames per GPU: per-launch traffic of another job size is not theirs)
+            pmc_ok, pmc_note = False, "profiles/%s was taken at 256 frames per GPU, this run has %d: traffic not replayed" % (pmc_name, B)
+        pj = json.load(open(pmc)) if pmc_ok else {}
+
+        def pmc_kernel(prefix):
+            """the instantiation with the most launches whose name contains `prefix` (templates: k_tick_dense<FrameLDSx<32, false>, 1>)"""
+            cands = [v for n, v in pj.items() if prefix in n and isinstance(v, dict) and "hbm_read_bytes_per_launch" in v]
+            return max(cands, key=lambda v: v.get("FETCH_SIZE", {}).get("launches", 0)) if cands else {}
         if args.lbs == "dense" and n_dense:
             # active-frame compaction makes the frames per launch vary: achieved = total algorithmic
             # flops of all launches / total kernel time (HIP events on the launch stream)
@@ -695,18 +839,11 @@ def main():
                                     "note": "achieved = SURVEY 8(d) algorithmic flops (dense 55-joint skinning product, 45.85 "
                                             "MFLOP/frame) / kernel time; achieved_executed counts only issued MFMA work "
                                             "(K padded to 512, skinning restricted to the %.1f joints per 16-vertex tile that "
-                                            "carry weight)" % tj})
-            # (one summary per workload: the body-only headline, --workload full, --workload pen -- tools/run_prof.sh TAG)
-            pmc_name = "pmc_summary_full.json" if full else "pmc_summary_pen.json" if pen else "pmc_summary.json"
-            pmc = os.path.join(ROOT, "profiles", pmc_name)
-            pmc_ok, pmc_note = pmc_is_current(pmc)
-            if pmc_ok and B != 256:     # (the counter passes run the default 256 frames per GPU: per-launch traffic of another job size is not theirs)
-                pmc_ok, pmc_note = False, "profiles/%s was taken at 256 frames per GPU, this run has %d: traffic not replayed" % (pmc_name, B)
+                                            "carry weight); mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES of the profiled run" % tj})
             if not pmc_ok:
                 out["roofline"]["traffic_note"] = pmc_note
-            if pmc_ok:     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/run_prof.sh)
-                pj = json.load(open(pmc))
-                k = pj.get("k_lbs_dense16", {})
+            else:           # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/run_prof.sh)
+                k = pmc_kernel("k_lbs_dense16")
                 if "hbm_read_bytes_per_launch" in k and "hbm_write_bytes_per_launch" in k:
                     out["roofline"]["traffic"] = k["hbm_read_bytes_per_launch"] + k["hbm_write_bytes_per_launch"]
                     out["roofline"]["traffic_detail"] = {
@@ -715,26 +852,41 @@ def main():
                         "source": "replayed: profiles/" + pmc_name + ", the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                   "command (tools/run_prof.sh; counters cannot be read inside an un-profiled run), FETCH_SIZE x2 "
                                   "per the gfx950 correction"}
-            # the other half of the step: loss + adjoint + L-BFGS tick + next pose / chain, one workgroup per frame.
-            # algorithmic bytes per active frame and launch: needed-rows constants (11 rows x (3 x 506 + 16) floats, forward
-            # offsets come from the GEMM: adjoint only) + optimiser vectors + the two-loop recursion's history (2 m N floats,
-            # m = history pairs held, N = 119 live variables) -- SURVEY 8(d) "L-BFGS state traffic"
+                if "mfma_busy_frac" in k:
+                    out["roofline"]["mfma_busy_frac"] = k["mfma_busy_frac"]
+            # the other half of the step: loss + adjoint + L-BFGS tick + next pose / chain, one workgroup per frame.  Byte model
+            # per frame and launch (tick_bytes_per_frame_launch) from THIS workload's own numbers: the vertex items under the
+            # keypoints that are live in a stage (body | + hands | all; fit_single_frame.py:569-572), weighted by the evaluations
+            # the run spent in each stage; the live optimiser variables; the VPoser decoder's weights when it is in the loop
             if n_clo:
-                rows = 11
-                by_frame = rows * (3 * 506 + 16) * 4.0 + 2.0 * 100 * 119 * 4.0 + 8 * 182 * 4.0
+                nbj = engine.NUM_BODY_JOINTS[cfg.get("format", "coco25")]
+                n_extra = len(model.get("extra_vertex_ids", engine.SMPLX_EXTRA_VERTEX_IDS))
+                rows_cls = item_rows_by_class(jm, n_extra, int(np.asarray(model["lmk_faces_idx"]).shape[0]), nbj)
+                sw_list, _ = engine.stage_weights_from_cfg(cfg)
+                cls_of = [2 if w.face_joint_weight != 0 else (1 if w.hand_joint_weight != 0 else 0) for w in sw_list]
+                ev_stage = st["stage_evals"].sum(0).astype(np.float64)           # [1 + stages]: camera stage first (all keypoints projected, 4 weighted)
+                wts = np.array([ev_stage[0]] + [ev_stage[1 + i] for i in range(len(cls_of))])
+                rws = np.array([rows_cls[2]] + [rows_cls[c] for c in cls_of], np.float64)
+                rows_live = float((wts * rws).sum() / max(wts.sum(), 1.0))
+                use_vp = bool(cfg.get("use_vposer", True))
+                n_live = (32 if use_vp else 63) + 3 + 10 + 3 + (24 + 3 + 3 + 3 + 10)          # embedding, orient, betas, cam | hands, jaw, eyes, expression
+                vp_bytes = 4.0 * (512 * 32 + 512 * 512 + 126 * 512 + 512 + 512 + 126) if use_vp else 0.0
+                by_frame = tick_bytes_per_frame_launch(rows_live, n_live, use_vp, vp_bytes)
                 t_clo = 1e-3 * ms_clo
                 act = u_clo if u_clo else fpl * n_clo
                 out["roofline_tick"] = {"kernel": "k_tick_dense", "bound": "hbm", "achieved": by_frame * act / t_clo / 1e9,
                                         "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": by_frame * act / t_clo / PEAK_HBM,
-                                        "traffic": None, "bytes_per_frame_launch": by_frame, "avg_launch_us": 1e6 * t_clo / n_clo,
+                                        "traffic": None, "bytes_per_frame_launch": by_frame, "rows_per_frame_launch": rows_live,
+                                        "bytes_per_launch": by_frame * act / n_clo,
+                                        "avg_launch_us": 1e6 * t_clo / n_clo,
                                         "launches": n_clo, "frames_per_launch": act / n_clo,
                                         "share_of_step": ms_clo * args.prof_every / (1e3 * dt),
+                                        "rows_by_stage_class": rows_cls, "live_variables": n_live, "vposer_weight_bytes": vp_bytes,
                                         "note": "latency-bound by construction (one frame's serial L-BFGS chain per workgroup): the "
-                                                "figure to watch is avg_launch_us; bytes = needed-rows adjoint + full history + vectors"}
+                                                "figure to watch is avg_launch_us; bytes = adjoint rows of the live vertex items "
+                                                "(evaluation-weighted over the stages) + history + vectors (+ 2 x VPoser weights)"}
                 if pmc_ok:
-                    # (a template instantiation: "void k_tick_dense<FrameLDSx<32, false>, 1>"; the variant with most launches)
-                    cands = [v for n, v in json.load(open(pmc)).items() if "k_tick_dense" in n and "hbm_read_bytes_per_launch" in v]
-                    k = max(cands, key=lambda v: v.get("FETCH_SIZE", {}).get("launches", 0)) if cands else {}
+                    k = pmc_kernel("k_tick_dense")
                     if "hbm_read_bytes_per_launch" in k:
                         out["roofline_tick"]["traffic"] = k["hbm_read_bytes_per_launch"] + k.get("hbm_write_bytes_per_launch", 0.0)
                         out["roofline_tick"]["traffic_source"] = "replayed: profiles/" + pmc_name
@@ -766,34 +918,37 @@ def main():
         if pen and prof["penetration"][1]:
             # the interpenetration step of a round (csrc/collide.hip k_pen_* + the dense skinning adjoint, csrc/lbs_adjoint.hip), timed
             # as ONE HIP-event scope per round.  Byte model per GEMM column whose stage carries a collision weight (F triangles, V
-            # vertices, E grid entries, P ordered pairs; E and P are read from the run): broad phase = vertices 12 V + faces 12 F +
-            # part labels 4 F read, boxes 24 F written and read back by the pair tests, entries 8 E written + (8 + 36) E read;
-            # narrow phase = pair list 8 P written and read, 2 x 36 B of geometry per pair read, 40 B per pair of per-pair results
-            # written and read, per-triangle sums 40 F, vertex gradient 12 V written; adjoint = d v_posed 12 V written and read by
-            # the fp32-MFMA GEMM (whose 63.7 MB of blend-shape rows are shared by the launch: not in the per-column figure).
+            # vertices, E grid entries, P ordered pairs -- E and P are COUNTED on the device over the timed region,
+            # engine.pen_work_get): broad phase = vertices 12 V + faces 12 F + part labels 4 F read, boxes 24 F written and read
+            # back by the pair tests, entries 8 E written + (8 + 36) E read; narrow phase = pair list 8 P written and read, 2 x 36 B
+            # of geometry per pair read, 40 B per pair of per-pair results written and read, per-triangle sums 40 F, vertex gradient
+            # 12 V written; adjoint = d v_posed 12 V written and read by the fp32-MFMA GEMM (whose 63.7 MB of blend-shape rows are
+            # shared by the launch: not in the per-column figure).
             ms_p, n_p, u_p = prof["penetration"]
             V_, F_ = dm.V, dm.F
-            E_, P_ = 10000.0, 8000.0        # typical of the synthetic surface mesh in these fits (engine.FrameBatch.penetration_stats)
+            E_, P_, cols = pen_work["entries_per_column"], pen_work["pairs_per_column"], pen_work["columns"]
             by_col = (12 * V_ + 12 * F_ + 4 * F_ + 2 * 24 * F_ + (8 + 8 + 36) * E_) + (2 * 8 * P_ + 72 * P_ + 2 * 40 * P_ + 40 * F_ + 12 * V_) + 2 * 12 * V_
             t_p = 1e-3 * ms_p
-            out["roofline_pen"] = {"kernels": "k_pen_want, k_pen_reset, k_pen_g1, k_pen_g2, k_pen_g3, k_pen_walk, k_pen_list, k_pen_rank, k_pen_eval, k_pen_facesum, k_pen_gather, k_adj_prep, "
-                                              "k_lbs_dense_adj, k_adj_reduce, k_adj_dA (one HIP-event scope per round)",
-                                   "bound": "hbm", "achieved": by_col * u_p / t_p / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                                   "frac": by_col * u_p / t_p / PEAK_HBM, "traffic": None, "bytes_per_column_launch": by_col,
-                                   "avg_scope_us": 1e6 * t_p / n_p, "launches": n_p, "columns_per_launch": u_p / n_p,
+            # columns that carried a collision weight per timed scope: counted on the device (cols over all scopes of the
+            # timed region) -- the scope's `units` are all active columns, with or without the weight
+            n_scopes_all = max(n_p * args.prof_every, 1)
+            want_per_launch = cols / n_scopes_all
+            out["roofline_pen"] = {"kernel": "k_pen_* + k_adj_* (one HIP-event scope per round)",
+                                   "bound": "hbm", "achieved": by_col * want_per_launch * n_p / t_p / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                                   "frac": by_col * want_per_launch * n_p / t_p / PEAK_HBM, "traffic": None, "bytes_per_column_launch": by_col,
+                                   "avg_launch_us": 1e6 * t_p / n_p, "launches": n_p, "columns_per_launch": want_per_launch,
+                                   "active_columns_per_launch": u_p / n_p,
+                                   "grid_entries_per_column": E_, "pairs_per_column": P_,
                                    "share_of_step": ms_p * args.prof_every / (1e3 * dt),
-                                   "bytes_per_launch": by_col * u_p / n_p,
-                                   "note": "latency- and issue-bound: fifteen dependent kernels per round whose per-frame chains (counting sort "
-                                           "of one frame's grid entries by one 1024-lane workgroup in k_pen_g3, bucket walks at ~25 vector + "
-                                           "~20 scalar instructions per candidate, list ranking) expose little parallelism per frame; per-kernel "
-                                           "times and counters: profiles/r03_pen_*"}
-            pmc_ok, pmc_note = pmc_is_current(os.path.join(ROOT, "profiles", "pmc_summary_pen.json"))
-            if pmc_ok and B != 256:
-                pmc_ok, pmc_note = False, "profiles/pmc_summary_pen.json was taken at 256 frames per GPU, this run has %d: traffic not replayed" % B
+                                   "bytes_per_launch": by_col * want_per_launch,
+                                   "launches_per_round": pen_work.get("launches_per_round"),
+                                   "note": "latency- and issue-bound: dependent kernels per round whose per-frame chains (counting sort "
+                                           "of one frame's grid entries in k_pen_g3, bucket walks at ~25 vector + ~20 scalar instructions "
+                                           "per candidate, list ranking) expose little parallelism per frame; E and P are device counts "
+                                           "over the timed region; per-kernel times and counters: profiles/r04_pen_*"}
             if pmc_ok:
-                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary_pen.json")))
                 tr = sum(v.get("hbm_read_bytes_per_launch", 0.0) + v.get("hbm_write_bytes_per_launch", 0.0) for k, v in pj.items()
-                         if k.startswith(("k_pen_", "k_adj_", "k_lbs_dense_adj")))
+                         if isinstance(v, dict) and k.startswith(("k_pen_", "k_adj_", "k_lbs_dense_adj")))
                 out["roofline_pen"]["traffic"] = tr
                 out["roofline_pen"]["traffic_source"] = "replayed: profiles/pmc_summary_pen.json (sum over the scope's kernels, FETCH_SIZE x 2 + WRITE_SIZE)"
             else:
@@ -815,7 +970,12 @@ def main():
         if cpu_meas is not None:
             out["cpu_baseline"] = cpu_baseline_report(cpu_meas, float(ref_evals.mean())) if "error" not in cpu_meas \
                 else {"value": None, "error": cpu_meas["error"]}
-        print(json.dumps(out))
+        dtag = args.workload + ("" if args.lbs == "dense" else "_" + args.lbs) + ("" if world == 1 else "_n%d" % world) + \
+            ("" if B in (256, 1024) and not args.slots else "_f%d" % B + ("_s%d" % args.slots if args.slots else ""))
+        out["detail"] = write_detail(out, dtag)
+        line = json.dumps(compact_line(out), allow_nan=False)
+        assert len(line) < LINE_LIMIT and "\n" not in line, len(line)
+        print(line, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -117,6 +117,10 @@ extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float
 extern "C" int sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host);
 int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
                         float* loss_dev, float* dverts_dev, const int* want_dev, void* stream);
+int sfx_pen_capacity(const sfx_pen* h);          // meshes per call the handle's buffers hold (collide.hip)
+int sfx_pen_stats_from(const int* stats_dev, int n, int32_t* stats_host);
+int sfx_pen_stats_stride(void);
+const int* sfx_pen_stats_dev(const sfx_pen* h);
 
 struct sfx_model {
     DevModel M{};
@@ -145,6 +149,8 @@ struct sfx_batch {
     int K = 0;
     sfx_pen* pen = nullptr;       // interpenetration operator (cfg.interpenetration)
     float pen_sigma = 0.f; int pen_outside = 1;
+    int* pen_stats_all = nullptr; // [B][stride] diagnostics of a CHUNKED evaluation (stand-alone call on a pooled batch), else unused
+    bool pen_chunked = false;     // the most recent evaluation was chunked: sfx_batch_pen_stats reads pen_stats_all
 };
 
 extern "C" int sfx_model_create(const sfx_model_desc* d, sfx_model** out) {
@@ -951,14 +957,31 @@ static int eval_penetration(sfx_batch* b, int stage_override, hipStream_t s) {
     ProfScope p("penetration", s, D.nact);
     hipMemsetAsync(D.pen_want, 0, (size_t)D.cfg.B * sizeof(int), s);
     hipLaunchKernelGGL(k_pen_want, dim3((D.cfg.B + 63) / 64), dim3(64), 0, s, D, b->sw_dev, stage_override);
-    int rc = sfx_pen_eval_masked(b->pen, D.nact, D.verts, b->pen_sigma, b->pen_outside, D.pen_loss, D.pen_dverts, D.pen_want, s);
-    if (rc) return rc;
+    // the collision buffers hold one mesh per column of the POOL (cfg.slots); inside the fused loop nact never exceeds it.
+    // A stand-alone call on a pooled batch (sfx_batch_closure / sfx_batch_step: one column per frame, nact = B) walks the
+    // columns in chunks of the pool's size -- the buffers are scratch between launches, every result lands in per-frame arrays
+    const int cap = sfx_pen_capacity(b->pen);
+    const size_t V3 = (size_t)b->m->M.V * 3;
+    b->pen_chunked = D.nact > cap;
+    const int stride = sfx_pen_stats_stride();
+    if (b->pen_chunked && !b->pen_stats_all) {
+        b->pen_stats_all = b->mem.zeros<int>((size_t)D.cfg.B * stride);
+        if (!b->pen_stats_all) { sfx_set_error("out of device memory"); return -2; }
+    }
+    for (int c0 = 0; c0 < D.nact; c0 += cap) {
+        const int n = std::min(cap, D.nact - c0);
+        int rc = sfx_pen_eval_masked(b->pen, n, D.verts + c0 * V3, b->pen_sigma, b->pen_outside, D.pen_loss + c0, D.pen_dverts + c0 * V3,
+                                     D.pen_want + c0, s);
+        if (rc) return rc;
+        if (b->pen_chunked)     // keep this chunk's diagnostics: the next chunk reuses the rows
+            SFX_CHECK(hipMemcpyAsync(b->pen_stats_all + (size_t)c0 * stride, sfx_pen_stats_dev(b->pen), (size_t)n * stride * sizeof(int), hipMemcpyDeviceToDevice, s));
+    }
     hipMemsetAsync(D.ext_n, 0, (size_t)D.cfg.B * sizeof(int), s);        // k_adj_prep counts the vertices that carry a gradient
     launch_pen_adjoint(b->m->M, D, s);
     return 0;
 }
 
-static void eval_closure(sfx_batch* b, int stage_override, int from_X, hipStream_t s) {
+static int eval_closure(sfx_batch* b, int stage_override, int from_X, hipStream_t s) {
     const DevModel& M = b->m->M; const BatchDev& D = b->D;
     ClosureArgs a{};
     a.stage_override = stage_override; a.from_X = from_X;
@@ -968,18 +991,19 @@ static void eval_closure(sfx_batch* b, int stage_override, int from_X, hipStream
         ClosureArgs e = a; e.export_dense = 1; e.forward_only = 2;
         { ProfScope p("export", s); launch_closure(M, D, b->vl_dev, b->sw_dev, e, s); }
         { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
-        eval_penetration(b, stage_override, s);
+        if (int rc = eval_penetration(b, stage_override, s)) return rc;
         a.use_dense_verts = 1;
     }
     ProfScope p("closure", s);
     launch_closure(M, D, b->vl_dev, b->sw_dev, a, s);
+    return 0;
 }
 
 extern "C" int sfx_batch_closure(sfx_batch* b, int32_t stage, float* loss_out, float* grad_out, void* stream) {
     if (!b) { sfx_set_error("null batch"); return -1; }
     if (stage >= b->D.cfg.n_stages) { sfx_set_error("stage %d out of range", stage); return -1; }
     hipStream_t s = (hipStream_t)stream;
-    eval_closure(b, stage < 0 ? -1 : stage, 1, s);
+    if (int rc = eval_closure(b, stage < 0 ? -1 : stage, 1, s)) return rc;
     SFX_CHECK(hipStreamSynchronize(s));
     SFX_CHECK(hipGetLastError());
     const int B = b->D.cfg.B, N = b->vl_host[stage < 0 ? 0 : 1].n;
@@ -1163,7 +1187,7 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
         } else {
             const int POLL = dense ? 8 : 32;
             for (int q = 0; q < POLL; ++q, ++tick) {
-                eval_closure(b, -2, 0, s);
+                if (int rc = eval_closure(b, -2, 0, s)) return rc;
                 ProfScope p("lbfgs", s);
                 launch_lbfgs_tick(M, D, b->vl_dev, first_stage, last_stage, 0, step_mode, s);
             }
@@ -1356,7 +1380,8 @@ extern "C" int sfx_batch_pen_stats(sfx_batch* b, int32_t* stats_host /* [B][4] *
     if (!b || !stats_host) { sfx_set_error("null argument"); return -1; }
     if (!b->pen) { sfx_set_error("batch was created without interpenetration"); return -1; }
     const int n = std::max(1, b->D.nact);
-    int rc = sfx_pen_stats(b->pen, n, stats_host);
+    int rc = b->pen_chunked ? sfx_pen_stats_from(b->pen_stats_all, n, stats_host)
+                            : sfx_pen_stats(b->pen, std::min(n, sfx_pen_capacity(b->pen)), stats_host);
     if (rc) return rc;
     if (ext_n_host) SFX_CHECK(hipMemcpy(ext_n_host, b->D.ext_n, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     return 0;

@@ -98,6 +98,7 @@ struct PenDev {
     int* cells;                // [B][PEN_CELLS + 1] bucket END offsets into entries ([PEN_CELLS] = number of entries)
     float* gridp;              // [B][4] low corner of the frame's box, 1 / cell size
     int* stats;                // [B][PEN_STATS]: pairs (ordered), dropped partners, overflow of entries, cells, phase clocks
+    unsigned long long* work;  // [4] process-wide counts since sfx_pen_work_reset: grid entries, ordered pairs, column evaluations, surviving triangles
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -518,7 +519,8 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     int2* ent = P.entries + (size_t)b * P.ent_cap;
     const bool ent_ok = s_total <= P.ent_cap - 4;
     if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = PEN_CELLS; st[13] = 0; st[14] = s_total; st[15] = 0; for (int q = 4; q < 13; ++q) st[q] = 0;
-                  for (int q = 16; q < PEN_STATS; ++q) st[q] = 0; }
+                  for (int q = 16; q < PEN_STATS; ++q) st[q] = 0;
+                  if (P.work) { atomicAdd(&P.work[0], (unsigned long long)s_total); atomicAdd(&P.work[2], 1ull); atomicAdd(&P.work[3], (unsigned long long)NT); } }
     if (!ent_ok) {       // grid too crowded for the entry buffer: report, produce no pairs
         if (t == 0) { st[0] = 0; st[1] = 0; P.ptotal[b] = 0; cells[PEN_CELLS] = 0; }
         return;
@@ -776,7 +778,8 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
             acc += c;
         }
         const float to = block_sum_fixed((float)n_over, red);
-        if (t == 0) { const int tot = min(ptot, P.pair_cap); P.ptotal[b] = tot; st[0] = tot; st[1] = (int)to; }
+        if (t == 0) { const int tot = min(ptot, P.pair_cap); P.ptotal[b] = tot; st[0] = tot; st[1] = (int)to;
+                      if (P.work) atomicAdd(&P.work[1], (unsigned long long)tot); }
     }
     __syncthreads();
     for (int w = t; w < P.hasp_words; w += PEN_T) hasp[w] = s_has[w];
@@ -1058,6 +1061,32 @@ void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss
 }
 
 // ---------------------------------------------------------------------------------------------
+// Work actually done by the term since the last reset, counted on the device (one atomic per column evaluation): what the
+// benchmark's byte model of the step is computed from (bench.py roofline_pen) instead of "typical" constants.
+static unsigned long long* g_pen_work = nullptr;      // device [4], process-wide (shared by every handle)
+static unsigned long long* pen_work_buffer() {
+    if (!g_pen_work) {
+        if (hipMalloc((void**)&g_pen_work, 4 * sizeof(unsigned long long)) != hipSuccess) { g_pen_work = nullptr; return nullptr; }
+        hipMemset(g_pen_work, 0, 4 * sizeof(unsigned long long));
+    }
+    return g_pen_work;
+}
+extern "C" int sfx_pen_work_reset(void) {
+    if (!pen_work_buffer()) { sfx_set_error("out of device memory"); return -2; }
+    if (hipDeviceSynchronize() != hipSuccess || hipMemset(g_pen_work, 0, 4 * sizeof(unsigned long long)) != hipSuccess) { sfx_set_error("device error"); return -4; }
+    return 0;
+}
+extern "C" int sfx_pen_work_get(int64_t* out /* [4] */) {
+    if (!out) { sfx_set_error("null argument"); return -1; }
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!g_pen_work) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) { sfx_set_error("device error"); return -4; }
+    unsigned long long h[4];
+    if (hipMemcpy(h, g_pen_work, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { sfx_set_error("device error"); return -4; }
+    for (int i = 0; i < 4; ++i) out[i] = (int64_t)h[i];
+    return 0;
+}
+
 struct sfx_pen {
     PenDev P{};
     int Bmax = 0;
@@ -1085,6 +1114,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     sfx_pen* h = new sfx_pen();
     PenDev& P = h->P;
     P.V = V; P.F = F; P.cap = max_collisions; h->Bmax = max_batch;
+    P.work = pen_work_buffer();
     P.pcap = std::max(P.cap, std::min(2 * P.cap, 2048));
     std::vector<int> fv(faces, faces + (size_t)F * 3), sg(F, 0);
     int np = 1;
@@ -1133,6 +1163,8 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     *out = h;
     return 0;
 }
+
+int sfx_pen_capacity(const sfx_pen* h) { return h ? h->Bmax : 0; }
 
 extern "C" void sfx_pen_destroy(sfx_pen* h) {
     if (!h) return;
@@ -1206,12 +1238,12 @@ extern "C" int sfx_pen_phase_clocks(sfx_pen* h, int32_t B, int32_t* out) {
     return 0;
 }
 
-extern "C" int sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host /* [B][4] */) {
-    if (!h || !stats_host || B < 1 || B > h->Bmax) { sfx_set_error("bad arguments"); return -1; }
+// stats rows (device, [n][PEN_STATS]) -> the four public figures per mesh
+int sfx_pen_stats_from(const int* stats_dev, int n, int32_t* stats_host) {
     if (hipDeviceSynchronize() != hipSuccess) { sfx_set_error("device error"); return -4; }
-    std::vector<int> st((size_t)B * PEN_STATS);
-    hipMemcpy(st.data(), h->P.stats, st.size() * sizeof(int), hipMemcpyDeviceToHost);
-    for (int i = 0; i < B; ++i) {
+    std::vector<int> st((size_t)n * PEN_STATS);
+    if (hipMemcpy(st.data(), stats_dev, st.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { sfx_set_error("device error"); return -4; }
+    for (int i = 0; i < n; ++i) {
         const int* r = &st[(size_t)i * PEN_STATS];
         // r[15]: ordered pairs in the list that only one of the two triangles kept (max_collisions cut the other's list):
         // they contribute nothing and count as dropped
@@ -1219,4 +1251,11 @@ extern "C" int sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host /* [B][4
         stats_host[i * 4 + 2] = r[2]; stats_host[i * 4 + 3] = r[13];      // [3]: walks cut short at PEN_MAX_WALK entries (0 on a sane mesh)
     }
     return 0;
+}
+int sfx_pen_stats_stride(void) { return PEN_STATS; }
+const int* sfx_pen_stats_dev(const sfx_pen* h) { return h ? h->P.stats : nullptr; }
+
+extern "C" int sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host /* [B][4] */) {
+    if (!h || !stats_host || B < 1 || B > h->Bmax) { sfx_set_error("bad arguments"); return -1; }
+    return sfx_pen_stats_from(h->P.stats, B, stats_host);
 }

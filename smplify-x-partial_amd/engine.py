@@ -423,6 +423,21 @@ def prof_get(name):
     return ms.value, n.value, u.value
 
 
+def pen_work_reset():
+    """Zero the device counters of the interpenetration term's work (sfx_pen_work_reset)."""
+    capi.check(capi.load().sfx_pen_work_reset())
+
+
+def pen_work_get():
+    """Work of the interpenetration term since the last reset, counted on the device: grid entries and ordered pairs per
+    column evaluation (a mesh that went through the broad phase), the number of those evaluations, surviving triangles."""
+    w = (C.c_int64 * 4)()
+    capi.check(capi.load().sfx_pen_work_get(w))
+    cols = max(int(w[2]), 1)
+    return dict(entries=int(w[0]), pairs=int(w[1]), columns=int(w[2]), survivors=int(w[3]),
+                entries_per_column=w[0] / cols, pairs_per_column=w[1] / cols, survivors_per_column=w[3] / cols)
+
+
 class Penetration(object):
     """Interpenetration term on a batch of posed meshes (sfx_pen_*):
     BVH + FilterFaces + DistanceFieldPenetrationLoss of the reference's external package

@@ -111,3 +111,94 @@ def test_raw_sequence_golden_is_the_filtered_one_with_two_frames_replaced():
         assert not np.array_equal(f["f%d_f32_losses" % i], r["f%d_f32_losses" % i])
         assert (r["keypoints"][i][[9, 12, 2, 5], 2] == 0).sum() == 2      # two of the four camera keypoints missing
     assert np.array_equal(f["f7_f32_losses"], r["f7_f32_losses"])
+
+
+def _fat_report():
+    """A report shaped like bench.py's full one, with everything that once made the line 20 KB: per-frame arrays, per-stage
+    lists, paragraph-long notes, NaN / inf values, numpy scalars."""
+    rng = np.random.RandomState(0)
+    arr = [float(x) for x in rng.rand(64)]
+    prose = "x" * 900
+    roof = {"kernel": "k_lbs_dense16", "bound": "mfma", "achieved": np.float64(120.9244523), "peak": 157.3, "unit": "TFLOP/s",
+            "frac": 0.768750491, "traffic": 89751775.5, "frac_executed": 0.56, "mfma_busy_frac": 0.527, "avg_launch_us": 58.05,
+            "launches": np.int64(1665), "frames_per_launch": 153.1, "share_of_step": 0.51, "note": prose,
+            "traffic_detail": {"source": prose}}
+    return {"metric": "fitted frames/sec", "value": 512.3456789, "unit": "frames/s", "n_gpus": 1, "steps": 3, "warmup": 1,
+            "ms_per_step": 499.7123, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: 256 synthetic frames/GPU, synthetic SMPL-X, body-only K=25", "keypoints": prose,
+                       "arithmetic": prose, "frames_per_gpu": 256, "lbs_mode": "dense", "gemm_columns_per_gpu": 256,
+                       "parallelism": "frames sharded, dp1", "closure_evals_per_frame_mean": 2448.1, "closure_evals_per_frame_max": 4429,
+                       "closure_evals_per_s": 1254177.1, "final_loss_mean": float("nan"), "final_loss_median": 73.4},
+            "roofline": roof, "roofline_tick": dict(roof, kernel="k_tick_dense", bound="hbm", rows_by_stage_class=[11, 53, 225]),
+            "roofline_pen": dict(roof, kernel="k_pen_* + k_adj_*"),
+            "cpu_baseline": {"value": 0.469, "unit": "frames/s", "cores": 16, "kind": "port", "sample": "16 procs x 14 s",
+                             "host": {"a": 1}, "sample_detail": {"t": prose}},
+            "reference_parity": {"frames": 63, "final_loss_rel_delta_mean": 0.0161, "final_loss_rel_delta_signed_mean": -0.0027,
+                                 "reference_f32_vs_f64_rel_delta_mean": 0.0284, "camera_stage_loss_rel_delta_max": 7.5e-5,
+                                 "final_loss": arr, "reference_final_loss_f32": arr, "reference_final_loss_f64": arr, "note": prose,
+                                 "per_stage_loss_rel_delta_mean": arr[:6]},
+            "closure_parity": {"loss_rel_err_max": 1.18e-7, "grad_rel_err_max": float("inf"), "loss_rel_err_max_per_stage": arr[:6]},
+            "value_min3_camera_keypoints": 553.36, "min3_camera_keypoints": {"reference_parity": {"final_loss": arr}},
+            "alt": {"lbs_mode": "rows", "value": 1394.27, "unit": "frames/s", "note": prose, "paired_vs_dense": {"x": 1}},
+            "kernels_ms_avg": {"lbs_dense": 0.058, "tick_dense": 0.0568, "fit_rows": 0.0},
+            "ranks": [{"rank": r, "frames_per_s": 600.0 + r} for r in range(8)], "detail": "gpurun_out/bench_detail_body.json"}
+
+
+def test_bench_line_is_compact_and_strict_json():
+    """The contract line: < 4 KB whatever the report holds (the driver keeps 8 000 bytes of stdout: round 3's 20-KB line was
+    cut and counted as unmeasured), strict JSON (no NaN / Infinity tokens), scalars only inside its objects, every
+    contract key present, the roofline and cpu_baseline objects with their required members."""
+    import json
+    full = _fat_report()
+    assert len(json.dumps(BB.sanitize(full))) > 8000                       # the long form IS long: it goes to the detail file
+    line = BB.compact_line(full)
+    txt = json.dumps(line, allow_nan=False)                                  # raises on NaN / inf
+    assert len(txt) < BB.LINE_LIMIT, len(txt)
+    back = json.loads(txt, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert back["config"]["workload"].startswith("configs[1]") and back["config"]["final_loss_mean"] is None
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in back["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in back["cpu_baseline"], k
+    assert back["closure_parity"]["grad_rel_err_max"] is None              # inf -> null
+    for name, obj in back.items():                                          # numbers and short tags only
+        if isinstance(obj, dict):
+            for k, v in obj.items():
+                assert not isinstance(v, (list, dict)), (name, k)
+                assert not isinstance(v, str) or len(v) <= 160, (name, k)
+    assert back["value"] == 512.346 and back["roofline"]["launches"] == 1665
+    # a report that is too long even after reduction sheds optional objects, never the contract's
+    full["config"]["workload"] = "w" * 5000
+    for k in ("roofline", "roofline_tick", "roofline_pen"):
+        full[k]["kernel"] = "k" * 5000
+    txt = json.dumps(BB.compact_line(full), allow_nan=False)
+    assert len(txt) < BB.LINE_LIMIT and "roofline" in json.loads(txt) and "cpu_baseline" in json.loads(txt)
+
+
+def test_detail_file_is_strict_json(tmp_path, monkeypatch):
+    import json
+    monkeypatch.setattr(BB, "ROOT", str(tmp_path))
+    rel = BB.write_detail(_fat_report(), "unit")
+    d = json.load(open(os.path.join(str(tmp_path), rel)), parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    assert len(d["reference_parity"]["final_loss"]) == 64 and d["config"]["final_loss_mean"] is None
+
+
+def test_tick_byte_model_follows_the_workload():
+    """roofline_tick's algorithmic bytes come from the workload's own vertex items and optimiser width (round 3 divided the
+    body-only 11 rows by the full model's kernel time): 11 rows body-only; 11 / 53 / 225 by stage class for coco25 +
+    hands + face + contour; VPoser adds its weights twice."""
+    from smplifyx_amd import utils as U
+    jm_body = U.smpl_to_annotation("smplx", use_hands=False, use_face=False, use_face_contour=False, format="coco25")
+    jm_full = U.smpl_to_annotation("smplx", use_hands=True, use_face=True, use_face_contour=True, format="coco25")
+    assert BB.item_rows_by_class(jm_body, 21, 51, 25) == [11, 11, 11]
+    rows = BB.item_rows_by_class(jm_full, 21, 51, 25)
+    assert rows[0] == 11 and rows[2] == 225 and rows[0] < rows[1] < rows[2]
+    b_body = BB.tick_bytes_per_frame_launch(11, 119, False)
+    assert abs(b_body - (11 * (3 * 506 + 16) * 4 + 2 * 100 * 119 * 4 + 8 * 119 * 4)) < 1e-6
+    vp = 4.0 * (512 * 32 + 512 * 512 + 126 * 512 + 512 + 512 + 126)
+    b_full = BB.tick_bytes_per_frame_launch(225, 88, True, vp)
+    assert b_full > 2 * vp and b_full - 2 * vp > b_body

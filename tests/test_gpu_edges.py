@@ -206,10 +206,17 @@ def test_bench_line_contract(workload):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    # the driver parses this line out of the last 8 000 bytes of stdout: it must stay small and strict (round 3's was 20 KB)
+    assert len(lines[0]) < 4096 and len(out.stdout) < 8000, (len(lines[0]), len(out.stdout))
+    d = json.loads(lines[0], parse_constant=lambda c: (_ for _ in ()).throw(ValueError("non-strict JSON: " + c)))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
+    for name, obj in d.items():
+        if isinstance(obj, dict):
+            assert all(not isinstance(v, (list, dict)) for v in obj.values()), name
+    detail = json.load(open(os.path.join(root, d["detail"])))
+    assert detail["value"] == pytest.approx(d["value"], rel=1e-5) and "note" in detail["roofline"]
     assert d["unit"] == "frames/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
@@ -221,6 +228,14 @@ def test_bench_line_contract(workload):
         assert abs(rp["final_loss_rel_delta_signed_mean"]) <= rp["reference_f32_vs_f64_rel_delta_mean"]
         assert rp["final_loss_rel_delta_median"] <= 1.5 * rp["reference_f32_vs_f64_rel_delta_median"]
         assert "roofline_tick" in d and d["roofline_tick"]["kernel"] == "k_tick_dense"
+        assert d["roofline_tick"]["rows_per_frame_launch"] == pytest.approx(11.0)
+    if workload == "full":       # the byte model of the per-frame kernel is this workload's: live items by stage, VPoser weights twice
+        rt = d["roofline_tick"]
+        assert 11.0 < rt["rows_per_frame_launch"] <= 225.0 and rt["bytes_per_frame_launch"] > 2 * 1.3e6
+    if workload == "pen":        # grid entries and pairs are COUNTED over the timed region, not typical constants
+        rp = d["roofline_pen"]
+        assert rp["grid_entries_per_column"] > 0 and rp["pairs_per_column"] >= 0 and rp["columns_per_launch"] > 0
+        assert rp["frac"] == pytest.approx(rp["achieved"] / rp["peak"], rel=1e-4)
 
 
 @pytest.mark.parametrize("mode", ["rows", "dense"])

@@ -735,10 +735,27 @@ def gen_parser():
     _save("parser", **out)
 
 
+def gen_expose_anchor():
+    """The only known-answer vector for the SMPL-X forward that exists in the reference tree: ExPose's own
+    evaluation of the model on the two demo frames -- shape / expression coefficients and the rotation matrices of every
+    joint in, vertices [10475, 3] and joints [144, 3] out (demo/ExPose_results/*/*_params.npz).  Numeric arrays only.
+    tests/test_real_model_anchor.py replays them through the oracle and through the HIP forward when a user supplies the
+    licensed SMPLX_*.npz (SFX_SMPLX_MODEL): that is what pins row a6."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ref_import.REF_ROOT if hasattr(ref_import, "REF_ROOT") else "/root/reference",
+                                          "demo", "ExPose_results", "*", "*_params.npz")))
+    assert len(files) == 2, files
+    out = {"names": np.array([os.path.basename(os.path.dirname(f)) for f in files])}
+    for k in ("global_orient", "body_pose", "left_hand_pose", "right_hand_pose", "jaw_pose", "betas", "expression",
+              "vertices", "joints", "transl"):
+        out[k] = np.stack([np.asarray(np.load(f, allow_pickle=True)[k]) for f in files])
+    _save("expose_anchor", **out)
+
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or ["tables", "euler", "objective", "lbfgs", "e2e", "demo", "e2e_vposer"]
     for w in todo:
         {"objective": gen_objective, "lbfgs": gen_lbfgs, "euler": gen_euler, "tables": gen_tables,
          "e2e": gen_e2e, "demo": gen_demo, "e2e_vposer": gen_e2e_vposer, "parser": gen_parser, "eval": gen_eval,
          "gmm": gen_gmm, "e2e_full": gen_e2e_full, "e2e_full_set": gen_e2e_full_set, "e2e_vposer_set": gen_e2e_vposer_set, "e2e_side": gen_e2e_side, "e2e_bench": gen_e2e_bench,
-         "gmm_unmerged": gen_gmm_unmerged, "e2e_bench_raw_delta": gen_e2e_bench_raw_delta}[w]()
+         "gmm_unmerged": gen_gmm_unmerged, "e2e_bench_raw_delta": gen_e2e_bench_raw_delta, "expose_anchor": gen_expose_anchor}[w]()
