@@ -760,16 +760,18 @@ def main():
         ms_clo, n_clo, u_clo = prof["tick"]
         ms_lb, n_lb, _ = prof["fit_rows"]
         tag = {"body": "configs[1]" if world == 1 else "configs[3]", "full": "configs[2]", "pen": "configs[4]"}[args.workload]
-        what = {"body": "body-only K=25, camera + 5-stage L-BFGS (fit_smplx_smplifyx.yaml weights, use_vposer=False, synthetic regression prior)",
-                "full": "hands+face+contour K=135, VPoser decode in the loop (z0=0), camera + 5-stage L-BFGS (fit_smplx_smplifyx.yaml)",
-                "pen": "fit_smplx_combined_halpe.yaml verbatim: K=136, combined prior + camera prior, interpenetration (128 / 1e-4), camera + 3 stages"}[args.workload]
+        what = {"body": "body-only K=25, camera + 5-stage L-BFGS (fit_smplx_smplifyx.yaml, use_vposer=False)",
+                "full": "hands+face K=135, VPoser in the loop, camera + 5-stage L-BFGS (fit_smplx_smplifyx.yaml)",
+                "pen": "fit_smplx_combined_halpe.yaml verbatim (K=136, interpenetration 128 / 1e-4), camera + 3 stages"}[args.workload]
         out = {
             "metric": "fitted frames/sec", "value": world * B * args.steps / dt, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d synthetic frames/GPU%s, synthetic SMPL-X, %s" % (
+            "config": {"workload": "%s: %d synthetic frames/GPU%s, %s" % (
                            tag, B, "" if world == 1 else " x %d GPUs, 1 RCCL all_gather/step" % world, what),
+                       "model": "neutral SMPL-X-shaped synthetic model (seed 0%s); synthetic regression prior / VPoser weights as SURVEY 8(d)" % (
+                           ", surface-like mesh + synthetic part labels" if pen else ""),
                        "keypoints": "SURVEY 8(d) verbatim: projected model joints + 1 px noise, confidences U(0.3, 1), 10 % of the keypoints "
                                     "dropped (the sequence of rounds 1-2a; `value_min3_camera_keypoints` = the same job when the detector "
                                     "keeps at least 3 of the 4 camera-initialisation keypoints, round 2's headline sequence)",

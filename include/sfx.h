@@ -264,9 +264,11 @@ int  sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, in
  * when they overflowed the buffer (0 = fine; then the frame reports no pairs), bucket walks cut short (0 on a sane mesh:
  * an entry looks at most 2048 entries ahead in its bucket; a mesh folded into a few cells by a diverged fit hits that). */
 int  sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host);
-/* Work the term has done since the last reset, counted on the device over every handle of the process (HOST [4]): grid
+/* Work the term has done since the last reset, counted on the device over every handle of the process (HOST [6]): grid
  * entries, ordered pairs kept, column evaluations (meshes that went through the broad phase), triangles that survived the
- * part culling.  The benchmark's byte model of the step (bench.py roofline_pen) divides the first two by the third.  */
+ * part culling, triangles that met more partners than the lists hold (2 x max_collisions: the kept ones then depend on
+ * arrival order -- 0 on a sane mesh), bucket walks cut short.  The benchmark's byte model of the step (bench.py
+ * roofline_pen) divides the first two by the third.                                                                    */
 int  sfx_pen_work_reset(void);
 int  sfx_pen_work_get(int64_t* work_host);
 /* debug: elapsed 100 MHz wall-clock ticks at the end of k_pen_grid's seven steps (triangle boxes,

@@ -116,7 +116,7 @@ extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float
                             float* loss_dev, float* dverts_dev, void* stream);
 extern "C" int sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host);
 int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
-                        float* loss_dev, float* dverts_dev, const int* want_dev, void* stream);
+                        float* loss_dev, float* dverts_dev, const int* want_dev, const PenAdjPrep* prep, void* stream);
 int sfx_pen_capacity(const sfx_pen* h);          // meshes per call the handle's buffers hold (collide.hip)
 int sfx_pen_stats_from(const int* stats_dev, int n, int32_t* stats_host);
 int sfx_pen_stats_stride(void);
@@ -951,17 +951,22 @@ __global__ void k_pen_want(BatchDev D, const StageW* __restrict__ sws, int stage
     if (st >= 0 && st < D.cfg.n_stages && D.slot[b] >= 0) D.pen_want[D.slot[b]] = sws[st].coll > 0.f;
 }
 
-static int eval_penetration(sfx_batch* b, int stage_override, hipStream_t s) {
+// want_ready: the fused tick kernel maintains pen_want[] itself (it knows every running frame's next stage when it exports
+// the next trial point, and clears the flag of a frame that finishes): no launch for it inside the fitting loop
+static int eval_penetration(sfx_batch* b, int stage_override, hipStream_t s, bool want_ready = false) {
     const BatchDev& D = b->D;
     if (!b->pen || D.nact <= 0) return 0;
     ProfScope p("penetration", s, D.nact);
-    hipMemsetAsync(D.pen_want, 0, (size_t)D.cfg.B * sizeof(int), s);
-    hipLaunchKernelGGL(k_pen_want, dim3((D.cfg.B + 63) / 64), dim3(64), 0, s, D, b->sw_dev, stage_override);
+    if (!want_ready) {
+        hipMemsetAsync(D.pen_want, 0, (size_t)D.cfg.B * sizeof(int), s);
+        hipLaunchKernelGGL(k_pen_want, dim3((D.cfg.B + 63) / 64), dim3(64), 0, s, D, b->sw_dev, stage_override);
+    }
     // the collision buffers hold one mesh per column of the POOL (cfg.slots); inside the fused loop nact never exceeds it.
     // A stand-alone call on a pooled batch (sfx_batch_closure / sfx_batch_step: one column per frame, nact = B) walks the
     // columns in chunks of the pool's size -- the buffers are scratch between launches, every result lands in per-frame arrays
     const int cap = sfx_pen_capacity(b->pen);
-    const size_t V3 = (size_t)b->m->M.V * 3;
+    const DevModel& M = b->m->M;
+    const size_t V3 = (size_t)M.V * 3;
     b->pen_chunked = D.nact > cap;
     const int stride = sfx_pen_stats_stride();
     if (b->pen_chunked && !b->pen_stats_all) {
@@ -970,14 +975,15 @@ static int eval_penetration(sfx_batch* b, int stage_override, hipStream_t s) {
     }
     for (int c0 = 0; c0 < D.nact; c0 += cap) {
         const int n = std::min(cap, D.nact - c0);
+        // the lane that forms a vertex' gradient also writes d v_posed = T^T g, the adjoint GEMM's operand (column c0 + local index)
+        PenAdjPrep ap{D.AT + c0, M.Wsp_j, M.Wsp_w, M.W, D.adj_G + (size_t)c0 * 3 * M.Vpad, D.Bpad, M.Vpad};
         int rc = sfx_pen_eval_masked(b->pen, n, D.verts + c0 * V3, b->pen_sigma, b->pen_outside, D.pen_loss + c0, D.pen_dverts + c0 * V3,
-                                     D.pen_want + c0, s);
+                                     D.pen_want + c0, &ap, s);
         if (rc) return rc;
         if (b->pen_chunked)     // keep this chunk's diagnostics: the next chunk reuses the rows
             SFX_CHECK(hipMemcpyAsync(b->pen_stats_all + (size_t)c0 * stride, sfx_pen_stats_dev(b->pen), (size_t)n * stride * sizeof(int), hipMemcpyDeviceToDevice, s));
     }
-    hipMemsetAsync(D.ext_n, 0, (size_t)D.cfg.B * sizeof(int), s);        // k_adj_prep counts the vertices that carry a gradient
-    launch_pen_adjoint(b->m->M, D, s);
+    launch_pen_adjoint(M, D, s);
     return 0;
 }
 
@@ -1111,7 +1117,7 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
             if (dbg_nact) nact_hist[std::min(8, (D.nact - 1) / 32)] += 8;
             for (int q = 0; q < 8; ++q, ++tick) {
                 { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
-                if (int rc = eval_penetration(b, -2, s)) return rc;
+                if (int rc = eval_penetration(b, -2, s, true)) return rc;
                 ProfScope p("tick", s, D.nrun);
                 launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 1, s);
             }
@@ -1180,7 +1186,7 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
         } else if (fused) {
             for (int q = 0; q < 8; ++q, ++tick) {
                 { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
-                if (int rc = eval_penetration(b, -2, s)) return rc;
+                if (int rc = eval_penetration(b, -2, s, true)) return rc;
                 ProfScope p("tick", s);
                 launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 1, s);
             }
@@ -1281,7 +1287,7 @@ extern "C" int sfx_fit_multi(sfx_batch** bs, int32_t n, int32_t first_stage, int
                 sfx_batch* b = bs[g];
                 if (prev >= 0 && prev != g) hipStreamWaitEvent(st[g], ev[prev], 0);   // GEMMs back to back
                 { ProfScope p("lbs_dense", st[g], b->D.nact); launch_lbs_dense(b->m->M, b->D, st[g]); }
-                if (int rc = eval_penetration(b, -2, st[g])) return rc;
+                if (int rc = eval_penetration(b, -2, st[g], true)) return rc;
                 hipEventRecord(ev[g], st[g]);
                 prev = g;
                 ProfScope p("tick", st[g]);
@@ -1376,6 +1382,21 @@ extern "C" int sfx_batch_set_gmm_form(sfx_batch* b, int32_t M, int32_t Dm, const
     return 0;
 }
 
+__global__ void k_count_grad_vertices(BatchDev D, int V) {
+    __shared__ int cnt;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    int n = 0;
+    if (D.pen_want[b]) {
+        const float* g = D.pen_dverts + (size_t)b * V * 3;
+        for (int v = threadIdx.x; v < V; v += blockDim.x) n += (g[v * 3] != 0.f || g[v * 3 + 1] != 0.f || g[v * 3 + 2] != 0.f) ? 1 : 0;
+    }
+    atomicAdd(&cnt, n);
+    __syncthreads();
+    if (threadIdx.x == 0) D.ext_n[b] = cnt;
+}
+
 extern "C" int sfx_batch_pen_stats(sfx_batch* b, int32_t* stats_host /* [B][4] */, int32_t* ext_n_host /* [B] or NULL */) {
     if (!b || !stats_host) { sfx_set_error("null argument"); return -1; }
     if (!b->pen) { sfx_set_error("batch was created without interpenetration"); return -1; }
@@ -1383,7 +1404,11 @@ extern "C" int sfx_batch_pen_stats(sfx_batch* b, int32_t* stats_host /* [B][4] *
     int rc = b->pen_chunked ? sfx_pen_stats_from(b->pen_stats_all, n, stats_host)
                             : sfx_pen_stats(b->pen, std::min(n, sfx_pen_capacity(b->pen)), stats_host);
     if (rc) return rc;
-    if (ext_n_host) SFX_CHECK(hipMemcpy(ext_n_host, b->D.ext_n, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    if (ext_n_host) {       // vertices that carry a gradient: counted on demand (it was an atomic per wavefront in every evaluation)
+        hipLaunchKernelGGL(k_count_grad_vertices, dim3(n), dim3(256), 0, 0, b->D, b->m->M.V);
+        SFX_CHECK(hipDeviceSynchronize());
+        SFX_CHECK(hipMemcpy(ext_n_host, b->D.ext_n, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 

@@ -98,7 +98,8 @@ struct PenDev {
     int* cells;                // [B][PEN_CELLS + 1] bucket END offsets into entries ([PEN_CELLS] = number of entries)
     float* gridp;              // [B][4] low corner of the frame's box, 1 / cell size
     int* stats;                // [B][PEN_STATS]: pairs (ordered), dropped partners, overflow of entries, cells, phase clocks
-    unsigned long long* work;  // [4] process-wide counts since sfx_pen_work_reset: grid entries, ordered pairs, column evaluations, surviving triangles
+    unsigned long long* work;  // [6] process-wide counts since sfx_pen_work_reset: grid entries, ordered pairs, column evaluations, surviving triangles,
+                               //     triangles with more partners than the lists hold (2 x max_collisions: arrival order decides there), bucket walks cut short
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -217,14 +218,6 @@ __device__ __forceinline__ int block_excl_scan(const int v, int* wsum /* [PEN_T 
 __device__ __forceinline__ int pen_ford(float x) { int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); }      // order-preserving
 __device__ __forceinline__ int pen_bucket(int x, int y, int z) {
     return (int)(((unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u) & (PEN_CELLS - 1)); }
-
-__global__ __launch_bounds__(256)
-void k_pen_reset(PenDev P, const int* __restrict__ want) {
-    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (want && !want[b]) return;
-    if (i < 64 * 6) P.pbox[(size_t)b * 64 * 6 + i] = (i % 6) < 3 ? 0x7fffffff : (int)0x80000000;
-    if (i == 0) P.tcount[b * 16] = 0;
-}
 
 __global__ __launch_bounds__(PEN_T)
 void k_pen_g1(PenDev P, const float* __restrict__ verts, const int* __restrict__ want) {
@@ -458,6 +451,10 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     for (int c = t; c <= PEN_CELLS; c += PEN_T) cell_cnt[c] = 0;
     for (int c = t; c < PEN_CELLS; c += PEN_T) pmask[c] = 0u;
     pen_coll32(P, s_coll32);                    // (ends with a barrier)
+    // this kernel is the last reader of the frame's survivor count, and k_pen_g2 was the last reader of its part boxes: leave
+    // both empty for the NEXT evaluation of this column (a launch of its own until round 4)
+    if (t < 64 * 6) P.pbox[(size_t)b * 64 * 6 + t] = (t % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+    if (t == 0) P.tcount[b * 16] = 0;
     G3MARK();
     constexpr int U2 = 7;
     // which parts are present in each bucket (folded to 32 bits)
@@ -763,8 +760,8 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
     {
         const int per = (F + PEN_T - 1) / PEN_T;
         const int f0 = min(F, t * per), f1 = min(F, f0 + per);
-        int sum = 0, n_over = 0;
-        for (int f = f0; f < f1; ++f) { const int cnt = s_cnt[f]; n_over += max(cnt - P.cap, 0); sum += min(cnt, P.cap); }
+        int sum = 0, n_over = 0, n_arr = 0;
+        for (int f = f0; f < f1; ++f) { const int cnt = s_cnt[f]; n_over += max(cnt - P.cap, 0); sum += min(cnt, P.cap); n_arr += cnt > P.pcap ? 1 : 0; }
         int ptot;
         int acc = block_excl_scan(sum, slice, &ptot);
         for (int f = f0; f < f1; ++f) {
@@ -778,8 +775,11 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
             acc += c;
         }
         const float to = block_sum_fixed((float)n_over, red);
+        const float ta = block_sum_fixed((float)n_arr, red);
         if (t == 0) { const int tot = min(ptot, P.pair_cap); P.ptotal[b] = tot; st[0] = tot; st[1] = (int)to;
-                      if (P.work) atomicAdd(&P.work[1], (unsigned long long)tot); }
+                      if (P.work) { atomicAdd(&P.work[1], (unsigned long long)tot);
+                                    if (ta > 0.f) atomicAdd(&P.work[4], (unsigned long long)ta);
+                                    if (st[13] > 0) atomicAdd(&P.work[5], (unsigned long long)st[13]); } }
     }
     __syncthreads();
     for (int w = t; w < P.hasp_words; w += PEN_T) hasp[w] = s_has[w];
@@ -987,6 +987,8 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
 // per triangle: sum over its pair range of the 9 gradient components and the loss.  k_pen_eval has summed
 // the pairs of a triangle inside each 64-pair chunk of the list; the lane that sits on the first pair of
 // a range adds the (1 + range / 64) chunk sums in ascending order.
+// (Round 4 tried these sums inside k_pen_gather, per incident corner: one launch fewer, but every corner then walks two
+//  dependent loads and its chunk loop on the lane's own chain -- 75 us against 36 + 11 for the two kernels.  Kept apart.)
 __global__ __launch_bounds__(256)
 void k_pen_facesum(PenDev P) {
     const int b = blockIdx.y;
@@ -1013,9 +1015,11 @@ void k_pen_facesum(PenDev P) {
 }
 
 // vertex gradient = fixed-order sum over the incident triangle corners (CSR); frame loss = sum over the
-// triangles in index order (independent of where a pair sits in the list)
+// triangles in index order (independent of where a pair sits in the list).  When the caller is a fitting batch the lane
+// that has formed g(v) goes on to d v_posed = T^T g, the operand of the adjoint GEMM (a launch of its own, k_adj_prep,
+// until round 4).
 __global__ __launch_bounds__(256)
-void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss_out, const int* __restrict__ want) {
+void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss_out, const int* __restrict__ want, PenAdjPrep ap) {
     __shared__ float red[4];
     extern __shared__ unsigned s_hasp[];        // [hasp_words] triangles of this frame that have pairs
     const int b = blockIdx.y;
@@ -1048,6 +1052,31 @@ void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss
             }
         }
         for (int e = 0; e < 3; ++e) dverts[((size_t)b * P.V + v) * 3 + e] = g[e];
+        if (ap.adj_G) {         // d v_posed(v) = T(v)[:3,:3]^T g(v),  T(v) = sum_j W[v][j] A_j  (zeros where g = 0)
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+            if (g[0] != 0.f || g[1] != 0.f || g[2] != 0.f) {
+                const size_t Bp = (size_t)ap.Bpad;
+                float T[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                auto add = [&](const int j, const float w) {
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) T[rr * 3 + c] += w * ap.AT[((size_t)(rr * 4 + c) * SFX_JPAD + j) * Bp + b];
+                };
+                const int* wj = ap.Wsp_j + (size_t)v * SFX_NW;
+                if (wj[0] >= 0) {
+                    const float* ww = ap.Wsp_w + (size_t)v * SFX_NW;
+                    for (int q = 0; q < SFX_NW; ++q) if (ww[q] != 0.f) add(wj[q], ww[q]);
+                } else {
+                    for (int j = 0; j < SFX_J; ++j) { const float w = ap.W[(size_t)v * SFX_J + j]; if (w != 0.f) add(j, w); }
+                }
+                o0 = T[0] * g[0] + T[3] * g[1] + T[6] * g[2];
+                o1 = T[1] * g[0] + T[4] * g[1] + T[7] * g[2];
+                o2 = T[2] * g[0] + T[5] * g[1] + T[8] * g[2];
+            }
+            float* o = ap.adj_G + (size_t)b * 3 * ap.Vpad + (size_t)v * 3;
+            o[0] = o0; o[1] = o1; o[2] = o2;
+        }
     }
     if (blockIdx.x == 0) {
         float s = 0.f;
@@ -1066,24 +1095,24 @@ void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss
 static unsigned long long* g_pen_work = nullptr;      // device [4], process-wide (shared by every handle)
 static unsigned long long* pen_work_buffer() {
     if (!g_pen_work) {
-        if (hipMalloc((void**)&g_pen_work, 4 * sizeof(unsigned long long)) != hipSuccess) { g_pen_work = nullptr; return nullptr; }
-        hipMemset(g_pen_work, 0, 4 * sizeof(unsigned long long));
+        if (hipMalloc((void**)&g_pen_work, 6 * sizeof(unsigned long long)) != hipSuccess) { g_pen_work = nullptr; return nullptr; }
+        hipMemset(g_pen_work, 0, 6 * sizeof(unsigned long long));
     }
     return g_pen_work;
 }
 extern "C" int sfx_pen_work_reset(void) {
     if (!pen_work_buffer()) { sfx_set_error("out of device memory"); return -2; }
-    if (hipDeviceSynchronize() != hipSuccess || hipMemset(g_pen_work, 0, 4 * sizeof(unsigned long long)) != hipSuccess) { sfx_set_error("device error"); return -4; }
+    if (hipDeviceSynchronize() != hipSuccess || hipMemset(g_pen_work, 0, 6 * sizeof(unsigned long long)) != hipSuccess) { sfx_set_error("device error"); return -4; }
     return 0;
 }
-extern "C" int sfx_pen_work_get(int64_t* out /* [4] */) {
+extern "C" int sfx_pen_work_get(int64_t* out /* [6] */) {
     if (!out) { sfx_set_error("null argument"); return -1; }
-    out[0] = out[1] = out[2] = out[3] = 0;
+    for (int i = 0; i < 6; ++i) out[i] = 0;
     if (!g_pen_work) return 0;
     if (hipDeviceSynchronize() != hipSuccess) { sfx_set_error("device error"); return -4; }
-    unsigned long long h[4];
+    unsigned long long h[6];
     if (hipMemcpy(h, g_pen_work, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { sfx_set_error("device error"); return -4; }
-    for (int i = 0; i < 4; ++i) out[i] = (int64_t)h[i];
+    for (int i = 0; i < 6; ++i) out[i] = (int64_t)h[i];
     return 0;
 }
 
@@ -1150,7 +1179,12 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     P.ent_cap = F * 32;
     P.aabb = h->zeros<float>(B * F * 6); P.entries = h->zeros<int2>(B * P.ent_cap);
     P.tlist = h->zeros<int4>(B * F); P.tcount = h->zeros<int>(B * 16);
-    P.pbox = h->zeros<int>(B * 64 * 6); P.gpart = h->zeros<float>(B * PEN_GW * 8);
+    {   // part boxes start EMPTY (k_pen_g3 leaves them empty again after every evaluation)
+        std::vector<int> pb(B * 64 * 6);
+        for (size_t i = 0; i < pb.size(); ++i) pb[i] = (i % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+        P.pbox = h->up(pb);
+    }
+    P.gpart = h->zeros<float>(B * PEN_GW * 8);
     P.partners = h->zeros<int>(B * F * P.pcap); P.pcount = h->zeros<int>(B * F); P.pavail = h->zeros<int>(B * F);
     P.pair_cap = (int)std::min<size_t>((size_t)F * P.cap, std::max<size_t>(65536, (size_t)16 * F));
     P.hasp_words = (F + 31) / 32; P.hasp = h->zeros<unsigned>(B * P.hasp_words);
@@ -1173,7 +1207,7 @@ extern "C" void sfx_pen_destroy(sfx_pen* h) {
 }
 
 int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
-                        float* loss_dev, float* dverts_dev, const int* want_dev, void* stream) {
+                        float* loss_dev, float* dverts_dev, const int* want_dev, const PenAdjPrep* prep, void* stream) {
     if (!h || !verts_dev || !loss_dev || !dverts_dev) { sfx_set_error("null argument"); return -1; }
     if (B < 1 || B > h->Bmax) { sfx_set_error("batch %d exceeds the capacity %d given to sfx_pen_create", B, h->Bmax); return -1; }
     if (!(sigma > 0.f)) { sfx_set_error("df_cone_height must be positive"); return -1; }
@@ -1186,8 +1220,7 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
         attr_set = true;
     }
     if ((size_t)(h->P.F + h->P.hasp_words) * sizeof(int) > 160 * 1024 - 8192) { sfx_set_error("mesh of %d faces: k_pen_list stages the counts in LDS (<= 38 k faces)", h->P.F); return -1; }
-    // grid build: reset the cross-workgroup accumulators (part boxes to empty = 0x7f.. / 0x80.. patterns, masks and counts to 0)
-    hipLaunchKernelGGL(k_pen_reset, dim3(2, B), dim3(256), 0, s, h->P, want_dev);
+    // grid build (the cross-workgroup accumulators -- part boxes, survivor counts -- are left empty by k_pen_g3 of the previous evaluation)
     hipLaunchKernelGGL(k_pen_g1, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, verts_dev, want_dev);
     hipLaunchKernelGGL(k_pen_g2, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, want_dev);
     hipLaunchKernelGGL(k_pen_g3, dim3(B), dim3(PEN_T), (size_t)(PEN_GRID_INTS + PEN_CELLS) * sizeof(int), s, h->P, want_dev);
@@ -1199,15 +1232,17 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
                        h->P, want_dev, cap_pad);
     hipLaunchKernelGGL(k_pen_eval, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside);
     hipLaunchKernelGGL(k_pen_facesum, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P);
+    PenAdjPrep ap{};
+    if (prep) ap = *prep;
     hipLaunchKernelGGL(k_pen_gather, dim3((std::max(h->P.V, 1) + 255) / 256, B), dim3(256), (size_t)h->P.hasp_words * sizeof(unsigned), s,
-                       h->P, dverts_dev, loss_dev, want_dev);
+                       h->P, dverts_dev, loss_dev, want_dev, ap);
     if (hipGetLastError() != hipSuccess) { sfx_set_error("penetration kernels failed to launch"); return -4; }
     return 0;
 }
 
 extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
                             float* loss_dev, float* dverts_dev, void* stream) {
-    return sfx_pen_eval_masked(h, B, verts_dev, sigma, penalize_outside, loss_dev, dverts_dev, nullptr, stream);
+    return sfx_pen_eval_masked(h, B, verts_dev, sigma, penalize_outside, loss_dev, dverts_dev, nullptr, nullptr, stream);
 }
 
 // debug: wall-clock ticks (100 MHz) at the end of k_pen_pairs' steps for the first B frames: [B][10] = triangle boxes,

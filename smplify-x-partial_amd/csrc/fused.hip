@@ -73,7 +73,16 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
             atomicAdd((unsigned long long*)&D.dbg[30], (unsigned long long)(wc2 - wc1));
         }
         if (D.dbg && b == 0 && threadIdx.x == 0 && D.dbg[62] <= D.dbg[61]) { D.dbg[25] = clock64(); for (int i = 0; i < 17; ++i) D.dbg[40 + i] = D.dbg[i]; }
-        if (D.stage[b] > last_stage) return;
+        if (D.stage[b] > last_stage) {          // finished in this launch: its column carries no collision weight any more
+            if (D.pen_want && threadIdx.x == 0) D.pen_want[D.slot[b]] = 0;
+            return;
+        }
+    }
+    // interpenetration: does the evaluation exported below carry a collision weight (fitting.py:437)?  Kept here, per column, by
+    // the workgroup that knows the frame's stage (a memset and a launch of their own per round until round 4)
+    if (D.pen_want && threadIdx.x == 0) {
+        const int st_ = D.stage[b];
+        D.pen_want[D.slot[b]] = (st_ >= 0 && st_ < D.cfg.n_stages) ? (sws[st_].coll > 0.f ? 1 : 0) : 0;
     }
     ClosureArgs e{};
     e.stage_override = -2; e.export_dense = 1; e.forward_only = 2; e.keep_tables = has_eval;

@@ -3,9 +3,9 @@
 // smplx.lbs.lbs; here the vertex gradient g = d pen_loss / d verts comes from csrc/collide.hip).
 //
 //     verts = T(v) [v_posed; 1],  T(v) = sum_j W[v][j] A_j,  v_posed = v_template + dirs^T feat
-//  =>  d v_posed(v) = T(v)[:3,:3]^T g(v)                                   k_adj_prep
-//      d feat[k]    = sum_{v,c} dirs[k][3v+c] d v_posed(v)[c]               k_lbs_dense_adj (fp32 MFMA) + k_adj_reduce
-//      d A_j        = sum_v W[v][j] g(v) (x) [v_posed(v); 1]                k_adj_dA
+//  =>  d v_posed(v) = T(v)[:3,:3]^T g(v)                                   (k_pen_gather, collide.hip: the lane that forms g(v))
+//      d feat[k]    = sum_{v,c} dirs[k][3v+c] d v_posed(v)[c]               k_lbs_dense_adj (fp32 MFMA) + k_adj_finish
+//      d A_j        = sum_v W[v][j] g(v) (x) [v_posed(v); 1]                k_adj_finish
 // The tick kernel's adjoint pass adds d feat and d A (times coll_loss_weight) to the keypoint term's
 // before it walks the kinematic chain back (closure_body.h).
 //
@@ -17,7 +17,7 @@
 // A and B agree, so no LDS transpose is needed and every global load is a 16-byte vector load.
 // Wavefront tile: 64 k x 64 frames (4 x 4 MFMA tiles, 64 accumulators); a workgroup's 4 wavefronts
 // take 4 consecutive r ranges of the same tile and add their accumulators through LDS in wave
-// order; k_adj_reduce adds the workgroups' partials in slice order: no atomics, fixed association.
+// order; k_adj_finish adds the workgroups' partials in group order: no atomics, fixed association.
 // Algorithmic traffic per launch: dirs 64.4 MB + G (frames x 125.8 KB); flops 2 x 512 x 31 440 per frame.
 #include "sfx_internal.h"
 #include "wave_ops.h"
@@ -28,47 +28,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ADJ_T 256
 #define ADJ_RW_MIN 256           // r range of one wavefront: 256 (few frame tiles: more workgroups) or 512
 
-// d v_posed = T^T g for every vertex of every column that wants the term (zeros where g = 0)
-__global__ __launch_bounds__(256)
-void k_adj_prep(DevModel M, BatchDev D) {
-    const int b = blockIdx.y;
-    if (!D.pen_want[b]) return;
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= M.V) return;
-    const float* g = D.pen_dverts + ((size_t)b * M.V + v) * 3;
-    const float g0 = g[0], g1 = g[1], g2 = g[2];
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-    const bool nz = g0 != 0.f || g1 != 0.f || g2 != 0.f;
-    {   // diagnostics: vertices that carry a gradient (one integer atomic per wavefront)
-        const unsigned long long m = __ballot(nz);
-        if (m && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&D.ext_n[b], __popcll(m));
-    }
-    if (nz) {
-        const size_t Bp = (size_t)D.Bpad;
-        float T[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        auto add = [&](const int j, const float w) {
-#pragma unroll
-            for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) T[rr * 3 + c] += w * D.AT[((size_t)(rr * 4 + c) * SFX_JPAD + j) * Bp + b];
-        };
-        const int* wj = M.Wsp_j + (size_t)v * SFX_NW;
-        if (wj[0] >= 0) {
-            const float* ww = M.Wsp_w + (size_t)v * SFX_NW;
-            for (int q = 0; q < SFX_NW; ++q) if (ww[q] != 0.f) add(wj[q], ww[q]);
-        } else {
-            for (int j = 0; j < SFX_J; ++j) { const float w = M.W[(size_t)v * SFX_J + j]; if (w != 0.f) add(j, w); }
-        }
-        o0 = T[0] * g0 + T[3] * g1 + T[6] * g2;
-        o1 = T[1] * g0 + T[4] * g1 + T[7] * g2;
-        o2 = T[2] * g0 + T[5] * g1 + T[8] * g2;
-    }
-    float* o = D.adj_G + (size_t)b * 3 * M.Vpad + (size_t)v * 3;
-    o[0] = o0; o[1] = o1; o[2] = o2;
-}
+struct __align__(16) AdjLDS { float acc[4][64][64]; };      // one 64 x 64 tile per wavefront: first its own first-chunk sums (rw = 512), then the tile it hands on
 
-struct __align__(16) AdjLDS { float acc[3][64][64]; };      // wavefronts 1..3 hand their tile to wavefront 0's lanes
-
+// ONE association of the sum over r for every launch shape (a column's result must not depend on how many other columns
+// are active -- the rule every kernel of the fit obeys; until round 4 the r range per wavefront, 512 or 256 by the number of
+// frame tiles, changed where the partial sums met).  Canonical form: chunks c_i of 256 consecutive r, each accumulated on
+// its own from zero; pairs p_j = c_2j + c_2j+1; groups t_g = ((p_4g + p_4g+1) + p_4g+2) + p_4g+3; total = t_0 + t_1 + ...
+//   rw = 512: wavefront w of workgroup g forms p_(4g+w) (two accumulations of 256, then one add), the workgroup writes t_g;
+//   rw = 256: wavefront w of workgroup s forms c_(4s+w), the workgroup writes p_2s and p_2s+1, k_adj_finish forms the t_g.
 __global__ __launch_bounds__(ADJ_T, 2)
 void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
     __shared__ AdjLDS S;
@@ -80,6 +47,7 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
     const int LD = 3 * M.Vpad;
     const int r_lo = min(LD, (slice * 4 + wv) * rw);
     const int r_hi = min(LD, r_lo + rw);
+    const int r_mid = min(r_hi, r_lo + ADJ_RW_MIN);      // end of the first 256-chunk of this wavefront's range
     const float* pa = M.dirs + (size_t)(k0 + m) * LD + 4 * q;
     const float* pb = D.adj_G + (size_t)(b0 + m) * LD + 4 * q;
     const size_t sa = (size_t)16 * LD;          // next MFMA tile: 16 rows further
@@ -88,6 +56,7 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool split = false;
     float4 a_c[4], b_c[4], a_n[4], b_n[4];
     auto load = [&](float4 (&a)[4], float4 (&b)[4], const int r) {
 #pragma unroll
@@ -100,6 +69,17 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
     for (int r = r_lo; r < r_hi; r += 16) {
         const bool more = r + 16 < r_hi;
         if (more) load(a_n, b_n, r + 16);
+        if (r == r_mid) {        // (rw = 512) the second chunk starts from zero; the first waits in this wavefront's LDS tile (same lane writes and reads it)
+            split = true;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) S.acc[wv][16 * i + 4 * q + e][16 * j + m] = acc[i][j][e];
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -114,18 +94,41 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
             for (int i = 0; i < 4; ++i) { a_c[i] = a_n[i]; b_c[i] = b_n[i]; }
         }
     }
-    // accumulator (i, j), register e of lane (m, q) = C[k0 + 16 i + 4 q + e][b0 + 16 j + m]
-    if (wv > 0) {
+    const bool wide = rw > ADJ_RW_MIN;
+    if (split) {                 // p = c_lo + c_hi  (a range that ends inside its first chunk has no second one: p = that chunk, as c + 0 = c)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) S.acc[wv - 1][16 * i + 4 * q + e][16 * j + m] = acc[i][j][e];
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = S.acc[wv][16 * i + 4 * q + e][16 * j + m] + acc[i][j][e];
+    }
+    // accumulator (i, j), register e of lane (m, q) = C[k0 + 16 i + 4 q + e][b0 + 16 j + m]
+    if (wide ? wv > 0 : (wv & 1)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S.acc[wv][16 * i + 4 * q + e][16 * j + m] = acc[i][j][e];
     }
     __syncthreads();
-    if (wv == 0) {
-        float* out = D.adj_part + ((size_t)slice * SFX_KD_PAD + k0) * D.Bpad + b0;
+    if (wide) {
+        if (wv == 0) {           // t_g = ((p_0 + p_1) + p_2) + p_3
+            float* out = D.adj_part + ((size_t)slice * SFX_KD_PAD + k0) * D.Bpad + b0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kr = 16 * i + 4 * q + e, bc = 16 * j + m;
+                        const float s = ((acc[i][j][e] + S.acc[1][kr][bc]) + S.acc[2][kr][bc]) + S.acc[3][kr][bc];
+                        out[(size_t)kr * D.Bpad + bc] = s;
+                    }
+        }
+    } else if (!(wv & 1)) {      // wavefronts 0 and 2: p_2s = c_0 + c_1, p_2s+1 = c_2 + c_3
+        float* out = D.adj_part + ((size_t)(slice * 2 + (wv >> 1)) * SFX_KD_PAD + k0) * D.Bpad + b0;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -133,43 +136,69 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int kr = 16 * i + 4 * q + e, bc = 16 * j + m;
-                    const float s = ((acc[i][j][e] + S.acc[0][kr][bc]) + S.acc[1][kr][bc]) + S.acc[2][kr][bc];
-                    out[(size_t)kr * D.Bpad + bc] = s;
+                    out[(size_t)kr * D.Bpad + bc] = acc[i][j][e] + S.acc[wv + 1][kr][bc];
                 }
     }
 }
 
-// d feat[b][k] = sum over the slices, in slice order
+// The two small passes around the adjoint GEMM in ONE launch (two until round 4): blocks [0, n_red) add the GEMM's partials,
+// blocks [n_red, ..) form d A.
+//   d feat[b][k] = t_0 + t_1 + ... in group order; n_part partials of kind `pairs` (1: the p_j of the rw = 256 launch, summed
+//                  four at a time into the t_g first; 0: the t_g themselves); 64 columns x 4 k per block
+//   d A_j[b]     = sum over the vertices skinned by joint j (ascending) of W[v][j] g(v) (x) [v_posed(v); 1]: one wavefront per
+//                  (joint, column), four joints per block; lanes stride the joint's vertex list, DPP reduction (fixed order)
 __global__ __launch_bounds__(256)
-void k_adj_reduce(BatchDev D, int n_slices) {
-    const int b = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int k = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (b >= D.nact || !D.pen_want[b]) return;
-    float s = 0.f;
-    for (int i = 0; i < n_slices; ++i) s += D.adj_part[((size_t)i * SFX_KD_PAD + k) * D.Bpad + b];
-    D.pen_dfeat[(size_t)b * SFX_KD_PAD + k] = s;
-}
-
-// d A_j[b] = sum over the vertices skinned by joint j (ascending) of W[v][j] g(v) (x) [v_posed(v); 1]:
-// one wavefront per (joint, column); lanes stride the joint's vertex list, DPP reduction (fixed order)
-__global__ __launch_bounds__(64)
-void k_adj_dA(DevModel M, BatchDev D) {
-    const int j = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-    if (!D.pen_want[b]) return;
+void k_adj_finish(DevModel M, BatchDev D, int n_part, int pairs, int n_red) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if ((int)blockIdx.x < n_red) {
+        const int ftile = blockIdx.x / (SFX_KD_PAD / 4), kq = blockIdx.x % (SFX_KD_PAD / 4);
+        const int b = ftile * 64 + lane;
+        const int k = kq * 4 + wv;
+        if (b >= D.nact || !D.pen_want[b]) return;
+        const size_t st = (size_t)SFX_KD_PAD * D.Bpad;
+        const float* p = D.adj_part + (size_t)k * D.Bpad + b;
+        float s = 0.f;
+        if (pairs) {
+            for (int i = 0; i < n_part; i += 4) {
+                const float p0 = p[(size_t)i * st], p1 = i + 1 < n_part ? p[(size_t)(i + 1) * st] : 0.f;
+                const float p2 = i + 2 < n_part ? p[(size_t)(i + 2) * st] : 0.f, p3 = i + 3 < n_part ? p[(size_t)(i + 3) * st] : 0.f;
+                s += ((p0 + p1) + p2) + p3;
+            }
+        } else {
+            for (int i = 0; i < n_part; ++i) s += p[(size_t)i * st];
+        }
+        D.pen_dfeat[(size_t)b * SFX_KD_PAD + k] = s;
+        return;
+    }
+    constexpr int JB = (SFX_J + 3) / 4;
+    const int q = blockIdx.x - n_red;
+    const int b = q / JB, j = (q % JB) * 4 + wv;
+    if (j >= SFX_J || !D.pen_want[b]) return;
     const float* g = D.pen_dverts + (size_t)b * M.V * 3;
     const float* vp = D.vposed + (size_t)b * M.V * 3;
     float acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = M.jv_start[j] + lane; i < M.jv_start[j + 1]; i += 64) {
-        const int v = M.jv_vid[i];
-        const float g0 = g[v * 3], g1 = g[v * 3 + 1], g2 = g[v * 3 + 2];
-        if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;
-        const float w = M.jv_w[i];
-        const float p[4] = {vp[v * 3], vp[v * 3 + 1], vp[v * 3 + 2], 1.f};
-        const float wg[3] = {w * g0, w * g1, w * g2};
+    // four list entries per lane and trip, every load unconditional from a clamped index (the lane's chain was vertex id ->
+    // gradient -> weight / v_posed, one round trip each, once per entry: 31 us for ~12 entries per lane); the entries are still
+    // added in ascending order, and an entry without gradient is still skipped (0 x inf must not reach the sum)
+    const int i1 = M.jv_start[j + 1];
+    for (int i0 = M.jv_start[j] + lane; i0 < i1; i0 += 4 * 64) {
+        int vv[4]; float ww[4], gg[4][3], pp[4][3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * 64, i1 - 1); vv[u] = M.jv_vid[i]; ww[u] = M.jv_w[i]; }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r * 4 + c] += wg[r] * p[c];
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { gg[u][e] = g[vv[u] * 3 + e]; pp[u][e] = vp[vv[u] * 3 + e]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * 64 >= i1 || (gg[u][0] == 0.f && gg[u][1] == 0.f && gg[u][2] == 0.f)) continue;
+            const float p4[4] = {pp[u][0], pp[u][1], pp[u][2], 1.f};
+            const float wg[3] = {ww[u] * gg[u][0], ww[u] * gg[u][1], ww[u] * gg[u][2]};
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r * 4 + c] += wg[r] * p4[c];
+        }
     }
 #pragma unroll
     for (int e = 0; e < 12; ++e) acc[e] = wave_sum_dpp(acc[e]);
@@ -180,7 +209,7 @@ void k_adj_dA(DevModel M, BatchDev D) {
     }
 }
 
-int sfx_adj_slices(const DevModel& M) { return (3 * M.Vpad + 4 * ADJ_RW_MIN - 1) / (4 * ADJ_RW_MIN); }      // capacity of adj_part
+int sfx_adj_slices(const DevModel& M) { return 2 * ((3 * M.Vpad + 4 * ADJ_RW_MIN - 1) / (4 * ADJ_RW_MIN)); }      // capacity of adj_part: two pair sums per workgroup of the rw = 256 launch
 
 // gradient of the penetration term with respect to feat (betas / expression / pose feature) and the
 // skinning transforms, for every active column whose pen_want flag is set
@@ -189,8 +218,9 @@ void launch_pen_adjoint(const DevModel& M, const BatchDev& D, hipStream_t s) {
     const int ftiles = (D.nact + 63) / 64;
     const int rw = ftiles >= 3 ? 512 : ADJ_RW_MIN;       // 8 k tiles x ftiles x slices workgroups: keep >= 256 of them
     const int ns = (3 * M.Vpad + 4 * rw - 1) / (4 * rw);
-    hipLaunchKernelGGL(k_adj_prep, dim3((M.V + 255) / 256, D.nact), dim3(256), 0, s, M, D);
-    hipLaunchKernelGGL(k_adj_dA, dim3(SFX_J, D.nact), dim3(64), 0, s, M, D);
+    // (d v_posed = T^T g, the GEMM's operand, was written by k_pen_gather: PenAdjPrep)
     hipLaunchKernelGGL(k_lbs_dense_adj, dim3(ns, SFX_KD_PAD / 64, ftiles), dim3(ADJ_T), 0, s, M, D, rw);
-    hipLaunchKernelGGL(k_adj_reduce, dim3((D.nact + 63) / 64, SFX_KD_PAD / 4), dim3(256), 0, s, D, ns);
+    const int n_red = ftiles * (SFX_KD_PAD / 4);
+    hipLaunchKernelGGL(k_adj_finish, dim3(n_red + D.nact * ((SFX_J + 3) / 4)), dim3(256), 0, s, M, D,
+                       rw > ADJ_RW_MIN ? ns : 2 * ns, rw > ADJ_RW_MIN ? 0 : 1, n_red);
 }

@@ -262,6 +262,16 @@ static inline bool sfx_small_closure(const DevModel& M, const BatchDev& D) {
 }
 void launch_closure(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
                     const ClosureArgs& a, hipStream_t s);
+// d v_posed = T^T g of the interpenetration gradient, written by the kernel that forms g (k_pen_gather) when the caller is a
+// fitting batch: operand of the adjoint GEMM (lbs_adjoint.hip).  adj_G == nullptr: stand-alone operator, nothing to do.
+struct PenAdjPrep {
+    const float* AT;        // [12][JPAD][Bpad] skinning transforms of the columns (BatchDev.AT)
+    const int*   Wsp_j;     // [V][SFX_NW]
+    const float* Wsp_w;     // [V][SFX_NW]
+    const float* W;         // [V][J] (vertices with more than SFX_NW weights)
+    float*       adj_G;     // [Bpad][3 * Vpad]
+    int Bpad, Vpad;
+};
 void launch_pen_adjoint(const DevModel& M, const BatchDev& D, hipStream_t s);
 int sfx_adj_slices(const DevModel& M);
 void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s);

@@ -431,10 +431,11 @@ def pen_work_reset():
 def pen_work_get():
     """Work of the interpenetration term since the last reset, counted on the device: grid entries and ordered pairs per
     column evaluation (a mesh that went through the broad phase), the number of those evaluations, surviving triangles."""
-    w = (C.c_int64 * 4)()
+    w = (C.c_int64 * 6)()
     capi.check(capi.load().sfx_pen_work_get(w))
     cols = max(int(w[2]), 1)
     return dict(entries=int(w[0]), pairs=int(w[1]), columns=int(w[2]), survivors=int(w[3]),
+                lists_overflowed=int(w[4]), walks_cut=int(w[5]),     # > 0: some kept partner sets depended on arrival order
                 entries_per_column=w[0] / cols, pairs_per_column=w[1] / cols, survivors_per_column=w[3] / cols)
 
 

@@ -167,8 +167,15 @@ def test_bench_two_rank_control_flow_rehearsal():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 32 and d["scaling"] == "weak"
-    assert abs(d["value"] - 2 * 32 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
-    assert [r["rank"] for r in d["ranks"]] == [0, 1] and all(r["closure_evals_total"] > 0 for r in d["ranks"])
+    assert abs(d["value"] - 2 * 32 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-4 * d["value"]      # (both figures are printed to 6 digits)
+    assert len(lines[0]) < 4096
+    # per-rank records live in the detail file; the line carries their summary and the single-GPU rate of the SAME job size
+    # (rank 0's own frames over its own time), which is what 1 -> N efficiency is computed against
+    ranks = json.load(open(os.path.join(root, d["detail"])))["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and all(r["closure_evals_total"] > 0 for r in ranks)
+    c = d["config"]
+    assert c["per_gpu_frames_per_s_min"] <= c["per_gpu_frames_per_s_mean"] and c["single_gpu_same_job_frames_per_s"] == pytest.approx(ranks[0]["frames_per_s"], rel=1e-4)
+    assert d["value"] <= 2 * c["per_gpu_frames_per_s_mean"] * 1.001          # the job's rate is bound by its slowest rank
     # ... and under an external launcher whose world size disagrees with --gpus it refuses instead of mis-reporting
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=root, capture_output=True, text=True, timeout=300)
@@ -218,9 +225,9 @@ def test_bench_line_contract(workload):
     detail = json.load(open(os.path.join(root, d["detail"])))
     assert detail["value"] == pytest.approx(d["value"], rel=1e-5) and "note" in detail["roofline"]
     assert d["unit"] == "frames/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
-    assert abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) < 1e-4 * d["value"]       # (both figures are printed to 6 digits)
     r = d["roofline"]
-    assert r["kernel"] == "k_lbs_dense16" and r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["kernel"] == "k_lbs_dense16" and r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
     assert np.isfinite(d["config"]["final_loss_mean"])
     if workload == "body":
         rp = d["reference_parity"]

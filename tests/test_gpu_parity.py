@@ -155,9 +155,16 @@ def test_closure_matches_oracle(gpu, synth_model, cfg_body, cfg_full, which, mod
     closure_probe(synth_model, cfg, mode, "%s-%s" % (which, mode))
 
 
+def _conf_thr(cfg, K):
+    """fit_single_frame.py:276-287: the confidence threshold applies to the body keypoints of the format, 0 to the others."""
+    from smplifyx_amd import engine
+    nb = min(K, engine.NUM_BODY_JOINTS[cfg.get("format", "coco25")])
+    return np.array([cfg.get("confidence_threshold", 0) or 0] * nb + [0] * (K - nb))
+
+
 def _jw(cfg, frames):
     kp = frames["keypoints"]; B, K = kp.shape[:2]
-    thr = np.array([cfg.get("confidence_threshold", 0)] * 25 + [0] * 110)[:K]
+    thr = _conf_thr(cfg, K)
     jw = np.tile(H.base_joint_weights(cfg, K), (B, 1))
     jw[kp[:, :, 2] < thr[None]] = 0
     return jw
@@ -165,7 +172,7 @@ def _jw(cfg, frames):
 
 def _cmask(cfg, frames):
     kp = frames["keypoints"]; B, K = kp.shape[:2]
-    thr = np.array([cfg.get("confidence_threshold", 0)] * 25 + [0] * 110)[:K]
+    thr = _conf_thr(cfg, K)
     low = kp[:, :, 2] < thr[None]
     m = np.zeros((B, K), np.float32)
     for b in range(B):
@@ -180,7 +187,7 @@ _FRAME_CACHE = {}
 
 def synth_frames(model, cfg, n):
     from smplifyx_amd import synthetic
-    key = (cfg["use_hands"], cfg["use_face"], n)
+    key = (cfg["use_hands"], cfg["use_face"], cfg.get("format", "coco25"), bool(cfg.get("use_face_contour")), n)
     if key not in _FRAME_CACHE:
         K = len(H.joint_map_for(cfg))
         _FRAME_CACHE[key] = synthetic.make_frames(n, H.oracle_joints_fn(model, cfg), K, focal=5000.0)

@@ -361,6 +361,40 @@ def test_dense_skinning_adjoint_matches_torch_reference(synth_model):
     fb.close()
 
 
+def test_dense_skinning_adjoint_does_not_depend_on_the_launch_shape():
+    """A column's d feat must not depend on how many other columns are active: k_lbs_dense_adj splits the reduction over
+    r into ranges of 512 per wavefront when the launch has three or more 64-frame tiles and of 256 otherwise -- both
+    launches form the same chunk / pair / group sums (lbs_adjoint.hip), so the same frames give the same bits in a batch of
+    3 (one tile, 256) and of 200 (four tiles, 512).  Also d A, the loss and the closure's gradient."""
+    import helpers as H
+    import test_gpu_parity as T
+    from smplifyx_amd import synthetic
+    model = synthetic.make_synthetic_model(0, surface=True)
+    cfg = H.load_cfg("fit_smplx_combined_halpe.yaml", use_hands=False, use_face=False, interpenetration=True)
+    parts = synthetic.make_synthetic_parts(model)
+    dm = T._dm(model, cfg)
+    dm.set_parts(parts["segm"], parts["parents"], cfg["ign_part_pairs"])
+    K = len(H.joint_map_for(cfg))
+    n = 3
+    frames = synthetic.make_frames(n, H.oracle_joints_fn(model, cfg), K, focal=5000.0)
+    rng = np.random.RandomState(5)
+    P = H.random_params(rng, n, scale=0.2)
+    P["pose_embedding"] = (0.05 * rng.normal(size=(n, 63))).astype(np.float32)
+    got = {}
+    for B in (n, 200):
+        idx = [i % n for i in range(B)]
+        fb = H.engine_batch_from_frames(dm, cfg, frames, idx, lbs_mode="dense")
+        fb.set_params(regression_pose=frames["reg_pose"][idx], **{k: v[idx] for k, v in P.items()})
+        loss, grad = fb.closure(2)
+        got[B] = (fb.debug_read("pen_dfeat")[:n].copy(), fb.debug_read("pen_dA")[:n].copy(), loss[:n].copy(), grad[:n].copy(),
+                  fb.debug_read("pen_dfeat"))
+        fb.close()
+    assert np.abs(got[n][0]).max() > 0
+    for q in range(4):
+        assert np.array_equal(got[n][q], got[200][q]), q
+    assert np.array_equal(got[200][4][:n], got[200][4][n:2 * n])          # and not on the column index either
+
+
 def test_fit_frames_with_interpenetration_runs(synth_model):
     """driver.fit_frames on cfg_files/fit_smplx_combined_halpe.yaml with interpenetration=True: the whole
     schedule runs on device with the penetration step between the dense LBS and the loss/adjoint
@@ -392,39 +426,48 @@ def test_fit_frames_with_interpenetration_runs(synth_model):
                           reg_global=frames["reg_global"], lbs_mode="rows")
 
 
-def test_pooled_batch_with_interpenetration(synth_model):
+def test_pooled_batch_with_interpenetration():
     """A job of more frames than GEMM columns (slots < B) WITH the interpenetration term: the collision buffers hold one mesh
     per column of the pool, so (i) the fit through the pool equals the resident fit bit for bit, (ii) a stand-alone closure
     on the pooled batch (one column per frame: more meshes than the buffers hold) walks the columns in chunks and returns
     the same loss and gradient as a resident batch -- it used to ignore the operator's "batch exceeds the capacity" and
-    build the gradient from stale buffers --, (iii) the diagnostics cover every frame."""
+    build the gradient from stale buffers --, (iii) the diagnostics cover every frame.  On the surface-like synthetic mesh:
+    the triangle soup overflows the partner lists (more than 2 x max_collisions partners), where arrival order decides."""
     import helpers as H
     import test_gpu_parity as T
     from smplifyx_amd import driver, engine, synthetic
+    model = synthetic.make_synthetic_model(0, surface=True)
     cfg = H.load_cfg("fit_smplx_combined_halpe.yaml", use_hands=False, use_face=False, interpenetration=True)
-    cfg.update(use_camera_prior=False, maxiters=3, df_cone_height=1e-2)
-    parts = synthetic.make_synthetic_parts(synth_model)
-    dm = T._dm(synth_model, cfg)
+    cfg.update(use_camera_prior=False, maxiters=3)
+    parts = synthetic.make_synthetic_parts(model)
+    dm = T._dm(model, cfg)
     dm.set_parts(parts["segm"], parts["parents"], cfg["ign_part_pairs"])
     K = len(H.joint_map_for(cfg))
     B, slots = 70, 32
-    frames = synthetic.make_frames(B, H.oracle_joints_fn(synth_model, cfg), K, focal=5000.0)
+    frames = synthetic.make_frames(B, H.oracle_joints_fn(model, cfg), K, focal=5000.0)
     jw = H.base_joint_weights(cfg, K)
     kw = dict(reg_pose=frames["reg_pose"], reg_global=frames["reg_global"], lbs_mode="dense")
     res_pool = driver.fit_frames(dm, cfg, frames["keypoints"], jw, 600, 800, 5000.0, slots=slots, **kw)
     res_all = driver.fit_frames(dm, cfg, frames["keypoints"], jw, 600, 800, 5000.0, **kw)
-    for k in ("stage_loss", "pose_embedding", "betas", "cam_translation", "global_orient"):
-        assert np.array_equal(res_pool[k], res_all[k]), k
-    assert np.array_equal(res_pool["stage_evals"], res_all["stage_evals"])
+    res_again = driver.fit_frames(dm, cfg, frames["keypoints"], jw, 600, 800, 5000.0, **kw)
+    # A triangle that meets more than 2 x max_collisions partners in some trial pose keeps the ones that ARRIVE first (DESIGN 4.6;
+    # engine.pen_work_get()['lists_overflowed']): such a frame is not reproducible run to run, whatever the batch -- frames the
+    # resident fit reproduces itself on (nearly all) must come out of the pool with the same bits
+    keys = ("stage_loss", "pose_embedding", "betas", "cam_translation", "global_orient", "stage_evals")
+    same = lambda a, b_: np.array([all(np.array_equal(a[k][i], b_[k][i], equal_nan=True) for k in keys) for i in range(B)])
+    stable = same(res_again, res_all)
+    assert stable.sum() >= B - 4, np.flatnonzero(~stable)
+    assert same(res_pool, res_all)[stable].all(), np.flatnonzero(~same(res_pool, res_all) & stable)
+    assert np.all(res_all["stage_evals"][:, 2:] > 0)
     # stand-alone closure of the last stage (collision weight 1.0) on a pooled batch vs a resident one, same parameters
     out = {}
-    for name, s in (("pool", slots), ("all", 0)):
+    for name, s_ in (("pool", slots), ("all", 0)):
         fb, _ = driver._make_batch(dm, cfg, frames["keypoints"], jw, 600, 800, 5000.0, frames["reg_pose"], frames["reg_global"],
-                                   None, None, "dense", True, slots=s)
+                                   None, None, "dense", True, slots=s_)
         loss, grad = fb.closure(fb.n_stages - 1)
         st = fb.penetration_stats()
         out[name] = (loss, grad, st)
         fb.close()
     assert np.array_equal(out["pool"][0], out["all"][0]) and np.array_equal(out["pool"][1], out["all"][1])
     assert np.array_equal(out["pool"][2]["pairs"], out["all"][2]["pairs"]) and out["all"][2]["pairs"].shape == (B,)
-    assert (out["all"][2]["pairs"] > 0).sum() > B // 2          # the synthetic soup interpenetrates: the term was really evaluated
+    assert (out["all"][2]["pairs"] > 0).sum() > B // 2          # the tubes of neighbouring bones run through each other: the term was evaluated
