@@ -9,7 +9,6 @@
 //               assembly / kinematic chain of evaluation i+1 and its export to the GEMM operands].
 #include "closure_body.h"
 #include "lbfgs_body.h"
-#include <cstdlib>
 
 #ifndef SFX_TICK_OCC
 #define SFX_TICK_OCC 2
@@ -43,16 +42,7 @@ void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const S
 // (small variant, OCC = 2: two workgroups per CU -- batches of more than 256 frames then run two latency-bound frames per
 //  CU; OCC = 1 is the same code with the whole register file, launched when every frame has a CU of its own: no spills,
 //  73.8 instead of 76.2 us per launch)
-// HW: pairs of the L-BFGS history kept in LDS during the tick (lbfgs_body.h HistWin; dynamic LDS behind the static members):
-// only where a workgroup has its compute unit to itself (OCC = 1) -- 52 pairs next to the 76 KB of the body-only variant
-// (2 x 53 rows of 768 B = 80 KB: 156 of the 160 KB), 13 next to the full model's 138 KB.
-#ifndef SFX_HWIN_SMALL
-#define SFX_HWIN_SMALL 52
-#endif
-#ifndef SFX_HWIN_BIG
-#define SFX_HWIN_BIG 13
-#endif
-template <class LDS, int OCC, int HW>
+template <class LDS, int OCC>
 __global__ __launch_bounds__(CT, OCC)
 void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const StageW* __restrict__ sws,
                   int first_stage, int last_stage, int has_eval) {
@@ -61,8 +51,6 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
     __shared__ float fval;
     __shared__ float s_al[SFX_HIST + 2 * LB_BS];
     __shared__ OptScal st;
-    __shared__ int s_hready;
-    extern __shared__ __align__(16) float s_hwin[];      // [2][HW + 1][NVAR_MAX]: S rows, then Y rows
     const int b = D.act ? D.act[blockIdx.x] : blockIdx.x;      // (frames that finished or still wait in the queue are not launched)
     if (D.stage[b] > last_stage) return;
     const long long wc0 = D.dbg ? wall_clock64() : 0;      // debug: per-workgroup duration statistics (100 MHz clock)
@@ -72,15 +60,12 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
         ClosureArgs a{};
         a.stage_override = -2; a.use_dense_verts = 1; a.reuse_fwd = 1;
         closure_body(S, M, D, vls, sws, a, b, gflat, &fval);
-        if (HW > 0 && threadIdx.x == 0) s_hready = 0;
         __syncthreads();
         const long long wc1 = D.dbg ? wall_clock64() : 0;
-        // (one wavefront runs the state machine: sharing the dot products of the two-loop recursion between four was measured
-        //  slower -- a workgroup barrier per block of 8 history pairs costs more than the reductions it removes; the other
-        //  three copy the newest history pairs into LDS meanwhile)
-        HistWin win{};
-        if constexpr (HW > 0) { win.S = s_hwin; win.Y = s_hwin + (size_t)(HW + 1) * SFX_NVAR_MAX; win.cap = HW; win.ready = &s_hready; win.copiers = CT / 64 - 1; }
-        lbfgs_tick_body<(OCC == 1 ? 3 : 2), (HW > 0)>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, S.T, &fval, gflat, win);      // (S.T: >= 2048 floats of closure scratch, dead between evaluations)
+        // (one wavefront: sharing the dot products of the two-loop recursion between four was measured slower --
+        //  a workgroup barrier per block of 8 history pairs costs more than the reductions it removes)
+        if (threadIdx.x < 64)
+            lbfgs_tick_body<(OCC == 1 ? 3 : 2)>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, S.T, &fval, gflat);      // (S.T: >= 2048 floats of closure scratch, dead between evaluations)
         __syncthreads();
         if (D.dbg && threadIdx.x == 0) {       // debug: mean duration of the two segments over all workgroups (100 MHz ticks)
             const long long wc2 = wall_clock64();
@@ -118,34 +103,16 @@ void launch_fit_rows(const DevModel& M, const BatchDev& D, const VarList* vl_dev
     else
         hipLaunchKernelGGL(k_fit_rows<FrameLDS>, dim3(D.cfg.B), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, max_ticks);
 }
-template <class LDS, int OCC, int HW>
-static void launch_tick_variant(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
-                                int first_stage, int last_stage, int has_eval, int grid, hipStream_t s) {
-    const size_t dyn = HW > 0 ? (size_t)2 * (HW + 1) * SFX_NVAR_MAX * sizeof(float) : 0;
-    if (HW > 0) {
-        static const bool attr = hipFuncSetAttribute((const void*)k_tick_dense<LDS, OCC, HW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) == hipSuccess;
-        if (!attr) {        // (cannot happen on gfx950: 160 KB of LDS per workgroup) -- the variant without a window is the same arithmetic
-            (void)hipGetLastError();
-            hipLaunchKernelGGL((k_tick_dense<LDS, OCC, 0>), dim3(grid), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
-            return;
-        }
-    }
-    hipLaunchKernelGGL((k_tick_dense<LDS, OCC, HW>), dim3(grid), dim3(CT), dyn, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
-}
 void launch_tick_dense(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
                        int first_stage, int last_stage, int has_eval, hipStream_t s) {
     const int grid = D.act ? D.nrun : D.cfg.B;
     if (grid <= 0) return;
     static const int n_cu = [] { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
-    static const bool no_win = getenv("SFX_NO_HIST_WINDOW") != nullptr;      // (measurement switch: same arithmetic either way)
     if (sfx_small_closure(M, D)) {
-        if (grid <= n_cu) {
-            if (no_win) launch_tick_variant<FrameLDSSmall, 1, 0>(M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval, grid, s);
-            else launch_tick_variant<FrameLDSSmall, 1, SFX_HWIN_SMALL>(M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval, grid, s);
-        } else
-            launch_tick_variant<FrameLDSSmall, SFX_TICK_OCC, 0>(M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval, grid, s);
-    } else {
-        if (no_win) launch_tick_variant<FrameLDS, 1, 0>(M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval, grid, s);
-        else launch_tick_variant<FrameLDS, 1, SFX_HWIN_BIG>(M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval, grid, s);
-    }
+        if (grid <= n_cu)
+            hipLaunchKernelGGL((k_tick_dense<FrameLDSSmall, 1>), dim3(grid), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
+        else
+            hipLaunchKernelGGL((k_tick_dense<FrameLDSSmall, SFX_TICK_OCC>), dim3(grid), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
+    } else
+        hipLaunchKernelGGL((k_tick_dense<FrameLDS, 1>), dim3(grid), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
 }

@@ -251,44 +251,6 @@ __device__ __forceinline__ LbRow lb_ldrow(const char* p) {
 #endif
     LbRow r; r.a.x = u.x; r.a.y = u.y; r.b = u.z; return r;
 }
-// The newest pairs of the history, resident in the workgroup's LDS for the duration of one tick (k_tick_dense, one workgroup
-// per compute unit): the three wavefronts that idle while wavefront 0 runs the state machine copy them there (LDS-DMA) during
-// the tick's prologue; the recursion then reads a block's rows from LDS -- ~100 cycles -- instead of from L2 / MALL / HBM, whose
-// latency two blocks of look-ahead did not cover (0.37 us per block against 0.26 us of instructions).  Exact image of the
-// global rows: the arithmetic, and with it every trajectory, is unchanged.
-//   row r of S / Y holds the pair whose logical index AT TICK ENTRY was first_e + r, r < rows_e; row rows_e is where a pair
-//   pushed in this tick is stored as well.  cap = 0: no window (every block comes from global memory).
-struct HistWin {
-    float* S; float* Y;         // [cap + 1][SFX_NVAR_MAX] each
-    int cap;                    // pairs the window holds
-    volatile int* ready;        // counts the copying wavefronts that have finished
-    int copiers;                // ... out of this many
-};
-__device__ __forceinline__ LbRow lb_ldrow_lds(const float* p) {
-    LbRow r; r.a.x = p[0]; r.a.y = p[1]; r.b = p[2]; return r;
-}
-// wavefronts 1 .. of the workgroup: copy the newest min(hist_n, cap) pairs of frame b's history into the window
-__device__ __forceinline__ void hist_window_fill(const HistWin& W, const BatchDev& D, const int b, const int wave, const int nwaves, const int lane) {
-    typedef __attribute__((address_space(3))) void* lds_vp;
-    typedef const __attribute__((address_space(1))) void* glb_vp;
-    const OptState* gst = reinterpret_cast<const OptState*>(D.opt) + b;
-    const int n = __builtin_amdgcn_readfirstlane(gst->s.hist_n), head = __builtin_amdgcn_readfirstlane(gst->s.hist_head);
-    const int R = n < W.cap ? n : W.cap;
-    const char* hY = reinterpret_cast<const char*>(D.hist + (size_t)b * 2 * SFX_HROWS * SFX_NVAR_MAX);
-    const char* hS = hY + (size_t)SFX_HROWS * LB_ROWB;
-    // one 16-byte LDS-DMA per lane: 48 lanes move one 768-byte row
-    for (int r = wave; r < R; r += nwaves) {
-        int p = head + (n - R) + r; p = p >= SFX_HIST ? p - SFX_HIST : p;
-        if (lane < LB_ROWB / 16) {
-            __builtin_amdgcn_global_load_lds((glb_vp)(hS + (size_t)p * LB_ROWB + 16 * lane), (lds_vp)(reinterpret_cast<char*>(W.S) + (size_t)r * LB_ROWB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_vp)(hY + (size_t)p * LB_ROWB + 16 * lane), (lds_vp)(reinterpret_cast<char*>(W.Y) + (size_t)r * LB_ROWB), 16, 0, 0);
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0070);       // vmcnt(0): gfx9 encoding, lgkmcnt / expcnt left at their maxima
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) atomicAdd(const_cast<int*>(W.ready), 1);
-}
-
 __device__ __forceinline__ float lb_dotpart(const LbRow& x, const LbRow& y) { return fmaf(x.b, y.b, fmaf(x.a.y, y.a.y, x.a.x * y.a.x)); }
 __device__ __forceinline__ void lb_axpy(LbRow& y, const float a, const LbRow& x) {
     const lb_v2 aa = {a, a};
@@ -303,7 +265,7 @@ __device__ __forceinline__ void lb_axpy(LbRow& y, const float a, const LbRow& x)
 template <int DIR>
 __device__ __forceinline__ void lb_load(LbSet& X, const int base, const int n, const int head, const float* hMine,
                                         const float* hAll, const float* tab, const float* ro, const float* s_alp,
-                                        const bool want_al, const int lane, const float* lMine = nullptr, const float* lAll = nullptr) {
+                                        const bool want_al, const int lane) {
     const int grp = lane >> 3;
     int p = head + base; p = p >= SFX_HIST ? p - SFX_HIST : p;
     if (DIR < 0 && p < 7) p += SFX_HIST;
@@ -316,14 +278,6 @@ __device__ __forceinline__ void lb_load(LbSet& X, const int base, const int n, c
     X.ro = valid ? rv : 0.f;
     X.al = 0.f;
     if (want_al) { const float av = s_alp[ig]; X.al = valid ? av : 0.f; }
-    if (lMine) {        // the block's 8 pairs are in the LDS window (wave-uniform): lMine / lAll point at member 0's row
-        const float* la = lAll + 3 * lane; const float* lm = lMine + 3 * lane;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) X.all[c] = lb_ldrow_lds(la + DIR * c * SFX_NVAR_MAX);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) X.mine[c] = lb_ldrow_lds(lm + DIR * c * SFX_NVAR_MAX);
-        return;
-    }
     const char* ra = reinterpret_cast<const char*>(hAll) + (size_t)p * LB_ROWB + 12 * lane;
     const char* rm = reinterpret_cast<const char*>(hMine) + (size_t)p * LB_ROWB + 12 * lane;
 #pragma unroll
@@ -336,13 +290,11 @@ __device__ __forceinline__ void lb_load(LbSet& X, const int base, const int n, c
 // recursion keeps per pair: ro, the band entries s_(k-th predecessor) . y_new -- the syt row of the new pair and entry k
 // of the k-th predecessor's syb row -- and the mirror of slots 0..7 behind the ring.
 __device__ __forceinline__ void lb_push_pair(float* hY, float* hS, OptState* gst, int& hist_n, int& hist_head, const Lane3& y,
-                                             const Lane3& sv, const float ys, const int lane, const int hist_cap = SFX_HIST,
-                                             float* ldsY = nullptr, float* ldsS = nullptr) {
+                                             const Lane3& sv, const float ys, const int lane, const int hist_cap = SFX_HIST) {
     if (hist_n >= hist_cap) { hist_head = (hist_head + 1) % SFX_HIST; hist_n -= 1; }      // (history_size <= SFX_HIST: the ring keeps its 100 slots)
     const int ph = (hist_head + hist_n) % SFX_HIST;
     st3_full(hY + (size_t)ph * SFX_NVAR_MAX, y, lane);
     st3_full(hS + (size_t)ph * SFX_NVAR_MAX, sv, lane);
-    if (ldsY) { st3_full(ldsY, y, lane); st3_full(ldsS, sv, lane); }      // (the window's row for a pair pushed in this tick)
     const float ro = 1.0f / ys;
     if (lane == 0) gst->ro[ph] = ro;
     if (ph < 8) {
@@ -380,8 +332,7 @@ __device__ __forceinline__ void lb_push_pair(float* hY, float* hS, OptState* gst
 
 template <int SETS>
 __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, const OptState* gst, float* s_al,
-                                             const int n_, const int head_, const float hd, const Lane3 q_in, const int lane,
-                                             const float* wS = nullptr, const float* wY = nullptr, const int w_first = 0, const int w_rows = 0) {
+                                             const int n_, const int head_, const float hd, const Lane3 q_in, const int lane) {
     const int n = __builtin_amdgcn_readfirstlane(n_), head = __builtin_amdgcn_readfirstlane(head_);
     float* s_alp = s_al + 8;        // members below index 0 of the last block land in the padding
     const int grp = lane >> 3;
@@ -407,12 +358,7 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
 #pragma unroll
         for (int c = 0; c < 8; ++c) lb_axpy(q, -al[c], X.all[c]);
     };
-    // window rows of logical pair i: wS / wY + (i - w_first) * NVAR_MAX, valid for w_first <= i < w_first + w_rows (wave-uniform)
-    const int w_lo = __builtin_amdgcn_readfirstlane(w_first), w_hi = __builtin_amdgcn_readfirstlane(w_first + w_rows);
-#define LB_INWIN(lo_, hi_) (wS != nullptr && (lo_) >= w_lo && (hi_) < w_hi)
-#define LB_LD1(X, b_) lb_load<-1>(X, (b_), n, head, hS, hY, gst->syt, gst->ro, s_alp, false, lane,                    \
-                                  LB_INWIN((b_) - 7, (b_)) ? wS + (size_t)((b_) - w_lo) * SFX_NVAR_MAX : nullptr,   \
-                                  LB_INWIN((b_) - 7, (b_)) ? wY + (size_t)((b_) - w_lo) * SFX_NVAR_MAX : nullptr)
+#define LB_LD1(X, b_) lb_load<-1>(X, (b_), n, head, hS, hY, gst->syt, gst->ro, s_alp, false, lane)
     {
         int i0 = n - 1;
         if constexpr (SETS == 3) {
@@ -448,9 +394,7 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
 #pragma unroll
         for (int c = 0; c < 8; ++c) lb_axpy(r, cc[c], X.all[c]);
     };
-#define LB_LD2(X, b_) lb_load<1>(X, (b_), n, head, hY, hS, gst->syb, gst->ro, s_alp, true, lane,                      \
-                                 LB_INWIN((b_), (b_) + 7) ? wY + (size_t)((b_) - w_lo) * SFX_NVAR_MAX : nullptr,    \
-                                 LB_INWIN((b_), (b_) + 7) ? wS + (size_t)((b_) - w_lo) * SFX_NVAR_MAX : nullptr)
+#define LB_LD2(X, b_) lb_load<1>(X, (b_), n, head, hY, hS, gst->syb, gst->ro, s_alp, true, lane)
     {
         int i0 = 0;
         if constexpr (SETS == 3) {
@@ -469,7 +413,6 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
         }
     }
 #undef LB_LD2
-#undef LB_INWIN
 #undef LB_RL
     Lane3 out; out.v[0] = r.a.x; out.v[1] = r.a.y; out.v[2] = r.b;
     return out;
@@ -479,11 +422,11 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
 // closure result (global D.f/D.g, or LDS copies in fused kernels).  s_al[SFX_HIST + 2 * LB_BS], s_state and
 // s_work[2048] (the tick's working copies; may alias any LDS that is dead during the tick)
 // are LDS scratch owned by the caller.
-template <int SETS, bool WIN = false>
+template <int SETS>
 __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchDev& D, const VarList* __restrict__ vls,
                                                  int first_stage, int last_stage, int init, int step_mode,
                                                  const int b, const int lane, float* s_al, OptScal& s_state, float* s_work,
-                                                 const float* f_src, const float* g_src, const HistWin win = HistWin{}) {
+                                                 const float* f_src, const float* g_src) {
     const BatchCfgDev& C = D.cfg;
     OptState* gst = reinterpret_cast<OptState*>(D.opt) + b;
     int stage = D.stage[b];
@@ -683,21 +626,11 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
                 const float tf = (float)s.t.v;
                 for (int e = 0; e < NE3; ++e) { y.v[e] = g.v[e] - pg.v[e]; sv.v[e] = dold.v[e] * tf; }
                 const float ys = dot3(y, sv);
-                // LDS window of the newest pairs (filled by the other wavefronts during this prologue): logical index, in the
-                // numbering AFTER a push, of its row 0, and the rows it holds
-                const int n_e = s.hist_n;
-                const int w_rows_e = WIN ? (n_e < win.cap ? n_e : win.cap) : 0;
-                int w_first = n_e - w_rows_e, w_rows = w_rows_e;
                 if (ys > 1e-10f) {
                     int hn = s.hist_n, hh = s.hist_head;
-                    const bool was_full = hn >= C.hist_cap;
-                    lb_push_pair(hY, hS, gst, hn, hh, y, sv, ys, lane, C.hist_cap,
-                                 WIN ? win.Y + (size_t)w_rows_e * SFX_NVAR_MAX : nullptr,
-                                 WIN ? win.S + (size_t)w_rows_e * SFX_NVAR_MAX : nullptr);
+                    lb_push_pair(hY, hS, gst, hn, hh, y, sv, ys, lane, C.hist_cap);
                     s.hist_n = hn; s.hist_head = hh;
                     s.H_diag = T(ys / dot3(y, y));
-                    if (was_full) w_first -= 1;      // the oldest pair left: every logical index moved down by one
-                    w_rows += 1;                     // the new pair sits behind the copied ones
                 }
                 LB_SYNC();
                 TMARK(3);
@@ -710,12 +643,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
                     if (n == 0) {
                         for (int e = 0; e < NE3; ++e) r.v[e] = q.v[e] * hd;
                     } else {
-                        if constexpr (WIN) {         // the copy has had the whole prologue (~4 us) to finish
-                            while (*win.ready < win.copiers) __builtin_amdgcn_s_sleep(2);
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                            r = lb_two_loop<SETS>(hS, hY, gst, s_al, n, s.hist_head, hd, q, lane, win.S, win.Y, w_first, w_rows);
-                        } else
-                            r = lb_two_loop<SETS>(hS, hY, gst, s_al, n, s.hist_head, hd, q, lane);
+                        r = lb_two_loop<SETS>(hS, hY, gst, s_al, n, s.hist_head, hd, q, lane);
                     }
                 }
                 TMARK(5);
@@ -918,16 +846,13 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
 }
 
 // Entry for a workgroup: wavefront 0 runs the state machine, the others pass through.  SETS: see lb_two_loop.
-template <int SETS, bool WIN = false>
+template <int SETS>
 __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDev& D, const VarList* __restrict__ vls,
                                                 int first_stage, int last_stage, int init, int step_mode,
                                                 const int b, const int tid, float* s_al, OptScal& s_state, float* s_work,
-                                                const float* f_src, const float* g_src, const HistWin win = HistWin{}) {
-    if (tid >= 64) {        // the idle wavefronts bring the newest history pairs into LDS while wavefront 0 works through the prologue
-        if constexpr (WIN) { if (init == 0 && D.stage[b] <= last_stage) hist_window_fill(win, D, b, (tid >> 6) - 1, win.copiers, tid & 63); }
-        return;
-    }
-    lbfgs_tick_wave0<SETS, WIN>(M, D, vls, first_stage, last_stage, init, step_mode, b, tid, s_al, s_state, s_work, f_src, g_src, win);
+                                                const float* f_src, const float* g_src) {
+    if (tid >= 64) return;
+    lbfgs_tick_wave0<SETS>(M, D, vls, first_stage, last_stage, init, step_mode, b, tid, s_al, s_state, s_work, f_src, g_src);
 }
 
 
