@@ -69,7 +69,8 @@ int  sfx_model_set_vposer(sfx_model* m, int32_t latent, int32_t hidden,
  * contiguous fp32; any output may be NULL.  `hands` are PCA coefficients [B][num_pca]. */
 /* Per-face part labels of smplx_parts_segm.pkl and the part pairs that never collide
  * (fit_single_frame.py:316-328): used by batches created with interpenetration = 1.  segm /
- * parents [F]; ign_pairs [n_ign][2].  Without this call no pair is filtered by part.           */
+ * parents [F]; ign_pairs [n_ign][2].  Without this call -- or after one with segm = parents = NULL,
+ * which clears the labels -- no pair is filtered by part.                                      */
 int  sfx_model_set_parts(sfx_model* m, const int32_t* segm, const int32_t* parents, const int32_t* ign_pairs,
                          int32_t n_ign);
 
@@ -132,7 +133,8 @@ typedef struct sfx_batch_cfg {
                                        that finish (continuous batching): the reference's loop over frames
                                        (main.py:207) for jobs larger than one GEMM batch.  A frame's result does
                                        not depend on when it is admitted or which column it gets              */
-    /* hyper-parameters of optimizers/lbfgs_ls.py's LBFGS that optim_factory.py:27-65 leaves at their defaults; 0 = default */
+    /* hyper-parameters of optimizers/lbfgs_ls.py's LBFGS that optim_factory.py:27-65 leaves at their defaults.  The two
+       tolerances: NEGATIVE = default, 0 is passed through (legal in the reference: the test is disabled); the counts: 0 = default */
     double  lbfgs_tolerance_grad;   /* 1e-5                                                          */
     double  lbfgs_tolerance_change; /* 1e-9                                                          */
     int32_t lbfgs_max_eval;         /* maxiters * 5 / 4                                              */

@@ -506,7 +506,12 @@ extern "C" void sfx_model_destroy(sfx_model* m) {
 
 extern "C" int sfx_model_set_parts(sfx_model* m, const int32_t* segm, const int32_t* parents, const int32_t* ign_pairs,
                                    int32_t n_ign) {
-    if (!m || !segm || !parents) { sfx_set_error("null argument"); return -1; }
+    if (!m) { sfx_set_error("null argument"); return -1; }
+    if (!segm && !parents) {        // no FilterFaces module (fit_single_frame.py:316 without part_segm_fn): no pair is filtered by part
+        m->segm_host.clear(); m->parents_host.clear(); m->ign_host.clear();
+        return 0;
+    }
+    if (!segm || !parents) { sfx_set_error("null argument"); return -1; }
     const size_t F = m->faces_host.size() / 3;
     m->segm_host.assign(segm, segm + F);
     m->parents_host.assign(parents, parents + F);
@@ -570,8 +575,9 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.cfg.side_thsh = c->side_view_thsh; D.cfg.lsh = c->left_shoulder_idx; D.cfg.rsh = c->right_shoulder_idx;
     D.cfg.pen = c->interpenetration ? 1 : 0;
     D.cfg.proj64 = c->high_precision ? 1 : 0;
-    D.cfg.tol_grad = c->lbfgs_tolerance_grad > 0 ? c->lbfgs_tolerance_grad : 1e-5;
-    D.cfg.tol_change = c->lbfgs_tolerance_change > 0 ? c->lbfgs_tolerance_change : 1e-9;
+    // negative = the reference's default; 0 is a legal value of lbfgs_ls.LBFGS (it disables the test) and reaches the device as 0
+    D.cfg.tol_grad = c->lbfgs_tolerance_grad >= 0 ? c->lbfgs_tolerance_grad : 1e-5;
+    D.cfg.tol_change = c->lbfgs_tolerance_change >= 0 ? c->lbfgs_tolerance_change : 1e-9;
     if (c->lbfgs_max_eval > 0) D.cfg.max_eval = c->lbfgs_max_eval;
     if (c->lbfgs_history_size > SFX_HIST) { sfx_set_error("history_size %d > %d", c->lbfgs_history_size, SFX_HIST); delete b; return -1; }
     D.cfg.hist_cap = c->lbfgs_history_size > 0 ? c->lbfgs_history_size : SFX_HIST;

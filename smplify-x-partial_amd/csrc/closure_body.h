@@ -89,6 +89,10 @@ __device__ __forceinline__ void lds_fill_async(void* lds_dst, const void* gsrc, 
         if (i < n_dwords) __builtin_amdgcn_global_load_lds((sfx_glb_vp)(g + 4 * (size_t)i), (sfx_lds_vp)(l + 4 * base), 4, 0, 0);
     }
 }
+// LDS-DMA completes in vmcnt order: the barrier that publishes DMA-filled LDS to the other wavefronts must be preceded by a
+// wait for this wavefront's own copies.  The compiler emits that s_waitcnt in front of every such s_barrier today; the memory
+// model does not oblige it to (a workgroup-scope release needs lgkmcnt only), so it is spelled out (CK: block_sync_lds_direct_load).
+__device__ __forceinline__ void lds_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0); expcnt / lgkmcnt untouched
 // the same in 16-byte units (both sides 16-byte aligned)
 __device__ __forceinline__ void lds_fill_async16(void* lds_dst, const void* gsrc, const int n16) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -339,6 +343,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     for (int i = t; i < SFX_KD_PAD; i += CT) { if (!reuse) S.feat[i] = 0.f; S.dfeat[i] = 0.f; }
     for (int i = t; i < SFX_NPAR_MAX; i += CT) S.gc[i] = 0.f;
     for (int i = t; i < 168; i += CT) S.dpose[i] = 0.f;
+    lds_dma_wait();
     __syncthreads();
     const float* bodypose = S.x + L.emb;
     if constexpr (HAS_VP) {
@@ -534,6 +539,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
             lds_fill_async(S.djs, M.dynp_js + (size_t)S.lut_row * (SFX_J + 1), SFX_J + 1);
             lds_fill_async(S.dji, M.dynp_ji + ro * SFX_NW, nd * SFX_NW); lds_fill_async(S.djw, M.dynp_jw + ro * SFX_NW, nd * SFX_NW);
         }
+        lds_dma_wait();
         __syncthreads();
     }
     // v_posed rows and skinning transforms of `ni` vertices listed in S.ivid (the model's items, or a

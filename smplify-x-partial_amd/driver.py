@@ -164,9 +164,19 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
                                 per(reg_global, lo, hi), per(cam_prior_t, lo, hi), per(cam_prior_center, lo, hi),
                                 lbs_mode, reuse_entry_eval, body_pose_prior, slots if groups == 1 else 0))
     fbs = [m[0] for m in made]
+    pen_on = bool(cfg.get("interpenetration", False))
+    work0 = engine.pen_work_get() if pen_on else None
     if groups == 1:
         fbs[0].fit(first_stage=-1, last_stage=fbs[0].n_stages - 1)
     else:
         engine.fit_multi(fbs, first_stage=-1, last_stage=fbs[0].n_stages - 1)
+    if pen_on:      # diagnostics of the interpenetration term over this fit (device counters, engine.pen_work_get)
+        w1 = engine.pen_work_get()
+        cut, over = w1["walks_cut"] - work0["walks_cut"], w1["lists_overflowed"] - work0["lists_overflowed"]
+        if cut or over:
+            import warnings
+            warnings.warn("interpenetration term: %d bucket walks were cut short and %d triangles met more than 2 x max_collisions "
+                          "partners during this fit (a mesh folded into a few grid cells by a diverging frame): the term is "
+                          "underestimated there and the partners kept depend on arrival order" % (cut, over), RuntimeWarning)
     parts = [_collect(fb, prep, want_vertices) for fb, prep in made]
     return {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}

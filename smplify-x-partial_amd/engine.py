@@ -147,6 +147,11 @@ class DeviceModel(object):
                                                  capi.iptr(ign) if pairs else None, len(pairs)))
         self.has_parts = True
 
+    def clear_parts(self):
+        """No part filter (a loss created without a FilterFaces module: the reference filters nothing then)."""
+        capi.check(self._lib.sfx_model_set_parts(self._h, None, None, None, 0))
+        self.has_parts = False
+
     def set_vposer(self, w):
         a = {k: capi.f32(v) for k, v in w.items()}
         latent, hidden = a["fc1_w"].shape[1], a["fc1_w"].shape[0]
@@ -227,8 +232,10 @@ class FrameBatch(object):
         c.penalize_outside = int(bool(cfg.get("penalize_outside", True)))
         c.slots = int(slots or 0)
         # LBFGS hyper-parameters (optimizers/lbfgs_ls.py); the cfg files never set them: 0 = the reference's defaults
-        c.lbfgs_tolerance_grad = float(cfg.get("lbfgs_tolerance_grad", 0.0) or 0.0)
-        c.lbfgs_tolerance_change = float(cfg.get("lbfgs_tolerance_change", 0.0) or 0.0)
+        # (tolerances: negative = default; an explicit 0 -- LBFGS(tolerance_grad=0): the test is disabled -- is passed through)
+        tg, tc = cfg.get("lbfgs_tolerance_grad"), cfg.get("lbfgs_tolerance_change")
+        c.lbfgs_tolerance_grad = -1.0 if tg is None else float(tg)
+        c.lbfgs_tolerance_change = -1.0 if tc is None else float(tc)
         c.lbfgs_max_eval = int(cfg.get("lbfgs_max_eval", 0) or 0)
         c.lbfgs_history_size = int(cfg.get("lbfgs_history_size", 0) or 0)
         # cfg float_dtype: float64 (main.py:99-105) -> the engine's high-precision mode (include/sfx.h sfx_batch_cfg.high_precision)
@@ -345,7 +352,7 @@ class FrameBatch(object):
         st = np.zeros((self.B, 4), np.int32)
         ext = np.zeros(self.B, np.int32)
         capi.check(self._lib.sfx_batch_pen_stats(self._h, capi.iptr(st), capi.iptr(ext)))
-        return dict(pairs=st[:, 0].copy(), dropped=st[:, 1].copy(), entry_overflow=st[:, 2].copy(), vertices=ext)
+        return dict(pairs=st[:, 0].copy(), dropped=st[:, 1].copy(), entry_overflow=st[:, 2].copy(), walks_cut=st[:, 3].copy(), vertices=ext)
 
     def last_grad(self, stage):
         """Gradient [B,N] of the most recent closure evaluation (what var.grad holds after step())."""

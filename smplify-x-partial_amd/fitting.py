@@ -210,16 +210,21 @@ class EngineClosure(object):
                 pen_cfg = dict(interpenetration=True, max_collisions=st.max_collisions, df_cone_height=pd.sigma,
                                penalize_outside=pd.penalize_outside)
                 w.coll_loss_weight = float(loss.coll_loss_weight)
+                # the part filter belongs to THIS loss: a loss without a FilterFaces module filters nothing, whatever an earlier
+                # loss on the same model had set (fit_single_frame.py:316-328 builds the module only with a part_segm_fn)
                 if tf is not None and getattr(dm, "_parts_from", None) is not tf:
                     dm.set_parts(tf.faces_segm, tf.faces_parents, tf.ign_part_pairs)
                     dm._parts_from = tf
+                elif tf is None and getattr(dm, "_parts_from", None) is not None:
+                    dm.clear_parts()
+                    dm._parts_from = None
             reg = loss.regression_pose
             has_reg = reg is not None and (not self.use_vposer or stage + 1 == loss.num_stages)
         cfg = dict(use_vposer=self.use_vposer, use_hands=use_hands, use_face=use_face,
                    use_joints_conf=bool(getattr(loss, "use_joints_conf", False)),
                    use_conf_for_camera_init=bool(getattr(loss, "use_conf", False)),
                    high_precision=getattr(bm, "dtype", torch.float32) == torch.float64,
-                   lbfgs_tolerance_grad=getattr(opt, "tolerance_grad", 0.0), lbfgs_tolerance_change=getattr(opt, "tolerance_change", 0.0),
+                   lbfgs_tolerance_grad=getattr(opt, "tolerance_grad", None), lbfgs_tolerance_change=getattr(opt, "tolerance_change", None),
                    lbfgs_max_eval=getattr(opt, "max_eval", 0), lbfgs_history_size=getattr(opt, "history_size", 0),
                    maxiters=self.monitor.maxiters, ftol=self.monitor.ftol, gtol=self.monitor.gtol,
                    lr=getattr(opt, "lr", 1.0), rho=getattr(loss, "rho", 100),

@@ -470,3 +470,28 @@ def test_create_loss_with_interpenetration_objects(synth_model):
     l2, g2 = fb.closure(2)
     assert float(l2[0]) == vals[1.0][0]
     assert np.array_equal(g2[0][-63:], vals[1.0][1].reshape(-1))
+    fb.close()
+    # the part filter belongs to the loss: one built WITHOUT a FilterFaces module after the filtered ones above filters nothing
+    # (it used to inherit the previous loss's labels through the shared device model) -- more pairs, a larger term
+    def closure_value(tf):
+        loss = fitting.create_loss(loss_type="smplify", joint_weights=joint_weights, rho=cfg["rho"], use_joints_conf=True,
+                                   use_face=False, use_hands=False, body_pose_prior=mk("l2"), shape_prior=mk("l2"),
+                                   angle_prior=mk("angle"), interpenetration=True, search_tree=search_tree,
+                                   pen_distance=pen_distance, tri_filtering_module=tf, dtype=torch.float32,
+                                   regression_pose=torch.tensor(frames["reg_pose"][:1], device=dev), num_stages=3).to(dev)
+        w = {"data_weight": 1000.0 / frames["H"], "body_pose_weight": torch.tensor(cfg["body_pose_prior_weights"][2], device=dev),
+             "shape_weight": torch.tensor(cfg["shape_weights"][2], device=dev), "coll_loss_weight": torch.tensor(1.0, device=dev)}
+        w["bending_prior_weight"] = 3.17 * w["body_pose_weight"]
+        loss.reset_loss_weights(w)
+        with fitting.FittingMonitor(**cfg) as monitor:
+            closure = monitor.create_fitting_closure(None, bm, camera=camera, gt_joints=gt_joints, joints_conf=joints_conf,
+                                                     joint_weights=joint_weights, loss=loss, use_vposer=False,
+                                                     pose_embedding=pose_embedding, return_verts=True, return_full_pose=True)
+            v = float(closure(stage=2))
+            if closure._fb is not None:
+                closure._fb.close()
+        return v
+    unfiltered = closure_value(None)
+    assert unfiltered > vals[1.0][0] * (1 + 1e-6), (unfiltered, vals[1.0][0])
+    assert closure_value(filter_faces) == vals[1.0][0]              # and back again
+    assert closure_value(None) == unfiltered

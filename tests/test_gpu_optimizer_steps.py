@@ -172,6 +172,40 @@ def test_non_default_lbfgs_hyper_parameters_match_the_machine(synth_model, cfg_b
     assert len(fd.get_trace()[0]) != len(dev) or not np.array_equal(fd.get_trace()[0], dev)
 
 
+def test_zero_tolerances_reach_the_device(synth_model, cfg_body):
+    """LBFGS(tolerance_grad=0, tolerance_change=0) is legal in the reference (lbfgs_ls.py:291,301,437,442: the tests can then
+    only fire on exact zeros); until round 4 a zero in sfx_batch_cfg meant "default" and silently became 1e-5 / 1e-9.  The
+    camera stage with both set to 0 follows the specification machine run with zeros, and differs from the default run."""
+    from oracle.lbfgs_machine import StageMachine
+    cfg, dm, frames = _setup(synth_model, cfg_body)
+    i = 0
+    runs = {}
+    for name, extra in (("zero", dict(lbfgs_tolerance_grad=0.0, lbfgs_tolerance_change=0.0)), ("default", {})):
+        fb = H.engine_batch_from_frames(dm, dict(cfg, **extra), frames, [i], lbs_mode="rows", reuse=False)
+        fb.guess_init(cfg["body_tri_idxs"])
+        P0 = fb.get_params()
+        fb.trace(8192)
+        fb.fit(first_stage=-1, last_stage=-1)
+        runs[name] = fb.get_trace()[0]
+    dev = runs["zero"]
+    assert len(dev) != len(runs["default"]) or not np.array_equal(dev, runs["default"])
+    fc = H.engine_batch_from_frames(dm, cfg, frames, [i], lbs_mode="rows", reuse=False)
+    fc.guess_init(cfg["body_tri_idxs"])
+    m = StageMachine(np.concatenate([P0["cam_translation"][0], P0["global_orient"][0]]), groups=[(0, 3, True), (3, 3, True)],
+                     maxiters=cfg["maxiters"], ftol=cfg["ftol"], gtol=cfg["gtol"], lr=cfg.get("lr", 1.0), dtype=np.float32,
+                     reuse_entry_eval=False, tol_grad=0.0, tol_change=0.0)
+    while not m.done:
+        x = m.x_trial
+        fc.set_params(regression_pose=frames["reg_pose"][i:i + 1], cam_translation=x[None, :3], global_orient=x[None, 3:],
+                      pose_embedding=P0["pose_embedding"])
+        f, gr = fc.closure(-1)
+        m.feed(f[0], gr[0])
+    mac = np.array(m.records)
+    k1 = np.flatnonzero(dev[:, 0] == 1)[0] + 1              # the first LBFGS.step, event by event
+    assert np.array_equal(dev[:k1, 0], mac[:k1, 0])
+    _compare(dev[:k1], mac[:k1], 5e-5, "camera stage, zero LBFGS tolerances", whole_stage=False, t_rtol=1e-3)
+
+
 def test_first_body_stage_steps_match_the_machine(synth_model, cfg_body):
     """N = 182 (119 live variables), ~400 evaluations, history filling up to 100 pairs: blocked two-loop recursion on the
     device against the plain one of the machine, both fed by the HIP closure.  Rounding differs (summation order), so the
