@@ -6,6 +6,7 @@
 #include "sfx_internal.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -132,6 +133,17 @@ struct sfx_model {
     int fwd_B = 0;
 };
 
+// The fused dense loop keeps `ahead` batches of 8 rounds queued beyond the one whose stage flags the host is waiting for: the
+// GPU only idles when the host thread stays away for longer than that much queued work.  Measured in round 4:
+// the host's own enqueueing is 4-7 % of the loop (7 us per round of 2 launches, 43 us per round of 13), so a captured graph
+// would save nothing on a quiet host; on a host whose 16 cores carry 32 spinning processes EVERY workload halves (body 509 ->
+// 239, interpenetration 349 -> 182 frames/s: the polling thread waits milliseconds for a time slice), and a deeper queue buys
+// back part of it where a round is two launches (body: 249 / 275 frames/s with 3 / 6 batches ahead) but HURTS where a round
+// is thirteen (interpenetration, quiet host: 349 / 322 / 221 frames/s with 1 / 3 / 6 ahead -- hundreds of queued packets).
+// Default: 3 batches ahead for the two-launch loops, 1 with the interpenetration term; SFX_POLL_AHEAD overrides.  The price of
+// depth: decisions (retirement, admission, compaction, the end) lag by ahead x 8 rounds; finished frames only ever stay
+// finished, and the surplus rounds at the end run on empty launches (0.1 % of a 256-frame fit at depth 3).
+#define SFX_POLL_BUFS 8
 struct sfx_batch {
     sfx_model* m = nullptr;
     BatchDev D{};
@@ -139,12 +151,12 @@ struct sfx_batch {
     VarList* vl_dev = nullptr;    // [2]: camera, body
     StageW* sw_dev = nullptr;     // [n_stages]
     VarList vl_host[2];
-    int* stage_host = nullptr;    // pinned, [2][B]
-    int* map_host = nullptr;      // pinned, [2][3B]: slot[], running-frame list, newly admitted frames (two uploads may be in flight)
+    int* stage_host = nullptr;    // pinned, [SFX_POLL_BUFS][B]
+    int* map_host = nullptr;      // pinned, [SFX_POLL_BUFS][3B]: slot[], running-frame list, newly admitted frames (one upload per batch in flight)
     int* act_dev = nullptr;       // [B] running frames of the fused dense loop
     int* act_new_dev = nullptr;   // [B] frames admitted at the latest poll (export-only launch)
     int slots = 0;                // GEMM columns of the fused dense loop (0: one per frame)
-    hipEvent_t poll_ev[2] = {nullptr, nullptr};
+    hipEvent_t poll_ev[SFX_POLL_BUFS] = {};
     std::vector<int> slot_host;
     int K = 0;
     sfx_pen* pen = nullptr;       // interpenetration operator (cfg.interpenetration)
@@ -695,12 +707,12 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
         sfx_set_error("out of device memory (batch of %d frames)", B);
         if (b->pen) sfx_pen_destroy(b->pen);
         b->mem.free_all(); delete b; return -2; }
-    if (hipHostMalloc((void**)&b->stage_host, (size_t)2 * B * sizeof(int)) != hipSuccess) b->stage_host = nullptr;      // two poll buffers
-    if (hipHostMalloc((void**)&b->map_host, (size_t)6 * B * sizeof(int)) != hipSuccess) b->map_host = nullptr;
+    if (hipHostMalloc((void**)&b->stage_host, (size_t)SFX_POLL_BUFS * B * sizeof(int)) != hipSuccess) b->stage_host = nullptr;      // poll buffers
+    if (hipHostMalloc((void**)&b->map_host, (size_t)SFX_POLL_BUFS * 3 * B * sizeof(int)) != hipSuccess) b->map_host = nullptr;
     if (c->lbs_mode == 1 && (!b->stage_host || !b->map_host)) {       // the fused dense loop polls through pinned memory
         sfx_set_error("out of pinned host memory"); sfx_batch_destroy(b); return -2; }
-    if (hipEventCreateWithFlags(&b->poll_ev[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b->poll_ev[1], hipEventDisableTiming) != hipSuccess) { sfx_set_error("event creation failed"); b->mem.free_all(); delete b; return -2; }
+    for (int i = 0; i < SFX_POLL_BUFS; ++i)
+        if (hipEventCreateWithFlags(&b->poll_ev[i], hipEventDisableTiming) != hipSuccess) { sfx_set_error("event creation failed"); sfx_batch_destroy(b); return -2; }
     *out = b;
     return 0;
 }
@@ -713,7 +725,7 @@ extern "C" void sfx_batch_destroy(sfx_batch* b) {
     b->mem.free_all();
     if (b->stage_host) hipHostFree(b->stage_host);
     if (b->map_host) hipHostFree(b->map_host);
-    for (int i = 0; i < 2; ++i) if (b->poll_ev[i]) hipEventDestroy(b->poll_ev[i]);
+    for (int i = 0; i < SFX_POLL_BUFS; ++i) if (b->poll_ev[i]) hipEventDestroy(b->poll_ev[i]);
     delete b;
 }
 
@@ -1104,7 +1116,7 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
         for (int i = 0; i < pool; ++i) { col[i] = i; run.push_back(i); }
         int next_q = pool, upl = 0;
         auto upload = [&](const std::vector<int>* fresh) -> int {      // slot[], running list (+ admitted list) through pinned memory
-            int* h = b->map_host + (size_t)upl * 3 * B; upl ^= 1;
+            int* h = b->map_host + (size_t)upl * 3 * B; upl = (upl + 1) % SFX_POLL_BUFS;      // (at most one upload per processed batch, at most `ahead` + 1 batches in flight)
             memcpy(h, col.data(), (size_t)B * sizeof(int));
             memcpy(h + B, run.data(), run.size() * sizeof(int));
             SFX_CHECK(hipMemcpyAsync(D.slot, h, (size_t)B * sizeof(int), hipMemcpyHostToDevice, s));
@@ -1119,8 +1131,15 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
         D.nact = pool;
         if (int rc = upload(nullptr)) return rc;
         { ProfScope p("tick", s, D.nrun); launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, s); }
+        // SFX_DEBUG_HOST=1: how much of the loop's wall time the HOST spends enqueueing (its headroom against a busy box)
+        static const bool dbg_host = getenv("SFX_DEBUG_HOST") != nullptr;
+        double host_enq_s = 0.0; long host_batches = 0;
+        const double wall0 = dbg_host ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
         auto rounds = [&](int buf) -> int {
             if (dbg_nact) nact_hist[std::min(8, (D.nact - 1) / 32)] += 8;
+            const auto h0 = std::chrono::steady_clock::now();
+            struct HostClock { const std::chrono::steady_clock::time_point t0; double& acc; long& n; bool on;
+                               ~HostClock() { if (on) { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); ++n; } } } hc{h0, host_enq_s, host_batches, dbg_host};
             for (int q = 0; q < 8; ++q, ++tick) {
                 { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
                 if (int rc = eval_penetration(b, -2, s, true)) return rc;
@@ -1131,10 +1150,14 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
             SFX_CHECK(hipEventRecord(b->poll_ev[buf], s));
             return 0;
         };
-        int cur = 0;
-        if (int rc = rounds(cur)) return rc;
-        while (!done && tick < max_ticks) {
-            if (int rc = rounds(cur ^ 1)) return rc;
+        static const int ahead_env = [] { const char* e = getenv("SFX_POLL_AHEAD"); return e ? atoi(e) : 0; }();
+        const int ahead = std::max(1, std::min(SFX_POLL_BUFS - 1, ahead_env > 0 ? ahead_env : (b->pen ? 1 : 3)));
+        long q_head = 0, q_next = 0;       // batches processed / queued
+        for (; q_next < ahead; ++q_next) if (int rc = rounds((int)(q_next % SFX_POLL_BUFS))) return rc;
+        while (!done && tick < max_ticks + 8L * ahead) {
+            if (int rc = rounds((int)(q_next % SFX_POLL_BUFS))) return rc;
+            ++q_next;
+            const int cur = (int)(q_head % SFX_POLL_BUFS); ++q_head;
             SFX_CHECK(hipEventSynchronize(b->poll_ev[cur]));
             const int* hq = b->stage_host + (size_t)cur * B;
             // frames of the running list that have finished (frames admitted after this snapshot show their start stage)
@@ -1173,10 +1196,14 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
                     if (int rc = upload(nullptr)) return rc;      // shorter running list: fewer workgroups per tick launch
                 }
             }
-            cur ^= 1;
         }
         SFX_CHECK(hipStreamSynchronize(s));
         D.act = nullptr; D.nrun = 0;
+        if (dbg_host) {
+            const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - wall0;
+            fprintf(stderr, "[sfx] host enqueue: %ld batches of 8 rounds, %.1f us of host time per round, %.1f %% of the loop's %.1f ms wall time\n",
+                    host_batches, 1e6 * host_enq_s / std::max(1L, host_batches * 8), 100.0 * host_enq_s / std::max(wall, 1e-9), 1e3 * wall);
+        }
         if (dbg_nact) {
             fprintf(stderr, "[sfx] rounds by active columns (<=32, <=64, ..., <=256, more), cumulative:");
             for (int i = 0; i < 9; ++i) fprintf(stderr, " %ld", nact_hist[i]);

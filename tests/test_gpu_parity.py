@@ -414,6 +414,47 @@ def test_continuous_batching_matches_resident_batch(gpu, synth_model):
         assert np.array_equal(a[k], b[k], equal_nan=True), k        # (a frame that ends non-finite does so in both)
 
 
+def test_one_gpu_share_of_the_8192_frame_job(gpu, synth_model):
+    """BASELINE configs[3] as one rank sees it: 1 024 frames (bench.py's generator) -- resident, and through a pool
+    of 256 GEMM columns (`bench.py --frames 1024 --slots 256`).  Camera stage + first body stage: every frame finishes, no
+    frame depends on the pool (bitwise), and the shard's records survive pack / unpack with exact frame indices."""
+    import bench as BB
+    from smplifyx_amd import driver, dist as sd
+    import torch
+    cfg = BB.build_cfg("body")
+    dm = _dm(synth_model, cfg)
+    B = 1024
+    dev = torch.device("cuda")
+
+    def joints_fn(P):
+        z = lambda n: torch.zeros([len(P["betas"]), n], device=dev)
+        t = lambda a: torch.tensor(a, device=dev)
+        _, j, _ = dm.lbs_forward(t(P["global_orient"]), t(P["body_pose"]), t(P["betas"]), z(10), z(3), z(3), z(3), z(12), z(12),
+                                 return_verts=False, return_full_pose=False)
+        return j.cpu().numpy()
+    from smplifyx_amd import synthetic
+    fr = synthetic.make_frames(B, joints_fn, 25, start=3 * B, focal=5000.0)           # rank 3's frames
+    jw = H.base_joint_weights(cfg, 25)
+    got = []
+    for slots in (0, 256):
+        fb, prep = driver._make_batch(dm, cfg, fr["keypoints"], jw, fr["H"], fr["W"], fr["focal"], fr["reg_pose"], fr["reg_global"],
+                                      None, None, "dense", True, slots=slots)
+        fb.fit(first_stage=-1, last_stage=0)
+        st, P = fb.stats(), fb.get_params()
+        got.append((st, P))
+        fb.close()
+    (sa, pa), (sb, pb) = got
+    assert np.all(sa["stage_evals"][:, :2] > 0) and np.isfinite(sa["stage_loss"][:, :2]).mean() > 0.99
+    for k in ("stage_loss", "stage_evals", "stage_ref_evals"):
+        assert np.array_equal(sa[k][:, :2], sb[k][:, :2], equal_nan=True), k
+    for k in ("pose_embedding", "betas", "global_orient", "cam_translation"):
+        assert np.array_equal(pa[k], pb[k], equal_nan=True), k
+    res = dict(pa, stage_evals=sa["stage_evals"], final_loss=sa["stage_loss"][:, 1])
+    rec = sd.pack_records(res, 3 * B)
+    u = sd.unpack_records(rec, sd.record_fields(res))
+    assert np.array_equal(u["frame"][:, 0], 3 * B + np.arange(B)) and np.array_equal(u["betas"], pa["betas"])
+
+
 def test_shard_invariance_bitwise(gpu, synth_model, cfg_body):
     """A frame's result does not depend on which other frames share its batch."""
     cfg = dict(cfg_body); cfg["use_camera_prior"] = False
