@@ -25,6 +25,32 @@ restates the published algorithm the package implements:
 
 Everything is plain numpy / torch (autograd supplies the gradient); brute force over triangle
 pairs, chunked -- small meshes in seconds, the 20908-face topology in tens of seconds per frame.
+
+NAMED ASSUMPTIONS -- the choices this restatement (and csrc/collide.hip with it) makes where the papers leave the
+package room.  Whoever obtains the package source, or its outputs on a known mesh, should test these FIRST, in this
+order; each names the symbol that would change:
+  A1  CANDIDATES = all AABB-overlapping pairs without a shared vertex.  The package's BVH returns at most max_collisions
+      hits per query triangle IN TRAVERSAL ORDER; when that cap binds, which partners survive is implementation-defined
+      there.  Here (`ordered_pairs_capped`, collide.hip k_pen_list): the max_collisions LOWEST triangle ids of each
+      triangle's partner list, and a pair counts only if both triangles kept each other.  Differs from the package
+      exactly when some triangle has more than max_collisions partners (never on the cfgs' 128 with a sane body mesh).
+  A2  PAIR ORDER / MULTIPLICITY: each unordered pair once, both directions of the penalty summed (receiver f / intruder g
+      and the reverse).  If the package lists (f, g) and (g, f) as separate collisions and sums both directions for each,
+      every value here is half of its value (a constant factor absorbed by coll_loss_weight -- visible at once).
+  A3  CONE PARAMETRISATION: axis through the circumcentre along the unit normal, radius shrinking linearly from r_f at
+      the triangle's plane (x = 0) to 0 at height x = sigma and growing below the plane (Phi = rho / (r - r x / sigma)).
+      Tzionas' text allows the apex at +sigma (built) or a cone symmetric about the plane.
+  A4  `linear_max` (a constructor argument of the package's DistanceFieldPenetrationLoss, default 1000; the reference
+      never passes it, fit_single_frame.py:311-314): believed to cap the linear branch of Ups for points far below the
+      plane (x <= -sigma).  NOT applied here: Ups grows without bound.  Matters only for penetration depths beyond
+      linear_max x sigma = 0.1 m at the cfgs' sigma 1e-4.
+  A5  `penalize_outside=False` keeps the points with x <= 0 only (built); the package may instead keep those inside the
+      mesh by a winding test.
+  A6  `point2plane=True` (cmd_parser.py:239; every shipped cfg leaves it False): refused, not restated.  With unit normals
+      Tzionas' point-to-plane form |Psi n|^2 equals Psi^2, so value and gradient would coincide with the built term
+      unless the package differentiates through the normal of the INTRUDING vertex.
+  A7  SHARED VERTICES: a pair of triangles with a common vertex is never a collision (the package filters such pairs in
+      its BVH traversal); triangles that merely touch along an edge of different vertices are.
 """
 import numpy as np
 import torch
