@@ -9,7 +9,7 @@
 // (the package's source is absent: parity unpinned).
 //
 // MI355X design (not the package's LBVH; DESIGN.md 4.6 has the table):
-//   k_pen_reset / g1 / g2 / g3   triangle AABBs (8 x 1024 lanes per frame) -> bounding box per body part: a triangle
+//   k_pen_g1 / g2 / g3   triangle AABBs (8 x 1024 lanes per frame) -> bounding box per body part: a triangle
 //                 whose box meets the box of no part it may collide with is dropped, the survivors are
 //                 compacted (8 x 1024) -> they enter a uniform grid (cell = twice the mean triangle extent,
 //                 every cell the AABB touches) hashed into 16384 LDS buckets by a counting sort (1 x 1024).
@@ -31,7 +31,11 @@
 //                 scheduling and of batch composition, and the work is balanced over the chip however
 //                 unevenly the collisions are spread over the triangles.
 //   k_pen_facesum / k_pen_gather   per-triangle sums over the pair ranges; vertex gradient = fixed-order
-//                 sum over the incident triangle corners (CSR); frame loss = triangles in index order.
+//                 sum over the incident triangle corners (CSR); frame loss = triangles in index order; for a fitting batch
+//                 the same lane writes d v_posed = T^T g, the operand of the adjoint GEMM (lbs_adjoint.hip).
+// Ten launches per evaluation (twelve + two memsets until round 4: the accumulators of the grid build are left empty by
+// k_pen_g3 for the next evaluation instead of by a kernel of their own, and the per-column "wanted" flags are kept by the
+// fitting loop's tick kernel).
 #include "../../include/sfx.h"
 #include "sfx_internal.h"
 #include "wave_ops.h"
@@ -78,7 +82,7 @@ struct PenDev {
     int2* entries;             // [B][ent_cap] (triangle | part << 24 | lz << 30, packed cell coordinates | lx << 30 | ly << 31), sorted by bucket;
                                //              lx, ly, lz: the cell holds the low corner of the triangle's box on that axis
     int4* tlist;               // [B][F] the triangles that survive the part culling, compacted (any order): packed cell range, spans + part, triangle
-    int* tcount;               // [B][16] (one cache line each) number of survivors (k_pen_reset -> 0, k_pen_g2 reserves ranges)
+    int* tcount;               // [B][16] (one cache line each) number of survivors (k_pen_g3 leaves 0 behind, k_pen_g2 reserves ranges)
     int* pbox;                 // [B][64][6] bounding box of every part, order-preserving ints (k_pen_g1; reset per evaluation)
     float* gpart;              // [B][PEN_GW][8] per workgroup of k_pen_g1: frame box lo / hi, extent sum
     int ent_cap;
