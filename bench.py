@@ -81,7 +81,8 @@ def sanitize(o):
 
 ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "frac_executed", "mfma_busy_frac",
                  "avg_launch_us", "launches", "frames_per_launch", "share_of_step", "hbm_frac", "bytes_per_launch",
-                 "bytes_per_frame_launch", "rows_per_frame_launch", "columns_per_launch", "bytes_per_column_launch",
+                 "bytes_per_frame_launch", "rows_per_frame_launch", "shared_bytes_per_launch", "l2_stream_bytes_per_frame", "l2_stream_GBps_per_cu",
+                 "columns_per_launch", "bytes_per_column_launch",
                  "grid_entries_per_column", "pairs_per_column", "launches_per_round")
 
 
@@ -150,18 +151,28 @@ def write_detail(full, tag):
 def item_rows_by_class(joint_map, n_extra, n_lmk, nbj):
     """Vertex items (blend-shape row triples) under the live keypoints of the three stage classes -- body only | + hands |
     all -- for a joint map (SFX model source indices: < 55 kinematic joint, then extra vertices (1 item), static landmarks
-    (3 items: face corners), dynamic contour landmarks (3 items)); keypoints are ordered body | hands (42) | face."""
-    per_k = [0 if s < 55 else (1 if s < 55 + n_extra else 3) for s in np.asarray(joint_map).tolist()]
+    (3 items: face corners), dynamic contour landmarks (3 items)); keypoints are ordered body | hands (42) | face.
+    Returns (all items per class, of which dynamic-contour items per class)."""
+    src = np.asarray(joint_map).tolist()
+    per_k = [0 if s_ < 55 else (1 if s_ < 55 + n_extra else 3) for s_ in src]
+    dyn_k = [3 if s_ >= 55 + n_extra + n_lmk else 0 for s_ in src]
     K = len(per_k)
-    return [int(sum(per_k[:min(K, nbj)])), int(sum(per_k[:min(K, nbj + 42)])), int(sum(per_k))]
+    cut = [min(K, nbj), min(K, nbj + 42), K]
+    return [int(sum(per_k[:c])) for c in cut], [int(sum(dyn_k[:c])) for c in cut]
 
 
-def tick_bytes_per_frame_launch(rows_live, n_var_live, use_vposer, vposer_bytes=0.0, kd=506, hist=100):
-    """Algorithmic bytes one frame's pass through k_tick_dense must move per launch: the adjoint streams 3 blend-shape
-    rows (kd floats + 16 B of skinning) per live vertex item (forward offsets come from the GEMM); the two-loop
-    recursion reads 2 x hist history rows of the live optimiser variables; 8 work vectors; with VPoser the decoder's
-    weights forward (next pose) and transposed (gradient)."""
-    return rows_live * (3 * kd + 16) * 4.0 + 2.0 * hist * n_var_live * 4.0 + 8 * n_var_live * 4.0 + (2.0 * vposer_bytes if use_vposer else 0.0)
+def tick_bytes(rows_static, rows_dynamic, n_var_live, use_vposer, vposer_bytes=0.0, kd=506, hist=100):
+    """Algorithmic HBM bytes of k_tick_dense: (shared per launch, per frame and launch).
+    Shared by every frame of a launch -- read from HBM once, like the GEMM's blend-shape matrix: the adjoint's 3 blend-shape
+    rows (kd floats + 16 B of skinning) per STATIC live vertex item (forward offsets come from the GEMM), and with VPoser the
+    decoder's weights forward (next pose) and transposed (gradient).  Per frame: the rows of its dynamic-contour items (they
+    follow the head pose), the two-loop recursion's 2 x hist history rows of the live optimiser variables, 8 work vectors.
+    What one FRAME streams through its compute unit's L2 port per launch is shared + per-frame: that, not HBM, is what the
+    kernel waits for (`l2_stream_*` keys)."""
+    row = (3 * kd + 16) * 4.0
+    shared = rows_static * row + (2.0 * vposer_bytes if use_vposer else 0.0)
+    per_frame = rows_dynamic * row + 2.0 * hist * n_var_live * 4.0 + 8 * n_var_live * 4.0
+    return shared, per_frame
 
 
 # The headline (`value`) is measured on SURVEY.md 8(d)'s generator VERBATIM: confidences U(0.3, 1), 10 % of the keypoints
@@ -863,30 +874,37 @@ def main():
             if n_clo:
                 nbj = engine.NUM_BODY_JOINTS[cfg.get("format", "coco25")]
                 n_extra = len(model.get("extra_vertex_ids", engine.SMPLX_EXTRA_VERTEX_IDS))
-                rows_cls = item_rows_by_class(jm, n_extra, int(np.asarray(model["lmk_faces_idx"]).shape[0]), nbj)
+                rows_cls, dyn_cls = item_rows_by_class(jm, n_extra, int(np.asarray(model["lmk_faces_idx"]).shape[0]), nbj)
                 sw_list, _ = engine.stage_weights_from_cfg(cfg)
                 cls_of = [2 if w.face_joint_weight != 0 else (1 if w.hand_joint_weight != 0 else 0) for w in sw_list]
                 ev_stage = st["stage_evals"].sum(0).astype(np.float64)           # [1 + stages]: camera stage first (all keypoints projected, 4 weighted)
                 wts = np.array([ev_stage[0]] + [ev_stage[1 + i] for i in range(len(cls_of))])
-                rws = np.array([rows_cls[2]] + [rows_cls[c] for c in cls_of], np.float64)
-                rows_live = float((wts * rws).sum() / max(wts.sum(), 1.0))
+                mean_over = lambda per_cls: float((wts * np.array([per_cls[2]] + [per_cls[c] for c in cls_of], np.float64)).sum() / max(wts.sum(), 1.0))
+                rows_live, rows_dyn = mean_over(rows_cls), mean_over(dyn_cls)
                 use_vp = bool(cfg.get("use_vposer", True))
                 n_live = (32 if use_vp else 63) + 3 + 10 + 3 + (24 + 3 + 3 + 3 + 10)          # embedding, orient, betas, cam | hands, jaw, eyes, expression
                 vp_bytes = 4.0 * (512 * 32 + 512 * 512 + 126 * 512 + 512 + 512 + 126) if use_vp else 0.0
-                by_frame = tick_bytes_per_frame_launch(rows_live, n_live, use_vp, vp_bytes)
+                by_shared, by_frame = tick_bytes(rows_live - rows_dyn, rows_dyn, n_live, use_vp, vp_bytes)
                 t_clo = 1e-3 * ms_clo
                 act = u_clo if u_clo else fpl * n_clo
-                out["roofline_tick"] = {"kernel": "k_tick_dense", "bound": "hbm", "achieved": by_frame * act / t_clo / 1e9,
-                                        "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": by_frame * act / t_clo / PEAK_HBM,
+                by_launch = by_shared + by_frame * act / n_clo
+                out["roofline_tick"] = {"kernel": "k_tick_dense", "bound": "hbm", "achieved": by_launch * n_clo / t_clo / 1e9,
+                                        "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": by_launch * n_clo / t_clo / PEAK_HBM,
                                         "traffic": None, "bytes_per_frame_launch": by_frame, "rows_per_frame_launch": rows_live,
-                                        "bytes_per_launch": by_frame * act / n_clo,
+                                        "bytes_per_launch": by_launch, "shared_bytes_per_launch": by_shared,
                                         "avg_launch_us": 1e6 * t_clo / n_clo,
                                         "launches": n_clo, "frames_per_launch": act / n_clo,
                                         "share_of_step": ms_clo * args.prof_every / (1e3 * dt),
-                                        "rows_by_stage_class": rows_cls, "live_variables": n_live, "vposer_weight_bytes": vp_bytes,
+                                        # what one frame pulls through its compute unit's L2 port per launch, and the rate that is over
+                                        # the launch (a CU streams ~100 GB/s from L2: tools/micro/stream_cu.hip)
+                                        "l2_stream_bytes_per_frame": by_shared + by_frame,
+                                        "l2_stream_GBps_per_cu": (by_shared + by_frame) * n_clo / t_clo / 1e9,
+                                        "rows_by_stage_class": rows_cls, "dynamic_rows_by_stage_class": dyn_cls, "live_variables": n_live,
+                                        "vposer_weight_bytes": vp_bytes,
                                         "note": "latency-bound by construction (one frame's serial L-BFGS chain per workgroup): the "
-                                                "figure to watch is avg_launch_us; bytes = adjoint rows of the live vertex items "
-                                                "(evaluation-weighted over the stages) + history + vectors (+ 2 x VPoser weights)"}
+                                                "figure to watch is avg_launch_us.  bytes_per_launch = constants every frame shares (static "
+                                                "adjoint rows, 2 x VPoser weights: once per launch, as the GEMM's matrix) + per frame "
+                                                "(dynamic-contour rows, history, vectors) x frames, rows evaluation-weighted over the stages"}
                 if pmc_ok:
                     k = pmc_kernel("k_tick_dense")
                     if "hbm_read_bytes_per_launch" in k:

@@ -190,15 +190,16 @@ def test_detail_file_is_strict_json(tmp_path, monkeypatch):
 def test_tick_byte_model_follows_the_workload():
     """roofline_tick's algorithmic bytes come from the workload's own vertex items and optimiser width (round 3 divided the
     body-only 11 rows by the full model's kernel time): 11 rows body-only; 11 / 53 / 225 by stage class for coco25 +
-    hands + face + contour; VPoser adds its weights twice."""
+    hands + face + contour, 51 of them dynamic-contour items; constants that every frame of a launch shares (static rows,
+    VPoser weights twice) count once per launch, like the GEMM's matrix."""
     from smplifyx_amd import utils as U
     jm_body = U.smpl_to_annotation("smplx", use_hands=False, use_face=False, use_face_contour=False, format="coco25")
     jm_full = U.smpl_to_annotation("smplx", use_hands=True, use_face=True, use_face_contour=True, format="coco25")
-    assert BB.item_rows_by_class(jm_body, 21, 51, 25) == [11, 11, 11]
-    rows = BB.item_rows_by_class(jm_full, 21, 51, 25)
-    assert rows[0] == 11 and rows[2] == 225 and rows[0] < rows[1] < rows[2]
-    b_body = BB.tick_bytes_per_frame_launch(11, 119, False)
-    assert abs(b_body - (11 * (3 * 506 + 16) * 4 + 2 * 100 * 119 * 4 + 8 * 119 * 4)) < 1e-6
+    assert BB.item_rows_by_class(jm_body, 21, 51, 25) == ([11, 11, 11], [0, 0, 0])
+    rows, dyn = BB.item_rows_by_class(jm_full, 21, 51, 25)
+    assert rows[0] == 11 and rows[2] == 225 and rows[0] < rows[1] < rows[2] and dyn == [0, 0, 51]
+    sh, pf = BB.tick_bytes(11, 0, 119, False)
+    assert abs(sh - 11 * (3 * 506 + 16) * 4) < 1e-6 and abs(pf - (2 * 100 * 119 * 4 + 8 * 119 * 4)) < 1e-6
     vp = 4.0 * (512 * 32 + 512 * 512 + 126 * 512 + 512 + 512 + 126)
-    b_full = BB.tick_bytes_per_frame_launch(225, 88, True, vp)
-    assert b_full > 2 * vp and b_full - 2 * vp > b_body
+    sh2, pf2 = BB.tick_bytes(174, 51, 88, True, vp)
+    assert sh2 > 2 * vp and abs(sh2 - 2 * vp - 174 * (3 * 506 + 16) * 4) < 1e-3 and pf2 > 51 * 3 * 506 * 4

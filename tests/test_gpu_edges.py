@@ -149,10 +149,12 @@ def test_halpe_closure_matches_oracle(synth_model):
             H.check_closure("halpe-full-rows", stage, loss[i], lo, grad[i], go)
 
 
-def test_bench_two_rank_control_flow_rehearsal():
+@pytest.mark.parametrize("extra", [["--lbs", "rows"], ["--workload", "pen"]], ids=["body-rows", "pen-dense"])
+def test_bench_two_rank_control_flow_rehearsal(extra):
     """`python bench.py --gpus 2` (it launches its own 2 ranks; both on GPU 0, gloo, in this rehearsal): the N > 1 control
     flow -- per-rank frame blocks, barriers, max-over-ranks time, the record gather -- produces one
-    JSON line whose frame count is the whole job's."""
+    JSON line whose frame count is the whole job's.  Also for BASELINE configs[4] (the halpe cfg with the interpenetration
+    term, which the 8-GPU run shards exactly like this: per-rank camera priors, per-rank collision buffers)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SFX_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
@@ -160,7 +162,7 @@ def test_bench_two_rank_control_flow_rehearsal():
         env.pop(k, None)
     # exactly what the driver types, no launcher: bench.py starts its ranks itself
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-           "--frames", "32", "--no-cpu", "--no-alt", "--lbs", "rows"]
+           "--frames", "32", "--no-cpu", "--no-alt"] + extra
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -176,6 +178,9 @@ def test_bench_two_rank_control_flow_rehearsal():
     c = d["config"]
     assert c["per_gpu_frames_per_s_min"] <= c["per_gpu_frames_per_s_mean"] and c["single_gpu_same_job_frames_per_s"] == pytest.approx(ranks[0]["frames_per_s"], rel=1e-4)
     assert d["value"] <= 2 * c["per_gpu_frames_per_s_mean"] * 1.001          # the job's rate is bound by its slowest rank
+    if "pen" in extra:
+        assert d["config"]["workload"].startswith("configs[4]") and d["roofline_pen"]["pairs_per_column"] >= 0
+        return
     # ... and under an external launcher whose world size disagrees with --gpus it refuses instead of mis-reporting
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=root, capture_output=True, text=True, timeout=300)
@@ -238,7 +243,8 @@ def test_bench_line_contract(workload):
         assert d["roofline_tick"]["rows_per_frame_launch"] == pytest.approx(11.0)
     if workload == "full":       # the byte model of the per-frame kernel is this workload's: live items by stage, VPoser weights twice
         rt = d["roofline_tick"]
-        assert 11.0 < rt["rows_per_frame_launch"] <= 225.0 and rt["bytes_per_frame_launch"] > 2 * 1.3e6
+        assert 11.0 < rt["rows_per_frame_launch"] <= 225.0 and rt["shared_bytes_per_launch"] > 2 * 1.3e6
+        assert rt["l2_stream_bytes_per_frame"] > rt["shared_bytes_per_launch"] and 0 < rt["frac"] < 0.2
     if workload == "pen":        # grid entries and pairs are COUNTED over the timed region, not typical constants
         rp = d["roofline_pen"]
         assert rp["grid_entries_per_column"] > 0 and rp["pairs_per_column"] >= 0 and rp["columns_per_launch"] > 0
