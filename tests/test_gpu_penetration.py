@@ -311,8 +311,8 @@ def test_interpenetration_at_the_cfg_values(synth_model):
 
 
 def test_dense_skinning_adjoint_matches_torch_reference(synth_model):
-    """csrc/lbs_adjoint.hip in isolation (k_adj_prep -> fp32-MFMA split-K GEMM k_lbs_dense_adj ->
-    k_adj_reduce, and k_adj_dA): from the evaluation's own vertex gradient g, skinning transforms A,
+    """The adjoint of the dense skinning in isolation (d v_posed = T^T g written by k_pen_gather -> fp32-MFMA split-K GEMM
+    k_lbs_dense_adj -> k_adj_finish: partial sums and d A): from the evaluation's own vertex gradient g, skinning transforms A,
     v_posed and the model constants, a plain torch fp64 restatement of
         d feat[k] = sum_{v,c} dirs[k][3v+c] (T_v^T g_v)[c],   T_v = sum_j W[v][j] A_j
         d A_j     = sum_v W[v][j] g_v (x) [v_posed_v; 1]
