@@ -212,6 +212,11 @@ int  sfx_batch_get_grad(sfx_batch* b, int32_t stage, float* grad_out);
 /* Interpenetration diagnostics of the most recent evaluation (batches with interpenetration = 1),
  * per active GEMM column: stats as sfx_pen_stats; ext_n = vertices that carried a gradient.    */
 int  sfx_batch_pen_stats(sfx_batch* b, int32_t* stats_host /* [B][4] */, int32_t* ext_n_host /* [B] or NULL */);
+/* Per FRAME, sticky since the start of the last fit / step (HOST [B]): 1 = the frame consumed a collision evaluation in which
+ * some triangle met more than 2 x max_collisions partners or a bucket walk was cut short -- there the partners kept depend on
+ * arrival order (the package's BVH is traversal-order dependent in the same situation, fitting.py:445-447), so this frame's
+ * result is not reproducible run to run.  0 on any sane mesh.                                                              */
+int  sfx_batch_pen_flags(sfx_batch* b, int32_t* flags_host);
 
 /* Per-frame results of the last sfx_batch_fit (HOST pointers, any may be NULL):
  *  stage_loss [B][1+n_stages]  value run_fitting returns per stage (camera first)

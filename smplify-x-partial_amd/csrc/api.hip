@@ -117,7 +117,7 @@ extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float
                             float* loss_dev, float* dverts_dev, void* stream);
 extern "C" int sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host);
 int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
-                        float* loss_dev, float* dverts_dev, const int* want_dev, const PenAdjPrep* prep, void* stream);
+                        float* loss_dev, float* dverts_dev, const int* want_dev, const PenAdjPrep* prep, int* over_dev, void* stream);
 int sfx_pen_capacity(const sfx_pen* h);          // meshes per call the handle's buffers hold (collide.hip)
 int sfx_pen_stats_from(const int* stats_dev, int n, int32_t* stats_host);
 int sfx_pen_stats_stride(void);
@@ -676,6 +676,8 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
         D.pen_dverts = b->mem.zeros<float>((size_t)B * m->M.V * 3);
         D.ext_n = b->mem.zeros<int>(B);
         D.pen_want = b->mem.zeros<int>(B);
+        D.pen_over = b->mem.zeros<int>(B);
+        D.pen_flag = b->mem.zeros<int>(B);
         D.vposed = b->mem.zeros<float>((size_t)B * m->M.V * 3);
         D.adj_G = b->mem.zeros<float>((size_t)D.Bpad * 3 * m->M.Vpad);
         D.adj_part = b->mem.zeros<float>((size_t)sfx_adj_slices(m->M) * SFX_KD_PAD * D.Bpad);
@@ -996,7 +998,7 @@ static int eval_penetration(sfx_batch* b, int stage_override, hipStream_t s, boo
         // the lane that forms a vertex' gradient also writes d v_posed = T^T g, the adjoint GEMM's operand (column c0 + local index)
         PenAdjPrep ap{D.AT + c0, M.Wsp_j, M.Wsp_w, M.W, D.adj_G + (size_t)c0 * 3 * M.Vpad, D.Bpad, M.Vpad};
         int rc = sfx_pen_eval_masked(b->pen, n, D.verts + c0 * V3, b->pen_sigma, b->pen_outside, D.pen_loss + c0, D.pen_dverts + c0 * V3,
-                                     D.pen_want + c0, &ap, s);
+                                     D.pen_want + c0, &ap, D.pen_over + c0, s);
         if (rc) return rc;
         if (b->pen_chunked)     // keep this chunk's diagnostics: the next chunk reuses the rows
             SFX_CHECK(hipMemcpyAsync(b->pen_stats_all + (size_t)c0 * stride, sfx_pen_stats_dev(b->pen), (size_t)n * stride * sizeof(int), hipMemcpyDeviceToDevice, s));
@@ -1085,6 +1087,7 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
     const bool dense = D.cfg.lbs_mode == 1;
     const bool fused = !step_mode && !g_unfused;
     D.act = nullptr; D.nrun = 0;          // (a previous fit that ended on an error may have left its running list attached)
+    if (init == 1 && D.pen_flag) SFX_CHECK(hipMemsetAsync(D.pen_flag, 0, (size_t)B * sizeof(int), s));
     launch_lbfgs_tick(M, D, b->vl_dev, first_stage, last_stage, init, step_mode, s);
     // bound on the rounds of the polled loops: one resident batch needs at most stages x maxiters LBFGS.step calls of
     // <= ~160 evaluations each; a job of B frames through a pool of `slots` columns needs that once per wave of the queue
@@ -1442,6 +1445,14 @@ extern "C" int sfx_batch_pen_stats(sfx_batch* b, int32_t* stats_host /* [B][4] *
         SFX_CHECK(hipDeviceSynchronize());
         SFX_CHECK(hipMemcpy(ext_n_host, b->D.ext_n, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     }
+    return 0;
+}
+
+extern "C" int sfx_batch_pen_flags(sfx_batch* b, int32_t* flags_host /* [B] */) {
+    if (!b || !flags_host) { sfx_set_error("null argument"); return -1; }
+    if (!b->pen) { sfx_set_error("batch was created without interpenetration"); return -1; }
+    SFX_CHECK(hipDeviceSynchronize());
+    SFX_CHECK(hipMemcpy(flags_host, b->D.pen_flag, (size_t)b->D.cfg.B * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -826,7 +826,10 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         if (C.use_hands) total = total + q[Q_LH] * h2 + q[Q_RH] * h2;
         // interpenetration (fitting.py:437-455): evaluated on all vertices by csrc/collide.hip right
         // after the dense LBS; its vertex gradient enters the reverse sweep below
-        if (C.pen && args.use_dense_verts && sw.coll > 0.f) total = total + sw.coll * D.pen_loss[D.slot[b]];
+        if (C.pen && args.use_dense_verts && sw.coll > 0.f) {
+            total = total + sw.coll * D.pen_loss[D.slot[b]];
+            if (t == 0 && D.pen_over && D.pen_over[D.slot[b]]) D.pen_flag[b] = 1;      // (diagnostic: see BatchDev.pen_flag)
+        }
         if (t < 3) S.gc[L.cam_t + t] = (t == 0) ? q[Q_D0] : (t == 1) ? q[Q_D1] : q[Q_D2];
     }
     __syncthreads();

@@ -42,6 +42,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define PEN_T 1024
@@ -102,6 +103,8 @@ struct PenDev {
     int* cells;                // [B][PEN_CELLS + 1] bucket END offsets into entries ([PEN_CELLS] = number of entries)
     float* gridp;              // [B][4] low corner of the frame's box, 1 / cell size
     int* stats;                // [B][PEN_STATS]: pairs (ordered), dropped partners, overflow of entries, cells, phase clocks
+    int* over;                 // [B] or NULL (set per call): 1 = this evaluation of the mesh kept partners by ARRIVAL order somewhere (a list beyond
+                               //     2 x max_collisions, a cut walk): its numbers are not reproducible run to run
     unsigned long long* work;  // [6] process-wide counts since sfx_pen_work_reset: grid entries, ordered pairs, column evaluations, surviving triangles,
                                //     triangles with more partners than the lists hold (2 x max_collisions: arrival order decides there), bucket walks cut short
 };
@@ -741,6 +744,7 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
     unsigned* hasp = P.hasp + (size_t)b * P.hasp_words;
     if ((want && !want[b]) || st[2] != 0) {          // skipped frame / grid overflow: k_pen_grid has zeroed the totals
         for (int w = t; w < P.hasp_words; w += PEN_T) hasp[w] = 0u;
+        if (P.over && t == 0) P.over[b] = 0;
         return;
     }
     const int F = P.F;
@@ -758,7 +762,15 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
     unsigned* s_has = reinterpret_cast<unsigned*>(s_cnt + F);
     // (every lane owns a contiguous run of triangles for the scan; read straight from global memory those runs are 84-byte
     //  strides across the lanes and two chains of 21 dependent loads -- the counts are staged through LDS coalesced instead)
-    for (int f = t; f < F; f += PEN_T) s_cnt[f] = pc[f];
+    // (round 4: every global access of this kernel is coalesced -- the clamped counts are written in the pass that reads the raw
+    //  ones, the offsets go to LDS in place and leave in a pass of their own; the per-lane runs of 21 triangles used to write
+    //  three arrays at a stride of 84 bytes across the lanes: 63 store instructions of 64 cache lines each, most of the kernel)
+    for (int f = t; f < F; f += PEN_T) {
+        const int raw = pc[f];
+        s_cnt[f] = raw;
+        pav[f] = min(raw, P.pcap);
+        pc[f] = min(raw, P.cap);
+    }
     for (int w = t; w < P.hasp_words; w += PEN_T) s_has[w] = 0u;
     __syncthreads();
     {
@@ -773,18 +785,20 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
             const int c = min(raw, P.cap);
             const int keep = max(0, min(c, P.pair_cap - acc));
             n_over += c - keep;
-            pav[f] = min(raw, P.pcap);
-            poff[f] = acc; pc[f] = c;            // readers cut at pair_cap: kept = clamp(pair_cap - poff, 0, pcount)
+            s_cnt[f] = acc;                      // the triangle's offset (readers cut at pair_cap: kept = clamp(pair_cap - poff, 0, pcount))
             if (c > 0 && acc < P.pair_cap) atomicOr(&s_has[f >> 5], 1u << (f & 31));
             acc += c;
         }
         const float to = block_sum_fixed((float)n_over, red);
         const float ta = block_sum_fixed((float)n_arr, red);
         if (t == 0) { const int tot = min(ptot, P.pair_cap); P.ptotal[b] = tot; st[0] = tot; st[1] = (int)to;
+                      if (P.over) P.over[b] = (ta > 0.f || st[13] > 0) ? 1 : 0;
                       if (P.work) { atomicAdd(&P.work[1], (unsigned long long)tot);
                                     if (ta > 0.f) atomicAdd(&P.work[4], (unsigned long long)ta);
                                     if (st[13] > 0) atomicAdd(&P.work[5], (unsigned long long)st[13]); } }
     }
+    __syncthreads();
+    for (int f = t; f < F; f += PEN_T) poff[f] = s_cnt[f];
     __syncthreads();
     for (int w = t; w < P.hasp_words; w += PEN_T) hasp[w] = s_has[w];
 }
@@ -899,16 +913,67 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
 // with respect to f's 9 coordinates only, so every number has one owner.
 // Loss of the frame = sum over the kept ordered pairs (f, g) of sum_{v in g} Psi_f(v)^2; the kept set is symmetric
 // (see below), so the gradient is exact also when max_collisions cuts a list
+//
+// Work distribution (round 4): ONE flat list of 64-pair chunks over all meshes of the call.  With a grid per mesh (128
+// workgroups each) a launch lasted as long as its most crowded mesh -- a frame whose limbs a trial step has pushed through each
+// other carries ten times the pairs of the others (p50 22 us, p90 178 us, mean 60) -- while the lanes of every other mesh idled.
+// Every workgroup forms the exclusive prefix of the meshes' chunk counts (ptotal, a few hundred integers) in LDS; a wavefront
+// takes chunks c = w, w + W, ...; the mesh of a chunk is found by bisection.  A chunk is 64 consecutive pairs of ONE mesh's
+// list, aligned to 64 in that list -- what k_pen_facesum's run sums rely on -- so the numbers are what they were.
+#define PEN_FLAT_MAXB 4096      // meshes per call the flat distribution handles (beyond: one grid row per mesh, as before)
+#define PEN_FLAT_BLOCKS 2048
+__device__ __forceinline__ int pen_chunk_prefix(const PenDev& P, const int B, int* s_pref /* [B + 1] */, int* s_scan /* [256] */) {
+    const int t = threadIdx.x;
+    const int per = (B + 255) / 256;
+    const int b0 = min(B, t * per), b1 = min(B, b0 + per);
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += (P.ptotal[b] + 63) >> 6;
+    s_scan[t] = sum;
+    __syncthreads();
+    // 256-entry scan by one wavefront (four per lane), fixed order
+    if (t < 64) {
+        int v[4], run = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { v[u] = s_scan[t * 4 + u]; run += v[u]; }
+        int inc = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (t >= d) inc += o; }
+        int ex = inc - run;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s_scan[t * 4 + u] = ex; ex += v[u]; }
+    }
+    __syncthreads();
+    int acc = s_scan[t];
+    for (int b = b0; b < b1; ++b) { s_pref[b] = acc; acc += (P.ptotal[b] + 63) >> 6; }
+    if (b1 == B && b0 < B) s_pref[B] = acc;
+    if (B == 0 && t == 0) s_pref[0] = 0;
+    __syncthreads();
+    return s_pref[B];
+}
+__device__ __forceinline__ int pen_chunk_mesh(const int* s_pref, const int B, const int c) {      // last b with s_pref[b] <= c
+    int lo = 0, hi = B - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= c) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
 __global__ __launch_bounds__(256)
-void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int penalize_outside) {
-    const int b = blockIdx.y;
-    const int total = P.ptotal[b];
-    const float* vb = verts + (size_t)b * P.V * 3;
-    const int* pown = P.pown + (size_t)b * P.pair_cap;
-    const int* plist = P.plist + (size_t)b * P.pair_cap;
-    float* po = P.pout + (size_t)b * 10 * P.pair_cap;
+void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int penalize_outside, int B, int flat) {
+    extern __shared__ int s_pref[];             // [B + 1] (flat distribution)
+    __shared__ int s_scan[256];
     const int lane = threadIdx.x & 63;
-    for (int i0 = blockIdx.x * 256 + (threadIdx.x & ~63); i0 < total; i0 += gridDim.x * 256) {      // wave-uniform trip count
+    int n_chunks = 0;
+    if (flat) n_chunks = pen_chunk_prefix(P, B, s_pref, s_scan);
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    // flat: chunk ids wave, wave + n_waves, ...; per mesh (flat = 0): blockIdx.y is the mesh, chunks of its own list
+    for (int c = flat ? wave : (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); ; c += n_waves) {
+        int b, i0;
+        if (flat) { if (c >= n_chunks) break; b = pen_chunk_mesh(s_pref, B, c); i0 = (c - s_pref[b]) * 64; }
+        else { b = blockIdx.y; i0 = c * 64; if (i0 >= P.ptotal[b]) break; }
+        const int total = P.ptotal[b];
+        const float* vb = verts + (size_t)b * P.V * 3;
+        const int* pown = P.pown + (size_t)b * P.pair_cap;
+        const int* plist = P.plist + (size_t)b * P.pair_cap;
+        float* po = P.pout + (size_t)b * 10 * P.pair_cap;
         const int i = i0 + lane;
         const bool valid = i < total;
         const int is_ = valid ? i : 0;
@@ -1147,7 +1212,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     sfx_pen* h = new sfx_pen();
     PenDev& P = h->P;
     P.V = V; P.F = F; P.cap = max_collisions; h->Bmax = max_batch;
-    P.work = pen_work_buffer();
+    P.work = pen_work_buffer(); P.over = nullptr;
     P.pcap = std::max(P.cap, std::min(2 * P.cap, 2048));
     std::vector<int> fv(faces, faces + (size_t)F * 3), sg(F, 0);
     int np = 1;
@@ -1211,7 +1276,7 @@ extern "C" void sfx_pen_destroy(sfx_pen* h) {
 }
 
 int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
-                        float* loss_dev, float* dverts_dev, const int* want_dev, const PenAdjPrep* prep, void* stream) {
+                        float* loss_dev, float* dverts_dev, const int* want_dev, const PenAdjPrep* prep, int* over_dev, void* stream) {
     if (!h || !verts_dev || !loss_dev || !dverts_dev) { sfx_set_error("null argument"); return -1; }
     if (B < 1 || B > h->Bmax) { sfx_set_error("batch %d exceeds the capacity %d given to sfx_pen_create", B, h->Bmax); return -1; }
     if (!(sigma > 0.f)) { sfx_set_error("df_cone_height must be positive"); return -1; }
@@ -1229,12 +1294,18 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
     hipLaunchKernelGGL(k_pen_g2, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, want_dev);
     hipLaunchKernelGGL(k_pen_g3, dim3(B), dim3(PEN_T), (size_t)(PEN_GRID_INTS + PEN_CELLS) * sizeof(int), s, h->P, want_dev);
     hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, h->P, want_dev);
-    hipLaunchKernelGGL(k_pen_list, dim3(B), dim3(PEN_T), (size_t)(h->P.F + h->P.hasp_words) * sizeof(int), s, h->P, want_dev);
+    PenDev Pl = h->P;
+    Pl.over = over_dev;         // (per call: the caller's per-mesh "arrival order decided" flags, or NULL)
+    hipLaunchKernelGGL(k_pen_list, dim3(B), dim3(PEN_T), (size_t)(h->P.F + h->P.hasp_words) * sizeof(int), s, Pl, want_dev);
     int cap_pad = 64;
     while (cap_pad < h->P.pcap) cap_pad <<= 1;
     hipLaunchKernelGGL(k_pen_rank, dim3(PEN_RANK_BLOCKS, B), dim3(256), (size_t)4 * std::min(std::max(cap_pad, 64), 2048) * sizeof(int), s,
                        h->P, want_dev, cap_pad);
-    hipLaunchKernelGGL(k_pen_eval, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside);
+    static const bool flat_off = getenv("SFX_PEN_FLAT_OFF") != nullptr;      // (A/B measurement switch: same numbers either way)
+    if (B <= PEN_FLAT_MAXB && !flat_off)
+        hipLaunchKernelGGL(k_pen_eval, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, verts_dev, sigma, penalize_outside, B, 1);
+    else
+        hipLaunchKernelGGL(k_pen_eval, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside, B, 0);
     hipLaunchKernelGGL(k_pen_facesum, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P);
     PenAdjPrep ap{};
     if (prep) ap = *prep;
@@ -1246,7 +1317,7 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
 
 extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
                             float* loss_dev, float* dverts_dev, void* stream) {
-    return sfx_pen_eval_masked(h, B, verts_dev, sigma, penalize_outside, loss_dev, dverts_dev, nullptr, nullptr, stream);
+    return sfx_pen_eval_masked(h, B, verts_dev, sigma, penalize_outside, loss_dev, dverts_dev, nullptr, nullptr, nullptr, stream);
 }
 
 // debug: wall-clock ticks (100 MHz) at the end of k_pen_pairs' steps for the first B frames: [B][10] = triangle boxes,

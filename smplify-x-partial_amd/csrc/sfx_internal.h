@@ -229,6 +229,8 @@ struct BatchDev {
     float* pen_dA;          // [B][J][12] (slot-indexed) d pen_loss / d A
     int*   pen_want;        // [B] (slot-indexed) 1 = the column's pending evaluation carries a collision weight
     int*   ext_n;           // [B] (slot-indexed) vertices with a nonzero penetration gradient (diagnostics)
+    int*   pen_over;        // [B] (slot-indexed) 1 = the column's latest collision evaluation kept partners by arrival order somewhere
+    int*   pen_flag;        // [B] (frame-indexed, sticky over a fit) the frame consumed such an evaluation: not reproducible run to run
     float* fwd;             // [B][SFX_FWD_N] forward state handed from the export pass to the adjoint pass
     long long* dbg;         // [64] phase timestamps of block 0 (NULL = off)
     float4* trace;          // [B][trace_cap] optimiser trace records (NULL = off), see sfx_batch_trace

@@ -120,6 +120,8 @@ def _collect(fb, prep, want_vertices):
                stage_ref_evals=st["stage_ref_evals"].copy(),
                n_orient=np.where(prep["try_both"] & (fb.n_stages > 0), 2, 1).astype(np.int32))
     out["final_loss"] = out["stage_loss"][:, -1].copy()
+    if fb.cfg.get("interpenetration", False):
+        out["pen_order_dependent"] = fb.penetration_flags()      # frames whose collision partners depended on arrival order somewhere
     if want_vertices:
         v, j = fb.forward()
         out["vertices"], out["joints"] = v.cpu().numpy(), j.cpu().numpy()
@@ -170,13 +172,16 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
         fbs[0].fit(first_stage=-1, last_stage=fbs[0].n_stages - 1)
     else:
         engine.fit_multi(fbs, first_stage=-1, last_stage=fbs[0].n_stages - 1)
-    if pen_on:      # diagnostics of the interpenetration term over this fit (device counters, engine.pen_work_get)
+    parts = [_collect(fb, prep, want_vertices) for fb, prep in made]
+    res = {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}
+    if pen_on:      # diagnostics of the interpenetration term over this fit (device counters, engine.pen_work_get; per-frame flags)
         w1 = engine.pen_work_get()
         cut, over = w1["walks_cut"] - work0["walks_cut"], w1["lists_overflowed"] - work0["lists_overflowed"]
         if cut or over:
             import warnings
+            bad = np.flatnonzero(res["pen_order_dependent"])
             warnings.warn("interpenetration term: %d bucket walks were cut short and %d triangles met more than 2 x max_collisions "
-                          "partners during this fit (a mesh folded into a few grid cells by a diverging frame): the term is "
-                          "underestimated there and the partners kept depend on arrival order" % (cut, over), RuntimeWarning)
-    parts = [_collect(fb, prep, want_vertices) for fb, prep in made]
-    return {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}
+                          "partners during this fit (a mesh folded into a few grid cells by a trial step): the term is "
+                          "underestimated there and the partners kept depend on arrival order -- frames %s are not reproducible "
+                          "run to run (result key 'pen_order_dependent')" % (cut, over, bad.tolist()[:32]), RuntimeWarning)
+    return res

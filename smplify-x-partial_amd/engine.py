@@ -354,6 +354,13 @@ class FrameBatch(object):
         capi.check(self._lib.sfx_batch_pen_stats(self._h, capi.iptr(st), capi.iptr(ext)))
         return dict(pairs=st[:, 0].copy(), dropped=st[:, 1].copy(), entry_overflow=st[:, 2].copy(), walks_cut=st[:, 3].copy(), vertices=ext)
 
+    def penetration_flags(self):
+        """Per frame: True when the frame's fit consumed a collision evaluation whose kept partners depended on arrival order
+        (a partner list beyond 2 x max_collisions, a cut bucket walk): its result is not reproducible run to run."""
+        fl = np.zeros(self.B, np.int32)
+        capi.check(self._lib.sfx_batch_pen_flags(self._h, capi.iptr(fl)))
+        return fl != 0
+
     def last_grad(self, stage):
         """Gradient [B,N] of the most recent closure evaluation (what var.grad holds after step())."""
         grad = np.zeros((self.B, self.num_vars(stage)), np.float32)

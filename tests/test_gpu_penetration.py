@@ -450,14 +450,16 @@ def test_pooled_batch_with_interpenetration():
     res_pool = driver.fit_frames(dm, cfg, frames["keypoints"], jw, 600, 800, 5000.0, slots=slots, **kw)
     res_all = driver.fit_frames(dm, cfg, frames["keypoints"], jw, 600, 800, 5000.0, **kw)
     res_again = driver.fit_frames(dm, cfg, frames["keypoints"], jw, 600, 800, 5000.0, **kw)
-    # A triangle that meets more than 2 x max_collisions partners in some trial pose keeps the ones that ARRIVE first (DESIGN 4.6;
-    # engine.pen_work_get()['lists_overflowed']): such a frame is not reproducible run to run, whatever the batch -- frames the
-    # resident fit reproduces itself on (nearly all) must come out of the pool with the same bits
+    # A triangle that meets more than 2 x max_collisions partners in some trial pose keeps the ones that ARRIVE first:
+    # such a frame is not reproducible run to run, whatever the batch, and the engine says which ones they are
+    # (result key 'pen_order_dependent', sticky per frame over the fit).  Every other frame must come out of the pool, and out
+    # of a second resident run, with the same bits.
     keys = ("stage_loss", "pose_embedding", "betas", "cam_translation", "global_orient", "stage_evals")
     same = lambda a, b_: np.array([all(np.array_equal(a[k][i], b_[k][i], equal_nan=True) for k in keys) for i in range(B)])
-    stable = same(res_again, res_all)
-    assert stable.sum() >= B - 4, np.flatnonzero(~stable)
-    assert same(res_pool, res_all)[stable].all(), np.flatnonzero(~same(res_pool, res_all) & stable)
+    clean = ~(res_all["pen_order_dependent"] | res_pool["pen_order_dependent"] | res_again["pen_order_dependent"])
+    assert clean.sum() >= B - 6, np.flatnonzero(~clean)
+    assert same(res_again, res_all)[clean].all(), np.flatnonzero(~same(res_again, res_all) & clean)
+    assert same(res_pool, res_all)[clean].all(), np.flatnonzero(~same(res_pool, res_all) & clean)
     assert np.all(res_all["stage_evals"][:, 2:] > 0)
     # stand-alone closure of the last stage (collision weight 1.0) on a pooled batch vs a resident one, same parameters
     out = {}
