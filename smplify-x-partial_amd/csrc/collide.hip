@@ -103,6 +103,9 @@ struct PenDev {
     int* cells;                // [B][PEN_CELLS + 1] bucket END offsets into entries ([PEN_CELLS] = number of entries)
     float* gridp;              // [B][4] low corner of the frame's box, 1 / cell size
     int* stats;                // [B][PEN_STATS]: pairs (ordered), dropped partners, overflow of entries, cells, phase clocks
+    int2* wq;                  // [B][wq_cap] chunks of the pair tests beyond a block's first 64 steps: (first entry of the block, chunk k)
+    int* wqn;                  // [B] chunks queued (k_pen_g3 -> 0, k_pen_walk appends, k_pen_walk2 consumes)
+    int wq_cap;
     int* over;                 // [B] or NULL (set per call): 1 = this evaluation of the mesh kept partners by ARRIVAL order somewhere (a list beyond
                                //     2 x max_collisions, a cut walk): its numbers are not reproducible run to run
     unsigned long long* work;  // [6] process-wide counts since sfx_pen_work_reset: grid entries, ordered pairs, column evaluations, surviving triangles,
@@ -440,6 +443,7 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     const int b = blockIdx.x, t = threadIdx.x;
     int* st = P.stats + b * PEN_STATS;
     int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
+    if (t == 0) P.wqn[b] = 0;                   // (the pair tests' chunk queue of this mesh starts empty)
     if (want && !want[b]) {                     // the frame's stage carries no collision weight: nothing to do
         if (t == 0) { P.ptotal[b] = 0; cells[PEN_CELLS] = 0; st[0] = st[1] = st[2] = st[3] = 0; st[13] = 0; st[15] = 0; }
         return;
@@ -559,178 +563,291 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
 }
 
 
-// pair tests over the bucket-sorted entries of k_pen_grid; PEN_WALK_BLOCKS workgroups per frame
-__global__ __launch_bounds__(256)
-void k_pen_walk(PenDev P, const int* __restrict__ want) {
+// ---- one flat work list over all meshes of a call (k_pen_walk2, k_pen_eval): every workgroup forms the exclusive prefix of the
+// meshes' item counts in LDS, a wavefront takes items w, w + W, ... and finds an item's mesh by bisection
+#define PEN_FLAT_MAXB 4096      // meshes per call the flat distribution handles (beyond: one grid row per mesh, as before)
+#define PEN_FLAT_BLOCKS 2048
+template <class CNT>
+__device__ __forceinline__ int pen_prefix(const int B, int* s_pref /* [B + 1] */, int* s_scan /* [256] */, CNT&& count) {
+    const int t = threadIdx.x;
+    const int per = (B + 255) / 256;
+    const int b0 = min(B, t * per), b1 = min(B, b0 + per);
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += count(b);
+    s_scan[t] = sum;
+    __syncthreads();
+    // 256-entry scan by one wavefront (four per lane), fixed order
+    if (t < 64) {
+        int v[4], run = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { v[u] = s_scan[t * 4 + u]; run += v[u]; }
+        int inc = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (t >= d) inc += o; }
+        int ex = inc - run;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s_scan[t * 4 + u] = ex; ex += v[u]; }
+    }
+    __syncthreads();
+    int acc = s_scan[t];
+    for (int b = b0; b < b1; ++b) { s_pref[b] = acc; acc += count(b); }
+    if (b1 == B && b0 < B) s_pref[B] = acc;
+    if (B == 0 && t == 0) s_pref[0] = 0;
+    __syncthreads();
+    return s_pref[B];
+}
+__device__ __forceinline__ int pen_chunk_prefix(const PenDev& P, const int B, int* s_pref, int* s_scan) {
+    return pen_prefix(B, s_pref, s_scan, [&](int b_) { return (P.ptotal[b_] + 63) >> 6; });
+}
+__device__ __forceinline__ int pen_chunk_mesh(const int* s_pref, const int B, const int c) {      // last b with s_pref[b] <= c
+    int lo = 0, hi = B - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= c) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+
+// ---- pair tests over the bucket-sorted entries of the grid.
+// A wavefront takes a BLOCK of 64 consecutive entries of the bucket-sorted list: its lanes hold one entry each (header = entry
+// record + AABB: 32 bytes) and lane i tests itself against the entries after it in its bucket -- entry i + d, the same d for
+// all lanes, so the headers it needs form a window sliding over the list, held in wavefront-private LDS (two int4 arrays: lane
+// i reading entry i + d is conflict-free).  All memory traffic is one gather per ENTRY; the pair tests run on registers and
+// LDS.  A pair is accepted in the cell that holds the low corner of the AABB intersection (both triangles are entered there),
+// and appended to both triangles' partner lists -- unless the triangles share a vertex, which is looked at when the queue of
+// accepted pairs is flushed (neighbours are almost always of one part or of parent and child, which the part mask has already
+// turned away: the vertex ids are not worth 16 bytes of every header).
+//
+// Round 4: the walk of a block is cut into CHUNKS of 64 steps (d = 64 k + 1 .. 64 k + 64; window = entries 64 k .. 64 k + 127
+// behind the block's first).  k_pen_walk does chunk 0 of every block -- all a block needs unless a bucket runs past its end --
+// and queues the chunks k >= 1; k_pen_walk2 runs the queued chunks of ALL meshes of the call as one flat list, a chunk per
+// wavefront.  Until then a block walked its bucket to the end on its own: the launch lasted as long as the block that
+// sits at the head of the fullest cell (418 entries on the synthetic surface: 209 dependent iterations and six window refills
+// on one wavefront, p50 97 us) while the other 500 wavefronts of the mesh had long finished.  Same candidates, same tests, same
+// accepted pairs (their order of arrival differs; the lists are ranked afterwards); the cut after PEN_MAX_WALK steps is the
+// chunk limit.
 #ifndef PEN_WIN
 #define PEN_WIN 128
 #endif
-    __shared__ __align__(16) int s_tile[4 * PEN_WIN * 8];    // per wavefront: a sliding window of PEN_WIN entry headers (32 bytes each)
-    __shared__ int s_queue[4 * 256];
+#ifndef PEN_NC
+#define PEN_NC 2               // candidates per lane and iteration: independent instruction streams cover the LDS / compare latencies
+#endif
+#define PEN_MAX_CHUNK ((PEN_MAX_WALK + 63) / 64)      // chunks per block (k < PEN_MAX_CHUNK: d <= PEN_MAX_WALK)
+static_assert(PEN_WIN == 128 && 64 % PEN_NC == 0, "a chunk's window is two 64-entry halves");
+
+struct PenWalkCtx {            // per wavefront
+    int4* tA; int4* tB;        // [PEN_WIN] window: entry | cell | lo.x | lo.y  and  lo.z | hi.x | hi.y | hi.z
+    int* queue; int qn;        // accepted pairs waiting to be appended (128 pairs)
+    const unsigned long long* s_mask;
+};
+
+__device__ __forceinline__ void pen_load_hdr(const int2* ent, const float* aabb, int q, bool ok, int (&hd)[8]) {
+    // (every load unconditional, from a clamped index: written as `ok ? p[i] : 0` each of the loads became its own
+    //  exec-masked branch with a full s_waitcnt behind it -- serial round trips per header)
+    const int qs = ok ? q : 0;
+    const int2 e01 = ent[qs];
+    const int e0 = e01.x, e1 = e01.y;
+    // (the mask goes through inline assembly: from `e0 & 0xffffff` the compiler forms a 24-bit multiply -- which masks
+    //  implicitly -- and, once the wide loads below make the row address 64-bit, turns it into v_mad_u64_u32 on the UNMASKED
+    //  word: rows 2^24 x part id beyond the array, a memory fault with ROCm 7.2's compiler)
+    int f;
+    asm("v_and_b32 %0, 0xffffff, %1" : "=v"(f) : "v"(e0));
+    const int2* bp = reinterpret_cast<const int2*>(aabb) + (size_t)f * 3;      // the box as three 8-byte loads (rows of 24 bytes)
+    const int2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
+    hd[0] = ok ? e0 : 0; hd[1] = ok ? e1 : 0x3fffffff;
+    hd[2] = ok ? b0.x : 0; hd[3] = ok ? b0.y : 0; hd[4] = ok ? b1.x : 0; hd[5] = ok ? b1.y : 0; hd[6] = ok ? b2.x : 0; hd[7] = ok ? b2.y : 0;
+}
+
+__device__ __forceinline__ void pen_flush_queue(const PenDev& P, const int b, PenWalkCtx& W, const int lane) {
+    const int n = W.qn;
+    if (!n) return;
+    int* pc = P.pcount + (size_t)b * P.F;
+    int* part = P.partners + (size_t)b * P.F * P.pcap;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+    for (int q = lane; q < n; q += 64) {
+        const int fa = W.queue[2 * q], fb = W.queue[2 * q + 1];
+        const int4 va = P.faces4[fa], vb = P.faces4[fb];      // triangles that share a vertex do not collide
+        const bool shared = va.x == vb.x || va.x == vb.y || va.x == vb.z || va.y == vb.x || va.y == vb.y || va.y == vb.z ||
+                            va.z == vb.x || va.z == vb.y || va.z == vb.z;
+        if (shared) continue;
+        const int pa = atomicAdd(&pc[fa], 1), pb = atomicAdd(&pc[fb], 1);
+        if (pa < P.pcap) part[(size_t)fa * P.pcap + pa] = fb;
+        if (pb < P.pcap) part[(size_t)fb * P.pcap + pb] = fa;
+    }
+    __builtin_amdgcn_wave_barrier();
+    W.qn = 0;
+}
+
+// The block's own side of the tests: what a lane knows about ITS entry
+struct PenOwn { int qi, fi, ck, bend; unsigned need; unsigned long long skip_i; float ai[6]; };
+
+__device__ __forceinline__ int pen_bucket_of(int ck) {
+    return (int)(((unsigned)(ck & 1023) * 73856093u ^ (unsigned)((ck >> 10) & 1023) * 19349663u ^ (unsigned)((ck >> 20) & 1023) * 83492791u) & (PEN_CELLS - 1));
+}
+
+// headers of block i0 -> the lane's own record (and its header words, for the window of chunk 0)
+__device__ __forceinline__ PenOwn pen_own(const PenDev& P, const int b, const int i0, const int s_total, const PenWalkCtx& W,
+                                          const int lane, int (&hi_)[8]) {
+    const float* aabb = P.aabb + (size_t)b * P.F * 6;
+    const int2* ent = P.entries + (size_t)b * P.ent_cap;
+    const int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
+    PenOwn O;
+    O.qi = i0 + lane;
+    const bool vi = O.qi < s_total;
+    pen_load_hdr(ent, aabb, O.qi, vi, hi_);
+    O.fi = hi_[0] & 0xffffff;
+    O.skip_i = vi ? W.s_mask[(hi_[0] >> 24) & 63] : ~0ull;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) O.ai[e] = __int_as_float(hi_[2 + e]);
+    O.ck = hi_[1] & 0x3fffffff;
+    // partners of an entry: the entries after it up to the end of ITS bucket
+    O.bend = vi ? cells[pen_bucket_of(O.ck)] : 0;
+    // Ownership: a pair is accepted in the cell that holds the low corner of the boxes' intersection.  Both triangles are
+    // entered in THIS cell, so on every axis the cells of both low corners are <= this cell's coordinate, and (the cell
+    // function is monotone) cell(max(a, k)) == c  <=>  cell(a) == c or cell(k) == c.  Whether an entry's cell holds its
+    // box's low corner on an axis is a bit of the entry record (k_pen_g3: bits 30, 31 of the key, bit 30 of the triangle
+    // word): `need` has the axes where this lane's own corner is elsewhere -- there the partner's must be here.
+    const unsigned lowb = ((unsigned)hi_[1] >> 30) | (((unsigned)hi_[0] >> 28) & 4u);      // x | y << 1 | z << 2
+    O.need = ~lowb & 7u;
+    return O;
+}
+
+// chunk k of the block at i0: steps d = 64 k + 1 .. 64 k + 64.  own_hdr: the block's own header words (chunk 0: they are the
+// first half of the window and are not loaded again).
+__device__ __forceinline__ void pen_walk_chunk(const PenDev& P, const int b, const int i0, const int k, const int bend_max,
+                                               const PenOwn& O, const int (&own_hdr)[8], PenWalkCtx& W, const int lane) {
+    const float* aabb = P.aabb + (size_t)b * P.F * 6;
+    const int2* ent = P.entries + (size_t)b * P.ent_cap;
+    const int w0 = i0 + 64 * k;                    // entry in window slot 0
+    __builtin_amdgcn_wave_barrier();               // (the previous chunk's reads of the window are done)
+    {
+        int h0[8], h1[8];
+        if (k == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h0[e] = own_hdr[e];
+        } else pen_load_hdr(ent, aabb, w0 + lane, w0 + lane < bend_max, h0);
+        pen_load_hdr(ent, aabb, w0 + 64 + lane, w0 + 64 + lane < bend_max, h1);
+        W.tA[lane] = make_int4(h0[0], h0[1], h0[2], h0[3]); W.tB[lane] = make_int4(h0[4], h0[5], h0[6], h0[7]);
+        W.tA[64 + lane] = make_int4(h1[0], h1[1], h1[2], h1[3]); W.tB[64 + lane] = make_int4(h1[4], h1[5], h1[6], h1[7]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+    // one candidate of this lane: window entry (lane + dd)
+    auto test = [&](const bool act, const int4 h0, const int4 h1) {
+        // (every test is evaluated, the results are combined with `&`: written with `&&` the compiler nests one exec-masked
+        //  branch per condition -- five s_and_saveexec / s_cbranch_execz pairs per candidate, the second LDS read inside them)
+        const float kl0 = __int_as_float(h0.z), kl1 = __int_as_float(h0.w), kl2 = __int_as_float(h1.x);
+        const float kh0 = __int_as_float(h1.y), kh1 = __int_as_float(h1.z), kh2 = __int_as_float(h1.w);
+        const bool same = ((h0.y ^ O.ck) & 0x3fffffff) == 0;
+        const bool coll = ((unsigned)(O.skip_i >> ((h0.x >> 24) & 63)) & 1u) == 0u;
+        const bool box = (O.ai[0] <= kh0) & (kl0 <= O.ai[3]) & (O.ai[1] <= kh1) & (kl1 <= O.ai[4]) & (O.ai[2] <= kh2) & (kl2 <= O.ai[5]);
+        const unsigned klow = ((unsigned)h0.y >> 30) | (((unsigned)h0.x >> 28) & 4u);
+        const bool own = (O.need & ~klow) == 0u;
+#ifdef PEN_COUNT    // diagnostic build: where do the candidates die?  stats[16..19] = walked, same cell, part mask passed, boxes overlap
+        {
+            int* st = P.stats + b * PEN_STATS;
+            const unsigned long long m0 = __ballot(act), m1 = __ballot(act & same), m2 = __ballot(act & same & coll), m3 = __ballot(act & same & coll & box);
+            if (lane == 0) { atomicAdd(&st[16], __popcll(m0)); atomicAdd(&st[17], __popcll(m1)); atomicAdd(&st[18], __popcll(m2)); atomicAdd(&st[19], __popcll(m3));
+                             atomicAdd(&st[20], 1); }      // [20] wavefront steps
+        }
+#endif
+        return act & same & coll & box & own;
+    };
+    // accepted pairs go to a wavefront-private queue and are appended to the partner lists
+    // 64 at a time: the list cursors are returning atomics, one memory round trip each
+    auto push = [&](const bool pass, const int other) {
+        const unsigned long long m = __ballot(pass);
+        if (m) {
+            const int pos = W.qn + __popcll(m & ((1ull << lane) - 1ull));
+            if (pass) { W.queue[2 * pos] = O.fi; W.queue[2 * pos + 1] = other & 0xffffff; }
+            W.qn += __popcll(m);
+            if (W.qn >= 64) pen_flush_queue(P, b, W, lane);
+        }
+    };
+    for (int dd = 1; dd <= 64; dd += PEN_NC) {      // dd = d - 64 k
+        const int d = 64 * k + dd;
+        if (!__ballot(O.qi + d < O.bend)) break;
+        int4 hA[PEN_NC], hB[PEN_NC];
+#pragma unroll
+        for (int c = 0; c < PEN_NC; ++c) { const int kk = lane + dd + c; hA[c] = W.tA[kk & (PEN_WIN - 1)]; hB[c] = W.tB[kk & (PEN_WIN - 1)]; }
+        bool ps[PEN_NC];
+#pragma unroll
+        for (int c = 0; c < PEN_NC; ++c) ps[c] = test(O.qi + d + c < O.bend, hA[c], hB[c]);
+#pragma unroll
+        for (int c = 0; c < PEN_NC; ++c) push(ps[c], hA[c].x);
+    }
+}
+
+#define PEN_WALK_LDS                                                                                          \
+    __shared__ __align__(16) int s_tile[4 * PEN_WIN * 8];    /* per wavefront: a window of PEN_WIN entry headers (32 bytes each) */ \
+    __shared__ int s_queue[4 * 256];                                                                          \
     __shared__ unsigned long long s_mask[64];
+
+// chunk 0 of every block; PEN_WALK_BLOCKS workgroups per mesh.  Queues the chunks k >= 1 (P.wq / P.wqn); when the queue is full
+// the block walks them itself, as it did before round 4.
+__global__ __launch_bounds__(256)
+void k_pen_walk(PenDev P, const int* __restrict__ want) {
+    PEN_WALK_LDS
     const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
     const int s_total = cells[PEN_CELLS];
     if ((want && !want[b]) || blockIdx.x * 256 >= s_total) return;
-    const int F = P.F;
-    const float* aabb = P.aabb + (size_t)b * F * 6;
-    const int2* ent = P.entries + (size_t)b * P.ent_cap;
-    if (t < 64) {
-        unsigned long long m = 0;
-        m = P.skipmask[t];
-        s_mask[t] = m;
-    }
+    if (t < 64) s_mask[t] = P.skipmask[t];
     __syncthreads();
-    auto bucket = [](int x, int y, int z) { return (int)(((unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u) & (PEN_CELLS - 1)); };
-
-    // ---- pairs.  A wavefront takes 64 consecutive entries of the bucket-sorted list: its lanes hold
-    // one entry each (header = entry record + AABB: 32 bytes) and the same headers sit in a
-    // wavefront-private LDS window (two int4 arrays: lane i reading entry i + d is conflict-free);
-    // lane i tests itself against the entries after it in its bucket.  All memory traffic is one
-    // gather per ENTRY; the pair tests run on registers and LDS.  A pair is accepted in the cell that
-    // holds the low corner of the AABB intersection (both triangles are entered there), and appended
-    // to both triangles' partner lists -- unless the triangles share a vertex, which is looked at when the
-    // queue of accepted pairs is flushed (neighbours are almost always of one part or of parent and child,
-    // which the part mask has already turned away: the vertex ids are not worth 16 bytes of every header).
-    int* tile = s_tile + wv * PEN_WIN * 8;
-    int* pc = P.pcount + (size_t)b * F;
-    int* part = P.partners + (size_t)b * F * P.pcap;
-    // (every load unconditional, from a clamped index: written as `ok ? p[i] : 0` each of the loads became its own
-    //  exec-masked branch with a full s_waitcnt behind it -- serial round trips per header, two headers per block of 64
-    //  entries: that chain, not the pair tests, was most of this kernel's time)
-    auto load_hdr = [&](int q, bool ok, int (&hd)[8]) {
-        const int qs = ok ? q : 0;
-        const int2 e01 = ent[qs];
-        const int e0 = e01.x, e1 = e01.y;
-        // (the mask goes through inline assembly: from `e0 & 0xffffff` the compiler forms a 24-bit multiply -- which masks
-        //  implicitly -- and, once the wide loads below make the row address 64-bit, turns it into v_mad_u64_u32 on the UNMASKED
-        //  word: rows 2^24 x part id beyond the array, a memory fault with ROCm 7.2's compiler)
-        int f;
-        asm("v_and_b32 %0, 0xffffff, %1" : "=v"(f) : "v"(e0));
-        const int2* bp = reinterpret_cast<const int2*>(aabb) + (size_t)f * 3;      // the box as three 8-byte loads (rows of 24 bytes)
-        const int2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
-        hd[0] = ok ? e0 : 0; hd[1] = ok ? e1 : 0x3fffffff;      // (no cell has the key 0x3fffffff with the low-corner bits clear... any key: `act` is false for such lanes)
-        hd[2] = ok ? b0.x : 0; hd[3] = ok ? b0.y : 0; hd[4] = ok ? b1.x : 0; hd[5] = ok ? b1.y : 0; hd[6] = ok ? b2.x : 0; hd[7] = ok ? b2.y : 0;
-    };
+    PenWalkCtx W;
+    W.tA = reinterpret_cast<int4*>(s_tile + wv * PEN_WIN * 8); W.tB = W.tA + PEN_WIN;
+    W.queue = s_queue + wv * 256; W.qn = 0; W.s_mask = s_mask;
     // (blocks of 64 entries, NOT whole buckets: a crowded bucket is shared by many wavefronts; the
     // cell key comparison keeps different cells of one bucket apart)
-    int* queue = s_queue + wv * 256;                 // 128 pairs per wavefront
-    int qn = 0;
-    auto flush_queue = [&](int n) {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
-        for (int q = lane; q < n; q += 64) {
-            const int fa = queue[2 * q], fb = queue[2 * q + 1];
-            const int4 va = P.faces4[fa], vb = P.faces4[fb];      // triangles that share a vertex do not collide
-            const bool shared = va.x == vb.x || va.x == vb.y || va.x == vb.z || va.y == vb.x || va.y == vb.y || va.y == vb.z ||
-                                va.z == vb.x || va.z == vb.y || va.z == vb.z;
-            if (shared) continue;
-            const int pa = atomicAdd(&pc[fa], 1), pb = atomicAdd(&pc[fb], 1);
-            if (pa < P.pcap) part[(size_t)fa * P.pcap + pa] = fb;
-            if (pb < P.pcap) part[(size_t)fb * P.pcap + pb] = fa;
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-    int4* tA = reinterpret_cast<int4*>(tile);        // [128] entry | cell | lo.x | lo.y
-    int4* tB = tA + PEN_WIN;                         // [PEN_WIN] lo.z | hi.x | hi.y | hi.z
     for (int i0 = (blockIdx.x * 4 + wv) * 64; i0 < s_total; i0 += gridDim.x * 256) {
-        const int qi = i0 + lane;
-        const bool vi = qi < s_total;
-        int hi_[8];
-        load_hdr(qi, vi, hi_);
-        const int fi = hi_[0] & 0xffffff;
-        const unsigned long long skip_i = vi ? s_mask[(hi_[0] >> 24) & 63] : ~0ull;
-        float ai[6];
-#pragma unroll
-        for (int e = 0; e < 6; ++e) ai[e] = __int_as_float(hi_[2 + e]);
-        // partners of an entry: the entries after it up to the end of ITS bucket (buckets hold a few
-        // entries, so this per-lane walk takes as many steps as the fullest bucket of the block)
-        const int ck = hi_[1] & 0x3fffffff;
-        const int bend = vi ? cells[bucket(ck & 1023, (ck >> 10) & 1023, (ck >> 20) & 1023)] : 0;
-        // the walk of all lanes advances in lockstep (lane i looks at entry i + d), so the headers it needs
-        // form a window of 64 entries sliding over the list: two 64-entry halves in LDS, the next half
-        // fetched (one header per lane) whenever the window reaches it -- a crowded bucket of hundreds of
-        // entries is walked out of LDS as well
-        const int bend_max = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)bend));      // entries < 2^24: exact
-        tA[lane] = make_int4(hi_[0], hi_[1], hi_[2], hi_[3]);
-        tB[lane] = make_int4(hi_[4], hi_[5], hi_[6], hi_[7]);
-        // Ownership: a pair is accepted in the cell that holds the low corner of the boxes' intersection.  Both triangles are
-        // entered in THIS cell, so on every axis the cells of both low corners are <= this cell's coordinate, and (the cell
-        // function is monotone) cell(max(a, k)) == c  <=>  cell(a) == c or cell(k) == c.  Whether an entry's cell holds its
-        // box's low corner on an axis is a bit of the entry record (k_pen_g3: bits 30, 31 of the key, bit 30 of the triangle
-        // word): `need` has the axes where this lane's own corner is elsewhere -- there the partner's must be here.
-        const unsigned lowb = ((unsigned)hi_[1] >> 30) | (((unsigned)hi_[0] >> 28) & 4u);      // x | y << 1 | z << 2
-        const unsigned need = ~lowb & 7u;
-        int staged = 64;                               // entries i0 .. i0 + staged - 1 are (or were) in the window
-        // one candidate of this lane: entry (lane + dd) of the window
-        auto test = [&](const bool act, const int4 h0, const int4 h1) {
-            // (every test is evaluated, the results are combined with `&`: written with `&&` the compiler nests one exec-masked
-            //  branch per condition -- five s_and_saveexec / s_cbranch_execz pairs per candidate, the second LDS read inside them)
-            const float kl0 = __int_as_float(h0.z), kl1 = __int_as_float(h0.w), kl2 = __int_as_float(h1.x);
-            const float kh0 = __int_as_float(h1.y), kh1 = __int_as_float(h1.z), kh2 = __int_as_float(h1.w);
-            const bool same = ((h0.y ^ ck) & 0x3fffffff) == 0;
-            const bool coll = ((unsigned)(skip_i >> ((h0.x >> 24) & 63)) & 1u) == 0u;
-            const bool box = (ai[0] <= kh0) & (kl0 <= ai[3]) & (ai[1] <= kh1) & (kl1 <= ai[4]) & (ai[2] <= kh2) & (kl2 <= ai[5]);
-            const unsigned klow = ((unsigned)h0.y >> 30) | (((unsigned)h0.x >> 28) & 4u);
-            const bool own = (need & ~klow) == 0u;
-#ifdef PEN_COUNT    // diagnostic build: where do the candidates die?  stats[16..19] = walked, same cell, part mask passed, boxes overlap
-            {
-                int* st = P.stats + b * PEN_STATS;
-                const unsigned long long m0 = __ballot(act), m1 = __ballot(act & same), m2 = __ballot(act & same & coll), m3 = __ballot(act & same & coll & box);
-                if (lane == 0) { atomicAdd(&st[16], __popcll(m0)); atomicAdd(&st[17], __popcll(m1)); atomicAdd(&st[18], __popcll(m2)); atomicAdd(&st[19], __popcll(m3));
-                                 atomicAdd(&st[20], 1); }      // [20] wavefront steps
-            }
-#endif
-            return act & same & coll & box & own;
-        };
-        // accepted pairs go to a wavefront-private queue and are appended to the partner lists
-        // 64 at a time: the list cursors are returning atomics, one memory round trip each
-        auto push = [&](const bool pass, const int other) {
-            const unsigned long long m = __ballot(pass);
-            if (m) {
-                const int pos = qn + __popcll(m & ((1ull << lane) - 1ull));
-                if (pass) { queue[2 * pos] = fi; queue[2 * pos + 1] = other & 0xffffff; }
-                qn += __popcll(m);
-                if (qn >= 64) { flush_queue(qn); qn = 0; }
-            }
-        };
-        // TWO candidates per lane and iteration (entries lane + d and lane + d + 1): their tests are independent instruction
-        // streams, which is what a wavefront needs to cover its own LDS and compare latencies -- one candidate per iteration kept
-        // the SIMDs a third busy with five wavefronts each
-#ifndef PEN_NC
-#define PEN_NC 2
-#endif
-        // (not more: a refill overwrites entries staged - 128 .. staged - 65 of the 128-entry window; it is triggered by the leading
-        //  edge 63 + d + PEN_NC - 1 reaching `staged`, i.e. at some d >= staged - 62 - PEN_NC, and lane 0 still needs entry d)
-        static_assert(PEN_NC >= 1 && PEN_NC <= PEN_WIN - 126, "window of PEN_WIN entries, refills of 64");
-        for (int d = 1; ; d += PEN_NC) {
-            const bool act0 = qi + d < bend;
-            if (!__ballot(act0)) break;
-            if (d > PEN_MAX_WALK) {                    // a bucket of thousands of entries: a mesh that has collapsed into a few cells
+        int hdr[8];
+        const PenOwn O = pen_own(P, b, i0, s_total, W, lane, hdr);
+        const int bend_max = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)O.bend));      // entries < 2^24: exact
+        pen_walk_chunk(P, b, i0, 0, bend_max, O, hdr, W, lane);
+        // steps this block needs: the longest walk of its lanes, bend - 1 - qi
+        const int dmax = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)max(O.bend - 1 - O.qi, 0)));
+        if (dmax > 64) {
+            int kmax = (dmax - 1) >> 6;                    // last chunk with a live step
+            if (kmax >= PEN_MAX_CHUNK) {                   // a bucket of thousands of entries: a mesh that has collapsed into a few cells
+                kmax = PEN_MAX_CHUNK - 1;
                 if (lane == 0) atomicAdd(&P.stats[b * PEN_STATS + 13], 1);      // (reported: sfx_pen_stats, "walks cut short")
-                break;
             }
-            if (62 + PEN_NC + d >= staged) {           // wave-uniform: the window's leading edge (entry 63 + d + PEN_NC - 1) reaches the next half
-                int hn[8];
-                const int qn_ = i0 + staged + lane;
-                load_hdr(qn_, qn_ < bend_max, hn);
-                const int sl = (staged + lane) & (PEN_WIN - 1);
-                tA[sl] = make_int4(hn[0], hn[1], hn[2], hn[3]);
-                tB[sl] = make_int4(hn[4], hn[5], hn[6], hn[7]);
-                staged += 64;
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();     // (d = 1 always refills: covers the first half too)
+            int pos = 0;
+            if (lane == 0) pos = atomicAdd(&P.wqn[b], kmax);
+            pos = __builtin_amdgcn_readfirstlane(pos);
+            if (pos + kmax <= P.wq_cap) {
+                if (lane >= 1 && lane <= kmax) P.wq[(size_t)b * P.wq_cap + pos + lane - 1] = make_int2(i0, lane);
+            } else {                                       // queue full: walk on here
+                if (lane == 0) atomicSub(&P.wqn[b], kmax);
+                for (int k = 1; k <= kmax; ++k) pen_walk_chunk(P, b, i0, k, bend_max, O, hdr, W, lane);
             }
-            int4 hA[PEN_NC], hB[PEN_NC];
-#pragma unroll
-            for (int c = 0; c < PEN_NC; ++c) { const int kk = (lane + d + c) & (PEN_WIN - 1); hA[c] = tA[kk]; hB[c] = tB[kk]; }
-            bool ps[PEN_NC];
-#pragma unroll
-            for (int c = 0; c < PEN_NC; ++c) ps[c] = test(qi + d + c < bend, hA[c], hB[c]);
-#pragma unroll
-            for (int c = 0; c < PEN_NC; ++c) push(ps[c], hA[c].x);
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (qn) flush_queue(qn);
+    pen_flush_queue(P, b, W, lane);
+}
+
+// the queued chunks of all meshes of the call, one flat list (the distribution of k_pen_eval): a chunk per wavefront
+__global__ __launch_bounds__(256)
+void k_pen_walk2(PenDev P, int B) {
+    PEN_WALK_LDS
+    extern __shared__ int s_pref[];             // [B + 1] exclusive prefix of the meshes' queued chunks
+    __shared__ int s_scan[256];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t < 64) s_mask[t] = P.skipmask[t];
+    const int n_items = pen_prefix(B, s_pref, s_scan, [&](int b_) { return min(P.wqn[b_], P.wq_cap); });
+    PenWalkCtx W;
+    W.tA = reinterpret_cast<int4*>(s_tile + wv * PEN_WIN * 8); W.tB = W.tA + PEN_WIN;
+    W.queue = s_queue + wv * 256; W.qn = 0; W.s_mask = s_mask;
+    int b_prev = -1;
+    for (int c = blockIdx.x * 4 + wv; c < n_items; c += gridDim.x * 4) {
+        const int b = pen_chunk_mesh(s_pref, B, c);
+        if (b != b_prev) { if (b_prev >= 0) pen_flush_queue(P, b_prev, W, lane); b_prev = b; }      // (the pair queue belongs to one mesh)
+        const int2 it = P.wq[(size_t)b * P.wq_cap + (c - s_pref[b])];
+        const int s_total = P.cells[(size_t)b * (PEN_CELLS + 1) + PEN_CELLS];
+        int hdr[8];
+        const PenOwn O = pen_own(P, b, it.x, s_total, W, lane, hdr);
+        const int bend_max = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)O.bend));
+        pen_walk_chunk(P, b, it.x, it.y, bend_max, O, hdr, W, lane);
+    }
+    if (b_prev >= 0) pen_flush_queue(P, b_prev, W, lane);
 }
 
 // offsets of the triangles' partner ranges in the frame's pair list (k_pen_rank fills the list)
@@ -920,42 +1037,6 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
 // Every workgroup forms the exclusive prefix of the meshes' chunk counts (ptotal, a few hundred integers) in LDS; a wavefront
 // takes chunks c = w, w + W, ...; the mesh of a chunk is found by bisection.  A chunk is 64 consecutive pairs of ONE mesh's
 // list, aligned to 64 in that list -- what k_pen_facesum's run sums rely on -- so the numbers are what they were.
-#define PEN_FLAT_MAXB 4096      // meshes per call the flat distribution handles (beyond: one grid row per mesh, as before)
-#define PEN_FLAT_BLOCKS 2048
-__device__ __forceinline__ int pen_chunk_prefix(const PenDev& P, const int B, int* s_pref /* [B + 1] */, int* s_scan /* [256] */) {
-    const int t = threadIdx.x;
-    const int per = (B + 255) / 256;
-    const int b0 = min(B, t * per), b1 = min(B, b0 + per);
-    int sum = 0;
-    for (int b = b0; b < b1; ++b) sum += (P.ptotal[b] + 63) >> 6;
-    s_scan[t] = sum;
-    __syncthreads();
-    // 256-entry scan by one wavefront (four per lane), fixed order
-    if (t < 64) {
-        int v[4], run = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { v[u] = s_scan[t * 4 + u]; run += v[u]; }
-        int inc = run;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (t >= d) inc += o; }
-        int ex = inc - run;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { s_scan[t * 4 + u] = ex; ex += v[u]; }
-    }
-    __syncthreads();
-    int acc = s_scan[t];
-    for (int b = b0; b < b1; ++b) { s_pref[b] = acc; acc += (P.ptotal[b] + 63) >> 6; }
-    if (b1 == B && b0 < B) s_pref[B] = acc;
-    if (B == 0 && t == 0) s_pref[0] = 0;
-    __syncthreads();
-    return s_pref[B];
-}
-__device__ __forceinline__ int pen_chunk_mesh(const int* s_pref, const int B, const int c) {      // last b with s_pref[b] <= c
-    int lo = 0, hi = B - 1;
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= c) lo = mid; else hi = mid - 1; }
-    return lo;
-}
-
 __global__ __launch_bounds__(256)
 void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int penalize_outside, int B, int flat) {
     extern __shared__ int s_pref[];             // [B + 1] (flat distribution)
@@ -1260,6 +1341,9 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     P.poff = h->zeros<int>(B * F); P.pown = h->zeros<int>(B * P.pair_cap); P.plist = h->zeros<int>(B * P.pair_cap);
     P.pout = h->zeros<float>(B * 10 * P.pair_cap); P.ptotal = h->zeros<int>(B); P.stats = h->zeros<int>(B * PEN_STATS);
     P.cells = h->zeros<int>(B * (PEN_CELLS + 1)); P.gridp = h->zeros<float>(B * 4);
+    P.wq_cap = std::max(1024, P.ent_cap / 8);      // (a block of 64 entries queues at most PEN_MAX_CHUNK - 1 chunks; a full queue makes the block walk on itself)
+    P.wq = h->zeros<int2>(B * (size_t)P.wq_cap); P.wqn = h->zeros<int>(B);
+    if (!P.wq || !P.wqn) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     P.tgrad = h->zeros<float>(B * F * 9); P.tloss = h->zeros<float>(B * F);
     if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tlist || !P.tcount || !P.pbox || !P.gpart || !P.aabb || !P.entries) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.pavail || !P.ptotal) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
@@ -1293,7 +1377,14 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
     hipLaunchKernelGGL(k_pen_g1, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, verts_dev, want_dev);
     hipLaunchKernelGGL(k_pen_g2, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, want_dev);
     hipLaunchKernelGGL(k_pen_g3, dim3(B), dim3(PEN_T), (size_t)(PEN_GRID_INTS + PEN_CELLS) * sizeof(int), s, h->P, want_dev);
-    hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, h->P, want_dev);
+    {
+        static const bool chunks_off = getenv("SFX_PEN_WALK_CHUNKS_OFF") != nullptr;      // (A/B measurement switch: same pair set either way)
+        PenDev Pw = h->P;
+        const bool queued = B <= PEN_FLAT_MAXB && !chunks_off;
+        if (!queued) Pw.wq_cap = 0;                // every block walks its bucket to the end itself
+        hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, Pw, want_dev);
+        if (queued) hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, Pw, B);
+    }
     PenDev Pl = h->P;
     Pl.over = over_dev;         // (per call: the caller's per-mesh "arrival order decided" flags, or NULL)
     hipLaunchKernelGGL(k_pen_list, dim3(B), dim3(PEN_T), (size_t)(h->P.F + h->P.hasp_words) * sizeof(int), s, Pl, want_dev);
