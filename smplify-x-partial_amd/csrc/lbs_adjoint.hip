@@ -28,6 +28,30 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ADJ_T 256
 #define ADJ_RW_MIN 256           // r range of one wavefront: 256 (few frame tiles: more workgroups) or 512
 
+// The columns of a launch that carry a collision weight (pen_want), in ascending order: frame tile `tile` of the adjoint GEMM
+// works on the 64 of them with ranks 64 tile .. 64 tile + 63 (round 4: it used to work on ALL active columns -- 40 of 127 want
+// the term in an average round of the benchmark, so half of its frame tiles multiplied stale operands for nobody).  Formed by
+// wavefront 0 of every workgroup from the flags (a few ballots); a column's arithmetic does not depend on where it sits in a
+// tile, so the numbers are what they were.  Returns the number of wanted columns.
+__device__ __forceinline__ int adj_tile_columns(const int* __restrict__ want, const int nact, const int tile, int* s_cols /* [64] */, int* s_nw) {
+    const int t = threadIdx.x, lane = t & 63;
+    if (t < 64) {
+        s_cols[lane] = 0;
+        int cnt = 0;
+        for (int base = 0; base < nact; base += 64) {
+            const int b = base + lane;
+            const bool w = b < nact && want[b] != 0;
+            const unsigned long long m = __ballot(w);
+            const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull)) - tile * 64;
+            if (w && pos >= 0 && pos < 64) s_cols[pos] = b;
+            cnt += __popcll(m);
+        }
+        if (lane == 0) *s_nw = cnt;
+    }
+    __syncthreads();
+    return *s_nw;
+}
+
 struct __align__(16) AdjLDS { float acc[4][64][64]; };      // one 64 x 64 tile per wavefront: first its own first-chunk sums (rw = 512), then the tile it hands on
 
 // ONE association of the sum over r for every launch shape (a column's result must not depend on how many other columns
@@ -39,18 +63,22 @@ struct __align__(16) AdjLDS { float acc[4][64][64]; };      // one 64 x 64 tile 
 __global__ __launch_bounds__(ADJ_T, 2)
 void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
     __shared__ AdjLDS S;
+    __shared__ int s_cols[64], s_nw;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int m = lane & 15, q = lane >> 4;
     // grid: x = r slice (fastest: the slices of one (k tile, frame tile) stream disjoint parts of dirs),
-    // y = k tile (8), z = frame tile
+    // y = k tile (8), z = frame tile: the 64 WANTED columns of ranks 64 z .. (results land at those ranks in adj_part)
     const int slice = blockIdx.x, k0 = blockIdx.y * 64, b0 = blockIdx.z * 64;
+    if (adj_tile_columns(D.pen_want, D.nact, blockIdx.z, s_cols, &s_nw) <= b0) return;      // no wanted column in this tile
     const int LD = 3 * M.Vpad;
     const int r_lo = min(LD, (slice * 4 + wv) * rw);
     const int r_hi = min(LD, r_lo + rw);
     const int r_mid = min(r_hi, r_lo + ADJ_RW_MIN);      // end of the first 256-chunk of this wavefront's range
     const float* pa = M.dirs + (size_t)(k0 + m) * LD + 4 * q;
-    const float* pb = D.adj_G + (size_t)(b0 + m) * LD + 4 * q;
-    const size_t sa = (size_t)16 * LD;          // next MFMA tile: 16 rows further
+    const float* pbc[4];                        // the lane's column of each of the four 16-column MFMA tiles
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pbc[i] = D.adj_G + (size_t)s_cols[16 * i + m] * LD + 4 * q;
+    const size_t sa = (size_t)16 * LD;          // next MFMA tile of the matrix: 16 rows further
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -62,7 +90,7 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             a[i] = *reinterpret_cast<const float4*>(pa + i * sa + r);
-            b[i] = *reinterpret_cast<const float4*>(pb + i * sa + r);
+            b[i] = *reinterpret_cast<const float4*>(pbc[i] + r);
         }
     };
     if (r_lo < r_hi) load(a_c, b_c, r_lo);
@@ -149,14 +177,17 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
 //                  (joint, column), four joints per block; lanes stride the joint's vertex list, DPP reduction (fixed order)
 __global__ __launch_bounds__(256)
 void k_adj_finish(DevModel M, BatchDev D, int n_part, int pairs, int n_red) {
+    __shared__ int s_cols[64], s_nw;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if ((int)blockIdx.x < n_red) {
         const int ftile = blockIdx.x / (SFX_KD_PAD / 4), kq = blockIdx.x % (SFX_KD_PAD / 4);
-        const int b = ftile * 64 + lane;
+        const int nw = adj_tile_columns(D.pen_want, D.nact, ftile, s_cols, &s_nw);
+        const int c = ftile * 64 + lane;            // rank among the wanted columns = position in adj_part
         const int k = kq * 4 + wv;
-        if (b >= D.nact || !D.pen_want[b]) return;
+        if (c >= nw) return;
+        const int b = s_cols[lane];
         const size_t st = (size_t)SFX_KD_PAD * D.Bpad;
-        const float* p = D.adj_part + (size_t)k * D.Bpad + b;
+        const float* p = D.adj_part + (size_t)k * D.Bpad + c;
         float s = 0.f;
         if (pairs) {
             for (int i = 0; i < n_part; i += 4) {
