@@ -1138,12 +1138,14 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
         static const bool dbg_host = getenv("SFX_DEBUG_HOST") != nullptr;
         double host_enq_s = 0.0; long host_batches = 0;
         const double wall0 = dbg_host ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
+        static const int rpb_env = [] { const char* e = getenv("SFX_POLL_ROUNDS"); return e ? atoi(e) : 0; }();
+        const int rpb = std::max(1, std::min(64, rpb_env > 0 ? rpb_env : 8));          // rounds per polled batch
         auto rounds = [&](int buf) -> int {
-            if (dbg_nact) nact_hist[std::min(8, (D.nact - 1) / 32)] += 8;
+            if (dbg_nact) nact_hist[std::min(8, (D.nact - 1) / 32)] += rpb;
             const auto h0 = std::chrono::steady_clock::now();
             struct HostClock { const std::chrono::steady_clock::time_point t0; double& acc; long& n; bool on;
                                ~HostClock() { if (on) { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); ++n; } } } hc{h0, host_enq_s, host_batches, dbg_host};
-            for (int q = 0; q < 8; ++q, ++tick) {
+            for (int q = 0; q < rpb; ++q, ++tick) {
                 { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
                 if (int rc = eval_penetration(b, -2, s, true)) return rc;
                 ProfScope p("tick", s, D.nrun);
@@ -1157,7 +1159,7 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
         const int ahead = std::max(1, std::min(SFX_POLL_BUFS - 1, ahead_env > 0 ? ahead_env : (b->pen ? 1 : 3)));
         long q_head = 0, q_next = 0;       // batches processed / queued
         for (; q_next < ahead; ++q_next) if (int rc = rounds((int)(q_next % SFX_POLL_BUFS))) return rc;
-        while (!done && tick < max_ticks + 8L * ahead) {
+        while (!done && tick < max_ticks + (long)rpb * (ahead + 1)) {
             if (int rc = rounds((int)(q_next % SFX_POLL_BUFS))) return rc;
             ++q_next;
             const int cur = (int)(q_head % SFX_POLL_BUFS); ++q_head;
@@ -1204,8 +1206,8 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
         D.act = nullptr; D.nrun = 0;
         if (dbg_host) {
             const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - wall0;
-            fprintf(stderr, "[sfx] host enqueue: %ld batches of 8 rounds, %.1f us of host time per round, %.1f %% of the loop's %.1f ms wall time\n",
-                    host_batches, 1e6 * host_enq_s / std::max(1L, host_batches * 8), 100.0 * host_enq_s / std::max(wall, 1e-9), 1e3 * wall);
+            fprintf(stderr, "[sfx] host enqueue: %ld batches of rounds, %.1f us of host time per round, %.1f %% of the loop's %.1f ms wall time\n",
+                    host_batches, 1e6 * host_enq_s / std::max(1L, host_batches * rpb), 100.0 * host_enq_s / std::max(wall, 1e-9), 1e3 * wall);
         }
         if (dbg_nact) {
             fprintf(stderr, "[sfx] rounds by active columns (<=32, <=64, ..., <=256, more), cumulative:");

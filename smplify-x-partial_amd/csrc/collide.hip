@@ -113,67 +113,89 @@ struct PenDev {
 };
 
 // ---------------------------------------------------------------------------------------------
-template <int N> struct Dual { float v; float d[N]; };
-template <int N> __device__ __forceinline__ Dual<N> dconst(float v) { Dual<N> r; r.v = v; for (int i = 0; i < N; ++i) r.d[i] = 0.f; return r; }
-template <int N> __device__ __forceinline__ Dual<N> dvar(float v, int k) { Dual<N> r = dconst<N>(v); r.d[k] = 1.f; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v + b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v - b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) { Dual<N> r; r.v = a.v * b.v; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator*(const Dual<N>& a, float s) { Dual<N> r; r.v = a.v * s; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * s; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator+(const Dual<N>& a, float s) { Dual<N> r = a; r.v += s; return r; }
-template <int N> __device__ __forceinline__ Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {
-    Dual<N> r; const float inv = 1.f / b.v; r.v = a.v * inv;
-    for (int i = 0; i < N; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
-    return r;
-}
-template <int N> __device__ __forceinline__ Dual<N> dsqrt(const Dual<N>& a) {
-    Dual<N> r; r.v = sqrtf(a.v); const float h = r.v > 0.f ? 0.5f / r.v : 0.f;
-    for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * h;
-    return r;
-}
-template <int N> struct DVec { Dual<N> x, y, z; };
-template <int N> __device__ __forceinline__ DVec<N> operator-(const DVec<N>& a, const DVec<N>& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-template <int N> __device__ __forceinline__ DVec<N> operator+(const DVec<N>& a, const DVec<N>& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-template <int N> __device__ __forceinline__ DVec<N> operator*(const DVec<N>& a, const Dual<N>& s) { return {a.x * s, a.y * s, a.z * s}; }
-template <int N> __device__ __forceinline__ Dual<N> ddot(const DVec<N>& a, const DVec<N>& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-template <int N> __device__ __forceinline__ DVec<N> dcross(const DVec<N>& a, const DVec<N>& b) {
-    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
-}
+// The cone field and its derivatives, written out in reverse mode (round 4; rounds 1-3 pushed forward-mode dual numbers with
+// nine tangents through the same formulas: ~10 x the flops of the value, and the pair evaluation was ALU-bound whenever most
+// columns of a launch carried the term: p90 155 us).  Notation of oracle/penetration.py.
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 operator+(const V3& a, const V3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(const V3& a, const float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float vdot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 vcross(const V3& a, const V3& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 
-// circumscribed circle + unit normal of a triangle (oracle/penetration.py: _cone_geometry)
-template <int N>
-__device__ __forceinline__ void cone_geometry(const DVec<N>& p0, const DVec<N>& p1, const DVec<N>& p2,
-                                              DVec<N>& o, Dual<N>& r, DVec<N>& n) {
-    const DVec<N> a = p1 - p0, b = p2 - p0;
-    const DVec<N> axb = dcross(a, b);
-    const Dual<N> n2 = ddot(axb, axb);
-    const Dual<N> den = n2 * 2.f;
-    const Dual<N> aa = ddot(a, a), bb = ddot(b, b);
-    const DVec<N> num = dcross(axb, a) * bb + dcross(b, axb) * aa;
-    const Dual<N> inv = dconst<N>(1.f) / den;
-    const DVec<N> oc = num * inv;
-    o = p0 + oc;
-    r = dsqrt(ddot(oc, oc));
-    const Dual<N> il = dconst<N>(1.f) / dsqrt(n2);
-    n = axb * il;
+// circumscribed circle + unit normal of a triangle (oracle/penetration.py: _cone_geometry); the intermediates the reverse
+// sweep needs are kept
+struct ConeGeo { V3 a, b, axb, num, oc, o, n; float n2, aa, bb, inv, il, r; };
+__device__ __forceinline__ ConeGeo cone_geometry(const V3& p0, const V3& p1, const V3& p2) {
+    ConeGeo g;
+    g.a = p1 - p0; g.b = p2 - p0;
+    g.axb = vcross(g.a, g.b);
+    g.n2 = vdot(g.axb, g.axb);
+    g.aa = vdot(g.a, g.a); g.bb = vdot(g.b, g.b);
+    g.num = vcross(g.axb, g.a) * g.bb + vcross(g.b, g.axb) * g.aa;
+    g.inv = 1.f / (g.n2 * 2.f);
+    g.oc = g.num * g.inv;
+    g.o = p0 + g.oc;
+    g.r = sqrtf(vdot(g.oc, g.oc));
+    g.il = 1.f / sqrtf(g.n2);
+    g.n = g.axb * g.il;
+    return g;
 }
-
-// Psi(v)^2 of the cone field (o, r, n) at the point v (oracle/penetration.py: _psi, squared)
-template <int N>
-__device__ __forceinline__ Dual<N> cone_penalty(const DVec<N>& o, const Dual<N>& r, const DVec<N>& n, const DVec<N>& v,
-                                                const float sigma, const int penalize_outside) {
-    const DVec<N> d = v - o;
-    const Dual<N> x = ddot(d, n);
-    if (!(x.v < sigma) || (!penalize_outside && x.v > 0.f)) return dconst<N>(0.f);
-    const DVec<N> q = d - n * x;
-    const Dual<N> rho = dsqrt(ddot(q, q));
-    const Dual<N> phi = rho / (r - (r * (1.f / sigma)) * x);
-    if (!(phi.v < 1.f)) return dconst<N>(0.f);
-    Dual<N> ups;
-    if (x.v <= -sigma) ups = (x * -1.f) + (1.f - sigma);
-    else ups = (x * x) * (-(1.f - 2.f * sigma) / (4.f * sigma * sigma)) + x * (-1.f / (2.f * sigma)) + ((3.f - 2.f * sigma) / 4.f);
-    const Dual<N> w = (dconst<N>(1.f) - phi) * ups;
-    const Dual<N> psi = w * w;
+// adjoint of cone_geometry: (d L / d o, d L / d r, d L / d n) -> d L / d (p0, p1, p2)
+__device__ __forceinline__ void cone_geometry_adj(const ConeGeo& g, const V3& go, const float gr, const V3& gn, V3& gp0, V3& gp1, V3& gp2) {
+    // r = |oc| (sqrt at 0: zero slope, as the forward-mode version had it); o = p0 + oc
+    const V3 goc = go + g.oc * (g.r > 0.f ? gr / g.r : 0.f);
+    // n = axb il, il = n2^(-1/2)
+    V3 gaxb = gn * g.il;
+    float gn2 = vdot(g.axb, gn) * (-0.5f * g.il / g.n2);
+    // oc = num inv, inv = 1 / (2 n2)
+    const V3 gnum = goc * g.inv;
+    gn2 += -vdot(g.num, goc) * g.inv * g.inv * 2.f;
+    gaxb = gaxb + g.axb * (2.f * gn2);
+    // num = (axb x a) bb + (b x axb) aa
+    const V3 u1 = vcross(g.axb, g.a), u2 = vcross(g.b, g.axb);
+    const V3 gu1 = gnum * g.bb, gu2 = gnum * g.aa;
+    const float gbb = vdot(u1, gnum), gaa = vdot(u2, gnum);
+    gaxb = gaxb + vcross(g.a, gu1) + vcross(gu2, g.b);         // u = x x y: dx = y x du, dy = du x x
+    V3 ga = vcross(gu1, g.axb) + g.a * (2.f * gaa);
+    V3 gb = vcross(g.axb, gu2) + g.b * (2.f * gbb);
+    // axb = a x b
+    ga = ga + vcross(g.b, gaxb);
+    gb = gb + vcross(gaxb, g.a);
+    gp1 = ga; gp2 = gb; gp0 = go - ga - gb;
+}
+// Psi(v)^2 of the cone field (o, r, n) at the point v (oracle/penetration.py: _psi, squared) and its derivatives with respect
+// to d = v - o (= d / d v = - d / d o), n and r
+__device__ __forceinline__ float cone_penalty(const V3& o, const float r, const V3& n, const V3& v, const float sigma,
+                                              const int penalize_outside, V3& gd, V3& gn, float& gr) {
+    gd = {0.f, 0.f, 0.f}; gn = {0.f, 0.f, 0.f}; gr = 0.f;
+    const V3 d = v - o;
+    const float x = vdot(d, n);
+    if (!(x < sigma) || (!penalize_outside && x > 0.f)) return 0.f;
+    const V3 q = d - n * x;
+    const float rho = sqrtf(vdot(q, q));
+    const float s = r * (1.f / sigma);
+    const float den = r - s * x;
+    const float phi = rho / den;
+    if (!(phi < 1.f)) return 0.f;
+    float ups, dups;
+    if (x <= -sigma) { ups = (x * -1.f) + (1.f - sigma); dups = -1.f; }
+    else {
+        const float c2 = -(1.f - 2.f * sigma) / (4.f * sigma * sigma), c1 = -1.f / (2.f * sigma);
+        ups = (x * x) * c2 + x * c1 + ((3.f - 2.f * sigma) / 4.f); dups = 2.f * c2 * x + c1;
+    }
+    const float w = (1.f - phi) * ups;
+    const float psi = w * w;
+    // pen = w^4
+    const float gw = 4.f * w * psi;
+    const float gphi = -ups * gw, gups = (1.f - phi) * gw;
+    const float grho = gphi / den, gden = -gphi * phi / den;           // phi = rho / den
+    gr = gden * (1.f - x * (1.f / sigma));                              // den = r - (r / sigma) x
+    float gx = gups * dups - gden * s;
+    const V3 gq = q * (rho > 0.f ? grho / rho : 0.f);                   // rho = |q|
+    gx -= vdot(n, gq);                                                  // q = d - n x
+    gd = gq + n * gx;                                                   // x = d . n
+    gn = gq * (-x) + d * gx;
     return psi * psi;
 }
 
@@ -1085,31 +1107,31 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
             const unsigned long long dead = __ballot(valid && !sym);
             if (dead && lane == 0) atomicAdd(&P.stats[b * PEN_STATS + 15], __popcll(dead));
         }
-        if (sym)
-        {   // (1) this triangle receives the partner's vertices: own geometry as duals over the 9 own coordinates
-            DVec<9> P0 = {dvar<9>(p[0], 0), dvar<9>(p[1], 1), dvar<9>(p[2], 2)};
-            DVec<9> P1 = {dvar<9>(p[3], 3), dvar<9>(p[4], 4), dvar<9>(p[5], 5)};
-            DVec<9> P2 = {dvar<9>(p[6], 6), dvar<9>(p[7], 7), dvar<9>(p[8], 8)};
-            DVec<9> o9, n9; Dual<9> r9;
-            cone_geometry(P0, P1, P2, o9, r9, n9);
-            for (int k = 0; k < 3; ++k) {
-                const DVec<9> v = {dconst<9>(qv[k * 3]), dconst<9>(qv[k * 3 + 1]), dconst<9>(qv[k * 3 + 2])};
-                const Dual<9> pen = cone_penalty(o9, r9, n9, v, sigma, penalize_outside);
-                loss += pen.v;
-                for (int j = 0; j < 9; ++j) g9[j] += pen.d[j];
+        if (sym) {
+            const V3 P0 = {p[0], p[1], p[2]}, P1 = {p[3], p[4], p[5]}, P2 = {p[6], p[7], p[8]};
+            const V3 Q[3] = {{qv[0], qv[1], qv[2]}, {qv[3], qv[4], qv[5]}, {qv[6], qv[7], qv[8]}};
+            {   // (1) this triangle receives the partner's vertices: the loss, and its gradient through the own cone's geometry
+                const ConeGeo g = cone_geometry(P0, P1, P2);
+                V3 go = {0.f, 0.f, 0.f}, gn = {0.f, 0.f, 0.f}; float gr = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    V3 gd, gnk; float grk;
+                    loss += cone_penalty(g.o, g.r, g.n, Q[k], sigma, penalize_outside, gd, gnk, grk);
+                    go = go - gd; gn = gn + gnk; gr += grk;            // d = v - o
+                }
+                V3 g0, g1, g2;
+                cone_geometry_adj(g, go, gr, gn, g0, g1, g2);
+                g9[0] += g0.x; g9[1] += g0.y; g9[2] += g0.z; g9[3] += g1.x; g9[4] += g1.y; g9[5] += g1.z; g9[6] += g2.x; g9[7] += g2.y; g9[8] += g2.z;
             }
-        }
-        if (sym)
-        {   // (2) this triangle's vertices intrude into the partner's cone (partner geometry constant)
-            DVec<3> Q0 = {dconst<3>(qv[0]), dconst<3>(qv[1]), dconst<3>(qv[2])};
-            DVec<3> Q1 = {dconst<3>(qv[3]), dconst<3>(qv[4]), dconst<3>(qv[5])};
-            DVec<3> Q2 = {dconst<3>(qv[6]), dconst<3>(qv[7]), dconst<3>(qv[8])};
-            DVec<3> o3, n3; Dual<3> r3;
-            cone_geometry(Q0, Q1, Q2, o3, r3, n3);
-            for (int k = 0; k < 3; ++k) {
-                const DVec<3> v = {dvar<3>(p[k * 3], 0), dvar<3>(p[k * 3 + 1], 1), dvar<3>(p[k * 3 + 2], 2)};
-                const Dual<3> pen = cone_penalty(o3, r3, n3, v, sigma, penalize_outside);
-                for (int e = 0; e < 3; ++e) g9[k * 3 + e] += pen.d[e];
+            {   // (2) this triangle's vertices intrude into the partner's cone (partner geometry constant): d / d v = d / d d
+                const ConeGeo g = cone_geometry(Q[0], Q[1], Q[2]);
+                const V3 Pk[3] = {P0, P1, P2};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    V3 gd, gnk; float grk;
+                    (void)cone_penalty(g.o, g.r, g.n, Pk[k], sigma, penalize_outside, gd, gnk, grk);
+                    g9[k * 3] += gd.x; g9[k * 3 + 1] += gd.y; g9[k * 3 + 2] += gd.z;
+                }
             }
         }
         // sum over the pairs of one triangle that sit in this wavefront (they are adjacent lanes): segmented
