@@ -473,3 +473,47 @@ def test_pooled_batch_with_interpenetration():
     assert np.array_equal(out["pool"][0], out["all"][0]) and np.array_equal(out["pool"][1], out["all"][1])
     assert np.array_equal(out["pool"][2]["pairs"], out["all"][2]["pairs"]) and out["all"][2]["pairs"].shape == (B,)
     assert (out["all"][2]["pairs"] > 0).sum() > B // 2          # the tubes of neighbouring bones run through each other: the term was evaluated
+
+
+def test_chunked_pair_tests_equal_the_unchunked_walk(tmp_path):
+    """k_pen_walk / k_pen_walk2 (round 4: a block's walk through its bucket in chunks of 64 steps, the chunks beyond the first as
+    one flat list over all meshes) against the walk that runs every bucket to its end on the block's own wavefront
+    (SFX_PEN_WALK_CHUNKS_OFF=1), and the flat pair evaluation against the per-mesh grid (SFX_PEN_FLAT_OFF=1): same pairs, same
+    loss, same gradient, bit for bit.  The mesh is built to make the chunks matter: 1 500 small triangles of two parts inside ONE
+    grid cell (a bucket of 1 500 entries: 24 chunks per block) next to a sparse cloud of large ones, three meshes with
+    different content in one call (the flat lists cross mesh boundaries).  max_collisions 1024 so that no partner list overflows."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import json, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from smplifyx_amd import engine
+rng = np.random.RandomState(0)
+def mesh(n_dense, n_sparse, seed):
+    r = np.random.RandomState(seed)
+    c = np.concatenate([0.2 * r.rand(n_dense, 3), 4.0 * r.rand(n_sparse, 3) + 1.0])        # one crowded cell + a sparse cloud of
+    sg = np.concatenate([np.full(n_dense, 0.01), np.full(n_sparse, 0.15)])                # large triangles (they set the cell size)
+    tri = c[:, None, :] + sg[:, None, None] * r.randn(len(c), 3, 3)
+    return tri.reshape(-1, 3).astype(np.float32)
+nd, ns = 1500, 1000
+F = nd + ns
+faces = np.arange(F * 3).reshape(F, 3)
+segm = (np.arange(F) %% 2).astype(np.int64); parents = np.full(F, -1, np.int64)
+verts = np.stack([mesh(nd, ns, s) for s in (1, 2, 3)])
+verts[1, : nd * 3 // 2] += 10.0           # the second mesh: half of the crowd moved away
+pen = engine.Penetration(F * 3, faces, segm=segm, parents=parents, max_collisions=1024, max_batch=3)
+loss, dv = pen.eval(torch.tensor(verts, device="cuda"), 0.01, True)
+st = pen.stats(3)
+print(json.dumps({"loss": [float(x).hex() for x in loss.cpu().numpy()], "pairs": st["pairs"].tolist(), "dropped": st["dropped"].tolist(),
+                  "cut": st["walks_cut"].tolist(), "grad_sum": float(np.abs(dv.cpu().numpy().astype(np.float64)).sum()).hex(),
+                  "grad_hash": hash(dv.cpu().numpy().tobytes()) & 0xffffffff}))
+''' % root
+    outs = {}
+    for name, env_extra in (("chunked", {}), ("unchunked", {"SFX_PEN_WALK_CHUNKS_OFF": "1", "SFX_PEN_FLAT_OFF": "1"})):
+        env = dict(os.environ, PYTHONHASHSEED="0", **env_extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = outs["chunked"], outs["unchunked"]
+    assert a["pairs"][0] > 3000 and a["pairs"][1] < a["pairs"][0] and a["dropped"] == [0, 0, 0] and a["cut"] == [0, 0, 0], a
+    assert a == b, (a, b)
