@@ -116,6 +116,8 @@ def compact_line(full):
         line["value_min3_camera_keypoints"] = _num(full["value_min3_camera_keypoints"])
     if isinstance(full.get("alt"), dict):
         line["alt"] = _pick(full["alt"], ("lbs_mode", "value", "unit", "ms_per_step", "closure_evals_per_frame_mean", "final_loss_median"))
+    if isinstance(full.get("host"), dict):
+        line["host"] = _pick(full["host"], ("enqueue_us_per_round", "loop_us_per_round", "kernels_us_per_round", "queue_dry_frac", "wait_frac"), sig=4)
     if "kernels_ms_avg" in full:
         line["kernels_ms_avg"] = _pick(full["kernels_ms_avg"], ("lbs_dense", "tick_dense", "fit_rows", "penetration"))
     if "detail" in full:
@@ -127,7 +129,7 @@ def compact_line(full):
         return o[:160] if isinstance(o, str) else o
     line = clip(line)
     # never exceed the limit: shed the optional objects, least essential first
-    for drop in ("kernels_ms_avg", "alt", "closure_parity", "roofline_pen", "roofline_tick", "reference_parity"):
+    for drop in ("kernels_ms_avg", "host", "alt", "closure_parity", "roofline_pen", "roofline_tick", "reference_parity"):
         if len(json.dumps(line, allow_nan=False)) < LINE_LIMIT:
             break
         line.pop(drop, None)
@@ -354,7 +356,7 @@ def csrc_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "smplify-x-partial_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
+        if f.endswith((".hip", ".h")) and f != "api.hip":      # (api.hip is the host layer: loops, launches, allocation -- not what the counters measure)
             h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -704,6 +706,7 @@ def main():
     prof_every = 1 if args.lbs == "rows" else args.prof_every
     engine.prof_enable(True, every=prof_every)
     engine.prof_reset()
+    engine.loop_host_stats(reset=True)
     if pen:
         engine.pen_work_reset()
     sync()
@@ -717,6 +720,7 @@ def main():
     engine.prof_enable(False)
     # per-kernel HIP-event figures of the headline region (read before the side runs add their launches)
     prof = {k: engine.prof_get(k) for k in ("lbs_dense", "tick", "fit_rows", "penetration")}
+    host = engine.loop_host_stats()            # the host thread's side of the timed fits (dense loops)
     pen_work = engine.pen_work_get() if pen else None      # device counts over the timed region: grid entries, ordered pairs, columns
     # side key: the same job on the detector that keeps >= 3 of the 4 camera-initialisation keypoints (round 2's headline)
     side_min3 = None
@@ -804,6 +808,14 @@ def main():
                                "timed_launches_per_step": (n_dense + n_clo + n_lb) / max(args.steps, 1)},
         }
         out["config"].update(loss_distribution(st["stage_loss"][:, -1]))
+        if host["rounds"]:
+            # where a step's wall time goes on the host: its thread enqueues (hidden behind the GPU on a quick host), waits for the
+            # stage flags of a finished batch (= the GPU is the bottleneck: good), or neither (the GPU starved: the loop's wall
+            # time minus the kernels' time is then queue-dry time)
+            k_us = 1e3 * (ms_dense / max(n_dense, 1) + ms_clo / max(n_clo, 1) + prof["penetration"][0] / max(prof["penetration"][1], 1))
+            out["host"] = {"enqueue_us_per_round": 1e6 * host["enqueue_s"] / host["rounds"], "wait_frac": host["wait_s"] / max(host["wall_s"], 1e-12),
+                           "loop_us_per_round": 1e6 * host["wall_s"] / host["rounds"], "kernels_us_per_round": k_us,
+                           "queue_dry_frac": max(0.0, 1.0 - k_us * host["rounds"] / max(1e6 * host["wall_s"], 1e-12))}
         if side_min3 is not None:
             out["value_min3_camera_keypoints"] = side_min3["value"]
             out["min3_camera_keypoints"] = side_min3

@@ -283,6 +283,11 @@ int  sfx_pen_work_get(int64_t* work_host);
  * recent evaluation, then the number of grid entries: HOST [B][11].                               */
 int  sfx_pen_phase_clocks(sfx_pen* h, int32_t B, int32_t* clocks_host);
 
+/* Host side of the fitting loops (dense mode) since the last reset, HOST [4]: seconds the host thread spent enqueueing launches,
+ * seconds it spent waiting for a batch's stage flags, wall seconds of the loops, rounds enqueued.  Wall time far above the kernels'
+ * time with little waiting = the queue ran dry behind a slow host (bench.py reports this next to the kernels' times).          */
+int  sfx_loop_host_stats(double* stats_host, int32_t reset);
+
 /* Timing hooks for the roofline report: total duration (ms), number of TIMED launches and
  * frames processed by them, of the named kernel since the last reset, measured with HIP events
  * on the launch stream.  name: "lbs_dense", "tick" (k_tick_dense), "fit_rows", "closure",

@@ -99,6 +99,7 @@ SYMBOLS = {
     "sfx_batch_set_gmm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, f32p, f32p]),
     "sfx_batch_set_gmm_form": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, f32p, f32p, f32p]),
     "sfx_batch_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, f32p, C.c_int64]),
+    "sfx_loop_host_stats": (C.c_int, [C.POINTER(C.c_double), C.c_int32]),
     "sfx_prof_enable": (C.c_int, [C.c_int32]),
     "sfx_prof_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "sfx_prof_reset": (None, []),

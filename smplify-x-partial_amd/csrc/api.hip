@@ -74,6 +74,16 @@ extern "C" int sfx_prof_enable(int32_t on) {
     return 0;
 }
 extern "C" void sfx_prof_reset(void) { std::lock_guard<std::mutex> lk(g_prof_mu); for (auto& kv : g_acc) { prof_flush(kv.second); } g_acc.clear(); }
+// Host side of the polled dense loops since the last reset (HOST [4]): seconds spent enqueueing, seconds spent waiting for a
+// batch's stage flags (the GPU was ahead of the host exactly when this is ~0 while the loop's wall time exceeds the kernels'),
+// wall seconds of the loops, rounds enqueued.
+static double g_loop_host[4] = {0, 0, 0, 0};
+extern "C" int sfx_loop_host_stats(double* out, int32_t reset) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (out) for (int i = 0; i < 4; ++i) out[i] = g_loop_host[i];
+    if (reset) for (int i = 0; i < 4; ++i) g_loop_host[i] = 0.0;
+    return 0;
+}
 extern "C" int sfx_prof_get(const char* name, double* total_ms, int64_t* launches, double* units) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     auto it = g_acc.find(name);
@@ -1136,15 +1146,15 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
         { ProfScope p("tick", s, D.nrun); launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, s); }
         // SFX_DEBUG_HOST=1: how much of the loop's wall time the HOST spends enqueueing (its headroom against a busy box)
         static const bool dbg_host = getenv("SFX_DEBUG_HOST") != nullptr;
-        double host_enq_s = 0.0; long host_batches = 0;
-        const double wall0 = dbg_host ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
+        double host_enq_s = 0.0, host_wait_s = 0.0; long host_batches = 0;
+        const double wall0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
         static const int rpb_env = [] { const char* e = getenv("SFX_POLL_ROUNDS"); return e ? atoi(e) : 0; }();
         const int rpb = std::max(1, std::min(64, rpb_env > 0 ? rpb_env : 8));          // rounds per polled batch
         auto rounds = [&](int buf) -> int {
             if (dbg_nact) nact_hist[std::min(8, (D.nact - 1) / 32)] += rpb;
             const auto h0 = std::chrono::steady_clock::now();
             struct HostClock { const std::chrono::steady_clock::time_point t0; double& acc; long& n; bool on;
-                               ~HostClock() { if (on) { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); ++n; } } } hc{h0, host_enq_s, host_batches, dbg_host};
+                               ~HostClock() { if (on) { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); ++n; } } } hc{h0, host_enq_s, host_batches, true};
             for (int q = 0; q < rpb; ++q, ++tick) {
                 { ProfScope p("lbs_dense", s, D.nact); launch_lbs_dense(M, D, s); }
                 if (int rc = eval_penetration(b, -2, s, true)) return rc;
@@ -1163,7 +1173,11 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
             if (int rc = rounds((int)(q_next % SFX_POLL_BUFS))) return rc;
             ++q_next;
             const int cur = (int)(q_head % SFX_POLL_BUFS); ++q_head;
-            SFX_CHECK(hipEventSynchronize(b->poll_ev[cur]));
+            {
+                const auto w0 = std::chrono::steady_clock::now();
+                SFX_CHECK(hipEventSynchronize(b->poll_ev[cur]));
+                host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+            }
             const int* hq = b->stage_host + (size_t)cur * B;
             // frames of the running list that have finished (frames admitted after this snapshot show their start stage)
             std::vector<int> fresh;
@@ -1204,8 +1218,12 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
         }
         SFX_CHECK(hipStreamSynchronize(s));
         D.act = nullptr; D.nrun = 0;
+        const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - wall0;
+        {   // the host's side of this loop, accumulated for sfx_loop_host_stats (bench.py reports it next to the kernels' times)
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            g_loop_host[0] += host_enq_s; g_loop_host[1] += host_wait_s; g_loop_host[2] += wall; g_loop_host[3] += (double)host_batches * rpb;
+        }
         if (dbg_host) {
-            const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - wall0;
             fprintf(stderr, "[sfx] host enqueue: %ld batches of rounds, %.1f us of host time per round, %.1f %% of the loop's %.1f ms wall time\n",
                     host_batches, 1e6 * host_enq_s / std::max(1L, host_batches * rpb), 100.0 * host_enq_s / std::max(wall, 1e-9), 1e3 * wall);
         }

@@ -437,6 +437,14 @@ def prof_get(name):
     return ms.value, n.value, u.value
 
 
+def loop_host_stats(reset=False):
+    """Host side of the dense fitting loops since the last reset: seconds enqueueing, seconds waiting for stage flags, wall
+    seconds, rounds (sfx_loop_host_stats)."""
+    w = (C.c_double * 4)()
+    capi.check(capi.load().sfx_loop_host_stats(w, int(bool(reset))))
+    return dict(enqueue_s=w[0], wait_s=w[1], wall_s=w[2], rounds=int(w[3]))
+
+
 def pen_work_reset():
     """Zero the device counters of the interpenetration term's work (sfx_pen_work_reset)."""
     capi.check(capi.load().sfx_pen_work_reset())

@@ -16,7 +16,7 @@ def csrc_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "smplify-x-partial_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
+        if f.endswith((".hip", ".h")) and f != "api.hip":      # (api.hip is the host layer: loops, launches, allocation -- not what the counters measure)
             h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
