@@ -80,7 +80,7 @@ def sanitize(o):
 
 
 ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "frac_executed", "mfma_busy_frac",
-                 "avg_launch_us", "launches", "frames_per_launch", "share_of_step", "hbm_frac", "bytes_per_launch",
+                 "avg_launch_us", "avg_launch_us_profile", "launches", "frames_per_launch", "share_of_step", "hbm_frac", "bytes_per_launch",
                  "bytes_per_frame_launch", "rows_per_frame_launch", "shared_bytes_per_launch", "l2_stream_bytes_per_frame", "l2_stream_GBps_per_cu",
                  "columns_per_launch", "bytes_per_column_launch",
                  "grid_entries_per_column", "pairs_per_column", "launches_per_round")
@@ -839,6 +839,20 @@ def main():
             pmc_ok, pmc_note = False, "profiles/%s was taken at 256 frames per GPU, this run has %d: traffic not replayed" % (pmc_name, B)
         pj = json.load(open(pmc)) if pmc_ok else {}
 
+        def profiled_us(prefix, path=None):
+            """Average duration (us) of the kernel in the rocprofv3 --kernel-trace --stats summary of this command
+            (profiles/kernel_stats*.csv, taken with the counters: same source hash), or None.  HIP events bracket the dispatch as
+            well: they read 2-3 us longer than the profiler's own clock on a 55-us kernel."""
+            import csv
+            path = path or os.path.join(ROOT, "profiles", pmc_name.replace("pmc_summary", "kernel_stats").replace(".json", ".csv"))
+            if not (pmc_ok and os.path.exists(path)):
+                return None
+            best = None
+            for row in csv.DictReader(open(path)):
+                if prefix in row["Name"] and (best is None or int(row["Calls"]) > best[0]):
+                    best = (int(row["Calls"]), float(row["AverageNs"]) * 1e-3)
+            return best[1] if best else None
+
         def pmc_kernel(prefix):
             """the instantiation with the most launches whose name contains `prefix` (templates: k_tick_dense<FrameLDSx<32, false>, 1>)"""
             cands = [v for n, v in pj.items() if prefix in n and isinstance(v, dict) and "hbm_read_bytes_per_launch" in v]
@@ -879,6 +893,7 @@ def main():
                                   "per the gfx950 correction"}
                 if "mfma_busy_frac" in k:
                     out["roofline"]["mfma_busy_frac"] = k["mfma_busy_frac"]
+            out["roofline"]["avg_launch_us_profile"] = profiled_us("k_lbs_dense16")
             # the other half of the step: loss + adjoint + L-BFGS tick + next pose / chain, one workgroup per frame.  Byte model
             # per frame and launch (tick_bytes_per_frame_launch) from THIS workload's own numbers: the vertex items under the
             # keypoints that are live in a stage (body | + hands | all; fit_single_frame.py:569-572), weighted by the evaluations
@@ -917,6 +932,7 @@ def main():
                                                 "figure to watch is avg_launch_us.  bytes_per_launch = constants every frame shares (static "
                                                 "adjoint rows, 2 x VPoser weights: once per launch, as the GEMM's matrix) + per frame "
                                                 "(dynamic-contour rows, history, vectors) x frames, rows evaluation-weighted over the stages"}
+                out["roofline_tick"]["avg_launch_us_profile"] = profiled_us("k_tick_dense")
                 if pmc_ok:
                     k = pmc_kernel("k_tick_dense")
                     if "hbm_read_bytes_per_launch" in k:

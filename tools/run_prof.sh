@@ -2,7 +2,8 @@
 # Profiling passes of a bench command on the GPU box (run through gpurun).
 #   tools/run_prof.sh TAG [bench.py flags ...]      e.g.  tools/run_prof.sh r03_full --workload full
 # Raw traces stay in /tmp on the box; the summaries land in gpurun_out/prof_TAG/ and are copied into profiles/ by hand
-# (kernel stats CSV, bench line under rocprof, pmc_summary.json).  Counter passes are separate runs (kernel trace + --pmc
+# (kernel stats CSV -> profiles/kernel_stats[_full|_pen|_rows].csv, bench line under rocprof, pmc_summary.json -> profiles/pmc_summary[...].json:
+# bench.py replays both when the summary's source hash equals the build's).  Counter passes are separate runs (kernel trace + --pmc
 # only: gpurun refuses --pmc together with the sys / runtime trace domains).  pmc_summary.json records the hash of the
 # csrc sources the counters were taken with (tools/pmc_summary.py csrc_sha): bench.py replays the traffic figures only
 # when that hash equals the running build's.
