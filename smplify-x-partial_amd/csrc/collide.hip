@@ -82,7 +82,8 @@ struct PenDev {
     float* aabb;               // [B][F][6]
     int2* entries;             // [B][ent_cap] (triangle | part << 24 | lz << 30, packed cell coordinates | lx << 30 | ly << 31), sorted by bucket;
                                //              lx, ly, lz: the cell holds the low corner of the triangle's box on that axis
-    int4* tlist;               // [B][F] the triangles that survive the part culling, compacted (any order): packed cell range, spans + part, triangle
+    int2* cand;                // [B][ent_cap] (round 4) one record per (surviving triangle, cell its box touches), any order: the entry record k_pen_g3 sorts
+    int4* tlist;               // [B][F] (unused since round 4: k_pen_g2 emits the candidate records itself)
     int* tcount;               // [B][16] (one cache line each) number of survivors (k_pen_g3 leaves 0 behind, k_pen_g2 reserves ranges)
     int* pbox;                 // [B][64][6] bounding box of every part, order-preserving ints (k_pen_g1; reset per evaluation)
     float* gpart;              // [B][PEN_GW][8] per workgroup of k_pen_g1: frame box lo / hi, extent sum
@@ -223,9 +224,7 @@ __device__ __forceinline__ float block_sum_fixed(float v, float* red) {
 // exclusive prefix sum over the PEN_T lanes of the block (fixed order); *total = sum of all
 __device__ __forceinline__ int block_excl_scan(const int v, int* wsum /* [PEN_T / 64] */, int* total) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    const int inc = wave_incl_scan_dpp(v);
     __syncthreads();
     if (lane == 63) wsum[wv] = inc;
     __syncthreads();
@@ -338,16 +337,28 @@ __device__ __forceinline__ PenGridCtx pen_grid_ctx(const PenDev& P, const int b)
 }
 __device__ __forceinline__ int pen_cell_of(const PenGridCtx& c, float x, int e) { return min(1 << 20, max(0, (int)fminf((x - c.glo[e]) * c.ih, 1048576.f))); }
 
+// fn(bucket, packed cell key) for every cell of a packed range
+template <class FN>
+__device__ __forceinline__ void pen_for_cells(const int2 pk, FN&& fn) {
+    const int x0 = pk.x & 1023, y0 = (pk.x >> 10) & 1023, z0 = (pk.x >> 20) & 1023;
+    const int sx = pk.y & 7, sy = (pk.y >> 3) & 7, sz = (pk.y >> 6) & 7;
+    // (the key's two spare bits, and bit 0 of the third argument, say on which axes -- x, y, z -- this cell is the one that
+    //  holds the LOW corner of the triangle's box: the pair tests decide ownership of a pair on these bits)
+    for (int dz = 0; dz <= sz; ++dz) for (int dy = 0; dy <= sy; ++dy) for (int dx = 0; dx <= sx; ++dx) {
+        const int x = (x0 + dx) & 1023, y = (y0 + dy) & 1023, z = (z0 + dz) & 1023;
+        fn(pen_bucket(x, y, z), x | (y << 10) | (z << 20) | ((dx == 0) << 30) | ((dy == 0) << 31), dz == 0);
+    }
+}
 __global__ __launch_bounds__(PEN_T)
 void k_pen_g2(PenDev P, const int* __restrict__ want) {
     __shared__ unsigned long long s_mask[64], s_near[64];
     __shared__ int s_pbox[64][6];
-    __shared__ int s_cnt, s_base;
+    __shared__ int s_cnt, s_base, s_ccnt, s_cbase;
     const int b = blockIdx.y, t = threadIdx.x, w = blockIdx.x, lane = t & 63;
     if (want && !want[b]) return;
     const int F = P.F;
     const float* aabb = P.aabb + (size_t)b * F * 6;
-    int4* tlist = P.tlist + (size_t)b * F;
+    int2* cand = P.cand + (size_t)b * P.ent_cap;
     const PenGridCtx C = pen_grid_ctx(P, b);
     if (w == 0 && t == 0) { float* gp = P.gridp + b * 4; gp[0] = C.glo[0]; gp[1] = C.glo[1]; gp[2] = C.glo[2]; gp[3] = C.ih; }
     if (t < 64) {
@@ -386,9 +397,9 @@ void k_pen_g2(PenDev P, const int* __restrict__ want) {
 #pragma unroll
             for (int e = 0; e < 6; ++e) bx[u][e] = aabb[ff * 6 + e];
         }
-        if (t == 0) s_cnt = 0;
+        if (t == 0) { s_cnt = 0; s_ccnt = 0; }
         __syncthreads();
-        int2 pk[PEN_GU]; int off[PEN_GU];
+        int2 pk[PEN_GU]; int coff[PEN_GU];
 #pragma unroll
         for (int u = 0; u < PEN_GU; ++u) {
             const int f = f0 + u * PEN_GW * PEN_T;
@@ -413,34 +424,39 @@ void k_pen_g2(PenDev P, const int* __restrict__ want) {
                 pk[u].x = (c0[0] & 1023) | ((c0[1] & 1023) << 10) | ((c0[2] & 1023) << 20) | (int)0x80000000;
                 pk[u].y = sp[0] | (sp[1] << 3) | (sp[2] << 6) | (seg[u] << 9);
             }
+            // Round 4: the survivor's CELLS are listed here, one entry record per cell its box touches, in one flat list of the
+            // frame (a wavefront reserves its share with one DPP scan and one LDS atomic, the workgroup its range with one global
+            // atomic; the order of the list is immaterial).  k_pen_g3 used to walk the cells of 4-7 triangles per lane in each of its
+            // three passes -- a wavefront's pass lasted as long as its widest lane (a triangle of 18 cells next to lanes with 2) --
+            // and now makes three balanced passes over this list.
             const unsigned long long m = __ballot(any);
+            if (lane == 0 && m) atomicAdd(&s_cnt, __popcll(m));
+            const int nc = any ? ((pk[u].y & 7) + 1) * (((pk[u].y >> 3) & 7) + 1) * (((pk[u].y >> 6) & 7) + 1) : 0;
+            const int inc = wave_incl_scan_dpp(nc);
+            const int wtot = __builtin_amdgcn_readlane(inc, 63);
             int wo = 0;
-            if (lane == 0 && m) wo = atomicAdd(&s_cnt, __popcll(m));
-            off[u] = __builtin_amdgcn_readfirstlane(wo) + __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0 && wtot) wo = atomicAdd(&s_ccnt, wtot);
+            coff[u] = __builtin_amdgcn_readfirstlane(wo) + inc - nc;
         }
         __syncthreads();
-        if (t == 0) s_base = s_cnt ? atomicAdd(&P.tcount[b * 16], s_cnt) : 0;
+        if (t == 0) { if (s_cnt) atomicAdd(&P.tcount[b * 16], s_cnt);            // survivors (statistics)
+                      s_cbase = s_ccnt ? atomicAdd(&P.tcount[b * 16 + 1], s_ccnt) : 0; }
         __syncthreads();
-        const int base = s_base;
+        const int cbase = s_cbase;
 #pragma unroll
         for (int u = 0; u < PEN_GU; ++u)
-            if (pk[u].x < 0) tlist[base + off[u]] = make_int4(pk[u].x, pk[u].y, f0 + u * PEN_GW * PEN_T, 0);
-        __syncthreads();        // (s_cnt is reset by the next batch)
+            if (pk[u].x < 0) {
+                const int f = f0 + u * PEN_GW * PEN_T, pf = (pk[u].y >> 9) & 63;
+                int pos = cbase + coff[u];
+                pen_for_cells(pk[u], [&](int, int key, int lowz) {
+                    if (pos < P.ent_cap) cand[pos] = make_int2(f | (pf << 24) | (lowz << 30), key);      // (triangle | part << 24 | low-corner bit z << 30, cell | low-corner bits x, y << 30)
+                    ++pos;
+                });
+            }
+        __syncthreads();        // (the counters are reset by the next batch)
     }
 }
 
-// fn(bucket, packed cell key) for every cell of a packed range
-template <class FN>
-__device__ __forceinline__ void pen_for_cells(const int2 pk, FN&& fn) {
-    const int x0 = pk.x & 1023, y0 = (pk.x >> 10) & 1023, z0 = (pk.x >> 20) & 1023;
-    const int sx = pk.y & 7, sy = (pk.y >> 3) & 7, sz = (pk.y >> 6) & 7;
-    // (the key's two spare bits, and bit 0 of the third argument, say on which axes -- x, y, z -- this cell is the one that
-    //  holds the LOW corner of the triangle's box: the pair tests decide ownership of a pair on these bits)
-    for (int dz = 0; dz <= sz; ++dz) for (int dy = 0; dy <= sy; ++dy) for (int dx = 0; dx <= sx; ++dx) {
-        const int x = (x0 + dx) & 1023, y = (y0 + dy) & 1023, z = (z0 + dz) & 1023;
-        fn(pen_bucket(x, y, z), x | (y << 10) | (z << 20) | ((dx == 0) << 30) | ((dy == 0) << 31), dz == 0);
-    }
-}
 // parts a triangle of part p may collide with, folded to 32 bits (a triangle only enters a cell that also holds such a
 // part: the crowded interior of a limb, and joints where only parent and child meet, never reach the pair tests)
 __device__ __forceinline__ void pen_coll32(const PenDev& P, unsigned* s_coll32) {
@@ -471,8 +487,10 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
         return;
     }
     const int F = P.F;
-    const int4* tlist = P.tlist + (size_t)b * F;
-    const int NT = min(P.tcount[b * 16], F);      // triangles that survived the part culling
+    const int2* cand = P.cand + (size_t)b * P.ent_cap;
+    const int NT = min(P.tcount[b * 16], F);              // triangles that survived the part culling (statistics)
+    const int NC_raw = P.tcount[b * 16 + 1];              // (triangle, cell) records k_pen_g2 listed
+    const int NC = min(NC_raw, P.ent_cap);
     unsigned* pmask = reinterpret_cast<unsigned*>(cell_cnt + PEN_GRID_INTS);
 #ifdef PEN_COUNT    // diagnostic build: shader clocks at the phase boundaries -> stats[24..30] (cycles per phase, thread 0)
     long long g3c[8]; int g3n = 0;
@@ -484,36 +502,34 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     for (int c = t; c <= PEN_CELLS; c += PEN_T) cell_cnt[c] = 0;
     for (int c = t; c < PEN_CELLS; c += PEN_T) pmask[c] = 0u;
     pen_coll32(P, s_coll32);                    // (ends with a barrier)
-    // this kernel is the last reader of the frame's survivor count, and k_pen_g2 was the last reader of its part boxes: leave
-    // both empty for the NEXT evaluation of this column (a launch of its own until round 4)
+    // this kernel is the last reader of the frame's counts, and k_pen_g2 was the last reader of its part boxes: leave
+    // them empty for the NEXT evaluation of this column (a launch of its own until round 4)
     if (t < 64 * 6) P.pbox[(size_t)b * 64 * 6 + t] = (t % 6) < 3 ? 0x7fffffff : (int)0x80000000;
-    if (t == 0) P.tcount[b * 16] = 0;
+    if (t == 0) { P.tcount[b * 16] = 0; P.tcount[b * 16 + 1] = 0; }
     G3MARK();
-    constexpr int U2 = 7;
+    // Three passes over the flat candidate list (coalesced 8-byte records, 8 in flight per lane): every lane does the same
+    // amount of work whatever the shapes of the triangles.
+    constexpr int U2 = 8;
+    auto cell_bucket = [](const int key) { return pen_bucket(key & 1023, (key >> 10) & 1023, (key >> 20) & 1023); };
     // which parts are present in each bucket (folded to 32 bits)
-    for (int f0 = t; f0 < NT; f0 += PEN_T * U2) {
-        int4 pk[U2];
+    for (int i0 = t; i0 < NC; i0 += PEN_T * U2) {
+        int2 r[U2];
 #pragma unroll
-        for (int u = 0; u < U2; ++u) { const int i = f0 + u * PEN_T; const int4 tc_ = tlist[i < NT ? i : 0]; pk[u] = i < NT ? tc_ : make_int4(0, 0, 0, 0); }
+        for (int u = 0; u < U2; ++u) { const int i = i0 + u * PEN_T; r[u] = cand[i < NC ? i : 0]; }
 #pragma unroll
-        for (int u = 0; u < U2; ++u) {
-            if (pk[u].x >= 0) continue;                    // (alive bit = sign bit: entries past the end of the list)
-            const unsigned bit = 1u << ((pk[u].y >> 9) & 31);
-            pen_for_cells(make_int2(pk[u].x, pk[u].y), [&](int bk, int, int) { atomicOr(&pmask[bk], bit); });
-        }
+        for (int u = 0; u < U2; ++u) if (i0 + u * PEN_T < NC) atomicOr(&pmask[cell_bucket(r[u].y)], 1u << ((r[u].x >> 24) & 31));
     }
     __syncthreads();
     G3MARK();
-    // histogram
-    for (int f0 = t; f0 < NT; f0 += PEN_T * U2) {
-        int4 pk[U2];
+    // histogram (a triangle only enters a cell that also holds a part it may collide with)
+    for (int i0 = t; i0 < NC; i0 += PEN_T * U2) {
+        int2 r[U2];
 #pragma unroll
-        for (int u = 0; u < U2; ++u) { const int i = f0 + u * PEN_T; const int4 tc_ = tlist[i < NT ? i : 0]; pk[u] = i < NT ? tc_ : make_int4(0, 0, 0, 0); }
+        for (int u = 0; u < U2; ++u) { const int i = i0 + u * PEN_T; r[u] = cand[i < NC ? i : 0]; }
 #pragma unroll
         for (int u = 0; u < U2; ++u) {
-            if (pk[u].x >= 0) continue;
-            const unsigned want32 = s_coll32[(pk[u].y >> 9) & 63];
-            pen_for_cells(make_int2(pk[u].x, pk[u].y), [&](int bk, int, int) { if (pmask[bk] & want32) atomicAdd(&cell_cnt[bk], 1); });
+            const int bk = cell_bucket(r[u].y);
+            if (i0 + u * PEN_T < NC && (pmask[bk] & s_coll32[(r[u].x >> 24) & 63])) atomicAdd(&cell_cnt[bk], 1);
         }
     }
     __syncthreads();
@@ -530,11 +546,9 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
 #pragma unroll
         for (int i = 0; i < per; ++i) {
             const int v = row0[i * 64];
-            int inc = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+            const int inc = wave_incl_scan_dpp(v);          // (six DPP adds; the __shfl_up ladder was 6 LDS-crossbar round trips, x 16 rows: 13.6 k of this kernel's 58 k cycles)
             ex[i] = carry + inc - v;
-            carry += __shfl(inc, 63);
+            carry += __builtin_amdgcn_readlane(inc, 63);
         }
         if (lane == 0) slice[wv] = carry;
         __syncthreads();
@@ -547,8 +561,8 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     }
     G3MARK();
     int2* ent = P.entries + (size_t)b * P.ent_cap;
-    const bool ent_ok = s_total <= P.ent_cap - 4;
-    if (t == 0) { st[2] = ent_ok ? 0 : s_total; st[3] = PEN_CELLS; st[13] = 0; st[14] = s_total; st[15] = 0; for (int q = 4; q < 13; ++q) st[q] = 0;
+    const bool ent_ok = s_total <= P.ent_cap - 4 && NC_raw <= P.ent_cap;
+    if (t == 0) { st[2] = ent_ok ? 0 : max(s_total, NC_raw); st[3] = PEN_CELLS; st[13] = 0; st[14] = s_total; st[15] = 0; for (int q = 4; q < 13; ++q) st[q] = 0;
                   for (int q = 16; q < PEN_STATS; ++q) st[q] = 0;
                   if (P.work) { atomicAdd(&P.work[0], (unsigned long long)s_total); atomicAdd(&P.work[2], 1ull); atomicAdd(&P.work[3], (unsigned long long)NT); } }
     if (!ent_ok) {       // grid too crowded for the entry buffer: report, produce no pairs
@@ -557,20 +571,14 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     }
     // scatter: the start offsets double as cursors, so bucket c ends up holding its END offset
     // (= the start of bucket c + 1); a bucket's entries are [c ? cell_cnt[c - 1] : 0, cell_cnt[c])
-    for (int f0 = t; f0 < NT; f0 += PEN_T * U2) {
-        int4 pk[U2];
+    for (int i0 = t; i0 < NC; i0 += PEN_T * U2) {
+        int2 r[U2];
 #pragma unroll
-        for (int u = 0; u < U2; ++u) { const int i = f0 + u * PEN_T; const int4 tc_ = tlist[i < NT ? i : 0]; pk[u] = i < NT ? tc_ : make_int4(0, 0, 0, 0); }
+        for (int u = 0; u < U2; ++u) { const int i = i0 + u * PEN_T; r[u] = cand[i < NC ? i : 0]; }
 #pragma unroll
         for (int u = 0; u < U2; ++u) {
-            if (pk[u].x >= 0) continue;
-            const int f = pk[u].z, pf = (pk[u].y >> 9) & 63;
-            const unsigned want32 = s_coll32[pf];
-            pen_for_cells(make_int2(pk[u].x, pk[u].y), [&](int bk, int key, int lowz) {
-                if (!(pmask[bk] & want32)) return;
-                const int q = atomicAdd(&cell_cnt[bk], 1);
-                ent[q] = make_int2(f | (pf << 24) | (lowz << 30), key);     // (triangle | part << 24 | low-corner bit z << 30, cell | low-corner bits x, y << 30): one 8-byte store
-            });
+            const int bk = cell_bucket(r[u].y);
+            if (i0 + u * PEN_T < NC && (pmask[bk] & s_coll32[(r[u].x >> 24) & 63])) ent[atomicAdd(&cell_cnt[bk], 1)] = r[u];      // one 8-byte store
         }
     }
     __threadfence_block();
@@ -1350,7 +1358,9 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     const size_t B = max_batch;
     P.ent_cap = F * 32;
     P.aabb = h->zeros<float>(B * F * 6); P.entries = h->zeros<int2>(B * P.ent_cap);
-    P.tlist = h->zeros<int4>(B * F); P.tcount = h->zeros<int>(B * 16);
+    P.tlist = nullptr; P.tcount = h->zeros<int>(B * 16);
+    P.cand = h->zeros<int2>(B * (size_t)P.ent_cap);
+    if (!P.cand) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     {   // part boxes start EMPTY (k_pen_g3 leaves them empty again after every evaluation)
         std::vector<int> pb(B * 64 * 6);
         for (size_t i = 0; i < pb.size(); ++i) pb[i] = (i % 6) < 3 ? 0x7fffffff : (int)0x80000000;
@@ -1367,7 +1377,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     P.wq = h->zeros<int2>(B * (size_t)P.wq_cap); P.wqn = h->zeros<int>(B);
     if (!P.wq || !P.wqn) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     P.tgrad = h->zeros<float>(B * F * 9); P.tloss = h->zeros<float>(B * F);
-    if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tlist || !P.tcount || !P.pbox || !P.gpart || !P.aabb || !P.entries) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
+    if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tcount || !P.pbox || !P.gpart || !P.aabb || !P.entries) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.pavail || !P.ptotal) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     *out = h;
     return 0;

@@ -36,3 +36,19 @@ __device__ __forceinline__ float wave_max_dpp(float x) {
     x = fmaxf(x, dpp_shift_or_self<0x143, 0xc>(x));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
+
+// inclusive prefix sum over the 64 lanes (integers): Hillis-Steele inside the rows of 16 on DPP shifts, then the row totals
+// travel with row_bcast -- six VALU adds where a __shfl_up ladder costs six LDS-crossbar round trips
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_shift_or_zero_i(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_incl_scan_dpp(int x) {
+    x += dpp_shift_or_zero_i<0x111, 0xf>(x);   // row_shr:1
+    x += dpp_shift_or_zero_i<0x112, 0xf>(x);   // row_shr:2
+    x += dpp_shift_or_zero_i<0x114, 0xf>(x);   // row_shr:4
+    x += dpp_shift_or_zero_i<0x118, 0xf>(x);   // row_shr:8   -> inclusive within each row of 16
+    x += dpp_shift_or_zero_i<0x142, 0xa>(x);   // row_bcast:15 into rows 1, 3
+    x += dpp_shift_or_zero_i<0x143, 0xc>(x);   // row_bcast:31 into rows 2, 3
+    return x;
+}
