@@ -895,7 +895,7 @@ def main():
                     out["roofline"]["mfma_busy_frac"] = k["mfma_busy_frac"]
             out["roofline"]["avg_launch_us_profile"] = profiled_us("k_lbs_dense16")
             # the other half of the step: loss + adjoint + L-BFGS tick + next pose / chain, one workgroup per frame.  Byte model
-            # per frame and launch (tick_bytes_per_frame_launch) from THIS workload's own numbers: the vertex items under the
+            # per launch (tick_bytes: shared once + per frame) from THIS workload's own numbers: the vertex items under the
             # keypoints that are live in a stage (body | + hands | all; fit_single_frame.py:569-572), weighted by the evaluations
             # the run spent in each stage; the live optimiser variables; the VPoser decoder's weights when it is in the loop
             if n_clo:
