@@ -142,6 +142,7 @@ def _fat_report():
             "value_min3_camera_keypoints": 553.36, "min3_camera_keypoints": {"reference_parity": {"final_loss": arr}},
             "alt": {"lbs_mode": "rows", "value": 1394.27, "unit": "frames/s", "note": prose, "paired_vs_dense": {"x": 1}},
             "kernels_ms_avg": {"lbs_dense": 0.058, "tick_dense": 0.0568, "fit_rows": 0.0},
+            "host": {"enqueue_us_per_round": 7.3, "loop_us_per_round": 112.2, "kernels_us_per_round": 115.3, "queue_dry_frac": 0.0, "wait_frac": 0.94},
             "ranks": [{"rank": r, "frames_per_s": 600.0 + r} for r in range(8)], "detail": "gpurun_out/bench_detail_body.json"}
 
 
@@ -165,6 +166,7 @@ def test_bench_line_is_compact_and_strict_json():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in back["cpu_baseline"], k
     assert back["closure_parity"]["grad_rel_err_max"] is None              # inf -> null
+    assert back["host"]["loop_us_per_round"] == 112.2
     for name, obj in back.items():                                          # numbers and short tags only
         if isinstance(obj, dict):
             for k, v in obj.items():

@@ -234,6 +234,8 @@ def test_bench_line_contract(workload):
     r = d["roofline"]
     assert r["kernel"] == "k_lbs_dense16" and r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
     assert np.isfinite(d["config"]["final_loss_mean"])
+    h = d["host"]        # the host thread's side of the loop: enqueue time and the loop's wall time per round next to the kernels'
+    assert 0 < h["enqueue_us_per_round"] < h["loop_us_per_round"] and 0 <= h["queue_dry_frac"] < 1 and h["kernels_us_per_round"] > 0
     if workload == "body":
         rp = d["reference_parity"]
         assert rp["frames"] >= 32 and rp["camera_stage_loss_rel_delta_max"] < 2e-4
