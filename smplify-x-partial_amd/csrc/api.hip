@@ -171,6 +171,10 @@ struct sfx_batch {
     int K = 0;
     sfx_pen* pen = nullptr;       // interpenetration operator (cfg.interpenetration)
     float pen_sigma = 0.f; int pen_outside = 1;
+    // the interpenetration step of a round of the fused loop as ONE captured graph per column count (twelve kernels; the count
+    // only changes when the columns are compacted -- a handful of times per fit): one API call per round instead of twelve
+    std::map<int, hipGraphExec_t> pen_graphs;
+    hipStream_t cap_stream = nullptr;   // capture happens on a stream of its own (the caller's may be the legacy NULL stream, which cannot capture)
     int* pen_stats_all = nullptr; // [B][stride] diagnostics of a CHUNKED evaluation (stand-alone call on a pooled batch), else unused
     bool pen_chunked = false;     // the most recent evaluation was chunked: sfx_batch_pen_stats reads pen_stats_all
 };
@@ -731,6 +735,9 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
 
 extern "C" void sfx_batch_destroy(sfx_batch* b) {
     if (!b) return;
+    for (auto& kv : b->pen_graphs) hipGraphExecDestroy(kv.second);
+    b->pen_graphs.clear();
+    if (b->cap_stream) hipStreamDestroy(b->cap_stream);
     if (b->pen) sfx_pen_destroy(b->pen);
     if (b->D.trace) hipFree(b->D.trace);
     if (b->D.trace_n) hipFree(b->D.trace_n);
@@ -1003,6 +1010,31 @@ static int eval_penetration(sfx_batch* b, int stage_override, hipStream_t s, boo
         b->pen_stats_all = b->mem.zeros<int>((size_t)D.cfg.B * stride);
         if (!b->pen_stats_all) { sfx_set_error("out of device memory"); return -2; }
     }
+    // Fused loop: the step is a captured graph (SFX_PEN_GRAPH=0 switches it off).  The first evaluation of a process runs directly
+    // (one-time attribute calls inside), every new column count is captured once on the loop's own stream.
+    static const bool graph_on = [] { const char* e = getenv("SFX_PEN_GRAPH"); return !e || atoi(e) != 0; }();
+    static bool warmed = false;
+    if (want_ready && graph_on && warmed && !b->pen_chunked) {
+        auto it = b->pen_graphs.find(D.nact);
+        if (it == b->pen_graphs.end()) {
+            hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+            if (!b->cap_stream) SFX_CHECK(hipStreamCreateWithFlags(&b->cap_stream, hipStreamNonBlocking));
+            hipStream_t cs = b->cap_stream;
+            SFX_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+            PenAdjPrep ap{D.AT, M.Wsp_j, M.Wsp_w, M.W, D.adj_G, D.Bpad, M.Vpad};
+            const int rc = sfx_pen_eval_masked(b->pen, D.nact, D.verts, b->pen_sigma, b->pen_outside, D.pen_loss, D.pen_dverts, D.pen_want, &ap, D.pen_over, cs);
+            launch_pen_adjoint(M, D, cs);
+            const hipError_t ec = hipStreamEndCapture(cs, &graph);
+            if (rc || ec != hipSuccess || !graph) { if (graph) hipGraphDestroy(graph); (void)hipGetLastError(); sfx_set_error("capture of the interpenetration step failed"); return rc ? rc : -2; }
+            const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            if (ei != hipSuccess) { sfx_set_error("hipGraphInstantiate failed"); return -2; }
+            it = b->pen_graphs.emplace(D.nact, exec).first;
+        }
+        SFX_CHECK(hipGraphLaunch(it->second, s));
+        return 0;
+    }
+    warmed = true;
     for (int c0 = 0; c0 < D.nact; c0 += cap) {
         const int n = std::min(cap, D.nact - c0);
         // the lane that forms a vertex' gradient also writes d v_posed = T^T g, the adjoint GEMM's operand (column c0 + local index)
