@@ -4,7 +4,7 @@ set -e
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${1:-$HERE/..}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $SFX_DEFINES"   # SFX_DEFINES: diagnostic -D switches (tools/)
 mkdir -p "$HERE/obj"
 pids=()
 $HIPCC $FLAGS -c "$HERE/api.hip" -o "$HERE/obj/api.o" & pids+=($!)

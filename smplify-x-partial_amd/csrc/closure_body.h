@@ -58,7 +58,13 @@ __device__ __forceinline__ void project_residual(const fwd_t* pj, const float* R
 __device__ __forceinline__ void sincos_t(double a, double* s, double* c) { sincos(a, s, c); }
 __device__ __forceinline__ void sincos_t(float a, float* s, float* c) { *s = sinf(a); *c = cosf(a); }
 
-#define CT 256
+// threads per closure workgroup: a property of the LDS variant (FrameLDSx::kThreads) -- 256 for the body-only working set
+// (two or three workgroups share a CU), 512 for the full one (142 KB: the workgroup owns its CU, and what it does there is
+// stream VPoser weights and adjoint rows through that CU's L2 port: 8 wavefronts keep 108 GB/s in flight, 4 keep 93)
+#ifndef SFX_BIG_THREADS
+#define SFX_BIG_THREADS 512
+#endif
+#define SFX_MAX_THREADS 512
 // RIF = 2-KiB blend-shape rows in flight per wavefront (forward dots and dfeat adjoint): 4 for the
 // body-only variant (33 rows: 16 + 16 + 1), SFX_RIF_BIG for the full model (675 rows)
 // debug timing: block 0 / thread 0 stores the shader clock at phase boundaries when D.dbg != NULL
@@ -80,6 +86,7 @@ struct EmptyLDS {};
 // LDS address; sources are per-lane.
 typedef __attribute__((address_space(3))) void* sfx_lds_vp;
 typedef const __attribute__((address_space(1))) void* sfx_glb_vp;
+template <int CT>
 __device__ __forceinline__ void lds_fill_async(void* lds_dst, const void* gsrc, const int n_dwords) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const char* g = reinterpret_cast<const char*>(gsrc);
@@ -94,6 +101,7 @@ __device__ __forceinline__ void lds_fill_async(void* lds_dst, const void* gsrc, 
 // model does not oblige it to (a workgroup-scope release needs lgkmcnt only), so it is spelled out (CK: block_sync_lds_direct_load).
 __device__ __forceinline__ void lds_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0); expcnt / lgkmcnt untouched
 // the same in 16-byte units (both sides 16-byte aligned)
+template <int CT>
 __device__ __forceinline__ void lds_fill_async16(void* lds_dst, const void* gsrc, const int n16) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const char* g = reinterpret_cast<const char*>(gsrc);
@@ -112,7 +120,9 @@ template <int MAXI, bool VP>
 struct __align__(16) FrameLDSx {
     static constexpr int kMaxItems = MAXI;
     static constexpr int kBlocksPerCU = (MAXI <= SFX_SMALL_ITEMS && !VP) ? SFX_SMALL_OCC : 1;    // register budget of the fused kernels
-    static constexpr int kScratch = (MAXI * 12 > 2048) ? MAXI * 12 : 2048;
+    static constexpr int kThreads = (MAXI <= SFX_SMALL_ITEMS && !VP) ? 256 : SFX_BIG_THREADS;
+    // scratch T: the item transforms, and (reverse sweep) one 512-float partial per wavefront
+    static constexpr int kScratch = (MAXI * 12 > (kThreads / 64) * 512) ? MAXI * 12 : (kThreads / 64) * 512;
     float feat[SFX_KD_PAD];        // first: read as float4
     float x[SFX_NPAR_MAX];
     float full_pose[168];
@@ -158,7 +168,7 @@ struct __align__(16) FrameLDSx {
     float dfeat[SFX_KD_PAD];
     float dpose[168];
     float gc[SFX_NPAR_MAX];
-    float red[CT];
+    float red[SFX_MAX_THREADS];
     float lh45[SFX_NHAND], rh45[SFX_NHAND];    // } contiguous: saved / reloaded as one run of 2 * SFX_NHAND + 1 dwords
     int   lut_row;                             // }
     typename std::conditional<VP, VposerLDS, EmptyLDS>::type V;   // VPoser activations (use_vposer only)
@@ -177,6 +187,7 @@ __device__ __forceinline__ float lb_quad(float x) {       // DPP quad permutatio
 
 // fixed-order block reduction: DPP sum per wavefront, then the CT/64 partials in order
 // (2 barriers instead of a 9-barrier LDS tree); result in all threads
+template <int CT>
 __device__ __forceinline__ float block_sum(float v, float* red) {
     const float w = wave_sum_dpp(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
@@ -277,6 +288,7 @@ template <class LDS>
 __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const BatchDev& D,
                                              const VarList* __restrict__ vls, const StageW* __restrict__ sws,
                                              const ClosureArgs& args, const int b, float* gflat, float* fout) {
+    constexpr int CT = LDS::kThreads;
     const int t = threadIdx.x;
     const int lane = t & 63, wv = t >> 6;
     const ParLayout& L = D.L;
@@ -311,33 +323,33 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     float* fwd = D.fwd ? D.fwd + (size_t)b * SFX_FWD_N : nullptr;
     const float* xsrc = (args.from_X ? D.X : D.Xt) + (size_t)b * SFX_NPAR_MAX;
     // every global source of this section goes to LDS asynchronously (lds_fill_async): one round trip for all of it
-    if (!reuse) lds_fill_async(S.x, xsrc, L.npar);
+    if (!reuse) lds_fill_async<CT>(S.x, xsrc, L.npar);
     if (!args.keep_tables) {   // (a persistent workgroup keeps the tables and its frame's data in LDS between evaluations)
     static_assert(SFX_META_N % 4 == 0 && FD_N % 4 == 0 && offsetof(LDS, meta) % 16 == 0 && offsetof(LDS, fd) % 16 == 0, "16-byte copies");
-    lds_fill_async16(S.meta, M.meta, SFX_META_N / 4);
-    lds_fill_async16(S.fd, D.fd + (size_t)b * FD_N, FD_N / 4);     // per-frame record (packed by k_pack_fd)
+    lds_fill_async16<CT>(S.meta, M.meta, SFX_META_N / 4);
+    lds_fill_async16<CT>(S.fd, D.fd + (size_t)b * FD_N, FD_N / 4);     // per-frame record (packed by k_pack_fd)
     // static items (vertex joints, static landmarks): vertex ids, weights, template rows, skinning weights, per-joint
     // adjoint lists -- none of it depends on the pose, so it is fetched here, next to the other tables (a persistent
     // workgroup keeps it for the whole fit), not item by item inside the evaluation
     const int ns = M.n_static_items;
-    lds_fill_async(S.ivid, M.item_vid, ns); lds_fill_async(S.iw, M.item_w, ns); lds_fill_async(S.uslot, M.item_uslot, ns);
-    lds_fill_async(S.vt, M.item_vt, ns * 3);
-    lds_fill_async(S.wj, M.item_wj, ns * SFX_NW); lds_fill_async(S.ww, M.item_ww, ns * SFX_NW);
+    lds_fill_async<CT>(S.ivid, M.item_vid, ns); lds_fill_async<CT>(S.iw, M.item_w, ns); lds_fill_async<CT>(S.uslot, M.item_uslot, ns);
+    lds_fill_async<CT>(S.vt, M.item_vt, ns * 3);
+    lds_fill_async<CT>(S.wj, M.item_wj, ns * SFX_NW); lds_fill_async<CT>(S.ww, M.item_ww, ns * SFX_NW);
     if (M.n_sj <= LDS::kMaxItems * SFX_NW) {
-        lds_fill_async(S.sjs, M.sj_start, SFX_J + 1);
-        lds_fill_async(S.sji, M.sj_item, M.n_sj); lds_fill_async(S.sjw, M.sj_w, M.n_sj);
+        lds_fill_async<CT>(S.sjs, M.sj_start, SFX_J + 1);
+        lds_fill_async<CT>(S.sji, M.sj_item, M.n_sj); lds_fill_async<CT>(S.sjw, M.sj_w, M.n_sj);
     }
     }
     if (reuse) {
         static_assert(offsetof(LDS, lut_row) == offsetof(LDS, lh45) + 2 * SFX_NHAND * sizeof(float), "hand poses + LUT row are one run");
-        lds_fill_async16(&S, fwd, FWD_PREFIX / 4);
+        lds_fill_async16<CT>(&S, fwd, FWD_PREFIX / 4);
         const float* ex = fwd + FWD_PREFIX;
-        lds_fill_async(S.lh45, ex, 2 * SFX_NHAND + 1);
+        lds_fill_async<CT>(S.lh45, ex, 2 * SFX_NHAND + 1);
         if constexpr (HAS_VP) if (C.use_vposer) {
             const float* vx = ex + 96;
             static_assert(offsetof(VposerLDS, h2) == VP_H * sizeof(float) && offsetof(VposerLDS, o) == 2 * VP_H * sizeof(float), "h1 | h2 | o are one run");
-            lds_fill_async16(S.V.h1, vx, (2 * VP_H + 128) / 4);
-            lds_fill_async16(S.V.body, vx + 2 * VP_H + 128, 64 / 4);
+            lds_fill_async16<CT>(S.V.h1, vx, (2 * VP_H + 128) / 4);
+            lds_fill_async16<CT>(S.V.body, vx + 2 * VP_H + 128, 64 / 4);
         }
     }
     for (int i = t; i < SFX_KD_PAD; i += CT) { if (!reuse) S.feat[i] = 0.f; S.dfeat[i] = 0.f; }
@@ -348,7 +360,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     const float* bodypose = S.x + L.emb;
     if constexpr (HAS_VP) {
         if (C.use_vposer && !reuse) {          // body_pose = vposer.decode(pose_embedding) (fitting.py:236-238)
-            vposer_forward<CT>(S.V, M, S.x + L.emb);
+            vposer_forward<CT>(S.V, M, S.x + L.emb, S.T);
             if (t < 63) D.bodypose[(size_t)b * 63 + t] = S.V.body[t];
         }
         if (C.use_vposer) bodypose = S.V.body;
@@ -530,14 +542,14 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     if (dyn_live) {
         const int ns = M.n_static_items, nd = M.n_dyn_items;
         const size_t ro = (size_t)S.lut_row * nd;
-        lds_fill_async(S.ivid + ns, M.dynp_vid + ro, nd); lds_fill_async(S.iw + ns, M.dynp_w + ro, nd);
-        lds_fill_async(S.vt + ns * 3, M.dynp_vt + ro * 3, nd * 3);
-        if (M.dynp_us) lds_fill_async(S.uslot + ns, M.dynp_us + ro, nd);
-        lds_fill_async(S.wj + ns * SFX_NW, M.dynp_wj + ro * SFX_NW, nd * SFX_NW);
-        lds_fill_async(S.ww + ns * SFX_NW, M.dynp_ww + ro * SFX_NW, nd * SFX_NW);
+        lds_fill_async<CT>(S.ivid + ns, M.dynp_vid + ro, nd); lds_fill_async<CT>(S.iw + ns, M.dynp_w + ro, nd);
+        lds_fill_async<CT>(S.vt + ns * 3, M.dynp_vt + ro * 3, nd * 3);
+        if (M.dynp_us) lds_fill_async<CT>(S.uslot + ns, M.dynp_us + ro, nd);
+        lds_fill_async<CT>(S.wj + ns * SFX_NW, M.dynp_wj + ro * SFX_NW, nd * SFX_NW);
+        lds_fill_async<CT>(S.ww + ns * SFX_NW, M.dynp_ww + ro * SFX_NW, nd * SFX_NW);
         if (dyn_lds) {
-            lds_fill_async(S.djs, M.dynp_js + (size_t)S.lut_row * (SFX_J + 1), SFX_J + 1);
-            lds_fill_async(S.dji, M.dynp_ji + ro * SFX_NW, nd * SFX_NW); lds_fill_async(S.djw, M.dynp_jw + ro * SFX_NW, nd * SFX_NW);
+            lds_fill_async<CT>(S.djs, M.dynp_js + (size_t)S.lut_row * (SFX_J + 1), SFX_J + 1);
+            lds_fill_async<CT>(S.dji, M.dynp_ji + ro * SFX_NW, nd * SFX_NW); lds_fill_async<CT>(S.djw, M.dynp_jw + ro * SFX_NW, nd * SFX_NW);
         }
         lds_dma_wait();
         __syncthreads();
@@ -685,7 +697,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     if (cam_stage && C.use_conf_cam) {
         float p = 0.f;
         if (t < K) { const float cm = fd[FD_CMASK + t]; const float cf = fd[FD_CONF + t]; p = (cm != 0.f) ? cf * cf : 0.f; }
-        csum = block_sum(p, S.red);
+        csum = block_sum<CT>(p, S.red);
     }
     enum { Q_L = 0, Q_D0, Q_D1, Q_D2, Q_PP, Q_SH, Q_ANG, Q_LH, Q_RH, Q_EX, Q_JW, NQ };
     float q[NQ];
@@ -932,14 +944,16 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
                 pb.x += db[u].x * dv; pb.y += db[u].y * dv; pb.z += db[u].z * dv; pb.w += db[u].w * dv;
             }
         }
-        float4* part = reinterpret_cast<float4*>(S.T);          // S.T is dead here: 4 x 512 floats of scratch
+        float4* part = reinterpret_cast<float4*>(S.T);          // S.T is dead here: one 512-float partial per wavefront
         part[wv * 128 + lane] = pa; part[wv * 128 + 64 + lane] = pb;
         __syncthreads();
         for (int k = t; k < SFX_KD_PAD; k += CT) {
             const int l4 = (k & 255) >> 2, hi = k >> 8, c = k & 3;
             const float* pf = S.T + (hi * 64 + l4) * 4 + c;
-            const float sum4 = ((pf[0] + pf[512]) + pf[1024]) + pf[1536];
-            S.dfeat[k] = accumulate ? S.dfeat[k] + sum4 : sum4;
+            float sumw = pf[0];
+#pragma unroll
+            for (int w = 1; w < CT / 64; ++w) sumw += pf[w * 512];
+            S.dfeat[k] = accumulate ? S.dfeat[k] + sumw : sumw;
         }
     }
     __syncthreads();

@@ -15,7 +15,7 @@
 #endif
 
 template <class LDS>
-__global__ __launch_bounds__(CT, LDS::kBlocksPerCU)
+__global__ __launch_bounds__(LDS::kThreads, LDS::kBlocksPerCU)
 void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const StageW* __restrict__ sws,
                 int first_stage, int last_stage, int max_ticks) {
     __shared__ LDS S;
@@ -43,7 +43,7 @@ void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const S
 //  CU; OCC = 1 is the same code with the whole register file, launched when every frame has a CU of its own: no spills,
 //  73.8 instead of 76.2 us per launch)
 template <class LDS, int OCC>
-__global__ __launch_bounds__(CT, OCC)
+__global__ __launch_bounds__(LDS::kThreads, OCC)
 void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const StageW* __restrict__ sws,
                   int first_stage, int last_stage, int has_eval) {
     __shared__ LDS S;
@@ -65,7 +65,7 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
         // (one wavefront: sharing the dot products of the two-loop recursion between four was measured slower --
         //  a workgroup barrier per block of 8 history pairs costs more than the reductions it removes)
         if (threadIdx.x < 64)
-            lbfgs_tick_body<(OCC == 1 ? 3 : 2)>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, S.T, &fval, gflat);      // (S.T: >= 2048 floats of closure scratch, dead between evaluations)
+            lbfgs_tick_body<((OCC == 1 && LDS::kThreads <= 256) ? 3 : 2)>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, S.T, &fval, gflat);      // (S.T: >= 2048 floats of closure scratch, dead between evaluations)
         __syncthreads();
         if (D.dbg && threadIdx.x == 0) {       // debug: mean duration of the two segments over all workgroups (100 MHz ticks)
             const long long wc2 = wall_clock64();
@@ -99,9 +99,9 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
 void launch_fit_rows(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
                      int first_stage, int last_stage, int max_ticks, hipStream_t s) {
     if (sfx_small_closure(M, D))
-        hipLaunchKernelGGL(k_fit_rows<FrameLDSSmall>, dim3(D.cfg.B), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, max_ticks);
+        hipLaunchKernelGGL(k_fit_rows<FrameLDSSmall>, dim3(D.cfg.B), dim3(FrameLDSSmall::kThreads), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, max_ticks);
     else
-        hipLaunchKernelGGL(k_fit_rows<FrameLDS>, dim3(D.cfg.B), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, max_ticks);
+        hipLaunchKernelGGL(k_fit_rows<FrameLDS>, dim3(D.cfg.B), dim3(FrameLDS::kThreads), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, max_ticks);
 }
 void launch_tick_dense(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
                        int first_stage, int last_stage, int has_eval, hipStream_t s) {
@@ -110,9 +110,9 @@ void launch_tick_dense(const DevModel& M, const BatchDev& D, const VarList* vl_d
     static const int n_cu = [] { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
     if (sfx_small_closure(M, D)) {
         if (grid <= n_cu)
-            hipLaunchKernelGGL((k_tick_dense<FrameLDSSmall, 1>), dim3(grid), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
+            hipLaunchKernelGGL((k_tick_dense<FrameLDSSmall, 1>), dim3(grid), dim3(FrameLDSSmall::kThreads), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
         else
-            hipLaunchKernelGGL((k_tick_dense<FrameLDSSmall, SFX_TICK_OCC>), dim3(grid), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
+            hipLaunchKernelGGL((k_tick_dense<FrameLDSSmall, SFX_TICK_OCC>), dim3(grid), dim3(FrameLDSSmall::kThreads), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
     } else
-        hipLaunchKernelGGL((k_tick_dense<FrameLDS, 1>), dim3(grid), dim3(CT), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
+        hipLaunchKernelGGL((k_tick_dense<FrameLDS, 1>), dim3(grid), dim3(FrameLDS::kThreads), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
 }

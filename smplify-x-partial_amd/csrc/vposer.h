@@ -129,9 +129,9 @@ __device__ __forceinline__ int vp_gemv_partial(const float* __restrict__ Wt, con
 
 // z[latent] (LDS) -> V.body[63]; all threads of the workgroup
 template <int NT>
-__device__ __forceinline__ void vposer_forward(VposerLDS& V, const DevModel& M, const float* z) {
+__device__ __forceinline__ void vposer_forward(VposerLDS& V, const DevModel& M, const float* z, float* scratch = nullptr) {
     const int t = threadIdx.x, L = M.vp_latent;
-    float* part = V.dh;                         // dh, dg (2 x 512 floats, contiguous) are free during the forward
+    float* part = NT > 256 ? scratch : V.dh;                         // dh, dg (2 x 512 floats, contiguous) are free during the forward
     // (16 weight loads in flight per thread in the forward products: 43 k -> 34 k cycles per decode at 256 frames; the
     //  transposed products, which follow a longer dependent prologue, are fastest with 12 -- 8 / 12 / 16: 51.8 k / 44.8 k /
     //  51.5 k cycles per backward at 256 frames, shader clocks of tools/phase_dense.py)

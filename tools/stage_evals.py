@@ -40,3 +40,8 @@ for r in range(R):
     act += (st < ns).sum()
 print("rounds", R, "mean active frames/round %.1f" % (act / R), "| rounds with >= 1 frame in stage q:", any_in.tolist(),
       "| mean frames in stage q over those rounds:", [round(frames_in[q] / max(any_in[q], 1), 1) for q in range(ns)])
+# how many rounds run with how many frames left (the per-round floors of both kernels are paid by every round)
+tot = cum[:, -1]
+n_act = np.array([(tot > r).sum() for r in range(R)])
+edges = [1, 8, 16, 32, 64, 96, 128, 192, 256, 512, 1024, 1 << 30]
+print("rounds by active frames:", {"%d-%d" % (lo, hi - 1): int(((n_act >= lo) & (n_act < hi)).sum()) for lo, hi in zip(edges[:-1], edges[1:]) if ((n_act >= lo) & (n_act < hi)).any()})
