@@ -143,6 +143,8 @@ typedef struct sfx_batch_cfg {
                                        projection up to the pixel residual is carried in fp64 in every stage -- gradient noise
                                        0.13 x torch fp32's, the fits behave like the reference's float64 run;
                                        parameters, reverse sweep and optimiser stay fp32                          */
+    int32_t point2plane;            /* DistanceFieldPenetrationLoss(point2plane=True) (cmd_parser.py:239): see
+                                       sfx_pen_set_point2plane                                                     */
 } sfx_batch_cfg;
 
 int  sfx_batch_create(sfx_model* m, const sfx_batch_cfg* cfg,
@@ -267,6 +269,10 @@ void sfx_pen_destroy(sfx_pen* h);
  * coll_loss_weight) and d loss / d vertices [B][V][3] (DEVICE).  sigma = df_cone_height.        */
 int  sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
                   float* loss_dev, float* dverts_dev, void* stream);
+/* DistanceFieldPenetrationLoss(point2plane=...) (fit_single_frame.py:311-314, cmd_parser.py:239; every shipped cfg: False).
+ * on: every Psi^2 of a pair (f, g) is weighted by (n_f . n_g)^2 -- the repulsion of a vertex measured along the other
+ * triangle's normal (oracle/penetration.py, assumption A6) -- in all later evaluations of the handle.               */
+int  sfx_pen_set_point2plane(sfx_pen* h, int32_t on);
 /* per frame (HOST [B][4]): ordered pairs kept, partners dropped by max_collisions / the pair list's capacity, grid entries
  * when they overflowed the buffer (0 = fine; then the frame reports no pairs), bucket walks cut short (0 on a sane mesh:
  * an entry looks at most 2048 entries ahead in its bucket; a mesh folded into a few cells by a diverged fit hits that). */

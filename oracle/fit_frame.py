@@ -193,7 +193,7 @@ class FrameFit(object):
         # BVH(max_collisions): a triangle keeps at most max_collisions partners (the lowest ids: oracle/penetration.py)
         opairs, self.pen_cut = P.ordered_pairs_capped(pairs, int(self.cfg.get("max_collisions", 8)))
         return cw * P.penetration_loss_ordered(v, self.pen["faces"], opairs, float(self.cfg.get("df_cone_height", 0.5)),
-                                               bool(self.cfg.get("penalize_outside", True)))
+                                               bool(self.cfg.get("penalize_outside", True)), bool(self.cfg.get("point2plane", False)))
 
     def body_terms(self, stage, w, jw):
         out = self.bm(return_verts=True, body_pose=self._body_pose(), return_full_pose=True)

@@ -5,7 +5,7 @@ PARITY UNPINNED.  The reference delegates this term to the external CUDA package
 `mesh_intersection` (xiyichen/torch-mesh-isect, fork of vchoutas/torch-mesh-isect; absent from
 /root/reference and from this image): `BVH(max_collisions)` -> candidate triangle pairs,
 `FilterFaces(faces_segm, faces_parents, ign_part_pairs)` -> pairs between unrelated body parts,
-`DistanceFieldPenetrationLoss(sigma, point2plane=False, penalize_outside)` -> scalar.  This file
+`DistanceFieldPenetrationLoss(sigma, point2plane, penalize_outside)` -> scalar.  This file
 restates the published algorithm the package implements:
 
   * candidates: pairs of triangles whose axis-aligned bounding boxes overlap and that share no
@@ -46,9 +46,12 @@ order; each names the symbol that would change:
       linear_max x sigma = 0.1 m at the cfgs' sigma 1e-4.
   A5  `penalize_outside=False` keeps the points with x <= 0 only (built); the package may instead keep those inside the
       mesh by a winding test.
-  A6  `point2plane=True` (cmd_parser.py:239; every shipped cfg leaves it False): refused, not restated.  With unit normals
-      Tzionas' point-to-plane form |Psi n|^2 equals Psi^2, so value and gradient would coincide with the built term
-      unless the package differentiates through the normal of the INTRUDING vertex.
+  A6  `point2plane=True` (cmd_parser.py:239, fit_single_frame.py:93,314; every shipped cfg leaves it False).  Tzionas' term
+      is the squared length of the repulsion vector -Psi_f(v) n_g; the point-to-plane form of a registration residual
+      measures a displacement along the OTHER surface's normal, so the built form (`penetration_loss(point2plane=True)`,
+      collide.hip k_pen_eval<true>) is  (n_f . (-Psi_f(v) n_g))^2 = Psi_f(v)^2 (n_f . n_g)^2  with the gradient through
+      Psi AND through both unit normals.  Value and gradient of the default form are untouched.  If the package projects
+      on something else (e.g. the vertex normal of v instead of the face normal of g) only the factor changes.
   A7  SHARED VERTICES: a pair of triangles with a common vertex is never a collision (the package filters such pairs in
       its BVH traversal); triangles that merely touch along an edge of different vertices are.
 """
@@ -127,8 +130,9 @@ def _psi(o, r, n, pts, sigma, penalize_outside):
     return torch.where(live, val, torch.zeros_like(val))
 
 
-def penetration_loss(verts, faces, pairs, sigma, penalize_outside=True):
-    """verts torch [V,3] (requires_grad for the gradient), faces [F,3], pairs [P,2] -> scalar."""
+def penetration_loss(verts, faces, pairs, sigma, penalize_outside=True, point2plane=False):
+    """verts torch [V,3] (requires_grad for the gradient), faces [F,3], pairs [P,2] -> scalar.
+    point2plane: every Psi^2 of a pair weighted by (n_f . n_g)^2 (assumption A6)."""
     if len(pairs) == 0:
         return verts.sum() * 0.0
     faces_t = torch.as_tensor(np.asarray(faces, np.int64))
@@ -136,8 +140,12 @@ def penetration_loss(verts, faces, pairs, sigma, penalize_outside=True):
     A, Bt = tri[torch.as_tensor(pairs[:, 0])], tri[torch.as_tensor(pairs[:, 1])]
     oa, ra, na = _cone_geometry(A)
     ob, rb, nb = _cone_geometry(Bt)
-    return (_psi(oa, ra, na, Bt, sigma, penalize_outside) ** 2).sum() + \
-           (_psi(ob, rb, nb, A, sigma, penalize_outside) ** 2).sum()
+    pa = (_psi(oa, ra, na, Bt, sigma, penalize_outside) ** 2).sum(1)
+    pb = (_psi(ob, rb, nb, A, sigma, penalize_outside) ** 2).sum(1)
+    if point2plane:
+        c = ((na * nb).sum(1)) ** 2
+        return (c * (pa + pb)).sum()
+    return pa.sum() + pb.sum()
 
 
 def ordered_pairs_capped(pairs, max_collisions):
@@ -162,22 +170,27 @@ def ordered_pairs_capped(pairs, max_collisions):
     return both[sym], int((~sym).sum())
 
 
-def penetration_loss_ordered(verts, faces, opairs, sigma, penalize_outside=True):
-    """sum over ordered pairs (f, g) of sum_{v in g} Psi_f(v)^2 (one direction per ordered pair)."""
+def penetration_loss_ordered(verts, faces, opairs, sigma, penalize_outside=True, point2plane=False):
+    """sum over ordered pairs (f, g) of sum_{v in g} Psi_f(v)^2 (one direction per ordered pair); point2plane: each
+    weighted by (n_f . n_g)^2 (assumption A6)."""
     if len(opairs) == 0:
         return verts.sum() * 0.0
     faces_t = torch.as_tensor(np.asarray(faces, np.int64))
     tri = verts[faces_t]
     A, Bt = tri[torch.as_tensor(opairs[:, 0])], tri[torch.as_tensor(opairs[:, 1])]
     oa, ra, na = _cone_geometry(A)
-    return (_psi(oa, ra, na, Bt, sigma, penalize_outside) ** 2).sum()
+    pa = (_psi(oa, ra, na, Bt, sigma, penalize_outside) ** 2).sum(1)
+    if point2plane:
+        _, _, nb = _cone_geometry(Bt)
+        pa = pa * ((na * nb).sum(1)) ** 2
+    return pa.sum()
 
 
 def penetration(verts, faces, segm=None, parents=None, ign_part_pairs=None, sigma=1e-4, penalize_outside=True,
-                dtype=torch.float64):
+                dtype=torch.float64, point2plane=False):
     """Convenience: numpy verts [V,3] -> (loss float, d loss / d verts [V,3], pairs [P,2])."""
     pairs = candidate_pairs(verts, faces, segm, parents, ign_part_pairs)
     v = torch.tensor(np.asarray(verts), dtype=dtype, requires_grad=True)
-    loss = penetration_loss(v, faces, pairs, sigma, penalize_outside)
+    loss = penetration_loss(v, faces, pairs, sigma, penalize_outside, point2plane)
     loss.backward()
     return float(loss.item()), v.grad.numpy().copy(), pairs

@@ -55,6 +55,7 @@ class BatchCfg(C.Structure):
         ("penalize_outside", C.c_int32), ("slots", C.c_int32),
         ("lbfgs_tolerance_grad", C.c_double), ("lbfgs_tolerance_change", C.c_double),
         ("lbfgs_max_eval", C.c_int32), ("lbfgs_history_size", C.c_int32), ("high_precision", C.c_int32),
+        ("point2plane", C.c_int32),
     ]
 
 
@@ -90,6 +91,7 @@ SYMBOLS = {
                                  C.POINTER(C.c_void_p)]),
     "sfx_pen_destroy": (None, [C.c_void_p]),
     "sfx_pen_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sfx_pen_set_point2plane": (C.c_int, [C.c_void_p, C.c_int32]),
     "sfx_pen_stats": (C.c_int, [C.c_void_p, C.c_int32, i32p]),
     "sfx_pen_phase_clocks": (C.c_int, [C.c_void_p, C.c_int32, i32p]),
     "sfx_batch_pen_flags": (C.c_int, [C.c_void_p, i32p]),

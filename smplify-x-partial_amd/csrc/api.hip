@@ -686,6 +686,7 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
                                 (int)(m->ign_host.size() / 2), std::max(1, c->max_collisions), pen_cols, &b->pen);
         if (rc) { b->mem.free_all(); delete b; return rc; }
         b->pen_sigma = c->df_cone_height; b->pen_outside = c->penalize_outside ? 1 : 0;
+        (void)sfx_pen_set_point2plane(b->pen, c->point2plane);
         D.pen_loss = b->mem.zeros<float>(B);
         D.pen_dverts = b->mem.zeros<float>((size_t)B * m->M.V * 3);
         D.ext_n = b->mem.zeros<int>(B);

@@ -71,6 +71,7 @@
 struct PenDev {
     int V, F, cap, n_parts;    // cap = max_collisions: partners KEPT per triangle
     int pcap;                  // partners HELD per triangle while the list is being collected (2 x cap)
+    int p2p;                   // DistanceFieldPenetrationLoss(point2plane=True): Psi^2 weighted by (n_f . n_g)^2
     const int* faces;          // [F][3]
     const int* segm;           // [F]
     const unsigned char* skip; // [n_parts][n_parts] 1 = pair of parts never collides
@@ -1067,6 +1068,11 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
 // Every workgroup forms the exclusive prefix of the meshes' chunk counts (ptotal, a few hundred integers) in LDS; a wavefront
 // takes chunks c = w, w + W, ...; the mesh of a chunk is found by bisection.  A chunk is 64 consecutive pairs of ONE mesh's
 // list, aligned to 64 in that list -- what k_pen_facesum's run sums rely on -- so the numbers are what they were.
+// P2P (DistanceFieldPenetrationLoss(point2plane=True), oracle/penetration.py assumption A6): the repulsion -Psi n of a vertex
+// is measured along the other triangle's normal -- every Psi^2 of the pair is weighted by c = (n_f . n_g)^2, and the gradient
+// gains the path through both unit normals.  A lane (f, g) owns d / d (vertices of f): its own cone's terms (1) and the terms
+// of g's cone at its vertices (2) both depend on n_f through c.
+template <bool P2P>
 __global__ __launch_bounds__(256)
 void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int penalize_outside, int B, int flat) {
     extern __shared__ int s_pref[];             // [B + 1] (flat distribution)
@@ -1118,6 +1124,7 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
         if (sym) {
             const V3 P0 = {p[0], p[1], p[2]}, P1 = {p[3], p[4], p[5]}, P2 = {p[6], p[7], p[8]};
             const V3 Q[3] = {{qv[0], qv[1], qv[2]}, {qv[3], qv[4], qv[5]}, {qv[6], qv[7], qv[8]}};
+            if constexpr (!P2P) {
             {   // (1) this triangle receives the partner's vertices: the loss, and its gradient through the own cone's geometry
                 const ConeGeo g = cone_geometry(P0, P1, P2);
                 V3 go = {0.f, 0.f, 0.f}, gn = {0.f, 0.f, 0.f}; float gr = 0.f;
@@ -1140,6 +1147,32 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
                     (void)cone_penalty(g.o, g.r, g.n, Pk[k], sigma, penalize_outside, gd, gnk, grk);
                     g9[k * 3] += gd.x; g9[k * 3 + 1] += gd.y; g9[k * 3 + 2] += gd.z;
                 }
+            }
+            } else {
+                const ConeGeo gf = cone_geometry(P0, P1, P2), gg = cone_geometry(Q[0], Q[1], Q[2]);
+                const float dt = vdot(gf.n, gg.n), c = dt * dt;
+                // (1) own cone at the partner's vertices: value S1, adjoint with respect to the own (o, r, n)
+                V3 go = {0.f, 0.f, 0.f}, gn = {0.f, 0.f, 0.f}; float gr = 0.f, S1 = 0.f, S2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    V3 gd, gnk; float grk;
+                    S1 += cone_penalty(gf.o, gf.r, gf.n, Q[k], sigma, penalize_outside, gd, gnk, grk);
+                    go = go - gd; gn = gn + gnk; gr += grk;
+                }
+                // (2) the partner's cone at the own vertices: value S2 (owned as a LOSS by the lane (g, f)), d / d v = d / d d
+                const V3 Pk[3] = {P0, P1, P2};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    V3 gd, gnk; float grk;
+                    S2 += cone_penalty(gg.o, gg.r, gg.n, Pk[k], sigma, penalize_outside, gd, gnk, grk);
+                    g9[k * 3] += c * gd.x; g9[k * 3 + 1] += c * gd.y; g9[k * 3 + 2] += c * gd.z;
+                }
+                loss += c * S1;
+                // c = (n_f . n_g)^2 multiplies both sums: d c / d n_f = 2 (n_f . n_g) n_g
+                gn = gn * c + gg.n * ((S1 + S2) * 2.f * dt);
+                V3 g0, g1, g2;
+                cone_geometry_adj(gf, go * c, gr * c, gn, g0, g1, g2);
+                g9[0] += g0.x; g9[1] += g0.y; g9[2] += g0.z; g9[3] += g1.x; g9[4] += g1.y; g9[5] += g1.z; g9[6] += g2.x; g9[7] += g2.y; g9[8] += g2.z;
             }
         }
         // sum over the pairs of one triangle that sit in this wavefront (they are adjacent lanes): segmented
@@ -1385,6 +1418,11 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
 
 int sfx_pen_capacity(const sfx_pen* h) { return h ? h->Bmax : 0; }
 
+extern "C" int sfx_pen_set_point2plane(sfx_pen* h, int32_t on) {
+    if (!h) { sfx_set_error("null handle"); return -1; }
+    h->P.p2p = on ? 1 : 0;
+    return 0;
+}
 extern "C" void sfx_pen_destroy(sfx_pen* h) {
     if (!h) return;
     for (void* p : h->mem) hipFree(p);
@@ -1426,9 +1464,11 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
                        h->P, want_dev, cap_pad);
     static const bool flat_off = getenv("SFX_PEN_FLAT_OFF") != nullptr;      // (A/B measurement switch: same numbers either way)
     if (B <= PEN_FLAT_MAXB && !flat_off)
-        hipLaunchKernelGGL(k_pen_eval, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, verts_dev, sigma, penalize_outside, B, 1);
+        { if (h->P.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, verts_dev, sigma, penalize_outside, B, 1);
+          else hipLaunchKernelGGL(k_pen_eval<false>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, verts_dev, sigma, penalize_outside, B, 1); }
     else
-        hipLaunchKernelGGL(k_pen_eval, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside, B, 0);
+        { if (h->P.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside, B, 0);
+          else hipLaunchKernelGGL(k_pen_eval<false>, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside, B, 0); }
     hipLaunchKernelGGL(k_pen_facesum, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P);
     PenAdjPrep ap{};
     if (prep) ap = *prep;

@@ -230,6 +230,7 @@ class FrameBatch(object):
         c.max_collisions = int(cfg.get("max_collisions", 8))
         c.df_cone_height = float(cfg.get("df_cone_height", 0.5))
         c.penalize_outside = int(bool(cfg.get("penalize_outside", True)))
+        c.point2plane = int(bool(cfg.get("point2plane", False)))
         c.slots = int(slots or 0)
         # LBFGS hyper-parameters (optimizers/lbfgs_ls.py); the cfg files never set them: 0 = the reference's defaults
         # (tolerances: negative = default; an explicit 0 -- LBFGS(tolerance_grad=0): the test is disabled -- is passed through)
@@ -486,9 +487,11 @@ class Penetration(object):
                                             self.max_batch, C.byref(h)))
         self._h = h
 
-    def eval(self, verts, sigma, penalize_outside=True, stream=None):
-        """verts: float32 CUDA tensor [B, V, 3] -> (loss [B], d loss / d verts [B, V, 3]) on the GPU."""
+    def eval(self, verts, sigma, penalize_outside=True, stream=None, point2plane=False):
+        """verts: float32 CUDA tensor [B, V, 3] -> (loss [B], d loss / d verts [B, V, 3]) on the GPU.
+        point2plane: DistanceFieldPenetrationLoss(point2plane=True) (include/sfx.h sfx_pen_set_point2plane)."""
         import torch
+        capi.check(self._lib.sfx_pen_set_point2plane(self._h, int(bool(point2plane))))
         assert verts.is_cuda and verts.dtype == torch.float32 and verts.shape[1:] == (self.V, 3)
         v = verts.contiguous()
         B = v.shape[0]

@@ -56,8 +56,6 @@ def fit_single_frame(img, keypoints, body_model, camera, joint_weights, body_pos
     assert batch_size == 1, "fit_single_frame handles one frame; use driver.fit_frames for batches"
     if visualize:      # (every shipped cfg sets it) rendering is outside the fitting path: the fit runs, nothing is drawn
         warnings.warn("visualize=True: no images are rendered by this engine; the fit itself is unaffected")
-    if interpenetration and point2plane:
-        raise NotImplementedError("point2plane=True: only the cone distance field of the shipped cfgs is built")
     if not use_cuda:
         raise RuntimeError("use_cuda=False: this engine has no CPU path")
     H, W, _ = np.asarray(img).shape
@@ -70,7 +68,7 @@ def fit_single_frame(img, keypoints, body_model, camera, joint_weights, body_pos
                face_joints_weights=face_joints_weights, global_orient_weights=global_orient_weights,
                depth_loss_weight=depth_loss_weight, interpenetration=bool(interpenetration),
                coll_loss_weights=coll_loss_weights, max_collisions=max_collisions, df_cone_height=df_cone_height,
-               penalize_outside=penalize_outside,
+               penalize_outside=penalize_outside, point2plane=bool(point2plane),
                side_view_thsh=side_view_thsh, rho=rho, use_joints_conf=use_joints_conf, format=format,
                left_shoulder_idx=left_shoulder_idx, right_shoulder_idx=right_shoulder_idx, use_vposer=use_vposer)
     if not use_joints_conf:

@@ -208,7 +208,7 @@ class EngineClosure(object):
                 if not self.return_verts:
                     raise ValueError("the interpenetration term reads every vertex: create_fitting_closure(return_verts=True)")
                 pen_cfg = dict(interpenetration=True, max_collisions=st.max_collisions, df_cone_height=pd.sigma,
-                               penalize_outside=pd.penalize_outside)
+                               penalize_outside=pd.penalize_outside, point2plane=bool(getattr(pd, "point2plane", False)))
                 w.coll_loss_weight = float(loss.coll_loss_weight)
                 # the part filter belongs to THIS loss: a loss without a FilterFaces module filters nothing, whatever an earlier
                 # loss on the same model had set (fit_single_frame.py:316-328 builds the module only with a part_segm_fn)

@@ -96,8 +96,6 @@ def main(**args):
         print("CUDA is not available, exiting!")
         sys.exit(-1)
     interpenetration = bool(args.get("interpenetration", True))
-    if interpenetration and args.get("point2plane", False):
-        raise NotImplementedError("point2plane=True: only the cone distance field of the shipped cfgs is built")
     # flags every shipped cfg sets that lie outside the fitting path: they must not stop a run of the unmodified cfg
     if args.get("use_gender_classifier", False):
         # main.py:197-200,258-262: the external homogenus network picks the model's gender per image; without it the

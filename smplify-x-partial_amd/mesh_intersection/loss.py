@@ -6,9 +6,7 @@ import torch.nn as nn
 class DistanceFieldPenetrationLoss(nn.Module):
     def __init__(self, sigma=0.5, point2plane=False, vectorized=True, penalize_outside=True, linear_max=1000):
         super().__init__()
-        if point2plane:
-            raise NotImplementedError("point2plane=True: only the cone distance field of the shipped cfgs is built")
-        self.sigma, self.point2plane, self.vectorized = float(sigma), False, vectorized
+        self.sigma, self.point2plane, self.vectorized = float(sigma), bool(point2plane), vectorized
         self.penalize_outside, self.linear_max = bool(penalize_outside), linear_max
 
     def forward(self, triangles, collision_idxs):

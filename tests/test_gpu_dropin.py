@@ -438,8 +438,9 @@ def test_create_loss_with_interpenetration_objects(synth_model):
     pen_distance = collisions_loss.DistanceFieldPenetrationLoss(sigma=cfg["df_cone_height"], point2plane=False, vectorized=True,
                                                                 penalize_outside=cfg["penalize_outside"])
     filter_faces = FilterFaces(faces_segm=parts["segm"], faces_parents=parts["parents"], ign_part_pairs=cfg["ign_part_pairs"]).to(dev)
-    with pytest.raises(NotImplementedError):
-        collisions_loss.DistanceFieldPenetrationLoss(sigma=0.5, point2plane=True)
+    pen_p2p = collisions_loss.DistanceFieldPenetrationLoss(sigma=cfg["df_cone_height"], point2plane=True, vectorized=True,
+                                                           penalize_outside=cfg["penalize_outside"])
+    assert pen_p2p.point2plane and not pen_distance.point2plane
     mk = lambda t: prior.create_prior(prior_type=t, dtype=torch.float32)
     vals = {}
     for cw in (1.0, 0.0):
@@ -473,11 +474,11 @@ def test_create_loss_with_interpenetration_objects(synth_model):
     fb.close()
     # the part filter belongs to the loss: one built WITHOUT a FilterFaces module after the filtered ones above filters nothing
     # (it used to inherit the previous loss's labels through the shared device model) -- more pairs, a larger term
-    def closure_value(tf):
+    def closure_value(tf, pd=pen_distance):
         loss = fitting.create_loss(loss_type="smplify", joint_weights=joint_weights, rho=cfg["rho"], use_joints_conf=True,
                                    use_face=False, use_hands=False, body_pose_prior=mk("l2"), shape_prior=mk("l2"),
                                    angle_prior=mk("angle"), interpenetration=True, search_tree=search_tree,
-                                   pen_distance=pen_distance, tri_filtering_module=tf, dtype=torch.float32,
+                                   pen_distance=pd, tri_filtering_module=tf, dtype=torch.float32,
                                    regression_pose=torch.tensor(frames["reg_pose"][:1], device=dev), num_stages=3).to(dev)
         w = {"data_weight": 1000.0 / frames["H"], "body_pose_weight": torch.tensor(cfg["body_pose_prior_weights"][2], device=dev),
              "shape_weight": torch.tensor(cfg["shape_weights"][2], device=dev), "coll_loss_weight": torch.tensor(1.0, device=dev)}
@@ -495,3 +496,8 @@ def test_create_loss_with_interpenetration_objects(synth_model):
     assert unfiltered > vals[1.0][0] * (1 + 1e-6), (unfiltered, vals[1.0][0])
     assert closure_value(filter_faces) == vals[1.0][0]              # and back again
     assert closure_value(None) == unfiltered
+    # DistanceFieldPenetrationLoss(point2plane=True) (fit_single_frame.py:93,314) reaches the device: every Psi^2 weighted by
+    # (n_f . n_g)^2 <= 1 -- a smaller term on the same pairs --, and the default form is back afterwards
+    p2p = closure_value(filter_faces, pen_p2p)
+    assert vals[0.0][0] < p2p < vals[1.0][0], (vals[0.0][0], p2p, vals[1.0][0])
+    assert closure_value(filter_faces) == vals[1.0][0]

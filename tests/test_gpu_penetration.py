@@ -69,6 +69,38 @@ def test_two_spheres_loss_and_gradient(sigma, outside):
         assert np.linalg.norm(dv[b] - go) <= 2e-3 * np.linalg.norm(go) + 1e-9, (b, np.linalg.norm(dv[b] - go), np.linalg.norm(go))
 
 
+@pytest.mark.parametrize("sigma,outside", [(0.5, True), (0.5, False), (1e-4, True)])
+def test_point2plane_loss_and_gradient(sigma, outside):
+    """DistanceFieldPenetrationLoss(point2plane=True) (cmd_parser.py:239; oracle/penetration.py assumption A6): every
+    Psi^2 of a pair weighted by (n_f . n_g)^2, gradient through Psi and through both normals -- against fp64 autograd of
+    the oracle; the flag changes the value (it is not the default form rescaled) and switching it off again restores the
+    default form bit for bit."""
+    verts, faces, segm, parents = _two_spheres(0.13)
+    B = 3
+    rng = np.random.RandomState(1)
+    vb = np.stack([verts + 0.004 * rng.normal(size=verts.shape) * (b > 0) + [0.01 * b, 0, 0] for b in range(B)])
+    t = torch.tensor(vb, dtype=torch.float32, device="cuda")
+    pen = engine.Penetration(len(verts), faces, segm, parents, max_collisions=64, max_batch=B)
+    l0, d0 = pen.eval(t, sigma, outside)
+    l0, d0 = l0.cpu().numpy(), d0.cpu().numpy()
+    loss, dv = pen.eval(t, sigma, outside, point2plane=True)
+    st = pen.stats(B)
+    assert np.all(st["dropped"] == 0) and np.all(st["entry_overflow"] == 0)
+    loss, dv = loss.cpu().numpy(), dv.cpu().numpy()
+    for b in range(B):
+        v32 = vb[b].astype(np.float32).astype(np.float64)
+        lo, go, pairs = OP.penetration(v32, faces, segm, parents, None, sigma=sigma, penalize_outside=outside, point2plane=True)
+        assert st["pairs"][b] == 2 * len(pairs) and len(pairs) > 50
+        assert abs(loss[b] - lo) <= 2e-4 * abs(lo) + 1e-9, (b, loss[b], lo)
+        assert np.linalg.norm(dv[b] - go) <= 2e-3 * np.linalg.norm(go) + 1e-9, (b, np.linalg.norm(dv[b] - go), np.linalg.norm(go))
+        assert 0 < loss[b] < 0.98 * l0[b], (loss[b], l0[b])               # (n_f . n_g)^2 < 1 on most pairs of two spheres
+        # not the default gradient rescaled: the normals carry gradient of their own
+        cosang = float((dv[b] * d0[b]).sum() / (np.linalg.norm(dv[b]) * np.linalg.norm(d0[b])))
+        assert cosang < 0.9999, cosang
+    l1, d1 = pen.eval(t, sigma, outside)
+    assert np.array_equal(l1.cpu().numpy(), l0) and np.array_equal(d1.cpu().numpy(), d0)
+
+
 def test_part_filter_and_separated_meshes():
     verts, faces, segm, parents = _two_spheres(0.13)
     t = torch.tensor(verts[None], dtype=torch.float32, device="cuda")
@@ -157,7 +189,8 @@ def test_synthetic_smplx_mesh(synth_model):
     assert float(loss1[0]) == float(loss[1]) and torch.equal(dv1[0], dv[1])
 
 
-def test_closure_with_interpenetration_matches_oracle(synth_model):
+@pytest.mark.parametrize("point2plane", [False, True])
+def test_closure_with_interpenetration_matches_oracle(synth_model, point2plane):
     """cfg_files/fit_smplx_combined_halpe.yaml with its interpenetration term (coll_loss_weights
     [0, 0.1, 1.0], max_collisions 128, ign_part_pairs) inside the fitting closure, dense path:
     total loss and gradient with respect to the 182 optimisation variables vs oracle autograd
@@ -170,6 +203,7 @@ def test_closure_with_interpenetration_matches_oracle(synth_model):
     cfg = H.load_cfg("fit_smplx_combined_halpe.yaml", use_hands=False, use_face=False, interpenetration=True)
     assert cfg["interpenetration"] and cfg["coll_loss_weights"] == [0.0, 0.1, 1.0] and cfg["max_collisions"] == 128
     cfg["df_cone_height"] = 1e-2
+    cfg["point2plane"] = point2plane  # cmd_parser.py:239 (the shipped cfgs: False); True: oracle/penetration.py assumption A6
     cfg["max_collisions"] = 1024      # the synthetic triangle soup: curled fingers give some triangles > 128 partners;
                                       # which partners a cap keeps is implementation defined, so the comparison avoids it
     parts = synthetic.make_synthetic_parts(synth_model)
