@@ -215,9 +215,11 @@ int  sfx_batch_get_grad(sfx_batch* b, int32_t stage, float* grad_out);
  * per active GEMM column: stats as sfx_pen_stats; ext_n = vertices that carried a gradient.    */
 int  sfx_batch_pen_stats(sfx_batch* b, int32_t* stats_host /* [B][4] */, int32_t* ext_n_host /* [B] or NULL */);
 /* Per FRAME, sticky since the start of the last fit / step (HOST [B]): 1 = the frame consumed a collision evaluation in which
- * some triangle met more than 2 x max_collisions partners or a bucket walk was cut short -- there the partners kept depend on
- * arrival order (the package's BVH is traversal-order dependent in the same situation, fitting.py:445-447), so this frame's
- * result is not reproducible run to run.  0 on any sane mesh.                                                              */
+ * a bucket walk was cut short (a mesh folded into a few grid cells) -- pairs beyond the cut are missing and which ones depends
+ * on arrival order (the package's BVH is traversal-order dependent in the same situation, fitting.py:445-447), so this frame's
+ * result is not reproducible run to run.  0 on any sane mesh.  (A triangle with more than 2 x max_collisions partners is no
+ * such case since round 4: its kept partners -- the lowest ids -- are derived from the grid again; max_collisions > 1024: it
+ * still is.)                                                                                                              */
 int  sfx_batch_pen_flags(sfx_batch* b, int32_t* flags_host);
 
 /* Per-frame results of the last sfx_batch_fit (HOST pointers, any may be NULL):
@@ -279,8 +281,8 @@ int  sfx_pen_set_point2plane(sfx_pen* h, int32_t on);
 int  sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host);
 /* Work the term has done since the last reset, counted on the device over every handle of the process (HOST [6]): grid
  * entries, ordered pairs kept, column evaluations (meshes that went through the broad phase), triangles that survived the
- * part culling, triangles that met more partners than the lists hold (2 x max_collisions: the kept ones then depend on
- * arrival order -- 0 on a sane mesh), bucket walks cut short.  The benchmark's byte model of the step (bench.py
+ * part culling, triangles that met more partners than the lists hold while they are collected (2 x max_collisions: their kept
+ * partners are derived from the grid a second time -- 0 on a sane mesh), bucket walks cut short.  The benchmark's byte model of the step (bench.py
  * roofline_pen) divides the first two by the third.                                                                    */
 int  sfx_pen_work_reset(void);
 int  sfx_pen_work_get(int64_t* work_host);

@@ -90,7 +90,7 @@ struct PenDev {
     float* gpart;              // [B][PEN_GW][8] per workgroup of k_pen_g1: frame box lo / hi, extent sum
     int ent_cap;
     int* partners;             // [B][F][pcap]
-    int* pavail;               // [B][F] partners held: min(found, pcap)
+    int* pavail;               // [B][F] partners FOUND (the list holds the first min(found, pcap) arrivals)
     int* pcount;               // [B][F]
     int* poff;                 // [B][F] start of the triangle's partner range in the frame's pair list
     unsigned* hasp;            // [B][hasp_words] bit f: triangle f has pairs in the list (k_pen_list -> k_pen_gather)
@@ -108,6 +108,10 @@ struct PenDev {
     int2* wq;                  // [B][wq_cap] chunks of the pair tests beyond a block's first 64 steps: (first entry of the block, chunk k)
     int* wqn;                  // [B] chunks queued (k_pen_g3 -> 0, k_pen_walk appends, k_pen_walk2 consumes)
     int wq_cap;
+    int* ovq;                  // [B][F] triangles whose partner list overflowed while it was collected (k_pen_list -> k_pen_rank: pen_rewalk)
+    int* ovn;                  // [B][2] their number, and the cursor the wavefronts of k_pen_rank take them with
+    int no_rewalk;             // SFX_PEN_REWALK_OFF=1 (A/B measurement switch): overflowing lists keep their first arrivals, as until round 4
+    int* callno;               // [2] evaluations so far (k_pen_g1), and the last one in which some list overflowed (k_pen_list): k_pen_rank looks for queues only then
     int* over;                 // [B] or NULL (set per call): 1 = this evaluation of the mesh kept partners by ARRIVAL order somewhere (a list beyond
                                //     2 x max_collisions, a cut walk): its numbers are not reproducible run to run
     unsigned long long* work;  // [6] process-wide counts since sfx_pen_work_reset: grid entries, ordered pairs, column evaluations, surviving triangles,
@@ -253,6 +257,7 @@ __device__ __forceinline__ int pen_bucket(int x, int y, int z) {
 
 __global__ __launch_bounds__(PEN_T)
 void k_pen_g1(PenDev P, const float* __restrict__ verts, const int* __restrict__ want) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.callno[0] += 1;      // (one writer per launch; launches of a handle are ordered)
     __shared__ float red[PEN_T / 64];
     __shared__ int pbox[64 * 6];               // this workgroup's part boxes (LDS atomics), merged into the frame's afterwards: atomics
                                                // straight to the frame's 12 cache lines serialise in L2 (measured: 0.4-1.5 ms)
@@ -882,6 +887,11 @@ void k_pen_walk2(PenDev P, int B) {
 }
 
 // offsets of the triangles' partner ranges in the frame's pair list (k_pen_rank fills the list)
+// can a triangle's partners be derived again from the grid by one wavefront (pen_rewalk: an LDS tile of `tcap` ids per wavefront
+// of k_pen_rank, which must hold the cap kept ones and a wavefront's worth of new ones)?  True for max_collisions <= 1024.
+__device__ __host__ __forceinline__ int pen_rank_tile(const int pcap) { int c = 64; while (c < pcap) c <<= 1; return c > 2048 ? 0 : (c < 128 ? 128 : c); }
+__device__ __forceinline__ bool pen_can_rewalk(const PenDev& P) { const int t = pen_rank_tile(P.pcap); return t > 0 && P.cap + 64 <= t && !P.no_rewalk; }
+
 __global__ __launch_bounds__(PEN_T)
 void k_pen_list(PenDev P, const int* __restrict__ want) {
     extern __shared__ int s_cnt[];             // [F] partner counts of the frame, then [hasp_words] bitmask
@@ -913,11 +923,14 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
     // (round 4: every global access of this kernel is coalesced -- the clamped counts are written in the pass that reads the raw
     //  ones, the offsets go to LDS in place and leave in a pass of their own; the per-lane runs of 21 triangles used to write
     //  three arrays at a stride of 84 bytes across the lanes: 63 store instructions of 64 cache lines each, most of the kernel)
+    if (t == 0) { P.ovn[b * 2] = 0; P.ovn[b * 2 + 1] = 0; }
+    __syncthreads();
     for (int f = t; f < F; f += PEN_T) {
         const int raw = pc[f];
         s_cnt[f] = raw;
-        pav[f] = min(raw, P.pcap);
+        pav[f] = raw;                        // (uncapped: > pcap tells k_pen_rank that the held list is incomplete)
         pc[f] = min(raw, P.cap);
+        if (raw > P.pcap) { P.ovq[(size_t)b * F + atomicAdd(&P.ovn[b * 2], 1)] = f; P.callno[1] = P.callno[0]; }      // (rare; the order of the queue is immaterial)
     }
     for (int w = t; w < P.hasp_words; w += PEN_T) s_has[w] = 0u;
     __syncthreads();
@@ -940,7 +953,7 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
         const float to = block_sum_fixed((float)n_over, red);
         const float ta = block_sum_fixed((float)n_arr, red);
         if (t == 0) { const int tot = min(ptot, P.pair_cap); P.ptotal[b] = tot; st[0] = tot; st[1] = (int)to;
-                      if (P.over) P.over[b] = (ta > 0.f || st[13] > 0) ? 1 : 0;
+                      if (P.over) P.over[b] = ((ta > 0.f && !pen_can_rewalk(P)) || st[13] > 0) ? 1 : 0;      // (lists beyond pcap are re-derived by k_pen_rank: pen_rewalk)
                       if (P.work) { atomicAdd(&P.work[1], (unsigned long long)tot);
                                     if (ta > 0.f) atomicAdd(&P.work[4], (unsigned long long)ta);
                                     if (st[13] > 0) atomicAdd(&P.work[5], (unsigned long long)st[13]); } }
@@ -951,14 +964,142 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
     for (int w = t; w < P.hasp_words; w += PEN_T) hasp[w] = s_has[w];
 }
 
+// A triangle that met more partners than its list holds (pcap = 2 x max_collisions; only a mesh pushed through itself has such
+// triangles) kept the first pcap ARRIVALS -- which ones depends on scheduling.  Its kept partners are therefore derived again,
+// by one wavefront, from the grid itself: every entry of every cell the triangle's box touches goes through the tests of the
+// pair walk (same cell, part mask, boxes, ownership of the pair by this cell, no shared vertex), the accepted ids are collected
+// in the wavefront's LDS tile and cut to the `cap` LOWEST whenever the tile fills up.  Result: tile[0 .. n) ascending, n =
+// min(partners, cap) -- the rule of the lists that fit (k_pen_list), now without exception: the pair set no longer depends on
+// arrival order anywhere (a cut bucket walk, reported separately, remains the only approximation).
+__device__ __forceinline__ void pen_tile_sort(int* tile, const int np, const int lane) {      // ascending bitonic sort of tile[0 .. np), np a power of two >= 64
+    for (int k = 2; k <= np; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < np; i += 64) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int va = tile[i], vb = tile[ixj];
+                    if ((va > vb) == ((i & k) == 0)) { tile[i] = vb; tile[ixj] = va; }
+                }
+            }
+        }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+}
+#ifndef PEN_RW
+#define PEN_RW 8
+#endif
+__device__ __forceinline__ int pen_rewalk(const PenDev& P, const int b, const int f, int* tile, const int tcap /* power of two >= cap + 64 */, const int lane) {
+    const float* aabb = P.aabb + (size_t)b * P.F * 6;
+    const int2* ent = P.entries + (size_t)b * P.ent_cap;
+    const int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
+    PenGridCtx C;
+    { const float* gp = P.gridp + b * 4; C.glo[0] = gp[0]; C.glo[1] = gp[1]; C.glo[2] = gp[2]; C.ih = gp[3]; }      // (k_pen_g2 left the frame's grid here)
+    float bx[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) bx[e] = aabb[(size_t)f * 6 + e];
+    const int seg = P.segm[f];
+    const unsigned long long skip_f = P.skipmask[seg];
+    const int4 vf = P.faces4[f];
+    int2 pk;
+    {
+        int c0[3], sp[3];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) { c0[e] = pen_cell_of(C, bx[e], e); sp[e] = min(pen_cell_of(C, bx[3 + e], e), c0[e] + PEN_SPAN - 1) - c0[e]; }
+        pk.x = (c0[0] & 1023) | ((c0[1] & 1023) << 10) | ((c0[2] & 1023) << 20);
+        pk.y = sp[0] | (sp[1] << 3) | (sp[2] << 6);
+    }
+    int n = 0;                                  // ids in the tile (wave-uniform)
+    // The scan is flat over (cell, 64-entry chunk of its bucket) items, PEN_RW of them in flight at a time: a lane looks up one
+    // cell's bucket range (64 cells per step), a prefix scan numbers the chunks, and item t is found by a ballot.  (Cell after
+    // cell it was three dependent memory round trips per cell -- bucket range, entry records, their boxes -- 27 to 512 times.)
+    const int x0 = pk.x & 1023, y0 = (pk.x >> 10) & 1023, z0 = (pk.x >> 20) & 1023;
+    const int ncx = (pk.y & 7) + 1, ncy = ((pk.y >> 3) & 7) + 1, ncz = ((pk.y >> 6) & 7) + 1, ncell = ncx * ncy * ncz;
+    for (int cb = 0; cb < ncell; cb += 64) {
+        const int ci = cb + lane;
+        const bool cv = ci < ncell;
+        const int dx = ci % ncx, dy = (ci / ncx) % ncy, dz = ci / (ncx * ncy);
+        const int cx = (x0 + dx) & 1023, cy = (y0 + dy) & 1023, cz = (z0 + dz) & 1023;
+        const int key_l = cx | (cy << 10) | (cz << 20);
+        const int lowf_l = (int)(dx == 0) | ((int)(dy == 0) << 1) | ((int)(dz == 0) << 2);
+        const int bucket = cv ? pen_bucket(cx, cy, cz) : 0;
+        const int eb_ld = cells[bucket > 0 ? bucket - 1 : 0], ee_ld = cells[bucket];
+        const int eb_l = cv ? (bucket > 0 ? eb_ld : 0) : 0, ee_l = cv ? ee_ld : 0;
+        const int nch_l = (ee_l - eb_l + 63) >> 6;
+        const int incl = wave_incl_scan_dpp(nch_l);
+        const int T = __builtin_amdgcn_readlane(incl, 63);
+        for (int t0 = 0; t0 < T; t0 += PEN_RW) {
+            int keyu[PEN_RW], lowu[PEN_RW]; bool okc[PEN_RW]; int2 rec[PEN_RW];
+#pragma unroll
+            for (int u = 0; u < PEN_RW; ++u) {
+                const int t = min(t0 + u, T - 1);
+                const int l = __ffsll((long long)__ballot(incl > t)) - 1;              // the cell that holds chunk t
+                const int k = t - (__builtin_amdgcn_readlane(incl, l) - __builtin_amdgcn_readlane(nch_l, l));
+                const int eb = __builtin_amdgcn_readlane(eb_l, l) + 64 * k, ee = __builtin_amdgcn_readlane(ee_l, l);
+                keyu[u] = __builtin_amdgcn_readlane(key_l, l); lowu[u] = __builtin_amdgcn_readlane(lowf_l, l);
+                okc[u] = (t0 + u < T) & (eb + lane < ee);
+                rec[u] = ent[eb + lane < ee ? eb + lane : eb];
+            }
+            int hd[PEN_RW][8];
+#pragma unroll
+            for (int c = 0; c < PEN_RW; ++c) {
+                int g_;
+                asm("v_and_b32 %0, 0xffffff, %1" : "=v"(g_) : "v"(rec[c].x));      // (see pen_load_hdr: the mask must not be folded into the address arithmetic)
+                const int2* bp = reinterpret_cast<const int2*>(aabb) + (size_t)g_ * 3;
+                const int2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
+                hd[c][0] = rec[c].x; hd[c][1] = rec[c].y;
+                hd[c][2] = b0.x; hd[c][3] = b0.y; hd[c][4] = b1.x; hd[c][5] = b1.y; hd[c][6] = b2.x; hd[c][7] = b2.y;
+            }
+            bool pass[PEN_RW]; int gid[PEN_RW];
+#pragma unroll
+            for (int c = 0; c < PEN_RW; ++c) {
+                const int g = hd[c][0] & 0xffffff;
+                const bool same = ((hd[c][1] ^ keyu[c]) & 0x3fffffff) == 0;
+                const bool coll = ((unsigned)(skip_f >> ((hd[c][0] >> 24) & 63)) & 1u) == 0u;
+                const float kl0 = __int_as_float(hd[c][2]), kl1 = __int_as_float(hd[c][3]), kl2 = __int_as_float(hd[c][4]);
+                const float kh0 = __int_as_float(hd[c][5]), kh1 = __int_as_float(hd[c][6]), kh2 = __int_as_float(hd[c][7]);
+                const bool box = (bx[0] <= kh0) & (kl0 <= bx[3]) & (bx[1] <= kh1) & (kl1 <= bx[4]) & (bx[2] <= kh2) & (kl2 <= bx[5]);
+                const unsigned klow = ((unsigned)hd[c][1] >> 30) | (((unsigned)hd[c][0] >> 28) & 4u);
+                const bool own = (((unsigned)lowu[c] | klow) & 7u) == 7u;      // on every axis one of the two boxes has its low corner in this cell
+                pass[c] = okc[c] & same & coll & box & own & (g != f);
+                gid[c] = g;
+            }
+#pragma unroll
+            for (int c = 0; c < PEN_RW; ++c) {
+                if (!__ballot(pass[c])) continue;
+                const int4 vg = P.faces4[pass[c] ? gid[c] : f];
+                const bool shared = vf.x == vg.x || vf.x == vg.y || vf.x == vg.z || vf.y == vg.x || vf.y == vg.y || vf.y == vg.z ||
+                                    vf.z == vg.x || vf.z == vg.y || vf.z == vg.z;
+                const bool keepit = pass[c] & !shared;
+                const unsigned long long m = __ballot(keepit);
+                if (!m) continue;
+                const int add = __popcll(m);
+                if (n + add > tcap) {                // cut to the cap lowest ids, then go on collecting
+                    for (int q = n + lane; q < tcap; q += 64) tile[q] = 0x7fffffff;
+                    pen_tile_sort(tile, tcap, lane);
+                    n = min(n, P.cap);
+                }
+                if (keepit) tile[n + __popcll(m & ((1ull << lane) - 1ull))] = gid[c];
+                n += add;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    for (int q = n + lane; q < tcap; q += 64) tile[q] = 0x7fffffff;
+    pen_tile_sort(tile, tcap, lane);
+    return min(n, P.cap);
+}
+
 // ranks every triangle's partner list into the frame's pair list; PEN_RANK_BLOCKS workgroups per frame
 #ifndef PEN_RANK_BLOCKS
 #define PEN_RANK_BLOCKS 64
 #endif
+#ifndef PEN_RANK_HELPERS
+#define PEN_RANK_HELPERS 8
+#endif
 #define PEN_SHORT 16            // lists up to this length are ranked element-wise, longer ones sorted by a wavefront
 __global__ __launch_bounds__(256)
 void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
-    extern __shared__ int s_sort[];             // [4][max(cap_pad, 64)]
+    extern __shared__ int s_sort[];             // [4][max(cap_pad, 128)]
     const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     if ((want && !want[b]) || P.ptotal[b] == 0) return;
     const int F = P.F;
@@ -968,16 +1109,20 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
     const int* pav = P.pavail + (size_t)b * F;
     int* pown = P.pown + (size_t)b * P.pair_cap;
     int* plist = P.plist + (size_t)b * P.pair_cap;
-    int* tile = s_sort + wv * min(max(cap_pad, 64), 2048);
+    const int tcap = min(max(cap_pad, 128), 2048);
+    int* tile = s_sort + wv * tcap;
     const bool can_sort = cap_pad <= 2048;
     // 64 consecutive triangles at a time per wavefront.  Short lists: their elements are dealt to the
     // lanes (owner found by bisection of the 64 offsets in LDS), each lane ranks its element within its
     // list.  Long lists: bitonic sort by the whole wavefront in LDS.
-    const int nw = gridDim.x * 4, gw = blockIdx.x * 4 + wv;
+    // (the last PEN_RANK_HELPERS workgroups of a mesh rank nothing: they start on the queue of overflowed lists at once, next to
+    //  the ranking instead of behind it -- a triangle's second look at the grid takes one wavefront ~25 us)
+    const bool helper = blockIdx.x >= PEN_RANK_BLOCKS;
+    const int nw = PEN_RANK_BLOCKS * 4, gw = blockIdx.x * 4 + wv;
     // (blocks of 64 triangles dealt round-robin to the frame's wavefronts: crowded triangles are neighbours in the index too,
     //  a contiguous range per wavefront gave one wavefront all the long lists)
     const int flim = F;
-    for (int fw = gw * 64; fw < flim; fw += nw * 64) {
+    for (int fw = helper ? flim : gw * 64; fw < flim; fw += nw * 64) {
         const int f = fw + lane;
         const bool inr = f < flim;
         const int fs = inr ? f : 0;                    // (unconditional loads from a clamped index: three loads in flight, not three round trips)
@@ -1011,7 +1156,9 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
             m &= m - 1;
             const int ff = fw + bit;
             const int cc = __builtin_amdgcn_readlane(c_l, bit), off = __builtin_amdgcn_readlane(off_l, bit);
-            const int av = __builtin_amdgcn_readlane(a_l, bit);       // sort all av held partners, keep the cc lowest
+            const int found = __builtin_amdgcn_readlane(a_l, bit);
+            if (found > P.pcap && pen_can_rewalk(P)) continue;         // incomplete list: queued by k_pen_list, taken below
+            const int av = min(found, P.pcap);                         // sort all av held partners, keep the cc lowest
             const int* mine = part + (size_t)ff * P.pcap;
             int np = 64;
             while (np < av) np <<= 1;
@@ -1054,6 +1201,44 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
             for (int q = lane; q < keep; q += 64) { plist[off + q] = tile[q]; pown[off + q] = ff; }
             __builtin_amdgcn_wave_barrier();
         }
+    }
+    // Triangles whose list overflowed while it was collected: one shared queue per mesh (k_pen_list), taken one triangle at a time
+    // through an atomic cursor by whichever wavefront is free -- first the mesh's own, then those of the other meshes of the call
+    // (such triangles come in crowds, in one or two meshes of a call: their own 256 wavefronts would be the launch's long pole).
+    // Who derives a triangle's partners has no influence on what they are.
+    if (!pen_can_rewalk(P) || P.callno[1] != P.callno[0]) return;      // (no list of this evaluation overflowed: nothing queued anywhere)
+    const int nB = gridDim.y;
+    // (which meshes have a queue at all: looked up by the lanes in parallel, 64 meshes per step -- one mesh after the other the
+    //  scan itself was a chain of dependent loads as long as the call has meshes)
+    for (int g0 = 0; g0 < nB; g0 += 64) {
+      const int bl = g0 + lane;
+      const int bq = bl < nB ? (b + bl < nB ? b + bl : b + bl - nB) : 0;           // the own mesh first
+      const int nql = P.ovn[bq * 2], ptl = P.ptotal[bq], wl = want ? want[bq] : 1;
+      unsigned long long todo = __ballot(bl < nB && wl && nql > 0 && ptl > 0 && P.ovn[bq * 2 + 1] < nql);
+      while (todo) {
+        const int bit = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int bb = __builtin_amdgcn_readlane(bq, bit);
+        const int nq = __builtin_amdgcn_readlane(nql, bit);
+        const int* pcb = P.pcount + (size_t)bb * F;
+        const int* poffb = P.poff + (size_t)bb * F;
+        int* pownb = P.pown + (size_t)bb * P.pair_cap;
+        int* plistb = P.plist + (size_t)bb * P.pair_cap;
+        for (;;) {
+            int idx = 0;
+            if (lane == 0) idx = atomicAdd(&P.ovn[bb * 2 + 1], 1);
+            idx = __builtin_amdgcn_readfirstlane(idx);
+            if (idx >= nq) break;
+            const int ff = P.ovq[(size_t)bb * F + idx];
+            const int cc = pcb[ff], off = poffb[ff];
+            if (off >= P.pair_cap) continue;
+            __builtin_amdgcn_wave_barrier();
+            const int got = pen_rewalk(P, bb, ff, tile, tcap, lane);
+            const int keep = min(min(cc, got), P.pair_cap - off);
+            for (int q = lane; q < keep; q += 64) { plistb[off + q] = tile[q]; pownb[off + q] = ff; }
+            __builtin_amdgcn_wave_barrier();
+        }
+      }
     }
 }
 
@@ -1401,6 +1586,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     }
     P.gpart = h->zeros<float>(B * PEN_GW * 8);
     P.partners = h->zeros<int>(B * F * P.pcap); P.pcount = h->zeros<int>(B * F); P.pavail = h->zeros<int>(B * F);
+    P.ovq = h->zeros<int>(B * F); P.ovn = h->zeros<int>(B * 2); P.callno = h->zeros<int>(2);
     P.pair_cap = (int)std::min<size_t>((size_t)F * P.cap, std::max<size_t>(65536, (size_t)16 * F));
     P.hasp_words = (F + 31) / 32; P.hasp = h->zeros<unsigned>(B * P.hasp_words);
     P.poff = h->zeros<int>(B * F); P.pown = h->zeros<int>(B * P.pair_cap); P.plist = h->zeros<int>(B * P.pair_cap);
@@ -1411,7 +1597,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     if (!P.wq || !P.wqn) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     P.tgrad = h->zeros<float>(B * F * 9); P.tloss = h->zeros<float>(B * F);
     if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tcount || !P.pbox || !P.gpart || !P.aabb || !P.entries) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
-    if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.pavail || !P.ptotal) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
+    if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.pavail || !P.ptotal || !P.ovq || !P.ovn || !P.callno) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     *out = h;
     return 0;
 }
@@ -1455,12 +1641,14 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
         hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, Pw, want_dev);
         if (queued) hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, Pw, B);
     }
+    static const bool rewalk_off = [] { const char* e = getenv("SFX_PEN_REWALK_OFF"); return e && atoi(e) != 0; }();      // (A/B measurement switch)
+    h->P.no_rewalk = rewalk_off ? 1 : 0;
     PenDev Pl = h->P;
     Pl.over = over_dev;         // (per call: the caller's per-mesh "arrival order decided" flags, or NULL)
     hipLaunchKernelGGL(k_pen_list, dim3(B), dim3(PEN_T), (size_t)(h->P.F + h->P.hasp_words) * sizeof(int), s, Pl, want_dev);
     int cap_pad = 64;
     while (cap_pad < h->P.pcap) cap_pad <<= 1;
-    hipLaunchKernelGGL(k_pen_rank, dim3(PEN_RANK_BLOCKS, B), dim3(256), (size_t)4 * std::min(std::max(cap_pad, 64), 2048) * sizeof(int), s,
+    hipLaunchKernelGGL(k_pen_rank, dim3(PEN_RANK_BLOCKS + (pen_rank_tile(h->P.pcap) > 0 && h->P.cap + 64 <= pen_rank_tile(h->P.pcap) ? PEN_RANK_HELPERS : 0), B), dim3(256), (size_t)4 * std::min(std::max(cap_pad, 128), 2048) * sizeof(int), s,
                        h->P, want_dev, cap_pad);
     static const bool flat_off = getenv("SFX_PEN_FLAT_OFF") != nullptr;      // (A/B measurement switch: same numbers either way)
     if (B <= PEN_FLAT_MAXB && !flat_off)

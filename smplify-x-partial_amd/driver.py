@@ -177,11 +177,13 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
     if pen_on:      # diagnostics of the interpenetration term over this fit (device counters, engine.pen_work_get; per-frame flags)
         w1 = engine.pen_work_get()
         cut, over = w1["walks_cut"] - work0["walks_cut"], w1["lists_overflowed"] - work0["lists_overflowed"]
-        if cut or over:
+        bad = np.flatnonzero(res["pen_order_dependent"])
+        # (triangles that met more than 2 x max_collisions partners -- `over` of them -- are not a reason to warn any more: their
+        #  kept partners are derived from the grid again, the lowest ids like everywhere else; csrc/collide.hip pen_rewalk)
+        if cut or len(bad):
             import warnings
-            bad = np.flatnonzero(res["pen_order_dependent"])
-            warnings.warn("interpenetration term: %d bucket walks were cut short and %d triangles met more than 2 x max_collisions "
-                          "partners during this fit (a mesh folded into a few grid cells by a trial step): the term is "
-                          "underestimated there and the partners kept depend on arrival order -- frames %s are not reproducible "
-                          "run to run (result key 'pen_order_dependent')" % (cut, over, bad.tolist()[:32]), RuntimeWarning)
+            warnings.warn("interpenetration term: %d bucket walks were cut short during this fit (a mesh folded into a few grid "
+                          "cells by a trial step; %d triangles met more than 2 x max_collisions partners): pairs beyond the cut "
+                          "are missing and which ones depends on arrival order -- frames %s are not reproducible run to run "
+                          "(result key 'pen_order_dependent')" % (cut, over, bad.tolist()[:32]), RuntimeWarning)
     return res

@@ -356,8 +356,9 @@ class FrameBatch(object):
         return dict(pairs=st[:, 0].copy(), dropped=st[:, 1].copy(), entry_overflow=st[:, 2].copy(), walks_cut=st[:, 3].copy(), vertices=ext)
 
     def penetration_flags(self):
-        """Per frame: True when the frame's fit consumed a collision evaluation whose kept partners depended on arrival order
-        (a partner list beyond 2 x max_collisions, a cut bucket walk): its result is not reproducible run to run."""
+        """Per frame: True when the frame's fit consumed a collision evaluation whose pair set depended on arrival order
+        (a cut bucket walk; with max_collisions > 1024 also a partner list beyond 2 x max_collisions): its result is not
+        reproducible run to run."""
         fl = np.zeros(self.B, np.int32)
         capi.check(self._lib.sfx_batch_pen_flags(self._h, capi.iptr(fl)))
         return fl != 0
@@ -458,7 +459,7 @@ def pen_work_get():
     capi.check(capi.load().sfx_pen_work_get(w))
     cols = max(int(w[2]), 1)
     return dict(entries=int(w[0]), pairs=int(w[1]), columns=int(w[2]), survivors=int(w[3]),
-                lists_overflowed=int(w[4]), walks_cut=int(w[5]),     # > 0: some kept partner sets depended on arrival order
+                lists_overflowed=int(w[4]), walks_cut=int(w[5]),     # lists re-derived from the grid (exact); walks cut (> 0: pairs missing, order dependent)
                 entries_per_column=w[0] / cols, pairs_per_column=w[1] / cols, survivors_per_column=w[3] / cols)
 
 

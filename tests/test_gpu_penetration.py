@@ -158,6 +158,40 @@ def test_max_collisions_cap_keeps_the_lowest_ids():
         assert np.linalg.norm(res[0][1] - go) <= 2e-3 * np.linalg.norm(go), (sigma, np.linalg.norm(res[0][1] - go), np.linalg.norm(go))
 
 
+def test_lists_beyond_twice_the_cap_are_derived_from_the_grid_again():
+    """A triangle with MORE than 2 x max_collisions partners (its list holds only the first 2 x cap arrivals) gets its kept
+    partners from a second look at the grid (collide.hip pen_rewalk): the cap lowest ids, like every other triangle -- pairs,
+    cut partners, loss and gradient against the oracle's statement of the rule, identical from run to run and whatever else
+    is in the batch, and nothing is reported as order dependent."""
+    verts, faces, segm, parents = _two_spheres(0.13)
+    v32 = verts.astype(np.float32)
+    pairs = OP.candidate_pairs(v32.astype(np.float64), faces, segm, parents)
+    cnt = np.bincount(pairs.reshape(-1), minlength=len(faces))
+    cap = max(2, int(cnt.max()) // 5)
+    assert (cnt > 2 * cap).sum() >= 10, (cnt.max(), cap)          # many lists overflow what is held while they are collected
+    opairs, n_cut = OP.ordered_pairs_capped(pairs, cap)
+    assert n_cut > 0
+    for sigma in (1e-4, 0.5):
+        vt = torch.tensor(v32.astype(np.float64), dtype=torch.float64, requires_grad=True)
+        lo = OP.penetration_loss_ordered(vt, faces, opairs, sigma)
+        lo.backward()
+        go = vt.grad.numpy()
+        pen = engine.Penetration(len(verts), faces, segm, parents, max_collisions=cap, max_batch=3)
+        rng = np.random.RandomState(5)
+        others = np.stack([v32 + 0.003 * rng.normal(size=v32.shape).astype(np.float32) for _ in range(2)])
+        res = []
+        for batch in (v32[None], np.concatenate([others[:1], v32[None], others[1:]]), v32[None]):
+            loss, dv = pen.eval(torch.tensor(batch, device="cuda"), sigma)
+            i = 0 if batch.shape[0] == 1 else 1
+            st = pen.stats(batch.shape[0])
+            assert st["pairs"][i] == len(opairs) and st["dropped"][i] == n_cut, (st, len(opairs), n_cut)
+            res.append((float(loss[i]), dv[i].cpu().numpy()))
+        for r in res[1:]:
+            assert res[0][0] == r[0] and np.array_equal(res[0][1], r[1])               # batch composition, run to run
+        assert abs(res[0][0] - float(lo)) <= 2e-4 * abs(float(lo)), (sigma, res[0][0], float(lo))
+        assert np.linalg.norm(res[0][1] - go) <= 2e-3 * np.linalg.norm(go), (sigma, np.linalg.norm(res[0][1] - go), np.linalg.norm(go))
+
+
 def test_max_collisions_cap_is_reported():
     verts, faces, segm, parents = _two_spheres(0.13)
     pen = engine.Penetration(len(verts), faces, segm, parents, max_collisions=2, max_batch=1)
@@ -491,7 +525,7 @@ def test_pooled_batch_with_interpenetration():
     keys = ("stage_loss", "pose_embedding", "betas", "cam_translation", "global_orient", "stage_evals")
     same = lambda a, b_: np.array([all(np.array_equal(a[k][i], b_[k][i], equal_nan=True) for k in keys) for i in range(B)])
     clean = ~(res_all["pen_order_dependent"] | res_pool["pen_order_dependent"] | res_again["pen_order_dependent"])
-    assert clean.sum() >= B - 6, np.flatnonzero(~clean)
+    assert clean.all(), np.flatnonzero(~clean)            # (round 4: overflowing partner lists are derived from the grid again; only a cut bucket walk is flagged)
     assert same(res_again, res_all)[clean].all(), np.flatnonzero(~same(res_again, res_all) & clean)
     assert same(res_pool, res_all)[clean].all(), np.flatnonzero(~same(res_pool, res_all) & clean)
     assert np.all(res_all["stage_evals"][:, 2:] > 0)
