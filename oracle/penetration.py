@@ -31,7 +31,8 @@ package room.  Whoever obtains the package source, or its outputs on a known mes
 order; each names the symbol that would change:
   A1  CANDIDATES = all AABB-overlapping pairs without a shared vertex.  The package's BVH returns at most max_collisions
       hits per query triangle IN TRAVERSAL ORDER; when that cap binds, which partners survive is implementation-defined
-      there.  Here (`ordered_pairs_capped`, collide.hip k_pen_list): the max_collisions LOWEST triangle ids of each
+      there.  Here (`ordered_pairs_capped`, collide.hip k_pen_list / k_pen_rank, without exception since round 4: a list that
+      overflows while it is collected is derived from the grid again): the max_collisions LOWEST triangle ids of each
       triangle's partner list, and a pair counts only if both triangles kept each other.  Differs from the package
       exactly when some triangle has more than max_collisions partners (never on the cfgs' 128 with a sane body mesh).
   A2  PAIR ORDER / MULTIPLICITY: each unordered pair once, both directions of the penalty summed (receiver f / intruder g
