@@ -218,8 +218,8 @@ int  sfx_batch_pen_stats(sfx_batch* b, int32_t* stats_host /* [B][4] */, int32_t
  * a bucket walk was cut short (a mesh folded into a few grid cells) -- pairs beyond the cut are missing and which ones depends
  * on arrival order (the package's BVH is traversal-order dependent in the same situation, fitting.py:445-447), so this frame's
  * result is not reproducible run to run.  0 on any sane mesh.  (A triangle with more than 2 x max_collisions partners is no
- * such case since round 4: its kept partners -- the lowest ids -- are derived from the grid again; max_collisions > 1024: it
- * still is.)                                                                                                              */
+ * such case since round 4: its kept partners -- the lowest ids -- are derived from the grid again; with max_collisions > 1024,
+ * or in a mesh with more than 4096 such triangles -- one that has collapsed onto itself -- it still is.)                                                                                                              */
 int  sfx_batch_pen_flags(sfx_batch* b, int32_t* flags_host);
 
 /* Per-frame results of the last sfx_batch_fit (HOST pointers, any may be NULL):

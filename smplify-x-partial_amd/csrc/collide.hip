@@ -65,6 +65,9 @@
 #ifndef PEN_EVAL_BLOCKS
 #define PEN_EVAL_BLOCKS 128     // workgroups per frame of the pair evaluation (grid-stride over the pair list)
 #endif
+#ifndef PEN_REWALK_MAX
+#define PEN_REWALK_MAX 4096   // overflowed lists per mesh and evaluation that are derived from the grid again (more: the mesh has collapsed)
+#endif
 #define PEN_CELLS 16384         // hash buckets of the grid: one 64-KB LDS array serves as histogram, start offsets and
                                 // scatter cursors (+ 48 KB of wavefront tiles, 16 KB of pair queues)
 
@@ -953,7 +956,12 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
         const float to = block_sum_fixed((float)n_over, red);
         const float ta = block_sum_fixed((float)n_arr, red);
         if (t == 0) { const int tot = min(ptot, P.pair_cap); P.ptotal[b] = tot; st[0] = tot; st[1] = (int)to;
-                      if (P.over) P.over[b] = ((ta > 0.f && !pen_can_rewalk(P)) || st[13] > 0) ? 1 : 0;      // (lists beyond pcap are re-derived by k_pen_rank: pen_rewalk)
+                      // a mesh with thousands of such triangles has collapsed onto itself (a diverged fit on its way to NaN): looking at
+                      // each of them again would cost milliseconds per evaluation for a term that means nothing there -- such a mesh
+                      // keeps its first arrivals, as every overflowing list did until round 4, and is reported as order dependent
+                      const bool rewalk = pen_can_rewalk(P) && ta <= (float)PEN_REWALK_MAX;
+                      if (!rewalk) P.ovn[b * 2] = 0;
+                      if (P.over) P.over[b] = ((ta > 0.f && !rewalk) || st[13] > 0) ? 1 : 0;      // (lists beyond pcap are re-derived by k_pen_rank: pen_rewalk)
                       if (P.work) { atomicAdd(&P.work[1], (unsigned long long)tot);
                                     if (ta > 0.f) atomicAdd(&P.work[4], (unsigned long long)ta);
                                     if (st[13] > 0) atomicAdd(&P.work[5], (unsigned long long)st[13]); } }
@@ -1111,6 +1119,7 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
     int* plist = P.plist + (size_t)b * P.pair_cap;
     const int tcap = min(max(cap_pad, 128), 2048);
     int* tile = s_sort + wv * tcap;
+    const bool rewalk_b = pen_can_rewalk(P) && P.ovn[b * 2] > 0;      // (k_pen_list empties the queue of a mesh it will not have looked at again)
     const bool can_sort = cap_pad <= 2048;
     // 64 consecutive triangles at a time per wavefront.  Short lists: their elements are dealt to the
     // lanes (owner found by bisection of the 64 offsets in LDS), each lane ranks its element within its
@@ -1157,7 +1166,7 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
             const int ff = fw + bit;
             const int cc = __builtin_amdgcn_readlane(c_l, bit), off = __builtin_amdgcn_readlane(off_l, bit);
             const int found = __builtin_amdgcn_readlane(a_l, bit);
-            if (found > P.pcap && pen_can_rewalk(P)) continue;         // incomplete list: queued by k_pen_list, taken below
+            if (found > P.pcap && rewalk_b) continue;                  // incomplete list: queued by k_pen_list, taken below
             const int av = min(found, P.pcap);                         // sort all av held partners, keep the cc lowest
             const int* mine = part + (size_t)ff * P.pcap;
             int np = 64;
