@@ -117,7 +117,7 @@ def compact_line(full):
     if isinstance(full.get("alt"), dict):
         line["alt"] = _pick(full["alt"], ("lbs_mode", "value", "unit", "ms_per_step", "closure_evals_per_frame_mean", "final_loss_median"))
     if isinstance(full.get("host"), dict):
-        line["host"] = _pick(full["host"], ("enqueue_us_per_round", "loop_us_per_round", "kernels_us_per_round", "queue_dry_frac", "wait_frac"), sig=4)
+        line["host"] = _pick(full["host"], ("enqueue_us_per_round", "loop_us_per_round", "kernels_us_per_round", "queue_dry_frac", "wait_frac", "outside_loop_ms_per_step"), sig=4)
     if "kernels_ms_avg" in full:
         line["kernels_ms_avg"] = _pick(full["kernels_ms_avg"], ("lbs_dense", "tick_dense", "fit_rows", "penetration"))
     if "detail" in full:
@@ -815,7 +815,11 @@ def main():
             k_us = 1e3 * (ms_dense / max(n_dense, 1) + ms_clo / max(n_clo, 1) + prof["penetration"][0] / max(prof["penetration"][1], 1))
             out["host"] = {"enqueue_us_per_round": 1e6 * host["enqueue_s"] / host["rounds"], "wait_frac": host["wait_s"] / max(host["wall_s"], 1e-12),
                            "loop_us_per_round": 1e6 * host["wall_s"] / host["rounds"], "kernels_us_per_round": k_us,
-                           "queue_dry_frac": max(0.0, 1.0 - k_us * host["rounds"] / max(1e6 * host["wall_s"], 1e-12))}
+                           "queue_dry_frac": max(0.0, 1.0 - k_us * host["rounds"] / max(1e6 * host["wall_s"], 1e-12)),
+                           # what a step spends OUTSIDE the fitting loop (batch set-up on the host, result collection, the gather):
+                           # ~15 ms on an idle host; hundreds of ms on a box whose host cores are taken -- the frames/s of such a run
+                           # say nothing about the kernels (halpe workload, round 4: 272 and 362 against 467-487 frames/s)
+                           "outside_loop_ms_per_step": 1e3 * (dt_rank - host["wall_s"]) / args.steps}
         if side_min3 is not None:
             out["value_min3_camera_keypoints"] = side_min3["value"]
             out["min3_camera_keypoints"] = side_min3

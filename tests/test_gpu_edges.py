@@ -236,6 +236,7 @@ def test_bench_line_contract(workload):
     assert np.isfinite(d["config"]["final_loss_mean"])
     h = d["host"]        # the host thread's side of the loop: enqueue time and the loop's wall time per round next to the kernels'
     assert 0 < h["enqueue_us_per_round"] < h["loop_us_per_round"] and 0 <= h["queue_dry_frac"] < 1 and h["kernels_us_per_round"] > 0
+    assert 0 <= h["outside_loop_ms_per_step"] < d["ms_per_step"]          # batch set-up, collection, gather: what a busy host inflates
     if workload == "body":
         rp = d["reference_parity"]
         assert rp["frames"] >= 32 and rp["camera_stage_loss_rel_delta_max"] < 2e-4
