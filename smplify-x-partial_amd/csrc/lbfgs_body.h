@@ -359,20 +359,28 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
         for (int c = 0; c < 8; ++c) lb_axpy(q, -al[c], X.all[c]);
     };
 #define LB_LD1(X, b_) lb_load<-1>(X, (b_), n, head, hS, hY, gst->syt, gst->ro, s_alp, false, lane)
+    // The look-ahead loads are UNCONDITIONAL (a block past the end of the window re-reads block 0; it is never used): with
+    // `if (i0 >= 16) load` the number of loads in flight at the next dot products depended on a branch, and the compiler then
+    // waits for the shorter path's count -- vmcnt(0): every block paid its own memory round trip and the look-ahead bought
+    // nothing (round 4, read off the ISA; the same holds for stores left pending by the pair push: gfx9 counts them in vmcnt).
+    // (and the loads must stay where they are written: left alone, the compiler sinks the look-ahead loads of two steps into the
+    //  third one, next to their use -- LB_PIN, an empty asm that memory operations do not cross)
+#define LB_PIN() asm volatile("" ::: "memory")
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     {
         int i0 = n - 1;
         if constexpr (SETS == 3) {
-        LB_LD1(A, i0); if (i0 >= 8) LB_LD1(B, i0 - 8);
+        LB_LD1(A, i0); LB_LD1(B, max(i0 - 8, 0));
         for (;;) {
-            if (i0 >= 16) LB_LD1(C, i0 - 16); down(A, i0); i0 -= 8; if (i0 < 0) break;
-            if (i0 >= 16) LB_LD1(A, i0 - 16); down(B, i0); i0 -= 8; if (i0 < 0) break;
-            if (i0 >= 16) LB_LD1(B, i0 - 16); down(C, i0); i0 -= 8; if (i0 < 0) break;
+            LB_LD1(C, max(i0 - 16, 0)); LB_PIN(); down(A, i0); LB_PIN(); i0 -= 8; if (i0 < 0) break;
+            LB_LD1(A, max(i0 - 16, 0)); LB_PIN(); down(B, i0); LB_PIN(); i0 -= 8; if (i0 < 0) break;
+            LB_LD1(B, max(i0 - 16, 0)); LB_PIN(); down(C, i0); LB_PIN(); i0 -= 8; if (i0 < 0) break;
         }
         } else {
         LB_LD1(A, i0);
         for (;;) {
-            if (i0 >= 8) LB_LD1(B, i0 - 8); down(A, i0); i0 -= 8; if (i0 < 0) break;
-            if (i0 >= 8) LB_LD1(A, i0 - 8); down(B, i0); i0 -= 8; if (i0 < 0) break;
+            LB_LD1(B, max(i0 - 8, 0)); LB_PIN(); down(A, i0); LB_PIN(); i0 -= 8; if (i0 < 0) break;
+            LB_LD1(A, max(i0 - 8, 0)); LB_PIN(); down(B, i0); LB_PIN(); i0 -= 8; if (i0 < 0) break;
         }
         }
     }
@@ -397,22 +405,24 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
 #define LB_LD2(X, b_) lb_load<1>(X, (b_), n, head, hY, hS, gst->syb, gst->ro, s_alp, true, lane)
     {
         int i0 = 0;
+        const int last = max(n - 1, 0);
         if constexpr (SETS == 3) {
-        LB_LD2(A, i0); if (i0 + 8 < n) LB_LD2(B, i0 + 8);
+        LB_LD2(A, i0); LB_LD2(B, min(i0 + 8, last));
         for (;;) {
-            if (i0 + 16 < n) LB_LD2(C, i0 + 16); up(A); i0 += 8; if (i0 >= n) break;
-            if (i0 + 16 < n) LB_LD2(A, i0 + 16); up(B); i0 += 8; if (i0 >= n) break;
-            if (i0 + 16 < n) LB_LD2(B, i0 + 16); up(C); i0 += 8; if (i0 >= n) break;
+            LB_LD2(C, min(i0 + 16, last)); LB_PIN(); up(A); LB_PIN(); i0 += 8; if (i0 >= n) break;
+            LB_LD2(A, min(i0 + 16, last)); LB_PIN(); up(B); LB_PIN(); i0 += 8; if (i0 >= n) break;
+            LB_LD2(B, min(i0 + 16, last)); LB_PIN(); up(C); LB_PIN(); i0 += 8; if (i0 >= n) break;
         }
         } else {
         LB_LD2(A, i0);
         for (;;) {
-            if (i0 + 8 < n) LB_LD2(B, i0 + 8); up(A); i0 += 8; if (i0 >= n) break;
-            if (i0 + 8 < n) LB_LD2(A, i0 + 8); up(B); i0 += 8; if (i0 >= n) break;
+            LB_LD2(B, min(i0 + 8, last)); LB_PIN(); up(A); LB_PIN(); i0 += 8; if (i0 >= n) break;
+            LB_LD2(A, min(i0 + 8, last)); LB_PIN(); up(B); LB_PIN(); i0 += 8; if (i0 >= n) break;
         }
         }
     }
 #undef LB_LD2
+#undef LB_PIN
 #undef LB_RL
     Lane3 out; out.v[0] = r.a.x; out.v[1] = r.a.y; out.v[2] = r.b;
     return out;
