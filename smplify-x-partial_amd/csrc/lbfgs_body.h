@@ -239,7 +239,7 @@ __device__ __forceinline__ float wave_sum8_groups(const float (&v)[8], const int
 // the pair feeds v_pk_fma_f32 as it is (left to itself the compiler pairs elements 1, 2 and copies every row)
 typedef float lb_v2 __attribute__((ext_vector_type(2)));
 struct LbRow { lb_v2 a; float b; };
-struct LbSet { LbRow mine[8]; LbRow all[8]; float bnd[7]; float ro, al; };
+struct LbSet { LbRow mine[8]; LbRow all[8]; float bnd[7]; float ro, al; bool valid; };      // ro / al as loaded: the consumer masks them with `valid`
 typedef float lb_v3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ LbRow lb_ldrow(const char* p) {
 #ifdef SFX_HIST_NT
@@ -274,10 +274,12 @@ __device__ __forceinline__ void lb_load(LbSet& X, const int base, const int n, c
     for (int m = 0; m < 7; ++m) X.bnd[m] = tb[DIR * m * LB_BROW - m];
     const int ig = base + DIR * grp;
     const bool valid = ig >= 0 && ig < n;
-    const float rv = ro[p + DIR * grp];
-    X.ro = valid ? rv : 0.f;
+    // ro / al are handed over as loaded and masked where they are used (lb_two_loop): a select right behind its load is a
+    // wait for that load, and in front of the 16 row requests it cost the prologue of loop 2 two serial memory round trips
+    X.valid = valid;
+    X.ro = ro[p + DIR * grp];
     X.al = 0.f;
-    if (want_al) { const float av = s_alp[ig]; X.al = valid ? av : 0.f; }
+    if (want_al) X.al = s_alp[ig];
     const char* ra = reinterpret_cast<const char*>(hAll) + (size_t)p * LB_ROWB + 12 * lane;
     const char* rm = reinterpret_cast<const char*>(hMine) + (size_t)p * LB_ROWB + 12 * lane;
 #pragma unroll
@@ -336,6 +338,7 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
     const int n = __builtin_amdgcn_readfirstlane(n_), head = __builtin_amdgcn_readfirstlane(head_);
     float* s_alp = s_al + 8;        // members below index 0 of the last block land in the padding
     const int grp = lane >> 3;
+    const int nb = max(1, (n + 7) >> 3);        // block steps per loop (the old loops ran one step for an empty window too)
 #define LB_RL(v, l) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (l)))
     // SETS register sets of history rows: the block in use + (SETS - 1) blocks of look-ahead (3 where the registers are
     // there -- the tick kernels; 2 inside the persistent per-frame kernel, which would spill)
@@ -348,13 +351,14 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
 #pragma unroll
         for (int c = 0; c < 8; ++c) part[c] = lb_dotpart(X.mine[c], q);
         float acc = wave_sum8_groups(part, lane);
+        const float ro = X.valid ? X.ro : 0.f;
         float al[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
-            al[m] = LB_RL(acc * X.ro, 8 * m);
+            al[m] = LB_RL(acc * ro, 8 * m);
             if (m < 7) acc = fmaf(-al[m], X.bnd[m], acc);
         }
-        s_alp[base - grp] = acc * X.ro;          // (members c <= m see zeros of the band: acc[c] is final after step c)
+        s_alp[base - grp] = acc * ro;          // (members c <= m see zeros of the band: acc[c] is final after step c)
 #pragma unroll
         for (int c = 0; c < 8; ++c) lb_axpy(q, -al[c], X.all[c]);
     };
@@ -368,20 +372,26 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
 #define LB_PIN() asm volatile("" ::: "memory")
     __builtin_amdgcn_s_waitcnt(0x0F70);
     {
-        int i0 = n - 1;
+        int i0 = n - 1, k = 0;
+        // ONE exit per loop: with `if (i0 < 0) break` after every step the unified loop exit gave the header an edge from each
+        // step, and the wait counts at the header and in the third step were those of the shortest such path -- vmcnt(8) and
+        // vmcnt(23) where 48 loads may stay in flight: two steps out of three waited for the look-ahead of the step before
+        // (round 4, read off the ISA).  Whole rounds of SETS steps in the loop, the 1 .. SETS - 1 left over behind it.
         if constexpr (SETS == 3) {
         LB_LD1(A, i0); LB_LD1(B, max(i0 - 8, 0));
-        for (;;) {
-            LB_LD1(C, max(i0 - 16, 0)); LB_PIN(); down(A, i0); LB_PIN(); i0 -= 8; if (i0 < 0) break;
-            LB_LD1(A, max(i0 - 16, 0)); LB_PIN(); down(B, i0); LB_PIN(); i0 -= 8; if (i0 < 0) break;
-            LB_LD1(B, max(i0 - 16, 0)); LB_PIN(); down(C, i0); LB_PIN(); i0 -= 8; if (i0 < 0) break;
+        for (; k + 3 <= nb; k += 3) {
+            LB_LD1(C, max(i0 - 16, 0)); LB_PIN(); down(A, i0); LB_PIN(); i0 -= 8;
+            LB_LD1(A, max(i0 - 16, 0)); LB_PIN(); down(B, i0); LB_PIN(); i0 -= 8;
+            LB_LD1(B, max(i0 - 16, 0)); LB_PIN(); down(C, i0); LB_PIN(); i0 -= 8;
         }
+        if (k < nb) { down(A, i0); LB_PIN(); i0 -= 8; if (k + 1 < nb) { down(B, i0); LB_PIN(); } }
         } else {
         LB_LD1(A, i0);
-        for (;;) {
-            LB_LD1(B, max(i0 - 8, 0)); LB_PIN(); down(A, i0); LB_PIN(); i0 -= 8; if (i0 < 0) break;
-            LB_LD1(A, max(i0 - 8, 0)); LB_PIN(); down(B, i0); LB_PIN(); i0 -= 8; if (i0 < 0) break;
+        for (; k + 2 <= nb; k += 2) {
+            LB_LD1(B, max(i0 - 8, 0)); LB_PIN(); down(A, i0); LB_PIN(); i0 -= 8;
+            LB_LD1(A, max(i0 - 8, 0)); LB_PIN(); down(B, i0); LB_PIN(); i0 -= 8;
         }
+        if (k < nb) { down(A, i0); LB_PIN(); }
         }
     }
 #undef LB_LD1
@@ -393,10 +403,11 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
 #pragma unroll
         for (int c = 0; c < 8; ++c) part[c] = lb_dotpart(X.mine[c], r);
         float acc = wave_sum8_groups(part, lane);
+        const float ro = X.valid ? X.ro : 0.f, alv = X.valid ? X.al : 0.f;
         float cc[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
-            cc[m] = LB_RL(X.al - acc * X.ro, 8 * m);
+            cc[m] = LB_RL(alv - acc * ro, 8 * m);
             if (m < 7) acc = fmaf(cc[m], X.bnd[m], acc);
         }
 #pragma unroll
@@ -404,21 +415,23 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
     };
 #define LB_LD2(X, b_) lb_load<1>(X, (b_), n, head, hY, hS, gst->syb, gst->ro, s_alp, true, lane)
     {
-        int i0 = 0;
+        int i0 = 0, k = 0;
         const int last = max(n - 1, 0);
         if constexpr (SETS == 3) {
         LB_LD2(A, i0); LB_LD2(B, min(i0 + 8, last));
-        for (;;) {
-            LB_LD2(C, min(i0 + 16, last)); LB_PIN(); up(A); LB_PIN(); i0 += 8; if (i0 >= n) break;
-            LB_LD2(A, min(i0 + 16, last)); LB_PIN(); up(B); LB_PIN(); i0 += 8; if (i0 >= n) break;
-            LB_LD2(B, min(i0 + 16, last)); LB_PIN(); up(C); LB_PIN(); i0 += 8; if (i0 >= n) break;
+        for (; k + 3 <= nb; k += 3) {
+            LB_LD2(C, min(i0 + 16, last)); LB_PIN(); up(A); LB_PIN(); i0 += 8;
+            LB_LD2(A, min(i0 + 16, last)); LB_PIN(); up(B); LB_PIN(); i0 += 8;
+            LB_LD2(B, min(i0 + 16, last)); LB_PIN(); up(C); LB_PIN(); i0 += 8;
         }
+        if (k < nb) { up(A); LB_PIN(); if (k + 1 < nb) { up(B); LB_PIN(); } }
         } else {
         LB_LD2(A, i0);
-        for (;;) {
-            LB_LD2(B, min(i0 + 8, last)); LB_PIN(); up(A); LB_PIN(); i0 += 8; if (i0 >= n) break;
-            LB_LD2(A, min(i0 + 8, last)); LB_PIN(); up(B); LB_PIN(); i0 += 8; if (i0 >= n) break;
+        for (; k + 2 <= nb; k += 2) {
+            LB_LD2(B, min(i0 + 8, last)); LB_PIN(); up(A); LB_PIN(); i0 += 8;
+            LB_LD2(A, min(i0 + 8, last)); LB_PIN(); up(B); LB_PIN(); i0 += 8;
         }
+        if (k < nb) { up(A); LB_PIN(); }
         }
     }
 #undef LB_LD2
