@@ -323,7 +323,10 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     float* fwd = D.fwd ? D.fwd + (size_t)b * SFX_FWD_N : nullptr;
     const float* xsrc = (args.from_X ? D.X : D.Xt) + (size_t)b * SFX_NPAR_MAX;
     // every global source of this section goes to LDS asynchronously (lds_fill_async): one round trip for all of it
-    if (!reuse) lds_fill_async<CT>(S.x, xsrc, L.npar);
+    if (!reuse) {
+        if (args.x_lds) { for (int i = t; i < L.npar; i += CT) S.x[i] = args.x_lds[i]; }      // (published by the barrier below)
+        else lds_fill_async<CT>(S.x, xsrc, L.npar);
+    }
     if (!args.keep_tables) {   // (a persistent workgroup keeps the tables and its frame's data in LDS between evaluations)
     static_assert(SFX_META_N % 4 == 0 && FD_N % 4 == 0 && offsetof(LDS, meta) % 16 == 0 && offsetof(LDS, fd) % 16 == 0, "16-byte copies");
     lds_fill_async16<CT>(S.meta, M.meta, SFX_META_N / 4);

@@ -51,6 +51,17 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
     __shared__ float fval;
     __shared__ float s_al[SFX_HIST + 2 * LB_BS];
     __shared__ OptScal st;
+    // PF (a workgroup per CU: LDS to spare): the optimiser tick's working set -- its 8 vectors, X, Xt, the scalar state, both
+    // variable lists -- is requested with the loss / adjoint pass's entry batch (LDS-DMA into memory of its own, waited for
+    // by that entry's barrier) instead of at the tick's start, where it was a memory round trip of the frame's serial chain;
+    // the pass that follows the tick takes the trial point and the stage from LDS instead of reading back what the tick
+    // has just stored (two more round trips).  Same values either way.
+    constexpr bool PF = (OCC == 1);
+    constexpr int CTK = LDS::kThreads;
+    __shared__ __align__(16) float s_pf[PF ? 2048 : 4];
+    __shared__ __align__(16) VarList s_vl[PF ? 2 : 1];
+    __shared__ int s_stage;
+    static_assert(sizeof(VarList) % 4 == 0 && sizeof(OptScal) % 4 == 0 && (NVEC * SFX_NVAR_MAX) % 4 == 0, "dword / 16-byte LDS-DMA");
     const int b = D.act ? D.act[blockIdx.x] : blockIdx.x;      // (frames that finished or still wait in the queue are not launched)
     if (D.stage[b] > last_stage) return;
     const long long wc0 = D.dbg ? wall_clock64() : 0;      // debug: per-workgroup duration statistics (100 MHz clock)
@@ -59,13 +70,24 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
     if (has_eval) {
         ClosureArgs a{};
         a.stage_override = -2; a.use_dense_verts = 1; a.reuse_fwd = 1;
+        if constexpr (PF) {
+            lds_fill_async16<CTK>(s_pf, D.vec + (size_t)b * NVEC * SFX_NVAR_MAX, NVEC * SFX_NVAR_MAX / 4);
+            lds_fill_async16<CTK>(s_pf + NVEC * SFX_NVAR_MAX, D.X + (size_t)b * SFX_NPAR_MAX, SFX_NPAR_MAX / 4);
+            lds_fill_async16<CTK>(s_pf + NVEC * SFX_NVAR_MAX + SFX_NPAR_MAX, D.Xt + (size_t)b * SFX_NPAR_MAX, SFX_NPAR_MAX / 4);
+            lds_fill_async<CTK>(&st, &(reinterpret_cast<const OptState*>(D.opt) + b)->s, (int)(sizeof(OptScal) / 4));
+            lds_fill_async<CTK>(s_vl, vls, (int)(2 * sizeof(VarList) / 4));
+        }
         closure_body(S, M, D, vls, sws, a, b, gflat, &fval);
         __syncthreads();
         const long long wc1 = D.dbg ? wall_clock64() : 0;
         // (one wavefront: sharing the dot products of the two-loop recursion between four was measured slower --
         //  a workgroup barrier per block of 8 history pairs costs more than the reductions it removes)
-        if (threadIdx.x < 64)
-            lbfgs_tick_body<((OCC == 1 && LDS::kThreads <= 256) ? 3 : 2)>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, S.T, &fval, gflat);      // (S.T: >= 2048 floats of closure scratch, dead between evaluations)
+        if (threadIdx.x < 64) {
+            if constexpr (PF)
+                lbfgs_tick_body<((LDS::kThreads <= 256) ? 3 : 2), true>(M, D, s_vl, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, s_pf, &fval, gflat, &s_stage);
+            else
+                lbfgs_tick_body<2>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, S.T, &fval, gflat);      // (S.T: >= 2048 floats of closure scratch, dead between evaluations)
+        }
         __syncthreads();
         if (D.dbg && threadIdx.x == 0) {       // debug: mean duration of the two segments over all workgroups (100 MHz ticks)
             const long long wc2 = wall_clock64();
@@ -73,19 +95,21 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
             atomicAdd((unsigned long long*)&D.dbg[30], (unsigned long long)(wc2 - wc1));
         }
         if (D.dbg && b == 0 && threadIdx.x == 0 && D.dbg[62] <= D.dbg[61]) { D.dbg[25] = clock64(); for (int i = 0; i < 17; ++i) D.dbg[40 + i] = D.dbg[i]; }
-        if (D.stage[b] > last_stage) {          // finished in this launch: its column carries no collision weight any more
+        if ((PF ? s_stage : D.stage[b]) > last_stage) {          // finished in this launch: its column carries no collision weight any more
             if (D.pen_want && threadIdx.x == 0) D.pen_want[D.slot[b]] = 0;
             return;
         }
     }
+    const int stage_now = (PF && has_eval) ? s_stage : D.stage[b];
     // interpenetration: does the evaluation exported below carry a collision weight (fitting.py:437)?  Kept here, per column, by
     // the workgroup that knows the frame's stage (a memset and a launch of their own per round until round 4)
     if (D.pen_want && threadIdx.x == 0) {
-        const int st_ = D.stage[b];
+        const int st_ = stage_now;
         D.pen_want[D.slot[b]] = (st_ >= 0 && st_ < D.cfg.n_stages) ? (sws[st_].coll > 0.f ? 1 : 0) : 0;
     }
     ClosureArgs e{};
     e.stage_override = -2; e.export_dense = 1; e.forward_only = 2; e.keep_tables = has_eval;
+    if (PF && has_eval) { e.stage_override = stage_now; e.x_lds = s_pf + NVEC * SFX_NVAR_MAX + SFX_NPAR_MAX; }
     closure_body(S, M, D, vls, sws, e, b, nullptr, nullptr);
     if (D.dbg && b == 0 && threadIdx.x == 0 && D.dbg[62] <= D.dbg[61]) D.dbg[26] = clock64();
     if (D.dbg && threadIdx.x == 0) {

@@ -370,7 +370,7 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
     // (and the loads must stay where they are written: left alone, the compiler sinks the look-ahead loads of two steps into the
     //  third one, next to their use -- LB_PIN, an empty asm that memory operations do not cross)
 #define LB_PIN() asm volatile("" ::: "memory")
-    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // (kept: without it the tick launch is 0.2 us slower, A/B in one session)
     {
         int i0 = n - 1, k = 0;
         // ONE exit per loop: with `if (i0 < 0) break` after every step the unified loop exit gave the header an edge from each
@@ -445,11 +445,14 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
 // closure result (global D.f/D.g, or LDS copies in fused kernels).  s_al[SFX_HIST + 2 * LB_BS], s_state and
 // s_work[2048] (the tick's working copies; may alias any LDS that is dead during the tick)
 // are LDS scratch owned by the caller.
-template <int SETS>
+// PF: the caller has the working set (vectors, X, Xt in s_work, the scalar state in s_state) and both variable lists (vls
+// points to LDS copies) in place already -- k_tick_dense requests them with its entry's LDS-DMA batch, a whole loss /
+// adjoint pass before the tick wants them -- and takes the frame's stage after the tick from *stage_out.
+template <int SETS, bool PF = false>
 __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchDev& D, const VarList* __restrict__ vls,
                                                  int first_stage, int last_stage, int init, int step_mode,
                                                  const int b, const int lane, float* s_al, OptScal& s_state, float* s_work,
-                                                 const float* f_src, const float* g_src) {
+                                                 const float* f_src, const float* g_src, int* stage_out = nullptr) {
     const BatchCfgDev& C = D.cfg;
     OptState* gst = reinterpret_cast<OptState*>(D.opt) + b;
     int stage = D.stage[b];
@@ -491,7 +494,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
         for (int i = lane; i < SFX_NPAR_MAX; i += 64) Xtg[i] = Xg[i];
         return;
     }
-    if (stage > last_stage) return;
+    if (stage > last_stage) { if (PF && lane == 0) *stage_out = stage; return; }
     // debug: frame 0 accumulates shader-clock deltas between TMARKs into dbg[32+i], tick count in dbg[63]
     long long tm_prev = 0;
 #define TMARK(i) do { if (D.dbg && b == 0 && lane == 0) { const long long c_ = clock64();                 \
@@ -510,7 +513,10 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
     const VarList& vl = vls[stage < 0 ? 0 : 1];
     int N = vl.n;
     int idx3[NE3];           // this lane's parameter slots (vl.idx: 6 bytes per lane, once per tick)
-    {
+    if constexpr (PF) {
+#pragma unroll
+        for (int e = 0; e < NE3; ++e) idx3[e] = vl.idx[3 * lane + e];
+    } else {
         Lane3 wv_[NVEC];
 #pragma unroll
         for (int k = 0; k < NVEC; ++k) wv_[k] = ld3_raw(vecg, (unsigned)k * SFX_NVAR_MAX, lane);
@@ -862,6 +868,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
     reinterpret_cast<float4*>(Xg)[lane] = reinterpret_cast<const float4*>(X)[lane];
     reinterpret_cast<float4*>(Xtg)[lane] = reinterpret_cast<const float4*>(Xt)[lane];
     if (lane == 0) gst->s = s_state;     // ro[] and the band tables are written in place
+    if (PF && lane == 0) *stage_out = stage;
     TMARK(7);
 #undef TMARK
 #undef TRACE
@@ -869,13 +876,13 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
 }
 
 // Entry for a workgroup: wavefront 0 runs the state machine, the others pass through.  SETS: see lb_two_loop.
-template <int SETS>
+template <int SETS, bool PF = false>
 __device__ __forceinline__ void lbfgs_tick_body(const DevModel& M, const BatchDev& D, const VarList* __restrict__ vls,
                                                 int first_stage, int last_stage, int init, int step_mode,
                                                 const int b, const int tid, float* s_al, OptScal& s_state, float* s_work,
-                                                const float* f_src, const float* g_src) {
+                                                const float* f_src, const float* g_src, int* stage_out = nullptr) {
     if (tid >= 64) return;
-    lbfgs_tick_wave0<SETS>(M, D, vls, first_stage, last_stage, init, step_mode, b, tid, s_al, s_state, s_work, f_src, g_src);
+    lbfgs_tick_wave0<SETS, PF>(M, D, vls, first_stage, last_stage, init, step_mode, b, tid, s_al, s_state, s_work, f_src, g_src, stage_out);
 }
 
 

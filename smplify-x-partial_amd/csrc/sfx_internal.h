@@ -256,6 +256,7 @@ struct ClosureArgs {
     int from_scratch_items; // 1: dense mode, but evaluate the item rows here (the GEMM export belongs to another call)
     int keep_tables;        // 1: S.meta / S.fd are still valid from the previous evaluation of this workgroup
     int reuse_fwd;          // 1: forward state of this trial point was saved by the export pass
+    const float* x_lds;     // the trial point in the workgroup's LDS (k_tick_dense: left there by the optimiser tick); NULL: read X / Xt
 };
 // the 47-KB closure variant serves models whose keypoints need at most SFX_SMALL_ITEMS vertex rows
 // when the VPoser decoder is not in the loop
