@@ -843,7 +843,7 @@ def main():
             pmc_ok, pmc_note = False, "profiles/%s was taken at 256 frames per GPU, this run has %d: traffic not replayed" % (pmc_name, B)
         pj = json.load(open(pmc)) if pmc_ok else {}
 
-        def profiled_us(prefix, path=None):
+        def profiled_us(prefix, path=None, merge=False):
             """Average duration (us) of the kernel in the rocprofv3 --kernel-trace --stats summary of this command
             (profiles/kernel_stats*.csv, taken with the counters: same source hash), or None.  HIP events bracket the dispatch as
             well: they read 2-3 us longer than the profiler's own clock on a 55-us kernel."""
@@ -851,10 +851,14 @@ def main():
             path = path or os.path.join(ROOT, "profiles", pmc_name.replace("pmc_summary", "kernel_stats").replace(".json", ".csv"))
             if not (pmc_ok and os.path.exists(path)):
                 return None
-            best = None
+            best, calls, tot = None, 0, 0.0
             for row in csv.DictReader(open(path)):
-                if prefix in row["Name"] and (best is None or int(row["Calls"]) > best[0]):
-                    best = (int(row["Calls"]), float(row["AverageNs"]) * 1e-3)
+                if prefix in row["Name"]:
+                    calls += int(row["Calls"]); tot += float(row["TotalDurationNs"]) * 1e-3
+                    if best is None or int(row["Calls"]) > best[0]:
+                        best = (int(row["Calls"]), float(row["AverageNs"]) * 1e-3)
+            if merge:       # one kernel in several workgroup widths (k_lbs_dense16<W>): all of its launches
+                return tot / calls if calls else None
             return best[1] if best else None
 
         def pmc_kernel(prefix):
@@ -897,7 +901,7 @@ def main():
                                   "per the gfx950 correction"}
                 if "mfma_busy_frac" in k:
                     out["roofline"]["mfma_busy_frac"] = k["mfma_busy_frac"]
-            out["roofline"]["avg_launch_us_profile"] = profiled_us("k_lbs_dense16")
+            out["roofline"]["avg_launch_us_profile"] = profiled_us("k_lbs_dense16", merge=True)
             # the other half of the step: loss + adjoint + L-BFGS tick + next pose / chain, one workgroup per frame.  Byte model
             # per launch (tick_bytes: shared once + per frame) from THIS workload's own numbers: the vertex items under the
             # keypoints that are live in a stage (body | + hands | all; fit_single_frame.py:569-572), weighted by the evaluations

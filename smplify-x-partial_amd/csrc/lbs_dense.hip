@@ -21,6 +21,7 @@
 //     66.0 MB of constants (dirs 61.1+2.5, W 2.3, template 0.1) + B * 125.7 KB of vertices.
 #include "sfx_internal.h"
 #include <cstdlib>
+#include <algorithm>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -216,22 +217,29 @@ void k_lbs_dense(DevModel M, BatchDev D) {
 // (Measured and dropped on the way: a K-split pair of wavefronts per 16 x 32 tile -- halves of the K range summed as
 //  (half 0) + (half 1) after an exchange through LDS: faster below 64 and at 129-192 frames, 4-8 % slower at 256-1024, and NOT
 //  interchangeable with k_lbs_dense bit for bit, so it could not be used for part of the batch sizes only.)
-#define FB3 64            // frames per workgroup
+// Round 4: the number of wavefronts per workgroup is a template parameter (16 W frames per workgroup, 64 W threads; W = 3, 4, 5
+// are instantiated, the launcher picks: launch_lbs_dense).  A wavefront's arithmetic does not depend on W: interchangeable
+// bit for bit.
+#define FB3 64            // frames per workgroup at W = 4 (the shape of round 3)
+template <int W>
 struct __align__(16) DenseLDS16 {
-    float a[2][FB3][LDK];
+    float a[2][16 * W][LDK];
     float b[2][KC][LDB];
 };
 #ifndef MINW16
 #define MINW16 4
 #endif
-__global__ __launch_bounds__(DT, MINW16)
+template <int W>
+__global__ __launch_bounds__(64 * W, MINW16)
 void k_lbs_dense16(DevModel M, BatchDev D) {
-    __shared__ DenseLDS16 S;
+    constexpr int DTW = 64 * W, FBW = 16 * W;
+    static_assert(W >= 3 && W <= 8, "staging: two rounds of DTW threads cover the 384 float4 of a dirs chunk");
+    __shared__ DenseLDS16<W> S;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     int tile, fblk, fpb;
     {
-        const int ny = (D.nact + FB3 - 1) / FB3, ntile = (M.V + VB - 1) / VB;
+        const int ny = (D.nact + FBW - 1) / FBW, ntile = (M.V + VB - 1) / VB;
         const int tpx = (ntile + 7) / 8;                        // tiles per XCD
         const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
         tile = xcd * tpx + slot / ny; fblk = slot % ny;
@@ -248,7 +256,7 @@ void k_lbs_dense16(DevModel M, BatchDev D) {
     const size_t Bp = (size_t)D.Bpad;
     const size_t LD = (size_t)3 * M.Vpad;
     const bool active = wv * 16 < fpb && b0 < B;
-    // staging: 512 (feat) + 384 (dirs) float4 per chunk
+    // staging: 128 W (feat: two per thread) + 384 (dirs) float4 per chunk
     const float4* gA = reinterpret_cast<const float4*>(D.featR + (size_t)fb0 * SFX_KD_PAD);
     // dirs tile-major ([tile of 16 vertices][k][48]: the 98 KB a workgroup streams are ONE contiguous block and a chunk is
     // 6 KB of consecutive float4 -- out of the k-major matrix it was 32 separate 192-byte pieces 240 KB apart per chunk)
@@ -257,10 +265,14 @@ void k_lbs_dense16(DevModel M, BatchDev D) {
     int gA_off[2], lA_off[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int idx = tid + q * DT, f = idx / (KC / 4), k4 = idx % (KC / 4);
-        gA_off[q] = f * (SFX_KD_PAD / 4) + k4; lA_off[q] = f * LDK + k4 * 4;
+        const int idx = tid + q * DTW, f = idx / (KC / 4), k4 = idx % (KC / 4);
+        // (the last frame block may reach past the padded batch when 16 W does not divide it: those rows feed lanes whose
+        //  results are not stored -- read the last row instead)
+        const int fr = min(fb0 + f, D.Bpad - 1) - fb0;
+        gA_off[q] = fr * (SFX_KD_PAD / 4) + k4; lA_off[q] = f * LDK + k4 * 4;
     }
-    const int i4 = tid, i5 = tid + DT;
+    const bool ok4 = tid < B4;                              // (W = 7, 8: more threads than float4 in a dirs chunk)
+    const int i4 = ok4 ? tid : 0, i5 = tid + DTW;
     const bool ok5 = i5 < B4;
     const int gB4 = i4, lB4 = (i4 / (NB3 / 4)) * LDB + (i4 % (NB3 / 4)) * 4;
     const int j5 = ok5 ? i5 : 0;
@@ -271,7 +283,7 @@ void k_lbs_dense16(DevModel M, BatchDev D) {
 #define ST3_WRITE(buf) do {                                                                            \
         *reinterpret_cast<float4*>(&S.a[buf][0][0] + lA_off[0]) = s0;                                  \
         *reinterpret_cast<float4*>(&S.a[buf][0][0] + lA_off[1]) = s1;                                  \
-        *reinterpret_cast<float4*>(&S.b[buf][0][0] + lB4) = s4;                                        \
+        if (W <= 6 || ok4) *reinterpret_cast<float4*>(&S.b[buf][0][0] + lB4) = s4;                     \
         if (ok5) *reinterpret_cast<float4*>(&S.b[buf][0][0] + lB5) = s5; } while (0)
     f32x4 ax0 = {0, 0, 0, 0}, ay0 = ax0, az0 = ax0;
     const float tx = M.v_template[v * 3], ty = M.v_template[v * 3 + 1], tz = M.v_template[v * 3 + 2];
@@ -433,6 +445,7 @@ void k_lbs_dense32(DevModel M, BatchDev D) {
 #endif
 
 int g_lbs_dense_form = [] { const char* e = getenv("SFX_LBS_DENSE"); return e ? atoi(e) : 16; }();
+static int g_lbs_dense_w = [] { const char* e = getenv("SFX_LBS_W"); const int v = e ? atoi(e) : 0; return (v >= 3 && v <= 5) ? v : 0; }();      // (measurement: one W for every launch)
 
 void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s) {
     if (D.nact <= 0) return;
@@ -449,9 +462,20 @@ void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s) {
     // interchangeability test: SFX_LBS_DENSE=32 in the environment or sfx_debug_lbs_dense_form(32).
     const bool use16 = g_lbs_dense_form != 32;
     if (use16) {
-        const int ny = (D.nact + FB3 - 1) / FB3, ntile = (M.V + VB - 1) / VB;
+        // frame blocks of at most 4 slices as in round 3, and the workgroup as wide as its busiest block: 6 and 9 slices are
+        // blocks of 3 (W = 3: no idle wavefront, six workgroups per CU), 5 slices one block of 5; tools/bench_dense.py with
+        // SFX_LBS_W, us per launch at 5 / 6 / 9 slices: W = 3: 44.2 / 45.1 / 60.1, W = 4: 47.6 / 48.5 / 65.5, W = 5: 41.2 / 55.3 / 74.1;
+        // every other count is fastest (or as fast) at W = 4, and W = 6 .. 8 lose everywhere (measured, not instantiated)
+        const int ns = (D.nact + 15) / 16, ny4 = (ns + 3) / 4;
+        int w = ns <= 4 ? 4 : (ns == 5 ? 5 : std::max(3, (ns + ny4 - 1) / ny4));
+        if (g_lbs_dense_w) w = g_lbs_dense_w;
+        const int ny = (ns + w - 1) / w, ntile = (M.V + VB - 1) / VB;
         dim3 grid(8 * ((ntile + 7) / 8) * ny);
-        hipLaunchKernelGGL(k_lbs_dense16, grid, dim3(DT), 0, s, M, D);
+        switch (w) {
+        case 3: hipLaunchKernelGGL(k_lbs_dense16<3>, grid, dim3(192), 0, s, M, D); break;
+        case 5: hipLaunchKernelGGL(k_lbs_dense16<5>, grid, dim3(320), 0, s, M, D); break;
+        default: hipLaunchKernelGGL(k_lbs_dense16<4>, grid, dim3(256), 0, s, M, D); break;
+        }
         return;
     }
     const int ny = (D.nact + FB - 1) / FB, ntile = (M.V + VB - 1) / VB;

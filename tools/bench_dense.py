@@ -6,7 +6,8 @@ from smplifyx_amd import engine, synthetic
 m = synthetic.make_synthetic_model(0)
 dm = engine.DeviceModel(m)
 dev = torch.device("cuda")
-for B in (1, 8, 16, 32, 48, 64, 80, 96, 112, 128, 144, 160, 176, 192, 208, 224, 240, 256, 384, 512, 1024):
+BS = [int(x) for x in sys.argv[1:]] or [1, 8, 16, 32, 48, 64, 80, 96, 112, 128, 144, 160, 176, 192, 208, 224, 240, 256, 384, 512, 1024]
+for B in BS:
     t = lambda n, s=0.3: (s * torch.randn([B, n], device=dev)).contiguous()
     args = [t(3), t(63), t(10, 1.0), t(10, 1.0), t(3), t(3), t(3), t(12, 1.0), t(12, 1.0)]
     for _ in range(3):

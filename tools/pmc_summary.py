@@ -28,7 +28,9 @@ def main():
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(f, newline="") as fh:
                 for row in csv.DictReader(fh):
-                    k = (row["Kernel_Name"].split("(")[0], row["Counter_Name"])
+                    kn = row["Kernel_Name"].split("(")[0]
+                    if "k_lbs_dense16<" in kn: kn = "k_lbs_dense16"      # (one kernel in three workgroup widths: launch_lbs_dense)
+                    k = (kn, row["Counter_Name"])
                     a = acc[k]
                     a[0] += 1; a[1] += float(row["Counter_Value"]); a[2] += float(row.get("Grid_Size", 0) or 0)
     res = {}
