@@ -108,7 +108,7 @@ typedef struct sfx_batch_cfg {
     int32_t has_regression_pose;    /* pprior = |emb - regression_pose|^2 (:391-397)      */
     int32_t use_conf_cam_init;      /* use_conf quirk of camera-init loss (:509-511)      */
     int32_t num_body_joints;        /* 25 / 26 / 23: start of the hand keypoints          */
-    int32_t maxiters;               /* run_fitting steps AND LBFGS max_iter (cfg: 30)     */
+    int32_t maxiters;               /* run_fitting steps, and LBFGS max_iter unless lbfgs_max_iter says otherwise (cfg: 30) */
     double  ftol, gtol;             /* run_fitting tolerances (cfg: 1e-9, 1e-9)           */
     float   lr;                     /* cfg: 1.0                                           */
     float   rho;                    /* GMoF rho (cfg: 100)                                */
@@ -139,6 +139,9 @@ typedef struct sfx_batch_cfg {
     double  lbfgs_tolerance_change; /* 1e-9                                                          */
     int32_t lbfgs_max_eval;         /* maxiters * 5 / 4                                              */
     int32_t lbfgs_history_size;     /* 100 (larger values are refused: the ring holds 100 pairs)     */
+    int32_t lbfgs_max_iter;         /* LBFGS(max_iter): iterations per LBFGS.step and bound of the zoom phase (lbfgs_ls.py:304,397);
+                                       0 = maxiters, the one value optim_factory.py:15 hands to both; lbfgs_max_eval's default
+                                       follows it (max_iter * 5 / 4, lbfgs_ls.py:203)                              */
     int32_t high_precision;         /* cfg float_dtype: float64 (main.py:99-105): besides the keypoint forward (always fp64) the
                                        projection up to the pixel residual is carried in fp64 in every stage -- gradient noise
                                        0.13 x torch fp32's, the fits behave like the reference's float64 run;

@@ -54,7 +54,7 @@ class BatchCfg(C.Structure):
         ("interpenetration", C.c_int32), ("max_collisions", C.c_int32), ("df_cone_height", C.c_float),
         ("penalize_outside", C.c_int32), ("slots", C.c_int32),
         ("lbfgs_tolerance_grad", C.c_double), ("lbfgs_tolerance_change", C.c_double),
-        ("lbfgs_max_eval", C.c_int32), ("lbfgs_history_size", C.c_int32), ("high_precision", C.c_int32),
+        ("lbfgs_max_eval", C.c_int32), ("lbfgs_history_size", C.c_int32), ("lbfgs_max_iter", C.c_int32), ("high_precision", C.c_int32),
         ("point2plane", C.c_int32),
     ]
 

@@ -595,7 +595,8 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.cfg.B = B; D.cfg.n_stages = c->n_stages; D.cfg.use_vposer = c->use_vposer; D.cfg.use_hands = c->use_hands;
     D.cfg.use_face = c->use_face; D.cfg.use_conf = c->use_joints_conf; D.cfg.has_reg = c->has_regression_pose;
     D.cfg.use_conf_cam = c->use_conf_cam_init; D.cfg.nbj = c->num_body_joints; D.cfg.maxiters = c->maxiters;
-    D.cfg.max_eval = c->maxiters * 5 / 4; D.cfg.ftol = c->ftol; D.cfg.gtol = c->gtol;
+    D.cfg.lbfgs_max_iter = c->lbfgs_max_iter > 0 ? c->lbfgs_max_iter : c->maxiters;
+    D.cfg.max_eval = D.cfg.lbfgs_max_iter * 5 / 4; D.cfg.ftol = c->ftol; D.cfg.gtol = c->gtol;
     D.cfg.lr = c->lr; D.cfg.rho = c->rho; D.cfg.depth_w = c->depth_loss_weight; D.cfg.lbs_mode = c->lbs_mode;
     D.cfg.reuse = c->reuse_entry_eval;
     D.cfg.side_thsh = c->side_view_thsh; D.cfg.lsh = c->left_shoulder_idx; D.cfg.rsh = c->right_shoulder_idx;
@@ -1134,7 +1135,7 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
     launch_lbfgs_tick(M, D, b->vl_dev, first_stage, last_stage, init, step_mode, s);
     // bound on the rounds of the polled loops: one resident batch needs at most stages x maxiters LBFGS.step calls of
     // <= ~160 evaluations each; a job of B frames through a pool of `slots` columns needs that once per wave of the queue
-    long max_ticks = (long)(last_stage - first_stage + 1) * D.cfg.maxiters * 80 * 2 + 64;
+    long max_ticks = (long)(last_stage - first_stage + 1) * D.cfg.maxiters * std::max(80, D.cfg.max_eval + 32) * 2 + 64;     // (an LBFGS.step takes at most max_eval + 25 evaluations)
     if (dense && b->slots > 0 && b->slots < B) max_ticks *= (B + b->slots - 1) / b->slots;
     std::vector<int> hs(B);
     int* hp = b->stage_host ? b->stage_host : hs.data();
@@ -1366,7 +1367,7 @@ extern "C" int sfx_fit_multi(sfx_batch** bs, int32_t n, int32_t first_stage, int
     }
     long tick = 0;
     long max_ticks = 0;
-    for (int g = 0; g < n; ++g) max_ticks = std::max(max_ticks, (long)(last_stage - first_stage + 1) * bs[g]->D.cfg.maxiters * 160 + 64);
+    for (int g = 0; g < n; ++g) max_ticks = std::max(max_ticks, (long)(last_stage - first_stage + 1) * bs[g]->D.cfg.maxiters * std::max(80, bs[g]->D.cfg.max_eval + 32) * 2 + 64);
     int remaining = n, prev = -1;
     int rc = 0;
     while (remaining > 0 && tick < max_ticks && rc == 0) {

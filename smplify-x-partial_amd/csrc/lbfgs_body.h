@@ -531,7 +531,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
     LB_SYNC();
     OptScal& s = s_state;
     const double tol_change = C.tol_change, tol_grad = C.tol_grad;      // (LBFGS defaults 1e-9 / 1e-5: optim_factory.py:27-65 never changes them)
-    const int max_iter = C.maxiters, max_eval = C.max_eval, max_ls = 25;
+    const int max_iter = C.lbfgs_max_iter, max_eval = C.max_eval, max_ls = 25;
 
     // incoming evaluation
     const Sc f_in = P((double)*f_src);

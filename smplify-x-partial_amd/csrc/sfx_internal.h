@@ -158,7 +158,7 @@ struct BatchCfgDev {
     int B, n_stages;
     int use_vposer, use_hands, use_face, use_conf, has_reg, use_conf_cam;
     int nbj;
-    int maxiters, max_eval;
+    int maxiters, max_eval, lbfgs_max_iter;     // (run_fitting's step count | LBFGS max_eval | LBFGS max_iter)
     double ftol, gtol;
     float lr, rho, depth_w;
     int lbs_mode, reuse;

@@ -239,6 +239,7 @@ class FrameBatch(object):
         c.lbfgs_tolerance_change = -1.0 if tc is None else float(tc)
         c.lbfgs_max_eval = int(cfg.get("lbfgs_max_eval", 0) or 0)
         c.lbfgs_history_size = int(cfg.get("lbfgs_history_size", 0) or 0)
+        c.lbfgs_max_iter = int(cfg.get("lbfgs_max_iter", 0) or 0)
         # cfg float_dtype: float64 (main.py:99-105) -> the engine's high-precision mode (include/sfx.h sfx_batch_cfg.high_precision)
         c.high_precision = int(str(cfg.get("float_dtype", "float32")) == "float64" or bool(cfg.get("high_precision", False)))
         if c.interpenetration and lbs_mode != "dense":

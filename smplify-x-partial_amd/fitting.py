@@ -180,9 +180,6 @@ class EngineClosure(object):
         dm = bm.device_model
         K = dm.K
         opt = self.optimizer
-        maxiters = getattr(opt, "max_iter", self.monitor.maxiters)
-        if maxiters != self.monitor.maxiters:
-            raise NotImplementedError("LBFGS max_iter != FittingMonitor maxiters (the reference passes one value to both)")
         w = capi.StageWeights()
         pen_cfg = {}
         has_reg = False
@@ -226,6 +223,7 @@ class EngineClosure(object):
                    high_precision=getattr(bm, "dtype", torch.float32) == torch.float64,
                    lbfgs_tolerance_grad=getattr(opt, "tolerance_grad", None), lbfgs_tolerance_change=getattr(opt, "tolerance_change", None),
                    lbfgs_max_eval=getattr(opt, "max_eval", 0), lbfgs_history_size=getattr(opt, "history_size", 0),
+                   lbfgs_max_iter=getattr(opt, "max_iter", 0),      # (optim_factory.py:15 passes maxiters; a caller's own LBFGS may not)
                    maxiters=self.monitor.maxiters, ftol=self.monitor.ftol, gtol=self.monitor.gtol,
                    lr=getattr(opt, "lr", 1.0), rho=getattr(loss, "rho", 100),
                    depth_loss_weight=(float(getattr(loss, "depth_loss_weight", 0.0))

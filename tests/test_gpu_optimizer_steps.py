@@ -172,6 +172,44 @@ def test_non_default_lbfgs_hyper_parameters_match_the_machine(synth_model, cfg_b
     assert len(fd.get_trace()[0]) != len(dev) or not np.array_equal(fd.get_trace()[0], dev)
 
 
+def test_lbfgs_max_iter_other_than_maxiters_matches_the_machine(synth_model, cfg_body):
+    """LBFGS(max_iter=7) under FittingMonitor(maxiters=30) -- two different numbers where optim_factory.py:15 passes one (the
+    handle refused that until round 4): an LBFGS.step ends after 7 iterations / 8 evaluations (lbfgs_ls.py:203,304,419), the
+    zoom phase is bounded by the same 7 (:397 hands max_iter to _strong_Wolfe), run_fitting still makes up to 30 steps.  Camera
+    stage, device trace against the specification machine on the same HIP closure."""
+    from oracle.lbfgs_machine import StageMachine
+    cfg, dm, frames = _setup(synth_model, cfg_body)
+    cfg = dict(cfg, lbfgs_max_iter=7)
+    i = 0
+    fb = H.engine_batch_from_frames(dm, cfg, frames, [i], lbs_mode="rows", reuse=False)
+    fb.guess_init(cfg["body_tri_idxs"])
+    P0 = fb.get_params()
+    fb.trace(4096)
+    fb.fit(first_stage=-1, last_stage=-1)
+    dev = fb.get_trace()[0]
+    fc = H.engine_batch_from_frames(dm, cfg, frames, [i], lbs_mode="rows", reuse=False)
+    fc.guess_init(cfg["body_tri_idxs"])
+    m = StageMachine(np.concatenate([P0["cam_translation"][0], P0["global_orient"][0]]), groups=[(0, 3, True), (3, 3, True)],
+                     maxiters=cfg["maxiters"], ftol=cfg["ftol"], gtol=cfg["gtol"], lr=cfg.get("lr", 1.0), dtype=np.float32,
+                     reuse_entry_eval=False, max_iter=7)
+    while not m.done:
+        x = m.x_trial
+        fc.set_params(regression_pose=frames["reg_pose"][i:i + 1], cam_translation=x[None, :3], global_orient=x[None, 3:],
+                      pose_embedding=P0["pose_embedding"])
+        f, gr = fc.closure(-1)
+        m.feed(f[0], gr[0])
+    mac = np.array(m.records); mac[-1, 3] = -1
+    _compare(dev, mac, 5e-5, "camera stage, LBFGS max_iter 7 under maxiters 30", t_rtol=1e-3)
+    st = dev[dev[:, 0] == 1]
+    # no LBFGS.step makes more than 7 iterations or 8 evaluations + its last line search, and the stage needs several steps
+    assert len(st) >= 3 and np.all(np.diff(np.concatenate([[0], st[:, 3]])) <= 7)
+    assert np.all(np.diff(np.concatenate([[0], st[:, 2]])) <= 8 + 25)
+    # the default (max_iter = maxiters = 30) takes another path through the same stage
+    fd = H.engine_batch_from_frames(dm, dict(cfg_body, use_camera_prior=False), frames, [i], lbs_mode="rows", reuse=False)
+    fd.guess_init(cfg["body_tri_idxs"]); fd.trace(4096); fd.fit(first_stage=-1, last_stage=-1)
+    assert len(fd.get_trace()[0]) != len(dev) or not np.array_equal(fd.get_trace()[0], dev)
+
+
 def test_zero_tolerances_reach_the_device(synth_model, cfg_body):
     """LBFGS(tolerance_grad=0, tolerance_change=0) is legal in the reference (lbfgs_ls.py:291,301,437,442: the tests can then
     only fire on exact zeros); until round 4 a zero in sfx_batch_cfg meant "default" and silently became 1e-5 / 1e-9.  The
