@@ -116,13 +116,20 @@ __device__ __forceinline__ void lds_fill_async16(void* lds_dst, const void* gsrc
 // present.  Two variants are instantiated: <240, true> (any model / configuration, 86 KB) and
 // <32, false> (body-only keypoints without VPoser, 47 KB -> three workgroups per CU, or one next
 // to two 48-KB GEMM workgroups).
-template <int MAXI, bool VP>
+// TH (round 4): threads of the workgroup when not the variant's default -- the body-only set on 512 threads where a workgroup owns
+// its CU (k_tick_dense at <= 256 frames): two wavefronts per SIMD cover each other's LDS round trips in the barrier-separated
+// passes.  The same bits as on 256 threads: every sum across wavefronts either has its terms in the first four wavefronts on
+// both (threads >= 256 hold no keypoint, parameter or item of this variant: they add zeros) or is dealt to kRowWaves = 4
+// wavefronts whatever the thread count (the adjoint's row streams), and the layout -- the forward-state blob two launches
+// hand each other -- does not depend on TH.
+template <int MAXI, bool VP, int TH = 0>
 struct __align__(16) FrameLDSx {
     static constexpr int kMaxItems = MAXI;
     static constexpr int kBlocksPerCU = (MAXI <= SFX_SMALL_ITEMS && !VP) ? SFX_SMALL_OCC : 1;    // register budget of the fused kernels
-    static constexpr int kThreads = (MAXI <= SFX_SMALL_ITEMS && !VP) ? 256 : SFX_BIG_THREADS;
-    // scratch T: the item transforms, and (reverse sweep) one 512-float partial per wavefront
-    static constexpr int kScratch = (MAXI * 12 > (kThreads / 64) * 512) ? MAXI * 12 : (kThreads / 64) * 512;
+    static constexpr int kThreads = TH ? TH : ((MAXI <= SFX_SMALL_ITEMS && !VP) ? 256 : SFX_BIG_THREADS);
+    static constexpr int kRowWaves = (MAXI <= SFX_SMALL_ITEMS && !VP) ? 4 : kThreads / 64;        // wavefronts that stream adjoint rows
+    // scratch T: the item transforms, and (reverse sweep) one 512-float partial per row-streaming wavefront
+    static constexpr int kScratch = (MAXI * 12 > kRowWaves * 512) ? MAXI * 12 : kRowWaves * 512;
     float feat[SFX_KD_PAD];        // first: read as float4
     float x[SFX_NPAR_MAX];
     float full_pose[168];
@@ -178,6 +185,7 @@ struct __align__(16) FrameLDSx {
 };
 using FrameLDS = FrameLDSx<SFX_MAX_ITEMS, true>;
 using FrameLDSSmall = FrameLDSx<SFX_SMALL_ITEMS, false>;
+using FrameLDSSmall8 = FrameLDSx<SFX_SMALL_ITEMS, false, 512>;      // the same set on eight wavefronts (k_tick_dense, a workgroup per CU)
 
 __device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 template <int CTRL>
@@ -928,8 +936,10 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
         }
         // 2. stream them: lane u of a wavefront looks up entry u of the pass, v_readlane moves row index and coefficient
         //    into scalar registers, the loads use scalar base + lane offset (all RIF rows of a pass are requested back to back)
+        constexpr int RW = LDS::kRowWaves;      // (<= CT / 64: wavefronts beyond it hold no rows and no partial)
         float4 pa = {0.f, 0.f, 0.f, 0.f}, pb = pa;
-        for (int w0 = wv * RIF; w0 < nrows; w0 += (CT / 64) * RIF) {
+        if (wv < RW)
+        for (int w0 = wv * RIF; w0 < nrows; w0 += RW * RIF) {
             float4 da[RIF], db[RIF];
             const bool mine = lane < RIF && w0 + lane < nrows;
             const int myrow = S.rl[mine ? w0 + lane : w0];
@@ -948,14 +958,14 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
             }
         }
         float4* part = reinterpret_cast<float4*>(S.T);          // S.T is dead here: one 512-float partial per wavefront
-        part[wv * 128 + lane] = pa; part[wv * 128 + 64 + lane] = pb;
+        if (wv < RW) { part[wv * 128 + lane] = pa; part[wv * 128 + 64 + lane] = pb; }
         __syncthreads();
         for (int k = t; k < SFX_KD_PAD; k += CT) {
             const int l4 = (k & 255) >> 2, hi = k >> 8, c = k & 3;
             const float* pf = S.T + (hi * 64 + l4) * 4 + c;
             float sumw = pf[0];
 #pragma unroll
-            for (int w = 1; w < CT / 64; ++w) sumw += pf[w * 512];
+            for (int w = 1; w < RW; ++w) sumw += pf[w * 512];
             S.dfeat[k] = accumulate ? S.dfeat[k] + sumw : sumw;
         }
     }
