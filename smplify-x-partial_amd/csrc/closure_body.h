@@ -814,17 +814,22 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     }
     MARK(22);
     {
+        // (every term of these sums sits in a thread < 256 -- keypoints, parameters --: wavefronts beyond the fourth hold zeros
+        //  and are left out, so eight wavefronts sum what four do)
+        constexpr int QW = (CT / 64 < 4) ? CT / 64 : 4;
+        if (wv < QW) {
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const float w = wave_sum_dpp(q[i]);
-            if (lane == 0) S.red[wv * NQ + i] = w;
+            for (int i = 0; i < NQ; ++i) {
+                const float w = wave_sum_dpp(q[i]);
+                if (lane == 0) S.red[wv * NQ + i] = w;
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             float r = S.red[i];
 #pragma unroll
-            for (int w = 1; w < CT / 64; ++w) r += S.red[w * NQ + i];
+            for (int w = 1; w < QW; ++w) r += S.red[w * NQ + i];
             q[i] = r;
         }
     }
