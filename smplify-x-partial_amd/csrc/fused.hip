@@ -10,6 +10,9 @@
 #include "closure_body.h"
 #include "lbfgs_body.h"
 
+#ifndef SFX_SETS_SMALL8
+#define SFX_SETS_SMALL8 3      // register sets of the two-loop recursion in the body-only tick kernels with a workgroup per CU
+#endif
 #ifndef SFX_TICK_OCC
 #define SFX_TICK_OCC 2
 #endif
@@ -84,7 +87,7 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
         //  a workgroup barrier per block of 8 history pairs costs more than the reductions it removes)
         if (threadIdx.x < 64) {
             if constexpr (PF)
-                lbfgs_tick_body<((LDS::kThreads <= 256) ? 3 : 2), true>(M, D, s_vl, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, s_pf, &fval, gflat, &s_stage);
+                lbfgs_tick_body<((LDS::kMaxItems <= SFX_SMALL_ITEMS) ? SFX_SETS_SMALL8 : 2), true>(M, D, s_vl, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, s_pf, &fval, gflat, &s_stage);
             else
                 lbfgs_tick_body<2>(M, D, vls, first_stage, last_stage, 0, 0, b, threadIdx.x, s_al, st, S.T, &fval, gflat);      // (S.T: >= 2048 floats of closure scratch, dead between evaluations)
         }
