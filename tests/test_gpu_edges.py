@@ -37,6 +37,46 @@ def test_dense_path_is_batch_composition_independent(synth_model, cfg_body, B):
     assert np.array_equal(out[0][3]["stage_evals"][-1], out[1][3]["stage_evals"][-1])
 
 
+def test_kernel_shapes_of_the_dense_loop_give_the_same_bits():
+    """Round 4 added launch shapes to both kernels of the dense loop, each chosen by the number of active frames: k_lbs_dense16<W>
+    with W = 3 / 4 / 5 wavefronts per workgroup, k_tick_dense on eight wavefronts (<= 256 frames) or four.  A frame's fit must not
+    depend on the shape: the same 90-frame job (6 slices: W = 3 by the launcher's rule; then 5, 4, ... as frames finish) with the
+    launcher's choices, with one width forced for every launch (SFX_LBS_W = 3, 4, 5) and with the four-wavefront tick kernel
+    (SFX_TICK_THREADS = 256) -- the switches are read once per process, hence the subprocesses -- bit for bit."""
+    import hashlib, json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import hashlib, json, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import helpers as H, test_gpu_parity as T
+from smplifyx_amd import synthetic
+model = synthetic.make_synthetic_model(0)
+cfg = H.load_cfg("fit_smplx_combined_coco25.yaml", use_hands=False, use_face=False); cfg["use_camera_prior"] = False
+dm = T._dm(model, cfg)
+frames = T.synth_frames(model, cfg, 5)
+fb = H.engine_batch_from_frames(dm, cfg, frames, [i %% 5 for i in range(90)], lbs_mode="dense", reuse=True)
+fb.guess_init(cfg["body_tri_idxs"])
+fb.fit(first_stage=-1, last_stage=1)
+P = fb.get_params(); st = fb.stats()
+h = hashlib.sha256()
+for k in sorted(P): h.update(np.ascontiguousarray(P[k]).tobytes())
+h.update(np.ascontiguousarray(st["stage_evals"]).tobytes()); h.update(np.ascontiguousarray(st["stage_loss"]).tobytes())
+v, j = fb.forward()
+h.update(v.cpu().numpy().tobytes())
+print(json.dumps({"sha": h.hexdigest(), "evals": int(np.asarray(st["stage_evals"]).sum())}))
+''' % (root, os.path.join(root, "tests"))
+    outs = {}
+    for name, env_extra in (("default", {}), ("w3", {"SFX_LBS_W": "3"}), ("w4", {"SFX_LBS_W": "4"}), ("w5", {"SFX_LBS_W": "5"}),
+                            ("tick256", {"SFX_TICK_THREADS": "256"})):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert outs["default"]["evals"] > 90 * 50, outs
+    for name, o in outs.items():
+        assert o == outs["default"], (name, outs)
+
+
 def test_the_two_dense_kernels_are_interchangeable_bit_for_bit(synth_model, cfg_body):
     """k_lbs_dense16 (16 frames per wavefront, the product kernel) and k_lbs_dense (32 per wavefront, kept for A/B
     measurements) put every (vertex, frame) through the same chain of fp32 operations: all vertices of a 100-frame launch
