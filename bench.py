@@ -190,7 +190,8 @@ def build_cfg(workload="body"):
     """body: BASELINE configs[1] (body-only keypoints, use_vposer=False + synthetic regression prior).
     full: BASELINE configs[2] (hands + face + contour, K=135, VPoser decode in the loop, z0 = 0);
     pen: BASELINE configs[4] (cfg_files/fit_smplx_combined_halpe.yaml VERBATIM: hands + face, K = 136, combined regression
-    prior, camera prior, interpenetration term; surface-like synthetic mesh with synthetic part labels) --
+    prior, camera prior, interpenetration term; on synthetic.make_topology_model: the real SMPL-X topology, part table and
+    ExPose body of the reference tree -- `--mesh tubes`: the surface-like synthetic mesh of rounds 2-4) --
     side measurements (`--workload full|pen`), never the headline."""
     from smplifyx_amd import cmd_parser
     over = dict(interpenetration=False, visualize=False, interactive=False, save_vertices=False,
@@ -591,6 +592,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the fit of the reference's golden frames (profiling passes: "
                     "keeps their launches out of the per-kernel averages)")
     ap.add_argument("--groups", type=int, default=1, help="independent sub-batches per GPU (host threads/streams)")
+    ap.add_argument("--mesh", choices=("topology", "tubes"), default="topology",
+                    help="--workload pen: the real SMPL-X topology + part table + ExPose body (default), or the synthetic tubes")
     ap.add_argument("--slots", type=int, default=0, help="dense mode: GEMM columns per GPU when --frames is larger (continuous "
                     "batching: retired columns are refilled from the frame queue); 0 = one column per frame")
     args = ap.parse_args()
@@ -635,7 +638,10 @@ def main():
 
     from smplifyx_amd import engine, synthetic, utils as U
     cfg = build_cfg(args.workload)
-    model = synthetic.make_synthetic_model(0, surface=pen)
+    # --workload pen: the SMPL-X topology, part table and ExPose body the reference tree ships (tests/golden/smplx_topology.npz,
+    # synthetic.make_topology_model) -- the mesh fitting.py:437-455 evaluates; --mesh tubes = rounds 2-4's surface-like stand-in
+    topo = pen and args.mesh == "topology"
+    model = synthetic.make_topology_model(0) if topo else synthetic.make_synthetic_model(0, surface=pen)
     jm = U.smpl_to_annotation("smplx", use_hands=cfg["use_hands"], use_face=cfg["use_face"],
                               use_face_contour=cfg["use_face_contour"], format=cfg["format"])
     dm = engine.DeviceModel(model, joint_map=jm, num_betas=cfg["num_betas"],
@@ -643,7 +649,7 @@ def main():
                             num_pca_comps=cfg["num_pca_comps"], use_face_contour=cfg["use_face_contour"],
                             vposer=synthetic.make_synthetic_vposer(0) if full else None)
     if pen:
-        parts = synthetic.make_synthetic_parts(model)
+        parts = synthetic.topology_parts() if topo else synthetic.make_synthetic_parts(model)
         dm.set_parts(parts["segm"], parts["parents"], cfg["ign_part_pairs"])
     B = args.frames
     dev = torch.device("cuda", local_rank)
@@ -786,7 +792,8 @@ def main():
             "config": {"workload": "%s: %d synthetic frames/GPU%s, %s" % (
                            tag, B, "" if world == 1 else " x %d GPUs, 1 RCCL all_gather/step" % world, what),
                        "model": "neutral SMPL-X-shaped synthetic model (seed 0%s); synthetic regression prior / VPoser weights as SURVEY 8(d)" % (
-                           ", surface-like mesh + synthetic part labels" if pen else ""),
+                           (", on the SMPL-X face topology, per-face part table and ExPose body of the reference tree (smplx_topology.npz)" if topo
+                            else ", surface-like tube mesh + synthetic part labels") if pen else ""),
                        "keypoints": "SURVEY 8(d) verbatim: projected model joints + 1 px noise, confidences U(0.3, 1), 10 % of the keypoints "
                                     "dropped (the sequence of rounds 1-2a; `value_min3_camera_keypoints` = the same job when the detector "
                                     "keeps at least 3 of the 4 camera-initialisation keypoints, round 2's headline sequence)",

@@ -224,6 +224,8 @@ int  sfx_batch_pen_stats(sfx_batch* b, int32_t* stats_host /* [B][4] */, int32_t
  * such case since round 4: its kept partners -- the lowest ids -- are derived from the grid again; with max_collisions > 1024,
  * or in a mesh with more than 4096 such triangles -- one that has collapsed onto itself -- it still is.)                                                                                                              */
 int  sfx_batch_pen_flags(sfx_batch* b, int32_t* flags_host);
+/* sfx_pen_pairs for GEMM column `column` of the batch's most recent evaluation (resident batches only). */
+int  sfx_batch_pen_pairs(sfx_batch* b, int32_t column, int32_t cap, int32_t* pairs_host, int32_t* n_out);
 
 /* Per-frame results of the last sfx_batch_fit (HOST pointers, any may be NULL):
  *  stage_loss [B][1+n_stages]  value run_fitting returns per stage (camera first)
@@ -282,6 +284,10 @@ int  sfx_pen_set_point2plane(sfx_pen* h, int32_t on);
  * when they overflowed the buffer (0 = fine; then the frame reports no pairs), bucket walks cut short (0 on a sane mesh:
  * an entry looks at most 2048 entries ahead in its bucket; a mesh folded into a few cells by a diverged fit hits that). */
 int  sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host);
+/* The pair list of mesh `mesh` of the most recent evaluation: HOST [cap][2] ordered pairs (receiving triangle, partner), receiver
+ * ascending, partner ascending within a receiver, both orders of every colliding pair; *n_out = pairs in the list (the first
+ * min(n, cap) are copied).  = collision_idxs after BVH and FilterFaces in the reference (fitting.py:445-450).                  */
+int  sfx_pen_pairs(sfx_pen* h, int32_t mesh, int32_t cap, int32_t* pairs_host, int32_t* n_out);
 /* Work the term has done since the last reset, counted on the device over every handle of the process (HOST [6]): grid
  * entries, ordered pairs kept, column evaluations (meshes that went through the broad phase), triangles that survived the
  * part culling, triangles that met more partners than the lists hold while they are collected (2 x max_collisions: their kept
@@ -316,6 +322,13 @@ int  sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out /* [32] */
  * product kernel), 32 = k_lbs_dense (32 frames per wavefront; the same chain of fp32 operations per vertex and frame, so
  * the same bits).  Process-wide; any other value only queries.  Returns the previous setting.                          */
 int  sfx_debug_lbs_dense_form(int32_t form);
+
+/* Debug / A-B measurements: which form of the interpenetration term handles and batches created FROM NOW ON take -- 1 = one
+ * workgroup per column behind the triangle boxes (k_pen_frame) plus the general kernels on the columns it hands over (round 5,
+ * default); 0 = the ten general kernels on every column (rounds 2-4); 2 = form 1 with every column handed over after the grid
+ * build.  The three forms produce the same bits (pair list, loss, gradients: tests/test_gpu_topology.py).  Any other value only
+ * queries.  Returns the previous setting.  Environment: SFX_PEN_FORM.                                                       */
+int  sfx_debug_pen_form(int32_t form);
 
 /* Experiment (timing only): `rounds` rounds of the dense loop; mode 0 serial (GEMM -> tick), mode 1 GEMM and tick of a
  * round launched together on two streams.  out_ms = elapsed time.  The batch's results are meaningless afterwards.     */

@@ -69,24 +69,34 @@ def parse_ign_part_pairs(ign_part_pairs):
     return sorted(set(out))
 
 
-def candidate_pairs(verts, faces, segm=None, parents=None, ign_part_pairs=None, chunk=512):
+def candidate_pairs(verts, faces, segm=None, parents=None, ign_part_pairs=None, chunk=512, sweep=True):
     """[P, 2] int64 array of colliding-candidate triangle pairs (i < j), lexicographically sorted.
-    verts [V,3], faces [F,3]; segm / parents [F] switch the part filter on."""
+    verts [V,3], faces [F,3]; segm / parents [F] switch the part filter on.
+    sweep=True only prunes the brute force: the triangles are visited in the order of their boxes' low x, and a chunk of
+    rows is compared with the columns whose low x does not exceed the chunk's highest x (every other column fails the
+    x-overlap test anyway); sweep=False compares every row with every column.  Same pairs either way (tested)."""
     verts = np.asarray(verts, np.float64)
     faces = np.asarray(faces, np.int64)
     tri = verts[faces]
     lo, hi = tri.min(1), tri.max(1)
     F = faces.shape[0]
     ign = set(parse_ign_part_pairs(ign_part_pairs))
+    order = np.argsort(lo[:, 0], kind="stable") if sweep else np.arange(F)
+    lo_s, hi_s = lo[order], hi[order]
     out = []
     for s in range(0, F, chunk):
         e = min(F, s + chunk)
-        ov = np.all((lo[s:e, None, :] <= hi[None, :, :]) & (lo[None, :, :] <= hi[s:e, None, :]), axis=2)
-        ov &= (np.arange(s, e)[:, None] < np.arange(F)[None, :])
+        # columns: sorted positions > row position, up to the last one whose low x <= the chunk's highest x
+        end = int(np.searchsorted(lo_s[:, 0], hi_s[s:e, 0].max(), side="right")) if sweep else F
+        if end <= s + 1:
+            continue
+        ov = np.all((lo_s[s:e, None, :] <= hi_s[None, s:end, :]) & (lo_s[None, s:end, :] <= hi_s[s:e, None, :]), axis=2)
+        ov &= (np.arange(s, e)[:, None] < np.arange(s, end)[None, :])
         ii, jj = np.nonzero(ov)
-        ii += s
         if ii.size == 0:
             continue
+        a, b = order[ii + s], order[jj + s]
+        ii, jj = np.minimum(a, b), np.maximum(a, b)
         share = (faces[ii][:, :, None] == faces[jj][:, None, :]).any(axis=(1, 2))
         keep = ~share
         if segm is not None:
@@ -95,11 +105,12 @@ def candidate_pairs(verts, faces, segm=None, parents=None, ign_part_pairs=None, 
             keep &= ~((sa == sb) | (sa == pb) | (sb == pa))
             if ign:
                 lo_p, hi_p = np.minimum(sa, sb), np.maximum(sa, sb)
-                keep &= ~np.array([(a, b) in ign for a, b in zip(lo_p, hi_p)], bool)
+                keep &= ~np.array([(a_, b_) in ign for a_, b_ in zip(lo_p, hi_p)], bool)
         out.append(np.stack([ii[keep], jj[keep]], 1))
     if not out:
         return np.zeros((0, 2), np.int64)
-    return np.concatenate(out, 0)
+    res = np.concatenate(out, 0)
+    return res[np.lexsort((res[:, 1], res[:, 0]))]
 
 
 def _cone_geometry(tri):

@@ -93,8 +93,11 @@ SYMBOLS = {
     "sfx_pen_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sfx_pen_set_point2plane": (C.c_int, [C.c_void_p, C.c_int32]),
     "sfx_pen_stats": (C.c_int, [C.c_void_p, C.c_int32, i32p]),
+    "sfx_pen_pairs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, i32p, C.POINTER(C.c_int32)]),
+    "sfx_batch_pen_pairs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, i32p, C.POINTER(C.c_int32)]),
     "sfx_pen_phase_clocks": (C.c_int, [C.c_void_p, C.c_int32, i32p]),
     "sfx_batch_pen_flags": (C.c_int, [C.c_void_p, i32p]),
+    "sfx_debug_pen_form": (C.c_int, [C.c_int32]),
     "sfx_pen_work_reset": (C.c_int, []),
     "sfx_pen_work_get": (C.c_int, [C.POINTER(C.c_int64)]),
     "sfx_debug_clocks": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),

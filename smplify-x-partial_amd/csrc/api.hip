@@ -126,6 +126,7 @@ extern "C" void sfx_pen_destroy(sfx_pen* h);
 extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
                             float* loss_dev, float* dverts_dev, void* stream);
 extern "C" int sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host);
+extern "C" int sfx_pen_pairs(sfx_pen* h, int32_t mesh, int32_t cap, int32_t* pairs_host, int32_t* n_out);
 int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
                         float* loss_dev, float* dverts_dev, const int* want_dev, const PenAdjPrep* prep, int* over_dev, void* stream);
 int sfx_pen_capacity(const sfx_pen* h);          // meshes per call the handle's buffers hold (collide.hip)
@@ -1500,6 +1501,13 @@ extern "C" int sfx_batch_pen_stats(sfx_batch* b, int32_t* stats_host /* [B][4] *
         SFX_CHECK(hipMemcpy(ext_n_host, b->D.ext_n, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     }
     return 0;
+}
+
+extern "C" int sfx_batch_pen_pairs(sfx_batch* b, int32_t column, int32_t cap, int32_t* pairs_host, int32_t* n_out) {
+    if (!b || !n_out) { sfx_set_error("null argument"); return -1; }
+    if (!b->pen) { sfx_set_error("batch was created without interpenetration"); return -1; }
+    if (b->pen_chunked) { sfx_set_error("the pair lists of a pooled batch's stand-alone evaluation are overwritten chunk by chunk"); return -1; }
+    return sfx_pen_pairs(b->pen, column, cap, pairs_host, n_out);
 }
 
 extern "C" int sfx_batch_pen_flags(sfx_batch* b, int32_t* flags_host /* [B] */) {

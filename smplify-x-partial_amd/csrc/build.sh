@@ -12,7 +12,7 @@ $HIPCC $FLAGS -c "$HERE/closure.hip" -o "$HERE/obj/closure.o" & pids+=($!)
 $HIPCC $FLAGS -c "$HERE/lbs_dense.hip" -o "$HERE/obj/lbs_dense.o" & pids+=($!)
 $HIPCC $FLAGS -ffp-contract=off -c "$HERE/lbfgs.hip" -o "$HERE/obj/lbfgs.o" & pids+=($!)
 $HIPCC $FLAGS -c "$HERE/fused.hip" -o "$HERE/obj/fused.o" & pids+=($!)
-$HIPCC $FLAGS -c "$HERE/collide.hip" -o "$HERE/obj/collide.o" & pids+=($!)
+$HIPCC $FLAGS -ffp-contract=off -c "$HERE/collide.hip" -o "$HERE/obj/collide.o" & pids+=($!)
 $HIPCC $FLAGS -c "$HERE/lbs_adjoint.hip" -o "$HERE/obj/lbs_adjoint.o" & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsfx.so" "$HERE/obj/api.o" "$HERE/obj/closure.o" \

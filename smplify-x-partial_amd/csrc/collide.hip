@@ -117,9 +117,25 @@ struct PenDev {
     int* callno;               // [2] evaluations so far (k_pen_g1), and the last one in which some list overflowed (k_pen_list): k_pen_rank looks for queues only then
     int* over;                 // [B] or NULL (set per call): 1 = this evaluation of the mesh kept partners by ARRIVAL order somewhere (a list beyond
                                //     2 x max_collisions, a cut walk): its numbers are not reproducible run to run
+    // round 5: the per-frame kernel (k_pen_frame) and the columns it hands to the general kernels
+    int* heavy;                // [B] 1 = this evaluation of the column goes through the general kernels (crowded grid / too many pairs for one workgroup's LDS)
+    int* hlist;                // [B] the heavy columns of this evaluation, any order
+    int* nheavy;               // [1] their number (k_pen_g1 -> 0, k_pen_frame appends)
+    int2* pbuf;                // [B][pf_cap] accepted pairs of a frame on the fast path, any order (the partner-list buffer: unused there)
+    int pf_cap;                // min(PEN_FP, F * pcap / 2)
+    int fast_ok;               // the mesh fits the per-frame kernel's LDS layout (F^2 < 2^32: 32-bit sort keys; bit sets and vertex list in 64 KB)
     unsigned long long* work;  // [6] process-wide counts since sfx_pen_work_reset: grid entries, ordered pairs, column evaluations, surviving triangles,
                                //     triangles with more partners than the lists hold (2 x max_collisions: arrival order decides there), bucket walks cut short
 };
+
+// Which columns a kernel of the general path works on.  hlist == NULL (the ten-kernel form, SFX / sfx_debug_pen_form 0): column
+// blockIdx.y of the call, masked by `want`.  hlist != NULL (round 5): the compact list of columns k_pen_frame has handed over
+// ("heavy": a crowded grid or more pairs than one workgroup's LDS sorts), *nheavy of them -- the grid's rows loop over the list,
+// and a launch that finds it empty (nearly every one) ends after one load.
+struct PenSel { const int* want; const int* hlist; const int* nheavy; const int* heavy; };
+__device__ __forceinline__ int pen_sel_n(const PenSel& s, const int rows) { return s.hlist ? min(*s.nheavy, rows) : rows; }
+__device__ __forceinline__ int pen_sel_col(const PenSel& s, const int i) { return s.hlist ? s.hlist[i] : i; }
+__device__ __forceinline__ bool pen_sel_on(const PenSel& s, const int b) { return s.hlist ? s.heavy[b] != 0 : (!s.want || s.want[b] != 0); }
 
 // ---------------------------------------------------------------------------------------------
 // The cone field and its derivatives, written out in reverse mode (round 4; rounds 1-3 pushed forward-mode dual numbers with
@@ -258,14 +274,23 @@ __device__ __forceinline__ int pen_ford(float x) { int i = __float_as_int(x); re
 __device__ __forceinline__ int pen_bucket(int x, int y, int z) {
     return (int)(((unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u) & (PEN_CELLS - 1)); }
 
+// zero_dverts / zero_G (round 5, with k_pen_frame): the per-frame kernel writes the gradient of the vertices that HAVE one (a few
+// hundred of 10 475 on a body); the other rows of d loss / d vertices and of the adjoint GEMM's operand are zeroed here, by the
+// launch that has eight workgroups per column and nothing else to write but the boxes.
 __global__ __launch_bounds__(PEN_T)
-void k_pen_g1(PenDev P, const float* __restrict__ verts, const int* __restrict__ want) {
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) P.callno[0] += 1;      // (one writer per launch; launches of a handle are ordered)
+void k_pen_g1(PenDev P, const float* __restrict__ verts, const int* __restrict__ want, float* __restrict__ zero_dverts,
+              float* __restrict__ zero_G, int Vpad) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { P.callno[0] += 1; P.nheavy[0] = 0; }      // (one writer per launch; launches of a handle are ordered)
     __shared__ float red[PEN_T / 64];
     __shared__ int pbox[64 * 6];               // this workgroup's part boxes (LDS atomics), merged into the frame's afterwards: atomics
                                                // straight to the frame's 12 cache lines serialise in L2 (measured: 0.4-1.5 ms)
     const int b = blockIdx.y, t = threadIdx.x, w = blockIdx.x;
     if (want && !want[b]) return;
+    if (zero_dverts) {
+        float* d = zero_dverts + (size_t)b * P.V * 3;
+        for (int i = w * PEN_T + t; i < P.V * 3; i += PEN_GW * PEN_T) d[i] = 0.f;
+        if (zero_G) { float* g = zero_G + (size_t)b * 3 * Vpad; for (int i = w * PEN_T + t; i < P.V * 3; i += PEN_GW * PEN_T) g[i] = 0.f; }
+    }
     const float* vb = verts + (size_t)b * P.V * 3;
     float* aabb = P.aabb + (size_t)b * P.F * 6;
     const int F = P.F;
@@ -723,11 +748,11 @@ __device__ __forceinline__ int pen_bucket_of(int ck) {
 }
 
 // headers of block i0 -> the lane's own record (and its header words, for the window of chunk 0)
+// (cells: the frame's bucket END offsets -- global memory for the general kernels, the per-frame kernel's LDS copy on the fast path)
 __device__ __forceinline__ PenOwn pen_own(const PenDev& P, const int b, const int i0, const int s_total, const PenWalkCtx& W,
-                                          const int lane, int (&hi_)[8]) {
+                                          const int lane, int (&hi_)[8], const int* cells) {
     const float* aabb = P.aabb + (size_t)b * P.F * 6;
     const int2* ent = P.entries + (size_t)b * P.ent_cap;
-    const int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
     PenOwn O;
     O.qi = i0 + lane;
     const bool vi = O.qi < s_total;
@@ -751,8 +776,9 @@ __device__ __forceinline__ PenOwn pen_own(const PenDev& P, const int b, const in
 
 // chunk k of the block at i0: steps d = 64 k + 1 .. 64 k + 64.  own_hdr: the block's own header words (chunk 0: they are the
 // first half of the window and are not loaded again).
+template <class FLUSH>
 __device__ __forceinline__ void pen_walk_chunk(const PenDev& P, const int b, const int i0, const int k, const int bend_max,
-                                               const PenOwn& O, const int (&own_hdr)[8], PenWalkCtx& W, const int lane) {
+                                               const PenOwn& O, const int (&own_hdr)[8], PenWalkCtx& W, const int lane, FLUSH&& flush) {
     const float* aabb = P.aabb + (size_t)b * P.F * 6;
     const int2* ent = P.entries + (size_t)b * P.ent_cap;
     const int w0 = i0 + 64 * k;                    // entry in window slot 0
@@ -797,7 +823,7 @@ __device__ __forceinline__ void pen_walk_chunk(const PenDev& P, const int b, con
             const int pos = W.qn + __popcll(m & ((1ull << lane) - 1ull));
             if (pass) { W.queue[2 * pos] = O.fi; W.queue[2 * pos + 1] = other & 0xffffff; }
             W.qn += __popcll(m);
-            if (W.qn >= 64) pen_flush_queue(P, b, W, lane);
+            if (W.qn >= 64) flush(W);
         }
     };
     for (int dd = 1; dd <= 64; dd += PEN_NC) {      // dd = d - 64 k
@@ -822,24 +848,29 @@ __device__ __forceinline__ void pen_walk_chunk(const PenDev& P, const int b, con
 // chunk 0 of every block; PEN_WALK_BLOCKS workgroups per mesh.  Queues the chunks k >= 1 (P.wq / P.wqn); when the queue is full
 // the block walks them itself, as it did before round 4.
 __global__ __launch_bounds__(256)
-void k_pen_walk(PenDev P, const int* __restrict__ want) {
+void k_pen_walk(PenDev P, PenSel sel) {
     PEN_WALK_LDS
-    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
-    const int s_total = cells[PEN_CELLS];
-    if ((want && !want[b]) || blockIdx.x * 256 >= s_total) return;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int nsel = pen_sel_n(sel, sel.hlist ? 0x7fffffff : (int)gridDim.y);
+    if (nsel == 0) return;
     if (t < 64) s_mask[t] = P.skipmask[t];
     __syncthreads();
+    for (int si = blockIdx.y; si < nsel; si += gridDim.y) {
+    const int b = pen_sel_col(sel, si);
+    const int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
+    const int s_total = cells[PEN_CELLS];
+    if (!pen_sel_on(sel, b) || blockIdx.x * 256 >= s_total) continue;
     PenWalkCtx W;
     W.tA = reinterpret_cast<int4*>(s_tile + wv * PEN_WIN * 8); W.tB = W.tA + PEN_WIN;
     W.queue = s_queue + wv * 256; W.qn = 0; W.s_mask = s_mask;
+    auto flush = [&](PenWalkCtx& W_) { pen_flush_queue(P, b, W_, lane); };
     // (blocks of 64 entries, NOT whole buckets: a crowded bucket is shared by many wavefronts; the
     // cell key comparison keeps different cells of one bucket apart)
     for (int i0 = (blockIdx.x * 4 + wv) * 64; i0 < s_total; i0 += gridDim.x * 256) {
         int hdr[8];
-        const PenOwn O = pen_own(P, b, i0, s_total, W, lane, hdr);
+        const PenOwn O = pen_own(P, b, i0, s_total, W, lane, hdr, cells);
         const int bend_max = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)O.bend));      // entries < 2^24: exact
-        pen_walk_chunk(P, b, i0, 0, bend_max, O, hdr, W, lane);
+        pen_walk_chunk(P, b, i0, 0, bend_max, O, hdr, W, lane, flush);
         // steps this block needs: the longest walk of its lanes, bend - 1 - qi
         const int dmax = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)max(O.bend - 1 - O.qi, 0)));
         if (dmax > 64) {
@@ -853,23 +884,29 @@ void k_pen_walk(PenDev P, const int* __restrict__ want) {
             pos = __builtin_amdgcn_readfirstlane(pos);
             if (pos + kmax <= P.wq_cap) {
                 if (lane >= 1 && lane <= kmax) P.wq[(size_t)b * P.wq_cap + pos + lane - 1] = make_int2(i0, lane);
-            } else {                                       // queue full: walk on here
-                if (lane == 0) atomicSub(&P.wqn[b], kmax);
-                for (int k = 1; k <= kmax; ++k) pen_walk_chunk(P, b, i0, k, bend_max, O, hdr, W, lane);
+            } else {
+                // queue full: walk on here.  The reservation is NOT rolled back (round 5; an atomicSub could interleave with a
+                // third wavefront's reservation and leave its records beyond the count, stale ones inside it): the count only
+                // grows, readers clamp it to the capacity, and the slots of this reservation that lie inside the capacity are
+                // filled with records k_pen_walk2 skips (chunk 0 is never queued).
+                if (lane >= 1 && lane <= kmax && pos + lane - 1 < P.wq_cap) P.wq[(size_t)b * P.wq_cap + pos + lane - 1] = make_int2(i0, 0);
+                for (int k = 1; k <= kmax; ++k) pen_walk_chunk(P, b, i0, k, bend_max, O, hdr, W, lane, flush);
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
     pen_flush_queue(P, b, W, lane);
+    }
 }
 
 // the queued chunks of all meshes of the call, one flat list (the distribution of k_pen_eval): a chunk per wavefront
 __global__ __launch_bounds__(256)
-void k_pen_walk2(PenDev P, int B) {
+void k_pen_walk2(PenDev P, int B, PenSel sel) {
     PEN_WALK_LDS
     extern __shared__ int s_pref[];             // [B + 1] exclusive prefix of the meshes' queued chunks
     __shared__ int s_scan[256];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (sel.hlist && *sel.nheavy == 0) return;          // (only heavy columns queue chunks: k_pen_frame leaves the others' queues empty)
     if (t < 64) s_mask[t] = P.skipmask[t];
     const int n_items = pen_prefix(B, s_pref, s_scan, [&](int b_) { return min(P.wqn[b_], P.wq_cap); });
     PenWalkCtx W;
@@ -880,11 +917,12 @@ void k_pen_walk2(PenDev P, int B) {
         const int b = pen_chunk_mesh(s_pref, B, c);
         if (b != b_prev) { if (b_prev >= 0) pen_flush_queue(P, b_prev, W, lane); b_prev = b; }      // (the pair queue belongs to one mesh)
         const int2 it = P.wq[(size_t)b * P.wq_cap + (c - s_pref[b])];
+        if (it.y == 0) continue;                       // (a slot of a reservation that did not fit: its block walked on itself)
         const int s_total = P.cells[(size_t)b * (PEN_CELLS + 1) + PEN_CELLS];
         int hdr[8];
-        const PenOwn O = pen_own(P, b, it.x, s_total, W, lane, hdr);
+        const PenOwn O = pen_own(P, b, it.x, s_total, W, lane, hdr, P.cells + (size_t)b * (PEN_CELLS + 1));
         const int bend_max = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)O.bend));
-        pen_walk_chunk(P, b, it.x, it.y, bend_max, O, hdr, W, lane);
+        pen_walk_chunk(P, b, it.x, it.y, bend_max, O, hdr, W, lane, [&](PenWalkCtx& W_) { pen_flush_queue(P, b, W_, lane); });
     }
     if (b_prev >= 0) pen_flush_queue(P, b_prev, W, lane);
 }
@@ -896,17 +934,21 @@ __device__ __host__ __forceinline__ int pen_rank_tile(const int pcap) { int c = 
 __device__ __forceinline__ bool pen_can_rewalk(const PenDev& P) { const int t = pen_rank_tile(P.pcap); return t > 0 && P.cap + 64 <= t && !P.no_rewalk; }
 
 __global__ __launch_bounds__(PEN_T)
-void k_pen_list(PenDev P, const int* __restrict__ want) {
+void k_pen_list(PenDev P, PenSel sel) {
     extern __shared__ int s_cnt[];             // [F] partner counts of the frame, then [hasp_words] bitmask
     __shared__ float red[PEN_T / 64];
     __shared__ int slice[PEN_T];
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x;
+    const int nsel = pen_sel_n(sel, sel.hlist ? 0x7fffffff : (int)gridDim.x);
+    for (int si = blockIdx.x; si < nsel; si += gridDim.x) {
+    const int b = pen_sel_col(sel, si);
+    __syncthreads();                                 // (the previous column's reads of the staging arrays are done)
     int* st = P.stats + b * PEN_STATS;
     unsigned* hasp = P.hasp + (size_t)b * P.hasp_words;
-    if ((want && !want[b]) || st[2] != 0) {          // skipped frame / grid overflow: k_pen_grid has zeroed the totals
+    if (!pen_sel_on(sel, b) || st[2] != 0) {         // skipped frame / grid overflow: the grid build has zeroed the totals
         for (int w = t; w < P.hasp_words; w += PEN_T) hasp[w] = 0u;
         if (P.over && t == 0) P.over[b] = 0;
-        return;
+        continue;
     }
     const int F = P.F;
     int* pc = P.pcount + (size_t)b * F;
@@ -970,6 +1012,7 @@ void k_pen_list(PenDev P, const int* __restrict__ want) {
     for (int f = t; f < F; f += PEN_T) poff[f] = s_cnt[f];
     __syncthreads();
     for (int w = t; w < P.hasp_words; w += PEN_T) hasp[w] = s_has[w];
+    }
 }
 
 // A triangle that met more partners than its list holds (pcap = 2 x max_collisions; only a mesh pushed through itself has such
@@ -1106,19 +1149,23 @@ __device__ __forceinline__ int pen_rewalk(const PenDev& P, const int b, const in
 #endif
 #define PEN_SHORT 16            // lists up to this length are ranked element-wise, longer ones sorted by a wavefront
 __global__ __launch_bounds__(256)
-void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
+void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
     extern __shared__ int s_sort[];             // [4][max(cap_pad, 128)]
-    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    if ((want && !want[b]) || P.ptotal[b] == 0) return;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int nsel = pen_sel_n(sel, sel.hlist ? 0x7fffffff : (int)gridDim.y);
+    if (nsel == 0) return;
     const int F = P.F;
+    const int tcap = min(max(cap_pad, 128), 2048);
+    int* tile = s_sort + wv * tcap;
+    for (int si = blockIdx.y; si < nsel; si += gridDim.y) {
+    const int b = pen_sel_col(sel, si);
+    if (!pen_sel_on(sel, b) || P.ptotal[b] == 0) continue;
     const int* pc = P.pcount + (size_t)b * F;
     const int* poff = P.poff + (size_t)b * F;
     const int* part = P.partners + (size_t)b * F * P.pcap;
     const int* pav = P.pavail + (size_t)b * F;
     int* pown = P.pown + (size_t)b * P.pair_cap;
     int* plist = P.plist + (size_t)b * P.pair_cap;
-    const int tcap = min(max(cap_pad, 128), 2048);
-    int* tile = s_sort + wv * tcap;
     const bool rewalk_b = pen_can_rewalk(P) && P.ovn[b * 2] > 0;      // (k_pen_list empties the queue of a mesh it will not have looked at again)
     const bool can_sort = cap_pad <= 2048;
     // 64 consecutive triangles at a time per wavefront.  Short lists: their elements are dealt to the
@@ -1215,14 +1262,15 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
     // through an atomic cursor by whichever wavefront is free -- first the mesh's own, then those of the other meshes of the call
     // (such triangles come in crowds, in one or two meshes of a call: their own 256 wavefronts would be the launch's long pole).
     // Who derives a triangle's partners has no influence on what they are.
+    }
     if (!pen_can_rewalk(P) || P.callno[1] != P.callno[0]) return;      // (no list of this evaluation overflowed: nothing queued anywhere)
-    const int nB = gridDim.y;
+    const int nB = nsel, b = (int)(blockIdx.y % (unsigned)nsel);        // (positions in the selection: the call's columns, or the heavy list)
     // (which meshes have a queue at all: looked up by the lanes in parallel, 64 meshes per step -- one mesh after the other the
     //  scan itself was a chain of dependent loads as long as the call has meshes)
     for (int g0 = 0; g0 < nB; g0 += 64) {
       const int bl = g0 + lane;
-      const int bq = bl < nB ? (b + bl < nB ? b + bl : b + bl - nB) : 0;           // the own mesh first
-      const int nql = P.ovn[bq * 2], ptl = P.ptotal[bq], wl = want ? want[bq] : 1;
+      const int bq = pen_sel_col(sel, bl < nB ? (b + bl < nB ? b + bl : b + bl - nB) : 0);           // the own mesh first
+      const int nql = P.ovn[bq * 2], ptl = P.ptotal[bq], wl = pen_sel_on(sel, bq) ? 1 : 0;
       unsigned long long todo = __ballot(bl < nB && wl && nql > 0 && ptl > 0 && P.ovn[bq * 2 + 1] < nql);
       while (todo) {
         const int bit = __ffsll((long long)todo) - 1;
@@ -1266,14 +1314,104 @@ void k_pen_rank(PenDev P, const int* __restrict__ want, int cap_pad) {
 // is measured along the other triangle's normal -- every Psi^2 of the pair is weighted by c = (n_f . n_g)^2, and the gradient
 // gains the path through both unit normals.  A lane (f, g) owns d / d (vertices of f): its own cone's terms (1) and the terms
 // of g's cone at its vertices (2) both depend on n_f through c.
+// One ordered pair (f receives g): the loss this lane owns and its gradient with respect to f's nine coordinates -> v[0..8], v[9].
+// Shared by k_pen_eval and k_pen_frame; this file is compiled with -ffp-contract=off, so the two instances perform the same
+// fp32 operations in the same order whatever surrounds them (a fused multiply-add chosen in one context and not in the other
+// would make the two forms of the term differ in the last bit).
+template <bool P2P>
+__device__ __forceinline__ void pen_pair_eval(const PenDev& P, const float* __restrict__ vb, const int f, const int g, const bool sym,
+                                              const float sigma, const int penalize_outside, float (&v)[10]) {
+    float p[9], qv[9];
+    for (int k = 0; k < 3; ++k) for (int e = 0; e < 3; ++e) {
+        p[k * 3 + e] = vb[(size_t)P.faces[f * 3 + k] * 3 + e];
+        qv[k * 3 + e] = vb[(size_t)P.faces[g * 3 + k] * 3 + e];
+    }
+    float loss = 0.f, g9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (sym) {
+        const V3 P0 = {p[0], p[1], p[2]}, P1 = {p[3], p[4], p[5]}, P2 = {p[6], p[7], p[8]};
+        const V3 Q[3] = {{qv[0], qv[1], qv[2]}, {qv[3], qv[4], qv[5]}, {qv[6], qv[7], qv[8]}};
+        if constexpr (!P2P) {
+        {   // (1) this triangle receives the partner's vertices: the loss, and its gradient through the own cone's geometry
+            const ConeGeo gg_ = cone_geometry(P0, P1, P2);
+            V3 go = {0.f, 0.f, 0.f}, gn = {0.f, 0.f, 0.f}; float gr = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                V3 gd, gnk; float grk;
+                loss += cone_penalty(gg_.o, gg_.r, gg_.n, Q[k], sigma, penalize_outside, gd, gnk, grk);
+                go = go - gd; gn = gn + gnk; gr += grk;            // d = v - o
+            }
+            V3 g0, g1, g2;
+            cone_geometry_adj(gg_, go, gr, gn, g0, g1, g2);
+            g9[0] += g0.x; g9[1] += g0.y; g9[2] += g0.z; g9[3] += g1.x; g9[4] += g1.y; g9[5] += g1.z; g9[6] += g2.x; g9[7] += g2.y; g9[8] += g2.z;
+        }
+        {   // (2) this triangle's vertices intrude into the partner's cone (partner geometry constant): d / d v = d / d d
+            const ConeGeo gg_ = cone_geometry(Q[0], Q[1], Q[2]);
+            const V3 Pk[3] = {P0, P1, P2};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                V3 gd, gnk; float grk;
+                (void)cone_penalty(gg_.o, gg_.r, gg_.n, Pk[k], sigma, penalize_outside, gd, gnk, grk);
+                g9[k * 3] += gd.x; g9[k * 3 + 1] += gd.y; g9[k * 3 + 2] += gd.z;
+            }
+        }
+        } else {
+            const ConeGeo gf = cone_geometry(P0, P1, P2), gg = cone_geometry(Q[0], Q[1], Q[2]);
+            const float dt = vdot(gf.n, gg.n), c = dt * dt;
+            // (1) own cone at the partner's vertices: value S1, adjoint with respect to the own (o, r, n)
+            V3 go = {0.f, 0.f, 0.f}, gn = {0.f, 0.f, 0.f}; float gr = 0.f, S1 = 0.f, S2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                V3 gd, gnk; float grk;
+                S1 += cone_penalty(gf.o, gf.r, gf.n, Q[k], sigma, penalize_outside, gd, gnk, grk);
+                go = go - gd; gn = gn + gnk; gr += grk;
+            }
+            // (2) the partner's cone at the own vertices: value S2 (owned as a LOSS by the lane (g, f)), d / d v = d / d d
+            const V3 Pk[3] = {P0, P1, P2};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                V3 gd, gnk; float grk;
+                S2 += cone_penalty(gg.o, gg.r, gg.n, Pk[k], sigma, penalize_outside, gd, gnk, grk);
+                g9[k * 3] += c * gd.x; g9[k * 3 + 1] += c * gd.y; g9[k * 3 + 2] += c * gd.z;
+            }
+            loss += c * S1;
+            // c = (n_f . n_g)^2 multiplies both sums: d c / d n_f = 2 (n_f . n_g) n_g
+            gn = gn * c + gg.n * ((S1 + S2) * 2.f * dt);
+            V3 g0, g1, g2;
+            cone_geometry_adj(gf, go * c, gr * c, gn, g0, g1, g2);
+            g9[0] += g0.x; g9[1] += g0.y; g9[2] += g0.z; g9[3] += g1.x; g9[4] += g1.y; g9[5] += g1.z; g9[6] += g2.x; g9[7] += g2.y; g9[8] += g2.z;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) v[j] = g9[j];
+    v[9] = loss;
+}
+// sum over the pairs of one triangle that sit in this wavefront (adjacent lanes): segmented inclusive scan, then the last lane of
+// every run stores the run's sum at its own list position i (po: [10][pair_cap])
+__device__ __forceinline__ void pen_run_sums(float (&v)[10], const int fkey, const bool valid, const int lane, float* __restrict__ po,
+                                             const int pair_cap, const int i) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int fu = __shfl_up(fkey, d);
+        const bool take = lane >= d && fu == fkey;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) { const float vu = __shfl_up(v[j], d); if (take) v[j] += vu; }
+    }
+    const int fnext = __shfl_down(fkey, 1);
+    if (valid && (lane == 63 || fnext != fkey)) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) po[(size_t)j * pair_cap + i] = v[j];
+    }
+}
+
 template <bool P2P>
 __global__ __launch_bounds__(256)
-void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int penalize_outside, int B, int flat) {
+void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int penalize_outside, int B, int flat, PenSel sel) {
     extern __shared__ int s_pref[];             // [B + 1] (flat distribution)
     __shared__ int s_scan[256];
     const int lane = threadIdx.x & 63;
+    if (sel.hlist && *sel.nheavy == 0) return;
     int n_chunks = 0;
-    if (flat) n_chunks = pen_chunk_prefix(P, B, s_pref, s_scan);
+    if (flat) n_chunks = pen_prefix(B, s_pref, s_scan, [&](int b_) { return pen_sel_on(sel, b_) ? (P.ptotal[b_] + 63) >> 6 : 0; });
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
     // flat: chunk ids wave, wave + n_waves, ...; per mesh (flat = 0): blockIdx.y is the mesh, chunks of its own list
     for (int c = flat ? wave : (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); ; c += n_waves) {
@@ -1290,12 +1428,6 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
         const int is_ = valid ? i : 0;
         const int f_ld = pown[is_], g_ld = plist[is_];
         const int f = valid ? f_ld : 0, g = valid ? g_ld : 0;
-        float p[9], qv[9];
-        for (int k = 0; k < 3; ++k) for (int e = 0; e < 3; ++e) {
-            p[k * 3 + e] = vb[(size_t)P.faces[f * 3 + k] * 3 + e];
-            qv[k * 3 + e] = vb[(size_t)P.faces[g * 3 + k] * 3 + e];
-        }
-        float loss = 0.f, g9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         // BVH(max_collisions): a triangle with more than max_collisions partners keeps its lowest ids (k_pen_list), and a
         // pair counts only if BOTH triangles kept each other -- the kept set is symmetric, so the two lanes (f, g) and
         // (g, f) exist together and every gradient term has its owner.  Lists that were not cut hold every partner; a cut
@@ -1315,79 +1447,9 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
             const unsigned long long dead = __ballot(valid && !sym);
             if (dead && lane == 0) atomicAdd(&P.stats[b * PEN_STATS + 15], __popcll(dead));
         }
-        if (sym) {
-            const V3 P0 = {p[0], p[1], p[2]}, P1 = {p[3], p[4], p[5]}, P2 = {p[6], p[7], p[8]};
-            const V3 Q[3] = {{qv[0], qv[1], qv[2]}, {qv[3], qv[4], qv[5]}, {qv[6], qv[7], qv[8]}};
-            if constexpr (!P2P) {
-            {   // (1) this triangle receives the partner's vertices: the loss, and its gradient through the own cone's geometry
-                const ConeGeo g = cone_geometry(P0, P1, P2);
-                V3 go = {0.f, 0.f, 0.f}, gn = {0.f, 0.f, 0.f}; float gr = 0.f;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    V3 gd, gnk; float grk;
-                    loss += cone_penalty(g.o, g.r, g.n, Q[k], sigma, penalize_outside, gd, gnk, grk);
-                    go = go - gd; gn = gn + gnk; gr += grk;            // d = v - o
-                }
-                V3 g0, g1, g2;
-                cone_geometry_adj(g, go, gr, gn, g0, g1, g2);
-                g9[0] += g0.x; g9[1] += g0.y; g9[2] += g0.z; g9[3] += g1.x; g9[4] += g1.y; g9[5] += g1.z; g9[6] += g2.x; g9[7] += g2.y; g9[8] += g2.z;
-            }
-            {   // (2) this triangle's vertices intrude into the partner's cone (partner geometry constant): d / d v = d / d d
-                const ConeGeo g = cone_geometry(Q[0], Q[1], Q[2]);
-                const V3 Pk[3] = {P0, P1, P2};
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    V3 gd, gnk; float grk;
-                    (void)cone_penalty(g.o, g.r, g.n, Pk[k], sigma, penalize_outside, gd, gnk, grk);
-                    g9[k * 3] += gd.x; g9[k * 3 + 1] += gd.y; g9[k * 3 + 2] += gd.z;
-                }
-            }
-            } else {
-                const ConeGeo gf = cone_geometry(P0, P1, P2), gg = cone_geometry(Q[0], Q[1], Q[2]);
-                const float dt = vdot(gf.n, gg.n), c = dt * dt;
-                // (1) own cone at the partner's vertices: value S1, adjoint with respect to the own (o, r, n)
-                V3 go = {0.f, 0.f, 0.f}, gn = {0.f, 0.f, 0.f}; float gr = 0.f, S1 = 0.f, S2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    V3 gd, gnk; float grk;
-                    S1 += cone_penalty(gf.o, gf.r, gf.n, Q[k], sigma, penalize_outside, gd, gnk, grk);
-                    go = go - gd; gn = gn + gnk; gr += grk;
-                }
-                // (2) the partner's cone at the own vertices: value S2 (owned as a LOSS by the lane (g, f)), d / d v = d / d d
-                const V3 Pk[3] = {P0, P1, P2};
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    V3 gd, gnk; float grk;
-                    S2 += cone_penalty(gg.o, gg.r, gg.n, Pk[k], sigma, penalize_outside, gd, gnk, grk);
-                    g9[k * 3] += c * gd.x; g9[k * 3 + 1] += c * gd.y; g9[k * 3 + 2] += c * gd.z;
-                }
-                loss += c * S1;
-                // c = (n_f . n_g)^2 multiplies both sums: d c / d n_f = 2 (n_f . n_g) n_g
-                gn = gn * c + gg.n * ((S1 + S2) * 2.f * dt);
-                V3 g0, g1, g2;
-                cone_geometry_adj(gf, go * c, gr * c, gn, g0, g1, g2);
-                g9[0] += g0.x; g9[1] += g0.y; g9[2] += g0.z; g9[3] += g1.x; g9[4] += g1.y; g9[5] += g1.z; g9[6] += g2.x; g9[7] += g2.y; g9[8] += g2.z;
-            }
-        }
-        // sum over the pairs of one triangle that sit in this wavefront (they are adjacent lanes): segmented
-        // inclusive scan, then the last lane of every run stores the run's sum at its own list position
         float v[10];
-#pragma unroll
-        for (int j = 0; j < 9; ++j) v[j] = g9[j];
-        v[9] = loss;
-        const int fkey = valid ? f : -1;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int fu = __shfl_up(fkey, d);
-            const bool take = lane >= d && fu == fkey;
-#pragma unroll
-            for (int j = 0; j < 10; ++j) { const float vu = __shfl_up(v[j], d); if (take) v[j] += vu; }
-        }
-        const int fnext = __shfl_down(fkey, 1);
-        if (valid && (lane == 63 || fnext != fkey)) {
-#pragma unroll
-            for (int j = 0; j < 10; ++j) po[(size_t)j * P.pair_cap + i] = v[j];
-        }
+        pen_pair_eval<P2P>(P, vb, f, g, sym, sigma, penalize_outside, v);
+        pen_run_sums(v, valid ? f : -1, valid, lane, po, P.pair_cap, i);
     }
 }
 
@@ -1396,9 +1458,26 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
 // a range adds the (1 + range / 64) chunk sums in ascending order.
 // (Round 4 tried these sums inside k_pen_gather, per incident corner: one launch fewer, but every corner then walks two
 //  dependent loads and its chunk loop on the lane's own chain -- 75 us against 36 + 11 for the two kernels.  Kept apart.)
+// the sums of one triangle's pair range [i, i + n) from the run sums k_pen_eval / k_pen_frame left per 64-pair chunk of the list
+__device__ __forceinline__ void pen_face_sum(const float* __restrict__ po, const int pair_cap, const int i, const int n, float* __restrict__ tg /* [9] */,
+                                             float* __restrict__ tl) {
+    float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int end = i + n - 1;
+    for (int c = i >> 6; c <= end >> 6; ++c) {           // one run sum per 64-pair chunk of the range
+        const int q = min(end, c * 64 + 63);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) acc[j] += po[(size_t)j * pair_cap + q];
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) tg[j] = acc[j];
+    *tl = acc[9];
+}
 __global__ __launch_bounds__(256)
-void k_pen_facesum(PenDev P) {
-    const int b = blockIdx.y;
+void k_pen_facesum(PenDev P, PenSel sel) {
+    const int nsel = pen_sel_n(sel, sel.hlist ? 0x7fffffff : (int)gridDim.y);
+    for (int si = blockIdx.y; si < nsel; si += gridDim.y) {
+    const int b = pen_sel_col(sel, si);
+    if (!pen_sel_on(sel, b)) continue;
     const int total = P.ptotal[b];
     const int* pown = P.pown + (size_t)b * P.pair_cap;
     const int* pc = P.pcount + (size_t)b * P.F;
@@ -1406,18 +1485,8 @@ void k_pen_facesum(PenDev P) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int f = pown[i];
         if (i > 0 && pown[i - 1] == f) continue;
-        const int n = min(pc[f], total - i);
-        float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const int end = i + n - 1;
-        for (int c = i >> 6; c <= end >> 6; ++c) {           // k_pen_eval left one run sum per 64-pair chunk of the range
-            const int q = min(end, c * 64 + 63);
-#pragma unroll
-            for (int j = 0; j < 10; ++j) acc[j] += po[(size_t)j * P.pair_cap + q];
-        }
-        float* tg = P.tgrad + ((size_t)b * P.F + f) * 9;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) tg[j] = acc[j];
-        P.tloss[(size_t)b * P.F + f] = acc[9];
+        pen_face_sum(po, P.pair_cap, i, min(pc[f], total - i), P.tgrad + ((size_t)b * P.F + f) * 9, P.tloss + (size_t)b * P.F + f);
+    }
     }
 }
 
@@ -1425,74 +1494,494 @@ void k_pen_facesum(PenDev P) {
 // triangles in index order (independent of where a pair sits in the list).  When the caller is a fitting batch the lane
 // that has formed g(v) goes on to d v_posed = T^T g, the operand of the adjoint GEMM (a launch of its own, k_adj_prep,
 // until round 4).
-__global__ __launch_bounds__(256)
-void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss_out, const int* __restrict__ want, PenAdjPrep ap) {
-    __shared__ float red[4];
-    extern __shared__ unsigned s_hasp[];        // [hasp_words] triangles of this frame that have pairs
-    const int b = blockIdx.y;
-    if (want && !want[b]) { if (blockIdx.x == 0 && threadIdx.x == 0) loss_out[b] = 0.f; return; }
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    const int total = P.ptotal[b];
-    for (int w = threadIdx.x; w < P.hasp_words; w += 256) s_hasp[w] = P.hasp[(size_t)b * P.hasp_words + w];
-    __syncthreads();
+// g(v) of one vertex and what follows from it (shared by k_pen_gather, every vertex, and k_pen_frame, the vertices of triangles
+// that have pairs -- the others' rows are zeroed by k_pen_g1).  s_hasp: the frame's "triangle has pairs" bits in LDS.
+__device__ __forceinline__ void pen_vertex_out(const PenDev& P, const int b, const int v, const int total, const unsigned* s_hasp,
+                                               float* __restrict__ dverts, const PenAdjPrep& ap) {
     auto has = [&](int face) { return (s_hasp[face >> 5] >> (face & 31)) & 1u; };
-    if (v < P.V) {
-        float g[3] = {0.f, 0.f, 0.f};
-        if (total > 0) {
-            const float* tg = P.tgrad + (size_t)b * P.F * 9;
-            // (the incident corners in batches of 8 -- a vertex of a closed mesh has ~6 -- so that the three dependent
-            //  loads per corner overlap across the corners instead of forming one chain per corner; same summation order)
-            const int q0 = P.vf_start[v], q1 = P.vf_start[v + 1];
-            for (int qb = q0; qb < q1; qb += 8) {
-                int fc[8]; bool use[8];
+    float g[3] = {0.f, 0.f, 0.f};
+    if (total > 0) {
+        const float* tg = P.tgrad + (size_t)b * P.F * 9;
+        // (the incident corners in batches of 8 -- a vertex of a closed mesh has ~6 -- so that the three dependent
+        //  loads per corner overlap across the corners instead of forming one chain per corner; same summation order)
+        const int q0 = P.vf_start[v], q1 = P.vf_start[v + 1];
+        for (int qb = q0; qb < q1; qb += 8) {
+            int fc[8]; bool use[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int l_ = P.vf_list[min(qb + u, q1 - 1)]; fc[u] = qb + u < q1 ? l_ : -1; }      // (unconditional loads)
+            for (int u = 0; u < 8; ++u) { const int l_ = P.vf_list[min(qb + u, q1 - 1)]; fc[u] = qb + u < q1 ? l_ : -1; }      // (unconditional loads)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) use[u] = fc[u] >= 0 && has(fc[u] / 3);      // (2.6 KB of bits in LDS instead of two gathers per corner)
-                float tv[8][3];
+            for (int u = 0; u < 8; ++u) use[u] = fc[u] >= 0 && has(fc[u] / 3);      // (2.6 KB of bits in LDS instead of two gathers per corner)
+            float tv[8][3];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 8; ++u)
 #pragma unroll
-                    for (int e = 0; e < 3; ++e) tv[u][e] = use[u] ? tg[(size_t)fc[u] * 3 + e] : 0.f;      // fc = face * 3 + corner -> [face][corner][3]
+                for (int e = 0; e < 3; ++e) tv[u][e] = use[u] ? tg[(size_t)fc[u] * 3 + e] : 0.f;      // fc = face * 3 + corner -> [face][corner][3]
 #pragma unroll
-                for (int u = 0; u < 8; ++u) if (use[u]) { g[0] += tv[u][0]; g[1] += tv[u][1]; g[2] += tv[u][2]; }
-            }
-        }
-        for (int e = 0; e < 3; ++e) dverts[((size_t)b * P.V + v) * 3 + e] = g[e];
-        if (ap.adj_G) {         // d v_posed(v) = T(v)[:3,:3]^T g(v),  T(v) = sum_j W[v][j] A_j  (zeros where g = 0)
-            float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-            if (g[0] != 0.f || g[1] != 0.f || g[2] != 0.f) {
-                const size_t Bp = (size_t)ap.Bpad;
-                float T[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                auto add = [&](const int j, const float w) {
-#pragma unroll
-                    for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) T[rr * 3 + c] += w * ap.AT[((size_t)(rr * 4 + c) * SFX_JPAD + j) * Bp + b];
-                };
-                const int* wj = ap.Wsp_j + (size_t)v * SFX_NW;
-                if (wj[0] >= 0) {
-                    const float* ww = ap.Wsp_w + (size_t)v * SFX_NW;
-                    for (int q = 0; q < SFX_NW; ++q) if (ww[q] != 0.f) add(wj[q], ww[q]);
-                } else {
-                    for (int j = 0; j < SFX_J; ++j) { const float w = ap.W[(size_t)v * SFX_J + j]; if (w != 0.f) add(j, w); }
-                }
-                o0 = T[0] * g[0] + T[3] * g[1] + T[6] * g[2];
-                o1 = T[1] * g[0] + T[4] * g[1] + T[7] * g[2];
-                o2 = T[2] * g[0] + T[5] * g[1] + T[8] * g[2];
-            }
-            float* o = ap.adj_G + (size_t)b * 3 * ap.Vpad + (size_t)v * 3;
-            o[0] = o0; o[1] = o1; o[2] = o2;
+            for (int u = 0; u < 8; ++u) if (use[u]) { g[0] += tv[u][0]; g[1] += tv[u][1]; g[2] += tv[u][2]; }
         }
     }
+    for (int e = 0; e < 3; ++e) dverts[((size_t)b * P.V + v) * 3 + e] = g[e];
+    if (ap.adj_G) {         // d v_posed(v) = T(v)[:3,:3]^T g(v),  T(v) = sum_j W[v][j] A_j  (zeros where g = 0)
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        if (g[0] != 0.f || g[1] != 0.f || g[2] != 0.f) {
+            const size_t Bp = (size_t)ap.Bpad;
+            float T[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            auto add = [&](const int j, const float w) {
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) T[rr * 3 + c] += w * ap.AT[((size_t)(rr * 4 + c) * SFX_JPAD + j) * Bp + b];
+            };
+            const int* wj = ap.Wsp_j + (size_t)v * SFX_NW;
+            if (wj[0] >= 0) {
+                const float* ww = ap.Wsp_w + (size_t)v * SFX_NW;
+                for (int q = 0; q < SFX_NW; ++q) if (ww[q] != 0.f) add(wj[q], ww[q]);
+            } else {
+                for (int j = 0; j < SFX_J; ++j) { const float w = ap.W[(size_t)v * SFX_J + j]; if (w != 0.f) add(j, w); }
+            }
+            o0 = T[0] * g[0] + T[3] * g[1] + T[6] * g[2];
+            o1 = T[1] * g[0] + T[4] * g[1] + T[7] * g[2];
+            o2 = T[2] * g[0] + T[5] * g[1] + T[8] * g[2];
+        }
+        float* o = ap.adj_G + (size_t)b * 3 * ap.Vpad + (size_t)v * 3;
+        o[0] = o0; o[1] = o1; o[2] = o2;
+    }
+}
+// the frame's loss: triangles with pairs in index order, dealt to 256 lanes, lanes and wavefronts combined in a fixed order
+// (called by the first 256 threads of a workgroup; red: 4 floats of LDS; contains a barrier: every thread of the FIRST FOUR
+// wavefronts must arrive -- the callers make the call wave-uniform)
+__device__ __forceinline__ float pen_frame_loss_partial(const PenDev& P, const int b, const int total, const unsigned* s_hasp, const int t256) {
+    float s = 0.f;
+    if (total > 0) for (int f = t256; f < P.F; f += 256)
+        if ((s_hasp[f >> 5] >> (f & 31)) & 1u) s += P.tloss[(size_t)b * P.F + f];
+    return wave_sum_dpp(s);
+}
+
+__global__ __launch_bounds__(256)
+void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss_out, PenSel sel, PenAdjPrep ap) {
+    __shared__ float red[4];
+    extern __shared__ unsigned s_hasp[];        // [hasp_words] triangles of this frame that have pairs
+    const int nsel = pen_sel_n(sel, sel.hlist ? 0x7fffffff : (int)gridDim.y);
+    for (int si = blockIdx.y; si < nsel; si += gridDim.y) {
+    const int b = pen_sel_col(sel, si);
+    if (!pen_sel_on(sel, b)) { if (blockIdx.x == 0 && threadIdx.x == 0) loss_out[b] = 0.f; continue; }
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const int total = P.ptotal[b];
+    __syncthreads();                            // (the previous column's readers of the bits are done)
+    for (int w = threadIdx.x; w < P.hasp_words; w += 256) s_hasp[w] = P.hasp[(size_t)b * P.hasp_words + w];
+    __syncthreads();
+    if (v < P.V) pen_vertex_out(P, b, v, total, s_hasp, dverts, ap);
     if (blockIdx.x == 0) {
-        float s = 0.f;
-        if (total > 0) for (int f = threadIdx.x; f < P.F; f += 256)
-            if (has(f)) s += P.tloss[(size_t)b * P.F + f];
-        s = wave_sum_dpp(s);
+        const float s = pen_frame_loss_partial(P, b, total, s_hasp, threadIdx.x);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         __syncthreads();
         if (threadIdx.x == 0) loss_out[b] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
+    }
+}
+
+// =============================================================================================
+// Round 5: the whole term of ONE column behind the triangle boxes in one workgroup.
+//
+// On the mesh the reference evaluates (the SMPL-X topology with smplx_parts_segm.pkl; tests/golden/smplx_topology.npz) the part
+// boxes turn away 88 % of the triangles before the grid, ~2 500 survivors make ~6 200 grid entries and ~1 700 ordered pairs per
+// evaluation: two orders of magnitude below what the ten general kernels above are dimensioned for, each of which paid a launch,
+// a pass over all F triangles or V vertices, and its own round trips (k_pen_g2 41 us, k_pen_g3 25, k_pen_walk 29 + 20,
+// k_pen_list 17, k_pen_rank 60, k_pen_eval 12, k_pen_facesum 8, k_pen_gather 28 = 240 us per round of the halpe cfg's fit).
+// k_pen_frame does the same steps for a column with the column's data in LDS:
+//   A  part culling + one (triangle, cell) record per cell of a survivor's box     (k_pen_g2: coalesced pass over the F boxes)
+//   B  counting sort of the records into the hashed grid                           (k_pen_g3, unchanged: 2 x 64 KB of LDS)
+//   C  pair tests, a block of 64 entries per wavefront, 16 wavefronts              (k_pen_walk's chunk walk; bucket ends from LDS)
+//      accepted pairs -> one list of the frame (global scratch; the per-triangle partner lists are not used)
+//   D  both orders of every pair as 32-bit keys f * F + g, bitonic sort in LDS, rank within a triangle's run: the max_collisions
+//      LOWEST partners are kept -> the frame's pair list, triangles ascending, partners ascending   (k_pen_list + k_pen_rank)
+//   E  pair evaluation per 64-aligned chunk of that list (pen_pair_eval, pen_run_sums: the general kernels' functions)
+//   F  per-triangle sums (pen_face_sum)
+//   G  gradient of the vertices of triangles that have pairs (pen_vertex_out) -- the other rows were zeroed by k_pen_g1 --,
+//      d v_posed = T^T g, the frame's loss (pen_frame_loss_partial)
+// Every number is formed by the same fp32 operations in the same order as in the ten-kernel form (sfx_debug_pen_form(0)): the
+// pair list is canonical, the sums are defined on it; tests/test_gpu_topology.py, tests/test_gpu_penetration.py compare bit for bit.
+// A column that does not fit -- more than PEN_FE grid entries, a bucket beyond PEN_FB entries (a limb pushed through another by a
+// trial step of the line search), more than PEN_FP pairs -- is handed to the general kernels ("heavy": P.heavy / P.hlist), which
+// run on the compact list of such columns and end after one load when it is empty.
+#define PEN_FE 16384            // grid entries of a column on the fast path
+#define PEN_FB 256              // longest bucket on the fast path (chunks 0..3 of a block's walk)
+#define PEN_FP 8192             // unordered pairs on the fast path: 2 x PEN_FP sort keys = 64 KB of LDS
+#define PEN_FW 16               // wavefronts of the workgroup
+#define PEN_HEAVY_ROWS 8        // grid rows of the general kernels when they work on the handed-over columns (they loop over the list)
+#define PEN_FRAME_LDS ((PEN_GRID_INTS + PEN_CELLS + PEN_FW * 256) * 4)        // cells | part masks -> windows -> sort keys | pair queues
+
+__device__ __forceinline__ int pen_block_excl_scan_max(const int v, int* wmax /* [PEN_T / 64] */) {      // exclusive prefix MAX over the block's lanes (values >= -1)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc = max(inc, o); }
+    __syncthreads();
+    if (lane == 63) wmax[wv] = inc;
+    __syncthreads();
+    int base = -1;
+    for (int i = 0; i < wv; ++i) base = max(base, wmax[i]);
+    const int prev = __shfl_up(inc, 1);
+    return max(base, lane > 0 ? prev : -1);
+}
+
+template <bool P2P>
+__global__ __launch_bounds__(PEN_T)
+void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, const int penalize_outside, float* __restrict__ dverts,
+                 float* __restrict__ loss_out, const int* __restrict__ want, PenAdjPrep ap, const int force_heavy) {
+    extern __shared__ int lds[];
+    int* cell_cnt = lds;                                            // [PEN_GRID_INTS] histogram -> start offsets -> cursors -> bucket ENDS
+    unsigned* pmask = reinterpret_cast<unsigned*>(lds + PEN_GRID_INTS);      // [PEN_CELLS] parts present per bucket (phase B)
+    int* r1 = lds + PEN_GRID_INTS;                                  // the same 64 KB: windows (C), sort keys / pair list (D-F), scratch (G)
+    int* s_queue = lds + PEN_GRID_INTS + PEN_CELLS;                 // [PEN_FW][256] pair queues of the wavefronts (C)
+    __shared__ unsigned long long s_mask[64], s_near[64];
+    __shared__ int s_pbox[64][6];
+    __shared__ unsigned s_coll32[64];
+    __shared__ int slice[PEN_T];
+    __shared__ float red[PEN_T / 64];
+    __shared__ int s_cnt, s_ccnt, s_total, s_maxb, s_npairs, s_dead;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int F = P.F;
+    int* st = P.stats + b * PEN_STATS;
+    int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
+    if (t == 0) { P.wqn[b] = 0; P.heavy[b] = 0; }
+    if (want && !want[b]) {                     // the frame's stage carries no collision weight: nothing to do
+        if (t == 0) { P.ptotal[b] = 0; cells[PEN_CELLS] = 0; st[0] = st[1] = st[2] = st[3] = 0; st[13] = 0; st[15] = 0; loss_out[b] = 0.f;
+                      if (P.over) P.over[b] = 0; }
+        return;
+    }
+    const float* aabb = P.aabb + (size_t)b * F * 6;
+    int2* cand = P.cand + (size_t)b * P.ent_cap;
+    const PenGridCtx C = pen_grid_ctx(P, b);
+    // ---------------------------------------------------------------- A: part culling, candidate records (k_pen_g2)
+    if (t == 0) { float* gp = P.gridp + b * 4; gp[0] = C.glo[0]; gp[1] = C.glo[1]; gp[2] = C.glo[2]; gp[3] = C.ih; s_cnt = 0; s_ccnt = 0; s_npairs = 0; s_dead = 0; }
+    if (t < 64) {
+        s_mask[t] = P.skipmask[t];
+        for (int e = 0; e < 6; ++e) s_pbox[t][e] = P.pbox[((size_t)b * 64 + t) * 6 + e];
+    }
+    for (int c = t; c <= PEN_CELLS; c += PEN_T) cell_cnt[c] = 0;
+    for (int c = t; c < PEN_CELLS; c += PEN_T) pmask[c] = 0u;
+    __syncthreads();
+    if (t < 64) {       // parts whose boxes meet and that may collide, as one 64-bit word per part
+        unsigned long long m = 0;
+        if (t < P.n_parts && s_pbox[t][0] <= s_pbox[t][3]) {
+            const unsigned long long sk = s_mask[t];
+            for (int q = 0; q < P.n_parts; ++q) {
+                const bool meet = s_pbox[t][0] <= s_pbox[q][3] && s_pbox[q][0] <= s_pbox[t][3] && s_pbox[t][1] <= s_pbox[q][4] &&
+                                  s_pbox[q][1] <= s_pbox[t][4] && s_pbox[t][2] <= s_pbox[q][5] && s_pbox[q][2] <= s_pbox[t][5];
+                if (meet && !((sk >> q) & 1ull)) m |= 1ull << q;
+            }
+        }
+        s_near[t] = m;
+    }
+    pen_coll32(P, s_coll32);                    // (ends with a barrier)
+    // the part boxes are read: leave them empty for the next evaluation of this column (k_pen_g1 accumulates into them)
+    if (t < 64 * 6) P.pbox[(size_t)b * 64 * 6 + t] = (t % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+    for (int fb = 0; fb < F; fb += PEN_T * PEN_GU) {
+        float bx[PEN_GU][6]; int seg[PEN_GU];
+#pragma unroll
+        for (int u = 0; u < PEN_GU; ++u) {
+            const int f = fb + u * PEN_T + t, ff = f < F ? f : 0;
+            seg[u] = P.segm[ff];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) bx[u][e] = aabb[ff * 6 + e];
+        }
+#pragma unroll
+        for (int u = 0; u < PEN_GU; ++u) {
+            const int f = fb + u * PEN_T + t;
+            bool any = false;
+            unsigned long long nm = f < F ? s_near[seg[u]] : 0ull;
+            if (nm) {
+                int a6[6];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) a6[e] = pen_ford(bx[u][e]);
+                while (nm && !any) {
+                    const int q = __ffsll((long long)nm) - 1;
+                    nm &= nm - 1;
+                    const int* pb = s_pbox[q];
+                    any = (a6[0] <= pb[3]) & (pb[0] <= a6[3]) & (a6[1] <= pb[4]) & (pb[1] <= a6[4]) & (a6[2] <= pb[5]) & (pb[2] <= a6[5]);
+                }
+            }
+            int2 pk = make_int2(0, 0);
+            if (any) {
+                int c0[3], sp[3];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) { c0[e] = pen_cell_of(C, bx[u][e], e); sp[e] = min(pen_cell_of(C, bx[u][3 + e], e), c0[e] + PEN_SPAN - 1) - c0[e]; }
+                pk.x = (c0[0] & 1023) | ((c0[1] & 1023) << 10) | ((c0[2] & 1023) << 20) | (int)0x80000000;
+                pk.y = sp[0] | (sp[1] << 3) | (sp[2] << 6) | (seg[u] << 9);
+            }
+            const unsigned long long m = __ballot(any);
+            const int nc = any ? ((pk.y & 7) + 1) * (((pk.y >> 3) & 7) + 1) * (((pk.y >> 6) & 7) + 1) : 0;
+            const int inc = wave_incl_scan_dpp(nc);
+            const int wtot = __builtin_amdgcn_readlane(inc, 63);
+            int wo = 0;
+            if (lane == 0 && m) { atomicAdd(&s_cnt, __popcll(m)); wo = atomicAdd(&s_ccnt, wtot); }
+            int pos = __builtin_amdgcn_readfirstlane(wo) + inc - nc;
+            if (pk.x < 0) {
+                const int pf = (pk.y >> 9) & 63;
+                pen_for_cells(pk, [&](int, int key, int lowz) {
+                    if (pos < P.ent_cap) cand[pos] = make_int2(f | (pf << 24) | (lowz << 30), key);
+                    ++pos;
+                });
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int NT = min(s_cnt, F), NC_raw = s_ccnt, NC = min(NC_raw, P.ent_cap);
+    // ---------------------------------------------------------------- B: counting sort into the hashed grid (k_pen_g3)
+    constexpr int U2 = 8;
+    auto cell_bucket = [](const int key) { return pen_bucket(key & 1023, (key >> 10) & 1023, (key >> 20) & 1023); };
+    for (int i0 = t; i0 < NC; i0 += PEN_T * U2) {
+        int2 r[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) { const int i = i0 + u * PEN_T; r[u] = cand[i < NC ? i : 0]; }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) if (i0 + u * PEN_T < NC) atomicOr(&pmask[cell_bucket(r[u].y)], 1u << ((r[u].x >> 24) & 31));
+    }
+    __syncthreads();
+    for (int i0 = t; i0 < NC; i0 += PEN_T * U2) {
+        int2 r[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) { const int i = i0 + u * PEN_T; r[u] = cand[i < NC ? i : 0]; }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const int bk = cell_bucket(r[u].y);
+            if (i0 + u * PEN_T < NC && (pmask[bk] & s_coll32[(r[u].x >> 24) & 63])) atomicAdd(&cell_cnt[bk], 1);
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int per = PEN_CELLS / PEN_T;
+        int* row0 = cell_cnt + wv * (64 * per) + lane;
+        int ex[per], carry = 0, mx = 0;
+#pragma unroll
+        for (int i = 0; i < per; ++i) {
+            const int v = row0[i * 64];
+            mx = max(mx, v);
+            const int inc = wave_incl_scan_dpp(v);
+            ex[i] = carry + inc - v;
+            carry += __builtin_amdgcn_readlane(inc, 63);
+        }
+        mx = (int)wave_max_dpp((float)mx);              // (counts < 2^24: exact)
+        if (lane == 0) { slice[wv] = carry; slice[PEN_FW + wv] = mx; }
+        __syncthreads();
+        int base = 0, tot = 0, mb = 0;
+        for (int i = 0; i < PEN_T / 64; ++i) { const int x = slice[i]; if (i < wv) base += x; tot += x; mb = max(mb, slice[PEN_FW + i]); }
+#pragma unroll
+        for (int i = 0; i < per; ++i) row0[i * 64] = base + ex[i];
+        if (t == 0) { cell_cnt[PEN_CELLS] = tot; s_total = tot; s_maxb = mb; }
+        __syncthreads();
+    }
+    int2* ent = P.entries + (size_t)b * P.ent_cap;
+    const int n_ent = s_total;
+    const bool ent_ok = n_ent <= P.ent_cap - 4 && NC_raw <= P.ent_cap;
+    if (t == 0) { st[2] = ent_ok ? 0 : max(n_ent, NC_raw); st[3] = PEN_CELLS; st[13] = 0; st[14] = n_ent; st[15] = 0; for (int q = 4; q < 13; ++q) st[q] = 0;
+                  for (int q = 16; q < PEN_STATS; ++q) st[q] = 0;
+                  if (P.work) { atomicAdd(&P.work[0], (unsigned long long)n_ent); atomicAdd(&P.work[2], 1ull); atomicAdd(&P.work[3], (unsigned long long)NT); } }
+    if (!ent_ok) {       // grid too crowded for the entry buffer: report, produce no pairs (the gradient rows are zero already)
+        if (t == 0) { st[0] = 0; st[1] = 0; P.ptotal[b] = 0; cells[PEN_CELLS] = 0; loss_out[b] = 0.f; if (P.over) P.over[b] = 0; }
+        return;
+    }
+    for (int i0 = t; i0 < NC; i0 += PEN_T * U2) {
+        int2 r[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) { const int i = i0 + u * PEN_T; r[u] = cand[i < NC ? i : 0]; }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const int bk = cell_bucket(r[u].y);
+            if (i0 + u * PEN_T < NC && (pmask[bk] & s_coll32[(r[u].x >> 24) & 63])) ent[atomicAdd(&cell_cnt[bk], 1)] = r[u];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // the general kernels take over from the sorted grid
+    auto hand_over = [&]() {
+        for (int c = t; c <= PEN_CELLS; c += PEN_T) cells[c] = cell_cnt[c];
+        if (t == 0) { P.heavy[b] = 1; P.hlist[atomicAdd(P.nheavy, 1)] = b; }
+    };
+    if (force_heavy || !P.fast_ok || n_ent > PEN_FE || s_maxb > PEN_FB) { hand_over(); return; }
+    // ---------------------------------------------------------------- C: pair tests (k_pen_walk's chunk walk)
+    {
+        PenWalkCtx W;
+        W.tA = reinterpret_cast<int4*>(r1 + wv * PEN_WIN * 8); W.tB = W.tA + PEN_WIN;
+        W.queue = s_queue + wv * 256; W.qn = 0; W.s_mask = s_mask;
+        int2* pbuf = P.pbuf + (size_t)b * P.pf_cap;
+        auto flush = [&](PenWalkCtx& W_) {
+            const int n = W_.qn;
+            if (!n) return;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+            for (int q0 = 0; q0 < n; q0 += 64) {
+                const int q = q0 + lane;
+                bool keep = false; int fa = 0, fb_ = 0;
+                if (q < n) {
+                    fa = W_.queue[2 * q]; fb_ = W_.queue[2 * q + 1];
+                    const int4 va = P.faces4[fa], vb = P.faces4[fb_];      // triangles that share a vertex do not collide
+                    keep = !(va.x == vb.x || va.x == vb.y || va.x == vb.z || va.y == vb.x || va.y == vb.y || va.y == vb.z ||
+                             va.z == vb.x || va.z == vb.y || va.z == vb.z);
+                }
+                const unsigned long long m = __ballot(keep);
+                if (!m) continue;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_npairs, __popcll(m));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (keep && pos < P.pf_cap) pbuf[pos] = make_int2(fa, fb_);
+            }
+            __builtin_amdgcn_wave_barrier();
+            W_.qn = 0;
+        };
+        for (int i0 = wv * 64; i0 < n_ent; i0 += PEN_FW * 64) {
+            int hdr[8];
+            const PenOwn O = pen_own(P, b, i0, n_ent, W, lane, hdr, cell_cnt);
+            const int bend_max = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)O.bend));
+            const int dmax = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)max(O.bend - 1 - O.qi, 0)));
+            const int kmax = dmax > 64 ? (dmax - 1) >> 6 : 0;          // (buckets <= PEN_FB: kmax < PEN_FB / 64 <= PEN_MAX_CHUNK)
+            for (int k = 0; k <= kmax; ++k) pen_walk_chunk(P, b, i0, k, bend_max, O, hdr, W, lane, flush);
+            __builtin_amdgcn_wave_barrier();
+        }
+        flush(W);
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int npairs = s_npairs;
+    if (npairs > P.pf_cap) { hand_over(); return; }
+    // ---------------------------------------------------------------- D: the pair list (k_pen_list + k_pen_rank)
+    unsigned* keys = reinterpret_cast<unsigned*>(r1);               // [np] both orders of every pair, then the kept list in place
+    unsigned* bits = reinterpret_cast<unsigned*>(cell_cnt);         // the grid is done with: [hw] cut lists | [hw] has pairs | [vw] touched vertices | vertex list
+    const int hw = P.hasp_words, vw = (P.V + 31) >> 5;
+    unsigned* cutb = bits; unsigned* hasb = bits + hw; unsigned* vtxb = bits + 2 * hw; int* vlist = reinterpret_cast<int*>(bits + 2 * hw + vw);
+    const int n2 = 2 * npairs;
+    int np = 64;
+    while (np < n2) np <<= 1;
+    {
+        const int2* pbuf = P.pbuf + (size_t)b * P.pf_cap;
+        for (int i = t; i < np / 2; i += PEN_T) {
+            unsigned k0 = 0xffffffffu, k1 = 0xffffffffu;
+            if (i < npairs) { const int2 pr = pbuf[i]; k0 = (unsigned)pr.x * (unsigned)F + (unsigned)pr.y; k1 = (unsigned)pr.y * (unsigned)F + (unsigned)pr.x; }
+            keys[2 * i] = k0; keys[2 * i + 1] = k1;
+        }
+        for (int w = t; w < 2 * hw + vw; w += PEN_T) bits[w] = 0u;
+    }
+    for (int k = 2; k <= np; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int i = t; i < np; i += PEN_T) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned va = keys[i], vb = keys[ixj];
+                    if ((va > vb) == ((i & k) == 0)) { keys[i] = vb; keys[ixj] = va; }
+                }
+            }
+        }
+    __syncthreads();
+    // rank within the triangle's run; the max_collisions lowest partners stay, positions by a prefix sum (every lane a contiguous range)
+    int T_ = 0;
+    {
+        const int per = (np + PEN_T - 1) / PEN_T;          // <= 16
+        const int j0 = min(n2, t * per), j1 = min(n2, j0 + per);
+        unsigned kk[16]; int fj[16];
+        int last_start = -1;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = j0 + u;
+            if (u < per && j < j1) {
+                kk[u] = keys[j]; fj[u] = (int)(kk[u] / (unsigned)F);
+                const bool start = j == 0 || (int)(keys[j - 1] / (unsigned)F) != fj[u];
+                if (start) last_start = j;
+            }
+        }
+        const int before = pen_block_excl_scan_max(last_start, slice);        // start of the run that is open when this lane's range begins
+        int cur = before, nkeep = 0, ncut = 0;
+        bool kp[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = j0 + u;
+            kp[u] = false;
+            if (u < per && j < j1) {
+                const bool start = j == 0 || (u > 0 ? fj[u - 1] != fj[u] : cur < 0 || (int)(keys[j - 1] / (unsigned)F) != fj[u]);
+                if (start) cur = j;
+                kp[u] = j - cur < P.cap;
+                if (kp[u]) ++nkeep; else { ++ncut; atomicOr(&cutb[fj[u] >> 5], 1u << (fj[u] & 31)); }
+            }
+        }
+        int ptot;
+        int pos = block_excl_scan(nkeep, slice, &ptot);
+        const float cut_all = block_sum_fixed((float)ncut, red);           // (ends with a barrier: every read of the sorted keys is done)
+        T_ = ptot;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (u < per && kp[u]) keys[pos++] = kk[u];
+        if (t == 0) { P.ptotal[b] = T_; st[0] = T_; st[1] = (int)cut_all; if (P.over) P.over[b] = 0;
+                      if (P.work) atomicAdd(&P.work[1], (unsigned long long)T_); }
+    }
+    __syncthreads();
+    const int T = T_;
+    {   // the list as the diagnostics read it (sfx_pen_pairs)
+        int* pown = P.pown + (size_t)b * P.pair_cap; int* plist = P.plist + (size_t)b * P.pair_cap;
+        for (int i = t; i < T; i += PEN_T) { const unsigned k = keys[i]; const int f = (int)(k / (unsigned)F); pown[i] = f; plist[i] = (int)(k - (unsigned)f * (unsigned)F); }
+    }
+    // ---------------------------------------------------------------- E: pair evaluation, a 64-aligned chunk of the list per wavefront
+    const float* vb = verts + (size_t)b * P.V * 3;
+    float* po = P.pout + (size_t)b * 10 * P.pair_cap;
+    for (int c = wv; c * 64 < T; c += PEN_FW) {
+        const int i = c * 64 + lane;
+        const bool valid = i < T;
+        const unsigned k = keys[valid ? i : 0];
+        const int f_ = (int)(k / (unsigned)F), g_ = (int)(k - (unsigned)f_ * (unsigned)F);
+        const int f = valid ? f_ : 0, g = valid ? g_ : 0;
+        bool sym = valid;
+        if (valid && ((cutb[g >> 5] >> (g & 31)) & 1u)) {          // the partner's list was cut: did it keep this triangle?
+            const unsigned want_k = (unsigned)g * (unsigned)F + (unsigned)f;
+            int lo = 0, hi = T;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < want_k) lo = mid + 1; else hi = mid; }
+            sym = lo < T && keys[lo] == want_k;
+        }
+        {
+            const unsigned long long dead = __ballot(valid && !sym);
+            if (dead && lane == 0) atomicAdd(&s_dead, __popcll(dead));
+        }
+        float v[10];
+        pen_pair_eval<P2P>(P, vb, f, g, sym, sigma, penalize_outside, v);
+        pen_run_sums(v, valid ? f : -1, valid, lane, po, P.pair_cap, i);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (t == 0) st[15] = s_dead;
+    // ---------------------------------------------------------------- F: per-triangle sums; which triangles / vertices carry a gradient
+    for (int i = t; i < T; i += PEN_T) {
+        const unsigned k = keys[i];
+        const int f = (int)(k / (unsigned)F);
+        if (i > 0 && (int)(keys[i - 1] / (unsigned)F) == f) continue;
+        const unsigned nextf = (unsigned)(f + 1) * (unsigned)F;        // (F^2 < 2^32: no wrap for f + 1 <= F)
+        int lo = i + 1, hi = T;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < nextf) lo = mid + 1; else hi = mid; }
+        pen_face_sum(po, P.pair_cap, i, lo - i, P.tgrad + ((size_t)b * F + f) * 9, P.tloss + (size_t)b * F + f);
+        atomicOr(&hasb[f >> 5], 1u << (f & 31));
+        const int4 vf = P.faces4[f];
+        atomicOr(&vtxb[vf.x >> 5], 1u << (vf.x & 31)); atomicOr(&vtxb[vf.y >> 5], 1u << (vf.y & 31)); atomicOr(&vtxb[vf.z >> 5], 1u << (vf.z & 31));
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---------------------------------------------------------------- G: vertex gradients, d v_posed, the frame's loss
+    {
+        int nv = 0;
+        for (int w0 = 0; w0 < vw; w0 += PEN_T) {             // (vw <= PEN_T for meshes of up to 32 k vertices: one trip)
+            const int w = w0 + t;
+            const unsigned word = w < vw ? vtxb[w] : 0u;
+            int tot;
+            int pos = nv + block_excl_scan(__popc(word), slice, &tot);
+            unsigned m = word;
+            while (m) { const int bit = __ffs((int)m) - 1; m &= m - 1; vlist[pos++] = w * 32 + bit; }
+            nv += tot;
+        }
+        __syncthreads();
+        for (int q = t; q < nv; q += PEN_T) pen_vertex_out(P, b, vlist[q], T, hasb, dverts, ap);
+        if (t < 256) {
+            const float s = pen_frame_loss_partial(P, b, T, hasb, t);
+            if (lane == 0) red[wv] = s;
+        }
+        __syncthreads();
+        if (t == 0) loss_out[b] = ((red[0] + red[1]) + red[2]) + red[3];
     }
 }
 
@@ -1523,9 +2012,20 @@ extern "C" int sfx_pen_work_get(int64_t* out /* [6] */) {
     return 0;
 }
 
+// which form of the term new handles take (sfx_debug_pen_form): 1 = the per-frame kernel + the general kernels on the columns it
+// hands over (round 5, default); 0 = the ten general kernels on every column (rounds 2-4; the A/B partner: same bits);
+// 2 = form 1 with every column handed over after the grid build (exercises the hand-over on any mesh)
+static int g_pen_form = [] { const char* e = getenv("SFX_PEN_FORM"); return e ? atoi(e) : 1; }();
+extern "C" int sfx_debug_pen_form(int32_t form) {
+    const int prev = g_pen_form;
+    if (form >= 0 && form <= 2) g_pen_form = form;
+    return prev;
+}
+
 struct sfx_pen {
     PenDev P{};
     int Bmax = 0;
+    int form = 1;
     std::vector<void*> mem;
     template <typename T> T* up(const std::vector<T>& h) {
         T* d = nullptr;
@@ -1605,6 +2105,13 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     P.wq = h->zeros<int2>(B * (size_t)P.wq_cap); P.wqn = h->zeros<int>(B);
     if (!P.wq || !P.wqn) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     P.tgrad = h->zeros<float>(B * F * 9); P.tloss = h->zeros<float>(B * F);
+    h->form = g_pen_form;
+    P.heavy = h->zeros<int>(B); P.hlist = h->zeros<int>(B); P.nheavy = h->zeros<int>(1);
+    P.pbuf = reinterpret_cast<int2*>(P.partners);         // (the partner lists are unused on the fast path)
+    P.pf_cap = (int)std::min<size_t>(PEN_FP, (size_t)F * P.pcap / 2);
+    P.fast_ok = ((unsigned long long)F * (unsigned long long)F < (1ull << 32)) && (2 * ((F + 31) / 32) + (V + 31) / 32 + V <= PEN_GRID_INTS) &&
+                (size_t)2 * PEN_FP <= (size_t)P.pair_cap ? 1 : 0;
+    if (!P.heavy || !P.hlist || !P.nheavy) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tcount || !P.pbox || !P.gpart || !P.aabb || !P.entries) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.pavail || !P.ptotal || !P.ovq || !P.ovn || !P.callno) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     *out = h;
@@ -1638,39 +2145,69 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
         attr_set = true;
     }
     if ((size_t)(h->P.F + h->P.hasp_words) * sizeof(int) > 160 * 1024 - 8192) { sfx_set_error("mesh of %d faces: k_pen_list stages the counts in LDS (<= 38 k faces)", h->P.F); return -1; }
+    PenAdjPrep ap{};
+    if (prep) ap = *prep;
+    static const bool rewalk_off = [] { const char* e = getenv("SFX_PEN_REWALK_OFF"); return e && atoi(e) != 0; }();      // (A/B measurement switch)
+    h->P.no_rewalk = rewalk_off ? 1 : 0;
+    static const bool chunks_off = getenv("SFX_PEN_WALK_CHUNKS_OFF") != nullptr;      // (A/B measurement switch: same pair set either way)
+    static const bool flat_off = getenv("SFX_PEN_FLAT_OFF") != nullptr;               // (A/B measurement switch: same numbers either way)
+    int cap_pad = 64;
+    while (cap_pad < h->P.pcap) cap_pad <<= 1;
+    const int rank_rows = PEN_RANK_BLOCKS + (pen_rank_tile(h->P.pcap) > 0 && h->P.cap + 64 <= pen_rank_tile(h->P.pcap) ? PEN_RANK_HELPERS : 0);
+    const size_t rank_lds = (size_t)4 * std::min(std::max(cap_pad, 128), 2048) * sizeof(int);
+    const size_t list_lds = (size_t)(h->P.F + h->P.hasp_words) * sizeof(int);
+    PenDev Pl = h->P;
+    Pl.over = over_dev;         // (per call: the caller's per-mesh "arrival order decided" flags, or NULL)
+    const bool fused = h->form != 0 && B <= PEN_FLAT_MAXB && !chunks_off && !flat_off;
+    if (fused) {
+        // round 5: boxes -> one workgroup per column -> the general kernels on the columns handed over (usually none: each of
+        // these seven launches then ends after one load)
+        static bool frame_attr = false;
+        if (!frame_attr) {
+            if (hipFuncSetAttribute((const void*)k_pen_frame<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PEN_FRAME_LDS) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_pen_frame<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PEN_FRAME_LDS) != hipSuccess) {
+                sfx_set_error("cannot reserve LDS for k_pen_frame"); return -2; }
+            frame_attr = true;
+        }
+        hipLaunchKernelGGL(k_pen_g1, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, verts_dev, want_dev, dverts_dev, ap.adj_G, ap.Vpad);
+        if (h->P.p2p) hipLaunchKernelGGL(k_pen_frame<true>, dim3(B), dim3(PEN_T), PEN_FRAME_LDS, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, h->form == 2 ? 1 : 0);
+        else hipLaunchKernelGGL(k_pen_frame<false>, dim3(B), dim3(PEN_T), PEN_FRAME_LDS, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, h->form == 2 ? 1 : 0);
+        const PenSel hv{nullptr, h->P.hlist, h->P.nheavy, h->P.heavy};
+        const int HY = std::min(B, PEN_HEAVY_ROWS);
+        hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, HY), dim3(256), 0, s, h->P, hv);
+        hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, B, hv);
+        hipLaunchKernelGGL(k_pen_list, dim3(HY), dim3(PEN_T), list_lds, s, Pl, hv);
+        hipLaunchKernelGGL(k_pen_rank, dim3(rank_rows, HY), dim3(256), rank_lds, s, h->P, hv, cap_pad);
+        if (h->P.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, verts_dev, sigma, penalize_outside, B, 1, hv);
+        else hipLaunchKernelGGL(k_pen_eval<false>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, verts_dev, sigma, penalize_outside, B, 1, hv);
+        hipLaunchKernelGGL(k_pen_facesum, dim3(PEN_EVAL_BLOCKS, HY), dim3(256), 0, s, h->P, hv);
+        hipLaunchKernelGGL(k_pen_gather, dim3((std::max(h->P.V, 1) + 255) / 256, HY), dim3(256), (size_t)h->P.hasp_words * sizeof(unsigned), s,
+                           h->P, dverts_dev, loss_dev, hv, ap);
+    } else {
+    const PenSel all{want_dev, nullptr, nullptr, nullptr};
     // grid build (the cross-workgroup accumulators -- part boxes, survivor counts -- are left empty by k_pen_g3 of the previous evaluation)
-    hipLaunchKernelGGL(k_pen_g1, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, verts_dev, want_dev);
+    hipLaunchKernelGGL(k_pen_g1, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, verts_dev, want_dev, (float*)nullptr, (float*)nullptr, 0);
     hipLaunchKernelGGL(k_pen_g2, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, want_dev);
     hipLaunchKernelGGL(k_pen_g3, dim3(B), dim3(PEN_T), (size_t)(PEN_GRID_INTS + PEN_CELLS) * sizeof(int), s, h->P, want_dev);
     {
-        static const bool chunks_off = getenv("SFX_PEN_WALK_CHUNKS_OFF") != nullptr;      // (A/B measurement switch: same pair set either way)
         PenDev Pw = h->P;
         const bool queued = B <= PEN_FLAT_MAXB && !chunks_off;
         if (!queued) Pw.wq_cap = 0;                // every block walks its bucket to the end itself
-        hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, Pw, want_dev);
-        if (queued) hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, Pw, B);
+        hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, Pw, all);
+        if (queued) hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, Pw, B, all);
     }
-    static const bool rewalk_off = [] { const char* e = getenv("SFX_PEN_REWALK_OFF"); return e && atoi(e) != 0; }();      // (A/B measurement switch)
-    h->P.no_rewalk = rewalk_off ? 1 : 0;
-    PenDev Pl = h->P;
-    Pl.over = over_dev;         // (per call: the caller's per-mesh "arrival order decided" flags, or NULL)
-    hipLaunchKernelGGL(k_pen_list, dim3(B), dim3(PEN_T), (size_t)(h->P.F + h->P.hasp_words) * sizeof(int), s, Pl, want_dev);
-    int cap_pad = 64;
-    while (cap_pad < h->P.pcap) cap_pad <<= 1;
-    hipLaunchKernelGGL(k_pen_rank, dim3(PEN_RANK_BLOCKS + (pen_rank_tile(h->P.pcap) > 0 && h->P.cap + 64 <= pen_rank_tile(h->P.pcap) ? PEN_RANK_HELPERS : 0), B), dim3(256), (size_t)4 * std::min(std::max(cap_pad, 128), 2048) * sizeof(int), s,
-                       h->P, want_dev, cap_pad);
-    static const bool flat_off = getenv("SFX_PEN_FLAT_OFF") != nullptr;      // (A/B measurement switch: same numbers either way)
+    hipLaunchKernelGGL(k_pen_list, dim3(B), dim3(PEN_T), list_lds, s, Pl, all);
+    hipLaunchKernelGGL(k_pen_rank, dim3(rank_rows, B), dim3(256), rank_lds, s, h->P, all, cap_pad);
     if (B <= PEN_FLAT_MAXB && !flat_off)
-        { if (h->P.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, verts_dev, sigma, penalize_outside, B, 1);
-          else hipLaunchKernelGGL(k_pen_eval<false>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, verts_dev, sigma, penalize_outside, B, 1); }
+        { if (h->P.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, verts_dev, sigma, penalize_outside, B, 1, all);
+          else hipLaunchKernelGGL(k_pen_eval<false>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, verts_dev, sigma, penalize_outside, B, 1, all); }
     else
-        { if (h->P.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside, B, 0);
-          else hipLaunchKernelGGL(k_pen_eval<false>, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside, B, 0); }
-    hipLaunchKernelGGL(k_pen_facesum, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P);
-    PenAdjPrep ap{};
-    if (prep) ap = *prep;
+        { if (h->P.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside, B, 0, all);
+          else hipLaunchKernelGGL(k_pen_eval<false>, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside, B, 0, all); }
+    hipLaunchKernelGGL(k_pen_facesum, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, all);
     hipLaunchKernelGGL(k_pen_gather, dim3((std::max(h->P.V, 1) + 255) / 256, B), dim3(256), (size_t)h->P.hasp_words * sizeof(unsigned), s,
-                       h->P, dverts_dev, loss_dev, want_dev, ap);
+                       h->P, dverts_dev, loss_dev, all, ap);
+    }
     if (hipGetLastError() != hipSuccess) { sfx_set_error("penetration kernels failed to launch"); return -4; }
     return 0;
 }
@@ -1724,6 +2261,25 @@ int sfx_pen_stats_from(const int* stats_dev, int n, int32_t* stats_host) {
 }
 int sfx_pen_stats_stride(void) { return PEN_STATS; }
 const int* sfx_pen_stats_dev(const sfx_pen* h) { return h ? h->P.stats : nullptr; }
+
+// The frame's pair list (k_pen_rank: receiving triangle ascending, partner ascending) -> HOST [cap][2]; *n_out = ordered pairs
+// in the list (may exceed cap: then the first cap are copied).  What BVH(...)(triangles) followed by FilterFaces(...) hands to the
+// loss in the reference (fitting.py:445-450) -- here both orders of every pair.
+extern "C" int sfx_pen_pairs(sfx_pen* h, int32_t mesh, int32_t cap, int32_t* pairs_host, int32_t* n_out) {
+    if (!h || !n_out || mesh < 0 || mesh >= h->Bmax || cap < 0 || (cap > 0 && !pairs_host)) { sfx_set_error("bad arguments"); return -1; }
+    if (hipDeviceSynchronize() != hipSuccess) { sfx_set_error("device error"); return -4; }
+    int tot = 0;
+    if (hipMemcpy(&tot, h->P.ptotal + mesh, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { sfx_set_error("device error"); return -4; }
+    *n_out = tot;
+    const int n = std::min(tot, cap);
+    if (n > 0) {
+        std::vector<int> a(n), b(n);
+        if (hipMemcpy(a.data(), h->P.pown + (size_t)mesh * h->P.pair_cap, (size_t)n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(b.data(), h->P.plist + (size_t)mesh * h->P.pair_cap, (size_t)n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { sfx_set_error("device error"); return -4; }
+        for (int i = 0; i < n; ++i) { pairs_host[2 * i] = a[i]; pairs_host[2 * i + 1] = b[i]; }
+    }
+    return 0;
+}
 
 extern "C" int sfx_pen_stats(sfx_pen* h, int32_t B, int32_t* stats_host /* [B][4] */) {
     if (!h || !stats_host || B < 1 || B > h->Bmax) { sfx_set_error("bad arguments"); return -1; }

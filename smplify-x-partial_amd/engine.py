@@ -356,6 +356,11 @@ class FrameBatch(object):
         capi.check(self._lib.sfx_batch_pen_stats(self._h, capi.iptr(st), capi.iptr(ext)))
         return dict(pairs=st[:, 0].copy(), dropped=st[:, 1].copy(), entry_overflow=st[:, 2].copy(), walks_cut=st[:, 3].copy(), vertices=ext)
 
+    def penetration_pairs(self, column):
+        """Ordered pair list [n, 2] (receiving triangle, partner) of GEMM column `column` in the most recent evaluation
+        (sfx_batch_pen_pairs): what BVH + FilterFaces hand to the loss in the reference (fitting.py:445-450)."""
+        return _read_pairs(lambda cap, buf, n: self._lib.sfx_batch_pen_pairs(self._h, int(column), cap, buf, n))
+
     def penetration_flags(self):
         """Per frame: True when the frame's fit consumed a collision evaluation whose pair set depended on arrival order
         (a cut bucket walk; with max_collisions > 1024 also a partner list beyond 2 x max_collisions): its result is not
@@ -464,6 +469,21 @@ def pen_work_get():
                 entries_per_column=w[0] / cols, pairs_per_column=w[1] / cols, survivors_per_column=w[3] / cols)
 
 
+def pen_form(form=-1):
+    """Debug / A-B: which form of the interpenetration term Penetration handles and FrameBatches created from now on take
+    (sfx_debug_pen_form: 1 = per-frame kernel, the default; 0 = the ten general kernels; 2 = per-frame kernel handing every
+    column over).  Returns the previous setting; any other argument only queries."""
+    return int(capi.load().sfx_debug_pen_form(int(form)))
+
+
+def _read_pairs(call):
+    n = C.c_int32(0)
+    capi.check(call(0, None, C.byref(n)))
+    out = np.zeros((max(int(n.value), 1), 2), np.int32)
+    capi.check(call(int(out.shape[0]), capi.iptr(out), C.byref(n)))
+    return out[:int(n.value)].astype(np.int64)
+
+
 class Penetration(object):
     """Interpenetration term on a batch of posed meshes (sfx_pen_*):
     BVH + FilterFaces + DistanceFieldPenetrationLoss of the reference's external package
@@ -508,6 +528,11 @@ class Penetration(object):
         out = np.zeros((B, 4), np.int32)
         capi.check(self._lib.sfx_pen_stats(self._h, int(B), capi.iptr(out)))
         return dict(pairs=out[:, 0].copy(), dropped=out[:, 1].copy(), entry_overflow=out[:, 2].copy(), walks_cut=out[:, 3].copy())
+
+    def pairs(self, mesh):
+        """Ordered pair list [n, 2] (receiving triangle, partner; receiver ascending, partner ascending) of mesh `mesh` of the
+        most recent eval(): both orders of every colliding pair, after the part filter and the max_collisions rule."""
+        return _read_pairs(lambda cap, buf, n: self._lib.sfx_pen_pairs(self._h, int(mesh), cap, buf, n))
 
     def phase_clocks(self, B):
         """Debug: microseconds at the end of the broad phase's ten steps, grid entries (see sfx_pen_phase_clocks)."""

@@ -237,6 +237,131 @@ def make_synthetic_parts(model):
     return dict(segm=segm, parents=par[segm])
 
 
+TOPOLOGY_FILE = "smplx_topology.npz"
+
+
+def load_topology(path=None):
+    """The arrays of tests/golden/smplx_topology.npz (tools/make_goldens.py smplx_topology: the SMPL-X face topology of
+    the reference's demo .ply files, `segm` / `parents` of smplifyx/smplx_parts_segm.pkl, ExPose's posed body of demo
+    frame 02) as a dict of int64 / float64 arrays.  path: the .npz, a directory holding it, or None = this repository's
+    fixture (SFX_SMPLX_TOPOLOGY overrides)."""
+    import os
+    if path is None:
+        path = os.environ.get("SFX_SMPLX_TOPOLOGY") or os.path.join(
+            os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    if os.path.isdir(path):
+        path = os.path.join(path, TOPOLOGY_FILE)
+    g = np.load(path)
+    return dict(faces=g["faces"].astype(np.int64), segm=g["segm"].astype(np.int64), parents=g["parents"].astype(np.int64),
+                vertices=g["vertices"].astype(np.float64), joints=g["joints"].astype(np.float64))
+
+
+def make_topology_model(seed=0, topology=None, dtype=np.float32, smooth_rounds=10):
+    """A body model on the REAL SMPL-X surface, as far as the reference tree holds it ("faces from the demo
+    .ply topology"): `f` = the true 20 908 faces, `v_template` = ExPose's posed body of demo frame 02 (pelvis at the
+    origin), rest joints = ExPose's first 55 joints, reproduced by a sparse non-negative row-stochastic `J_regressor`;
+    skinning weights grown from the per-face part labels of smplx_parts_segm.pkl (a vertex starts with the labels of its
+    faces; `smooth_rounds` rounds of averaging over mesh edges blend neighbouring parts; the 4 largest are kept --
+    SMPL-X's own sparsity); the 21 vertex joints are SMPL-X's real vertex ids (they reproduce ExPose's joints 55..75
+    exactly); blend shapes are smooth displacement fields (the licensed ones are absent) of the magnitudes SURVEY.md 8d
+    names; landmarks are seeded picks among the head / jaw / eye faces.  This is the mesh the interpenetration term
+    (fitting.py:437-455) is tested and benchmarked on: real triangles, real part structure, a real self-touching pose.
+    Returns the model dict (same keys as make_synthetic_model); the part labels come from topology_parts()."""
+    import scipy.sparse as sp
+    from scipy.optimize import nnls
+    from scipy.spatial import cKDTree
+    tp = load_topology(topology) if not isinstance(topology, dict) else topology
+    rng = np.random.RandomState(seed)
+    faces, segm = tp["faces"], tp["segm"]
+    J = NUM_JOINTS
+    origin = tp["joints"][0]
+    v_template = tp["vertices"] - origin
+    Jrest = tp["joints"][:J] - origin
+    V = v_template.shape[0]
+    assert V == NUM_VERTS and faces.shape == (NUM_FACES, 3) and segm.max() < J
+
+    # ---- skinning weights from the part labels -------------------------------------------------------
+    W = np.zeros((V, J))
+    for c in range(3):
+        np.add.at(W, (faces[:, c], segm), 1.0)
+    W /= W.sum(1, keepdims=True)
+    e = np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]])
+    e = np.concatenate([e, e[:, ::-1]])
+    A = sp.coo_matrix((np.ones(len(e)), (e[:, 0], e[:, 1])), shape=(V, V)).tocsr()
+    A.data[:] = 1.0
+    deg = np.asarray(A.sum(1)).ravel()
+    for _ in range(smooth_rounds):
+        W = 0.5 * W + 0.5 * (A @ W) / deg[:, None]
+    top = np.argsort(-W, 1)[:, :4]
+    weights = np.zeros_like(W)
+    np.put_along_axis(weights, top, np.take_along_axis(W, top, 1), 1)
+    weights[weights < 0.01] = 0.0
+    weights /= weights.sum(1, keepdims=True)
+
+    # ---- joint regressor: half a local Gaussian average, half a non-negative correction that lands on the joint ----
+    tree = cKDTree(v_template)
+    J_regressor = np.zeros((J, V))
+    for j in range(J):
+        for k, alpha in ((400, 0.5), (400, 1.0), (2000, 0.5), (2000, 1.0), (V, 1.0)):
+            d, nb = tree.query(Jrest[j], k=k)
+            w0 = np.exp(-(d / (d[:24].mean() + 1e-9)) ** 2)
+            w0 /= w0.sum()
+            pts = v_template[nb]
+            target = (Jrest[j] - (1.0 - alpha) * (w0 @ pts)) / alpha
+            w1, _ = nnls(np.vstack([pts.T, 10.0 * np.ones((1, len(nb)))]), np.concatenate([target, [10.0]]))
+            w = (1.0 - alpha) * w0 + alpha * w1
+            if np.abs(w @ pts - Jrest[j]).max() < 1e-9 and abs(w.sum() - 1.0) < 1e-9:
+                break
+        else:
+            raise RuntimeError("joint %d is not inside the hull of the vertices" % j)
+        J_regressor[j, nb] = w / w.sum()
+
+    # ---- blend shapes: smooth fields (random plane waves, wavelength >= 0.4 m) ------------------------
+    r2 = np.random.RandomState(seed + 1000)
+
+    def smooth_field(n, amp):
+        k = r2.normal(size=(n, 3, 3)) * (2 * np.pi / 0.6)
+        ph = r2.uniform(0, 2 * np.pi, size=(n, 3))
+        return amp * np.sin(np.einsum("vx,ncx->vcn", v_template, k) + ph.T[None])
+    shapedirs = smooth_field(20, 0.01 * np.sqrt(2.0))
+    shapedirs[:, :, 0] += 0.03 * v_template * np.array([0.3, 1.0, 0.3])
+    shapedirs[:, :, 1] += 0.03 * v_template * np.array([1.0, 0.1, 1.0])
+    shapedirs[:, :, 2] += 0.02 * v_template * np.array([1.0, 0.0, 0.0])
+    posedirs = smooth_field(NUM_POSE_BASIS, 0.001 * np.sqrt(2.0))
+
+    ql, _ = np.linalg.qr(rng.normal(size=(45, 45)))
+    qr_, _ = np.linalg.qr(rng.normal(size=(45, 45)))
+    hands_meanl = 0.1 * rng.normal(size=45)
+    hands_meanr = 0.1 * rng.normal(size=45)
+
+    head_faces = np.nonzero(np.isin(segm, (15, 22, 23, 24)))[0]
+    lmk_faces_idx = rng.choice(head_faces, size=51, replace=False)
+    lmk_bary = rng.dirichlet(np.ones(3), size=51)
+    dyn_faces = rng.choice(head_faces, size=(79, 17))
+    dyn_bary = rng.dirichlet(np.ones(3), size=(79, 17))
+
+    parents = SMPLX_PARENTS
+    model = dict(
+        v_template=v_template.astype(dtype), f=faces.astype(np.uint32),
+        shapedirs=shapedirs.astype(dtype), posedirs=posedirs.astype(dtype),
+        J_regressor=J_regressor.astype(dtype), weights=weights.astype(dtype),
+        kintree_table=np.stack([parents, np.arange(J)]).astype(np.int64),
+        hands_componentsl=ql.T.astype(dtype), hands_componentsr=qr_.T.astype(dtype),
+        hands_meanl=hands_meanl.astype(dtype), hands_meanr=hands_meanr.astype(dtype),
+        lmk_faces_idx=lmk_faces_idx.astype(np.int64), lmk_bary_coords=lmk_bary.astype(dtype),
+        dynamic_lmk_faces_idx=dyn_faces.astype(np.int64), dynamic_lmk_bary_coords=dyn_bary.astype(dtype),
+        extra_vertex_ids=SMPLX_EXTRA_VERTEX_IDS.copy(),
+    )
+    model["kintree_table"][0, 0] = -1
+    return model
+
+
+def topology_parts(topology=None):
+    """`segm` / `parents` per face exactly as smplifyx/smplx_parts_segm.pkl holds them (fit_single_frame.py:317-324)."""
+    tp = load_topology(topology) if not isinstance(topology, dict) else topology
+    return dict(segm=tp["segm"].copy(), parents=tp["parents"].copy())
+
+
 def make_synthetic_gmm(seed=0, num_gaussians=8, dim=63):
     """Synthetic stand-in for SMPLify's gmm_08.pkl (not shipped with the reference; 69-D for SMPL):
     dict(means [M,dim], covars [M,dim,dim] SPD, weights [M]) with pose-like scales (means ~0.15 rad,

@@ -2,7 +2,7 @@
 """Generate tests/golden/*.npz by running the REAL reference (imported from
 /root/reference, this container only) on seeded inputs.  The reference Python never
 ships; only these numeric arrays do.  Re-run: `python tools/make_goldens.py [what ...]`
-with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_full_set, e2e_vposer_set, e2e_side, e2e_bench, gmm_unmerged, e2e_bench_raw_delta}.
+with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_full_set, e2e_vposer_set, e2e_side, e2e_bench, gmm_unmerged, e2e_bench_raw_delta, smplx_topology}.
 
 The LBS itself has no reference implementation here (external `smplx`, absent): wherever a
 body model is needed the reference drives oracle.body_model.SMPLXRef built from
@@ -735,21 +735,42 @@ def gen_parser():
     _save("parser", **out)
 
 
-def gen_expose_anchor():
-    """The only known-answer vector for the SMPL-X forward that exists in the reference tree: ExPose's own
-    evaluation of the model on the two demo frames -- shape / expression coefficients and the rotation matrices of every
-    joint in, vertices [10475, 3] and joints [144, 3] out (demo/ExPose_results/*/*_params.npz).  Numeric arrays only.
-    tests/test_real_model_anchor.py replays them through the oracle and through the HIP forward when a user supplies the
-    licensed SMPLX_*.npz (SFX_SMPLX_MODEL): that is what pins row a6."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ref_import.REF_ROOT if hasattr(ref_import, "REF_ROOT") else "/root/reference",
-                                          "demo", "ExPose_results", "*", "*_params.npz")))
-    assert len(files) == 2, files
-    out = {"names": np.array([os.path.basename(os.path.dirname(f)) for f in files])}
-    for k in ("global_orient", "body_pose", "left_hand_pose", "right_hand_pose", "jaw_pose", "betas", "expression",
-              "vertices", "joints", "transl"):
-        out[k] = np.stack([np.asarray(np.load(f, allow_pickle=True)[k]) for f in files])
-    _save("expose_anchor", **out)
+def _read_ply_mesh(path):
+    """(vertices [V,3] float64, faces [F,3] int64) of a binary-little-endian .ply with double vertices and uchar/uint
+    face lists (what Open3D wrote into demo/ExPose_results)."""
+    raw = open(path, "rb").read()
+    i = raw.index(b"end_header\n") + len(b"end_header\n")
+    hdr = raw[:i].decode().splitlines()
+    assert "format binary_little_endian 1.0" in hdr and "property double x" in hdr, hdr
+    nv = int([l for l in hdr if l.startswith("element vertex")][0].split()[-1])
+    nf = int([l for l in hdr if l.startswith("element face")][0].split()[-1])
+    v = np.frombuffer(raw, "<f8", nv * 3, i).reshape(nv, 3)
+    f = np.frombuffer(raw, np.dtype([("n", "u1"), ("idx", "<u4", 3)]), nf, i + nv * 24)
+    assert (f["n"] == 3).all()
+    return v.copy(), f["idx"].astype(np.int64)
+
+
+def gen_smplx_topology():
+    """The mesh the reference's interpenetration term is evaluated on (fitting.py:437-455, fit_single_frame.py:300-328),
+    as far as the reference tree holds it: the SMPL-X face topology [20908, 3] (demo/ExPose_results/*/*.ply -- the four
+    files agree), the per-face body part and parent part of smplifyx/smplx_parts_segm.pkl (`segm`, `parents`; loaded at
+    fit_single_frame.py:317-324), and ONE posed body on that topology: ExPose's vertices [10475, 3] and joints [144, 3]
+    of demo frame 02 (numeric arrays only; MPG non-commercial research licence, LICENSE:1-20).
+    smplifyx_amd.synthetic.make_topology_model builds the benchmark's / tests' body model around these arrays."""
+    root = ref_import.REF_ROOT if hasattr(ref_import, "REF_ROOT") else "/root/reference"
+    demo = os.path.join(root, "demo", "ExPose_results")
+    meshes = [_read_ply_mesh(p) for p in sorted(__import__("glob").glob(os.path.join(demo, "*", "*.ply")))]
+    assert len(meshes) == 4 and all(np.array_equal(m[1], meshes[0][1]) for m in meshes)
+    faces = meshes[0][1]
+    with open(os.path.join(root, "smplifyx", "smplx_parts_segm.pkl"), "rb") as fh:
+        parts = pickle.load(fh, encoding="latin1")
+    segm, parents = np.asarray(parts["segm"], np.int64), np.asarray(parts["parents"], np.int64)
+    assert segm.shape == parents.shape == (len(faces),)
+    z = np.load(os.path.join(demo, "02_cropped.jpg", "02_cropped.jpg_params.npz"), allow_pickle=True)
+    verts, joints = np.asarray(z["vertices"], np.float32), np.asarray(z["joints"], np.float32)
+    assert np.abs(meshes[0][0] - (verts.astype(np.float64) + np.asarray(z["transl"]))).max() < 1e-6     # the .ply = vertices + transl
+    _save("smplx_topology", faces=faces.astype(np.int32), segm=segm.astype(np.int8), parents=parents.astype(np.int8),
+          vertices=verts, joints=joints)
 
 
 if __name__ == "__main__":
@@ -758,4 +779,4 @@ if __name__ == "__main__":
         {"objective": gen_objective, "lbfgs": gen_lbfgs, "euler": gen_euler, "tables": gen_tables,
          "e2e": gen_e2e, "demo": gen_demo, "e2e_vposer": gen_e2e_vposer, "parser": gen_parser, "eval": gen_eval,
          "gmm": gen_gmm, "e2e_full": gen_e2e_full, "e2e_full_set": gen_e2e_full_set, "e2e_vposer_set": gen_e2e_vposer_set, "e2e_side": gen_e2e_side, "e2e_bench": gen_e2e_bench,
-         "gmm_unmerged": gen_gmm_unmerged, "e2e_bench_raw_delta": gen_e2e_bench_raw_delta, "expose_anchor": gen_expose_anchor}[w]()
+         "gmm_unmerged": gen_gmm_unmerged, "e2e_bench_raw_delta": gen_e2e_bench_raw_delta, "smplx_topology": gen_smplx_topology}[w]()
