@@ -121,6 +121,9 @@ struct PenDev {
     int* heavy;                // [B] 1 = this evaluation of the column goes through the general kernels (crowded grid / too many pairs for one workgroup's LDS)
     int* hlist;                // [B] the heavy columns of this evaluation, any order
     int* nheavy;               // [1] their number (k_pen_g1 -> 0, k_pen_frame appends)
+    float* wbox;               // [B][n_clus][6] boxes of the clusters of 64 consecutive triangles (k_pen_g1: one DPP reduction per wavefront)
+    const unsigned long long* cpm;   // [n_clus] parts present in a cluster, one bit each (static)
+    int n_clus;                // (F + 63) / 64
     int2* pbuf;                // [B][pf_cap] accepted pairs of a frame on the fast path, any order (the partner-list buffer: unused there)
     int pf_cap;                // min(PEN_FP, F * pcap / 2)
     int fast_ok;               // the mesh fits the per-frame kernel's LDS layout (F^2 < 2^32: 32-bit sort keys; bit sets and vertex list in 64 KB)
@@ -297,7 +300,8 @@ void k_pen_g1(PenDev P, const float* __restrict__ verts, const int* __restrict__
     if (t < 64 * 6) pbox[t] = (t % 6) < 3 ? 0x7fffffff : (int)0x80000000;
     __syncthreads();
     float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f}, ext_sum = 0.f;
-    for (int f0 = w * PEN_T + t; f0 < F; f0 += PEN_GW * PEN_T * PEN_GU) {
+    for (int fw = w * PEN_T + (t & ~63); fw < F; fw += PEN_GW * PEN_T * PEN_GU) {        // (wave-uniform trip count: wave reductions inside)
+        const int f0 = fw + (t & 63);
         int vid[PEN_GU][3], seg[PEN_GU];
 #pragma unroll
         for (int u = 0; u < PEN_GU; ++u) {
@@ -318,27 +322,30 @@ void k_pen_g1(PenDev P, const float* __restrict__ verts, const int* __restrict__
 #pragma unroll
         for (int u = 0; u < PEN_GU; ++u) {
             const int f = f0 + u * PEN_GW * PEN_T;
-            if (f >= F) continue;
+            const bool valid = f < F;
+            if (!__ballot(valid)) continue;            // (wave-uniform: the reductions below need every lane)
             float a[3], c[3];
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
-                a[e] = fminf(fminf(px[u][e], px[u][3 + e]), px[u][6 + e]); c[e] = fmaxf(fmaxf(px[u][e], px[u][3 + e]), px[u][6 + e]);
-                aabb[f * 6 + e] = a[e]; aabb[f * 6 + 3 + e] = c[e];
+                a[e] = valid ? fminf(fminf(px[u][e], px[u][3 + e]), px[u][6 + e]) : 3e38f;
+                c[e] = valid ? fmaxf(fmaxf(px[u][e], px[u][3 + e]), px[u][6 + e]) : -3e38f;
+                if (valid) { aabb[f * 6 + e] = a[e]; aabb[f * 6 + 3 + e] = c[e]; }
                 lo[e] = fminf(lo[e], a[e]); hi[e] = fmaxf(hi[e], c[e]);
             }
-            ext_sum += fmaxf(fmaxf(c[0] - a[0], c[1] - a[1]), c[2] - a[2]);
+            if (valid) ext_sum += fmaxf(fmaxf(c[0] - a[0], c[1] - a[1]), c[2] - a[2]);
             // part boxes: consecutive triangles mostly belong to one part -- a complete wavefront of one part reduces its 64
-            // boxes on DPP and one lane updates the part's box
+            // boxes on DPP and one lane updates the part's box.  The wavefront's own box -- a cluster of 64 consecutive triangles --
+            // is kept as well (round 5): k_pen_frame culls whole clusters against the part boxes before it looks at a triangle.
             const int s0 = __builtin_amdgcn_readfirstlane(seg[u]);
-            if (__ballot(seg[u] == s0) == ~0ull) {
+            const bool one_part = __ballot(!valid || seg[u] == s0) == ~0ull;
 #pragma unroll
-                for (int e = 0; e < 3; ++e) {
-                    const float wl = -wave_max_dpp(-a[e]), wh = wave_max_dpp(c[e]);
-                    if ((t & 63) == 0) { atomicMin(&pbox[s0 * 6 + e], pen_ford(wl)); atomicMax(&pbox[s0 * 6 + 3 + e], pen_ford(wh)); }
+            for (int e = 0; e < 3; ++e) {
+                const float wl = -wave_max_dpp(-a[e]), wh = wave_max_dpp(c[e]);
+                if ((t & 63) == 0) {
+                    if (P.wbox) { float* wb = P.wbox + ((size_t)b * P.n_clus + (f >> 6)) * 6; wb[e] = wl; wb[3 + e] = wh; }
+                    if (one_part) { atomicMin(&pbox[s0 * 6 + e], pen_ford(wl)); atomicMax(&pbox[s0 * 6 + 3 + e], pen_ford(wh)); }
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 3; ++e) { atomicMin(&pbox[seg[u] * 6 + e], pen_ford(a[e])); atomicMax(&pbox[seg[u] * 6 + 3 + e], pen_ford(c[e])); }
+                if (!one_part && valid) { atomicMin(&pbox[seg[u] * 6 + e], pen_ford(a[e])); atomicMax(&pbox[seg[u] * 6 + 3 + e], pen_ford(c[e])); }
             }
         }
     }
@@ -493,14 +500,62 @@ void k_pen_g2(PenDev P, const int* __restrict__ want) {
 
 // parts a triangle of part p may collide with, folded to 32 bits (a triangle only enters a cell that also holds such a
 // part: the crowded interior of a limb, and joints where only parent and child meet, never reach the pair tests)
-__device__ __forceinline__ void pen_coll32(const PenDev& P, unsigned* s_coll32) {
+// (round 5: both halves of the 64-bit word -- [t] parts 0..31, [64 + t] parts 32..63.  Folded to one 32-bit word per bucket, as
+//  until round 4, part p and part p + 32 were one bit: on the SMPL-X part table every finger of the right hand (40..54) looked
+//  like a collar, the head or an arm (8..22) to the cell filter, and the grid held 3-4 x the entries an exact filter leaves.)
+__device__ __forceinline__ void pen_coll32(const PenDev& P, unsigned* s_coll32 /* [128] */) {
     const int t = threadIdx.x;
     if (t < 64) {
-        unsigned m = 0;
-        if (t < P.n_parts) { const unsigned long long c = ~P.skipmask[t] & (P.n_parts >= 64 ? ~0ull : (1ull << P.n_parts) - 1ull); m = (unsigned)c | (unsigned)(c >> 32); }
-        s_coll32[t] = m;
+        unsigned long long c = 0ull;
+        if (t < P.n_parts) c = ~P.skipmask[t] & (P.n_parts >= 64 ? ~0ull : (1ull << P.n_parts) - 1ull);
+        s_coll32[t] = (unsigned)c; s_coll32[64 + t] = (unsigned)(c >> 32);
     }
     __syncthreads();
+}
+// The cell filter of the grid build: a (triangle, cell) record becomes a grid entry only if its cell also holds a triangle of a
+// part the record's part may collide with.  Which parts a bucket holds is one 32-bit word of LDS per bucket, so the 64 possible
+// parts take two rounds over the records: parts 0..31 first -- the verdict is parked in bit 31 of the record --, then parts
+// 32..63 in the same words.  Leaves pmask holding the second round's words: `pen_cell_keep` is the test the histogram and the
+// scatter pass apply.  Contains barriers: the whole workgroup calls it.
+template <int U2>
+__device__ __forceinline__ void pen_cell_filter(const PenDev& P, int2* __restrict__ cand, const int NC, unsigned* pmask, const unsigned* s_coll32) {
+    const int t = threadIdx.x;
+    auto cell_bucket = [](const int key) { return pen_bucket(key & 1023, (key >> 10) & 1023, (key >> 20) & 1023); };
+    for (int i0 = t; i0 < NC; i0 += PEN_T * U2) {
+        int2 r[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) { const int i = i0 + u * PEN_T; r[u] = cand[i < NC ? i : 0]; }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) { const int pf = (r[u].x >> 24) & 63; if (i0 + u * PEN_T < NC && pf < 32) atomicOr(&pmask[cell_bucket(r[u].y)], 1u << pf); }
+    }
+    __syncthreads();
+    if (P.n_parts <= 32) return;
+    for (int i0 = t; i0 < NC; i0 += PEN_T * U2) {
+        int2 r[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) { const int i = i0 + u * PEN_T; r[u] = cand[i < NC ? i : 0]; }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) {
+            const int i = i0 + u * PEN_T;
+            if (i < NC && (pmask[cell_bucket(r[u].y)] & s_coll32[(r[u].x >> 24) & 63])) cand[i].x = r[u].x | (int)0x80000000;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int c = t; c < PEN_CELLS; c += PEN_T) pmask[c] = 0u;
+    __syncthreads();
+    for (int i0 = t; i0 < NC; i0 += PEN_T * U2) {
+        int2 r[U2];
+#pragma unroll
+        for (int u = 0; u < U2; ++u) { const int i = i0 + u * PEN_T; r[u] = cand[i < NC ? i : 0]; }
+#pragma unroll
+        for (int u = 0; u < U2; ++u) { const int pf = (r[u].x >> 24) & 63; if (i0 + u * PEN_T < NC && pf >= 32) atomicOr(&pmask[cell_bucket(r[u].y)], 1u << (pf - 32)); }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ bool pen_cell_keep(const PenDev& P, const int2 r, const unsigned* pmask, const unsigned* s_coll32, const int bk) {
+    const int pf = (r.x >> 24) & 63;
+    return P.n_parts <= 32 ? (pmask[bk] & s_coll32[pf]) != 0u : ((r.x < 0) | ((pmask[bk] & s_coll32[64 + pf]) != 0u));
 }
 
 // One workgroup per frame: bucket part masks, histogram, scan and scatter of the (cell, triangle) entries, all on LDS atomics
@@ -511,7 +566,7 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     extern __shared__ int cell_cnt[];           // [PEN_CELLS + 1] histogram, then start offsets, then cursors | [PEN_CELLS] part masks
     __shared__ int slice[PEN_T];
     __shared__ int s_total;
-    __shared__ unsigned s_coll32[64];
+    __shared__ unsigned s_coll32[128];
     const int b = blockIdx.x, t = threadIdx.x;
     int* st = P.stats + b * PEN_STATS;
     int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
@@ -521,7 +576,7 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
         return;
     }
     const int F = P.F;
-    const int2* cand = P.cand + (size_t)b * P.ent_cap;
+    int2* cand = P.cand + (size_t)b * P.ent_cap;
     const int NT = min(P.tcount[b * 16], F);              // triangles that survived the part culling (statistics)
     const int NC_raw = P.tcount[b * 16 + 1];              // (triangle, cell) records k_pen_g2 listed
     const int NC = min(NC_raw, P.ent_cap);
@@ -545,15 +600,8 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     // amount of work whatever the shapes of the triangles.
     constexpr int U2 = 8;
     auto cell_bucket = [](const int key) { return pen_bucket(key & 1023, (key >> 10) & 1023, (key >> 20) & 1023); };
-    // which parts are present in each bucket (folded to 32 bits)
-    for (int i0 = t; i0 < NC; i0 += PEN_T * U2) {
-        int2 r[U2];
-#pragma unroll
-        for (int u = 0; u < U2; ++u) { const int i = i0 + u * PEN_T; r[u] = cand[i < NC ? i : 0]; }
-#pragma unroll
-        for (int u = 0; u < U2; ++u) if (i0 + u * PEN_T < NC) atomicOr(&pmask[cell_bucket(r[u].y)], 1u << ((r[u].x >> 24) & 31));
-    }
-    __syncthreads();
+    // which parts are present in each bucket: the cell filter (two rounds of 32 parts each; pen_cell_filter)
+    pen_cell_filter<U2>(P, cand, NC, pmask, s_coll32);
     G3MARK();
     // histogram (a triangle only enters a cell that also holds a part it may collide with)
     for (int i0 = t; i0 < NC; i0 += PEN_T * U2) {
@@ -563,7 +611,7 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
 #pragma unroll
         for (int u = 0; u < U2; ++u) {
             const int bk = cell_bucket(r[u].y);
-            if (i0 + u * PEN_T < NC && (pmask[bk] & s_coll32[(r[u].x >> 24) & 63])) atomicAdd(&cell_cnt[bk], 1);
+            if (i0 + u * PEN_T < NC && pen_cell_keep(P, r[u], pmask, s_coll32, bk)) atomicAdd(&cell_cnt[bk], 1);
         }
     }
     __syncthreads();
@@ -612,7 +660,7 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
 #pragma unroll
         for (int u = 0; u < U2; ++u) {
             const int bk = cell_bucket(r[u].y);
-            if (i0 + u * PEN_T < NC && (pmask[bk] & s_coll32[(r[u].x >> 24) & 63])) ent[atomicAdd(&cell_cnt[bk], 1)] = r[u];      // one 8-byte store
+            if (i0 + u * PEN_T < NC && pen_cell_keep(P, r[u], pmask, s_coll32, bk)) ent[atomicAdd(&cell_cnt[bk], 1)] = make_int2(r[u].x & 0x7fffffff, r[u].y);      // one 8-byte store
         }
     }
     __threadfence_block();
@@ -1636,7 +1684,7 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
     int* s_queue = lds + PEN_GRID_INTS + PEN_CELLS;                 // [PEN_FW][256] pair queues of the wavefronts (C)
     __shared__ unsigned long long s_mask[64], s_near[64];
     __shared__ int s_pbox[64][6];
-    __shared__ unsigned s_coll32[64];
+    __shared__ unsigned s_coll32[128];
     __shared__ int slice[PEN_T];
     __shared__ float red[PEN_T / 64];
     __shared__ int s_cnt, s_ccnt, s_total, s_maxb, s_npairs, s_dead;
@@ -1644,6 +1692,10 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
     const int F = P.F;
     int* st = P.stats + b * PEN_STATS;
     int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
+    // wall-clock stamps (100 MHz) at the ends of the phases -> stats[4..11] (sfx_pen_phase_clocks: ticks since the kernel's start)
+    const long long t_start = wall_clock64();
+    int n_mark = 0;
+    auto mark = [&]() { if (t == 0) st[4 + n_mark] = (int)(wall_clock64() - t_start); ++n_mark; };
     if (t == 0) { P.wqn[b] = 0; P.heavy[b] = 0; }
     if (want && !want[b]) {                     // the frame's stage carries no collision weight: nothing to do
         if (t == 0) { P.ptotal[b] = 0; cells[PEN_CELLS] = 0; st[0] = st[1] = st[2] = st[3] = 0; st[13] = 0; st[15] = 0; loss_out[b] = 0.f;
@@ -1677,38 +1729,70 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
     pen_coll32(P, s_coll32);                    // (ends with a barrier)
     // the part boxes are read: leave them empty for the next evaluation of this column (k_pen_g1 accumulates into them)
     if (t < 64 * 6) P.pbox[(size_t)b * 64 * 6 + t] = (t % 6) < 3 ? 0x7fffffff : (int)0x80000000;
-    for (int fb = 0; fb < F; fb += PEN_T * PEN_GU) {
-        float bx[PEN_GU][6]; int seg[PEN_GU];
-#pragma unroll
-        for (int u = 0; u < PEN_GU; ++u) {
-            const int f = fb + u * PEN_T + t, ff = f < F ? f : 0;
-            seg[u] = P.segm[ff];
-#pragma unroll
-            for (int e = 0; e < 6; ++e) bx[u][e] = aabb[ff * 6 + e];
-        }
-#pragma unroll
-        for (int u = 0; u < PEN_GU; ++u) {
-            const int f = fb + u * PEN_T + t;
+    // Two levels (round 5): first the CLUSTERS of 64 consecutive triangles -- their boxes are one DPP reduction per wavefront in
+    // k_pen_g1, their part sets are static -- against the boxes of the parts they may collide with, one cluster per lane; then the
+    // triangles of the clusters that are left (a fifth of them on a body), a cluster per wavefront.  A lane per triangle through all
+    // F boxes, each walking its part's list of near parts on LDS round trips, took 58 us of this kernel's 210.
+    int* clist = reinterpret_cast<int*>(pmask);             // (the part masks are filled in phase B; the list is consumed before)
+    if (t == 0) st[11] = (int)(wall_clock64() - t_start);   // (diagnostic: end of the prologue)
+    {
+        int n_surv = 0;
+        for (int c0 = 0; c0 < P.n_clus; c0 += PEN_T) {      // (one trip for meshes of up to 65 k triangles)
+            const int c = c0 + t;
             bool any = false;
-            unsigned long long nm = f < F ? s_near[seg[u]] : 0ull;
+            if (c < P.n_clus) {
+                unsigned long long pm = P.cpm[c], nm = 0ull;
+                while (pm) { const int q = __ffsll((long long)pm) - 1; pm &= pm - 1; nm |= s_near[q]; }
+                if (nm) {
+                    const float* wb = P.wbox + ((size_t)b * P.n_clus + c) * 6;
+                    int a6[6];
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) a6[e] = pen_ford(wb[e]);
+                    while (nm) {      // (two parts per trip, no early exit inside a trip: independent LDS reads)
+                        const int q0 = __ffsll((long long)nm) - 1; nm &= nm - 1;
+                        const int q1 = nm ? __ffsll((long long)nm) - 1 : q0; nm &= nm - 1;
+                        const int* pa = s_pbox[q0]; const int* pb = s_pbox[q1];
+                        const bool m0 = (a6[0] <= pa[3]) & (pa[0] <= a6[3]) & (a6[1] <= pa[4]) & (pa[1] <= a6[4]) & (a6[2] <= pa[5]) & (pa[2] <= a6[5]);
+                        const bool m1 = (a6[0] <= pb[3]) & (pb[0] <= a6[3]) & (a6[1] <= pb[4]) & (pb[1] <= a6[4]) & (a6[2] <= pb[5]) & (pb[2] <= a6[5]);
+                        if (m0 | m1) { any = true; break; }
+                    }
+                }
+            }
+            int tot;
+            const int pos = n_surv + block_excl_scan(any ? 1 : 0, slice, &tot);
+            if (any) clist[pos] = c;
+            n_surv += tot;
+        }
+        __syncthreads();
+        if (t == 0) st[12] = (int)(wall_clock64() - t_start);   // (diagnostic: end of the cluster culling)
+        for (int ci = wv; ci < n_surv; ci += PEN_FW) {
+            const int f = clist[ci] * 64 + lane, ff = f < F ? f : 0;
+            const int seg = P.segm[ff];
+            float bx[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) bx[e] = aabb[ff * 6 + e];
+            bool any = false;
+            unsigned long long nm = f < F ? s_near[seg] : 0ull;
             if (nm) {
                 int a6[6];
 #pragma unroll
-                for (int e = 0; e < 6; ++e) a6[e] = pen_ford(bx[u][e]);
-                while (nm && !any) {
-                    const int q = __ffsll((long long)nm) - 1;
-                    nm &= nm - 1;
-                    const int* pb = s_pbox[q];
-                    any = (a6[0] <= pb[3]) & (pb[0] <= a6[3]) & (a6[1] <= pb[4]) & (pb[1] <= a6[4]) & (a6[2] <= pb[5]) & (pb[2] <= a6[5]);
+                for (int e = 0; e < 6; ++e) a6[e] = pen_ford(bx[e]);
+                while (nm) {
+                    const int q0 = __ffsll((long long)nm) - 1; nm &= nm - 1;
+                    const int q1 = nm ? __ffsll((long long)nm) - 1 : q0; nm &= nm - 1;
+                    const int* pa = s_pbox[q0]; const int* pb = s_pbox[q1];
+                    const bool m0 = (a6[0] <= pa[3]) & (pa[0] <= a6[3]) & (a6[1] <= pa[4]) & (pa[1] <= a6[4]) & (a6[2] <= pa[5]) & (pa[2] <= a6[5]);
+                    const bool m1 = (a6[0] <= pb[3]) & (pb[0] <= a6[3]) & (a6[1] <= pb[4]) & (pb[1] <= a6[4]) & (a6[2] <= pb[5]) & (pb[2] <= a6[5]);
+                    if (m0 | m1) { any = true; break; }
                 }
             }
             int2 pk = make_int2(0, 0);
             if (any) {
                 int c0[3], sp[3];
 #pragma unroll
-                for (int e = 0; e < 3; ++e) { c0[e] = pen_cell_of(C, bx[u][e], e); sp[e] = min(pen_cell_of(C, bx[u][3 + e], e), c0[e] + PEN_SPAN - 1) - c0[e]; }
+                for (int e = 0; e < 3; ++e) { c0[e] = pen_cell_of(C, bx[e], e); sp[e] = min(pen_cell_of(C, bx[3 + e], e), c0[e] + PEN_SPAN - 1) - c0[e]; }
                 pk.x = (c0[0] & 1023) | ((c0[1] & 1023) << 10) | ((c0[2] & 1023) << 20) | (int)0x80000000;
-                pk.y = sp[0] | (sp[1] << 3) | (sp[2] << 6) | (seg[u] << 9);
+                pk.y = sp[0] | (sp[1] << 3) | (sp[2] << 6) | (seg << 9);
             }
             const unsigned long long m = __ballot(any);
             const int nc = any ? ((pk.y & 7) + 1) * (((pk.y >> 3) & 7) + 1) * (((pk.y >> 6) & 7) + 1) : 0;
@@ -1725,21 +1809,17 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
                 });
             }
         }
+        __syncthreads();
+        for (int c = t; c < P.n_clus && c < PEN_CELLS; c += PEN_T) pmask[c] = 0u;       // (the cluster list lay in the part masks' array)
     }
     __threadfence_block();
     __syncthreads();
     const int NT = min(s_cnt, F), NC_raw = s_ccnt, NC = min(NC_raw, P.ent_cap);
+    mark();                                     // [4] A: part culling
     // ---------------------------------------------------------------- B: counting sort into the hashed grid (k_pen_g3)
     constexpr int U2 = 8;
     auto cell_bucket = [](const int key) { return pen_bucket(key & 1023, (key >> 10) & 1023, (key >> 20) & 1023); };
-    for (int i0 = t; i0 < NC; i0 += PEN_T * U2) {
-        int2 r[U2];
-#pragma unroll
-        for (int u = 0; u < U2; ++u) { const int i = i0 + u * PEN_T; r[u] = cand[i < NC ? i : 0]; }
-#pragma unroll
-        for (int u = 0; u < U2; ++u) if (i0 + u * PEN_T < NC) atomicOr(&pmask[cell_bucket(r[u].y)], 1u << ((r[u].x >> 24) & 31));
-    }
-    __syncthreads();
+    pen_cell_filter<U2>(P, cand, NC, pmask, s_coll32);
     for (int i0 = t; i0 < NC; i0 += PEN_T * U2) {
         int2 r[U2];
 #pragma unroll
@@ -1747,7 +1827,7 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
 #pragma unroll
         for (int u = 0; u < U2; ++u) {
             const int bk = cell_bucket(r[u].y);
-            if (i0 + u * PEN_T < NC && (pmask[bk] & s_coll32[(r[u].x >> 24) & 63])) atomicAdd(&cell_cnt[bk], 1);
+            if (i0 + u * PEN_T < NC && pen_cell_keep(P, r[u], pmask, s_coll32, bk)) atomicAdd(&cell_cnt[bk], 1);
         }
     }
     __syncthreads();
@@ -1776,7 +1856,7 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
     int2* ent = P.entries + (size_t)b * P.ent_cap;
     const int n_ent = s_total;
     const bool ent_ok = n_ent <= P.ent_cap - 4 && NC_raw <= P.ent_cap;
-    if (t == 0) { st[2] = ent_ok ? 0 : max(n_ent, NC_raw); st[3] = PEN_CELLS; st[13] = 0; st[14] = n_ent; st[15] = 0; for (int q = 4; q < 13; ++q) st[q] = 0;
+    if (t == 0) { st[2] = ent_ok ? 0 : max(n_ent, NC_raw); st[3] = PEN_CELLS; st[13] = 0; st[14] = n_ent; st[15] = 0; for (int q = 5; q < 11; ++q) st[q] = 0;
                   for (int q = 16; q < PEN_STATS; ++q) st[q] = 0;
                   if (P.work) { atomicAdd(&P.work[0], (unsigned long long)n_ent); atomicAdd(&P.work[2], 1ull); atomicAdd(&P.work[3], (unsigned long long)NT); } }
     if (!ent_ok) {       // grid too crowded for the entry buffer: report, produce no pairs (the gradient rows are zero already)
@@ -1790,32 +1870,39 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
 #pragma unroll
         for (int u = 0; u < U2; ++u) {
             const int bk = cell_bucket(r[u].y);
-            if (i0 + u * PEN_T < NC && (pmask[bk] & s_coll32[(r[u].x >> 24) & 63])) ent[atomicAdd(&cell_cnt[bk], 1)] = r[u];
+            if (i0 + u * PEN_T < NC && pen_cell_keep(P, r[u], pmask, s_coll32, bk)) ent[atomicAdd(&cell_cnt[bk], 1)] = make_int2(r[u].x & 0x7fffffff, r[u].y);
         }
     }
     __threadfence_block();
     __syncthreads();
+    mark();                                     // [5] B: grid
     // the general kernels take over from the sorted grid
     auto hand_over = [&]() {
         for (int c = t; c <= PEN_CELLS; c += PEN_T) cells[c] = cell_cnt[c];
         if (t == 0) { P.heavy[b] = 1; P.hlist[atomicAdd(P.nheavy, 1)] = b; }
     };
     if (force_heavy || !P.fast_ok || n_ent > PEN_FE || s_maxb > PEN_FB) { hand_over(); return; }
-    // ---------------------------------------------------------------- C: pair tests (k_pen_walk's chunk walk)
+    // ---------------------------------------------------------------- C: pair tests
+    // The bucket-sorted entries go through LDS in TILES of PEN_TW headers (entry record + box: 32 bytes), loaded by all 1024 lanes
+    // at once -- two round trips per tile for the whole workgroup -- and every wavefront then walks blocks of 64 entries of the tile
+    // on LDS alone: lane i of a block looks at the entries behind it up to the end of its bucket (<= PEN_FB on this path, the halo
+    // of the tile), two candidates per step, the tests of k_pen_walk (same cell, part mask, boxes, ownership by the cell of the
+    // intersection's low corner; shared vertices when the queue of accepted pairs is flushed).  A wavefront that fetched its own
+    // block and window (k_pen_walk's scheme) spent ~8 us per block waiting for three dependent round trips: 75-150 us per column.
     {
-        PenWalkCtx W;
-        W.tA = reinterpret_cast<int4*>(r1 + wv * PEN_WIN * 8); W.tB = W.tA + PEN_WIN;
-        W.queue = s_queue + wv * 256; W.qn = 0; W.s_mask = s_mask;
+        constexpr int PEN_TW = 2048, PEN_TOWN = PEN_TW - PEN_FB;
+        int4* tA = reinterpret_cast<int4*>(r1); int4* tB = tA + PEN_TW;
+        int* queue = s_queue + wv * 256; int qn = 0;
         int2* pbuf = P.pbuf + (size_t)b * P.pf_cap;
-        auto flush = [&](PenWalkCtx& W_) {
-            const int n = W_.qn;
+        auto flush = [&]() {
+            const int n = qn;
             if (!n) return;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
             for (int q0 = 0; q0 < n; q0 += 64) {
                 const int q = q0 + lane;
                 bool keep = false; int fa = 0, fb_ = 0;
                 if (q < n) {
-                    fa = W_.queue[2 * q]; fb_ = W_.queue[2 * q + 1];
+                    fa = queue[2 * q]; fb_ = queue[2 * q + 1];
                     const int4 va = P.faces4[fa], vb = P.faces4[fb_];      // triangles that share a vertex do not collide
                     keep = !(va.x == vb.x || va.x == vb.y || va.x == vb.z || va.y == vb.x || va.y == vb.y || va.y == vb.z ||
                              va.z == vb.x || va.z == vb.y || va.z == vb.z);
@@ -1829,22 +1916,62 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
                 if (keep && pos < P.pf_cap) pbuf[pos] = make_int2(fa, fb_);
             }
             __builtin_amdgcn_wave_barrier();
-            W_.qn = 0;
+            qn = 0;
         };
-        for (int i0 = wv * 64; i0 < n_ent; i0 += PEN_FW * 64) {
-            int hdr[8];
-            const PenOwn O = pen_own(P, b, i0, n_ent, W, lane, hdr, cell_cnt);
-            const int bend_max = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)O.bend));
-            const int dmax = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)max(O.bend - 1 - O.qi, 0)));
-            const int kmax = dmax > 64 ? (dmax - 1) >> 6 : 0;          // (buckets <= PEN_FB: kmax < PEN_FB / 64 <= PEN_MAX_CHUNK)
-            for (int k = 0; k <= kmax; ++k) pen_walk_chunk(P, b, i0, k, bend_max, O, hdr, W, lane, flush);
-            __builtin_amdgcn_wave_barrier();
+        for (int tile0 = 0; tile0 < n_ent; tile0 += PEN_TOWN) {
+            __syncthreads();                                        // (the previous tile's walks are done)
+            for (int idx = t; idx < PEN_TW; idx += PEN_T) {
+                int hd[8];
+                pen_load_hdr(ent, aabb, tile0 + idx, tile0 + idx < n_ent, hd);
+                tA[idx] = make_int4(hd[0], hd[1], hd[2], hd[3]); tB[idx] = make_int4(hd[4], hd[5], hd[6], hd[7]);
+            }
+            __syncthreads();
+            const int nown = min(PEN_TOWN, n_ent - tile0);
+            for (int blk = wv; blk * 64 < nown; blk += PEN_FW) {
+                const int idx0 = blk * 64 + lane, qi = tile0 + idx0;
+                const bool vi = idx0 < nown;
+                const int4 o0 = tA[idx0], o1 = tB[idx0];
+                const int fi = o0.x & 0xffffff, ck = o0.y & 0x3fffffff;
+                const unsigned long long skip_i = vi ? s_mask[(o0.x >> 24) & 63] : ~0ull;
+                const float ai0 = __int_as_float(o0.z), ai1 = __int_as_float(o0.w), ai2 = __int_as_float(o1.x);
+                const float ai3 = __int_as_float(o1.y), ai4 = __int_as_float(o1.z), ai5 = __int_as_float(o1.w);
+                const int bend = vi ? cell_cnt[pen_bucket_of(ck)] : 0;
+                const unsigned lowb = ((unsigned)o0.y >> 30) | (((unsigned)o0.x >> 28) & 4u);
+                const unsigned need = ~lowb & 7u;
+                const int dmax = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)max(bend - 1 - qi, 0)));      // <= PEN_FB - 1
+                auto test = [&](const bool act, const int4 h0, const int4 h1) {
+                    const float kl0 = __int_as_float(h0.z), kl1 = __int_as_float(h0.w), kl2 = __int_as_float(h1.x);
+                    const float kh0 = __int_as_float(h1.y), kh1 = __int_as_float(h1.z), kh2 = __int_as_float(h1.w);
+                    const bool same = ((h0.y ^ ck) & 0x3fffffff) == 0;
+                    const bool coll = ((unsigned)(skip_i >> ((h0.x >> 24) & 63)) & 1u) == 0u;
+                    const bool box = (ai0 <= kh0) & (kl0 <= ai3) & (ai1 <= kh1) & (kl1 <= ai4) & (ai2 <= kh2) & (kl2 <= ai5);
+                    const unsigned klow = ((unsigned)h0.y >> 30) | (((unsigned)h0.x >> 28) & 4u);
+                    const bool own = (need & ~klow) == 0u;
+                    return act & same & coll & box & own;
+                };
+                auto push = [&](const bool pass, const int other) {
+                    const unsigned long long m = __ballot(pass);
+                    if (m) {
+                        const int pos = qn + __popcll(m & ((1ull << lane) - 1ull));
+                        if (pass) { queue[2 * pos] = fi; queue[2 * pos + 1] = other & 0xffffff; }
+                        qn += __popcll(m);
+                        if (qn >= 64) flush();
+                    }
+                };
+                for (int d = 1; d <= dmax; d += 2) {
+                    const int k0 = min(idx0 + d, PEN_TW - 1), k1 = min(idx0 + d + 1, PEN_TW - 1);
+                    const int4 hA0 = tA[k0], hB0 = tB[k0], hA1 = tA[k1], hB1 = tB[k1];
+                    const bool p0 = test(qi + d < bend, hA0, hB0), p1 = test(qi + d + 1 < bend, hA1, hB1);
+                    push(p0, hA0.x); push(p1, hA1.x);
+                }
+            }
         }
-        flush(W);
+        flush();
     }
     __threadfence_block();
     __syncthreads();
     const int npairs = s_npairs;
+    mark();                                     // [6] C: pair tests
     if (npairs > P.pf_cap) { hand_over(); return; }
     // ---------------------------------------------------------------- D: the pair list (k_pen_list + k_pen_rank)
     unsigned* keys = reinterpret_cast<unsigned*>(r1);               // [np] both orders of every pair, then the kept list in place
@@ -1866,12 +1993,10 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
     for (int k = 2; k <= np; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
             __syncthreads();
-            for (int i = t; i < np; i += PEN_T) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned va = keys[i], vb = keys[ixj];
-                    if ((va > vb) == ((i & k) == 0)) { keys[i] = vb; keys[ixj] = va; }
-                }
+            for (int q = t; q < np / 2; q += PEN_T) {           // compare-exchange q of this step: i = q with a 0 inserted at bit j
+                const int i = 2 * q - (q & (j - 1)), ixj = i + j;
+                const unsigned va = keys[i], vb = keys[ixj];
+                if ((va > vb) == ((i & k) == 0)) { keys[i] = vb; keys[ixj] = va; }
             }
         }
     __syncthreads();
@@ -1915,6 +2040,7 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
                       if (P.work) atomicAdd(&P.work[1], (unsigned long long)T_); }
     }
     __syncthreads();
+    mark();                                     // [7] D: pair list
     const int T = T_;
     {   // the list as the diagnostics read it (sfx_pen_pairs)
         int* pown = P.pown + (size_t)b * P.pair_cap; int* plist = P.plist + (size_t)b * P.pair_cap;
@@ -1947,6 +2073,7 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
     __threadfence_block();
     __syncthreads();
     if (t == 0) st[15] = s_dead;
+    mark();                                     // [8] E: pair evaluation
     // ---------------------------------------------------------------- F: per-triangle sums; which triangles / vertices carry a gradient
     for (int i = t; i < T; i += PEN_T) {
         const unsigned k = keys[i];
@@ -1962,6 +2089,7 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
     }
     __threadfence_block();
     __syncthreads();
+    mark();                                     // [9] F: per-triangle sums
     // ---------------------------------------------------------------- G: vertex gradients, d v_posed, the frame's loss
     {
         int nv = 0;
@@ -1983,6 +2111,7 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
         __syncthreads();
         if (t == 0) loss_out[b] = ((red[0] + red[1]) + red[2]) + red[3];
     }
+    mark();                                     // [10] G: vertices, loss
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2106,6 +2235,14 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     if (!P.wq || !P.wqn) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     P.tgrad = h->zeros<float>(B * F * 9); P.tloss = h->zeros<float>(B * F);
     h->form = g_pen_form;
+    P.n_clus = (F + 63) / 64;
+    {
+        std::vector<unsigned long long> cpm(P.n_clus, 0ull);
+        for (int f = 0; f < F; ++f) cpm[f >> 6] |= 1ull << sg[f];
+        P.cpm = h->up(cpm);
+        P.wbox = h->zeros<float>(B * P.n_clus * 6);
+        if (!P.cpm || !P.wbox) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
+    }
     P.heavy = h->zeros<int>(B); P.hlist = h->zeros<int>(B); P.nheavy = h->zeros<int>(1);
     P.pbuf = reinterpret_cast<int2*>(P.partners);         // (the partner lists are unused on the fast path)
     P.pf_cap = (int)std::min<size_t>(PEN_FP, (size_t)F * P.pcap / 2);
