@@ -323,12 +323,17 @@ int  sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out /* [32] */
  * the same bits).  Process-wide; any other value only queries.  Returns the previous setting.                          */
 int  sfx_debug_lbs_dense_form(int32_t form);
 
-/* Debug / A-B measurements: which form of the interpenetration term handles and batches created FROM NOW ON take -- 1 = one
- * workgroup per column behind the triangle boxes (k_pen_frame) plus the general kernels on the columns it hands over (round 5,
- * default); 0 = the ten general kernels on every column (rounds 2-4); 2 = form 1 with every column handed over after the grid
- * build.  The three forms produce the same bits (pair list, loss, gradients: tests/test_gpu_topology.py).  Any other value only
- * queries.  Returns the previous setting.  Environment: SFX_PEN_FORM.                                                       */
+/* Debug / A-B measurements: which form of the interpenetration term handles and batches created FROM NOW ON take -- 0 = the ten
+ * general kernels on every column, every step dealt flat over the chip (default); 1 = grid build and pair tests spread over the
+ * chip, then ONE workgroup per column from the accepted pairs to the gradient (k_pen_narrow), plus the general kernels on the
+ * columns it hands over; 2 = form 1 with every column handed over; 3 = one workgroup per column behind the triangle boxes
+ * (k_pen_frame).  Forms 1 and 3 were built in round 5 and measured slower on whole fits (a round lasts as long as its most crowded
+ * column); all forms produce the same bits (pair list, loss, gradients: tests/test_gpu_topology.py).  Any other value only queries.
+ * Returns the previous setting.  Environment: SFX_PEN_FORM.                                                                    */
 int  sfx_debug_pen_form(int32_t form);
+/* Debug: 100-MHz ticks the workgroups of k_pen_narrow spent in their phases since sfx_pen_work_reset, summed over the column
+ * evaluations: HOST [8] = entry, pair list, pair evaluation, triangle sums, vertices + loss, evaluations, their ordered pairs, 0. */
+int  sfx_debug_pen_phase_ticks(int64_t* ticks_host);
 
 /* Experiment (timing only): `rounds` rounds of the dense loop; mode 0 serial (GEMM -> tick), mode 1 GEMM and tick of a
  * round launched together on two streams.  out_ms = elapsed time.  The batch's results are meaningless afterwards.     */

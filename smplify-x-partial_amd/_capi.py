@@ -98,6 +98,7 @@ SYMBOLS = {
     "sfx_pen_phase_clocks": (C.c_int, [C.c_void_p, C.c_int32, i32p]),
     "sfx_batch_pen_flags": (C.c_int, [C.c_void_p, i32p]),
     "sfx_debug_pen_form": (C.c_int, [C.c_int32]),
+    "sfx_debug_pen_phase_ticks": (C.c_int, [C.POINTER(C.c_int64)]),
     "sfx_pen_work_reset": (C.c_int, []),
     "sfx_pen_work_get": (C.c_int, [C.POINTER(C.c_int64)]),
     "sfx_debug_clocks": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),

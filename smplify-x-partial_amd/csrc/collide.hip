@@ -124,6 +124,7 @@ struct PenDev {
     float* wbox;               // [B][n_clus][6] boxes of the clusters of 64 consecutive triangles (k_pen_g1: one DPP reduction per wavefront)
     const unsigned long long* cpm;   // [n_clus] parts present in a cluster, one bit each (static)
     int n_clus;                // (F + 63) / 64
+    int* pcnt;                 // [B] pairs the pair tests have accepted (k_pen_g3 -> 0; beyond pf_cap they are counted, not stored)
     int2* pbuf;                // [B][pf_cap] accepted pairs of a frame on the fast path, any order (the partner-list buffer: unused there)
     int pf_cap;                // min(PEN_FP, F * pcap / 2)
     int fast_ok;               // the mesh fits the per-frame kernel's LDS layout (F^2 < 2^32: 32-bit sort keys; bit sets and vertex list in 64 KB)
@@ -570,7 +571,7 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
     const int b = blockIdx.x, t = threadIdx.x;
     int* st = P.stats + b * PEN_STATS;
     int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
-    if (t == 0) P.wqn[b] = 0;                   // (the pair tests' chunk queue of this mesh starts empty)
+    if (t == 0) { P.wqn[b] = 0; P.pcnt[b] = 0; }      // (the pair tests' chunk queue and pair list of this mesh start empty)
     if (want && !want[b]) {                     // the frame's stage carries no collision weight: nothing to do
         if (t == 0) { P.ptotal[b] = 0; cells[PEN_CELLS] = 0; st[0] = st[1] = st[2] = st[3] = 0; st[13] = 0; st[15] = 0; }
         return;
@@ -788,6 +789,34 @@ __device__ __forceinline__ void pen_flush_queue(const PenDev& P, const int b, Pe
     W.qn = 0;
 }
 
+// round 5: the accepted pairs go to ONE list of the frame, any order (k_pen_narrow sorts them in LDS) -- one returning atomic per
+// flush instead of two per pair; the partner lists are used by the columns k_pen_narrow hands back
+__device__ __forceinline__ void pen_flush_pairs(const PenDev& P, const int b, PenWalkCtx& W, const int lane) {
+    const int n = W.qn;
+    if (!n) return;
+    int2* pbuf = P.pbuf + (size_t)b * P.pf_cap;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+    for (int q0 = 0; q0 < n; q0 += 64) {
+        const int q = q0 + lane;
+        bool keep = false; int fa = 0, fb = 0;
+        if (q < n) {
+            fa = W.queue[2 * q]; fb = W.queue[2 * q + 1];
+            const int4 va = P.faces4[fa], vb = P.faces4[fb];      // triangles that share a vertex do not collide
+            keep = !(va.x == vb.x || va.x == vb.y || va.x == vb.z || va.y == vb.x || va.y == vb.y || va.y == vb.z ||
+                     va.z == vb.x || va.z == vb.y || va.z == vb.z);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (!m) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&P.pcnt[b], __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep && pos < P.pf_cap) pbuf[pos] = make_int2(fa, fb);
+    }
+    __builtin_amdgcn_wave_barrier();
+    W.qn = 0;
+}
+
 // The block's own side of the tests: what a lane knows about ITS entry
 struct PenOwn { int qi, fi, ck, bend; unsigned need; unsigned long long skip_i; float ai[6]; };
 
@@ -896,7 +925,7 @@ __device__ __forceinline__ void pen_walk_chunk(const PenDev& P, const int b, con
 // chunk 0 of every block; PEN_WALK_BLOCKS workgroups per mesh.  Queues the chunks k >= 1 (P.wq / P.wqn); when the queue is full
 // the block walks them itself, as it did before round 4.
 __global__ __launch_bounds__(256)
-void k_pen_walk(PenDev P, PenSel sel) {
+void k_pen_walk(PenDev P, PenSel sel, int to_pbuf) {
     PEN_WALK_LDS
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int nsel = pen_sel_n(sel, sel.hlist ? 0x7fffffff : (int)gridDim.y);
@@ -911,7 +940,7 @@ void k_pen_walk(PenDev P, PenSel sel) {
     PenWalkCtx W;
     W.tA = reinterpret_cast<int4*>(s_tile + wv * PEN_WIN * 8); W.tB = W.tA + PEN_WIN;
     W.queue = s_queue + wv * 256; W.qn = 0; W.s_mask = s_mask;
-    auto flush = [&](PenWalkCtx& W_) { pen_flush_queue(P, b, W_, lane); };
+    auto flush = [&](PenWalkCtx& W_) { if (to_pbuf) pen_flush_pairs(P, b, W_, lane); else pen_flush_queue(P, b, W_, lane); };
     // (blocks of 64 entries, NOT whole buckets: a crowded bucket is shared by many wavefronts; the
     // cell key comparison keeps different cells of one bucket apart)
     for (int i0 = (blockIdx.x * 4 + wv) * 64; i0 < s_total; i0 += gridDim.x * 256) {
@@ -943,13 +972,13 @@ void k_pen_walk(PenDev P, PenSel sel) {
         }
         __builtin_amdgcn_wave_barrier();
     }
-    pen_flush_queue(P, b, W, lane);
+    flush(W);
     }
 }
 
 // the queued chunks of all meshes of the call, one flat list (the distribution of k_pen_eval): a chunk per wavefront
 __global__ __launch_bounds__(256)
-void k_pen_walk2(PenDev P, int B, PenSel sel) {
+void k_pen_walk2(PenDev P, int B, PenSel sel, int to_pbuf) {
     PEN_WALK_LDS
     extern __shared__ int s_pref[];             // [B + 1] exclusive prefix of the meshes' queued chunks
     __shared__ int s_scan[256];
@@ -963,16 +992,16 @@ void k_pen_walk2(PenDev P, int B, PenSel sel) {
     int b_prev = -1;
     for (int c = blockIdx.x * 4 + wv; c < n_items; c += gridDim.x * 4) {
         const int b = pen_chunk_mesh(s_pref, B, c);
-        if (b != b_prev) { if (b_prev >= 0) pen_flush_queue(P, b_prev, W, lane); b_prev = b; }      // (the pair queue belongs to one mesh)
+        if (b != b_prev) { if (b_prev >= 0) { if (to_pbuf) pen_flush_pairs(P, b_prev, W, lane); else pen_flush_queue(P, b_prev, W, lane); } b_prev = b; }      // (the pair queue belongs to one mesh)
         const int2 it = P.wq[(size_t)b * P.wq_cap + (c - s_pref[b])];
         if (it.y == 0) continue;                       // (a slot of a reservation that did not fit: its block walked on itself)
         const int s_total = P.cells[(size_t)b * (PEN_CELLS + 1) + PEN_CELLS];
         int hdr[8];
         const PenOwn O = pen_own(P, b, it.x, s_total, W, lane, hdr, P.cells + (size_t)b * (PEN_CELLS + 1));
         const int bend_max = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)O.bend));
-        pen_walk_chunk(P, b, it.x, it.y, bend_max, O, hdr, W, lane, [&](PenWalkCtx& W_) { pen_flush_queue(P, b, W_, lane); });
+        pen_walk_chunk(P, b, it.x, it.y, bend_max, O, hdr, W, lane, [&](PenWalkCtx& W_) { if (to_pbuf) pen_flush_pairs(P, b, W_, lane); else pen_flush_queue(P, b, W_, lane); });
     }
-    if (b_prev >= 0) pen_flush_queue(P, b_prev, W, lane);
+    if (b_prev >= 0) { if (to_pbuf) pen_flush_pairs(P, b_prev, W, lane); else pen_flush_queue(P, b_prev, W, lane); }
 }
 
 // offsets of the triangles' partner ranges in the frame's pair list (k_pen_rank fills the list)
@@ -1239,18 +1268,32 @@ void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
         if (E == 0) continue;
         __builtin_amdgcn_wave_barrier();
         tile[lane] = off_l - base;
+        tile[64 + lane] = c_l | (a_l > c_l ? 0x10000 : 0);       // (kept count and "the list was cut" of the 64 triangles: no second trip to memory for them)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
         for (int e = lane; e < E; e += 64) {
             int l = 0;
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) if (tile[l + d] <= e) l += d;      // last l with offset <= e
             const int ff = fw + l, lo = tile[l], slot = e - lo, off = base + lo;
-            const int cc = pc[ff];
-            if (can_sort && (cc > PEN_SHORT || pav[ff] > cc)) continue;
+            const int cw = tile[64 + l], cc = cw & 0xffff;
+            if (can_sort && (cc > PEN_SHORT || (cw & 0x10000))) continue;
             const int* mine = part + (size_t)ff * P.pcap;
-            const int x = mine[slot];
+            // the whole short list in one round trip (round 5: `for (r < cc) y = mine[r]` compiled to cc dependent waits -- up to 16
+            // memory round trips per element on the lane's chain: most of this kernel's 60 us on a body mesh)
+            int y[PEN_SHORT];
+#pragma unroll
+            for (int r = 0; r < PEN_SHORT; ++r) y[r] = mine[min(r, P.pcap - 1)];
+            int x = 0;
+#pragma unroll
+            for (int r = 0; r < PEN_SHORT; ++r) x = r == slot ? y[r] : x;
             int rank = 0;
-            for (int r = 0; r < cc; ++r) { const int y = mine[r]; rank += (int)((y < x) | ((y == x) & (r < slot))); }
+            if (!can_sort && cc > PEN_SHORT) {           // (max_collisions beyond the wavefront sort: element-wise all the way, as before)
+                x = mine[slot];
+                for (int r = 0; r < cc; ++r) { const int yy = mine[r]; rank += (int)((yy < x) | ((yy == x) & (r < slot))); }
+            } else {
+#pragma unroll
+                for (int r = 0; r < PEN_SHORT; ++r) rank += (int)((r < cc) & ((y[r] < x) | ((y[r] == x) & (r < slot))));
+            }
             if (off + rank < P.pair_cap) { plist[off + rank] = x; pown[off + rank] = ff; }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1656,6 +1699,9 @@ void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss
 #define PEN_FB 256              // longest bucket on the fast path (chunks 0..3 of a block's walk)
 #define PEN_FP 8192             // unordered pairs on the fast path: 2 x PEN_FP sort keys = 64 KB of LDS
 #define PEN_FW 16               // wavefronts of the workgroup
+#ifndef PEN_AU
+#define PEN_AU 1               // (4 faulted with a memory access error on the device -- not understood; 2 ran and changed nothing)
+#endif
 #define PEN_HEAVY_ROWS 8        // grid rows of the general kernels when they work on the handed-over columns (they loop over the list)
 #define PEN_FRAME_LDS ((PEN_GRID_INTS + PEN_CELLS + PEN_FW * 256) * 4)        // cells | part masks -> windows -> sort keys | pair queues
 
@@ -1671,6 +1717,200 @@ __device__ __forceinline__ int pen_block_excl_scan_max(const int v, int* wmax /*
     for (int i = 0; i < wv; ++i) base = max(base, wmax[i]);
     const int prev = __shfl_up(inc, 1);
     return max(base, lane > 0 ? prev : -1);
+}
+
+// Phases D-G of the per-column work: from the column's accepted pairs (P.pbuf, any order) to the pair list, the pair evaluation,
+// the per-triangle sums, the gradient of the vertices that have one, d v_posed and the frame's loss -- one workgroup of PEN_T lanes,
+// everything between the pair buffer and the outputs in LDS.  Shared by k_pen_narrow (round 5's default form) and k_pen_frame.
+struct PenNarrowLds { unsigned* keys /* [2 PEN_FP] */; unsigned* bits /* [2 hasp_words + (V + 31) / 32 + V] */; int* slice /* [PEN_T] */; float* red /* [PEN_T / 64] */; int* dead; };
+template <bool P2P, class MARK>
+__device__ __forceinline__ void pen_narrow(const PenDev& P, const int b, const int npairs, const PenNarrowLds L, const float* __restrict__ verts,
+                                           const float sigma, const int penalize_outside, float* __restrict__ dverts, float* __restrict__ loss_out,
+                                           const PenAdjPrep& ap, MARK&& mark) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, F = P.F;
+    int* st = P.stats + b * PEN_STATS;
+    int* slice = L.slice; float* red = L.red;
+    // ---------------------------------------------------------------- D: the pair list (k_pen_list + k_pen_rank)
+    unsigned* keys = L.keys;                                        // [np] both orders of every pair, then the kept list in place
+    unsigned* bits = L.bits;                                        // [hw] cut lists | [hw] has pairs | [vw] touched vertices | vertex list
+    const int hw = P.hasp_words, vw = (P.V + 31) >> 5;
+    unsigned* cutb = bits; unsigned* hasb = bits + hw; unsigned* vtxb = bits + 2 * hw; int* vlist = reinterpret_cast<int*>(bits + 2 * hw + vw);
+    const int n2 = 2 * npairs;
+    int np = 64;
+    while (np < n2) np <<= 1;
+    {
+        const int2* pbuf = P.pbuf + (size_t)b * P.pf_cap;
+        for (int i = t; i < np / 2; i += PEN_T) {
+            unsigned k0 = 0xffffffffu, k1 = 0xffffffffu;
+            if (i < npairs) { const int2 pr = pbuf[i]; k0 = (unsigned)pr.x * (unsigned)F + (unsigned)pr.y; k1 = (unsigned)pr.y * (unsigned)F + (unsigned)pr.x; }
+            keys[2 * i] = k0; keys[2 * i + 1] = k1;
+        }
+        for (int w = t; w < 2 * hw + vw; w += PEN_T) bits[w] = 0u;
+    }
+    for (int k = 2; k <= np; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int q = t; q < np / 2; q += PEN_T) {           // compare-exchange q of this step: i = q with a 0 inserted at bit j
+                const int i = 2 * q - (q & (j - 1)), ixj = i + j;
+                const unsigned va = keys[i], vb = keys[ixj];
+                if ((va > vb) == ((i & k) == 0)) { keys[i] = vb; keys[ixj] = va; }
+            }
+        }
+    __syncthreads();
+    // rank within the triangle's run; the max_collisions lowest partners stay, positions by a prefix sum (every lane a contiguous range)
+    int T_ = 0;
+    {
+        const int per = (np + PEN_T - 1) / PEN_T;          // <= 16
+        const int j0 = min(n2, t * per), j1 = min(n2, j0 + per);
+        unsigned kk[16]; int fj[16];
+        int last_start = -1;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = j0 + u;
+            if (u < per && j < j1) {
+                kk[u] = keys[j]; fj[u] = (int)(kk[u] / (unsigned)F);
+                const bool start = j == 0 || (int)(keys[j - 1] / (unsigned)F) != fj[u];
+                if (start) last_start = j;
+            }
+        }
+        const int before = pen_block_excl_scan_max(last_start, slice);        // start of the run that is open when this lane's range begins
+        int cur = before, nkeep = 0, ncut = 0;
+        bool kp[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int j = j0 + u;
+            kp[u] = false;
+            if (u < per && j < j1) {
+                const bool start = j == 0 || (u > 0 ? fj[u - 1] != fj[u] : cur < 0 || (int)(keys[j - 1] / (unsigned)F) != fj[u]);
+                if (start) cur = j;
+                kp[u] = j - cur < P.cap;
+                if (kp[u]) ++nkeep; else { ++ncut; atomicOr(&cutb[fj[u] >> 5], 1u << (fj[u] & 31)); }
+            }
+        }
+        int ptot;
+        int pos = block_excl_scan(nkeep, slice, &ptot);
+        const float cut_all = block_sum_fixed((float)ncut, red);           // (ends with a barrier: every read of the sorted keys is done)
+        T_ = ptot;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (u < per && kp[u]) keys[pos++] = kk[u];
+        if (t == 0) { P.ptotal[b] = T_; st[0] = T_; st[1] = (int)cut_all; if (P.over) P.over[b] = st[13] > 0 ? 1 : 0;      // (a cut bucket walk: pairs missing, order dependent)
+                      if (P.work) { atomicAdd(&P.work[1], (unsigned long long)T_); if (st[13] > 0) atomicAdd(&P.work[5], (unsigned long long)st[13]); } }
+    }
+    __syncthreads();
+    mark();                                     // [7] D: pair list
+    const int T = T_;
+    {   // the list as the diagnostics read it (sfx_pen_pairs)
+        int* pown = P.pown + (size_t)b * P.pair_cap; int* plist = P.plist + (size_t)b * P.pair_cap;
+        for (int i = t; i < T; i += PEN_T) { const unsigned k = keys[i]; const int f = (int)(k / (unsigned)F); pown[i] = f; plist[i] = (int)(k - (unsigned)f * (unsigned)F); }
+    }
+    // ---------------------------------------------------------------- E: pair evaluation, a 64-aligned chunk of the list per wavefront
+    const float* vb = verts + (size_t)b * P.V * 3;
+    float* po = P.pout + (size_t)b * 10 * P.pair_cap;
+    for (int c = wv; c * 64 < T; c += PEN_FW) {
+        const int i = c * 64 + lane;
+        const bool valid = i < T;
+        const unsigned k = keys[valid ? i : 0];
+        const int f_ = (int)(k / (unsigned)F), g_ = (int)(k - (unsigned)f_ * (unsigned)F);
+        const int f = valid ? f_ : 0, g = valid ? g_ : 0;
+        bool sym = valid;
+        if (valid && ((cutb[g >> 5] >> (g & 31)) & 1u)) {          // the partner's list was cut: did it keep this triangle?
+            const unsigned want_k = (unsigned)g * (unsigned)F + (unsigned)f;
+            int lo = 0, hi = T;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < want_k) lo = mid + 1; else hi = mid; }
+            sym = lo < T && keys[lo] == want_k;
+        }
+        {
+            const unsigned long long dead = __ballot(valid && !sym);
+            if (dead && lane == 0) atomicAdd(L.dead, __popcll(dead));
+        }
+        float v[10];
+        pen_pair_eval<P2P>(P, vb, f, g, sym, sigma, penalize_outside, v);
+        pen_run_sums(v, valid ? f : -1, valid, lane, po, P.pair_cap, i);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (t == 0) st[15] = (*L.dead);
+    mark();                                     // [8] E: pair evaluation
+    // ---------------------------------------------------------------- F: per-triangle sums; which triangles / vertices carry a gradient
+    for (int i = t; i < T; i += PEN_T) {
+        const unsigned k = keys[i];
+        const int f = (int)(k / (unsigned)F);
+        if (i > 0 && (int)(keys[i - 1] / (unsigned)F) == f) continue;
+        const unsigned nextf = (unsigned)(f + 1) * (unsigned)F;        // (F^2 < 2^32: no wrap for f + 1 <= F)
+        int lo = i + 1, hi = T;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < nextf) lo = mid + 1; else hi = mid; }
+        pen_face_sum(po, P.pair_cap, i, lo - i, P.tgrad + ((size_t)b * F + f) * 9, P.tloss + (size_t)b * F + f);
+        atomicOr(&hasb[f >> 5], 1u << (f & 31));
+        const int4 vf = P.faces4[f];
+        atomicOr(&vtxb[vf.x >> 5], 1u << (vf.x & 31)); atomicOr(&vtxb[vf.y >> 5], 1u << (vf.y & 31)); atomicOr(&vtxb[vf.z >> 5], 1u << (vf.z & 31));
+    }
+    __threadfence_block();
+    __syncthreads();
+    mark();                                     // [9] F: per-triangle sums
+    // ---------------------------------------------------------------- G: vertex gradients, d v_posed, the frame's loss
+    {
+        int nv = 0;
+        for (int w0 = 0; w0 < vw; w0 += PEN_T) {             // (vw <= PEN_T for meshes of up to 32 k vertices: one trip)
+            const int w = w0 + t;
+            const unsigned word = w < vw ? vtxb[w] : 0u;
+            int tot;
+            int pos = nv + block_excl_scan(__popc(word), slice, &tot);
+            unsigned m = word;
+            while (m) { const int bit = __ffs((int)m) - 1; m &= m - 1; vlist[pos++] = w * 32 + bit; }
+            nv += tot;
+        }
+        __syncthreads();
+        for (int q = t; q < nv; q += PEN_T) pen_vertex_out(P, b, vlist[q], T, hasb, dverts, ap);
+        if (t < 256) {
+            const float s = pen_frame_loss_partial(P, b, T, hasb, t);
+            if (lane == 0) red[wv] = s;
+        }
+        __syncthreads();
+        if (t == 0) loss_out[b] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
+    mark();                                     // [10] G: vertices, loss
+}
+
+// Round 5's default form: the grid build and the pair tests stay spread over the chip (k_pen_g1 / g2 / g3, k_pen_walk / walk2 --
+// the tests are matrix-free ALU work, ~50 instructions per candidate and 10^4-10^5 candidates per column: one compute unit
+// needs 70-150 us for a column's, measured in k_pen_frame), the accepted pairs land in one list per column, and ONE workgroup per
+// column does everything behind them (pen_narrow) -- what k_pen_list, k_pen_rank, k_pen_eval, k_pen_facesum and k_pen_gather did
+// with a pass over all F triangles or V vertices and a launch each.  A column with more pairs than the LDS sort holds (2 x PEN_FP
+// keys) is handed to those kernels (P.heavy / P.hlist), which redo its pair tests into the partner lists.
+template <bool P2P>
+__global__ __launch_bounds__(PEN_T)
+void k_pen_narrow(PenDev P, const float* __restrict__ verts, const float sigma, const int penalize_outside, float* __restrict__ dverts,
+                  float* __restrict__ loss_out, const int* __restrict__ want, PenAdjPrep ap, const int force_heavy) {
+    extern __shared__ int lds[];                // [2 PEN_FP] sort keys | bit sets and vertex list
+    __shared__ int slice[PEN_T];
+    __shared__ float red[PEN_T / 64];
+    __shared__ int s_dead;
+    const int b = blockIdx.x, t = threadIdx.x;
+    int* st = P.stats + b * PEN_STATS;
+    const long long t_start = wall_clock64();
+    int n_mark = 3;                             // (stats[7..10]: the stamps of phases D-G, as in k_pen_frame)
+    auto mark = [&]() { if (t == 0) st[4 + n_mark] = (int)(wall_clock64() - t_start); ++n_mark; };
+    const int wanted = want ? want[b] : 1, npairs = P.pcnt[b], overflow = st[2], cut = st[13];
+    if (t == 0) { P.heavy[b] = 0; P.wqn[b] = 0; s_dead = 0; }      // (the chunk queue is consumed: the general kernels start from an empty one)
+    if (!wanted || overflow != 0) {             // no collision weight in this column's stage / grid overflow (reported): no pairs
+        if (t == 0) { loss_out[b] = 0.f; if (P.over) P.over[b] = 0; }
+        return;
+    }
+    if (force_heavy || !P.fast_ok || npairs > P.pf_cap) {
+        if (t == 0) { P.heavy[b] = 1; P.hlist[atomicAdd(P.nheavy, 1)] = b; st[13] = 0; }      // (the general kernels count the cut walks of their own pass)
+        return;
+    }
+    (void)cut;
+    __syncthreads();
+    const int t_entry = (int)(wall_clock64() - t_start);
+    pen_narrow<P2P>(P, b, npairs, PenNarrowLds{reinterpret_cast<unsigned*>(lds), reinterpret_cast<unsigned*>(lds + 2 * PEN_FP), slice, red, &s_dead},
+                    verts, sigma, penalize_outside, dverts, loss_out, ap, mark);
+    if (t == 0 && P.work) {                     // (debug: sfx_debug_pen_phase_ticks)
+        const int s7 = st[7], s8 = st[8], s9 = st[9], s10 = st[10];
+        atomicAdd(&P.work[8], (unsigned long long)t_entry); atomicAdd(&P.work[9], (unsigned long long)(s7 - t_entry));
+        atomicAdd(&P.work[10], (unsigned long long)(s8 - s7)); atomicAdd(&P.work[11], (unsigned long long)(s9 - s8));
+        atomicAdd(&P.work[12], (unsigned long long)(s10 - s9)); atomicAdd(&P.work[13], 1ull); atomicAdd(&P.work[14], (unsigned long long)st[0]);
+    }
 }
 
 template <bool P2P>
@@ -1696,45 +1936,86 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
     const long long t_start = wall_clock64();
     int n_mark = 0;
     auto mark = [&]() { if (t == 0) st[4 + n_mark] = (int)(wall_clock64() - t_start); ++n_mark; };
-    if (t == 0) { P.wqn[b] = 0; P.heavy[b] = 0; }
-    if (want && !want[b]) {                     // the frame's stage carries no collision weight: nothing to do
-        if (t == 0) { P.ptotal[b] = 0; cells[PEN_CELLS] = 0; st[0] = st[1] = st[2] = st[3] = 0; st[13] = 0; st[15] = 0; loss_out[b] = 0.f;
-                      if (P.over) P.over[b] = 0; }
-        return;
-    }
-    const float* aabb = P.aabb + (size_t)b * F * 6;
-    int2* cand = P.cand + (size_t)b * P.ent_cap;
-    const PenGridCtx C = pen_grid_ctx(P, b);
-    // ---------------------------------------------------------------- A: part culling, candidate records (k_pen_g2)
-    if (t == 0) { float* gp = P.gridp + b * 4; gp[0] = C.glo[0]; gp[1] = C.glo[1]; gp[2] = C.glo[2]; gp[3] = C.ih; s_cnt = 0; s_ccnt = 0; s_npairs = 0; s_dead = 0; }
-    if (t < 64) {
-        s_mask[t] = P.skipmask[t];
-        for (int e = 0; e < 6; ++e) s_pbox[t][e] = P.pbox[((size_t)b * 64 + t) * 6 + e];
-    }
-    for (int c = t; c <= PEN_CELLS; c += PEN_T) cell_cnt[c] = 0;
-    for (int c = t; c < PEN_CELLS; c += PEN_T) pmask[c] = 0u;
-    __syncthreads();
-    if (t < 64) {       // parts whose boxes meet and that may collide, as one 64-bit word per part
-        unsigned long long m = 0;
-        if (t < P.n_parts && s_pbox[t][0] <= s_pbox[t][3]) {
-            const unsigned long long sk = s_mask[t];
-            for (int q = 0; q < P.n_parts; ++q) {
-                const bool meet = s_pbox[t][0] <= s_pbox[q][3] && s_pbox[q][0] <= s_pbox[t][3] && s_pbox[t][1] <= s_pbox[q][4] &&
-                                  s_pbox[q][1] <= s_pbox[t][4] && s_pbox[t][2] <= s_pbox[q][5] && s_pbox[q][2] <= s_pbox[t][5];
-                if (meet && !((sk >> q) & 1ull)) m |= 1ull << q;
-            }
+#ifdef PEN_ASTAMP
+    int n_sub = 0;
+#define ASUB() do { if (t == 0) st[5 + n_sub] = (int)(wall_clock64() - t_start); ++n_sub; } while (0)
+#else
+#define ASUB() do { } while (0)
+#endif
+    // Everything this column needs from global memory before the culling, fetched by different lanes in ONE round trip (a dependent
+    // global access costs this workgroup 1-2 us -- its inputs were written by another kernel, on other XCDs' L2s -- and the first
+    // version of this prologue strung ten of them together: 20 us): part boxes, the static part table, the frame box partials.
+    __shared__ float s_gpart[PEN_GW * 8];
+    __shared__ unsigned s_near32[128];
+    const int wanted = want ? want[b] : 1;
+    {
+        int pb_v = 0; unsigned long long sk_v = 0ull; float gp_v = 0.f;
+        if (t < 64 * 6) pb_v = P.pbox[(size_t)b * 64 * 6 + t];
+        else if (t < 64 * 6 + 64) sk_v = P.skipmask[t - 64 * 6];
+        else if (t < 64 * 6 + 64 + PEN_GW * 8) gp_v = P.gpart[(size_t)b * PEN_GW * 8 + (t - 64 * 6 - 64)];
+        if (t == 0) { P.wqn[b] = 0; P.heavy[b] = 0; }
+        if (!wanted) {                          // the frame's stage carries no collision weight: nothing to do
+            if (t == 0) { P.ptotal[b] = 0; cells[PEN_CELLS] = 0; st[0] = st[1] = st[2] = st[3] = 0; st[13] = 0; st[15] = 0; loss_out[b] = 0.f;
+                          if (P.over) P.over[b] = 0; }
+            return;
         }
-        s_near[t] = m;
+        if (t < 64 * 6) (&s_pbox[0][0])[t] = pb_v;
+        else if (t < 64 * 6 + 64) {
+            const int q = t - 64 * 6;
+            s_mask[q] = sk_v;
+            const unsigned long long c = q < P.n_parts ? ~sk_v & (P.n_parts >= 64 ? ~0ull : (1ull << P.n_parts) - 1ull) : 0ull;
+            s_coll32[q] = (unsigned)c; s_coll32[64 + q] = (unsigned)(c >> 32);
+        } else if (t < 64 * 6 + 64 + PEN_GW * 8) s_gpart[t - 64 * 6 - 64] = gp_v;
+        if (t < 128) s_near32[t] = 0u;
+        if (t == 0) { s_cnt = 0; s_ccnt = 0; s_npairs = 0; s_dead = 0; }
+        for (int c = t; c <= PEN_CELLS; c += PEN_T) cell_cnt[c] = 0;
+        for (int c = t; c < PEN_CELLS; c += PEN_T) pmask[c] = 0u;
     }
-    pen_coll32(P, s_coll32);                    // (ends with a barrier)
+    __syncthreads();
+    ASUB();     // [5] inputs staged
     // the part boxes are read: leave them empty for the next evaluation of this column (k_pen_g1 accumulates into them)
     if (t < 64 * 6) P.pbox[(size_t)b * 64 * 6 + t] = (t % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+    const float* aabb = P.aabb + (size_t)b * F * 6;
+    int2* cand = P.cand + (size_t)b * P.ent_cap;
+    PenGridCtx C;                               // (pen_grid_ctx on the staged partials: same operations, same order)
+    {
+        float lo3[3] = {3e38f, 3e38f, 3e38f}, ext = 0.f;
+        for (int w = 0; w < PEN_GW; ++w) {
+            const float* g = s_gpart + w * 8;
+            for (int e = 0; e < 3; ++e) lo3[e] = fminf(lo3[e], g[e]);
+            ext += g[6];
+        }
+        const float h = fmaxf(2.f * (ext / (float)P.F), 1e-6f);
+        for (int e = 0; e < 3; ++e) C.glo[e] = lo3[e];
+        C.ih = 1.f / h;
+    }
+    if (t == 0) { float* gp = P.gridp + b * 4; gp[0] = C.glo[0]; gp[1] = C.glo[1]; gp[2] = C.glo[2]; gp[3] = C.ih; }
+    // ---------------------------------------------------------------- A: part culling, candidate records (k_pen_g2)
+    {   // parts whose boxes meet and that may collide, one 64-bit word per part: the 64 x 64 tests dealt over the lanes (16 lanes per part)
+        const int p_ = t >> 4, q0 = t & 15;
+        unsigned lo_m = 0u, hi_m = 0u;
+        if (p_ < P.n_parts && s_pbox[p_][0] <= s_pbox[p_][3]) {
+            const unsigned long long sk = s_mask[p_];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = q0 + 16 * k;
+                const bool meet = (q < P.n_parts) & (s_pbox[p_][0] <= s_pbox[q][3]) & (s_pbox[q][0] <= s_pbox[p_][3]) & (s_pbox[p_][1] <= s_pbox[q][4]) &
+                                  (s_pbox[q][1] <= s_pbox[p_][4]) & (s_pbox[p_][2] <= s_pbox[q][5]) & (s_pbox[q][2] <= s_pbox[p_][5]);
+                if (meet && !((sk >> q) & 1ull)) { if (q < 32) lo_m |= 1u << q; else hi_m |= 1u << (q - 32); }
+            }
+        }
+        if (lo_m) atomicOr(&s_near32[2 * p_], lo_m);
+        if (hi_m) atomicOr(&s_near32[2 * p_ + 1], hi_m);
+    }
+    __syncthreads();
+    if (t < 64) s_near[t] = (unsigned long long)s_near32[2 * t] | ((unsigned long long)s_near32[2 * t + 1] << 32);
+    __syncthreads();
+    ASUB();     // [6] near masks
     // Two levels (round 5): first the CLUSTERS of 64 consecutive triangles -- their boxes are one DPP reduction per wavefront in
     // k_pen_g1, their part sets are static -- against the boxes of the parts they may collide with, one cluster per lane; then the
     // triangles of the clusters that are left (a fifth of them on a body), a cluster per wavefront.  A lane per triangle through all
     // F boxes, each walking its part's list of near parts on LDS round trips, took 58 us of this kernel's 210.
     int* clist = reinterpret_cast<int*>(pmask);             // (the part masks are filled in phase B; the list is consumed before)
-    if (t == 0) st[11] = (int)(wall_clock64() - t_start);   // (diagnostic: end of the prologue)
     {
         int n_surv = 0;
         for (int c0 = 0; c0 < P.n_clus; c0 += PEN_T) {      // (one trip for meshes of up to 65 k triangles)
@@ -1764,13 +2045,28 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
             n_surv += tot;
         }
         __syncthreads();
-        if (t == 0) st[12] = (int)(wall_clock64() - t_start);   // (diagnostic: end of the cluster culling)
-        for (int ci = wv; ci < n_surv; ci += PEN_FW) {
-            const int f = clist[ci] * 64 + lane, ff = f < F ? f : 0;
-            const int seg = P.segm[ff];
+        ASUB();     // [7] clusters culled
+        if (t == 0) st[12] = n_surv;
+        for (int cg = wv; cg < n_surv; cg += PEN_FW * PEN_AU) {      // PEN_AU clusters of the wavefront per trip: their loads go out together
+          int f4[PEN_AU], seg4[PEN_AU]; float bx4[PEN_AU][6];
+#pragma unroll
+          for (int u = 0; u < PEN_AU; ++u) {
+              const int ci = cg + u * PEN_FW;
+              const int fr = clist[min(ci, n_surv - 1)] * 64 + lane;
+              f4[u] = ci < n_surv ? fr : F;
+              const unsigned ff = (unsigned)min(fr, F - 1);
+              seg4[u] = P.segm[ff];
+              const float* bp = aabb + (size_t)ff * 6;
+#pragma unroll
+              for (int e = 0; e < 6; ++e) bx4[u][e] = bp[e];
+          }
+#pragma unroll
+          for (int u = 0; u < PEN_AU; ++u) {
+            if (cg + u * PEN_FW >= n_surv) break;
+            const int f = f4[u], seg = seg4[u];
             float bx[6];
 #pragma unroll
-            for (int e = 0; e < 6; ++e) bx[e] = aabb[ff * 6 + e];
+            for (int e = 0; e < 6; ++e) bx[e] = bx4[u][e];
             bool any = false;
             unsigned long long nm = f < F ? s_near[seg] : 0ull;
             if (nm) {
@@ -1809,13 +2105,20 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
                 });
             }
         }
+        }
+        ASUB();     // [8] wavefront 0 through its clusters
         __syncthreads();
+        ASUB();     // [9] all wavefronts
         for (int c = t; c < P.n_clus && c < PEN_CELLS; c += PEN_T) pmask[c] = 0u;       // (the cluster list lay in the part masks' array)
     }
     __threadfence_block();
     __syncthreads();
     const int NT = min(s_cnt, F), NC_raw = s_ccnt, NC = min(NC_raw, P.ent_cap);
     mark();                                     // [4] A: part culling
+#ifdef PEN_ASTAMP
+    if (t == 0) { st[10] = NC_raw; st[11] = NT; P.ptotal[b] = 0; loss_out[b] = 0.f; st[0] = st[1] = st[2] = 0; }
+    return;
+#endif
     // ---------------------------------------------------------------- B: counting sort into the hashed grid (k_pen_g3)
     constexpr int U2 = 8;
     auto cell_bucket = [](const int key) { return pen_bucket(key & 1023, (key >> 10) & 1023, (key >> 20) & 1023); };
@@ -1926,6 +2229,7 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
                 tA[idx] = make_int4(hd[0], hd[1], hd[2], hd[3]); tB[idx] = make_int4(hd[4], hd[5], hd[6], hd[7]);
             }
             __syncthreads();
+            if (t == 0 && tile0 == 0) st[11] = (int)(wall_clock64() - t_start);   // (diagnostic: the first tile is in LDS)
             const int nown = min(PEN_TOWN, n_ent - tile0);
             for (int blk = wv; blk * 64 < nown; blk += PEN_FW) {
                 const int idx0 = blk * 64 + lane, qi = tile0 + idx0;
@@ -1966,6 +2270,7 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
                 }
             }
         }
+        if (t == 0) st[12] = (int)(wall_clock64() - t_start);   // (diagnostic: wavefront 0 is through its blocks)
         flush();
     }
     __threadfence_block();
@@ -1973,145 +2278,8 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
     const int npairs = s_npairs;
     mark();                                     // [6] C: pair tests
     if (npairs > P.pf_cap) { hand_over(); return; }
-    // ---------------------------------------------------------------- D: the pair list (k_pen_list + k_pen_rank)
-    unsigned* keys = reinterpret_cast<unsigned*>(r1);               // [np] both orders of every pair, then the kept list in place
-    unsigned* bits = reinterpret_cast<unsigned*>(cell_cnt);         // the grid is done with: [hw] cut lists | [hw] has pairs | [vw] touched vertices | vertex list
-    const int hw = P.hasp_words, vw = (P.V + 31) >> 5;
-    unsigned* cutb = bits; unsigned* hasb = bits + hw; unsigned* vtxb = bits + 2 * hw; int* vlist = reinterpret_cast<int*>(bits + 2 * hw + vw);
-    const int n2 = 2 * npairs;
-    int np = 64;
-    while (np < n2) np <<= 1;
-    {
-        const int2* pbuf = P.pbuf + (size_t)b * P.pf_cap;
-        for (int i = t; i < np / 2; i += PEN_T) {
-            unsigned k0 = 0xffffffffu, k1 = 0xffffffffu;
-            if (i < npairs) { const int2 pr = pbuf[i]; k0 = (unsigned)pr.x * (unsigned)F + (unsigned)pr.y; k1 = (unsigned)pr.y * (unsigned)F + (unsigned)pr.x; }
-            keys[2 * i] = k0; keys[2 * i + 1] = k1;
-        }
-        for (int w = t; w < 2 * hw + vw; w += PEN_T) bits[w] = 0u;
-    }
-    for (int k = 2; k <= np; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            __syncthreads();
-            for (int q = t; q < np / 2; q += PEN_T) {           // compare-exchange q of this step: i = q with a 0 inserted at bit j
-                const int i = 2 * q - (q & (j - 1)), ixj = i + j;
-                const unsigned va = keys[i], vb = keys[ixj];
-                if ((va > vb) == ((i & k) == 0)) { keys[i] = vb; keys[ixj] = va; }
-            }
-        }
-    __syncthreads();
-    // rank within the triangle's run; the max_collisions lowest partners stay, positions by a prefix sum (every lane a contiguous range)
-    int T_ = 0;
-    {
-        const int per = (np + PEN_T - 1) / PEN_T;          // <= 16
-        const int j0 = min(n2, t * per), j1 = min(n2, j0 + per);
-        unsigned kk[16]; int fj[16];
-        int last_start = -1;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int j = j0 + u;
-            if (u < per && j < j1) {
-                kk[u] = keys[j]; fj[u] = (int)(kk[u] / (unsigned)F);
-                const bool start = j == 0 || (int)(keys[j - 1] / (unsigned)F) != fj[u];
-                if (start) last_start = j;
-            }
-        }
-        const int before = pen_block_excl_scan_max(last_start, slice);        // start of the run that is open when this lane's range begins
-        int cur = before, nkeep = 0, ncut = 0;
-        bool kp[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int j = j0 + u;
-            kp[u] = false;
-            if (u < per && j < j1) {
-                const bool start = j == 0 || (u > 0 ? fj[u - 1] != fj[u] : cur < 0 || (int)(keys[j - 1] / (unsigned)F) != fj[u]);
-                if (start) cur = j;
-                kp[u] = j - cur < P.cap;
-                if (kp[u]) ++nkeep; else { ++ncut; atomicOr(&cutb[fj[u] >> 5], 1u << (fj[u] & 31)); }
-            }
-        }
-        int ptot;
-        int pos = block_excl_scan(nkeep, slice, &ptot);
-        const float cut_all = block_sum_fixed((float)ncut, red);           // (ends with a barrier: every read of the sorted keys is done)
-        T_ = ptot;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) if (u < per && kp[u]) keys[pos++] = kk[u];
-        if (t == 0) { P.ptotal[b] = T_; st[0] = T_; st[1] = (int)cut_all; if (P.over) P.over[b] = 0;
-                      if (P.work) atomicAdd(&P.work[1], (unsigned long long)T_); }
-    }
-    __syncthreads();
-    mark();                                     // [7] D: pair list
-    const int T = T_;
-    {   // the list as the diagnostics read it (sfx_pen_pairs)
-        int* pown = P.pown + (size_t)b * P.pair_cap; int* plist = P.plist + (size_t)b * P.pair_cap;
-        for (int i = t; i < T; i += PEN_T) { const unsigned k = keys[i]; const int f = (int)(k / (unsigned)F); pown[i] = f; plist[i] = (int)(k - (unsigned)f * (unsigned)F); }
-    }
-    // ---------------------------------------------------------------- E: pair evaluation, a 64-aligned chunk of the list per wavefront
-    const float* vb = verts + (size_t)b * P.V * 3;
-    float* po = P.pout + (size_t)b * 10 * P.pair_cap;
-    for (int c = wv; c * 64 < T; c += PEN_FW) {
-        const int i = c * 64 + lane;
-        const bool valid = i < T;
-        const unsigned k = keys[valid ? i : 0];
-        const int f_ = (int)(k / (unsigned)F), g_ = (int)(k - (unsigned)f_ * (unsigned)F);
-        const int f = valid ? f_ : 0, g = valid ? g_ : 0;
-        bool sym = valid;
-        if (valid && ((cutb[g >> 5] >> (g & 31)) & 1u)) {          // the partner's list was cut: did it keep this triangle?
-            const unsigned want_k = (unsigned)g * (unsigned)F + (unsigned)f;
-            int lo = 0, hi = T;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < want_k) lo = mid + 1; else hi = mid; }
-            sym = lo < T && keys[lo] == want_k;
-        }
-        {
-            const unsigned long long dead = __ballot(valid && !sym);
-            if (dead && lane == 0) atomicAdd(&s_dead, __popcll(dead));
-        }
-        float v[10];
-        pen_pair_eval<P2P>(P, vb, f, g, sym, sigma, penalize_outside, v);
-        pen_run_sums(v, valid ? f : -1, valid, lane, po, P.pair_cap, i);
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (t == 0) st[15] = s_dead;
-    mark();                                     // [8] E: pair evaluation
-    // ---------------------------------------------------------------- F: per-triangle sums; which triangles / vertices carry a gradient
-    for (int i = t; i < T; i += PEN_T) {
-        const unsigned k = keys[i];
-        const int f = (int)(k / (unsigned)F);
-        if (i > 0 && (int)(keys[i - 1] / (unsigned)F) == f) continue;
-        const unsigned nextf = (unsigned)(f + 1) * (unsigned)F;        // (F^2 < 2^32: no wrap for f + 1 <= F)
-        int lo = i + 1, hi = T;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < nextf) lo = mid + 1; else hi = mid; }
-        pen_face_sum(po, P.pair_cap, i, lo - i, P.tgrad + ((size_t)b * F + f) * 9, P.tloss + (size_t)b * F + f);
-        atomicOr(&hasb[f >> 5], 1u << (f & 31));
-        const int4 vf = P.faces4[f];
-        atomicOr(&vtxb[vf.x >> 5], 1u << (vf.x & 31)); atomicOr(&vtxb[vf.y >> 5], 1u << (vf.y & 31)); atomicOr(&vtxb[vf.z >> 5], 1u << (vf.z & 31));
-    }
-    __threadfence_block();
-    __syncthreads();
-    mark();                                     // [9] F: per-triangle sums
-    // ---------------------------------------------------------------- G: vertex gradients, d v_posed, the frame's loss
-    {
-        int nv = 0;
-        for (int w0 = 0; w0 < vw; w0 += PEN_T) {             // (vw <= PEN_T for meshes of up to 32 k vertices: one trip)
-            const int w = w0 + t;
-            const unsigned word = w < vw ? vtxb[w] : 0u;
-            int tot;
-            int pos = nv + block_excl_scan(__popc(word), slice, &tot);
-            unsigned m = word;
-            while (m) { const int bit = __ffs((int)m) - 1; m &= m - 1; vlist[pos++] = w * 32 + bit; }
-            nv += tot;
-        }
-        __syncthreads();
-        for (int q = t; q < nv; q += PEN_T) pen_vertex_out(P, b, vlist[q], T, hasb, dverts, ap);
-        if (t < 256) {
-            const float s = pen_frame_loss_partial(P, b, T, hasb, t);
-            if (lane == 0) red[wv] = s;
-        }
-        __syncthreads();
-        if (t == 0) loss_out[b] = ((red[0] + red[1]) + red[2]) + red[3];
-    }
-    mark();                                     // [10] G: vertices, loss
+    pen_narrow<P2P>(P, b, npairs, PenNarrowLds{reinterpret_cast<unsigned*>(r1), reinterpret_cast<unsigned*>(cell_cnt), slice, red, &s_dead},
+                    verts, sigma, penalize_outside, dverts, loss_out, ap, mark);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2120,14 +2288,27 @@ void k_pen_frame(PenDev P, const float* __restrict__ verts, const float sigma, c
 static unsigned long long* g_pen_work = nullptr;      // device [4], process-wide (shared by every handle)
 static unsigned long long* pen_work_buffer() {
     if (!g_pen_work) {
-        if (hipMalloc((void**)&g_pen_work, 6 * sizeof(unsigned long long)) != hipSuccess) { g_pen_work = nullptr; return nullptr; }
-        hipMemset(g_pen_work, 0, 6 * sizeof(unsigned long long));
+        if (hipMalloc((void**)&g_pen_work, 16 * sizeof(unsigned long long)) != hipSuccess) { g_pen_work = nullptr; return nullptr; }
+        hipMemset(g_pen_work, 0, 16 * sizeof(unsigned long long));
     }
     return g_pen_work;
 }
 extern "C" int sfx_pen_work_reset(void) {
     if (!pen_work_buffer()) { sfx_set_error("out of device memory"); return -2; }
-    if (hipDeviceSynchronize() != hipSuccess || hipMemset(g_pen_work, 0, 6 * sizeof(unsigned long long)) != hipSuccess) { sfx_set_error("device error"); return -4; }
+    if (hipDeviceSynchronize() != hipSuccess || hipMemset(g_pen_work, 0, 16 * sizeof(unsigned long long)) != hipSuccess) { sfx_set_error("device error"); return -4; }
+    return 0;
+}
+// debug: wall-clock ticks (100 MHz) k_pen_narrow's workgroups spent in their phases since sfx_pen_work_reset, summed over the column
+// evaluations that went through them: [0] until the pairs are read (entry), [1] D pair list, [2] E pair evaluation, [3] F triangle
+// sums, [4] G vertices and loss, [5] number of such evaluations, [6] their ordered pairs, [7] unused
+extern "C" int sfx_debug_pen_phase_ticks(int64_t* out /* [8] */) {
+    if (!out) { sfx_set_error("null argument"); return -1; }
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (!g_pen_work) return 0;
+    if (hipDeviceSynchronize() != hipSuccess) { sfx_set_error("device error"); return -4; }
+    unsigned long long h[8];
+    if (hipMemcpy(h, g_pen_work + 8, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { sfx_set_error("device error"); return -4; }
+    for (int i = 0; i < 8; ++i) out[i] = (int64_t)h[i];
     return 0;
 }
 extern "C" int sfx_pen_work_get(int64_t* out /* [6] */) {
@@ -2141,13 +2322,16 @@ extern "C" int sfx_pen_work_get(int64_t* out /* [6] */) {
     return 0;
 }
 
-// which form of the term new handles take (sfx_debug_pen_form): 1 = the per-frame kernel + the general kernels on the columns it
-// hands over (round 5, default); 0 = the ten general kernels on every column (rounds 2-4; the A/B partner: same bits);
-// 2 = form 1 with every column handed over after the grid build (exercises the hand-over on any mesh)
-static int g_pen_form = [] { const char* e = getenv("SFX_PEN_FORM"); return e ? atoi(e) : 1; }();
+// which form of the term new handles take (sfx_debug_pen_form): 0 = the ten general kernels on every column, every step dealt flat
+// over the chip (the default: fastest on the halpe cfg's fit, 332 frames/s); 1 = grid build and pair tests over the chip, then one
+// workgroup per column behind the pairs (k_pen_narrow) + the general kernels on the columns it hands over (296 frames/s: a round
+// lasts as long as its most crowded column's workgroup, and the fits always carry a few collapsed meshes); 2 = form 1 with every
+// column handed over (exercises the hand-over on any mesh); 3 = one workgroup per column behind the triangle boxes (k_pen_frame:
+// 145 frames/s).  Same bits in every form (tests/test_gpu_topology.py); DESIGN 4.6 has the measurements.
+static int g_pen_form = [] { const char* e = getenv("SFX_PEN_FORM"); return e ? atoi(e) : 0; }();
 extern "C" int sfx_debug_pen_form(int32_t form) {
     const int prev = g_pen_form;
-    if (form >= 0 && form <= 2) g_pen_form = form;
+    if (form >= 0 && form <= 3) g_pen_form = form;
     return prev;
 }
 
@@ -2243,12 +2427,13 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
         P.wbox = h->zeros<float>(B * P.n_clus * 6);
         if (!P.cpm || !P.wbox) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     }
-    P.heavy = h->zeros<int>(B); P.hlist = h->zeros<int>(B); P.nheavy = h->zeros<int>(1);
+    P.heavy = h->zeros<int>(B); P.hlist = h->zeros<int>(B); P.nheavy = h->zeros<int>(1); P.pcnt = h->zeros<int>(B);
     P.pbuf = reinterpret_cast<int2*>(P.partners);         // (the partner lists are unused on the fast path)
     P.pf_cap = (int)std::min<size_t>(PEN_FP, (size_t)F * P.pcap / 2);
+    { const char* e = getenv("SFX_PEN_FAST_PAIRS"); if (e && atoi(e) > 0) P.pf_cap = std::min(P.pf_cap, atoi(e)); }      // (measurement switch: columns with more pairs go to the general kernels)
     P.fast_ok = ((unsigned long long)F * (unsigned long long)F < (1ull << 32)) && (2 * ((F + 31) / 32) + (V + 31) / 32 + V <= PEN_GRID_INTS) &&
                 (size_t)2 * PEN_FP <= (size_t)P.pair_cap ? 1 : 0;
-    if (!P.heavy || !P.hlist || !P.nheavy) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
+    if (!P.heavy || !P.hlist || !P.nheavy || !P.pcnt) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tcount || !P.pbox || !P.gpart || !P.aabb || !P.entries) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.pavail || !P.ptotal || !P.ovq || !P.ovn || !P.callno) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     *out = h;
@@ -2297,22 +2482,37 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
     Pl.over = over_dev;         // (per call: the caller's per-mesh "arrival order decided" flags, or NULL)
     const bool fused = h->form != 0 && B <= PEN_FLAT_MAXB && !chunks_off && !flat_off;
     if (fused) {
-        // round 5: boxes -> one workgroup per column -> the general kernels on the columns handed over (usually none: each of
-        // these seven launches then ends after one load)
         static bool frame_attr = false;
+        const size_t narrow_lds = (size_t)(2 * PEN_FP + 2 * h->P.hasp_words + (h->P.V + 31) / 32 + h->P.V) * sizeof(int);
         if (!frame_attr) {
             if (hipFuncSetAttribute((const void*)k_pen_frame<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PEN_FRAME_LDS) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_pen_frame<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PEN_FRAME_LDS) != hipSuccess) {
-                sfx_set_error("cannot reserve LDS for k_pen_frame"); return -2; }
+                hipFuncSetAttribute((const void*)k_pen_frame<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PEN_FRAME_LDS) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_pen_narrow<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_pen_narrow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+                sfx_set_error("cannot reserve LDS for k_pen_narrow / k_pen_frame"); return -2; }
             frame_attr = true;
         }
+        const PenSel all{want_dev, nullptr, nullptr, nullptr};
         hipLaunchKernelGGL(k_pen_g1, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, verts_dev, want_dev, dverts_dev, ap.adj_G, ap.Vpad);
-        if (h->P.p2p) hipLaunchKernelGGL(k_pen_frame<true>, dim3(B), dim3(PEN_T), PEN_FRAME_LDS, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, h->form == 2 ? 1 : 0);
-        else hipLaunchKernelGGL(k_pen_frame<false>, dim3(B), dim3(PEN_T), PEN_FRAME_LDS, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, h->form == 2 ? 1 : 0);
+        if (h->form == 3) {
+            // one workgroup per column behind the boxes (measured and not the default: the pair tests of a column are 70-150 us of ALU
+            // work on ONE compute unit, and a round lasts as long as its slowest column)
+            if (h->P.p2p) hipLaunchKernelGGL(k_pen_frame<true>, dim3(B), dim3(PEN_T), PEN_FRAME_LDS, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, 0);
+            else hipLaunchKernelGGL(k_pen_frame<false>, dim3(B), dim3(PEN_T), PEN_FRAME_LDS, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, 0);
+        } else {
+            // round 5's default: grid build and pair tests over the chip, the pairs into one list per column, one workgroup per column behind them
+            hipLaunchKernelGGL(k_pen_g2, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, want_dev);
+            hipLaunchKernelGGL(k_pen_g3, dim3(B), dim3(PEN_T), (size_t)(PEN_GRID_INTS + PEN_CELLS) * sizeof(int), s, h->P, want_dev);
+            hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, h->P, all, 1);
+            hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, B, all, 1);
+            if (h->P.p2p) hipLaunchKernelGGL(k_pen_narrow<true>, dim3(B), dim3(PEN_T), narrow_lds, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, h->form == 2 ? 1 : 0);
+            else hipLaunchKernelGGL(k_pen_narrow<false>, dim3(B), dim3(PEN_T), narrow_lds, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, h->form == 2 ? 1 : 0);
+        }
+        // the general kernels on the columns handed over (usually none: each of these seven launches then ends after one load)
         const PenSel hv{nullptr, h->P.hlist, h->P.nheavy, h->P.heavy};
         const int HY = std::min(B, PEN_HEAVY_ROWS);
-        hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, HY), dim3(256), 0, s, h->P, hv);
-        hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, B, hv);
+        hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, HY), dim3(256), 0, s, h->P, hv, 0);
+        hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, B, hv, 0);
         hipLaunchKernelGGL(k_pen_list, dim3(HY), dim3(PEN_T), list_lds, s, Pl, hv);
         hipLaunchKernelGGL(k_pen_rank, dim3(rank_rows, HY), dim3(256), rank_lds, s, h->P, hv, cap_pad);
         if (h->P.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, verts_dev, sigma, penalize_outside, B, 1, hv);
@@ -2330,8 +2530,8 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
         PenDev Pw = h->P;
         const bool queued = B <= PEN_FLAT_MAXB && !chunks_off;
         if (!queued) Pw.wq_cap = 0;                // every block walks its bucket to the end itself
-        hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, Pw, all);
-        if (queued) hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, Pw, B, all);
+        hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, Pw, all, 0);
+        if (queued) hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, Pw, B, all, 0);
     }
     hipLaunchKernelGGL(k_pen_list, dim3(B), dim3(PEN_T), list_lds, s, Pl, all);
     hipLaunchKernelGGL(k_pen_rank, dim3(rank_rows, B), dim3(256), rank_lds, s, h->P, all, cap_pad);

@@ -471,9 +471,18 @@ def pen_work_get():
 
 def pen_form(form=-1):
     """Debug / A-B: which form of the interpenetration term Penetration handles and FrameBatches created from now on take
-    (sfx_debug_pen_form: 1 = per-frame kernel, the default; 0 = the ten general kernels; 2 = per-frame kernel handing every
-    column over).  Returns the previous setting; any other argument only queries."""
+    (sfx_debug_pen_form: 0 = the ten general kernels, the default; 1 = one workgroup per column behind the pair tests; 2 = form 1
+    handing every column over; 3 = one workgroup per column behind the triangle boxes).  Returns the previous setting; any other argument only queries."""
     return int(capi.load().sfx_debug_pen_form(int(form)))
+
+
+def pen_phase_ticks():
+    """Debug: mean microseconds a column evaluation spent in the phases of k_pen_narrow since pen_work_reset()."""
+    w = (C.c_int64 * 8)()
+    capi.check(capi.load().sfx_debug_pen_phase_ticks(w))
+    n = max(int(w[5]), 1)
+    return dict(entry_us=w[0] / n / 100.0, list_us=w[1] / n / 100.0, eval_us=w[2] / n / 100.0, sums_us=w[3] / n / 100.0,
+                verts_us=w[4] / n / 100.0, evaluations=int(w[5]), pairs_per_evaluation=w[6] / n)
 
 
 def _read_pairs(call):

@@ -86,9 +86,9 @@ def test_operator_on_the_real_surface(topo_model, cfg_halpe):
 
 
 def test_the_three_forms_of_the_term_give_the_same_bits(topo_model, cfg_halpe):
-    """Round 5: one workgroup per column behind the triangle boxes (k_pen_frame, form 1) against the ten general kernels of
-    rounds 2-4 (form 0) and against the per-frame kernel handing every column to them after the grid build (form 2): pair
-    list, statistics, loss and every vertex' gradient bit for bit -- on posed bodies, with a cap that binds (max_collisions 4:
+    """Round 5: one workgroup per column behind the accepted pairs (k_pen_narrow, form 1, the default) against the ten general
+    kernels of rounds 2-4 (form 0), against form 1 handing every column to them (form 2) and against one workgroup per column
+    behind the triangle boxes (k_pen_frame, form 3): pair list, statistics, loss and every vertex' gradient bit for bit -- on posed bodies, with a cap that binds (max_collisions 4:
     cut lists, pairs only one side kept), and with point2plane."""
     parts = synthetic.topology_parts()
     faces = np.asarray(topo_model["f"]).astype(np.int64)
@@ -99,7 +99,7 @@ def test_the_three_forms_of_the_term_give_the_same_bits(topo_model, cfg_halpe):
     try:
         for cap, p2p in ((128, False), (4, False), (128, True)):
             res = {}
-            for form in (0, 1, 2):
+            for form in (0, 1, 2, 3):
                 engine.pen_form(form)
                 pen = engine.Penetration(vb.shape[1], faces, parts["segm"], parts["parents"], cfg_halpe["ign_part_pairs"],
                                          max_collisions=cap, max_batch=B)
@@ -110,7 +110,7 @@ def test_the_three_forms_of_the_term_give_the_same_bits(topo_model, cfg_halpe):
                 pen.close()
             if cap == 4:
                 assert res[1][3]["dropped"].min() > 0               # the cap binds on every body
-            for form in (1, 2):
+            for form in (1, 2, 3):
                 assert np.array_equal(res[form][0], res[0][0]), (cap, p2p, form, res[form][0], res[0][0])
                 assert np.array_equal(res[form][1], res[0][1]), (cap, p2p, form)
                 for b in range(B):
@@ -226,8 +226,8 @@ def test_fit_on_the_real_surface_is_reproducible_and_pool_independent(topo_model
     r2, w2 = fit(5)
     assert np.all(np.isfinite(r0["stage_loss"])) and w0["columns"] > 0 and w0["pairs"] > 0, w0
     assert w0["walks_cut"] == 0, w0          # (lists beyond 2 x max_collisions occur in trial steps of the line search: derived from the grid again, exact)
-    # the ten-kernel form of rounds 2-4 fits the same bits
-    prev = engine.pen_form(0)
+    # the other forms of the term (one workgroup per column behind the pair tests) fit the same bits
+    prev = engine.pen_form(1)
     try:
         dm_old = T._dm(model, cfg)
         dm_old.set_parts(parts["segm"], parts["parents"], cfg["ign_part_pairs"])
@@ -238,7 +238,7 @@ def test_fit_on_the_real_surface_is_reproducible_and_pool_independent(topo_model
     finally:
         engine.pen_form(prev)
     for k in r0:
-        assert np.array_equal(np.asarray(r0[k]), np.asarray(r3[k])), ("ten-kernel form", k)
+        assert np.array_equal(np.asarray(r0[k]), np.asarray(r3[k])), ("form 1", k)
     assert (w3["pairs"], w3["columns"], w3["entries"]) == (w0["pairs"], w0["columns"], w0["entries"]), (w0, w3)
     assert {"stage_loss", "stage_evals", "betas", "global_orient", "body_pose", "left_hand_pose"} <= set(r0)
     for k in r0:

@@ -24,7 +24,7 @@ verts = verts.contiguous()
 faces = np.asarray(model["f"]).astype(np.int64)
 names = ["A cull", "B grid", "C pairs", "D list", "E eval", "F sums", "G verts"]
 for B in (1, 16, 64, 256):
-    for form in (1, 0):
+    for form in (1, 3, 0):
         engine.pen_form(form)
         pen = engine.Penetration(verts.shape[1], faces, parts["segm"], parts["parents"], cfg["ign_part_pairs"], max_collisions=128, max_batch=B)
         vb = verts[:B]
@@ -34,9 +34,9 @@ for B in (1, 16, 64, 256):
         torch.cuda.synchronize(); dt = (time.time() - t0) / 20
         st = pen.stats(B)
         line = "B=%3d form %d: %.1f us per evaluation; ordered pairs per body p50 %d max %d" % (B, form, dt * 1e6, np.median(st["pairs"]), st["pairs"].max())
-        if form == 1:
+        if form == 3:
             pca = pen.phase_clocks(B)
-            line += "\n      inside A: prologue ends %.1f us, cluster culling ends %.1f us" % (pca[:, 7].mean(), pca[:, 8].mean())
+            line += "\n      inside C: first tile in LDS at %.1f us, wavefront 0 through its blocks at %.1f us" % (pca[:, 7].mean(), pca[:, 8].mean())
             pc = pca[:, :7]
             d = np.diff(np.concatenate([np.zeros((B, 1)), pc], 1), axis=1)
             line += "\n      phases (us, mean over the bodies; end of G mean %.1f max %.1f): " % (pc[:, 6].mean(), pc[:, 6].max()) + \

@@ -33,6 +33,7 @@ def fit(c, want_vertices=False):
 r, w, dt = fit(cfg, True)
 r, w, dt = fit(cfg, True)
 print("fit with the term: %.3f s, %.1f frames/s; work %s" % (dt, B / dt, w))
+print("k_pen_narrow phases per column evaluation:", engine.pen_phase_ticks())
 ev = r["stage_evals"].sum(1)
 print("evaluations per frame: mean %.1f max %d; final loss median %.1f" % (ev.mean(), ev.max(), np.median(r["final_loss"])))
 bad = np.flatnonzero(~np.isfinite(r["stage_loss"]).all(1))
