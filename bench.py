@@ -94,7 +94,7 @@ def compact_line(full):
     line["config"] = _pick(cfg, ("workload", "frames_per_gpu", "lbs_mode", "gemm_columns_per_gpu", "parallelism",
                                  "closure_evals_per_frame_mean", "closure_evals_per_frame_max", "closure_evals_per_s",
                                  "reference_equiv_evals_per_frame_mean", "final_loss_mean", "final_loss_median", "non_finite",
-                                 "single_gpu_same_job_frames_per_s", "per_gpu_frames_per_s_min", "per_gpu_frames_per_s_mean",
+                                 "configs3_single_gpu_frames_per_s", "single_gpu_same_job_frames_per_s", "per_gpu_frames_per_s_min", "per_gpu_frames_per_s_mean",
                                  "per_gpu_closure_evals_max", "gather_ms_max"))
     for name in ("roofline", "roofline_tick", "roofline_pen"):
         if name in full:
@@ -342,7 +342,7 @@ def cpu_baseline_report(m, ref_evals_per_frame):
             "throughput": {"value": thr, "processes": m["throughput_processes"], "threads_per_process": 1,
                            "closure_evals_per_s": m["throughput_evals_per_s"]},
             "closure_evals_per_s": max(m["latency_evals_per_s"], m["throughput_evals_per_s"]),
-            "sample": "oracle fit (torch fp32) of this job's frames 0..%d: %d procs x 1 thread x %.0f s = %d closure evals; / %.0f evals per frame" % (
+            "sample": "EXTRAPOLATED from evals/s: oracle fit (torch fp32) of this job's frames 0..%d: %d procs x 1 thread x %.0f s = %d closure evals; / %.0f evals per fitted frame" % (
                 m["throughput_processes"] - 1, m["throughput_processes"], m["throughput_s"], m["throughput_evals"], per),
             "sample_detail": {"latency_mode": "1 process x %d threads on frame 0 for %.0f s = %d evaluations" % (m["latency_threads"], m["latency_s"], m["latency_evals"]),
                               "throughput_mode": "%d single-threaded processes on frames 0..%d for %.0f s = %d evaluations" % (
@@ -594,8 +594,11 @@ def main():
     ap.add_argument("--groups", type=int, default=1, help="independent sub-batches per GPU (host threads/streams)")
     ap.add_argument("--mesh", choices=("topology", "tubes"), default="topology",
                     help="--workload pen: the real SMPL-X topology + part table + ExPose body (default), or the synthetic tubes")
-    ap.add_argument("--slots", type=int, default=0, help="dense mode: GEMM columns per GPU when --frames is larger (continuous "
-                    "batching: retired columns are refilled from the frame queue); 0 = one column per frame")
+    ap.add_argument("--no-configs3", action="store_true", help="N = 1: skip the extra 1 024-frame fit (configs[3]'s per-GPU job) behind the "
+                    "headline")
+    ap.add_argument("--slots", type=int, default=-1, help="dense mode: GEMM columns per GPU when --frames is larger (continuous "
+                    "batching: retired columns are refilled from the frame queue, longest predicted fits first); 0 = one column per frame; "
+                    "-1 (default) = driver.auto_slots: resident up to 512 frames, a 512-column pool beyond")
     args = ap.parse_args()
     if args.frames <= 0:
         args.frames = 256 if args.gpus == 1 else 1024
@@ -655,7 +658,8 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     def joints_fn(P):
-        z = lambda n: torch.zeros([B, n], device=dev)
+        nB = P["global_orient"].shape[0]
+        z = lambda n: torch.zeros([nB, n], device=dev)
         t = lambda a: torch.tensor(a, device=dev)
         _, j, _ = dm.lbs_forward(t(P["global_orient"]), t(P["body_pose"]), t(P["betas"]), z(10), z(3), z(3), z(3),
                                  z(12), z(12), return_verts=False, return_full_pose=False)
@@ -666,6 +670,8 @@ def main():
                                         camera_keypoints=cfg.get("init_joints_idxs", (9, 12, 2, 5)))
 
     from smplifyx_amd import driver, dist as sdist
+    if args.slots < 0:
+        args.slots = driver.auto_slots(B) if args.lbs == "dense" else 0
     jw = np.ones(len(jm), np.float32)
     jw[cfg["joints_to_ign"]] = 0.0                 # COCO25.get_joint_weights (data_parser.py:159-171)
     n_total = world * B
@@ -728,6 +734,26 @@ def main():
     prof = {k: engine.prof_get(k) for k in ("lbs_dense", "tick", "fit_rows", "penetration")}
     host = engine.loop_host_stats()            # the host thread's side of the timed fits (dense loops)
     pen_work = engine.pen_work_get() if pen else None      # device counts over the timed region: grid entries, ordered pairs, columns
+    # configs[3]'s per-GPU job on THIS GPU (N = 1 only): 1 024 frames of the same generator through the default column pool, so that
+    # a 1 -> N curve read off the driver's lines divides equal jobs (the N > 1 lines fit 1 024 frames per GPU and carry
+    # `single_gpu_same_job_frames_per_s`; this is the same figure measured in the N = 1 run)
+    configs3 = None
+    if world == 1 and not (full or pen) and not args.no_configs3 and B != 1024 and args.lbs == "dense":
+        n3 = 1024
+        fr3 = synthetic.make_frames(n3, joints_fn, len(jm), start=0, focal=focal)
+
+        def fit3():
+            return driver.fit_frames(dm, cfg, fr3["keypoints"], jw, fr3["H"], fr3["W"], fr3["focal"], reg_pose=fr3["reg_pose"],
+                                     reg_global=fr3["reg_global"], lbs_mode="dense", reuse_entry_eval=True, slots=-1)
+        fit3()
+        torch.cuda.synchronize()
+        t3 = time.time()
+        r3 = fit3()
+        torch.cuda.synchronize()
+        d3 = time.time() - t3
+        ev3 = r3["stage_evals"].sum(1)
+        configs3 = {"frames": n3, "gemm_columns": driver.auto_slots(n3) or n3, "frames_per_s": n3 / d3, "ms": 1e3 * d3,
+                    "closure_evals_per_frame_mean": float(ev3.mean()), "closure_evals_per_frame_max": int(ev3.max())}
     # side key: the same job on the detector that keeps >= 3 of the 4 camera-initialisation keypoints (round 2's headline)
     side_min3 = None
     if not (full or pen) and not args.no_side:
@@ -798,8 +824,12 @@ def main():
                                     "dropped (the sequence of rounds 1-2a; `value_min3_camera_keypoints` = the same job when the detector "
                                     "keeps at least 3 of the 4 camera-initialisation keypoints, round 2's headline sequence)",
                        "frames_per_gpu": B, "lbs_mode": args.lbs, "groups_per_gpu": args.groups,
-                       "gemm_columns_per_gpu": (args.slots if (args.slots and args.lbs == "dense") else B),
+                       "gemm_columns_per_gpu": (args.slots if (0 < args.slots < B and args.lbs == "dense") else B),
                        "parallelism": "frames sharded, dp%d" % world,
+                       # N = 1: configs[3]'s per-GPU job (1 024 frames through the default column pool) fitted behind the headline --
+                       # the denominator of a 1 -> N scaling curve on equal jobs (N > 1 lines: single_gpu_same_job_frames_per_s)
+                       "configs3_single_gpu_frames_per_s": configs3["frames_per_s"] if configs3 else None,
+                       "configs3_single_gpu": configs3,
                        "closure_evals_per_frame_mean": float(evals.mean()),
                        "closure_evals_per_frame_max": int(evals.max()),
                        # frames/s depends on how many evaluations a fit takes (a noisier closure stops earlier: round 1

@@ -129,9 +129,31 @@ def _collect(fb, prep, want_vertices):
     return out
 
 
+POOL_COLUMNS = 512          # GEMM columns of the pool a job larger than this is run through by default (slots=-1)
+
+
+def auto_slots(n_frames):
+    """Default size of the column pool: jobs of up to POOL_COLUMNS frames are resident (one column per frame), larger ones queue
+    through POOL_COLUMNS columns -- the columns a straggler would leave idle at the end of a resident run are refilled
+    (1 024 frames of the benchmark's generator: 710 frames/s resident, 830-840 through 512 columns)."""
+    return 0 if n_frames <= POOL_COLUMNS else POOL_COLUMNS
+
+
+def predicted_cost(cfg, prep):
+    """What is known about a frame's fitting time BEFORE the fit (the queue of a column pool is ordered by it, longest first):
+    a side view is fitted from two orientations (fit_single_frame.py:527-551: twice the body stages), and a frame that has lost
+    two or more of the four camera-initialisation keypoints (cfg init_joints_idxs) starts from an under-determined camera and
+    takes 2-3 x the evaluations of a well-posed one (bench.py MIN_CAMERA_KEYPOINTS; the reference's own fp32 / fp64 runs end
+    such frames in different basins)."""
+    n_cam = prep["cmask"].sum(1)
+    n_init = len(cfg.get("init_joints_idxs", (9, 12, 2, 5)))
+    cost = np.where(n_cam < min(3, n_init), 2.5, 1.0) * np.where(prep["try_both"], 2.0, 1.0)
+    return cost
+
+
 def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, reg_global=None,
                cam_prior_t=None, cam_prior_center=None, lbs_mode="dense", reuse_entry_eval=True,
-               want_vertices=False, groups=1, body_pose_prior=None, slots=0):
+               want_vertices=False, groups=1, body_pose_prior=None, slots=0, order="auto"):
     """Fit B frames.  Arrays are [B, ...]; H, W, focal scalars or [B].  Returns a dict of
     [B, ...] arrays: the reference's result-pkl fields + per-stage losses / evaluation counts.
 
@@ -146,8 +168,31 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
 
     slots (dense mode, groups == 1): size of the GEMM column pool when there are more frames than that --
     the reference's loop over frames (main.py:207) as continuous batching: frames queue and take over the
-    columns of frames that finish.  Results are unchanged."""
+    columns of frames that finish.  Results are unchanged.  slots = -1: auto_slots(B).
+    order (pooled runs only): "auto" = the queue is ordered by predicted_cost, longest first (a straggler admitted last holds
+    its column -- and the whole job -- long after the others are done); "given" = frame order.  Frames are independent and
+    every per-frame sum has a fixed order, so the results do not depend on it (returned in the caller's order, bitwise equal)."""
     B_all = np.asarray(keypoints).shape[0]
+    if slots is not None and slots < 0:
+        slots = auto_slots(B_all) if lbs_mode == "dense" else 0
+    perm = None
+    if lbs_mode == "dense" and groups == 1 and 0 < slots < B_all and order == "auto":
+        cost = predicted_cost(cfg, prepare_frames(cfg, keypoints, joint_weights))
+        perm = np.argsort(-cost, kind="stable")
+        if np.array_equal(perm, np.arange(B_all)):
+            perm = None
+    if perm is not None:
+        def pm(a):
+            if a is None:
+                return None
+            a = np.asarray(a)
+            return a[perm] if a.ndim > 0 and a.shape[0] == B_all and B_all > 1 else a
+        jw_a = np.asarray(joint_weights)
+        keypoints = np.asarray(keypoints)[perm]
+        if jw_a.ndim == 2 and jw_a.shape[0] == B_all and B_all > 1:
+            joint_weights = jw_a[perm]
+        H, W, focal, reg_pose, reg_global = pm(H), pm(W), pm(focal), pm(reg_pose), pm(reg_global)
+        cam_prior_t, cam_prior_center = pm(cam_prior_t), pm(cam_prior_center)
     groups = max(1, min(int(groups), B_all // 32)) if lbs_mode == "dense" else 1
     cuts = [(B_all * g) // groups for g in range(groups + 1)]
     jw_all = np.asarray(joint_weights)
@@ -185,5 +230,9 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
             warnings.warn("interpenetration term: %d bucket walks were cut short during this fit (a mesh folded into a few grid "
                           "cells by a trial step; %d triangles met more than 2 x max_collisions partners): pairs beyond the cut "
                           "are missing and which ones depends on arrival order -- frames %s are not reproducible run to run "
-                          "(result key 'pen_order_dependent')" % (cut, over, bad.tolist()[:32]), RuntimeWarning)
+                          "(result key 'pen_order_dependent')" % (cut, over, (bad if perm is None else np.sort(perm[bad])).tolist()[:32]), RuntimeWarning)
+    if perm is not None:        # back to the caller's frame order
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(B_all)
+        res = {k: (np.asarray(v)[inv] if np.ndim(v) > 0 and np.asarray(v).shape[0] == B_all else v) for k, v in res.items()}
     return res

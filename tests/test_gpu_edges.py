@@ -189,8 +189,8 @@ def test_halpe_closure_matches_oracle(synth_model):
             H.check_closure("halpe-full-rows", stage, loss[i], lo, grad[i], go)
 
 
-@pytest.mark.parametrize("extra", [["--lbs", "rows"], ["--workload", "pen"]], ids=["body-rows", "pen-dense"])
-def test_bench_two_rank_control_flow_rehearsal(extra):
+@pytest.mark.parametrize("n,extra", [(2, ["--lbs", "rows"]), (2, ["--workload", "pen"]), (4, [])], ids=["body-rows-2", "pen-dense-2", "body-dense-4"])
+def test_bench_two_rank_control_flow_rehearsal(n, extra):
     """`python bench.py --gpus 2` (it launches its own 2 ranks; both on GPU 0, gloo, in this rehearsal): the N > 1 control
     flow -- per-rank frame blocks, barriers, max-over-ranks time, the record gather -- produces one
     JSON line whose frame count is the whole job's.  Also for BASELINE configs[4] (the halpe cfg with the interpenetration
@@ -201,25 +201,27 @@ def test_bench_two_rank_control_flow_rehearsal(extra):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     # exactly what the driver types, no launcher: bench.py starts its ranks itself
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0",
            "--frames", "32", "--no-cpu", "--no-alt"] + extra
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 32 and d["scaling"] == "weak"
-    assert abs(d["value"] - 2 * 32 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-4 * d["value"]      # (both figures are printed to 6 digits)
+    assert d["n_gpus"] == n and d["config"]["frames_per_gpu"] == 32 and d["scaling"] == "weak"
+    assert abs(d["value"] - n * 32 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-4 * d["value"]      # (both figures are printed to 6 digits)
     assert len(lines[0]) < 4096
     # per-rank records live in the detail file; the line carries their summary and the single-GPU rate of the SAME job size
     # (rank 0's own frames over its own time), which is what 1 -> N efficiency is computed against
     ranks = json.load(open(os.path.join(root, d["detail"])))["ranks"]
-    assert [r["rank"] for r in ranks] == [0, 1] and all(r["closure_evals_total"] > 0 for r in ranks)
+    assert [r["rank"] for r in ranks] == list(range(n)) and all(r["closure_evals_total"] > 0 for r in ranks)
     c = d["config"]
     assert c["per_gpu_frames_per_s_min"] <= c["per_gpu_frames_per_s_mean"] and c["single_gpu_same_job_frames_per_s"] == pytest.approx(ranks[0]["frames_per_s"], rel=1e-4)
-    assert d["value"] <= 2 * c["per_gpu_frames_per_s_mean"] * 1.001          # the job's rate is bound by its slowest rank
+    assert d["value"] <= n * c["per_gpu_frames_per_s_mean"] * 1.001          # the job's rate is bound by its slowest rank
     if "pen" in extra:
         assert d["config"]["workload"].startswith("configs[4]") and d["roofline_pen"]["pairs_per_column"] >= 0
+        return
+    if n != 2:
         return
     # ... and under an external launcher whose world size disagrees with --gpus it refuses instead of mis-reporting
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu"],
@@ -284,6 +286,10 @@ def test_bench_line_contract(workload):
         assert rp["final_loss_rel_delta_median"] <= 1.5 * rp["reference_f32_vs_f64_rel_delta_median"]
         assert "roofline_tick" in d and d["roofline_tick"]["kernel"] == "k_tick_dense"
         assert d["roofline_tick"]["rows_per_frame_launch"] == pytest.approx(11.0)
+        # configs[3]'s per-GPU job (1 024 frames through the default 512-column pool) behind the headline: the equal-job denominator
+        c3 = detail["config"]["configs3_single_gpu"]
+        assert c3["frames"] == 1024 and c3["gemm_columns"] == 512 and d["config"]["configs3_single_gpu_frames_per_s"] == pytest.approx(c3["frames_per_s"], rel=1e-4)
+        assert c3["frames_per_s"] > d["value"]             # (1 024 frames fill the GEMM's columns better than 32)
     if workload == "full":       # the byte model of the per-frame kernel is this workload's: live items by stage, VPoser weights twice
         rt = d["roofline_tick"]
         assert 11.0 < rt["rows_per_frame_launch"] <= 225.0 and rt["shared_bytes_per_launch"] > 2 * 1.3e6

@@ -423,6 +423,43 @@ def test_continuous_batching_matches_resident_batch(gpu, synth_model):
         assert np.array_equal(a[k], b[k], equal_nan=True), k        # (a frame that ends non-finite does so in both)
 
 
+def test_pool_queue_ordered_by_predicted_cost_returns_the_callers_order(gpu, synth_model):
+    """driver.fit_frames through a column pool smaller than the job: the queue is ordered by what is known about a frame
+    before the fit (side views are fitted twice, frames with fewer than 3 of the 4 camera keypoints start from an
+    under-determined camera: driver.predicted_cost), longest first -- and every result comes back in the caller's frame
+    order, bit for bit what the resident run (one column per frame, frame order) produces."""
+    import bench as BB
+    from smplifyx_amd import driver, synthetic
+    import torch
+    cfg = BB.build_cfg("body")
+    dm = _dm(synth_model, cfg)
+    B = 160
+    dev = torch.device("cuda")
+
+    def joints_fn(P):
+        z = lambda n: torch.zeros([len(P["betas"]), n], device=dev)
+        t = lambda a: torch.tensor(a, device=dev)
+        _, j, _ = dm.lbs_forward(t(P["global_orient"]), t(P["body_pose"]), t(P["betas"]), z(10), z(3), z(3), z(3), z(12), z(12),
+                                 return_verts=False, return_full_pose=False)
+        return j.cpu().numpy()
+    fr = synthetic.make_frames(B, joints_fn, 25, start=0, focal=5000.0)
+    jw = H.base_joint_weights(cfg, 25)
+    cost = driver.predicted_cost(cfg, driver.prepare_frames(cfg, fr["keypoints"], jw))
+    assert 0 < (cost > 1).sum() < B                      # some frames are predicted long (the generator drops 10 % of the keypoints)
+    kw = dict(reg_pose=fr["reg_pose"], reg_global=fr["reg_global"], lbs_mode="dense", reuse_entry_eval=True)
+    ra = driver.fit_frames(dm, cfg, fr["keypoints"], jw, fr["H"], fr["W"], fr["focal"], slots=0, **kw)
+    rb = driver.fit_frames(dm, cfg, fr["keypoints"], jw, fr["H"], fr["W"], fr["focal"], slots=48, order="auto", **kw)
+    rc = driver.fit_frames(dm, cfg, fr["keypoints"], jw, fr["H"], fr["W"], fr["focal"], slots=48, order="given", **kw)
+    assert set(ra) == set(rb) == set(rc)
+    for k in ra:
+        assert np.array_equal(np.asarray(ra[k]), np.asarray(rb[k]), equal_nan=True), k
+        assert np.array_equal(np.asarray(ra[k]), np.asarray(rc[k]), equal_nan=True), k
+    # the predictor is worth ordering by: the predicted-long frames take more evaluations than the others
+    ev = ra["stage_evals"].sum(1)
+    assert ev[cost > 1].mean() > 1.2 * ev[cost == 1].mean(), (ev[cost > 1].mean(), ev[cost == 1].mean())
+    assert driver.auto_slots(256) == 0 and driver.auto_slots(512) == 0 and driver.auto_slots(1024) == 512
+
+
 def test_one_gpu_share_of_the_8192_frame_job(gpu, synth_model):
     """BASELINE configs[3] as one rank sees it: 1 024 frames (bench.py's generator) -- resident, and through a pool
     of 256 GEMM columns (`bench.py --frames 1024 --slots 256`).  Camera stage + first body stage: every frame finishes, no
