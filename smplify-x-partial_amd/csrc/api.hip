@@ -991,6 +991,15 @@ __global__ void k_pen_want(BatchDev D, const StageW* __restrict__ sws, int stage
     if (st >= 0 && st < D.cfg.n_stages && D.slot[b] >= 0) D.pen_want[D.slot[b]] = sws[st].coll > 0.f;
 }
 
+// Upper bound on the rounds a fit can take (a guard against a loop that never ends, not a budget): an LBFGS.step costs at most
+// max_eval evaluations in its iterations plus one line search that may run over -- the bracket phase up to 25 evaluations, the zoom
+// phase up to LBFGS(max_iter) (lbfgs_ls.py:108) -- plus the entry evaluation; a side view is fitted from two orientations
+// (fit_single_frame.py:527-551), accounted for as a factor of its own (the old bound let the `* 2` do both).
+static long sfx_fit_tick_bound(const BatchCfgDev& c, int first_stage, int last_stage) {
+    const long per_step = (long)c.max_eval + std::max(25, (int)c.lbfgs_max_iter) + 1;
+    return (long)(last_stage - first_stage + 1) * c.maxiters * std::max(80L, per_step + 7) * 2 /* orientations */ * 2 /* slack */ + 64;
+}
+
 // want_ready: the fused tick kernel maintains pen_want[] itself (it knows every running frame's next stage when it exports
 // the next trial point, and clears the flag of a frame that finishes): no launch for it inside the fitting loop
 static int eval_penetration(sfx_batch* b, int stage_override, hipStream_t s, bool want_ready = false) {
@@ -1136,7 +1145,7 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
     launch_lbfgs_tick(M, D, b->vl_dev, first_stage, last_stage, init, step_mode, s);
     // bound on the rounds of the polled loops: one resident batch needs at most stages x maxiters LBFGS.step calls of
     // <= ~160 evaluations each; a job of B frames through a pool of `slots` columns needs that once per wave of the queue
-    long max_ticks = (long)(last_stage - first_stage + 1) * D.cfg.maxiters * std::max(80, D.cfg.max_eval + 32) * 2 + 64;     // (an LBFGS.step takes at most max_eval + 25 evaluations)
+    long max_ticks = sfx_fit_tick_bound(D.cfg, first_stage, last_stage);
     if (dense && b->slots > 0 && b->slots < B) max_ticks *= (B + b->slots - 1) / b->slots;
     std::vector<int> hs(B);
     int* hp = b->stage_host ? b->stage_host : hs.data();
@@ -1368,7 +1377,7 @@ extern "C" int sfx_fit_multi(sfx_batch** bs, int32_t n, int32_t first_stage, int
     }
     long tick = 0;
     long max_ticks = 0;
-    for (int g = 0; g < n; ++g) max_ticks = std::max(max_ticks, (long)(last_stage - first_stage + 1) * bs[g]->D.cfg.maxiters * std::max(80, bs[g]->D.cfg.max_eval + 32) * 2 + 64);
+    for (int g = 0; g < n; ++g) max_ticks = std::max(max_ticks, sfx_fit_tick_bound(bs[g]->D.cfg, first_stage, last_stage));
     int remaining = n, prev = -1;
     int rc = 0;
     while (remaining > 0 && tick < max_ticks && rc == 0) {

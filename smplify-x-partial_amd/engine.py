@@ -231,6 +231,8 @@ class FrameBatch(object):
         c.df_cone_height = float(cfg.get("df_cone_height", 0.5))
         c.penalize_outside = int(bool(cfg.get("penalize_outside", True)))
         c.point2plane = int(bool(cfg.get("point2plane", False)))
+        if c.point2plane and cfg.get("interpenetration", False):
+            _warn_point2plane()
         c.slots = int(slots or 0)
         # LBFGS hyper-parameters (optimizers/lbfgs_ls.py); the cfg files never set them: 0 = the reference's defaults
         # (tolerances: negative = default; an explicit 0 -- LBFGS(tolerance_grad=0): the test is disabled -- is passed through)
@@ -485,6 +487,13 @@ def pen_phase_ticks():
                 verts_us=w[4] / n / 100.0, evaluations=int(w[5]), pairs_per_evaluation=w[6] / n)
 
 
+def _warn_point2plane():
+    import warnings
+    warnings.warn("point2plane=True: the form built here -- Psi^2 (n_f . n_g)^2, gradient through both normals -- is assumption A6 of "
+                  "oracle/penetration.py; the mesh_intersection package's own form is not available to compare with, so the numbers "
+                  "may differ from the reference's (every shipped cfg leaves the flag False)", RuntimeWarning, stacklevel=3)
+
+
 def _read_pairs(call):
     n = C.c_int32(0)
     capi.check(call(0, None, C.byref(n)))
@@ -521,6 +530,8 @@ class Penetration(object):
     def eval(self, verts, sigma, penalize_outside=True, stream=None, point2plane=False):
         """verts: float32 CUDA tensor [B, V, 3] -> (loss [B], d loss / d verts [B, V, 3]) on the GPU.
         point2plane: DistanceFieldPenetrationLoss(point2plane=True) (include/sfx.h sfx_pen_set_point2plane)."""
+        if point2plane:
+            _warn_point2plane()
         import torch
         capi.check(self._lib.sfx_pen_set_point2plane(self._h, int(bool(point2plane))))
         assert verts.is_cuda and verts.dtype == torch.float32 and verts.shape[1:] == (self.V, 3)

@@ -375,7 +375,7 @@ def test_vposer_set_matches_reference(gpu, synth_model, mode):
     51 %) after the last one (face keypoints on the dynamic contour's lookup table: non-smooth).  Required: camera stage
     2e-4 per frame; stages 1-3 signed mean within +- max(the reference's own mean |difference|, 5e-3) and mean |difference|
     within twice that; stage 4 median within that yard, median |difference| within twice the reference's, mean |difference|
-    within three yards; last stage signed mean within +- the reference's own mean |difference| and median within 1.5 x."""
+    within three yards, and the bounds of stages 1-3 on the frames left without the two largest differences; last stage signed mean within +- the reference's own mean |difference| and median within 1.5 x."""
     from smplifyx_amd import synthetic
     g = _golden("e2e_vposer_set")
     cfg = H.load_cfg("fit_smplx_smplifyx.yaml")
@@ -400,6 +400,12 @@ def test_vposer_set_matches_reference(gpu, synth_model, mode):
     assert abs(np.median(d[:, 4])) <= yard, (np.median(d[:, 4]), yard)
     assert np.median(np.abs(d[:, 4])) <= 2 * max(np.median(np.abs(y[:, 4])), 5e-3), (np.median(np.abs(d[:, 4])), np.median(np.abs(y[:, 4])))
     assert np.abs(d[:, 4]).mean() <= 3 * yard, (np.abs(d[:, 4]).mean(), yard)
+    # ... and so that the medians cannot hide a regression across the set: the bounds stages 1-3 are held to --
+    # signed mean within the yard, mean |difference| within twice it -- on the 14 frames left when the two largest draws are set
+    # aside (the four builds of profiles/r04_vposer_set_probe.txt: 0.006 / 0.026, -0.004 / 0.017, 0.000 / 0.013, -0.002 / 0.011
+    # against 0.039 / 0.079; a shift of every frame by the reference's own fp32 / fp64 spread fails it)
+    keep = np.argsort(np.abs(d[:, 4]))[:-2]
+    assert abs(d[keep, 4].mean()) <= yard and np.abs(d[keep, 4]).mean() <= 2 * yard, (d[keep, 4].mean(), np.abs(d[keep, 4]).mean(), yard)
     assert abs(d[:, 5].mean()) <= np.abs(y[:, 5]).mean(), (d[:, 5].mean(), np.abs(y[:, 5]).mean())
     assert np.median(np.abs(d[:, 5])) <= 1.5 * np.median(np.abs(y[:, 5])), (np.median(np.abs(d[:, 5])), np.median(np.abs(y[:, 5])))
 
