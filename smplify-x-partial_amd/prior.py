@@ -47,74 +47,79 @@ class L2Prior(nn.Module):
         return torch.sum(module_input.pow(2))
 
 
+def read_mixture(prior_folder, num_gaussians):
+    """`gmm_{num_gaussians:02d}.pkl` of SMPLify (a dict with means / covars / weights, or a pickled sklearn GMM; prior.py:118-135)
+    -> the three arrays as the file holds them."""
+    path = os.path.join(prior_folder, "gmm_{:02d}.pkl".format(num_gaussians))
+    if not os.path.exists(path):
+        raise FileNotFoundError('The path to the mixture prior "{}" does not exist'.format(path))
+    with open(path, "rb") as f:
+        return mixture_arrays(pickle.load(f, encoding="latin1"))
+
+
+def mixture_arrays(gmm):
+    if isinstance(gmm, dict):
+        return np.asarray(gmm["means"]), np.asarray(gmm["covars"]), np.asarray(gmm["weights"])
+    if "sklearn.mixture.gmm.GMM" in str(type(gmm)):
+        return np.asarray(gmm.means_), np.asarray(gmm.covars_), np.asarray(gmm.weights_)
+    raise ValueError("Unknown type for the prior: {}".format(type(gmm)))
+
+
+def mixture_tables(means, covars, weights, np_dtype=np.float32, epsilon=1e-16):
+    """Everything the mixture prior evaluates with, from the mixture's parameters: the table the device receives through
+    sfx_batch_set_gmm[_form] and the stand-alone module registers as buffers (names and shapes are the interface:
+    fitting.py:399-401 and the result files read them).  Arithmetic as prior.py:137-175, so that tests/golden/gmm*.npz -- the
+    reference's own module -- pins every entry: the precisions are inverses of the covariances ROUNDED to the working type,
+    the normalisation weights come from the unrounded ones, with the reference's literal 69 in the constant."""
+    covs_t = np.asarray(covars).astype(np_dtype)
+    root_dets = np.sqrt(np.linalg.det(np.asarray(covars)))
+    return {
+        "means": np.asarray(means).astype(np_dtype),
+        "covs": covs_t,
+        "precisions": np.linalg.inv(covs_t).astype(np_dtype),
+        "nll_weights": (np.asarray(weights) / ((2 * np.pi) ** (69 / 2.) * (root_dets / root_dets.min())))[None],
+        "weights": np.asarray(weights)[None],
+        "pi_term": np.log(np.asarray(2 * np.pi, np_dtype)),
+        "cov_dets": np.log(np.linalg.det(covs_t) + epsilon),
+    }
+
+
 class MaxMixturePrior(nn.Module):
-    """Gaussian-mixture pose prior of SMPLify (prior.py:100-231): reads `gmm_{num_gaussians:02d}.pkl`
-    (dict with means / covars / weights, or a pickled sklearn GMM) from `prior_folder`, keeps the
-    reference's buffers (means, covs, precisions, nll_weights, weights, pi_term, cov_dets) and evaluates
-    min_m [ 0.5 d_m^T P_m d_m - log nll_weights_m ] (`use_merged`, the reference's default) or the
-    per-component form.  `gmm` may be passed as a dict directly instead of a file."""
+    """Gaussian-mixture pose prior of SMPLify (prior.py:100-231): `gmm_{num_gaussians:02d}.pkl` from `prior_folder` (or `gmm`:
+    the mixture as a dict / sklearn object), the reference's buffers (mixture_tables) and
+    min_m [ 0.5 d_m^T P_m d_m - log nll_weights_m ] (`use_merged`, the reference's default) or the per-component form.
+    In the fitting loop the evaluation is the HIP closure's (csrc/closure_body.h); this module gives the same numbers
+    stand-alone."""
 
     def __init__(self, prior_folder="prior", num_gaussians=6, dtype=DEFAULT_DTYPE, epsilon=1e-16, use_merged=True,
                  gmm=None, **kwargs):
         super().__init__()
-        if dtype == DEFAULT_DTYPE:
-            np_dtype = np.float32
-        elif dtype == torch.float64:
-            np_dtype = np.float64
-        else:
+        np_dtype = {torch.float32: np.float32, torch.float64: np.float64}.get(dtype)
+        if np_dtype is None:
             raise ValueError("Unknown float type {}".format(dtype))
         self.num_gaussians, self.epsilon, self.use_merged = num_gaussians, epsilon, use_merged
-        if gmm is None:
-            full_gmm_fn = os.path.join(prior_folder, "gmm_{:02d}.pkl".format(num_gaussians))
-            if not os.path.exists(full_gmm_fn):
-                raise FileNotFoundError('The path to the mixture prior "{}" does not exist'.format(full_gmm_fn))
-            with open(full_gmm_fn, "rb") as f:
-                gmm = pickle.load(f, encoding="latin1")
-        if isinstance(gmm, dict):
-            means, covs, weights = gmm["means"], gmm["covars"], gmm["weights"]
-        elif "sklearn.mixture.gmm.GMM" in str(type(gmm)):
-            means, covs, weights = gmm.means_, gmm.covars_, gmm.weights_
-        else:
-            raise ValueError("Unknown type for the prior: {}".format(type(gmm)))
-        covs_in, weights_in = np.asarray(covs), np.asarray(weights)
-        means, covs = np.asarray(means).astype(np_dtype), covs_in.astype(np_dtype)
-        self.register_buffer("means", torch.tensor(means, dtype=dtype))
-        self.register_buffer("covs", torch.tensor(covs, dtype=dtype))
-        precisions = np.stack([np.linalg.inv(cov) for cov in covs]).astype(np_dtype)
-        self.register_buffer("precisions", torch.tensor(precisions, dtype=dtype))
-        # the constant term keeps the reference's literal 69 (the SMPL body pose size), prior.py:157
-        sqrdets = np.array([np.sqrt(np.linalg.det(c)) for c in covs_in])
-        const = (2 * np.pi) ** (69 / 2.)
-        nll_weights = np.asarray(weights_in / (const * (sqrdets / sqrdets.min())))
-        self.register_buffer("nll_weights", torch.tensor(nll_weights, dtype=dtype).unsqueeze(dim=0))
-        self.register_buffer("weights", torch.tensor(weights_in, dtype=dtype).unsqueeze(dim=0))
-        self.register_buffer("pi_term", torch.log(torch.tensor(2 * np.pi, dtype=dtype)))
-        cov_dets = [np.log(np.linalg.det(cov.astype(np_dtype)) + epsilon) for cov in covs]
-        self.register_buffer("cov_dets", torch.tensor(cov_dets, dtype=dtype))
+        arrays = mixture_arrays(gmm) if gmm is not None else read_mixture(prior_folder, num_gaussians)
+        for name, table in mixture_tables(*arrays, np_dtype=np_dtype, epsilon=epsilon).items():
+            self.register_buffer(name, torch.tensor(table, dtype=dtype))
         self.random_var_dim = self.means.shape[1]
 
     def get_mean(self):
-        """Mean of the mixture [1, D]: the initial body pose when there is no regression prior
-        (fit_single_frame.py:252)."""
-        return torch.matmul(self.weights, self.means)
+        """Mean of the mixture [1, D]: the initial body pose when there is no regression prior (fit_single_frame.py:252)."""
+        return self.weights @ self.means
+
+    def _quadratic_forms(self, pose):
+        d = pose[:, None, :] - self.means[None]                       # [B, M, D]
+        return (torch.einsum("mij,bmj->bmi", self.precisions, d) * d).sum(-1)
 
     def merged_log_likelihood(self, pose, betas=None):
-        diff = pose.unsqueeze(dim=1) - self.means
-        prec_diff = torch.einsum("mij,bmj->bmi", self.precisions, diff)
-        quad = (prec_diff * diff).sum(dim=-1)
-        ll = 0.5 * quad - torch.log(self.nll_weights)
-        return torch.min(ll, dim=1)[0]
+        return (0.5 * self._quadratic_forms(pose) - torch.log(self.nll_weights)).min(dim=1)[0]
 
     def log_likelihood(self, pose, betas=None, *args, **kwargs):
-        lls = []
-        for idx in range(self.num_gaussians):
-            diff = pose - self.means[idx]
-            ll = torch.einsum("bi,bi->b", torch.einsum("bj,ji->bi", diff, self.precisions[idx]), diff)
-            cov_term = torch.log(torch.det(self.covs[idx]) + self.epsilon)
-            lls.append(ll + 0.5 * (cov_term + self.random_var_dim * self.pi_term))
-        lls = torch.stack(lls, dim=1)
-        min_idx = torch.argmin(lls, dim=1)
-        return -torch.log(self.nll_weights[:, min_idx]) + lls[:, min_idx]
+        """The per-component form (prior.py:203-231; written for batch 1 there, and here)."""
+        const = 0.5 * (torch.log(torch.det(self.covs) + self.epsilon) + self.random_var_dim * self.pi_term)      # [M]
+        lls = torch.stack([torch.einsum("bi,bi->b", (pose - self.means[m]) @ self.precisions[m], pose - self.means[m]) for m in range(self.num_gaussians)], 1) + const
+        best = torch.argmin(lls, dim=1)
+        return -torch.log(self.nll_weights[:, best]) + lls[:, best]
 
     def forward(self, pose, betas=None):
         return self.merged_log_likelihood(pose, betas) if self.use_merged else self.log_likelihood(pose, betas)
