@@ -280,6 +280,12 @@ int  sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, in
  * on: every Psi^2 of a pair (f, g) is weighted by (n_f . n_g)^2 -- the repulsion of a vertex measured along the other
  * triangle's normal (oracle/penetration.py, assumption A6) -- in all later evaluations of the handle.               */
 int  sfx_pen_set_point2plane(sfx_pen* h, int32_t on);
+/* DistanceFieldPenetrationLoss(...)(triangles, collision_idxs) stand-alone (fitting.py:451-455): loss and gradients for pairs the
+ * CALLER supplies -- pairs_dev DEVICE int32 [B][n_pairs][2] triangle ids, each unordered pair once, rows with a negative id empty
+ * (the package's -1 padding).  Outputs as sfx_pen_eval, plus dtri_dev DEVICE [B][F][3][3] or NULL: the gradient with respect to
+ * every triangle CORNER (what autograd needs for the `triangles` tensor).  At most 8192 pairs per mesh.  Synchronises the stream. */
+int  sfx_pen_eval_pairs(sfx_pen* h, int32_t B, const float* verts_dev, const int32_t* pairs_dev, int32_t n_pairs, float sigma,
+                        int32_t penalize_outside, float* loss_dev, float* dverts_dev, float* dtri_dev, void* stream);
 /* per frame (HOST [B][4]): ordered pairs kept, partners dropped by max_collisions / the pair list's capacity, grid entries
  * when they overflowed the buffer (0 = fine; then the frame reports no pairs), bucket walks cut short (0 on a sane mesh:
  * an entry looks at most 2048 entries ahead in its bucket; a mesh folded into a few cells by a diverged fit hits that). */

@@ -92,6 +92,8 @@ SYMBOLS = {
     "sfx_pen_destroy": (None, [C.c_void_p]),
     "sfx_pen_eval": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sfx_pen_set_point2plane": (C.c_int, [C.c_void_p, C.c_int32]),
+    "sfx_pen_eval_pairs": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "sfx_pen_stats": (C.c_int, [C.c_void_p, C.c_int32, i32p]),
     "sfx_pen_pairs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, i32p, C.POINTER(C.c_int32)]),
     "sfx_batch_pen_pairs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, i32p, C.POINTER(C.c_int32)]),

@@ -2554,6 +2554,71 @@ extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float
     return sfx_pen_eval_masked(h, B, verts_dev, sigma, penalize_outside, loss_dev, dverts_dev, nullptr, nullptr, nullptr, stream);
 }
 
+// ---- DistanceFieldPenetrationLoss(triangles, collision_idxs) stand-alone (fitting.py:451-455): the caller supplies the pairs.
+// k_pen_pairs_in stages a mesh's pairs ([n][2] triangle ids, any order within a pair, each unordered pair once, rows with a
+// negative id empty -- the package's -1 padding) where the pair tests would have left them, k_pen_narrow does the rest.
+__global__ __launch_bounds__(PEN_T)
+void k_pen_pairs_in(PenDev P, const int* __restrict__ pairs, const int n, float* __restrict__ dverts, float* __restrict__ dtri) {
+    __shared__ int s_n;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    if (b == 0 && t == 0) P.nheavy[0] = 0;
+    if (t == 0) s_n = 0;
+    for (int i = t; i < P.V * 3; i += PEN_T) dverts[(size_t)b * P.V * 3 + i] = 0.f;
+    if (dtri) for (int i = t; i < P.F * 9; i += PEN_T) dtri[(size_t)b * P.F * 9 + i] = 0.f;
+    __syncthreads();
+    int2* pbuf = P.pbuf + (size_t)b * P.pf_cap;
+    const int2* in = reinterpret_cast<const int2*>(pairs) + (size_t)b * n;
+    for (int i0 = 0; i0 < n; i0 += PEN_T) {
+        const int i = i0 + t;
+        const int2 pr = i < n ? in[i] : make_int2(-1, -1);
+        const bool ok = pr.x >= 0 && pr.y >= 0 && pr.x < P.F && pr.y < P.F && pr.x != pr.y;
+        const unsigned long long m = __ballot(ok);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(&s_n, __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (ok && pos < P.pf_cap) pbuf[pos] = pr;
+    }
+    __syncthreads();
+    if (t == 0) { int* st = P.stats + b * PEN_STATS; for (int q = 0; q < PEN_STATS; ++q) st[q] = 0; P.pcnt[b] = s_n; P.wqn[b] = 0; }
+}
+// per-corner gradient of the triangles that have pairs (the others' rows were zeroed): the gradient with respect to the
+// `triangles` tensor the caller differentiates through
+__global__ void k_pen_dtri_out(PenDev P, float* __restrict__ dtri) {
+    const int b = blockIdx.y;
+    const int total = P.ptotal[b];
+    const int* pown = P.pown + (size_t)b * P.pair_cap;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int f = pown[i];
+        if (i > 0 && pown[i - 1] == f) continue;
+        for (int j = 0; j < 9; ++j) dtri[((size_t)b * P.F + f) * 9 + j] = P.tgrad[((size_t)b * P.F + f) * 9 + j];
+    }
+}
+extern "C" int sfx_pen_eval_pairs(sfx_pen* h, int32_t B, const float* verts_dev, const int32_t* pairs_dev, int32_t n_pairs, float sigma,
+                                  int32_t penalize_outside, float* loss_dev, float* dverts_dev, float* dtri_dev, void* stream) {
+    if (!h || !verts_dev || !loss_dev || !dverts_dev || (n_pairs > 0 && !pairs_dev)) { sfx_set_error("null argument"); return -1; }
+    if (B < 1 || B > h->Bmax) { sfx_set_error("batch %d exceeds the capacity %d given to sfx_pen_create", B, h->Bmax); return -1; }
+    if (!(sigma > 0.f) || n_pairs < 0) { sfx_set_error("bad arguments"); return -1; }
+    if (!h->P.fast_ok) { sfx_set_error("mesh too large for the stand-alone pair evaluation (one workgroup sorts a mesh's pairs in LDS)"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t narrow_lds = (size_t)(2 * PEN_FP + 2 * h->P.hasp_words + (h->P.V + 31) / 32 + h->P.V) * sizeof(int);
+    if (hipFuncSetAttribute((const void*)k_pen_narrow<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_pen_narrow<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+        sfx_set_error("cannot reserve LDS for k_pen_narrow"); return -2; }
+    PenDev Pl = h->P;
+    Pl.over = nullptr;
+    hipLaunchKernelGGL(k_pen_pairs_in, dim3(B), dim3(PEN_T), 0, s, h->P, pairs_dev, n_pairs, dverts_dev, dtri_dev);
+    PenAdjPrep ap{};
+    if (h->P.p2p) hipLaunchKernelGGL(k_pen_narrow<true>, dim3(B), dim3(PEN_T), narrow_lds, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, (const int*)nullptr, ap, 0);
+    else hipLaunchKernelGGL(k_pen_narrow<false>, dim3(B), dim3(PEN_T), narrow_lds, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, (const int*)nullptr, ap, 0);
+    if (dtri_dev) hipLaunchKernelGGL(k_pen_dtri_out, dim3(32, B), dim3(256), 0, s, h->P, dtri_dev);
+    if (hipGetLastError() != hipSuccess) { sfx_set_error("penetration kernels failed to launch"); return -4; }
+    int nh = 0;
+    if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(&nh, h->P.nheavy, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { sfx_set_error("device error"); return -4; }
+    if (nh > 0) { sfx_set_error("%d mesh(es) carry more than %d pairs: beyond what the stand-alone pair evaluation sorts in one workgroup's LDS", nh, h->P.pf_cap); return -1; }
+    return 0;
+}
+
 // debug: wall-clock ticks (100 MHz) at the end of k_pen_pairs' steps for the first B frames: [B][10] = triangle boxes,
 // frame box, part boxes, part culling, grid histogram, scan, scatter ([7..9] unused: those steps are kernels of their own); [10] = grid entries
 extern "C" int sfx_pen_phase_clocks(sfx_pen* h, int32_t B, int32_t* out) {

@@ -544,6 +544,27 @@ class Penetration(object):
                                           C.c_void_p(loss.data_ptr()), C.c_void_p(dv.data_ptr()), C.c_void_p(s)))
         return loss, dv
 
+    def eval_pairs(self, verts, pairs, sigma, penalize_outside=True, point2plane=False, stream=None):
+        """DistanceFieldPenetrationLoss on pairs the CALLER supplies (sfx_pen_eval_pairs): verts float32 CUDA [B, V, 3], pairs
+        int32 CUDA [B, n, 2] (each unordered pair once; rows with -1 are empty) -> (loss [B], d loss / d verts [B, V, 3],
+        d loss / d triangle corners [B, F, 3, 3])."""
+        import torch
+        if point2plane:
+            _warn_point2plane()
+        capi.check(self._lib.sfx_pen_set_point2plane(self._h, int(bool(point2plane))))
+        assert verts.is_cuda and verts.dtype == torch.float32 and verts.shape[1:] == (self.V, 3)
+        assert pairs.is_cuda and pairs.dtype == torch.int32 and pairs.dim() == 3 and pairs.shape[2] == 2 and pairs.shape[0] == verts.shape[0]
+        v, pr = verts.contiguous(), pairs.contiguous()
+        B = v.shape[0]
+        loss = torch.empty([B], dtype=torch.float32, device=v.device)
+        dv = torch.empty_like(v)
+        dtri = torch.empty([B, self.F, 3, 3], dtype=torch.float32, device=v.device)
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        capi.check(self._lib.sfx_pen_eval_pairs(self._h, B, C.c_void_p(v.data_ptr()), C.c_void_p(pr.data_ptr()), int(pr.shape[1]), float(sigma),
+                                                int(bool(penalize_outside)), C.c_void_p(loss.data_ptr()), C.c_void_p(dv.data_ptr()),
+                                                C.c_void_p(dtri.data_ptr()), C.c_void_p(s)))
+        return loss, dv, dtri
+
     def stats(self, B):
         out = np.zeros((B, 4), np.int32)
         capi.check(self._lib.sfx_pen_stats(self._h, int(B), capi.iptr(out)))

@@ -122,6 +122,56 @@ def test_the_three_forms_of_the_term_give_the_same_bits(topo_model, cfg_halpe):
         engine.pen_form(prev)
 
 
+def test_the_reference_lines_run_on_the_stand_alone_modules(topo_model, cfg_halpe):
+    """fitting.py:440-455 literally, on smplifyx_amd.mesh_intersection's three modules built the way fit_single_frame.py:300-328
+    builds them: triangles = index_select(vertices, 1, faces) -> search_tree(triangles) -> tri_filtering_module(collision_idxs) ->
+    pen_distance(triangles, collision_idxs), and backward through it.  Against the fused operator on the same bodies: the
+    filtered collision tensor is the oracle's pair set, the loss is the operator's bit for bit, vertices.grad its gradient."""
+    from smplifyx_amd.mesh_intersection.bvh_search_tree import BVH
+    from smplifyx_amd.mesh_intersection.loss import DistanceFieldPenetrationLoss
+    from smplifyx_amd.mesh_intersection.filter_faces import FilterFaces
+    parts = synthetic.topology_parts()
+    faces = np.asarray(topo_model["f"]).astype(np.int64)
+    B = 2
+    vb = _posed_meshes(topo_model, cfg_halpe, B + 1, seed=5)[1:]
+    dev = torch.device("cuda")
+    search_tree = BVH(max_collisions=cfg_halpe["max_collisions"]).to(dev)
+    pen_distance = DistanceFieldPenetrationLoss(sigma=cfg_halpe["df_cone_height"], point2plane=False, vectorized=True,
+                                                penalize_outside=cfg_halpe["penalize_outside"])
+    tri_filtering_module = FilterFaces(faces_segm=parts["segm"], faces_parents=parts["parents"],
+                                       ign_part_pairs=cfg_halpe["ign_part_pairs"]).to(dev)
+    vertices = torch.tensor(vb, device=dev, requires_grad=True)
+    body_model_faces = torch.tensor(faces.reshape(-1), device=dev)
+    coll_loss_weight = 0.1
+    # ---- the reference's lines
+    triangles = torch.index_select(vertices, 1, body_model_faces).view(B, -1, 3, 3)
+    with torch.no_grad():
+        collision_idxs = search_tree(triangles)
+    assert collision_idxs.shape == (B, len(faces) * cfg_halpe["max_collisions"], 2) and collision_idxs.dtype == torch.long
+    unfiltered = [int((collision_idxs[b, :, 0] >= 0).sum()) for b in range(B)]
+    if tri_filtering_module is not None:
+        collision_idxs = tri_filtering_module(collision_idxs)
+    assert collision_idxs.ge(0).sum().item() > 0
+    pen_loss = torch.sum(coll_loss_weight * pen_distance(triangles, collision_idxs))
+    pen_loss.backward()
+    # ---- against the oracle's pair sets and the fused operator
+    pen = engine.Penetration(vb.shape[1], faces, parts["segm"], parts["parents"], cfg_halpe["ign_part_pairs"],
+                             max_collisions=cfg_halpe["max_collisions"], max_batch=B)
+    loss, dv = pen.eval(torch.tensor(vb, device=dev), cfg_halpe["df_cone_height"])
+    for b in range(B):
+        got = collision_idxs[b][(collision_idxs[b] >= 0).all(-1)].cpu().numpy()
+        want = OP.candidate_pairs(vb[b].astype(np.float64), faces, parts["segm"], parts["parents"], cfg_halpe["ign_part_pairs"])
+        assert np.array_equal(got[np.lexsort((got[:, 1], got[:, 0]))], want), (b, len(got), len(want))
+        assert unfiltered[b] == len(OP.candidate_pairs(vb[b].astype(np.float64), faces)) > 10 * len(want)
+    assert float(pen_loss) == pytest.approx(coll_loss_weight * float(loss.sum()), rel=1e-6)
+    single = pen_distance(triangles.detach(), collision_idxs)
+    assert torch.equal(single, loss)                                    # the term itself: the fused operator's bits
+    g = vertices.grad.cpu().numpy() / coll_loss_weight
+    ref = dv.cpu().numpy()
+    assert np.linalg.norm(g - ref) <= 1e-6 * np.linalg.norm(ref), np.linalg.norm(g - ref) / np.linalg.norm(ref)
+    pen.close()
+
+
 def test_closure_on_the_real_surface(topo_model, cfg_halpe):
     """The halpe cfg verbatim inside the fitting closure (dense path): per stage with a collision weight, on the device's OWN
     vertices (read back; DESIGN 4.6: at sigma 1e-4 the field amplifies the 1e-7 m between two fp32 skinnings) -- pair set
