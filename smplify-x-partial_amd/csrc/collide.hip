@@ -397,31 +397,58 @@ void k_pen_g2(PenDev P, const int* __restrict__ want) {
     __shared__ int s_pbox[64][6];
     __shared__ int s_cnt, s_base, s_ccnt, s_cbase;
     const int b = blockIdx.y, t = threadIdx.x, w = blockIdx.x, lane = t & 63;
-    if (want && !want[b]) return;
+    // (round 5: the inputs of the culling -- part boxes, the static part table, the frame-box partials -- come in ONE round trip,
+    //  fetched by different lanes, and the 64 x 64 "do these parts' boxes meet" tests are dealt over the lanes, 16 per part: the
+    //  prologue was a string of dependent loads and a 55-trip loop on 64 lanes)
+    __shared__ float s_gpart[PEN_GW * 8];
+    __shared__ unsigned s_near32[128];
+    const int wanted = want ? want[b] : 1;
+    {
+        int pb_v = 0; unsigned long long sk_v = 0ull; float gp_v = 0.f;
+        if (t < 64 * 6) pb_v = P.pbox[(size_t)b * 64 * 6 + t];
+        else if (t < 64 * 6 + 64) sk_v = P.skipmask[t - 64 * 6];
+        else if (t < 64 * 6 + 64 + PEN_GW * 8) gp_v = P.gpart[(size_t)b * PEN_GW * 8 + (t - 64 * 6 - 64)];
+        if (!wanted) return;
+        if (t < 64 * 6) (&s_pbox[0][0])[t] = pb_v;
+        else if (t < 64 * 6 + 64) s_mask[t - 64 * 6] = sk_v;
+        else if (t < 64 * 6 + 64 + PEN_GW * 8) s_gpart[t - 64 * 6 - 64] = gp_v;
+        if (t < 128) s_near32[t] = 0u;
+    }
+    __syncthreads();
     const int F = P.F;
     const float* aabb = P.aabb + (size_t)b * F * 6;
     int2* cand = P.cand + (size_t)b * P.ent_cap;
-    const PenGridCtx C = pen_grid_ctx(P, b);
-    if (w == 0 && t == 0) { float* gp = P.gridp + b * 4; gp[0] = C.glo[0]; gp[1] = C.glo[1]; gp[2] = C.glo[2]; gp[3] = C.ih; }
-    if (t < 64) {
-        unsigned long long m = 0;
-        m = P.skipmask[t];
-        s_mask[t] = m;
-        for (int e = 0; e < 6; ++e) s_pbox[t][e] = P.pbox[((size_t)b * 64 + t) * 6 + e];
+    PenGridCtx C;                               // (pen_grid_ctx on the staged partials: same operations, same order)
+    {
+        float lo3[3] = {3e38f, 3e38f, 3e38f}, ext = 0.f;
+        for (int w_ = 0; w_ < PEN_GW; ++w_) {
+            const float* g = s_gpart + w_ * 8;
+            for (int e = 0; e < 3; ++e) lo3[e] = fminf(lo3[e], g[e]);
+            ext += g[6];
+        }
+        const float h = fmaxf(2.f * (ext / (float)P.F), 1e-6f);
+        for (int e = 0; e < 3; ++e) C.glo[e] = lo3[e];
+        C.ih = 1.f / h;
     }
-    __syncthreads();
-    if (t < 64) {       // parts whose boxes meet and that may collide, as one 64-bit word per part
-        unsigned long long m = 0;
-        if (t < P.n_parts && s_pbox[t][0] <= s_pbox[t][3]) {
-            const unsigned long long sk = s_mask[t];
-            for (int q = 0; q < P.n_parts; ++q) {
-                const bool meet = s_pbox[t][0] <= s_pbox[q][3] && s_pbox[q][0] <= s_pbox[t][3] && s_pbox[t][1] <= s_pbox[q][4] &&
-                                  s_pbox[q][1] <= s_pbox[t][4] && s_pbox[t][2] <= s_pbox[q][5] && s_pbox[q][2] <= s_pbox[t][5];
-                if (meet && !((sk >> q) & 1ull)) m |= 1ull << q;
+    if (w == 0 && t == 0) { float* gp = P.gridp + b * 4; gp[0] = C.glo[0]; gp[1] = C.glo[1]; gp[2] = C.glo[2]; gp[3] = C.ih; }
+    {
+        const int p_ = t >> 4, q0 = t & 15;
+        unsigned lo_m = 0u, hi_m = 0u;
+        if (p_ < P.n_parts && s_pbox[p_][0] <= s_pbox[p_][3]) {
+            const unsigned long long sk = s_mask[p_];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = q0 + 16 * k;
+                const bool meet = (q < P.n_parts) & (s_pbox[p_][0] <= s_pbox[q][3]) & (s_pbox[q][0] <= s_pbox[p_][3]) & (s_pbox[p_][1] <= s_pbox[q][4]) &
+                                  (s_pbox[q][1] <= s_pbox[p_][4]) & (s_pbox[p_][2] <= s_pbox[q][5]) & (s_pbox[q][2] <= s_pbox[p_][5]);
+                if (meet && !((sk >> q) & 1ull)) { if (q < 32) lo_m |= 1u << q; else hi_m |= 1u << (q - 32); }
             }
         }
-        s_near[t] = m;
+        if (lo_m) atomicOr(&s_near32[2 * p_], lo_m);
+        if (hi_m) atomicOr(&s_near32[2 * p_ + 1], hi_m);
     }
+    __syncthreads();
+    if (t < 64) s_near[t] = (unsigned long long)s_near32[2 * t] | ((unsigned long long)s_near32[2 * t + 1] << 32);
     __syncthreads();
     // part culling (a triangle whose box meets the box of no part it may collide with cannot have a partner and never
     // enters the grid), packed cell range of the survivors, part masks of the buckets (folded to 32 bits)
@@ -451,11 +478,12 @@ void k_pen_g2(PenDev P, const int* __restrict__ want) {
                 int a6[6];
 #pragma unroll
                 for (int e = 0; e < 6; ++e) a6[e] = pen_ford(bx[u][e]);
-                while (nm && !any) {
-                    const int q = __ffsll((long long)nm) - 1;
-                    nm &= nm - 1;
-                    const int* pb = s_pbox[q];      // (all six comparisons, combined with `&`: `&&` compiles to a branch per condition)
-                    any = (a6[0] <= pb[3]) & (pb[0] <= a6[3]) & (a6[1] <= pb[4]) & (pb[1] <= a6[4]) & (a6[2] <= pb[5]) & (pb[2] <= a6[5]);
+                while (nm && !any) {      // (two parts per trip: independent LDS reads; all comparisons combined with `&`: `&&` compiles to a branch per condition)
+                    const int q0_ = __ffsll((long long)nm) - 1; nm &= nm - 1;
+                    const int q1_ = nm ? __ffsll((long long)nm) - 1 : q0_; nm &= nm - 1;
+                    const int* pa = s_pbox[q0_]; const int* pb = s_pbox[q1_];
+                    any = ((a6[0] <= pa[3]) & (pa[0] <= a6[3]) & (a6[1] <= pa[4]) & (pa[1] <= a6[4]) & (a6[2] <= pa[5]) & (pa[2] <= a6[5])) |
+                          ((a6[0] <= pb[3]) & (pb[0] <= a6[3]) & (a6[1] <= pb[4]) & (pb[1] <= a6[4]) & (a6[2] <= pb[5]) & (pb[2] <= a6[5]));
                 }
             }
             pk[u] = make_int2(0, 0);
@@ -1298,36 +1326,56 @@ void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
         }
         __builtin_amdgcn_wave_barrier();
         unsigned long long m = __ballot(can_sort && (c_l > PEN_SHORT || a_l > c_l) && off_l < P.pair_cap);
+        // (round 5: the first 128 partners of the NEXT long list of the block are fetched while this one is sorted -- such lists
+        //  come in crowds, 64 of a block's 64 triangles in a collapsed mesh, and a load -> sort -> store chain per list made the
+        //  block's wavefront the launch's long pole: ~3 us per list, 2 of them waiting for memory)
+        int nx[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+        auto fetch = [&](const unsigned long long mm) {
+            if (!mm) return;
+            const int bit_ = __ffsll((long long)mm) - 1;
+            const int av_ = min(__builtin_amdgcn_readlane(a_l, bit_), P.pcap);
+            const int* mine_ = part + (size_t)(fw + bit_) * P.pcap;
+            int l_[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) l_[r] = mine_[min(lane + 64 * r, P.pcap - 1)];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nx[r] = lane + 64 * r < av_ ? l_[r] : 0x7fffffff;
+        };
+        fetch(m);
         while (m) {
             const int bit = __ffsll((long long)m) - 1;
             m &= m - 1;
             const int ff = fw + bit;
             const int cc = __builtin_amdgcn_readlane(c_l, bit), off = __builtin_amdgcn_readlane(off_l, bit);
             const int found = __builtin_amdgcn_readlane(a_l, bit);
+            int x[4] = {nx[0], nx[1], nx[2], nx[3]};
+            fetch(m);
             if (found > P.pcap && rewalk_b) continue;                  // incomplete list: queued by k_pen_list, taken below
             const int av = min(found, P.pcap);                         // sort all av held partners, keep the cc lowest
             const int* mine = part + (size_t)ff * P.pcap;
             int np = 64;
             while (np < av) np <<= 1;
-            if (np <= 128) {
-                // up to 128 partners (the cfgs' max_collisions): bitonic network on one or two registers per
-                // lane, element e = lane + 64 r; exchanges through ds_bpermute, no LDS traffic
-                int x0 = lane < av ? mine[lane] : 0x7fffffff;
-                int x1 = (np == 128 && lane + 64 < av) ? mine[lane + 64] : 0x7fffffff;
-                for (int k = 2; k <= np; k <<= 1)
-                    for (int j = k >> 1; j > 0; j >>= 1) {
-                        if (j == 64) { const int lo = min(x0, x1), hi = max(x0, x1); x0 = lo; x1 = hi; continue; }   // k = 128: ascending
-                        const bool lower = (lane & j) == 0;
-                        const int y0 = __shfl_xor(x0, j);
-                        x0 = (lower == ((lane & k) == 0)) ? min(x0, y0) : max(x0, y0);
-                        if (np == 128) {
-                            const int y1 = __shfl_xor(x1, j);
-                            x1 = (lower == (((lane + 64) & k) == 0)) ? min(x1, y1) : max(x1, y1);
-                        }
-                    }
+            if (np <= 256 && np <= tcap) {
+                // up to 256 partners (2 x the cfgs' max_collisions: what a list holds while it is collected).  Round 5: ranked, not
+                // sorted -- the list goes to the wavefront's LDS tile once, every lane counts how many of its values are smaller
+                // than each of its own (all lanes read the same word: a broadcast, no dependence between the reads) and stores its
+                // values at their ranks; partner ids are distinct.  The bitonic network it replaces was 28-45 DEPENDENT cross-lane
+                // exchanges per list (~3 us), and a collapsed mesh brings blocks of 64 such lists.
+                const int R = np >> 6;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (r < R) tile[lane + 64 * r] = x[r];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+                int rk[4] = {0, 0, 0, 0};
+                for (int i = 0; i < av; i += 4) {
+                    const int4 v4 = *reinterpret_cast<const int4*>(tile + i);        // (entries beyond av are 0x7fffffff: never smaller)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rk[r] += (int)(v4.x < x[r]) + (int)(v4.y < x[r]) + (int)(v4.z < x[r]) + (int)(v4.w < x[r]);
+                }
                 const int keep = min(cc, P.pair_cap - off);
-                if (lane < keep) { plist[off + lane] = x0; pown[off + lane] = ff; }
-                if (lane + 64 < keep) { plist[off + lane + 64] = x1; pown[off + lane + 64] = ff; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (r < R && lane + 64 * r < av && rk[r] < keep) { plist[off + rk[r]] = x[r]; pown[off + rk[r]] = ff; }
+                __builtin_amdgcn_wave_barrier();
                 continue;
             }
 
@@ -1591,6 +1639,13 @@ __device__ __forceinline__ void pen_vertex_out(const PenDev& P, const int b, con
                                                float* __restrict__ dverts, const PenAdjPrep& ap) {
     auto has = [&](int face) { return (s_hasp[face >> 5] >> (face & 31)) & 1u; };
     float g[3] = {0.f, 0.f, 0.f};
+    // (round 5: the vertex' skinning row is fetched with the first loads of the chain, not behind the gradient it multiplies --
+    //  one dependent round trip less on every vertex that carries a gradient)
+    int wj_[SFX_NW]; float ww_[SFX_NW];
+    if (ap.adj_G) {
+#pragma unroll
+        for (int q = 0; q < SFX_NW; ++q) { wj_[q] = ap.Wsp_j[(size_t)v * SFX_NW + q]; ww_[q] = ap.Wsp_w[(size_t)v * SFX_NW + q]; }
+    }
     if (total > 0) {
         const float* tg = P.tgrad + (size_t)b * P.F * 9;
         // (the incident corners in batches of 8 -- a vertex of a closed mesh has ~6 -- so that the three dependent
@@ -1623,10 +1678,9 @@ __device__ __forceinline__ void pen_vertex_out(const PenDev& P, const int b, con
 #pragma unroll
                     for (int c = 0; c < 3; ++c) T[rr * 3 + c] += w * ap.AT[((size_t)(rr * 4 + c) * SFX_JPAD + j) * Bp + b];
             };
-            const int* wj = ap.Wsp_j + (size_t)v * SFX_NW;
-            if (wj[0] >= 0) {
-                const float* ww = ap.Wsp_w + (size_t)v * SFX_NW;
-                for (int q = 0; q < SFX_NW; ++q) if (ww[q] != 0.f) add(wj[q], ww[q]);
+            if (wj_[0] >= 0) {
+#pragma unroll
+                for (int q = 0; q < SFX_NW; ++q) if (ww_[q] != 0.f) add(wj_[q], ww_[q]);
             } else {
                 for (int j = 0; j < SFX_J; ++j) { const float w = ap.W[(size_t)v * SFX_J + j]; if (w != 0.f) add(j, w); }
             }
