@@ -118,6 +118,23 @@ def test_the_three_forms_of_the_term_give_the_same_bits(topo_model, cfg_halpe):
                 for k in ("pairs", "dropped", "entry_overflow", "walks_cut"):
                     assert np.array_equal(res[form][3][k], res[0][3][k]), (cap, p2p, form, k, res[form][3][k], res[0][3][k])
             assert np.all(res[0][0] > 0)
+        # a MIXED batch: columns with more than 700 pairs are handed to the general kernels, the others stay with the per-column
+        # workgroup (SFX_PEN_FAST_PAIRS is read when a handle is created; the default hands over beyond 8 192)
+        import os
+        n_un = np.array([len(p) // 2 for p in res[0][2]])
+        assert (n_un > 700).any() and (n_un <= 700).any(), n_un
+        os.environ["SFX_PEN_FAST_PAIRS"] = "700"
+        try:
+            for form in (1, 3):
+                engine.pen_form(form)
+                pen = engine.Penetration(vb.shape[1], faces, parts["segm"], parts["parents"], cfg_halpe["ign_part_pairs"], max_collisions=128, max_batch=B)
+                for _ in range(2):
+                    loss, dv = pen.eval(vt, cfg_halpe["df_cone_height"], point2plane=True)
+                assert np.array_equal(loss.cpu().numpy(), res[0][0]) and np.array_equal(dv.cpu().numpy(), res[0][1]), form
+                assert all(np.array_equal(pen.pairs(b), res[0][2][b]) for b in range(B)), form
+                pen.close()
+        finally:
+            del os.environ["SFX_PEN_FAST_PAIRS"]
     finally:
         engine.pen_form(prev)
 
