@@ -117,7 +117,7 @@ def compact_line(full):
     if isinstance(full.get("alt"), dict):
         line["alt"] = _pick(full["alt"], ("lbs_mode", "value", "unit", "ms_per_step", "closure_evals_per_frame_mean", "final_loss_median"))
     if isinstance(full.get("host"), dict):
-        line["host"] = _pick(full["host"], ("enqueue_us_per_round", "loop_us_per_round", "kernels_us_per_round", "queue_dry_frac", "wait_frac", "outside_loop_ms_per_step"), sig=4)
+        line["host"] = _pick(full["host"], ("enqueue_us_per_round", "loop_us_per_round", "kernels_us_per_round", "event_pair_us", "queue_dry_frac", "wait_frac", "outside_loop_ms_per_step"), sig=4)
     if "kernels_ms_avg" in full:
         line["kernels_ms_avg"] = _pick(full["kernels_ms_avg"], ("lbs_dense", "tick_dense", "fit_rows", "penetration"))
     if "detail" in full:
@@ -349,6 +349,17 @@ def cpu_baseline_report(m, ref_evals_per_frame):
                                   m["throughput_processes"], m["throughput_processes"] - 1, m["throughput_s"], m["throughput_evals"]),
                               "closure": "dense LBS forward + autograd backward per evaluation",
                               "evals_per_fitted_frame": per}}
+
+
+def event_pair_overhead_us(n=200):
+    """Median elapsed time of a HIP-event pair with nothing between them on the current stream (microseconds)."""
+    import torch
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record(); b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in ev]) * 1e3)
 
 
 def csrc_sha():
@@ -733,6 +744,7 @@ def main():
     # per-kernel HIP-event figures of the headline region (read before the side runs add their launches)
     prof = {k: engine.prof_get(k) for k in ("lbs_dense", "tick", "fit_rows", "penetration")}
     host = engine.loop_host_stats()            # the host thread's side of the timed fits (dense loops)
+    pair_us = event_pair_overhead_us()         # what a HIP-event pair around nothing reads: every timed scope over-reads by it
     pen_work = engine.pen_work_get() if pen else None      # device counts over the timed region: grid entries, ordered pairs, columns
     # configs[3]'s per-GPU job on THIS GPU (N = 1 only): 1 024 frames of the same generator through the default column pool, so that
     # a 1 -> N curve read off the driver's lines divides equal jobs (the N > 1 lines fit 1 024 frames per GPU and carry
@@ -850,9 +862,16 @@ def main():
             # stage flags of a finished batch (= the GPU is the bottleneck: good), or neither (the GPU starved: the loop's wall
             # time minus the kernels' time is then queue-dry time)
             k_us = 1e3 * (ms_dense / max(n_dense, 1) + ms_clo / max(n_clo, 1) + prof["penetration"][0] / max(prof["penetration"][1], 1))
+            # a HIP-event pair around NOTHING on an idle stream reads this much (the timestamps sit in the command processor's
+            # packet stream, not at the kernel's first and last wavefront): each of the round's timed scopes over-reads by it, which
+            # made the scopes sum to MORE than the loop's wall time per round (round 4: 107.9 against 105.1 us) and pinned
+            # queue_dry_frac at its clamp.  Measured here, subtracted from the per-round sum the host figures use.
+            n_scopes = 2 + (1 if prof["penetration"][1] else 0)
+            k_net = max(k_us - n_scopes * pair_us, 0.0)
             out["host"] = {"enqueue_us_per_round": 1e6 * host["enqueue_s"] / host["rounds"], "wait_frac": host["wait_s"] / max(host["wall_s"], 1e-12),
-                           "loop_us_per_round": 1e6 * host["wall_s"] / host["rounds"], "kernels_us_per_round": k_us,
-                           "queue_dry_frac": max(0.0, 1.0 - k_us * host["rounds"] / max(1e6 * host["wall_s"], 1e-12)),
+                           "loop_us_per_round": 1e6 * host["wall_s"] / host["rounds"], "kernels_us_per_round": k_net,
+                           "kernels_us_per_round_events": k_us, "event_pair_us": pair_us,
+                           "queue_dry_frac": max(0.0, 1.0 - k_net * host["rounds"] / max(1e6 * host["wall_s"], 1e-12)),
                            # what a step spends OUTSIDE the fitting loop (batch set-up on the host, result collection, the gather):
                            # ~15 ms on an idle host; hundreds of ms on a box whose host cores are taken -- the frames/s of such a run
                            # say nothing about the kernels (halpe workload, round 4: 272 and 362 against 467-487 frames/s)
@@ -914,7 +933,7 @@ def main():
                                "traffic": None, "flops_per_launch": fl / n_dense, "bytes_per_launch": by / n_dense,
                                "hbm_GBps": by / t_tot / 1e9, "hbm_frac": by / t_tot / PEAK_HBM,
                                "avg_launch_us": 1e6 * t_tot / n_dense, "launches": n_dense, "frames_per_launch": fpl,
-                               "share_of_step": ms_dense * args.prof_every / (1e3 * dt),
+                               "share_of_step": max(ms_dense - 1e-3 * pair_us * n_dense, 0.0) * args.prof_every / (1e3 * dt),
                                "launch_sampling": "HIP events around every %d-th launch over the whole timed region" % args.prof_every}
             W_ = model["weights"]
             tj = np.mean([((int((W_[i:i + 16] != 0).any(0).sum()) + 3) // 4) * 4 for i in range(0, dm.V, 16)])
@@ -966,7 +985,7 @@ def main():
                                         "bytes_per_launch": by_launch, "shared_bytes_per_launch": by_shared,
                                         "avg_launch_us": 1e6 * t_clo / n_clo,
                                         "launches": n_clo, "frames_per_launch": act / n_clo,
-                                        "share_of_step": ms_clo * args.prof_every / (1e3 * dt),
+                                        "share_of_step": max(ms_clo - 1e-3 * pair_us * n_clo, 0.0) * args.prof_every / (1e3 * dt),
                                         # what one frame pulls through its compute unit's L2 port per launch, and the rate that is over
                                         # the launch (a CU streams ~100 GB/s from L2: tools/micro/stream_cu.hip)
                                         "l2_stream_bytes_per_frame": by_shared + by_frame,
@@ -1032,7 +1051,7 @@ def main():
                                    "avg_launch_us": 1e6 * t_p / n_p, "launches": n_p, "columns_per_launch": want_per_launch,
                                    "active_columns_per_launch": u_p / n_p,
                                    "grid_entries_per_column": E_, "pairs_per_column": P_,
-                                   "share_of_step": ms_p * args.prof_every / (1e3 * dt),
+                                   "share_of_step": max(ms_p - 1e-3 * pair_us * n_p, 0.0) * args.prof_every / (1e3 * dt),
                                    "bytes_per_launch": by_col * want_per_launch,
                                    "launches_per_round": pen_work.get("launches_per_round"),
                                    "note": "latency- and issue-bound: dependent kernels per round whose per-frame chains (counting sort "
