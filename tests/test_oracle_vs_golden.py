@@ -253,3 +253,88 @@ def test_frame_driver_matches_reference_fit_on_the_benchmark_configuration(synth
     assert rel[0] < 1e-5
     assert np.all(rel[1:4] < np.maximum(2 * spread[1:4], 3e-3)), (rel, spread)
     assert np.all(rel[4:] < np.maximum(3 * spread[4:], 5e-2)), (rel, spread)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The interpenetration oracle (oracle/penetration.py, PARITY UNPINNED: the package is absent) against a second, independent
+# statement of the same published algorithm (oracle/penetration_numpy.py: plain loops, other routes to the same quantities),
+# finite differences of its gradient, and the invariants the term must have.
+def _two_blobs(offset, seed=0):
+    """two small closed meshes (octahedra subdivided once) that intersect when offset is small; part labels 0 / 2 (2's parent = 1)"""
+    def octa(c, r):
+        v = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], float)
+        f = [[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]]
+        vs, fs, mid = [tuple(x) for x in v], [], {}
+        def m(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in mid:
+                p = (np.array(vs[a]) + np.array(vs[b])) / 2
+                vs.append(tuple(p / np.linalg.norm(p))); mid[k] = len(vs) - 1
+            return mid[k]
+        for a, b, c_ in f:
+            ab, bc, ca = m(a, b), m(b, c_), m(c_, a)
+            fs += [[a, ab, ca], [ab, b, bc], [ca, bc, c_], [ab, bc, ca]]
+        return np.array(vs) * r + np.array(c), np.array(fs)
+    rng = np.random.RandomState(seed)
+    v0, f0 = octa([0, 0, 0], 0.10)
+    v1, f1 = octa([offset, 0.013, 0.021], 0.08)
+    v = np.concatenate([v0, v1]) + 0.003 * rng.normal(size=(len(v0) + len(v1), 3))
+    f = np.concatenate([f0, f1 + len(v0)])
+    segm = np.concatenate([np.zeros(len(f0), int), 2 * np.ones(len(f1), int)])
+    parents = np.concatenate([-np.ones(len(f0), int), np.ones(len(f1), int)])
+    return v, f, segm, parents
+
+
+@pytest.mark.parametrize("sigma,outside,p2p", [(0.5, True, False), (0.05, False, False), (1e-2, True, True), (1e-4, True, False)])
+def test_penetration_two_independent_implementations_agree(sigma, outside, p2p):
+    from oracle import penetration as OP, penetration_numpy as PN
+    v, f, segm, parents = _two_blobs(0.12)
+    pairs = OP.candidate_pairs(v, f, segm, parents)
+    assert [tuple(p) for p in pairs.tolist()] == PN.colliding_pairs(v, f, segm, parents) and len(pairs) > 20
+    # the part rules, each on its own: same part / parent-child / an ignored pair -> nothing left; no labels -> self-collisions too
+    assert PN.colliding_pairs(v, f, np.zeros_like(segm), -np.ones_like(parents)) == [] == OP.candidate_pairs(v, f, np.zeros_like(segm), -np.ones_like(parents)).tolist()
+    assert OP.candidate_pairs(v, f, segm, np.where(segm == 2, 0, -1)).tolist() == PN.colliding_pairs(v, f, segm, np.where(segm == 2, 0, -1)) == []
+    assert OP.candidate_pairs(v, f, segm, parents, ["2,0"]).tolist() == PN.colliding_pairs(v, f, segm, parents, [(0, 2)]) == []
+    assert [tuple(p) for p in OP.candidate_pairs(v, f).tolist()] == PN.colliding_pairs(v, f)
+    a = float(OP.penetration_loss(torch.tensor(v, dtype=torch.float64), f, pairs, sigma, outside, p2p))
+    b = PN.loss(v, f, [tuple(p) for p in pairs.tolist()], sigma, outside, p2p)
+    assert a > 0 and abs(a - b) <= 1e-10 * a, (a, b)
+
+
+def test_penetration_gradient_finite_differences_and_invariants():
+    from oracle import penetration as OP
+    v, f, segm, parents = _two_blobs(0.12, seed=1)
+    sigma = 0.05
+    lo, g, pairs = OP.penetration(v, f, segm, parents, None, sigma=sigma)
+    rng = np.random.RandomState(2)
+    for _ in range(6):          # central differences along random directions (the field is C1: quadratic band, linear tail)
+        d = rng.normal(size=v.shape); d /= np.linalg.norm(d)
+        h = 1e-6
+        fp = float(OP.penetration_loss(torch.tensor(v + h * d), f, pairs, sigma))
+        fm = float(OP.penetration_loss(torch.tensor(v - h * d), f, pairs, sigma))
+        assert abs((fp - fm) / (2 * h) - float((g * d).sum())) <= 1e-5 * np.abs(g).sum(), ((fp - fm) / (2 * h), float((g * d).sum()))
+    # a rigid motion of the whole scene changes nothing for a FIXED pair list, and the gradient turns with it (the candidate set
+    # itself is found on axis-aligned boxes: it may change under a rotation, and does on this scene)
+    from scipy.spatial.transform import Rotation
+    R = Rotation.from_rotvec([0.3, -0.7, 0.5]).as_matrix()
+    vt = torch.tensor(v @ R.T + [0.3, -0.1, 2.0], requires_grad=True)
+    lo2 = OP.penetration_loss(vt, f, pairs, sigma)
+    lo2.backward()
+    assert abs(float(lo2) - lo) <= 1e-9 * lo and np.abs(vt.grad.numpy() - g @ R.T).max() <= 1e-8 * np.abs(g).max()
+    lo_t, _, pairs_t = OP.penetration(v + [0.3, -0.1, 2.0], f, segm, parents, None, sigma=sigma)       # a translation keeps the boxes' overlaps
+    assert np.array_equal(pairs_t, pairs) and abs(lo_t - lo) <= 1e-9 * lo
+    # separated meshes: no candidates, zero loss; relabelling the triangles' corner order (same orientation) changes nothing
+    v_far, f_far, s_far, p_far = _two_blobs(0.5)
+    assert len(OP.candidate_pairs(v_far, f_far, s_far, p_far)) == 0 and OP.penetration(v_far, f_far, s_far, p_far)[0] == 0.0
+    lo3 = float(OP.penetration_loss(torch.tensor(v), np.roll(f, 1, axis=1), pairs, sigma))
+    assert abs(lo3 - lo) <= 1e-12 * lo
+    # the capped list (assumption A1): symmetric, lowest ids, cut count consistent
+    cnt = np.bincount(pairs.reshape(-1), minlength=len(f))
+    cap = max(2, int(cnt.max() // 2))
+    op, n_cut = OP.ordered_pairs_capped(pairs, cap)
+    sset = set(map(tuple, op.tolist()))
+    assert n_cut > 0 and len(op) == 2 * len(pairs) - n_cut and all((b_, a_) in sset for a_, b_ in sset)
+    for t in np.unique(op[:, 0]):
+        mine = np.sort(op[op[:, 0] == t, 1])
+        allp = np.sort(np.concatenate([pairs[pairs[:, 0] == t, 1], pairs[pairs[:, 1] == t, 0]]))
+        assert len(mine) <= cap and set(mine) <= set(allp[:cap])
