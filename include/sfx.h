@@ -325,8 +325,9 @@ void sfx_prof_reset(void);
 int  sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out /* [32] */);
 
 /* Debug / A-B measurements: which dense LBS kernel the rounds launch -- 16 = k_lbs_dense16 (16 frames per wavefront: the
- * product kernel), 32 = k_lbs_dense (32 frames per wavefront; the same chain of fp32 operations per vertex and frame, so
- * the same bits).  Process-wide; any other value only queries.  Returns the previous setting.                          */
+ * product kernel; at <= 32 active frames its form with one coordinate per wavefront, k_lbs_dense16c), 17 = k_lbs_dense16 at
+ * every size, 32 = k_lbs_dense (32 frames per wavefront).  The same chain of fp32 operations per vertex and frame in all of
+ * them, so the same bits.  Process-wide; any other value only queries.  Returns the previous setting.                   */
 int  sfx_debug_lbs_dense_form(int32_t form);
 
 /* Debug / A-B measurements: which form of the interpenetration term handles and batches created FROM NOW ON take -- 0 = the ten

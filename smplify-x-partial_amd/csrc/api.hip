@@ -918,7 +918,7 @@ extern "C" int sfx_debug_two_loop(const float* S, const float* Y, int32_t count,
 // whose loss pass does not wait for the GEMM would cost); out_ms = elapsed wall time of the rounds.
 extern "C" int sfx_debug_lbs_dense_form(int32_t form) {
     const int prev = g_lbs_dense_form;
-    if (form == 16 || form == 32) g_lbs_dense_form = form;
+    if (form == 16 || form == 17 || form == 32) g_lbs_dense_form = form;
     return prev;
 }
 

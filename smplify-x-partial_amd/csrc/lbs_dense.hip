@@ -362,6 +362,123 @@ void k_lbs_dense16(DevModel M, BatchDev D) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_lbs_dense16c (round 5): the launch FLOOR.  At <= 32 active frames -- the tail of every fit: the frames still running when most
+// have finished -- k_lbs_dense16 has one or two wavefronts per workgroup doing all three coordinates of their 16 x 16 tile: 24
+// dependent-issue MFMAs per chunk on one wavefront while the workgroup's others only stage (20-21 us per launch whatever the
+// number of frames).  Here the three coordinates of a slice go to three wavefronts (6 wavefronts = 2 slices x 3 coordinates per
+// workgroup): every accumulator is its own MFMA chain over the same operands in the same K order, the skinning rows likewise
+// (wavefront c forms output row c from the three blend-shape accumulators, exchanged through LDS), so a (vertex, frame) goes
+// through exactly the fp32 operations of k_lbs_dense16 -- interchangeable bit for bit
+// (test_the_two_dense_kernels_are_interchangeable_bit_for_bit).
+struct __align__(16) DenseLDS16c {
+    float a[2][32][LDK];
+    float b[2][KC][LDB];
+    float x[2][3][64][4];        // [slice][coordinate][lane][register]: v_posed accumulators on their way to the skinning rows
+};
+__global__ __launch_bounds__(384, 2)
+void k_lbs_dense16c(DevModel M, BatchDev D) {
+    __shared__ DenseLDS16c S;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6, sl = wv / 3, co = wv % 3;
+    int tile;
+    {
+        const int ntile = (M.V + VB - 1) / VB, tpx = (ntile + 7) / 8;
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        tile = xcd * tpx + slot;
+        if (tile >= ntile || slot >= tpx) return;
+    }
+    const int v0 = tile * VB, b0 = sl * 16;
+    const int jl = lane & 15, kq = lane >> 4;
+    const int V = M.V, B = D.nact;
+    const int vtx = v0 + jl;
+    const int v = vtx < V ? vtx : V - 1;
+    const size_t Bp = (size_t)D.Bpad;
+    const bool active = b0 < B;
+    const float4* gA = reinterpret_cast<const float4*>(D.featR);
+    const float4* gB = reinterpret_cast<const float4*>(M.dirs_tiled + (size_t)tile * SFX_KD_PAD * NB3);
+    const int stepA = KC / 4, stepB = KC * (NB3 / 4);
+    // staging: 384 float4 of dirs (one per thread) + 256 of feat (threads < 256) per chunk
+    const bool okA = tid < 32 * (KC / 4);
+    const int ia = okA ? tid : 0, fa = ia / (KC / 4), ka = ia % (KC / 4);
+    const int gAo = (min(fa, D.Bpad - 1)) * (SFX_KD_PAD / 4) + ka, lAo = fa * LDK + ka * 4;
+    const int gBo = tid, lBo = (tid / (NB3 / 4)) * LDB + (tid % (NB3 / 4)) * 4;
+    float4 sA, sB;
+#define STC_LOAD(c) do { sA = gA[gAo + (c) * stepA]; sB = gB[gBo + (c) * stepB]; } while (0)
+#define STC_WRITE(buf) do { if (okA) *reinterpret_cast<float4*>(&S.a[buf][0][0] + lAo) = sA;           \
+        *reinterpret_cast<float4*>(&S.b[buf][0][0] + lBo) = sB; } while (0)
+    f32x4 acc = {0, 0, 0, 0};
+    const float tc = M.v_template[v * 3 + co];
+    constexpr int NCHUNK = SFX_KD_PAD / KC;
+    STC_LOAD(KCHUNK(0));
+    STC_WRITE(0);
+    __syncthreads();
+    for (int c = 0; c < NCHUNK; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < NCHUNK) STC_LOAD(KCHUNK(c + 1));
+        if (active) {
+            const float* sa = &S.a[cur][sl * 16 + jl][kq];
+            const float* sb = &S.b[cur][kq][jl * 3 + co];
+#pragma unroll
+            for (int ks = 0; ks < KC / 4; ++ks) acc = MFMA(sa[ks * 4], sb[ks * 4 * LDB], acc);
+        }
+        if (c + 1 < NCHUNK) STC_WRITE(cur ^ 1);
+        __syncthreads();
+    }
+#undef STC_LOAD
+#undef STC_WRITE
+    const bool vok = vtx < V;
+    if (active) {
+        const int us = vok ? M.vslot[vtx] : -1;      // export index of an item vertex
+        if (us >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f0 = b0 + kq * 4 + r;
+                if (f0 < B) D.uvp[((size_t)f0 * M.n_uniq + us) * 3 + co] = acc[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += tc;
+        *reinterpret_cast<f32x4*>(&S.x[sl][co][lane][0]) = acc;
+    }
+    __syncthreads();
+    if (!active) return;
+    const f32x4 ax0 = *reinterpret_cast<const f32x4*>(&S.x[sl][0][lane][0]);
+    const f32x4 ay0 = *reinterpret_cast<const f32x4*>(&S.x[sl][1][lane][0]);
+    const f32x4 az0 = *reinterpret_cast<const f32x4*>(&S.x[sl][2][lane][0]);
+    const int njs = M.tj_n[tile] >> 2;
+    const int* jl4 = M.tj_list + (size_t)tile * SFX_JPAD + kq;
+    const float* wl = M.tj_w + ((size_t)tile * SFX_JPAD + kq) * 16 + jl;
+    const float* atb = D.AT + b0 + jl;
+    const size_t estep = (size_t)SFX_JPAD * Bp;
+    float P0, P1, P2, P3, N0, N1, N2, N3, wc, wn;
+#define ATC_LOAD(p0, p1, p2, p3, ww, js) do {                                                                \
+        const float* at_ = atb + ((size_t)(co * 4) * SFX_JPAD + jl4[(js) * 4]) * Bp;                          \
+        p0 = at_[0]; p1 = at_[estep]; p2 = at_[2 * estep]; p3 = at_[3 * estep];                               \
+        ww = wl[(js) * 64]; } while (0)
+    ATC_LOAD(P0, P1, P2, P3, wc, 0);
+    f32x4 t00 = {0, 0, 0, 0}, t01 = t00, t02 = t00, t03 = t00;
+    for (int js = 0; js < njs; ++js) {
+        if (js + 1 < njs) ATC_LOAD(N0, N1, N2, N3, wn, js + 1);
+        t00 = MFMA(P0, wc, t00); t01 = MFMA(P1, wc, t01); t02 = MFMA(P2, wc, t02); t03 = MFMA(P3, wc, t03);
+        P0 = N0; P1 = N1; P2 = N2; P3 = N3; wc = wn;
+    }
+#undef ATC_LOAD
+    float o0[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o0[r] = t00[r] * ax0[r] + t01[r] * ay0[r] + t02[r] * az0[r] + t03[r];
+    if (vok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f0 = b0 + kq * 4 + r;
+            if (f0 < B) {
+                if (D.vposed) D.vposed[((size_t)f0 * V + vtx) * 3 + co] = co == 0 ? ax0[r] : co == 1 ? ay0[r] : az0[r];
+                D.verts[((size_t)f0 * V + vtx) * 3 + co] = o0[r];
+            }
+        }
+    }
+}
+
 #ifdef MF32
 // DIAGNOSTIC build only (tools/build_variant.sh mf32 lbs_dense -DMF32 -DNO_T): the K loop of the blend-shape GEMM on
 // v_mfma_f32_32x32x2_f32 -- wavefront tile 32 vertices x 32 frames, 3 x 16 accumulator registers, per K step of two rows
@@ -467,6 +584,11 @@ void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s) {
         // SFX_LBS_W, us per launch at 5 / 6 / 9 slices: W = 3: 44.2 / 45.1 / 60.1, W = 4: 47.6 / 48.5 / 65.5, W = 5: 41.2 / 55.3 / 74.1;
         // every other count is fastest (or as fast) at W = 4, and W = 6 .. 8 lose everywhere (measured, not instantiated)
         const int ns = (D.nact + 15) / 16, ny4 = (ns + 3) / 4;
+        if (ns <= 2 && g_lbs_dense_form != 17 && !g_lbs_dense_w) {       // the tail of a fit: three coordinates on three wavefronts (same bits)
+            const int ntile_ = (M.V + VB - 1) / VB;
+            hipLaunchKernelGGL(k_lbs_dense16c, dim3(8 * ((ntile_ + 7) / 8)), dim3(384), 0, s, M, D);
+            return;
+        }
         int w = ns <= 4 ? 4 : (ns == 5 ? 5 : std::max(3, (ns + ny4 - 1) / ny4));
         if (g_lbs_dense_w) w = g_lbs_dense_w;
         const int ny = (ns + w - 1) / w, ntile = (M.V + VB - 1) / VB;

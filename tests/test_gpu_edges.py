@@ -109,6 +109,40 @@ def test_the_two_dense_kernels_are_interchangeable_bit_for_bit(synth_model, cfg_
     assert np.array_equal(out[0][4], out[1][4])
 
 
+@pytest.mark.parametrize("n", [1, 9, 16, 17, 32])
+def test_the_few_frames_dense_kernel_is_interchangeable_bit_for_bit(synth_model, cfg_body, n):
+    """k_lbs_dense16c (round 5: at <= 32 active frames the three coordinates of a 16-frame slice go to three wavefronts -- the
+    launch floor) against k_lbs_dense16 (form 17 = without it) and k_lbs_dense (form 32): vertices, exported keypoint offsets
+    (through the closure's loss and gradient) and a two-stage fit, bit for bit, at 1, 9, 16, 17 and 32 frames."""
+    from smplifyx_amd import _capi
+    lib = _capi.load()
+    cfg = dict(cfg_body); cfg["use_camera_prior"] = False
+    dm = T._dm(synth_model, cfg)
+    frames = T.synth_frames(synth_model, cfg, 3)
+    idx = [i % 3 for i in range(n)]
+    out = []
+    prev = lib.sfx_debug_lbs_dense_form(0)
+    try:
+        for form in (16, 17, 32):
+            lib.sfx_debug_lbs_dense_form(form)
+            assert lib.sfx_debug_lbs_dense_form(0) == form
+            fb = H.engine_batch_from_frames(dm, cfg, frames, idx, lbs_mode="dense", reuse=True)
+            fb.guess_init(cfg["body_tri_idxs"])
+            l, g = fb.closure(0)
+            verts = fb.debug_read("verts").copy()
+            fb.fit(first_stage=-1, last_stage=1)
+            out.append((l.copy(), g.copy(), verts, {k: v.copy() for k, v in fb.get_params().items()}, fb.stats()["stage_evals"].copy()))
+            fb.close()
+    finally:
+        lib.sfx_debug_lbs_dense_form(prev)
+    assert np.abs(out[0][2]).max() > 0.1
+    for other in (1, 2):
+        assert np.array_equal(out[0][0], out[other][0]) and np.array_equal(out[0][1], out[other][1]) and np.array_equal(out[0][2], out[other][2]), other
+        for k in out[0][3]:
+            assert np.array_equal(out[0][3][k], out[other][3][k]), (other, k)
+        assert np.array_equal(out[0][4], out[other][4])
+
+
 def test_dense_and_rows_agree_per_closure(synth_model, cfg_body):
     """The needed-rows kernel and the all-vertices MFMA kernel evaluate the same objective: loss
     and gradient agree to fp32 rounding (both are compared with the oracle elsewhere)."""
