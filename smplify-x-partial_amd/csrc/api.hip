@@ -1245,7 +1245,7 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
                     BatchDev Dn = D; Dn.act = b->act_new_dev; Dn.nrun = (int)fresh.size();
                     ProfScope p("tick_admit", s, Dn.nrun);
                     launch_tick_dense(M, Dn, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, s);
-                } else if ((D.nact + 31) / 32 != ((int)run.size() + 31) / 32) {
+                } else if ((D.nact + 31) / 32 != ((int)run.size() + 31) / 32 || (D.nact > 16 && run.size() <= 16)) {      // (round 5: also down to ONE 16-frame slice -- the few-frames GEMM's floor is 17.5 us there, 23 at two slices)
                     // queue dry and a 32-frame MFMA slice has emptied: compact.  The pending evaluation of every running
                     // frame lives in column slot[f] of featR / AT, so re-export after remapping (queued behind the rounds
                     // already in flight, which still use the old mapping consistently).
