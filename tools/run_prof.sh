@@ -11,9 +11,9 @@ set -x
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 TAG=$1; shift
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG; mkdir -p $O
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu --no-parity --no-alt $*"
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu --no-parity --no-alt --no-configs3 $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o p -- $CMD > $O/bench_under_rocprof.json 2> $O/kt.log
-PM="python bench.py --steps 1 --warmup 0 --no-cpu --no-alt --no-parity $*"
+PM="python bench.py --steps 1 --warmup 0 --no-cpu --no-alt --no-parity --no-configs3 $*"
 rm -rf /tmp/pmc_f /tmp/pmc_w /tmp/pmc_s /tmp/pmc_c
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o p -- $PM > /dev/null 2> $O/pmc_f.log
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o p -- $PM > /dev/null 2> $O/pmc_w.log
