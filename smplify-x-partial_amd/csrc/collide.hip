@@ -115,6 +115,7 @@ struct PenDev {
     int* ovn;                  // [B][2] their number, and the cursor the wavefronts of k_pen_rank take them with
     int no_rewalk;             // SFX_PEN_REWALK_OFF=1 (A/B measurement switch): overflowing lists keep their first arrivals, as until round 4
     int* callno;               // [2] evaluations so far (k_pen_g1), and the last one in which some list overflowed (k_pen_list): k_pen_rank looks for queues only then
+    int* ovm;                  // [1 + B] meshes of this evaluation whose overflow queue k_pen_rank has to drain: count (k_pen_g1 -> 0), ids (k_pen_list)
     int* over;                 // [B] or NULL (set per call): 1 = this evaluation of the mesh kept partners by ARRIVAL order somewhere (a list beyond
                                //     2 x max_collisions, a cut walk): its numbers are not reproducible run to run
     // round 5: the per-frame kernel (k_pen_frame) and the columns it hands to the general kernels
@@ -284,7 +285,7 @@ __device__ __forceinline__ int pen_bucket(int x, int y, int z) {
 __global__ __launch_bounds__(PEN_T)
 void k_pen_g1(PenDev P, const float* __restrict__ verts, const int* __restrict__ want, float* __restrict__ zero_dverts,
               float* __restrict__ zero_G, int Vpad) {
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { P.callno[0] += 1; P.nheavy[0] = 0; }      // (one writer per launch; launches of a handle are ordered)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { P.callno[0] += 1; P.nheavy[0] = 0; P.ovm[0] = 0; }      // (one writer per launch; launches of a handle are ordered)
     __shared__ float red[PEN_T / 64];
     __shared__ int pbox[64 * 6];               // this workgroup's part boxes (LDS atomics), merged into the frame's afterwards: atomics
                                                // straight to the frame's 12 cache lines serialise in L2 (measured: 0.4-1.5 ms)
@@ -1108,6 +1109,7 @@ void k_pen_list(PenDev P, PenSel sel) {
                       // keeps its first arrivals, as every overflowing list did until round 4, and is reported as order dependent
                       const bool rewalk = pen_can_rewalk(P) && ta <= (float)PEN_REWALK_MAX;
                       if (!rewalk) P.ovn[b * 2] = 0;
+                      else if (ta > 0.f) P.ovm[1 + atomicAdd(&P.ovm[0], 1)] = b;      // (k_pen_rank drains the queues of the meshes listed here)
                       if (P.over) P.over[b] = ((ta > 0.f && !rewalk) || st[13] > 0) ? 1 : 0;      // (lists beyond pcap are re-derived by k_pen_rank: pen_rewalk)
                       if (P.work) { atomicAdd(&P.work[1], (unsigned long long)tot);
                                     if (ta > 0.f) atomicAdd(&P.work[4], (unsigned long long)ta);
@@ -1262,16 +1264,27 @@ void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
     const int F = P.F;
     const int tcap = min(max(cap_pad, 128), 2048);
     int* tile = s_sort + wv * tcap;
+#ifdef PEN_RANKT
+    const long long rt0 = wall_clock64(); long long rt_long = 0, rt_ld = 0, rt_short = 0; int n_long = 0, n_rew = 0;
+#endif
+    // (round 5: the few words EVERY wavefront of the launch wants -- is this column selected, has it pairs, has it a queue; below:
+    //  has any mesh a queue -- are fetched by ONE lane per workgroup and handed on through LDS.  34 k wavefronts asking the same
+    //  handful of cache lines at the same moment queue up behind each other at one L2 channel: measured with -DPEN_RANKT, the
+    //  launch's slow wavefronts spent 50 us on such loads and 12 us on their lists)
+    __shared__ int s_u[4];
     for (int si = blockIdx.y; si < nsel; si += gridDim.y) {
     const int b = pen_sel_col(sel, si);
-    if (!pen_sel_on(sel, b) || P.ptotal[b] == 0) continue;
+    __syncthreads();
+    if (t == 0) { s_u[0] = pen_sel_on(sel, b) ? 1 : 0; s_u[1] = P.ptotal[b]; s_u[2] = P.ovn[b * 2]; }
+    __syncthreads();
+    if (!s_u[0] || s_u[1] == 0) continue;
     const int* pc = P.pcount + (size_t)b * F;
     const int* poff = P.poff + (size_t)b * F;
     const int* part = P.partners + (size_t)b * F * P.pcap;
     const int* pav = P.pavail + (size_t)b * F;
     int* pown = P.pown + (size_t)b * P.pair_cap;
     int* plist = P.plist + (size_t)b * P.pair_cap;
-    const bool rewalk_b = pen_can_rewalk(P) && P.ovn[b * 2] > 0;      // (k_pen_list empties the queue of a mesh it will not have looked at again)
+    const bool rewalk_b = pen_can_rewalk(P) && s_u[2] > 0;      // (k_pen_list empties the queue of a mesh it will not have looked at again)
     const bool can_sort = cap_pad <= 2048;
     // 64 consecutive triangles at a time per wavefront.  Short lists: their elements are dealt to the
     // lanes (owner found by bisection of the 64 offsets in LDS), each lane ranks its element within its
@@ -1292,39 +1305,61 @@ void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
         const int a_l = inr ? a_ld : 0;                // partners held (> c_l: the list is cut to its c_l lowest ids)
         const int base = __builtin_amdgcn_readfirstlane(off_l);
         const int lastv = min(63, flim - 1 - fw);
+#ifdef PEN_RANKT
+        const long long rq0 = wall_clock64();
+#endif
         const int E = __builtin_amdgcn_readlane(off_l + c_l, lastv) - base;
+#ifdef PEN_RANKT
+        rt_ld += wall_clock64() - rq0;
+#endif
         if (E == 0) continue;
         __builtin_amdgcn_wave_barrier();
+#ifdef PEN_RANKT
+        const long long rs0 = wall_clock64();
+#endif
+        if (can_sort) {
+            // Short lists (<= PEN_SHORT partners, not cut): ONE LANE PER TRIANGLE -- the lane fetches its whole list in one round trip,
+            // ranks its values against each other in registers and stores them at their ranks.  (Until round 5 the block's ELEMENTS
+            // were dealt to the lanes, 64 per trip of a loop, every trip paying its own dependent loads: a block in a hand region --
+            // 64 triangles x ~10 partners -- was ten trips; measured with -DPEN_RANKT: the wavefronts beyond 40 us spent 56 us in this
+            // pass and 1.6 of them on long lists.)
+            const bool mine_short = inr && c_l > 0 && c_l <= PEN_SHORT && a_l <= c_l && off_l < P.pair_cap;
+            if (mine_short) {
+                const int* mine = part + (size_t)f * P.pcap;
+                int y[PEN_SHORT];
+#pragma unroll
+                for (int r = 0; r < PEN_SHORT; ++r) y[r] = mine[min(r, P.pcap - 1)];
+#pragma unroll
+                for (int s_ = 0; s_ < PEN_SHORT; ++s_) {
+                    if (s_ < c_l) {
+                        int rank = 0;
+#pragma unroll
+                        for (int r = 0; r < PEN_SHORT; ++r) rank += (int)((r < c_l) & ((y[r] < y[s_]) | ((y[r] == y[s_]) & (r < s_))));
+                        if (off_l + rank < P.pair_cap) { plist[off_l + rank] = y[s_]; pown[off_l + rank] = f; }
+                    }
+                }
+            }
+        } else {
         tile[lane] = off_l - base;
         tile[64 + lane] = c_l | (a_l > c_l ? 0x10000 : 0);       // (kept count and "the list was cut" of the 64 triangles: no second trip to memory for them)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
-        for (int e = lane; e < E; e += 64) {
+        for (int e = lane; e < E; e += 64) {            // (max_collisions beyond the wavefront sort: element-wise all the way, as before)
             int l = 0;
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) if (tile[l + d] <= e) l += d;      // last l with offset <= e
             const int ff = fw + l, lo = tile[l], slot = e - lo, off = base + lo;
-            const int cw = tile[64 + l], cc = cw & 0xffff;
-            if (can_sort && (cc > PEN_SHORT || (cw & 0x10000))) continue;
+            const int cc = tile[64 + l] & 0xffff;
             const int* mine = part + (size_t)ff * P.pcap;
-            // the whole short list in one round trip (round 5: `for (r < cc) y = mine[r]` compiled to cc dependent waits -- up to 16
-            // memory round trips per element on the lane's chain: most of this kernel's 60 us on a body mesh)
-            int y[PEN_SHORT];
-#pragma unroll
-            for (int r = 0; r < PEN_SHORT; ++r) y[r] = mine[min(r, P.pcap - 1)];
-            int x = 0;
-#pragma unroll
-            for (int r = 0; r < PEN_SHORT; ++r) x = r == slot ? y[r] : x;
+            const int x = mine[slot];
             int rank = 0;
-            if (!can_sort && cc > PEN_SHORT) {           // (max_collisions beyond the wavefront sort: element-wise all the way, as before)
-                x = mine[slot];
-                for (int r = 0; r < cc; ++r) { const int yy = mine[r]; rank += (int)((yy < x) | ((yy == x) & (r < slot))); }
-            } else {
-#pragma unroll
-                for (int r = 0; r < PEN_SHORT; ++r) rank += (int)((r < cc) & ((y[r] < x) | ((y[r] == x) & (r < slot))));
-            }
+            for (int r = 0; r < cc; ++r) { const int yy = mine[r]; rank += (int)((yy < x) | ((yy == x) & (r < slot))); }
             if (off + rank < P.pair_cap) { plist[off + rank] = x; pown[off + rank] = ff; }
         }
+        }
         __builtin_amdgcn_wave_barrier();
+#ifdef PEN_RANKT
+        rt_short += wall_clock64() - rs0;
+#endif
         unsigned long long m = __ballot(can_sort && (c_l > PEN_SHORT || a_l > c_l) && off_l < P.pair_cap);
         // (round 5: the first 128 partners of the NEXT long list of the block are fetched while this one is sorted -- such lists
         //  come in crowds, 64 of a block's 64 triangles in a collapsed mesh, and a load -> sort -> store chain per list made the
@@ -1342,6 +1377,9 @@ void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
             for (int r = 0; r < 4; ++r) nx[r] = lane + 64 * r < av_ ? l_[r] : 0x7fffffff;
         };
         fetch(m);
+#ifdef PEN_RANKT
+        const long long rl0 = wall_clock64(); n_long += __popcll(m);
+#endif
         while (m) {
             const int bit = __ffsll((long long)m) - 1;
             m &= m - 1;
@@ -1396,19 +1434,43 @@ void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
             for (int q = lane; q < keep; q += 64) { plist[off + q] = tile[q]; pown[off + q] = ff; }
             __builtin_amdgcn_wave_barrier();
         }
+#ifdef PEN_RANKT
+        rt_long += wall_clock64() - rl0;
+#endif
     }
     // Triangles whose list overflowed while it was collected: one shared queue per mesh (k_pen_list), taken one triangle at a time
     // through an atomic cursor by whichever wavefront is free -- first the mesh's own, then those of the other meshes of the call
     // (such triangles come in crowds, in one or two meshes of a call: their own 256 wavefronts would be the launch's long pole).
     // Who derives a triangle's partners has no influence on what they are.
     }
-    if (!pen_can_rewalk(P) || P.callno[1] != P.callno[0]) return;      // (no list of this evaluation overflowed: nothing queued anywhere)
-    const int nB = nsel, b = (int)(blockIdx.y % (unsigned)nsel);        // (positions in the selection: the call's columns, or the heavy list)
-    // (which meshes have a queue at all: looked up by the lanes in parallel, 64 meshes per step -- one mesh after the other the
-    //  scan itself was a chain of dependent loads as long as the call has meshes)
+#ifdef PEN_RANKT
+    const long long rt1 = wall_clock64();
+    auto rank_report = [&]() {
+        const long long rt2 = wall_clock64();
+        if (lane == 0 && P.work && rt2 - rt0 > 4000) {      // wavefronts that took more than 40 us
+            atomicAdd(&P.work[8], 1ull); atomicAdd(&P.work[9], (unsigned long long)(rt1 - rt0)); atomicAdd(&P.work[10], (unsigned long long)rt_long);
+            atomicAdd(&P.work[11], (unsigned long long)(rt2 - rt1)); atomicAdd(&P.work[12], (unsigned long long)n_long); atomicAdd(&P.work[13], (unsigned long long)n_rew);
+            atomicAdd(&P.work[14], (unsigned long long)rt_ld); atomicAdd(&P.work[15], (unsigned long long)rt_short);
+        }
+    };
+    __syncthreads();
+    if (t == 0) s_u[3] = pen_can_rewalk(P) ? P.ovm[0] : 0;      // (meshes with a queue in this evaluation: k_pen_g1 -> 0, k_pen_list appends)
+    __syncthreads();
+    if (s_u[3] == 0) { rank_report(); return; }
+#else
+    __syncthreads();
+    if (t == 0) s_u[3] = pen_can_rewalk(P) ? P.ovm[0] : 0;      // (meshes with a queue in this evaluation: k_pen_g1 -> 0, k_pen_list appends)
+    __syncthreads();
+    if (s_u[3] == 0) return;                                     // (no list of this evaluation overflowed: nothing queued anywhere)
+#endif
+    // (round 5: WHICH meshes have a queue is a compact list k_pen_list appends to -- a handful per evaluation.  Until then every
+    //  wavefront of the launch looked through the counters of ALL the call's meshes: 12 k wavefronts x 119 meshes x 3 loads on the
+    //  same few cache lines whenever any mesh had overflowed -- which the collapsed meshes of a fit make the normal case: 54 us of
+    //  the slow wavefronts' 110, measured with -DPEN_RANKT)
+    const int nB = min(s_u[3], P.F), b = nB > 0 ? (int)(blockIdx.y % (unsigned)nB) : 0;      // (at most one entry per mesh of the evaluation)
     for (int g0 = 0; g0 < nB; g0 += 64) {
       const int bl = g0 + lane;
-      const int bq = pen_sel_col(sel, bl < nB ? (b + bl < nB ? b + bl : b + bl - nB) : 0);           // the own mesh first
+      const int bq = P.ovm[1 + (bl < nB ? (b + bl < nB ? b + bl : b + bl - nB) : 0)];           // (a rotation of the list: the takers spread over the queues)
       const int nql = P.ovn[bq * 2], ptl = P.ptotal[bq], wl = pen_sel_on(sel, bq) ? 1 : 0;
       unsigned long long todo = __ballot(bl < nB && wl && nql > 0 && ptl > 0 && P.ovn[bq * 2 + 1] < nql);
       while (todo) {
@@ -1429,6 +1491,9 @@ void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
             const int cc = pcb[ff], off = poffb[ff];
             if (off >= P.pair_cap) continue;
             __builtin_amdgcn_wave_barrier();
+#ifdef PEN_RANKT
+            ++n_rew;
+#endif
             const int got = pen_rewalk(P, bb, ff, tile, tcap, lane);
             const int keep = min(min(cc, got), P.pair_cap - off);
             for (int q = lane; q < keep; q += 64) { plistb[off + q] = tile[q]; pownb[off + q] = ff; }
@@ -1436,6 +1501,9 @@ void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
         }
       }
     }
+#ifdef PEN_RANKT
+    rank_report();
+#endif
 }
 
 // one lane per ORDERED pair (f receives g, and f's vertices intrude into g): the lane differentiates
@@ -2462,7 +2530,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     }
     P.gpart = h->zeros<float>(B * PEN_GW * 8);
     P.partners = h->zeros<int>(B * F * P.pcap); P.pcount = h->zeros<int>(B * F); P.pavail = h->zeros<int>(B * F);
-    P.ovq = h->zeros<int>(B * F); P.ovn = h->zeros<int>(B * 2); P.callno = h->zeros<int>(2);
+    P.ovq = h->zeros<int>(B * F); P.ovn = h->zeros<int>(B * 2); P.callno = h->zeros<int>(2); P.ovm = h->zeros<int>(B + 1);
     P.pair_cap = (int)std::min<size_t>((size_t)F * P.cap, std::max<size_t>(65536, (size_t)16 * F));
     P.hasp_words = (F + 31) / 32; P.hasp = h->zeros<unsigned>(B * P.hasp_words);
     P.poff = h->zeros<int>(B * F); P.pown = h->zeros<int>(B * P.pair_cap); P.plist = h->zeros<int>(B * P.pair_cap);
@@ -2489,7 +2557,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
                 (size_t)2 * PEN_FP <= (size_t)P.pair_cap ? 1 : 0;
     if (!P.heavy || !P.hlist || !P.nheavy || !P.pcnt) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tcount || !P.pbox || !P.gpart || !P.aabb || !P.entries) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
-    if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.pavail || !P.ptotal || !P.ovq || !P.ovn || !P.callno) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
+    if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.pavail || !P.ptotal || !P.ovq || !P.ovn || !P.callno || !P.ovm) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     *out = h;
     return 0;
 }
