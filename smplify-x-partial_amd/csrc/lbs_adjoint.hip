@@ -69,7 +69,13 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
     // grid: x = r slice (fastest: the slices of one (k tile, frame tile) stream disjoint parts of dirs),
     // y = k tile (8), z = frame tile: the 64 WANTED columns of ranks 64 z .. (results land at those ranks in adj_part)
     const int slice = blockIdx.x, k0 = blockIdx.y * 64, b0 = blockIdx.z * 64;
-    if (adj_tile_columns(D.pen_want, D.nact, blockIdx.z, s_cols, &s_nw) <= b0) return;      // no wanted column in this tile
+    const int n_wanted = adj_tile_columns(D.pen_want, D.nact, blockIdx.z, s_cols, &s_nw);
+    if (n_wanted <= b0) return;      // no wanted column in this tile
+    // (round 5) 16-column MFMA tiles of this frame tile that hold a wanted column at all: the others are neither loaded nor
+    // multiplied -- in the rounds where a handful of columns carry a collision weight (the start of the stages with the term, the
+    // tail of a fit) three quarters of the launch's MFMA work was for columns nobody reads (27.5 us floor).  A column's
+    // arithmetic does not depend on its neighbours: same bits.
+    const int nj = min(4, (n_wanted - b0 + 15) >> 4);
     const int LD = 3 * M.Vpad;
     const int r_lo = min(LD, (slice * 4 + wv) * rw);
     const int r_hi = min(LD, r_lo + rw);
@@ -90,7 +96,7 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             a[i] = *reinterpret_cast<const float4*>(pa + i * sa + r);
-            b[i] = *reinterpret_cast<const float4*>(pbc[i] + r);
+            if (i < nj) b[i] = *reinterpret_cast<const float4*>(pbc[i] + r);
         }
     };
     if (r_lo < r_hi) load(a_c, b_c, r_lo);
@@ -109,13 +115,15 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
                 }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (j < nj) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[i][j] = MFMA(a_c[i].x, b_c[j].x, acc[i][j]);
-                acc[i][j] = MFMA(a_c[i].y, b_c[j].y, acc[i][j]);
-                acc[i][j] = MFMA(a_c[i].z, b_c[j].z, acc[i][j]);
-                acc[i][j] = MFMA(a_c[i].w, b_c[j].w, acc[i][j]);
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][j] = MFMA(a_c[i].x, b_c[j].x, acc[i][j]);
+                    acc[i][j] = MFMA(a_c[i].y, b_c[j].y, acc[i][j]);
+                    acc[i][j] = MFMA(a_c[i].z, b_c[j].z, acc[i][j]);
+                    acc[i][j] = MFMA(a_c[i].w, b_c[j].w, acc[i][j]);
+                }
             }
         if (more) {
 #pragma unroll
