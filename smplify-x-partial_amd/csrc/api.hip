@@ -643,6 +643,11 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
         if (c->n_stages > 0) { sfx_set_error("%d optimisation variables (limit %d): reduce num_pca_comps", body.n, SFX_NVAR_MAX); delete b; return -1; }
         body.n = SFX_NVAR_MAX;
     }
+    D.cfg.hist_dead_lo = D.cfg.hist_dead_hi = 0;
+    if (const char* e = getenv("SFX_HIST_ZEROPAGE")) if (atoi(e) > 0)
+        for (int g = 0; g < body.ngroups; ++g) if (!body.g_has[g]) {
+            D.cfg.hist_dead_lo = (body.g_off[g] + 2) / 3; D.cfg.hist_dead_hi = (body.g_off[g] + body.g_len[g]) / 3;
+            if (atoi(e) == 2) { D.cfg.hist_dead_lo += 25; D.cfg.hist_dead_hi += 25; } }      // (2: LIVE lanes instead -- the fit must change: shows that the switch is wired)
     b->vl_host[0] = cam; b->vl_host[1] = body;
     std::vector<VarList> vls = {cam, body};
     b->vl_dev = b->mem.up(vls);
@@ -711,7 +716,7 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     if (b->slots >= B) b->slots = 0;
     D.opt = b->mem.zeros<char>((size_t)B * sfx_optstate_size());
     D.vec = b->mem.zeros<float>((size_t)B * NVEC * SFX_NVAR_MAX);
-    D.hist = b->mem.zeros<float>((size_t)B * 2 * SFX_HROWS * SFX_NVAR_MAX);
+    D.hist = b->mem.zeros<float>(((size_t)B * 2 * SFX_HROWS + 16) * SFX_NVAR_MAX);      // (+ 16 rows of zeros nobody writes: hist_dead_lo)
     D.n_active = b->mem.zeros<int>(4);
     D.stage_loss = b->mem.zeros<float>((size_t)B * (1 + SFX_MAX_STAGES));
     D.stage_evals = b->mem.zeros<int>((size_t)B * (1 + SFX_MAX_STAGES));

@@ -168,6 +168,8 @@ struct BatchCfgDev {
     double tol_grad, tol_change;       // LBFGS tolerance_grad / tolerance_change (lbfgs_ls.py defaults 1e-5 / 1e-9)
     int hist_cap;                      // LBFGS history_size (<= SFX_HIST)
     int proj64;                        // projection in fp64 in every stage (cfg float_dtype float64; the camera stage always is)
+    int hist_dead_lo, hist_dead_hi;    // lanes [lo, hi) of the body stage's history rows hold only the dead body_pose slots (0, 0: none /
+                                       // measurement switched off): they read a page of zeros behind the history (lbfgs_body.h lb_load)
 };
 
 // Per-frame data pointers (all device).
