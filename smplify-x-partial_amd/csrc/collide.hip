@@ -276,6 +276,16 @@ __device__ __forceinline__ int block_excl_scan(const int v, int* wsum /* [PEN_T 
 #define PEN_GW 8                // workgroups per frame in k_pen_g1 / g2
 #define PEN_GU 3                // triangles per lane of those kernels: ceil(F / (PEN_GW * PEN_T)) for F <= 24576; more loop
 __device__ __forceinline__ int pen_ford(float x) { int i = __float_as_int(x); return i ^ ((i >> 31) & 0x7fffffff); }      // order-preserving
+// The PEN_GW workgroups of a column on ONE XCD (round 5).  Workgroup i of a launch, x fastest, runs on XCD i % 8 (observed; a matter
+// of speed only): with (w, b) = blockIdx the eight workgroups of a column sat on eight XCDs, each of whose L2s fetched the column's
+// vertices for its share of the triangles (k_pen_g1 read 5x the vertices' bytes from HBM).  Here a group of 64 consecutive
+// workgroups serves 8 columns, column = group * 8 + (i % 8); the launch has a multiple of 8 rows, nb: the real column count.
+__device__ __forceinline__ bool pen_gw_map(const int nb, int& b, int& w) {
+    static_assert(PEN_GW == 8, "one workgroup of a column per slot of an XCD group");
+    const int lin = blockIdx.y * PEN_GW + blockIdx.x;
+    b = (lin >> 6) * 8 + (lin & 7); w = (lin >> 3) & 7;
+    return b < nb;
+}
 __device__ __forceinline__ int pen_bucket(int x, int y, int z) {
     return (int)(((unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u) & (PEN_CELLS - 1)); }
 
@@ -284,12 +294,14 @@ __device__ __forceinline__ int pen_bucket(int x, int y, int z) {
 // launch that has eight workgroups per column and nothing else to write but the boxes.
 __global__ __launch_bounds__(PEN_T)
 void k_pen_g1(PenDev P, const float* __restrict__ verts, const int* __restrict__ want, float* __restrict__ zero_dverts,
-              float* __restrict__ zero_G, int Vpad) {
+              float* __restrict__ zero_G, int Vpad, int nb) {
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { P.callno[0] += 1; P.nheavy[0] = 0; P.ovm[0] = 0; }      // (one writer per launch; launches of a handle are ordered)
     __shared__ float red[PEN_T / 64];
     __shared__ int pbox[64 * 6];               // this workgroup's part boxes (LDS atomics), merged into the frame's afterwards: atomics
                                                // straight to the frame's 12 cache lines serialise in L2 (measured: 0.4-1.5 ms)
-    const int b = blockIdx.y, t = threadIdx.x, w = blockIdx.x;
+    const int t = threadIdx.x;
+    int b, w;
+    if (!pen_gw_map(nb, b, w)) return;
     if (want && !want[b]) return;
     if (zero_dverts) {
         float* d = zero_dverts + (size_t)b * P.V * 3;
@@ -393,11 +405,13 @@ __device__ __forceinline__ void pen_for_cells(const int2 pk, FN&& fn) {
     }
 }
 __global__ __launch_bounds__(PEN_T)
-void k_pen_g2(PenDev P, const int* __restrict__ want) {
+void k_pen_g2(PenDev P, const int* __restrict__ want, int nb) {
     __shared__ unsigned long long s_mask[64], s_near[64];
     __shared__ int s_pbox[64][6];
     __shared__ int s_cnt, s_base, s_ccnt, s_cbase;
-    const int b = blockIdx.y, t = threadIdx.x, w = blockIdx.x, lane = t & 63;
+    const int t = threadIdx.x, lane = t & 63;
+    int b, w;
+    if (!pen_gw_map(nb, b, w)) return;
     // (round 5: the inputs of the culling -- part boxes, the static part table, the frame-box partials -- come in ONE round trip,
     //  fetched by different lanes, and the 64 x 64 "do these parts' boxes meet" tests are dealt over the lanes, 16 per part: the
     //  prologue was a string of dependent loads and a 55-trip loop on 64 lanes)
@@ -2615,7 +2629,7 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
             frame_attr = true;
         }
         const PenSel all{want_dev, nullptr, nullptr, nullptr};
-        hipLaunchKernelGGL(k_pen_g1, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, verts_dev, want_dev, dverts_dev, ap.adj_G, ap.Vpad);
+        hipLaunchKernelGGL(k_pen_g1, dim3(PEN_GW, (B + 7) & ~7), dim3(PEN_T), 0, s, h->P, verts_dev, want_dev, dverts_dev, ap.adj_G, ap.Vpad, B);
         if (h->form == 3) {
             // one workgroup per column behind the boxes (measured and not the default: the pair tests of a column are 70-150 us of ALU
             // work on ONE compute unit, and a round lasts as long as its slowest column)
@@ -2623,7 +2637,7 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
             else hipLaunchKernelGGL(k_pen_frame<false>, dim3(B), dim3(PEN_T), PEN_FRAME_LDS, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, 0);
         } else {
             // round 5's default: grid build and pair tests over the chip, the pairs into one list per column, one workgroup per column behind them
-            hipLaunchKernelGGL(k_pen_g2, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, want_dev);
+            hipLaunchKernelGGL(k_pen_g2, dim3(PEN_GW, (B + 7) & ~7), dim3(PEN_T), 0, s, h->P, want_dev, B);
             hipLaunchKernelGGL(k_pen_g3, dim3(B), dim3(PEN_T), (size_t)(PEN_GRID_INTS + PEN_CELLS) * sizeof(int), s, h->P, want_dev);
             hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, h->P, all, 1);
             hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, B, all, 1);
@@ -2645,8 +2659,8 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
     } else {
     const PenSel all{want_dev, nullptr, nullptr, nullptr};
     // grid build (the cross-workgroup accumulators -- part boxes, survivor counts -- are left empty by k_pen_g3 of the previous evaluation)
-    hipLaunchKernelGGL(k_pen_g1, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, verts_dev, want_dev, (float*)nullptr, (float*)nullptr, 0);
-    hipLaunchKernelGGL(k_pen_g2, dim3(PEN_GW, B), dim3(PEN_T), 0, s, h->P, want_dev);
+    hipLaunchKernelGGL(k_pen_g1, dim3(PEN_GW, (B + 7) & ~7), dim3(PEN_T), 0, s, h->P, verts_dev, want_dev, (float*)nullptr, (float*)nullptr, 0, B);
+    hipLaunchKernelGGL(k_pen_g2, dim3(PEN_GW, (B + 7) & ~7), dim3(PEN_T), 0, s, h->P, want_dev, B);
     hipLaunchKernelGGL(k_pen_g3, dim3(B), dim3(PEN_T), (size_t)(PEN_GRID_INTS + PEN_CELLS) * sizeof(int), s, h->P, want_dev);
     {
         PenDev Pw = h->P;
