@@ -138,7 +138,7 @@ typedef struct sfx_batch_cfg {
     double  lbfgs_tolerance_grad;   /* 1e-5                                                          */
     double  lbfgs_tolerance_change; /* 1e-9                                                          */
     int32_t lbfgs_max_eval;         /* maxiters * 5 / 4                                              */
-    int32_t lbfgs_history_size;     /* 100 (larger values are refused: the ring holds 100 pairs)     */
+    int32_t lbfgs_history_size;     /* 100; up to 400 (a larger history gets a ring of that many slots) */
     int32_t lbfgs_max_iter;         /* LBFGS(max_iter): iterations per LBFGS.step and bound of the zoom phase (lbfgs_ls.py:304,397);
                                        0 = maxiters, the one value optim_factory.py:15 hands to both; lbfgs_max_eval's default
                                        follows it (max_iter * 5 / 4, lbfgs_ls.py:203)                              */
@@ -346,9 +346,9 @@ int  sfx_debug_pen_phase_ticks(int64_t* ticks_host);
  * round launched together on two streams.  out_ms = elapsed time.  The batch's results are meaningless afterwards.     */
 int  sfx_debug_overlap_test(sfx_batch* b, int32_t rounds, int32_t mode, double* out_ms);
 /* Debug: direction of the device's blocked two-loop recursion for a caller-supplied history (rows of 192 floats, zero
- * padded; `count` pairs pushed in order, the window keeps the last 100) and gradient g[192]; d_out[192].  Host pointers.
- * Specification: optimizers/lbfgs_ls.py:312-341. */
-int  sfx_debug_two_loop(const float* S, const float* Y, int32_t count, const float* g, float* d_out);
+ * padded; `count` pairs pushed in order, the window keeps the last history_size -- <= 0: 100, at most 400) and gradient
+ * g[192]; d_out[192].  Host pointers.  Specification: optimizers/lbfgs_ls.py:312-341. */
+int  sfx_debug_two_loop(const float* S, const float* Y, int32_t count, int32_t history_size, const float* g, float* d_out);
 
 /* Debug: attach (enable>=1) a 64-slot clock buffer to the batch, run any entry point, then read it
  * and detach (enable=0): out[0..18] = closure phase stamps of the last launch, out[32+i] =

@@ -82,7 +82,7 @@ SYMBOLS = {
     "sfx_batch_get_stats": (C.c_int, [C.c_void_p, f32p, i32p, i32p]),
     "sfx_debug_lbs_dense_form": (C.c_int, [C.c_int32]),
     "sfx_debug_overlap_test": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
-    "sfx_debug_two_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sfx_debug_two_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "sfx_batch_trace": (C.c_int, [C.c_void_p, C.c_int32]),
     "sfx_batch_get_trace": (C.c_int, [C.c_void_p, f32p, i32p]),
     "sfx_batch_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

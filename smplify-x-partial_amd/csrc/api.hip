@@ -607,8 +607,10 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.cfg.tol_grad = c->lbfgs_tolerance_grad >= 0 ? c->lbfgs_tolerance_grad : 1e-5;
     D.cfg.tol_change = c->lbfgs_tolerance_change >= 0 ? c->lbfgs_tolerance_change : 1e-9;
     if (c->lbfgs_max_eval > 0) D.cfg.max_eval = c->lbfgs_max_eval;
-    if (c->lbfgs_history_size > SFX_HIST) { sfx_set_error("history_size %d > %d", c->lbfgs_history_size, SFX_HIST); delete b; return -1; }
+    // (round 5: a history_size beyond the default's 100 gets a ring of that many slots; the bound is the LDS array of the alphas)
+    if (c->lbfgs_history_size > SFX_HIST_MAX) { sfx_set_error("history_size %d > %d", c->lbfgs_history_size, SFX_HIST_MAX); delete b; return -1; }
     D.cfg.hist_cap = c->lbfgs_history_size > 0 ? c->lbfgs_history_size : SFX_HIST;
+    D.cfg.hist_ring = std::max(D.cfg.hist_cap, SFX_HIST);
     if (D.cfg.pen && c->lbs_mode != 1) {
         sfx_set_error("interpenetration needs lbs_mode = 1 (the term reads every vertex)"); delete b; return -1; }
     if (D.cfg.pen && !(c->df_cone_height > 0.f)) { sfx_set_error("df_cone_height must be positive"); delete b; return -1; }
@@ -716,7 +718,7 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     if (b->slots >= B) b->slots = 0;
     D.opt = b->mem.zeros<char>((size_t)B * sfx_optstate_size());
     D.vec = b->mem.zeros<float>((size_t)B * NVEC * SFX_NVAR_MAX);
-    D.hist = b->mem.zeros<float>(((size_t)B * 2 * SFX_HROWS + 16) * SFX_NVAR_MAX);      // (+ 16 rows of zeros nobody writes: hist_dead_lo)
+    D.hist = b->mem.zeros<float>(((size_t)B * 2 * (D.cfg.hist_ring + 8) + 16) * SFX_NVAR_MAX);      // (+ 16 rows of zeros nobody writes: hist_dead_lo)
     D.n_active = b->mem.zeros<int>(4);
     D.stage_loss = b->mem.zeros<float>((size_t)B * (1 + SFX_MAX_STAGES));
     D.stage_evals = b->mem.zeros<int>((size_t)B * (1 + SFX_MAX_STAGES));
@@ -907,11 +909,11 @@ extern "C" int sfx_batch_debug_read(sfx_batch* b, const char* name, float* out, 
 }
 
 // debug: the direction the device's blocked two-loop recursion (lbfgs_body.h lb_two_loop) computes from a history of `count`
-// curvature pairs pushed in order (rows of SFX_NVAR_MAX = 192 floats, zero padded; the window keeps the last 100) and a
-// gradient g: d = -H g with H_diag = y.s / y.y of the last pair (lbfgs_ls.py:312-341).  Host pointers.
-extern "C" int sfx_debug_two_loop(const float* S, const float* Y, int32_t count, const float* g, float* d_out) {
-    if (!S || !Y || !g || !d_out || count < 1) { sfx_set_error("sfx_debug_two_loop: bad arguments"); return -1; }
-    const int rc = debug_two_loop(S, Y, count, g, d_out);
+// curvature pairs pushed in order (rows of SFX_NVAR_MAX = 192 floats, zero padded; the window keeps the last history_size,
+// <= 0: 100) and a gradient g: d = -H g with H_diag = y.s / y.y of the last pair (lbfgs_ls.py:312-341).  Host pointers.
+extern "C" int sfx_debug_two_loop(const float* S, const float* Y, int32_t count, int32_t history_size, const float* g, float* d_out) {
+    if (!S || !Y || !g || !d_out || count < 1 || history_size > SFX_HIST_MAX) { sfx_set_error("sfx_debug_two_loop: bad arguments"); return -1; }
+    const int rc = debug_two_loop(S, Y, count, history_size > 0 ? history_size : SFX_HIST, g, d_out);
     if (rc) { sfx_set_error("sfx_debug_two_loop: HIP error"); return -1; }
     return 0;
 }

@@ -24,7 +24,7 @@ void k_fit_rows(DevModel M, BatchDev D, const VarList* __restrict__ vls, const S
     __shared__ LDS S;
     __shared__ float gflat[SFX_NVAR_MAX];
     __shared__ float fval;
-    __shared__ float s_al[SFX_HIST + 2 * LB_BS];
+    __shared__ float s_al[SFX_HIST_MAX + 2 * LB_BS];
     __shared__ OptScal st;
     const int b = blockIdx.x;
     ClosureArgs a{};
@@ -52,7 +52,7 @@ void k_tick_dense(DevModel M, BatchDev D, const VarList* __restrict__ vls, const
     __shared__ LDS S;
     __shared__ float gflat[SFX_NVAR_MAX];
     __shared__ float fval;
-    __shared__ float s_al[SFX_HIST + 2 * LB_BS];
+    __shared__ float s_al[SFX_HIST_MAX + 2 * LB_BS];
     __shared__ OptScal st;
     // PF (a workgroup per CU: LDS to spare): the optimiser tick's working set -- its 8 vectors, X, Xt, the scalar state, both
     // variable lists -- is requested with the loss / adjoint pass's entry batch (LDS-DMA into memory of its own, waited for

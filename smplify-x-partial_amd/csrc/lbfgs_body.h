@@ -121,9 +121,9 @@ struct OptScal {
 #define LB_BROW 16
 struct OptState {
     OptScal s;
-    float ro[SFX_HROWS];                 // (rows HIST..HIST+7 of all three mirror slots 0..7, as the history does)
-    float syb[SFX_HROWS * LB_BROW];
-    float syt[SFX_HROWS * LB_BROW];
+    float ro[SFX_HROWS_MAX];             // (rows R..R+7 of all three mirror slots 0..7, as the history does; R: the ring's slots)
+    float syb[SFX_HROWS_MAX * LB_BROW];
+    float syt[SFX_HROWS_MAX * LB_BROW];
 };
 
 
@@ -265,10 +265,10 @@ __device__ __forceinline__ void lb_axpy(LbRow& y, const float a, const LbRow& x)
 template <int DIR>
 __device__ __forceinline__ void lb_load(LbSet& X, const int base, const int n, const int head, const float* hMine,
                                         const float* hAll, const float* tab, const float* ro, const float* s_alp,
-                                        const bool want_al, const int lane, const char* zrow = nullptr) {
+                                        const bool want_al, const int lane, const int R, const char* zrow = nullptr) {
     const int grp = lane >> 3;
-    int p = head + base; p = p >= SFX_HIST ? p - SFX_HIST : p;
-    if (DIR < 0 && p < 7) p += SFX_HIST;
+    int p = head + base; p = p >= R ? p - R : p;
+    if (DIR < 0 && p < 7) p += R;
     const float* tb = tab + p * LB_BROW + 8 + grp;
 #pragma unroll
     for (int m = 0; m < 7; ++m) X.bnd[m] = tb[DIR * m * LB_BROW - m];
@@ -293,17 +293,18 @@ __device__ __forceinline__ void lb_load(LbSet& X, const int base, const int n, c
 // recursion keeps per pair: ro, the band entries s_(k-th predecessor) . y_new -- the syt row of the new pair and entry k
 // of the k-th predecessor's syb row -- and the mirror of slots 0..7 behind the ring.
 __device__ __forceinline__ void lb_push_pair(float* hY, float* hS, OptState* gst, int& hist_n, int& hist_head, const Lane3& y,
-                                             const Lane3& sv, const float ys, const int lane, const int hist_cap = SFX_HIST) {
-    if (hist_n >= hist_cap) { hist_head = (hist_head + 1) % SFX_HIST; hist_n -= 1; }      // (history_size <= SFX_HIST: the ring keeps its 100 slots)
-    const int ph = (hist_head + hist_n) % SFX_HIST;
+                                             const Lane3& sv, const float ys, const int lane, const int hist_cap = SFX_HIST,
+                                             const int R = SFX_HIST) {
+    if (hist_n >= hist_cap) { hist_head = hist_head + 1 >= R ? 0 : hist_head + 1; hist_n -= 1; }      // (history_size <= R, the ring's slots: 100 unless history_size asks for more)
+    int ph = hist_head + hist_n; ph = ph >= R ? ph - R : ph;
     st3_full(hY + (size_t)ph * SFX_NVAR_MAX, y, lane);
     st3_full(hS + (size_t)ph * SFX_NVAR_MAX, sv, lane);
     const float ro = 1.0f / ys;
     if (lane == 0) gst->ro[ph] = ro;
     if (ph < 8) {
-        st3_full(hY + (size_t)(ph + SFX_HIST) * SFX_NVAR_MAX, y, lane);
-        st3_full(hS + (size_t)(ph + SFX_HIST) * SFX_NVAR_MAX, sv, lane);
-        if (lane == 0) gst->ro[ph + SFX_HIST] = ro;
+        st3_full(hY + (size_t)(ph + R) * SFX_NVAR_MAX, y, lane);
+        st3_full(hS + (size_t)(ph + R) * SFX_NVAR_MAX, sv, lane);
+        if (lane == 0) gst->ro[ph + R] = ro;
     }
     hist_n += 1;
     const int n1 = __builtin_amdgcn_readfirstlane(hist_n), hd1 = __builtin_amdgcn_readfirstlane(hist_head);
@@ -311,7 +312,7 @@ __device__ __forceinline__ void lb_push_pair(float* hY, float* hS, OptState* gst
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
         const int i_ = n1 - 1 - k;
-        int t_ = hd1 + (i_ >= 0 ? i_ : 0); t_ = t_ >= SFX_HIST ? t_ - SFX_HIST : t_;
+        int t_ = hd1 + (i_ >= 0 ? i_ : 0); t_ = t_ >= R ? t_ - R : t_;
         SP[k - 1] = ld3_raw(hS, (unsigned)t_ * SFX_NVAR_MAX, lane);
     }
     float eb[8];
@@ -320,15 +321,15 @@ __device__ __forceinline__ void lb_push_pair(float* hY, float* hS, OptState* gst
     for (int k = 1; k < 8; ++k) eb[k] = fmaf(SP[k - 1].v[2], y.v[2], fmaf(SP[k - 1].v[1], y.v[1], SP[k - 1].v[0] * y.v[0]));
     const float e = wave_sum8_groups(eb, lane);      // group k: s_(k-th predecessor) . y_new
     const int k = lane >> 3, i_ = n1 - 1 - k;
-    int t_ = hd1 + (i_ >= 0 ? i_ : 0); t_ = t_ >= SFX_HIST ? t_ - SFX_HIST : t_;
+    int t_ = hd1 + (i_ >= 0 ? i_ : 0); t_ = t_ >= R ? t_ - R : t_;
     const float ev = (k >= 1 && i_ >= 0) ? e : 0.f;   // (no such predecessor: a finite 0)
     if ((lane & 7) == 0) {
         gst->syt[ph * LB_BROW + 8 + k] = ev;
         gst->syb[ph * LB_BROW + 8 + k] = 0.f;         // successors of the new pair do not exist yet
-        if (ph < 8) { gst->syt[(ph + SFX_HIST) * LB_BROW + 8 + k] = ev; gst->syb[(ph + SFX_HIST) * LB_BROW + 8 + k] = 0.f; }
+        if (ph < 8) { gst->syt[(ph + R) * LB_BROW + 8 + k] = ev; gst->syb[(ph + R) * LB_BROW + 8 + k] = 0.f; }
         if (k >= 1 && i_ >= 0) {
             gst->syb[t_ * LB_BROW + 8 + k] = ev;
-            if (t_ < 8) gst->syb[(t_ + SFX_HIST) * LB_BROW + 8 + k] = ev;
+            if (t_ < 8) gst->syb[(t_ + R) * LB_BROW + 8 + k] = ev;
         }
     }
 }
@@ -336,7 +337,7 @@ __device__ __forceinline__ void lb_push_pair(float* hY, float* hS, OptState* gst
 template <int SETS>
 __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, const OptState* gst, float* s_al,
                                              const int n_, const int head_, const float hd, const Lane3 q_in, const int lane,
-                                             const char* zrow = nullptr) {
+                                             const int R = SFX_HIST, const char* zrow = nullptr) {
     const int n = __builtin_amdgcn_readfirstlane(n_), head = __builtin_amdgcn_readfirstlane(head_);
     float* s_alp = s_al + 8;        // members below index 0 of the last block land in the padding
     const int grp = lane >> 3;
@@ -364,7 +365,7 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
 #pragma unroll
         for (int c = 0; c < 8; ++c) lb_axpy(q, -al[c], X.all[c]);
     };
-#define LB_LD1(X, b_) lb_load<-1>(X, (b_), n, head, hS, hY, gst->syt, gst->ro, s_alp, false, lane, zrow)
+#define LB_LD1(X, b_) lb_load<-1>(X, (b_), n, head, hS, hY, gst->syt, gst->ro, s_alp, false, lane, R, zrow)
     // The look-ahead loads are UNCONDITIONAL (a block past the end of the window re-reads block 0; it is never used): with
     // `if (i0 >= 16) load` the number of loads in flight at the next dot products depended on a branch, and the compiler then
     // waits for the shorter path's count -- vmcnt(0): every block paid its own memory round trip and the look-ahead bought
@@ -415,7 +416,7 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
 #pragma unroll
         for (int c = 0; c < 8; ++c) lb_axpy(r, cc[c], X.all[c]);
     };
-#define LB_LD2(X, b_) lb_load<1>(X, (b_), n, head, hY, hS, gst->syb, gst->ro, s_alp, true, lane, zrow)
+#define LB_LD2(X, b_) lb_load<1>(X, (b_), n, head, hY, hS, gst->syb, gst->ro, s_alp, true, lane, R, zrow)
     {
         int i0 = 0, k = 0;
         const int last = max(n - 1, 0);
@@ -444,7 +445,7 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
 }
 
 // One tick of frame b's optimiser, executed by ONE wavefront (lanes 0..63).  f_in / g_in: the
-// closure result (global D.f/D.g, or LDS copies in fused kernels).  s_al[SFX_HIST + 2 * LB_BS], s_state and
+// closure result (global D.f/D.g, or LDS copies in fused kernels).  s_al[SFX_HIST_MAX + 2 * LB_BS], s_state and
 // s_work[2048] (the tick's working copies; may alias any LDS that is dead during the tick)
 // are LDS scratch owned by the caller.
 // PF: the caller has the working set (vectors, X, Xt in s_work, the scalar state in s_state) and both variable lists (vls
@@ -461,8 +462,13 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
     float* Xg = D.X + (size_t)b * SFX_NPAR_MAX;          // global homes of the parameters, the trial point and the vectors;
     float* Xtg = D.Xt + (size_t)b * SFX_NPAR_MAX;        // a tick works on LDS copies (below)
     float* vecg = D.vec + (size_t)b * NVEC * SFX_NVAR_MAX;
-    float* hY = D.hist + (size_t)b * 2 * SFX_HROWS * SFX_NVAR_MAX;
-    float* hS = hY + (size_t)SFX_HROWS * SFX_NVAR_MAX;
+#ifdef SFX_RING_CONST                                   // (measurement: the ring's size as the compile-time constant it was until round 5)
+    const int R = SFX_HIST, hrows = R + 8;
+#else
+    const int R = C.hist_ring, hrows = R + 8;          // slots of the history ring (SFX_HIST unless history_size is larger)
+#endif
+    float* hY = D.hist + (size_t)b * 2 * hrows * SFX_NVAR_MAX;
+    float* hS = hY + (size_t)hrows * SFX_NVAR_MAX;
 #define VEC(k) (vec + (k) * SFX_NVAR_MAX)
 
     // ---------------------------------------------------------------- (re)initialisation
@@ -481,7 +487,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
             }
             D.try_both[b] = both;
         }
-        for (int i = lane; i < SFX_HROWS * LB_BROW; i += 64) { gst->syb[i] = 0.f; gst->syt[i] = 0.f; }     // (columns 0..8 stay zero)
+        for (int i = lane; i < hrows * LB_BROW; i += 64) { gst->syb[i] = 0.f; gst->syt[i] = 0.f; }     // (columns 0..8 stay zero)
         for (int q = lane; q < 1 + SFX_MAX_STAGES; q += 64) {
             if (q >= first_stage + 1 && q <= last_stage + 1) {
                 D.stage_evals[(size_t)b * (1 + SFX_MAX_STAGES) + q] = 0;
@@ -659,7 +665,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
                 const float ys = dot3(y, sv);
                 if (ys > 1e-10f) {
                     int hn = s.hist_n, hh = s.hist_head;
-                    lb_push_pair(hY, hS, gst, hn, hh, y, sv, ys, lane, C.hist_cap);
+                    lb_push_pair(hY, hS, gst, hn, hh, y, sv, ys, lane, C.hist_cap, R);
                     s.hist_n = hn; s.hist_head = hh;
                     s.H_diag = T(ys / dot3(y, y));
                 }
@@ -676,8 +682,8 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
                     } else {
                         // (measurement, DESIGN 4.5: lanes of the dead body_pose slots read zeros from one shared line)
                         const char* zrow = (stage >= 0 && lane >= C.hist_dead_lo && lane < C.hist_dead_hi)
-                            ? reinterpret_cast<const char*>(D.hist + ((size_t)C.B * 2 * SFX_HROWS + 8) * SFX_NVAR_MAX) : nullptr;
-                        r = lb_two_loop<SETS>(hS, hY, gst, s_al, n, s.hist_head, hd, q, lane, zrow);
+                            ? reinterpret_cast<const char*>(D.hist + ((size_t)C.B * 2 * hrows + 8) * SFX_NVAR_MAX) : nullptr;
+                        r = lb_two_loop<SETS>(hS, hY, gst, s_al, n, s.hist_head, hd, q, lane, R, zrow);
                     }
                 }
                 TMARK(5);

@@ -22,9 +22,12 @@
 #define SFX_KD_PAD 512      // padded blend-shape depth (20 + 486 = 506)
 #define SFX_JPAD 56         // joints padded to an even MFMA depth
 #define SFX_MAX_LEVELS 16
-#define SFX_HIST 100        // L-BFGS history (optim_factory 'lbfgsls' default)
-#define SFX_HROWS (SFX_HIST + 8)   // ring of SFX_HIST slots + rows HIST..HIST+7 mirroring slots 0..7: any 8 consecutive
-                                  // members of the window are 8 consecutive rows (lbfgs_body.h lb_load)
+#define SFX_HIST 100        // L-BFGS history (optim_factory 'lbfgsls' default): slots of the ring unless history_size asks for more
+#ifndef SFX_HIST_MAX
+#define SFX_HIST_MAX 400    // largest history_size (the alphas of the two-loop recursion live in LDS: lbfgs_body.h s_al)
+#endif
+#define SFX_HROWS (SFX_HIST + 8)   // ring of R slots + rows R..R+7 mirroring slots 0..7: any 8 consecutive members of the
+#define SFX_HROWS_MAX (SFX_HIST_MAX + 8)   // window are 8 consecutive rows (lbfgs_body.h lb_load); R = BatchCfgDev::hist_ring
 #define SFX_NVAR_MAX 192    // optimiser vector length (182 / 88 / 6), padded to 3*64
 #define SFX_FWD_N 6016      // floats per frame of saved forward state (FrameLDS prefix incl. the fp64 transforms + 96 + VPoser 1280)
 #define SFX_NPAR_MAX 256    // canonical per-frame parameter block (182 with 12 hand components; 248 with all 45: forward only)
@@ -166,7 +169,8 @@ struct BatchCfgDev {
     int pen;                           // interpenetration term enabled (dense mode)
     int kl[3], nil[3];                 // live keypoints / vertex items by stage class: body only, + hands, all (closure_body)
     double tol_grad, tol_change;       // LBFGS tolerance_grad / tolerance_change (lbfgs_ls.py defaults 1e-5 / 1e-9)
-    int hist_cap;                      // LBFGS history_size (<= SFX_HIST)
+    int hist_cap;                      // LBFGS history_size (<= SFX_HIST_MAX)
+    int hist_ring;                     // slots of the history ring: SFX_HIST, or history_size when that is larger (round 5)
     int proj64;                        // projection in fp64 in every stage (cfg float_dtype float64; the camera stage always is)
     int hist_dead_lo, hist_dead_hi;    // lanes [lo, hi) of the body stage's history rows hold only the dead body_pose slots (0, 0: none /
                                        // measurement switched off): they read a page of zeros behind the history (lbfgs_body.h lb_load)
@@ -204,7 +208,7 @@ struct BatchDev {
     int*   stage;      // [B] current stage (-1 camera, 0.. body, n_stages = done)
     void*  opt;        // [B] OptState
     float* vec;        // [B][NVEC][NVAR_MAX] optimiser vectors
-    float* hist;       // [B][2][HROWS][NVAR_MAX]
+    float* hist;       // [B][2][hist_ring + 8][NVAR_MAX]
     int*   n_active;   // [1] frames not done
     float* stage_loss; // [B][1+MAX_STAGES]
     int*   stage_evals;     // [B][1+MAX_STAGES]
@@ -284,7 +288,7 @@ extern int g_lbs_dense_form;          // 16 (k_lbs_dense16, default) | 32 (k_lbs
 void launch_lbfgs_tick(const DevModel& M, const BatchDev& D, const VarList* vl_dev, int first_stage,
                        int last_stage, int init, int step_mode, hipStream_t s);
 size_t sfx_optstate_size();
-int debug_two_loop(const float* S, const float* Y, int cnt, const float* g, float* d_out);   // lbfgs.hip (host pointers)
+int debug_two_loop(const float* S, const float* Y, int cnt, int hist_cap, const float* g, float* d_out);   // lbfgs.hip (host pointers)
 void launch_fit_rows(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,
                      int first_stage, int last_stage, int max_ticks, hipStream_t s);
 void launch_tick_dense(const DevModel& M, const BatchDev& D, const VarList* vl_dev, const StageW* sw_dev,

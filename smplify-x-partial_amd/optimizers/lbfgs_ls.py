@@ -1,5 +1,5 @@
 """Drop-in handle for smplifyx/optimizers/lbfgs_ls.py's LBFGS (strong-Wolfe).  The algorithm
-itself -- two-loop recursion with history 100, first-step scaling min(1, 1/|g|_1) * lr, bracket
+itself -- two-loop recursion over the last history_size pairs, first-step scaling min(1, 1/|g|_1) * lr, bracket
 and zoom phases of the strong-Wolfe search, all stopping rules -- runs on the GPU in
 csrc/lbfgs.hip (specification: oracle/lbfgs_machine.py).  This object carries the hyper-
 parameters and forwards `.step(closure)` to the engine batch bound to the closure."""
@@ -10,8 +10,8 @@ class LBFGS(object):
                  history_size=100, line_search_fn=None):
         if line_search_fn != "strong_Wolfe":
             raise RuntimeError("only 'strong_Wolfe' is supported")
-        if history_size > 100 or history_size < 1:
-            raise NotImplementedError("history_size must be 1..100 (the device keeps a ring of 100 curvature pairs)")
+        if history_size > 400 or history_size < 1:
+            raise NotImplementedError("history_size must be 1..400 (the device keeps the alphas of the two-loop recursion in LDS)")
         self._params = list(params)
         self.lr, self.max_iter = lr, max_iter
         self.max_eval = max_iter * 5 // 4 if max_eval is None else max_eval

@@ -320,9 +320,84 @@ def test_blocked_two_loop_matches_the_sequential_recursion(count):
     g = np.zeros(W, np.float32); g[:N] = rng.standard_normal(N)
     d = np.zeros(W, np.float32)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    _capi.check(_capi.load().sfx_debug_two_loop(p(S), p(Y), count, p(g), p(d)))
+    _capi.check(_capi.load().sfx_debug_two_loop(p(S), p(Y), count, 0, p(g), p(d)))
     w = slice(max(0, count - 100), count)
     ref = _two_loop_fp64(S[w, :N].astype(np.float64), Y[w, :N].astype(np.float64), g[:N])
     assert np.all(d[N:] == 0)
     err = np.abs(d[:N] - ref).max() / np.abs(ref).max()
     assert err < 2e-5, (count, err)
+
+
+@pytest.mark.parametrize("count,history", [(150, 150), (151, 150), (157, 150), (158, 150), (299, 150), (300, 150), (120, 400), (400, 400),
+                                           (407, 400), (408, 400), (801, 400), (60, 37), (101, 101)])
+def test_blocked_two_loop_with_a_history_size_other_than_100(count, history):
+    """LBFGS(history_size=...) (lbfgs_ls.py:200,271,325 takes any; refused beyond 100 until round 5): a history_size above 100
+    gets a ring of that many slots (api.hip hist_ring) -- window, wrap and mirror rows at every offset against the sequential
+    recursion in fp64 over the LAST history_size pairs; below 100 the window is shorter than the ring's 100 slots."""
+    import ctypes as C
+    from smplifyx_amd import _capi
+    rng = np.random.default_rng(1000 * history + count)
+    N, W = 182, 192
+    Hm = rng.standard_normal((N, N)) / np.sqrt(N); Hm = Hm @ Hm.T + 0.5 * np.eye(N)
+    S = np.zeros((count, W), np.float32); Y = np.zeros((count, W), np.float32)
+    S[:, :N] = rng.standard_normal((count, N)) * 0.1
+    Y[:, :N] = (S[:, :N].astype(np.float64) @ Hm).astype(np.float32)
+    g = np.zeros(W, np.float32); g[:N] = rng.standard_normal(N)
+    d = np.zeros(W, np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib = _capi.load()
+    _capi.check(lib.sfx_debug_two_loop(p(S), p(Y), count, history, p(g), p(d)))
+    w = slice(max(0, count - history), count)
+    ref = _two_loop_fp64(S[w, :N].astype(np.float64), Y[w, :N].astype(np.float64), g[:N])
+    assert np.all(d[N:] == 0)
+    err = np.abs(d[:N] - ref).max() / np.abs(ref).max()
+    # (more pairs, more fp32 dot products in the chain: the bound of the 100-pair test scaled with the window)
+    assert err < 2e-5 * max(1.0, min(count, history) / 100.0), (count, history, err)
+    if count > history and history != 100:      # ... and it is not the 100-pair window's direction
+        ref100 = _two_loop_fp64(S[max(0, count - 100):, :N].astype(np.float64), Y[max(0, count - 100):, :N].astype(np.float64), g[:N])
+        assert np.abs(d[:N] - ref100).max() / np.abs(ref).max() > 50 * err
+    assert lib.sfx_debug_two_loop(p(S), p(Y), count, 401, p(g), p(d)) != 0      # beyond the LDS array of the alphas: refused, loudly
+
+
+def test_first_body_stage_with_history_size_150(synth_model, cfg_body):
+    """The first body stage (several hundred iterations: the history fills up) with LBFGS(history_size=150): identical to the
+    default's trace while both hold the same pairs -- the first 100 iterations --, another trajectory afterwards, and the
+    specification machine run with history 150 on the same HIP closure arrives at the same result."""
+    from oracle.lbfgs_machine import StageMachine
+    cfg, dm, frames = _setup(synth_model, cfg_body)
+    i = 0
+    runs = {}
+    for h in (100, 150):
+        fb = H.engine_batch_from_frames(dm, dict(cfg, lbfgs_history_size=h), frames, [i], lbs_mode="rows", reuse=True)
+        fb.guess_init(cfg["body_tri_idxs"])
+        fb.fit(first_stage=-1, last_stage=-1)
+        P1 = fb.get_params()
+        fb.trace(8192)
+        fb.fit(first_stage=0, last_stage=0)
+        runs[h] = fb.get_trace()[0]
+    d100, d150 = runs[100], runs[150]
+    ls100 = np.flatnonzero(d100[:, 0] == 0)
+    assert len(ls100) > 130, len(ls100)                                        # the stage outlasts both windows
+    k = 0
+    while k < min(len(d100), len(d150)) and np.array_equal(d100[k], d150[k]):
+        k += 1
+    n_ls = int((d100[:k, 0] == 0).sum())
+    # every finished line search pushes at most one pair: the two windows hold the same pairs for at least 100 of them, bit for bit
+    assert n_ls >= 100, n_ls
+    assert k < max(len(d100), len(d150)), "history_size 150 left the trace of the default unchanged"
+    fc = H.engine_batch_from_frames(dm, cfg, frames, [i], lbs_mode="rows", reuse=True)
+    fc.guess_init(cfg["body_tri_idxs"])
+    groups, o = [], 0
+    for kk, n in ORDER:
+        groups.append((o, n, kk is not None)); o += n
+    m = StageMachine(_flat(P1, 0), groups=groups, maxiters=cfg["maxiters"], ftol=cfg["ftol"], gtol=cfg["gtol"], lr=cfg.get("lr", 1.0),
+                     dtype=np.float32, reuse_entry_eval=True, history=150)
+    while not m.done:
+        fc.set_params(regression_pose=frames["reg_pose"][i:i + 1], cam_translation=P1["cam_translation"], **_unflat(m.x_trial))
+        f, gr = fc.closure(0)
+        m.feed(f[0], gr[0])
+    mac = np.array(m.records)
+    k10 = np.flatnonzero(d150[:, 0] == 0)[9] + 1
+    _compare(d150[:k10], mac[:k10], 1e-5, "first body stage, history 150, first ten line searches", whole_stage=False, t_rtol=1e-3)
+    assert abs(d150[-1, 1] - mac[-1, 1]) <= 1e-3 * abs(mac[-1, 1]), (d150[-1], mac[-1])
+    assert abs(d150[-1, 2] - mac[-1, 2]) <= 0.3 * mac[-1, 2], (d150[-1], mac[-1])
