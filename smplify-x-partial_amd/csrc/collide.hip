@@ -722,7 +722,9 @@ void k_pen_g3(PenDev P, const int* __restrict__ want) {
 // ---- one flat work list over all meshes of a call (k_pen_walk2, k_pen_eval): every workgroup forms the exclusive prefix of the
 // meshes' item counts in LDS, a wavefront takes items w, w + W, ... and finds an item's mesh by bisection
 #define PEN_FLAT_MAXB 4096      // meshes per call the flat distribution handles (beyond: one grid row per mesh, as before)
+#ifndef PEN_FLAT_BLOCKS
 #define PEN_FLAT_BLOCKS 2048
+#endif
 template <class CNT>
 __device__ __forceinline__ int pen_prefix(const int B, int* s_pref /* [B + 1] */, int* s_scan /* [256] */, CNT&& count) {
     const int t = threadIdx.x;
