@@ -80,11 +80,15 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
     const int r_lo = min(LD, (slice * 4 + wv) * rw);
     const int r_hi = min(LD, r_lo + rw);
     const int r_mid = min(r_hi, r_lo + ADJ_RW_MIN);      // end of the first 256-chunk of this wavefront's range
-    const float* pa = M.dirs + (size_t)(k0 + m) * LD + 4 * q;
+    // (round 5) the matrix is read from the TILE-major copy the forward GEMM streams ([tile of 16 vertices][k][48], lbs_dense.hip):
+    // element [k][r] sits at (r / 48) * KD_PAD * 48 + k * 48 + r % 48, a 16-r step never leaves a tile (48 = 3 x 16), and the three
+    // steps of a tile use every byte of its [16 k][48] block -- out of the k-major matrix a load instruction touched 16 half-used
+    // lines 126 KB apart.  One 64-MB matrix per round instead of two: the forward's and the adjoint's.  Same values, same order.
+    const float* pa = M.dirs_tiled + (size_t)(k0 + m) * 48 + 4 * q;
     const float* pbc[4];                        // the lane's column of each of the four 16-column MFMA tiles
 #pragma unroll
     for (int i = 0; i < 4; ++i) pbc[i] = D.adj_G + (size_t)s_cols[16 * i + m] * LD + 4 * q;
-    const size_t sa = (size_t)16 * LD;          // next MFMA tile of the matrix: 16 rows further
+    const size_t sa = (size_t)16 * 48;          // next MFMA tile of the matrix: 16 rows further
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -93,9 +97,11 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
     bool split = false;
     float4 a_c[4], b_c[4], a_n[4], b_n[4];
     auto load = [&](float4 (&a)[4], float4 (&b)[4], const int r) {
+        const int tl = r / 48;
+        const float* pt = pa + (size_t)tl * (SFX_KD_PAD * 48) + (r - tl * 48);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            a[i] = *reinterpret_cast<const float4*>(pa + i * sa + r);
+            a[i] = *reinterpret_cast<const float4*>(pt + i * sa);
             if (i < nj) b[i] = *reinterpret_cast<const float4*>(pbc[i] + r);
         }
     };
