@@ -125,6 +125,8 @@ struct PenDev {
     float* wbox;               // [B][n_clus][6] boxes of the clusters of 64 consecutive triangles (k_pen_g1: one DPP reduction per wavefront)
     const unsigned long long* cpm;   // [n_clus] parts present in a cluster, one bit each (static)
     int n_clus;                // (F + 63) / 64
+    int* wl;                   // [B] the columns of this evaluation that carry the term (want != 0), ascending: k_pen_g1's first workgroup
+    int* nw;                   // [1] their number      (-> the rows of the later launches loop over this list: no workgroup for a column nobody wants)
     int* pcnt;                 // [B] pairs the pair tests have accepted (k_pen_g3 -> 0; beyond pf_cap they are counted, not stored)
     int2* pbuf;                // [B][pf_cap] accepted pairs of a frame on the fast path, any order (the partner-list buffer: unused there)
     int pf_cap;                // min(PEN_FP, F * pcap / 2)
@@ -140,7 +142,10 @@ struct PenDev {
 struct PenSel { const int* want; const int* hlist; const int* nheavy; const int* heavy; };
 __device__ __forceinline__ int pen_sel_n(const PenSel& s, const int rows) { return s.hlist ? min(*s.nheavy, rows) : rows; }
 __device__ __forceinline__ int pen_sel_col(const PenSel& s, const int i) { return s.hlist ? s.hlist[i] : i; }
-__device__ __forceinline__ bool pen_sel_on(const PenSel& s, const int b) { return s.hlist ? s.heavy[b] != 0 : (!s.want || s.want[b] != 0); }
+__device__ __forceinline__ bool pen_sel_on(const PenSel& s, const int b) { return s.hlist ? (!s.heavy || s.heavy[b] != 0) : (!s.want || s.want[b] != 0); }
+// the column of a row's FIRST trip, requested together with the list's length (entries beyond the length are stale but in bounds:
+// the list has a slot per column and a launch has at most as many rows) -- one round trip instead of two at every kernel's entry
+__device__ __forceinline__ int pen_sel_first(const PenSel& s, const int row) { return s.hlist ? s.hlist[row] : row; }
 
 // ---------------------------------------------------------------------------------------------
 // The cone field and its derivatives, written out in reverse mode (round 4; rounds 1-3 pushed forward-mode dual numbers with
@@ -292,17 +297,35 @@ __device__ __forceinline__ int pen_bucket(int x, int y, int z) {
 // zero_dverts / zero_G (round 5, with k_pen_frame): the per-frame kernel writes the gradient of the vertices that HAVE one (a few
 // hundred of 10 475 on a body); the other rows of d loss / d vertices and of the adjoint GEMM's operand are zeroed here, by the
 // launch that has eight workgroups per column and nothing else to write but the boxes.
-__global__ __launch_bounds__(PEN_T)
+#ifndef PEN_G1_OCC
+#define PEN_G1_OCC 1
+#endif
+__global__ __launch_bounds__(PEN_T, PEN_G1_OCC)
 void k_pen_g1(PenDev P, const float* __restrict__ verts, const int* __restrict__ want, float* __restrict__ zero_dverts,
-              float* __restrict__ zero_G, int Vpad, int nb) {
+              float* __restrict__ zero_G, int Vpad, int nb, float* __restrict__ loss_out) {
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { P.callno[0] += 1; P.nheavy[0] = 0; P.ovm[0] = 0; }      // (one writer per launch; launches of a handle are ordered)
+    // (round 5) the columns that carry the term, as a list for the launches behind the grid build (P.wl / P.nw): their rows loop
+    // over it, where a grid row per ACTIVE column sent two workgroups in three through a load and out again (76 of 119 columns
+    // want nothing in an average round: ~10 k workgroups per launch of the pair tests)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64 && want) {
+        const int lane = threadIdx.x;
+        int cnt = 0;
+        for (int base = 0; base < nb; base += 64) {
+            const int c = base + lane;
+            const bool w_ = c < nb && want[c] != 0;
+            const unsigned long long m = __ballot(w_);
+            if (w_) P.wl[cnt + __popcll(m & ((1ull << lane) - 1ull))] = c;
+            cnt += __popcll(m);
+        }
+        if (lane == 0) P.nw[0] = cnt;
+    }
     __shared__ float red[PEN_T / 64];
     __shared__ int pbox[64 * 6];               // this workgroup's part boxes (LDS atomics), merged into the frame's afterwards: atomics
                                                // straight to the frame's 12 cache lines serialise in L2 (measured: 0.4-1.5 ms)
     const int t = threadIdx.x;
     int b, w;
     if (!pen_gw_map(nb, b, w)) return;
-    if (want && !want[b]) return;
+    if (want && !want[b]) { if (w == 0 && t == 0 && loss_out) loss_out[b] = 0.f; return; }      // (what the gather's row of such a column wrote)
     if (zero_dverts) {
         float* d = zero_dverts + (size_t)b * P.V * 3;
         for (int i = w * PEN_T + t; i < P.V * 3; i += PEN_GW * PEN_T) d[i] = 0.f;
@@ -973,12 +996,13 @@ __global__ __launch_bounds__(256)
 void k_pen_walk(PenDev P, PenSel sel, int to_pbuf) {
     PEN_WALK_LDS
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int b_first = pen_sel_first(sel, blockIdx.y);
     const int nsel = pen_sel_n(sel, sel.hlist ? 0x7fffffff : (int)gridDim.y);
     if (nsel == 0) return;
     if (t < 64) s_mask[t] = P.skipmask[t];
     __syncthreads();
     for (int si = blockIdx.y; si < nsel; si += gridDim.y) {
-    const int b = pen_sel_col(sel, si);
+    const int b = si == (int)blockIdx.y ? b_first : pen_sel_col(sel, si);
     const int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
     const int s_total = cells[PEN_CELLS];
     if (!pen_sel_on(sel, b) || blockIdx.x * 256 >= s_total) continue;
@@ -1271,10 +1295,14 @@ __device__ __forceinline__ int pen_rewalk(const PenDev& P, const int b, const in
 #define PEN_RANK_HELPERS 8
 #endif
 #define PEN_SHORT 16            // lists up to this length are ranked element-wise, longer ones sorted by a wavefront
-__global__ __launch_bounds__(256)
+#ifndef PEN_RANK_OCC
+#define PEN_RANK_OCC 1
+#endif
+__global__ __launch_bounds__(256, PEN_RANK_OCC)
 void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
     extern __shared__ int s_sort[];             // [4][max(cap_pad, 128)]
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int b_first = pen_sel_first(sel, blockIdx.y);
     const int nsel = pen_sel_n(sel, sel.hlist ? 0x7fffffff : (int)gridDim.y);
     if (nsel == 0) return;
     const int F = P.F;
@@ -1289,7 +1317,7 @@ void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
     //  launch's slow wavefronts spent 50 us on such loads and 12 us on their lists)
     __shared__ int s_u[4];
     for (int si = blockIdx.y; si < nsel; si += gridDim.y) {
-    const int b = pen_sel_col(sel, si);
+    const int b = si == (int)blockIdx.y ? b_first : pen_sel_col(sel, si);
     __syncthreads();
     if (t == 0) { s_u[0] = pen_sel_on(sel, b) ? 1 : 0; s_u[1] = P.ptotal[b]; s_u[2] = P.ovn[b * 2]; }
     __syncthreads();
@@ -1697,9 +1725,10 @@ __device__ __forceinline__ void pen_face_sum(const float* __restrict__ po, const
 }
 __global__ __launch_bounds__(256)
 void k_pen_facesum(PenDev P, PenSel sel) {
+    const int b_first = pen_sel_first(sel, blockIdx.y);
     const int nsel = pen_sel_n(sel, sel.hlist ? 0x7fffffff : (int)gridDim.y);
     for (int si = blockIdx.y; si < nsel; si += gridDim.y) {
-    const int b = pen_sel_col(sel, si);
+    const int b = si == (int)blockIdx.y ? b_first : pen_sel_col(sel, si);
     if (!pen_sel_on(sel, b)) continue;
     const int total = P.ptotal[b];
     const int* pown = P.pown + (size_t)b * P.pair_cap;
@@ -1790,9 +1819,10 @@ __global__ __launch_bounds__(256)
 void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss_out, PenSel sel, PenAdjPrep ap) {
     __shared__ float red[4];
     extern __shared__ unsigned s_hasp[];        // [hasp_words] triangles of this frame that have pairs
+    const int b_first = pen_sel_first(sel, blockIdx.y);
     const int nsel = pen_sel_n(sel, sel.hlist ? 0x7fffffff : (int)gridDim.y);
     for (int si = blockIdx.y; si < nsel; si += gridDim.y) {
-    const int b = pen_sel_col(sel, si);
+    const int b = si == (int)blockIdx.y ? b_first : pen_sel_col(sel, si);
     if (!pen_sel_on(sel, b)) { if (blockIdx.x == 0 && threadIdx.x == 0) loss_out[b] = 0.f; continue; }
     const int v = blockIdx.x * 256 + threadIdx.x;
     const int total = P.ptotal[b];
@@ -2473,10 +2503,23 @@ extern "C" int sfx_debug_pen_form(int32_t form) {
     return prev;
 }
 
+#ifndef PEN_SEL_ROWS
+#define PEN_SEL_ROWS 64            // rows of the launches that loop over the list of wanted columns
+#endif
+#define PEN_MAX_BRANCHES 4
+#ifndef PEN_DEFAULT_BRANCHES
+#define PEN_DEFAULT_BRANCHES 1
+#endif
+#define PEN_BRANCH_MIN_COLS 4       // columns a branch is worth starting for
 struct sfx_pen {
     PenDev P{};
     int Bmax = 0;
     int form = 1;
+    // concurrent branches of an evaluation (sfx_pen_eval_masked): streams, fork / join events, the launch-wide words of each branch
+    int branches = 1;
+    hipStream_t br_stream[PEN_MAX_BRANCHES] = {};
+    hipEvent_t br_fork = nullptr, br_join[PEN_MAX_BRANCHES] = {};
+    int* br_callno[PEN_MAX_BRANCHES] = {}; int* br_ovm[PEN_MAX_BRANCHES] = {}; int* br_nheavy[PEN_MAX_BRANCHES] = {}; int* br_nw[PEN_MAX_BRANCHES] = {};
     std::vector<void*> mem;
     template <typename T> T* up(const std::vector<T>& h) {
         T* d = nullptr;
@@ -2566,14 +2609,28 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
         if (!P.cpm || !P.wbox) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     }
     P.heavy = h->zeros<int>(B); P.hlist = h->zeros<int>(B); P.nheavy = h->zeros<int>(1); P.pcnt = h->zeros<int>(B);
+    P.wl = h->zeros<int>(B); P.nw = h->zeros<int>(1);
     P.pbuf = reinterpret_cast<int2*>(P.partners);         // (the partner lists are unused on the fast path)
     P.pf_cap = (int)std::min<size_t>(PEN_FP, (size_t)F * P.pcap / 2);
     { const char* e = getenv("SFX_PEN_FAST_PAIRS"); if (e && atoi(e) > 0) P.pf_cap = std::min(P.pf_cap, atoi(e)); }      // (measurement switch: columns with more pairs go to the general kernels)
     P.fast_ok = ((unsigned long long)F * (unsigned long long)F < (1ull << 32)) && (2 * ((F + 31) / 32) + (V + 31) / 32 + V <= PEN_GRID_INTS) &&
                 (size_t)2 * PEN_FP <= (size_t)P.pair_cap ? 1 : 0;
-    if (!P.heavy || !P.hlist || !P.nheavy || !P.pcnt) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
+    if (!P.heavy || !P.hlist || !P.nheavy || !P.pcnt || !P.wl || !P.nw) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tcount || !P.pbox || !P.gpart || !P.aabb || !P.entries) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.pavail || !P.ptotal || !P.ovq || !P.ovn || !P.callno || !P.ovm) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
+    {   // branches of an evaluation (sfx_pen_eval_masked); SFX_PEN_BRANCHES=1: the single chain of rounds 1-4 (A/B switch, same bits)
+        const char* e = getenv("SFX_PEN_BRANCHES");
+        h->branches = std::max(1, std::min(PEN_MAX_BRANCHES, e && atoi(e) > 0 ? atoi(e) : PEN_DEFAULT_BRANCHES));
+        bool ok = hipEventCreateWithFlags(&h->br_fork, hipEventDisableTiming) == hipSuccess;
+        h->br_callno[0] = P.callno; h->br_ovm[0] = P.ovm; h->br_nheavy[0] = P.nheavy; h->br_nw[0] = P.nw;
+        for (int i = 1; i < h->branches && ok; ++i) {
+            ok = hipStreamCreateWithFlags(&h->br_stream[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&h->br_join[i], hipEventDisableTiming) == hipSuccess;
+            h->br_callno[i] = h->zeros<int>(2); h->br_ovm[i] = h->zeros<int>(B + 1); h->br_nheavy[i] = h->zeros<int>(1); h->br_nw[i] = h->zeros<int>(1);
+            ok = ok && h->br_callno[i] && h->br_ovm[i] && h->br_nheavy[i] && h->br_nw[i];
+        }
+        if (!ok) { sfx_set_error("cannot create the streams / events of the interpenetration branches"); sfx_pen_destroy(h); return -2; }
+    }
     *out = h;
     return 0;
 }
@@ -2587,16 +2644,32 @@ extern "C" int sfx_pen_set_point2plane(sfx_pen* h, int32_t on) {
 }
 extern "C" void sfx_pen_destroy(sfx_pen* h) {
     if (!h) return;
+    for (int i = 1; i < PEN_MAX_BRANCHES; ++i) { if (h->br_stream[i]) hipStreamDestroy(h->br_stream[i]); if (h->br_join[i]) hipEventDestroy(h->br_join[i]); }
+    if (h->br_fork) hipEventDestroy(h->br_fork);
     for (void* p : h->mem) hipFree(p);
     delete h;
 }
 
-int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
-                        float* loss_dev, float* dverts_dev, const int* want_dev, const PenAdjPrep* prep, int* over_dev, void* stream) {
-    if (!h || !verts_dev || !loss_dev || !dverts_dev) { sfx_set_error("null argument"); return -1; }
-    if (B < 1 || B > h->Bmax) { sfx_set_error("batch %d exceeds the capacity %d given to sfx_pen_create", B, h->Bmax); return -1; }
-    if (!(sigma > 0.f)) { sfx_set_error("df_cone_height must be positive"); return -1; }
-    hipStream_t s = (hipStream_t)stream;
+// The handle's buffers as a branch of an evaluation sees them: every per-column array advanced by c0 columns (so that the branch's
+// column 0 is the call's column c0 and every result lands where the single chain would have put it), the launch-wide words its own.
+static PenDev pen_view(const PenDev& P, const int c0, int* callno, int* ovm, int* nheavy, int* nw) {
+    PenDev Q = P;
+    const size_t c = (size_t)c0, F = (size_t)P.F;
+    Q.aabb += c * F * 6; Q.entries += c * P.ent_cap; Q.cand += c * P.ent_cap; if (Q.tlist) Q.tlist += c * F;
+    Q.tcount += c * 16; Q.pbox += c * 64 * 6; Q.gpart += c * PEN_GW * 8;
+    Q.partners += c * F * P.pcap; Q.pavail += c * F; Q.pcount += c * F; Q.poff += c * F; Q.hasp += c * P.hasp_words;
+    Q.pown += c * P.pair_cap; Q.plist += c * P.pair_cap; Q.pout += c * 10 * P.pair_cap; Q.tgrad += c * F * 9; Q.tloss += c * F;
+    Q.ptotal += c; Q.cells += c * (PEN_CELLS + 1); Q.gridp += c * 4; Q.stats += c * PEN_STATS;
+    Q.wq += c * P.wq_cap; Q.wqn += c; Q.ovq += c * F; Q.ovn += c * 2;
+    Q.heavy += c; Q.hlist += c; if (Q.wbox) Q.wbox += c * P.n_clus * 6; Q.pcnt += c; Q.wl += c;
+    Q.pbuf = reinterpret_cast<int2*>(Q.partners);      // (only the general kernels run in branches: unused)
+    Q.callno = callno; Q.ovm = ovm; Q.nheavy = nheavy; Q.nw = nw;
+    return Q;
+}
+
+// the kernels of one evaluation for the columns [0, B) of the view P0 (the handle's buffers, or a branch's share of them: pen_view)
+static int pen_eval_cols(sfx_pen* h, const PenDev& P0, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
+                         float* loss_dev, float* dverts_dev, const int* want_dev, const PenAdjPrep* prep, int* over_dev, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)k_pen_list, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192) != hipSuccess ||
@@ -2604,24 +2677,22 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
             sfx_set_error("cannot reserve LDS for k_pen_list / k_pen_g3"); return -2; }
         attr_set = true;
     }
-    if ((size_t)(h->P.F + h->P.hasp_words) * sizeof(int) > 160 * 1024 - 8192) { sfx_set_error("mesh of %d faces: k_pen_list stages the counts in LDS (<= 38 k faces)", h->P.F); return -1; }
+    if ((size_t)(P0.F + P0.hasp_words) * sizeof(int) > 160 * 1024 - 8192) { sfx_set_error("mesh of %d faces: k_pen_list stages the counts in LDS (<= 38 k faces)", P0.F); return -1; }
     PenAdjPrep ap{};
     if (prep) ap = *prep;
-    static const bool rewalk_off = [] { const char* e = getenv("SFX_PEN_REWALK_OFF"); return e && atoi(e) != 0; }();      // (A/B measurement switch)
-    h->P.no_rewalk = rewalk_off ? 1 : 0;
     static const bool chunks_off = getenv("SFX_PEN_WALK_CHUNKS_OFF") != nullptr;      // (A/B measurement switch: same pair set either way)
     static const bool flat_off = getenv("SFX_PEN_FLAT_OFF") != nullptr;               // (A/B measurement switch: same numbers either way)
     int cap_pad = 64;
-    while (cap_pad < h->P.pcap) cap_pad <<= 1;
-    const int rank_rows = PEN_RANK_BLOCKS + (pen_rank_tile(h->P.pcap) > 0 && h->P.cap + 64 <= pen_rank_tile(h->P.pcap) ? PEN_RANK_HELPERS : 0);
+    while (cap_pad < P0.pcap) cap_pad <<= 1;
+    const int rank_rows = PEN_RANK_BLOCKS + (pen_rank_tile(P0.pcap) > 0 && P0.cap + 64 <= pen_rank_tile(P0.pcap) ? PEN_RANK_HELPERS : 0);
     const size_t rank_lds = (size_t)4 * std::min(std::max(cap_pad, 128), 2048) * sizeof(int);
-    const size_t list_lds = (size_t)(h->P.F + h->P.hasp_words) * sizeof(int);
-    PenDev Pl = h->P;
+    const size_t list_lds = (size_t)(P0.F + P0.hasp_words) * sizeof(int);
+    PenDev Pl = P0;
     Pl.over = over_dev;         // (per call: the caller's per-mesh "arrival order decided" flags, or NULL)
     const bool fused = h->form != 0 && B <= PEN_FLAT_MAXB && !chunks_off && !flat_off;
     if (fused) {
         static bool frame_attr = false;
-        const size_t narrow_lds = (size_t)(2 * PEN_FP + 2 * h->P.hasp_words + (h->P.V + 31) / 32 + h->P.V) * sizeof(int);
+        const size_t narrow_lds = (size_t)(2 * PEN_FP + 2 * P0.hasp_words + (P0.V + 31) / 32 + P0.V) * sizeof(int);
         if (!frame_attr) {
             if (hipFuncSetAttribute((const void*)k_pen_frame<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PEN_FRAME_LDS) != hipSuccess ||
                 hipFuncSetAttribute((const void*)k_pen_frame<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PEN_FRAME_LDS) != hipSuccess ||
@@ -2631,60 +2702,103 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
             frame_attr = true;
         }
         const PenSel all{want_dev, nullptr, nullptr, nullptr};
-        hipLaunchKernelGGL(k_pen_g1, dim3(PEN_GW, (B + 7) & ~7), dim3(PEN_T), 0, s, h->P, verts_dev, want_dev, dverts_dev, ap.adj_G, ap.Vpad, B);
+        hipLaunchKernelGGL(k_pen_g1, dim3(PEN_GW, (B + 7) & ~7), dim3(PEN_T), 0, s, P0, verts_dev, want_dev, dverts_dev, ap.adj_G, ap.Vpad, B, (float*)nullptr);
         if (h->form == 3) {
             // one workgroup per column behind the boxes (measured and not the default: the pair tests of a column are 70-150 us of ALU
             // work on ONE compute unit, and a round lasts as long as its slowest column)
-            if (h->P.p2p) hipLaunchKernelGGL(k_pen_frame<true>, dim3(B), dim3(PEN_T), PEN_FRAME_LDS, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, 0);
+            if (P0.p2p) hipLaunchKernelGGL(k_pen_frame<true>, dim3(B), dim3(PEN_T), PEN_FRAME_LDS, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, 0);
             else hipLaunchKernelGGL(k_pen_frame<false>, dim3(B), dim3(PEN_T), PEN_FRAME_LDS, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, 0);
         } else {
             // round 5's default: grid build and pair tests over the chip, the pairs into one list per column, one workgroup per column behind them
-            hipLaunchKernelGGL(k_pen_g2, dim3(PEN_GW, (B + 7) & ~7), dim3(PEN_T), 0, s, h->P, want_dev, B);
-            hipLaunchKernelGGL(k_pen_g3, dim3(B), dim3(PEN_T), (size_t)(PEN_GRID_INTS + PEN_CELLS) * sizeof(int), s, h->P, want_dev);
-            hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, h->P, all, 1);
-            hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, B, all, 1);
-            if (h->P.p2p) hipLaunchKernelGGL(k_pen_narrow<true>, dim3(B), dim3(PEN_T), narrow_lds, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, h->form == 2 ? 1 : 0);
+            hipLaunchKernelGGL(k_pen_g2, dim3(PEN_GW, (B + 7) & ~7), dim3(PEN_T), 0, s, P0, want_dev, B);
+            hipLaunchKernelGGL(k_pen_g3, dim3(B), dim3(PEN_T), (size_t)(PEN_GRID_INTS + PEN_CELLS) * sizeof(int), s, P0, want_dev);
+            hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, P0, all, 1);
+            hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, P0, B, all, 1);
+            if (P0.p2p) hipLaunchKernelGGL(k_pen_narrow<true>, dim3(B), dim3(PEN_T), narrow_lds, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, h->form == 2 ? 1 : 0);
             else hipLaunchKernelGGL(k_pen_narrow<false>, dim3(B), dim3(PEN_T), narrow_lds, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, h->form == 2 ? 1 : 0);
         }
         // the general kernels on the columns handed over (usually none: each of these seven launches then ends after one load)
-        const PenSel hv{nullptr, h->P.hlist, h->P.nheavy, h->P.heavy};
+        const PenSel hv{nullptr, P0.hlist, P0.nheavy, P0.heavy};
         const int HY = std::min(B, PEN_HEAVY_ROWS);
-        hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, HY), dim3(256), 0, s, h->P, hv, 0);
-        hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, B, hv, 0);
+        hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, HY), dim3(256), 0, s, P0, hv, 0);
+        hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, P0, B, hv, 0);
         hipLaunchKernelGGL(k_pen_list, dim3(HY), dim3(PEN_T), list_lds, s, Pl, hv);
-        hipLaunchKernelGGL(k_pen_rank, dim3(rank_rows, HY), dim3(256), rank_lds, s, h->P, hv, cap_pad);
-        if (h->P.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, verts_dev, sigma, penalize_outside, B, 1, hv);
-        else hipLaunchKernelGGL(k_pen_eval<false>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, verts_dev, sigma, penalize_outside, B, 1, hv);
-        hipLaunchKernelGGL(k_pen_facesum, dim3(PEN_EVAL_BLOCKS, HY), dim3(256), 0, s, h->P, hv);
-        hipLaunchKernelGGL(k_pen_gather, dim3((std::max(h->P.V, 1) + 255) / 256, HY), dim3(256), (size_t)h->P.hasp_words * sizeof(unsigned), s,
-                           h->P, dverts_dev, loss_dev, hv, ap);
+        hipLaunchKernelGGL(k_pen_rank, dim3(rank_rows, HY), dim3(256), rank_lds, s, P0, hv, cap_pad);
+        if (P0.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, P0, verts_dev, sigma, penalize_outside, B, 1, hv);
+        else hipLaunchKernelGGL(k_pen_eval<false>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, P0, verts_dev, sigma, penalize_outside, B, 1, hv);
+        hipLaunchKernelGGL(k_pen_facesum, dim3(PEN_EVAL_BLOCKS, HY), dim3(256), 0, s, P0, hv);
+        hipLaunchKernelGGL(k_pen_gather, dim3((std::max(P0.V, 1) + 255) / 256, HY), dim3(256), (size_t)P0.hasp_words * sizeof(unsigned), s,
+                           P0, dverts_dev, loss_dev, hv, ap);
     } else {
     const PenSel all{want_dev, nullptr, nullptr, nullptr};
+    // with a mask: the launches behind the grid build take their columns from the list k_pen_g1 makes of the wanted ones (rows loop
+    // over it); SFX_PEN_ROWS_OFF: a grid row per column of the call, as until round 5 (A/B switch, same bits)
+    const bool rows_off = getenv("SFX_PEN_ROWS_OFF") != nullptr;      // (read per call: a batch captures its graphs with the value of its time)
+    const bool listed = want_dev && !rows_off;
+    const PenSel cw = listed ? PenSel{nullptr, P0.wl, P0.nw, nullptr} : all;
+    const int RY = listed ? std::min(B, PEN_SEL_ROWS) : B;
     // grid build (the cross-workgroup accumulators -- part boxes, survivor counts -- are left empty by k_pen_g3 of the previous evaluation)
-    hipLaunchKernelGGL(k_pen_g1, dim3(PEN_GW, (B + 7) & ~7), dim3(PEN_T), 0, s, h->P, verts_dev, want_dev, (float*)nullptr, (float*)nullptr, 0, B);
-    hipLaunchKernelGGL(k_pen_g2, dim3(PEN_GW, (B + 7) & ~7), dim3(PEN_T), 0, s, h->P, want_dev, B);
-    hipLaunchKernelGGL(k_pen_g3, dim3(B), dim3(PEN_T), (size_t)(PEN_GRID_INTS + PEN_CELLS) * sizeof(int), s, h->P, want_dev);
+    hipLaunchKernelGGL(k_pen_g1, dim3(PEN_GW, (B + 7) & ~7), dim3(PEN_T), 0, s, P0, verts_dev, want_dev, (float*)nullptr, (float*)nullptr, 0, B, listed ? loss_dev : (float*)nullptr);
+    hipLaunchKernelGGL(k_pen_g2, dim3(PEN_GW, (B + 7) & ~7), dim3(PEN_T), 0, s, P0, want_dev, B);
+    hipLaunchKernelGGL(k_pen_g3, dim3(B), dim3(PEN_T), (size_t)(PEN_GRID_INTS + PEN_CELLS) * sizeof(int), s, P0, want_dev);
     {
-        PenDev Pw = h->P;
+        PenDev Pw = P0;
         const bool queued = B <= PEN_FLAT_MAXB && !chunks_off;
         if (!queued) Pw.wq_cap = 0;                // every block walks its bucket to the end itself
-        hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, Pw, all, 0);
+        hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, RY), dim3(256), 0, s, Pw, cw, 0);
         if (queued) hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, Pw, B, all, 0);
     }
     hipLaunchKernelGGL(k_pen_list, dim3(B), dim3(PEN_T), list_lds, s, Pl, all);
-    hipLaunchKernelGGL(k_pen_rank, dim3(rank_rows, B), dim3(256), rank_lds, s, h->P, all, cap_pad);
+    hipLaunchKernelGGL(k_pen_rank, dim3(rank_rows, RY), dim3(256), rank_lds, s, P0, cw, cap_pad);
     if (B <= PEN_FLAT_MAXB && !flat_off)
-        { if (h->P.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, verts_dev, sigma, penalize_outside, B, 1, all);
-          else hipLaunchKernelGGL(k_pen_eval<false>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, h->P, verts_dev, sigma, penalize_outside, B, 1, all); }
+        { if (P0.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, P0, verts_dev, sigma, penalize_outside, B, 1, all);
+          else hipLaunchKernelGGL(k_pen_eval<false>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, P0, verts_dev, sigma, penalize_outside, B, 1, all); }
     else
-        { if (h->P.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside, B, 0, all);
-          else hipLaunchKernelGGL(k_pen_eval<false>, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, verts_dev, sigma, penalize_outside, B, 0, all); }
-    hipLaunchKernelGGL(k_pen_facesum, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, h->P, all);
-    hipLaunchKernelGGL(k_pen_gather, dim3((std::max(h->P.V, 1) + 255) / 256, B), dim3(256), (size_t)h->P.hasp_words * sizeof(unsigned), s,
-                       h->P, dverts_dev, loss_dev, all, ap);
+        { if (P0.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, P0, verts_dev, sigma, penalize_outside, B, 0, all);
+          else hipLaunchKernelGGL(k_pen_eval<false>, dim3(PEN_EVAL_BLOCKS, B), dim3(256), 0, s, P0, verts_dev, sigma, penalize_outside, B, 0, all); }
+    hipLaunchKernelGGL(k_pen_facesum, dim3(PEN_EVAL_BLOCKS, RY), dim3(256), 0, s, P0, cw);
+    // (the gather keeps a row per column: 41 workgroups per column leave few to be turned away, and rows that loop cost it its p90 --
+    //  48 -> 64 us where most columns carry the term)
+    hipLaunchKernelGGL(k_pen_gather, dim3((std::max(P0.V, 1) + 255) / 256, B), dim3(256), (size_t)P0.hasp_words * sizeof(unsigned), s,
+                       P0, dverts_dev, loss_dev, all, ap);
     }
     if (hipGetLastError() != hipSuccess) { sfx_set_error("penetration kernels failed to launch"); return -4; }
     return 0;
+}
+
+int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
+                        float* loss_dev, float* dverts_dev, const int* want_dev, const PenAdjPrep* prep, int* over_dev, void* stream) {
+    if (!h || !verts_dev || !loss_dev || !dverts_dev) { sfx_set_error("null argument"); return -1; }
+    if (B < 1 || B > h->Bmax) { sfx_set_error("batch %d exceeds the capacity %d given to sfx_pen_create", B, h->Bmax); return -1; }
+    if (!(sigma > 0.f)) { sfx_set_error("df_cone_height must be positive"); return -1; }
+    hipStream_t s = (hipStream_t)stream;
+    static const bool rewalk_off = [] { const char* e = getenv("SFX_PEN_REWALK_OFF"); return e && atoi(e) != 0; }();      // (A/B measurement switch)
+    h->P.no_rewalk = rewalk_off ? 1 : 0;
+    // Round 5: the columns of a call in `branches` contiguous shares, each share's ten kernels on a stream of its own (fork / join
+    // on events: parallel branches of the captured graph).  Every kernel of the step is a few dependent memory round trips with the
+    // chip mostly idle: two chains side by side hide each other's trips.  A column's numbers do not depend on which
+    // other columns share its launches, so the bits are those of one chain.  The shares work on views of the handle's buffers
+    // (pen_view: every per-column array advanced by the share's first column; the few launch-wide words -- evaluation counter,
+    // the list of meshes with an overflow queue -- exist once per branch).
+    const int nbr = (h->form == 0 && h->branches > 1) ? std::min(h->branches, std::max(1, B / PEN_BRANCH_MIN_COLS)) : 1;
+    if (nbr <= 1) return pen_eval_cols(h, h->P, B, verts_dev, sigma, penalize_outside, loss_dev, dverts_dev, want_dev, prep, over_dev, s);
+    if (hipEventRecord(h->br_fork, s) != hipSuccess) { sfx_set_error("event record failed"); return -4; }
+    int rc = 0;
+    for (int i = 0; i < nbr; ++i) {
+        const int c0 = (int)((long long)B * i / nbr), c1 = (int)((long long)B * (i + 1) / nbr), n = c1 - c0;
+        hipStream_t si = i == 0 ? s : h->br_stream[i];
+        if (i > 0 && hipStreamWaitEvent(si, h->br_fork, 0) != hipSuccess) { sfx_set_error("stream wait failed"); return -4; }
+        const PenDev Pv = pen_view(h->P, c0, h->br_callno[i], h->br_ovm[i], h->br_nheavy[i], h->br_nw[i]);
+        PenAdjPrep ap{};
+        if (prep) { ap = *prep; ap.AT += c0; ap.adj_G += (size_t)c0 * 3 * ap.Vpad; }
+        const size_t V3 = (size_t)h->P.V * 3;
+        const int r = pen_eval_cols(h, Pv, n, verts_dev + c0 * V3, sigma, penalize_outside, loss_dev + c0, dverts_dev + c0 * V3,
+                                    want_dev ? want_dev + c0 : nullptr, prep ? &ap : nullptr, over_dev ? over_dev + c0 : nullptr, si);
+        if (r && !rc) rc = r;
+        if (i > 0 && (hipEventRecord(h->br_join[i], si) != hipSuccess || hipStreamWaitEvent(s, h->br_join[i], 0) != hipSuccess)) {
+            sfx_set_error("join of the interpenetration branches failed"); return -4; }
+    }
+    return rc;
 }
 
 extern "C" int sfx_pen_eval(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,

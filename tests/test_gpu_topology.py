@@ -307,6 +307,19 @@ def test_fit_on_the_real_surface_is_reproducible_and_pool_independent(topo_model
     for k in r0:
         assert np.array_equal(np.asarray(r0[k]), np.asarray(r3[k])), ("form 1", k)
     assert (w3["pairs"], w3["columns"], w3["entries"]) == (w0["pairs"], w0["columns"], w0["entries"]), (w0, w3)
+    # round 5's two ways of launching the same kernels: a grid row per column of the call instead of rows that loop over the list of
+    # columns carrying the term (SFX_PEN_ROWS_OFF), and the columns in two shares on two streams (SFX_PEN_BRANCHES=2; read when
+    # the batch's operator is created) -- a column's numbers depend on neither
+    import os
+    for var, val in (("SFX_PEN_ROWS_OFF", "1"), ("SFX_PEN_BRANCHES", "2")):
+        os.environ[var] = val
+        try:
+            r4, w4 = fit(0)
+        finally:
+            del os.environ[var]
+        for k in r0:
+            assert np.array_equal(np.asarray(r0[k]), np.asarray(r4[k])), (var, k)
+        assert (w4["pairs"], w4["columns"], w4["entries"]) == (w0["pairs"], w0["columns"], w0["entries"]), (var, w0, w4)
     assert {"stage_loss", "stage_evals", "betas", "global_orient", "body_pose", "left_hand_pose"} <= set(r0)
     for k in r0:
         assert np.array_equal(np.asarray(r0[k]), np.asarray(r1[k])), k
