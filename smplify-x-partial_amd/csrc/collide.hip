@@ -59,6 +59,9 @@
                                 // them out took 7-8 ms per evaluation and held up the whole batch (3 % of the launches of a 256-frame fit,
                                 // half of this kernel's total time).  The reference's BVH bounds a query by max_collisions hits instead.
 #ifndef PEN_WALK_BLOCKS
+#ifndef PEN_WALK_FLAT
+#define PEN_WALK_FLAT 512       // workgroups of the flat form of k_pen_walk (a block of 64 grid entries per wavefront)
+#endif
 #define PEN_WALK_BLOCKS 128     // workgroups (of 4 wavefronts) per frame of the pair tests: a frame whose limbs are pushed
                                 // through each other has 100x the candidates of a clean one, and must not hold up the launch
 #endif
@@ -125,6 +128,10 @@ struct PenDev {
     float* wbox;               // [B][n_clus][6] boxes of the clusters of 64 consecutive triangles (k_pen_g1: one DPP reduction per wavefront)
     const unsigned long long* cpm;   // [n_clus] parts present in a cluster, one bit each (static)
     int n_clus;                // (F + 63) / 64
+    int* rb;                   // [B][n_clus] the blocks of 64 consecutive triangles of a column that have partners, ascending (k_pen_list -> k_pen_rank)
+    int* nrb;                  // [B] their number
+    int* lq;                   // [B][F] the triangles of a column with a long list (more than PEN_SHORT partners, or cut), any order
+    int* nlq;                  // [B] their number
     int* wl;                   // [B] the columns of this evaluation that carry the term (want != 0), ascending: k_pen_g1's first workgroup
     int* nw;                   // [1] their number      (-> the rows of the later launches loop over this list: no workgroup for a column nobody wants)
     int* pcnt;                 // [B] pairs the pair tests have accepted (k_pen_g3 -> 0; beyond pf_cap they are counted, not stored)
@@ -993,26 +1000,22 @@ __device__ __forceinline__ void pen_walk_chunk(const PenDev& P, const int b, con
 // chunk 0 of every block; PEN_WALK_BLOCKS workgroups per mesh.  Queues the chunks k >= 1 (P.wq / P.wqn); when the queue is full
 // the block walks them itself, as it did before round 4.
 __global__ __launch_bounds__(256)
-void k_pen_walk(PenDev P, PenSel sel, int to_pbuf) {
+void k_pen_walk(PenDev P, PenSel sel, int to_pbuf, int flatB) {
     PEN_WALK_LDS
+    extern __shared__ int s_wpref[];            // (flat) [flatB + 1] exclusive prefix of the columns' blocks of 64 entries
+    __shared__ int s_wscan[256];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int b_first = pen_sel_first(sel, blockIdx.y);
     const int nsel = pen_sel_n(sel, sel.hlist ? 0x7fffffff : (int)gridDim.y);
-    if (nsel == 0) return;
+    if (nsel == 0 && !flatB) return;
     if (t < 64) s_mask[t] = P.skipmask[t];
     __syncthreads();
-    for (int si = blockIdx.y; si < nsel; si += gridDim.y) {
-    const int b = si == (int)blockIdx.y ? b_first : pen_sel_col(sel, si);
-    const int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
-    const int s_total = cells[PEN_CELLS];
-    if (!pen_sel_on(sel, b) || blockIdx.x * 256 >= s_total) continue;
     PenWalkCtx W;
     W.tA = reinterpret_cast<int4*>(s_tile + wv * PEN_WIN * 8); W.tB = W.tA + PEN_WIN;
     W.queue = s_queue + wv * 256; W.qn = 0; W.s_mask = s_mask;
-    auto flush = [&](PenWalkCtx& W_) { if (to_pbuf) pen_flush_pairs(P, b, W_, lane); else pen_flush_queue(P, b, W_, lane); };
-    // (blocks of 64 entries, NOT whole buckets: a crowded bucket is shared by many wavefronts; the
-    // cell key comparison keeps different cells of one bucket apart)
-    for (int i0 = (blockIdx.x * 4 + wv) * 64; i0 < s_total; i0 += gridDim.x * 256) {
+    // chunk 0 of the block of 64 entries that starts at i0 of column b; its later chunks are queued for k_pen_walk2
+    auto walk_block = [&](const int b, const int i0, const int s_total, const int* cells) {
+        auto flush = [&](PenWalkCtx& W_) { if (to_pbuf) pen_flush_pairs(P, b, W_, lane); else pen_flush_queue(P, b, W_, lane); };
         int hdr[8];
         const PenOwn O = pen_own(P, b, i0, s_total, W, lane, hdr, cells);
         const int bend_max = __builtin_amdgcn_readfirstlane((int)wave_max_dpp((float)O.bend));      // entries < 2^24: exact
@@ -1040,8 +1043,32 @@ void k_pen_walk(PenDev P, PenSel sel, int to_pbuf) {
             }
         }
         __builtin_amdgcn_wave_barrier();
+    };
+    if (flatB > 0) {
+        // (round 5) ONE flat list of the blocks over all columns of the call, a block per wavefront: a body's grid has ~30 blocks of 64
+        // entries, and 128 workgroups per column -- sized for a mesh that has collapsed into itself -- sent 120 of them through two
+        // loads and out again, each holding a wavefront slot
+        const int n_items = pen_prefix(flatB, s_wpref, s_wscan, [&](int b_) {
+            return pen_sel_on(sel, b_) ? (P.cells[(size_t)b_ * (PEN_CELLS + 1) + PEN_CELLS] + 63) >> 6 : 0; });
+        int b_prev = -1;
+        for (int c = blockIdx.x * 4 + wv; c < n_items; c += gridDim.x * 4) {
+            const int b = pen_chunk_mesh(s_wpref, flatB, c);
+            if (b != b_prev) { if (b_prev >= 0) { if (to_pbuf) pen_flush_pairs(P, b_prev, W, lane); else pen_flush_queue(P, b_prev, W, lane); } b_prev = b; }      // (the pair queue belongs to one mesh)
+            const int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
+            walk_block(b, (c - s_wpref[b]) * 64, cells[PEN_CELLS], cells);
+        }
+        if (b_prev >= 0) { if (to_pbuf) pen_flush_pairs(P, b_prev, W, lane); else pen_flush_queue(P, b_prev, W, lane); }
+        return;
     }
-    flush(W);
+    for (int si = blockIdx.y; si < nsel; si += gridDim.y) {
+    const int b = si == (int)blockIdx.y ? b_first : pen_sel_col(sel, si);
+    const int* cells = P.cells + (size_t)b * (PEN_CELLS + 1);
+    const int s_total = cells[PEN_CELLS];
+    if (!pen_sel_on(sel, b) || blockIdx.x * 256 >= s_total) continue;
+    // (blocks of 64 entries, NOT whole buckets: a crowded bucket is shared by many wavefronts; the
+    // cell key comparison keeps different cells of one bucket apart)
+    for (int i0 = (blockIdx.x * 4 + wv) * 64; i0 < s_total; i0 += gridDim.x * 256) walk_block(b, i0, s_total, cells);
+    if (to_pbuf) pen_flush_pairs(P, b, W, lane); else pen_flush_queue(P, b, W, lane);
     }
 }
 
@@ -1079,11 +1106,15 @@ void k_pen_walk2(PenDev P, int B, PenSel sel, int to_pbuf) {
 __device__ __host__ __forceinline__ int pen_rank_tile(const int pcap) { int c = 64; while (c < pcap) c <<= 1; return c > 2048 ? 0 : (c < 128 ? 128 : c); }
 __device__ __forceinline__ bool pen_can_rewalk(const PenDev& P) { const int t = pen_rank_tile(P.pcap); return t > 0 && P.cap + 64 <= t && !P.no_rewalk; }
 
+#ifndef PEN_SHORT
+#define PEN_SHORT 16
+#endif
 __global__ __launch_bounds__(PEN_T)
 void k_pen_list(PenDev P, PenSel sel) {
     extern __shared__ int s_cnt[];             // [F] partner counts of the frame, then [hasp_words] bitmask
     __shared__ float red[PEN_T / 64];
     __shared__ int slice[PEN_T];
+    __shared__ int s_nl;
     const int t = threadIdx.x;
     const int nsel = pen_sel_n(sel, sel.hlist ? 0x7fffffff : (int)gridDim.x);
     for (int si = blockIdx.x; si < nsel; si += gridDim.x) {
@@ -1094,6 +1125,7 @@ void k_pen_list(PenDev P, PenSel sel) {
     if (!pen_sel_on(sel, b) || st[2] != 0) {         // skipped frame / grid overflow: the grid build has zeroed the totals
         for (int w = t; w < P.hasp_words; w += PEN_T) hasp[w] = 0u;
         if (P.over && t == 0) P.over[b] = 0;
+        if (t == 0) { P.nrb[b] = 0; P.nlq[b] = 0; }
         continue;
     }
     const int F = P.F;
@@ -1114,7 +1146,7 @@ void k_pen_list(PenDev P, PenSel sel) {
     // (round 4: every global access of this kernel is coalesced -- the clamped counts are written in the pass that reads the raw
     //  ones, the offsets go to LDS in place and leave in a pass of their own; the per-lane runs of 21 triangles used to write
     //  three arrays at a stride of 84 bytes across the lanes: 63 store instructions of 64 cache lines each, most of the kernel)
-    if (t == 0) { P.ovn[b * 2] = 0; P.ovn[b * 2 + 1] = 0; }
+    if (t == 0) { P.ovn[b * 2] = 0; P.ovn[b * 2 + 1] = 0; s_nl = 0; }
     __syncthreads();
     for (int f = t; f < F; f += PEN_T) {
         const int raw = pc[f];
@@ -1122,9 +1154,31 @@ void k_pen_list(PenDev P, PenSel sel) {
         pav[f] = raw;                        // (uncapped: > pcap tells k_pen_rank that the held list is incomplete)
         pc[f] = min(raw, P.cap);
         if (raw > P.pcap) { P.ovq[(size_t)b * F + atomicAdd(&P.ovn[b * 2], 1)] = f; P.callno[1] = P.callno[0]; }      // (rare; the order of the queue is immaterial)
+        if (min(raw, P.cap) > PEN_SHORT || raw > P.cap) P.lq[(size_t)b * F + atomicAdd(&s_nl, 1)] = f;      // (what k_pen_rank calls a long list: a work item of its own there)
     }
     for (int w = t; w < P.hasp_words; w += PEN_T) s_has[w] = 0u;
     __syncthreads();
+    {   // (round 5) the blocks of 64 consecutive triangles that have partners at all: k_pen_rank's flat work list (a body: ~30 of 327)
+        const int wvl = t >> 6, ln = t & 63;
+        for (int j = wvl; j < P.n_clus; j += PEN_T / 64) {
+            const int f = j * 64 + ln;
+            const unsigned long long m = __ballot(f < F && s_cnt[min(f, F - 1)] > 0);
+            if (ln == 0) slice[j] = m ? 1 : 0;
+        }
+        __syncthreads();
+        if (t < 64) {
+            int cnt = 0;
+            for (int base = 0; base < P.n_clus; base += 64) {
+                const int j = base + t;
+                const bool w_ = j < P.n_clus && slice[j] != 0;
+                const unsigned long long m = __ballot(w_);
+                if (w_) P.rb[(size_t)b * P.n_clus + cnt + __popcll(m & ((1ull << t) - 1ull))] = j;
+                cnt += __popcll(m);
+            }
+            if (t == 0) { P.nrb[b] = cnt; P.nlq[b] = s_nl; }
+        }
+        __syncthreads();
+    }
     {
         const int per = (F + PEN_T - 1) / PEN_T;
         const int f0 = min(F, t * per), f1 = min(F, f0 + per);
@@ -1288,23 +1342,28 @@ __device__ __forceinline__ int pen_rewalk(const PenDev& P, const int b, const in
 }
 
 // ranks every triangle's partner list into the frame's pair list; PEN_RANK_BLOCKS workgroups per frame
+#ifndef PEN_RANK_FLAT
+#define PEN_RANK_FLAT 512       // workgroups of the flat form of k_pen_rank (a block of 64 triangles with pairs per wavefront)
+#endif
 #ifndef PEN_RANK_BLOCKS
 #define PEN_RANK_BLOCKS 64
 #endif
 #ifndef PEN_RANK_HELPERS
 #define PEN_RANK_HELPERS 8
 #endif
+#ifndef PEN_SHORT
 #define PEN_SHORT 16            // lists up to this length are ranked element-wise, longer ones sorted by a wavefront
+#endif
 #ifndef PEN_RANK_OCC
 #define PEN_RANK_OCC 1
 #endif
 __global__ __launch_bounds__(256, PEN_RANK_OCC)
-void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
-    extern __shared__ int s_sort[];             // [4][max(cap_pad, 128)]
+void k_pen_rank(PenDev P, PenSel sel, int cap_pad, int flatB) {
+    extern __shared__ int s_sort[];             // [4][max(cap_pad, 128)], then (flat) [flatB + 1]: exclusive prefix of the columns' blocks with pairs
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int b_first = pen_sel_first(sel, blockIdx.y);
     const int nsel = pen_sel_n(sel, sel.hlist ? 0x7fffffff : (int)gridDim.y);
-    if (nsel == 0) return;
+    if (nsel == 0 && !flatB) return;
     const int F = P.F;
     const int tcap = min(max(cap_pad, 128), 2048);
     int* tile = s_sort + wv * tcap;
@@ -1316,31 +1375,66 @@ void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
     //  handful of cache lines at the same moment queue up behind each other at one L2 channel: measured with -DPEN_RANKT, the
     //  launch's slow wavefronts spent 50 us on such loads and 12 us on their lists)
     __shared__ int s_u[4];
-    for (int si = blockIdx.y; si < nsel; si += gridDim.y) {
-    const int b = si == (int)blockIdx.y ? b_first : pen_sel_col(sel, si);
-    __syncthreads();
-    if (t == 0) { s_u[0] = pen_sel_on(sel, b) ? 1 : 0; s_u[1] = P.ptotal[b]; s_u[2] = P.ovn[b * 2]; }
-    __syncthreads();
-    if (!s_u[0] || s_u[1] == 0) continue;
+    __shared__ int s_scan[256];
+    const bool can_sort = cap_pad <= 2048;
+    // one long list (more than PEN_SHORT partners, or cut): the wavefront ranks the held partners in its LDS tile and keeps the cc lowest
+    auto rank_one = [&](const int* part, int* pown, int* plist, const int ff, const int cc, const int off, const int found, const int (&x)[4]) {
+            const int av = min(found, P.pcap);                         // sort all av held partners, keep the cc lowest
+            const int* mine = part + (size_t)ff * P.pcap;
+            int np = 64;
+            while (np < av) np <<= 1;
+            if (np <= 256 && np <= tcap) {
+                // up to 256 partners (2 x the cfgs' max_collisions: what a list holds while it is collected).  Round 5: ranked, not
+                // sorted -- the list goes to the wavefront's LDS tile once, every lane counts how many of its values are smaller
+                // than each of its own (all lanes read the same word: a broadcast, no dependence between the reads) and stores its
+                // values at their ranks; partner ids are distinct.  The bitonic network it replaces was 28-45 DEPENDENT cross-lane
+                // exchanges per list (~3 us), and a collapsed mesh brings blocks of 64 such lists.
+                const int R = np >> 6;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (r < R) tile[lane + 64 * r] = x[r];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+                int rk[4] = {0, 0, 0, 0};
+                for (int i = 0; i < av; i += 4) {
+                    const int4 v4 = *reinterpret_cast<const int4*>(tile + i);        // (entries beyond av are 0x7fffffff: never smaller)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rk[r] += (int)(v4.x < x[r]) + (int)(v4.y < x[r]) + (int)(v4.z < x[r]) + (int)(v4.w < x[r]);
+                }
+                const int keep = min(cc, P.pair_cap - off);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (r < R && lane + 64 * r < av && rk[r] < keep) { plist[off + rk[r]] = x[r]; pown[off + rk[r]] = ff; }
+                __builtin_amdgcn_wave_barrier();
+                return;
+            }
+
+            for (int q = lane; q < np; q += 64) tile[q] = q < av ? mine[q] : 0x7fffffff;
+            for (int k = 2; k <= np; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+                    for (int i = lane; i < np; i += 64) {
+                        const int ixj = i ^ j;
+                        if (ixj > i) {
+                            const int va = tile[i], vb = tile[ixj];
+                            if ((va > vb) == ((i & k) == 0)) { tile[i] = vb; tile[ixj] = va; }
+                        }
+                    }
+                }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
+            const int keep = min(cc, P.pair_cap - off);
+            for (int q = lane; q < keep; q += 64) { plist[off + q] = tile[q]; pown[off + q] = ff; }
+            __builtin_amdgcn_wave_barrier();
+    };
+    // one block of 64 consecutive triangles of column b: short lists by a lane each, long ones by the wavefront (skip_long: they
+    // are work items of their own)
+    auto rank_block = [&](const int b, const int fw, const bool rewalk_b, const bool skip_long) {
     const int* pc = P.pcount + (size_t)b * F;
     const int* poff = P.poff + (size_t)b * F;
     const int* part = P.partners + (size_t)b * F * P.pcap;
     const int* pav = P.pavail + (size_t)b * F;
     int* pown = P.pown + (size_t)b * P.pair_cap;
     int* plist = P.plist + (size_t)b * P.pair_cap;
-    const bool rewalk_b = pen_can_rewalk(P) && s_u[2] > 0;      // (k_pen_list empties the queue of a mesh it will not have looked at again)
-    const bool can_sort = cap_pad <= 2048;
-    // 64 consecutive triangles at a time per wavefront.  Short lists: their elements are dealt to the
-    // lanes (owner found by bisection of the 64 offsets in LDS), each lane ranks its element within its
-    // list.  Long lists: bitonic sort by the whole wavefront in LDS.
-    // (the last PEN_RANK_HELPERS workgroups of a mesh rank nothing: they start on the queue of overflowed lists at once, next to
-    //  the ranking instead of behind it -- a triangle's second look at the grid takes one wavefront ~25 us)
-    const bool helper = blockIdx.x >= PEN_RANK_BLOCKS;
-    const int nw = PEN_RANK_BLOCKS * 4, gw = blockIdx.x * 4 + wv;
-    // (blocks of 64 triangles dealt round-robin to the frame's wavefronts: crowded triangles are neighbours in the index too,
-    //  a contiguous range per wavefront gave one wavefront all the long lists)
     const int flim = F;
-    for (int fw = helper ? flim : gw * 64; fw < flim; fw += nw * 64) {
+    {
         const int f = fw + lane;
         const bool inr = f < flim;
         const int fs = inr ? f : 0;                    // (unconditional loads from a clamped index: three loads in flight, not three round trips)
@@ -1356,7 +1450,7 @@ void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
 #ifdef PEN_RANKT
         rt_ld += wall_clock64() - rq0;
 #endif
-        if (E == 0) continue;
+        if (E == 0) return;
         __builtin_amdgcn_wave_barrier();
 #ifdef PEN_RANKT
         const long long rs0 = wall_clock64();
@@ -1404,7 +1498,7 @@ void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
 #ifdef PEN_RANKT
         rt_short += wall_clock64() - rs0;
 #endif
-        unsigned long long m = __ballot(can_sort && (c_l > PEN_SHORT || a_l > c_l) && off_l < P.pair_cap);
+        unsigned long long m = skip_long ? 0ull : __ballot(can_sort && (c_l > PEN_SHORT || a_l > c_l) && off_l < P.pair_cap);
         // (round 5: the first 128 partners of the NEXT long list of the block are fetched while this one is sorted -- such lists
         //  come in crowds, 64 of a block's 64 triangles in a collapsed mesh, and a load -> sort -> store chain per list made the
         //  block's wavefront the launch's long pole: ~3 us per list, 2 of them waiting for memory)
@@ -1433,55 +1527,59 @@ void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
             int x[4] = {nx[0], nx[1], nx[2], nx[3]};
             fetch(m);
             if (found > P.pcap && rewalk_b) continue;                  // incomplete list: queued by k_pen_list, taken below
-            const int av = min(found, P.pcap);                         // sort all av held partners, keep the cc lowest
-            const int* mine = part + (size_t)ff * P.pcap;
-            int np = 64;
-            while (np < av) np <<= 1;
-            if (np <= 256 && np <= tcap) {
-                // up to 256 partners (2 x the cfgs' max_collisions: what a list holds while it is collected).  Round 5: ranked, not
-                // sorted -- the list goes to the wavefront's LDS tile once, every lane counts how many of its values are smaller
-                // than each of its own (all lanes read the same word: a broadcast, no dependence between the reads) and stores its
-                // values at their ranks; partner ids are distinct.  The bitonic network it replaces was 28-45 DEPENDENT cross-lane
-                // exchanges per list (~3 us), and a collapsed mesh brings blocks of 64 such lists.
-                const int R = np >> 6;
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (r < R) tile[lane + 64 * r] = x[r];
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
-                int rk[4] = {0, 0, 0, 0};
-                for (int i = 0; i < av; i += 4) {
-                    const int4 v4 = *reinterpret_cast<const int4*>(tile + i);        // (entries beyond av are 0x7fffffff: never smaller)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) rk[r] += (int)(v4.x < x[r]) + (int)(v4.y < x[r]) + (int)(v4.z < x[r]) + (int)(v4.w < x[r]);
-                }
-                const int keep = min(cc, P.pair_cap - off);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (r < R && lane + 64 * r < av && rk[r] < keep) { plist[off + rk[r]] = x[r]; pown[off + rk[r]] = ff; }
-                __builtin_amdgcn_wave_barrier();
-                continue;
-            }
-
-            for (int q = lane; q < np; q += 64) tile[q] = q < av ? mine[q] : 0x7fffffff;
-            for (int k = 2; k <= np; k <<= 1)
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
-                    for (int i = lane; i < np; i += 64) {
-                        const int ixj = i ^ j;
-                        if (ixj > i) {
-                            const int va = tile[i], vb = tile[ixj];
-                            if ((va > vb) == ((i & k) == 0)) { tile[i] = vb; tile[ixj] = va; }
-                        }
-                    }
-                }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier();
-            const int keep = min(cc, P.pair_cap - off);
-            for (int q = lane; q < keep; q += 64) { plist[off + q] = tile[q]; pown[off + q] = ff; }
-            __builtin_amdgcn_wave_barrier();
+            rank_one(part, pown, plist, ff, cc, off, found, x);
         }
 #ifdef PEN_RANKT
         rt_long += wall_clock64() - rl0;
 #endif
     }
+    };
+    if (flatB > 0) {
+    // (round 5) ONE flat list of the blocks that HAVE pairs over all columns of the call (k_pen_list leaves them per column: P.rb /
+    // P.nrb), a block per wavefront: a body's ~400 triangles with partners sit in ~30 of its 327 blocks, and a grid of 64
+    // workgroups per column sent nine wavefronts in ten through three loads and out again, each holding a wavefront slot that
+    // a busy one was waiting for (the step is bound by slots x round trips)
+    int* s_pref = s_sort + 4 * tcap;
+    const int n_items = pen_prefix(flatB, s_pref, s_scan, [&](int b_) { return pen_sel_on(sel, b_) && P.ptotal[b_] > 0 ? P.nrb[b_] + P.nlq[b_] : 0; });
+    const int n_rankers = ((int)gridDim.x - PEN_RANK_HELPERS) * 4;
+    if ((int)blockIdx.x < (int)gridDim.x - PEN_RANK_HELPERS)      // (the last workgroups start on the queues of overflowed lists at once)
+    for (int c = blockIdx.x * 4 + wv; c < n_items; c += n_rankers) {
+        const int b = pen_chunk_mesh(s_pref, flatB, c);
+        const int r = c - s_pref[b], nb_ = P.nrb[b];
+        const bool rewalk_b = pen_can_rewalk(P) && P.ovn[b * 2] > 0;
+        if (r < nb_) { rank_block(b, P.rb[(size_t)b * P.n_clus + r] * 64, rewalk_b, true); continue; }
+        // a long list is an item of its own (k_pen_list: P.lq): a collapsed mesh brings blocks of 64 of them, ~1.5 us each, and the
+        // wavefront that held such a block was the launch's long pole (rank p50 28 us with the blocks dealt flat, p90 98)
+        const int ff = P.lq[(size_t)b * F + (r - nb_)];
+        const int cc = P.pcount[(size_t)b * F + ff], off = P.poff[(size_t)b * F + ff], found = P.pavail[(size_t)b * F + ff];
+        if (off >= P.pair_cap || (found > P.pcap && rewalk_b)) continue;      // (incomplete list: queued by k_pen_list, taken below)
+        const int* part = P.partners + (size_t)b * F * P.pcap;
+        const int* mine_ = part + (size_t)ff * P.pcap;
+        const int av_ = min(found, P.pcap);
+        int x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int v_ = mine_[min(lane + 64 * q, P.pcap - 1)]; x[q] = lane + 64 * q < av_ ? v_ : 0x7fffffff; }
+        rank_one(part, P.pown + (size_t)b * P.pair_cap, P.plist + (size_t)b * P.pair_cap, ff, cc, off, found, x);
+    }
+    } else
+    for (int si = blockIdx.y; si < nsel; si += gridDim.y) {
+    const int b = si == (int)blockIdx.y ? b_first : pen_sel_col(sel, si);
+    __syncthreads();
+    if (t == 0) { s_u[0] = pen_sel_on(sel, b) ? 1 : 0; s_u[1] = P.ptotal[b]; s_u[2] = P.ovn[b * 2]; }
+    __syncthreads();
+    if (!s_u[0] || s_u[1] == 0) continue;
+    const bool rewalk_b = pen_can_rewalk(P) && s_u[2] > 0;      // (k_pen_list empties the queue of a mesh it will not have looked at again)
+    // 64 consecutive triangles at a time per wavefront.  Short lists: their elements are dealt to the
+    // lanes (owner found by bisection of the 64 offsets in LDS), each lane ranks its element within its
+    // list.  Long lists: bitonic sort by the whole wavefront in LDS.
+    // (the last PEN_RANK_HELPERS workgroups of a mesh rank nothing: they start on the queue of overflowed lists at once, next to
+    //  the ranking instead of behind it -- a triangle's second look at the grid takes one wavefront ~25 us)
+    const bool helper = blockIdx.x >= PEN_RANK_BLOCKS;
+    const int nw = PEN_RANK_BLOCKS * 4, gw = blockIdx.x * 4 + wv;
+    // (blocks of 64 triangles dealt round-robin to the frame's wavefronts: crowded triangles are neighbours in the index too,
+    //  a contiguous range per wavefront gave one wavefront all the long lists)
+    const int flim = F;
+    for (int fw = helper ? flim : gw * 64; fw < flim; fw += nw * 64) rank_block(b, fw, rewalk_b, false);
     // Triangles whose list overflowed while it was collected: one shared queue per mesh (k_pen_list), taken one triangle at a time
     // through an atomic cursor by whichever wavefront is free -- first the mesh's own, then those of the other meshes of the call
     // (such triangles come in crowds, in one or two meshes of a call: their own 256 wavefronts would be the launch's long pole).
@@ -1511,7 +1609,7 @@ void k_pen_rank(PenDev P, PenSel sel, int cap_pad) {
     //  wavefront of the launch looked through the counters of ALL the call's meshes: 12 k wavefronts x 119 meshes x 3 loads on the
     //  same few cache lines whenever any mesh had overflowed -- which the collapsed meshes of a fit make the normal case: 54 us of
     //  the slow wavefronts' 110, measured with -DPEN_RANKT)
-    const int nB = min(s_u[3], P.F), b = nB > 0 ? (int)(blockIdx.y % (unsigned)nB) : 0;      // (at most one entry per mesh of the evaluation)
+    const int nB = min(s_u[3], P.F), b = nB > 0 ? (int)((blockIdx.x + blockIdx.y) % (unsigned)nB) : 0;      // (at most one entry per mesh of the evaluation)
     for (int g0 = 0; g0 < nB; g0 += 64) {
       const int bl = g0 + lane;
       const int bq = P.ovm[1 + (bl < nB ? (b + bl < nB ? b + bl : b + bl - nB) : 0)];           // (a rotation of the list: the takers spread over the queues)
@@ -2609,13 +2707,13 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
         if (!P.cpm || !P.wbox) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     }
     P.heavy = h->zeros<int>(B); P.hlist = h->zeros<int>(B); P.nheavy = h->zeros<int>(1); P.pcnt = h->zeros<int>(B);
-    P.wl = h->zeros<int>(B); P.nw = h->zeros<int>(1);
+    P.wl = h->zeros<int>(B); P.nw = h->zeros<int>(1); P.rb = h->zeros<int>((size_t)B * P.n_clus); P.nrb = h->zeros<int>(B); P.lq = h->zeros<int>((size_t)B * F); P.nlq = h->zeros<int>(B);
     P.pbuf = reinterpret_cast<int2*>(P.partners);         // (the partner lists are unused on the fast path)
     P.pf_cap = (int)std::min<size_t>(PEN_FP, (size_t)F * P.pcap / 2);
     { const char* e = getenv("SFX_PEN_FAST_PAIRS"); if (e && atoi(e) > 0) P.pf_cap = std::min(P.pf_cap, atoi(e)); }      // (measurement switch: columns with more pairs go to the general kernels)
     P.fast_ok = ((unsigned long long)F * (unsigned long long)F < (1ull << 32)) && (2 * ((F + 31) / 32) + (V + 31) / 32 + V <= PEN_GRID_INTS) &&
                 (size_t)2 * PEN_FP <= (size_t)P.pair_cap ? 1 : 0;
-    if (!P.heavy || !P.hlist || !P.nheavy || !P.pcnt || !P.wl || !P.nw) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
+    if (!P.heavy || !P.hlist || !P.nheavy || !P.pcnt || !P.wl || !P.nw || !P.rb || !P.nrb || !P.lq || !P.nlq) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tcount || !P.pbox || !P.gpart || !P.aabb || !P.entries) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.pavail || !P.ptotal || !P.ovq || !P.ovn || !P.callno || !P.ovm) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     {   // branches of an evaluation (sfx_pen_eval_masked); SFX_PEN_BRANCHES=1: the single chain of rounds 1-4 (A/B switch, same bits)
@@ -2661,7 +2759,7 @@ static PenDev pen_view(const PenDev& P, const int c0, int* callno, int* ovm, int
     Q.pown += c * P.pair_cap; Q.plist += c * P.pair_cap; Q.pout += c * 10 * P.pair_cap; Q.tgrad += c * F * 9; Q.tloss += c * F;
     Q.ptotal += c; Q.cells += c * (PEN_CELLS + 1); Q.gridp += c * 4; Q.stats += c * PEN_STATS;
     Q.wq += c * P.wq_cap; Q.wqn += c; Q.ovq += c * F; Q.ovn += c * 2;
-    Q.heavy += c; Q.hlist += c; if (Q.wbox) Q.wbox += c * P.n_clus * 6; Q.pcnt += c; Q.wl += c;
+    Q.heavy += c; Q.hlist += c; if (Q.wbox) Q.wbox += c * P.n_clus * 6; Q.pcnt += c; Q.wl += c; Q.rb += c * P.n_clus; Q.nrb += c; Q.lq += c * F; Q.nlq += c;
     Q.pbuf = reinterpret_cast<int2*>(Q.partners);      // (only the general kernels run in branches: unused)
     Q.callno = callno; Q.ovm = ovm; Q.nheavy = nheavy; Q.nw = nw;
     return Q;
@@ -2712,7 +2810,7 @@ static int pen_eval_cols(sfx_pen* h, const PenDev& P0, int32_t B, const float* v
             // round 5's default: grid build and pair tests over the chip, the pairs into one list per column, one workgroup per column behind them
             hipLaunchKernelGGL(k_pen_g2, dim3(PEN_GW, (B + 7) & ~7), dim3(PEN_T), 0, s, P0, want_dev, B);
             hipLaunchKernelGGL(k_pen_g3, dim3(B), dim3(PEN_T), (size_t)(PEN_GRID_INTS + PEN_CELLS) * sizeof(int), s, P0, want_dev);
-            hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, P0, all, 1);
+            hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, B), dim3(256), 0, s, P0, all, 1, 0);
             hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, P0, B, all, 1);
             if (P0.p2p) hipLaunchKernelGGL(k_pen_narrow<true>, dim3(B), dim3(PEN_T), narrow_lds, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, h->form == 2 ? 1 : 0);
             else hipLaunchKernelGGL(k_pen_narrow<false>, dim3(B), dim3(PEN_T), narrow_lds, s, Pl, verts_dev, sigma, penalize_outside, dverts_dev, loss_dev, want_dev, ap, h->form == 2 ? 1 : 0);
@@ -2720,10 +2818,10 @@ static int pen_eval_cols(sfx_pen* h, const PenDev& P0, int32_t B, const float* v
         // the general kernels on the columns handed over (usually none: each of these seven launches then ends after one load)
         const PenSel hv{nullptr, P0.hlist, P0.nheavy, P0.heavy};
         const int HY = std::min(B, PEN_HEAVY_ROWS);
-        hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, HY), dim3(256), 0, s, P0, hv, 0);
+        hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, HY), dim3(256), 0, s, P0, hv, 0, 0);
         hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, P0, B, hv, 0);
         hipLaunchKernelGGL(k_pen_list, dim3(HY), dim3(PEN_T), list_lds, s, Pl, hv);
-        hipLaunchKernelGGL(k_pen_rank, dim3(rank_rows, HY), dim3(256), rank_lds, s, P0, hv, cap_pad);
+        hipLaunchKernelGGL(k_pen_rank, dim3(rank_rows, HY), dim3(256), rank_lds, s, P0, hv, cap_pad, 0);
         if (P0.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, P0, verts_dev, sigma, penalize_outside, B, 1, hv);
         else hipLaunchKernelGGL(k_pen_eval<false>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, P0, verts_dev, sigma, penalize_outside, B, 1, hv);
         hipLaunchKernelGGL(k_pen_facesum, dim3(PEN_EVAL_BLOCKS, HY), dim3(256), 0, s, P0, hv);
@@ -2745,11 +2843,15 @@ static int pen_eval_cols(sfx_pen* h, const PenDev& P0, int32_t B, const float* v
         PenDev Pw = P0;
         const bool queued = B <= PEN_FLAT_MAXB && !chunks_off;
         if (!queued) Pw.wq_cap = 0;                // every block walks its bucket to the end itself
-        hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, RY), dim3(256), 0, s, Pw, cw, 0);
+        if (queued && !flat_off && !rows_off)      // one flat list of the blocks of 64 entries
+            hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_FLAT), dim3(256), (size_t)(B + 1) * sizeof(int), s, Pw, all, 0, B);
+        else hipLaunchKernelGGL(k_pen_walk, dim3(PEN_WALK_BLOCKS, RY), dim3(256), 0, s, Pw, cw, 0, 0);
         if (queued) hipLaunchKernelGGL(k_pen_walk2, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, Pw, B, all, 0);
     }
     hipLaunchKernelGGL(k_pen_list, dim3(B), dim3(PEN_T), list_lds, s, Pl, all);
-    hipLaunchKernelGGL(k_pen_rank, dim3(rank_rows, RY), dim3(256), rank_lds, s, P0, cw, cap_pad);
+    if (B <= PEN_FLAT_MAXB && !flat_off && !rows_off && cap_pad <= 2048)      // one flat list of the blocks that have pairs (k_pen_list: P.rb)
+        hipLaunchKernelGGL(k_pen_rank, dim3(PEN_RANK_FLAT + PEN_RANK_HELPERS), dim3(256), rank_lds + (size_t)(B + 1) * sizeof(int), s, P0, all, cap_pad, B);
+    else hipLaunchKernelGGL(k_pen_rank, dim3(rank_rows, RY), dim3(256), rank_lds, s, P0, cw, cap_pad, 0);
     if (B <= PEN_FLAT_MAXB && !flat_off)
         { if (P0.p2p) hipLaunchKernelGGL(k_pen_eval<true>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, P0, verts_dev, sigma, penalize_outside, B, 1, all);
           else hipLaunchKernelGGL(k_pen_eval<false>, dim3(PEN_FLAT_BLOCKS), dim3(256), (size_t)(B + 1) * sizeof(int), s, P0, verts_dev, sigma, penalize_outside, B, 1, all); }
