@@ -1155,30 +1155,25 @@ void k_pen_list(PenDev P, PenSel sel) {
         pc[f] = min(raw, P.cap);
         if (raw > P.pcap) { P.ovq[(size_t)b * F + atomicAdd(&P.ovn[b * 2], 1)] = f; P.callno[1] = P.callno[0]; }      // (rare; the order of the queue is immaterial)
         if (min(raw, P.cap) > PEN_SHORT || raw > P.cap) P.lq[(size_t)b * F + atomicAdd(&s_nl, 1)] = f;      // (what k_pen_rank calls a long list: a work item of its own there)
+        // (round 5) does this block of 64 consecutive triangles -- the wavefront's lanes of this trip -- have partners at all?
+        // -> k_pen_rank's flat work list (a body: ~30 blocks of 327)
+        const unsigned long long any = __ballot(raw > 0);
+        if ((t & 63) == 0) slice[f >> 6] = any ? 1 : 0;
     }
     for (int w = t; w < P.hasp_words; w += PEN_T) s_has[w] = 0u;
     __syncthreads();
-    {   // (round 5) the blocks of 64 consecutive triangles that have partners at all: k_pen_rank's flat work list (a body: ~30 of 327)
-        const int wvl = t >> 6, ln = t & 63;
-        for (int j = wvl; j < P.n_clus; j += PEN_T / 64) {
-            const int f = j * 64 + ln;
-            const unsigned long long m = __ballot(f < F && s_cnt[min(f, F - 1)] > 0);
-            if (ln == 0) slice[j] = m ? 1 : 0;
+    if (t < 64) {
+        int cnt = 0;
+        for (int base = 0; base < P.n_clus; base += 64) {
+            const int j = base + t;
+            const bool w_ = j < P.n_clus && slice[j] != 0;
+            const unsigned long long m = __ballot(w_);
+            if (w_) P.rb[(size_t)b * P.n_clus + cnt + __popcll(m & ((1ull << t) - 1ull))] = j;
+            cnt += __popcll(m);
         }
-        __syncthreads();
-        if (t < 64) {
-            int cnt = 0;
-            for (int base = 0; base < P.n_clus; base += 64) {
-                const int j = base + t;
-                const bool w_ = j < P.n_clus && slice[j] != 0;
-                const unsigned long long m = __ballot(w_);
-                if (w_) P.rb[(size_t)b * P.n_clus + cnt + __popcll(m & ((1ull << t) - 1ull))] = j;
-                cnt += __popcll(m);
-            }
-            if (t == 0) { P.nrb[b] = cnt; P.nlq[b] = s_nl; }
-        }
-        __syncthreads();
+        if (t == 0) { P.nrb[b] = cnt; P.nlq[b] = s_nl; }
     }
+    __syncthreads();
     {
         const int per = (F + PEN_T - 1) / PEN_T;
         const int f0 = min(F, t * per), f1 = min(F, f0 + per);

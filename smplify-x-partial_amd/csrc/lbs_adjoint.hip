@@ -52,7 +52,7 @@ __device__ __forceinline__ int adj_tile_columns(const int* __restrict__ want, co
     return *s_nw;
 }
 
-struct __align__(16) AdjLDS { float acc[4][64][64]; };      // one 64 x 64 tile per wavefront: first its own first-chunk sums (rw = 512), then the tile it hands on
+template <int KI> struct __align__(16) AdjLDS { float acc[4][16 * KI][64]; };      // one 64 x 64 tile per wavefront: first its own first-chunk sums (rw = 512), then the tile it hands on
 
 // ONE association of the sum over r for every launch shape (a column's result must not depend on how many other columns
 // are active -- the rule every kernel of the fit obeys; until round 4 the r range per wavefront, 512 or 256 by the number of
@@ -60,15 +60,18 @@ struct __align__(16) AdjLDS { float acc[4][64][64]; };      // one 64 x 64 tile 
 // its own from zero; pairs p_j = c_2j + c_2j+1; groups t_g = ((p_4g + p_4g+1) + p_4g+2) + p_4g+3; total = t_0 + t_1 + ...
 //   rw = 512: wavefront w of workgroup g forms p_(4g+w) (two accumulations of 256, then one add), the workgroup writes t_g;
 //   rw = 256: wavefront w of workgroup s forms c_(4s+w), the workgroup writes p_2s and p_2s+1, k_adj_finish forms the t_g.
+// KI: 16-row MFMA tiles of the matrix per wavefront (4: a 64 k x 64 column tile; 2, round 5: 32 k x 64 -- twice the workgroups on the
+// same r ranges, i.e. the same association of every sum, for a launch that is one workgroup per CU and waits for its own loads)
+template <int KI>
 __global__ __launch_bounds__(ADJ_T, 2)
 void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
-    __shared__ AdjLDS S;
+    __shared__ AdjLDS<KI> S;
     __shared__ int s_cols[64], s_nw;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int m = lane & 15, q = lane >> 4;
     // grid: x = r slice (fastest: the slices of one (k tile, frame tile) stream disjoint parts of dirs),
     // y = k tile (8), z = frame tile: the 64 WANTED columns of ranks 64 z .. (results land at those ranks in adj_part)
-    const int slice = blockIdx.x, k0 = blockIdx.y * 64, b0 = blockIdx.z * 64;
+    const int slice = blockIdx.x, k0 = blockIdx.y * 16 * KI, b0 = blockIdx.z * 64;
     const int n_wanted = adj_tile_columns(D.pen_want, D.nact, blockIdx.z, s_cols, &s_nw);
     if (n_wanted <= b0) return;      // no wanted column in this tile
     // (round 5) 16-column MFMA tiles of this frame tile that hold a wanted column at all: the others are neither loaded nor
@@ -89,19 +92,19 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) pbc[i] = D.adj_G + (size_t)s_cols[16 * i + m] * LD + 4 * q;
     const size_t sa = (size_t)16 * 48;          // next MFMA tile of the matrix: 16 rows further
-    f32x4 acc[4][4];
+    f32x4 acc[KI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < KI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bool split = false;
-    float4 a_c[4], b_c[4], a_n[4], b_n[4];
-    auto load = [&](float4 (&a)[4], float4 (&b)[4], const int r) {
+    float4 a_c[KI], b_c[4], a_n[KI], b_n[4];
+    auto load = [&](float4 (&a)[KI], float4 (&b)[4], const int r) {
         const int tl = r / 48;
         const float* pt = pa + (size_t)tl * (SFX_KD_PAD * 48) + (r - tl * 48);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            a[i] = *reinterpret_cast<const float4*>(pt + i * sa);
+            if (i < KI) a[i] = *reinterpret_cast<const float4*>(pt + i * sa);
             if (i < nj) b[i] = *reinterpret_cast<const float4*>(pbc[i] + r);
         }
     };
@@ -112,7 +115,7 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
         if (r == r_mid) {        // (rw = 512) the second chunk starts from zero; the first waits in this wavefront's LDS tile (same lane writes and reads it)
             split = true;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < KI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -124,7 +127,7 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
         for (int j = 0; j < 4; ++j)
             if (j < nj) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < KI; ++i) {
                     acc[i][j] = MFMA(a_c[i].x, b_c[j].x, acc[i][j]);
                     acc[i][j] = MFMA(a_c[i].y, b_c[j].y, acc[i][j]);
                     acc[i][j] = MFMA(a_c[i].z, b_c[j].z, acc[i][j]);
@@ -133,13 +136,13 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
             }
         if (more) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { a_c[i] = a_n[i]; b_c[i] = b_n[i]; }
+            for (int i = 0; i < 4; ++i) { if (i < KI) a_c[i] = a_n[i]; b_c[i] = b_n[i]; }
         }
     }
     const bool wide = rw > ADJ_RW_MIN;
     if (split) {                 // p = c_lo + c_hi  (a range that ends inside its first chunk has no second one: p = that chunk, as c + 0 = c)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < KI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -148,7 +151,7 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
     // accumulator (i, j), register e of lane (m, q) = C[k0 + 16 i + 4 q + e][b0 + 16 j + m]
     if (wide ? wv > 0 : (wv & 1)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < KI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -159,7 +162,7 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
         if (wv == 0) {           // t_g = ((p_0 + p_1) + p_2) + p_3
             float* out = D.adj_part + ((size_t)slice * SFX_KD_PAD + k0) * D.Bpad + b0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < KI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -172,7 +175,7 @@ void k_lbs_dense_adj(DevModel M, BatchDev D, int rw) {
     } else if (!(wv & 1)) {      // wavefronts 0 and 2: p_2s = c_0 + c_1, p_2s+1 = c_2 + c_3
         float* out = D.adj_part + ((size_t)(slice * 2 + (wv >> 1)) * SFX_KD_PAD + k0) * D.Bpad + b0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < KI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -264,7 +267,9 @@ void launch_pen_adjoint(const DevModel& M, const BatchDev& D, hipStream_t s) {
     const int rw = ftiles >= 3 ? 512 : ADJ_RW_MIN;       // 8 k tiles x ftiles x slices workgroups: keep >= 256 of them
     const int ns = (3 * M.Vpad + 4 * rw - 1) / (4 * rw);
     // (d v_posed = T^T g, the GEMM's operand, was written by k_pen_gather: PenAdjPrep)
-    hipLaunchKernelGGL(k_lbs_dense_adj, dim3(ns, SFX_KD_PAD / 64, ftiles), dim3(ADJ_T), 0, s, M, D, rw);
+    static const int ki = [] { const char* e = getenv("SFX_ADJ_KI"); return e && atoi(e) == 4 ? 4 : 2; }();      // (4: the 64-k tile of rounds 3-5, A/B switch; same bits)
+    if (ki == 4) hipLaunchKernelGGL(k_lbs_dense_adj<4>, dim3(ns, SFX_KD_PAD / 64, ftiles), dim3(ADJ_T), 0, s, M, D, rw);
+    else hipLaunchKernelGGL(k_lbs_dense_adj<2>, dim3(ns, SFX_KD_PAD / 32, ftiles), dim3(ADJ_T), 0, s, M, D, rw);
     const int n_red = ftiles * (SFX_KD_PAD / 4);
     hipLaunchKernelGGL(k_adj_finish, dim3(n_red + D.nact * ((SFX_J + 3) / 4)), dim3(256), 0, s, M, D,
                        rw > ADJ_RW_MIN ? ns : 2 * ns, rw > ADJ_RW_MIN ? 0 : 1, n_red);
