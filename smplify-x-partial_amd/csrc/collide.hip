@@ -60,7 +60,7 @@
                                 // half of this kernel's total time).  The reference's BVH bounds a query by max_collisions hits instead.
 #ifndef PEN_WALK_BLOCKS
 #ifndef PEN_WALK_FLAT
-#define PEN_WALK_FLAT 512       // workgroups of the flat form of k_pen_walk (a block of 64 grid entries per wavefront)
+#define PEN_WALK_FLAT 1024      // workgroups of the flat form of k_pen_walk (a block of 64 grid entries per wavefront)
 #endif
 #define PEN_WALK_BLOCKS 128     // workgroups (of 4 wavefronts) per frame of the pair tests: a frame whose limbs are pushed
                                 // through each other has 100x the candidates of a clean one, and must not hold up the launch
