@@ -206,14 +206,20 @@ void k_adj_finish(DevModel M, BatchDev D, int n_part, int pairs, int n_red) {
         const size_t st = (size_t)SFX_KD_PAD * D.Bpad;
         const float* p = D.adj_part + (size_t)k * D.Bpad + c;
         float s = 0.f;
-        if (pairs) {
-            for (int i = 0; i < n_part; i += 4) {
-                const float p0 = p[(size_t)i * st], p1 = i + 1 < n_part ? p[(size_t)(i + 1) * st] : 0.f;
-                const float p2 = i + 2 < n_part ? p[(size_t)(i + 2) * st] : 0.f, p3 = i + 3 < n_part ? p[(size_t)(i + 3) * st] : 0.f;
-                s += ((p0 + p1) + p2) + p3;
+        // (round 5: sixteen partials in flight per trip, from clamped indices with a select behind the loads -- the loop used to wait
+        //  for four loads, add, and ask for the next four: 16 dependent round trips for the 62 partials of the rw = 256 launch.  The
+        //  sums keep their association.)
+        for (int i0 = 0; i0 < n_part; i0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { const float x = p[(size_t)min(i0 + j, n_part - 1) * st]; v[j] = i0 + j < n_part ? x : 0.f; }
+            if (pairs) {
+#pragma unroll
+                for (int j = 0; j < 16; j += 4) if (i0 + j < n_part) s += ((v[j] + v[j + 1]) + v[j + 2]) + v[j + 3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) if (i0 + j < n_part) s += v[j];
             }
-        } else {
-            for (int i = 0; i < n_part; ++i) s += p[(size_t)i * st];
         }
         D.pen_dfeat[(size_t)b * SFX_KD_PAD + k] = s;
         return;
@@ -229,14 +235,25 @@ void k_adj_finish(DevModel M, BatchDev D, int n_part, int pairs, int n_red) {
     // gradient -> weight / v_posed, one round trip each, once per entry: 31 us for ~12 entries per lane); the entries are still
     // added in ascending order, and an entry without gradient is still skipped (0 x inf must not reach the sum)
     const int i1 = M.jv_start[j + 1];
-    for (int i0 = M.jv_start[j] + lane; i0 < i1; i0 += 4 * 64) {
+    // (round 5: the ids and weights of the NEXT trip are requested before this trip's gathers are consumed -- a trip was two
+    //  dependent round trips, list entry -> gradient / position, and a torso joint's list is a dozen trips.  Same order of the sums.)
+    int vn[4]; float wn[4];
+    auto heads = [&](const int i0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = max(min(i0 + u * 64, i1 - 1), 0); vn[u] = M.jv_vid[i]; wn[u] = M.jv_w[i]; }
+    };
+    int i0 = M.jv_start[j] + lane;
+    if (i0 < i1) heads(i0);
+    for (; i0 < i1; i0 += 4 * 64) {
         int vv[4]; float ww[4], gg[4][3], pp[4][3];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * 64, i1 - 1); vv[u] = M.jv_vid[i]; ww[u] = M.jv_w[i]; }
+        for (int u = 0; u < 4; ++u) { vv[u] = vn[u]; ww[u] = wn[u]; }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int e = 0; e < 3; ++e) { gg[u][e] = g[vv[u] * 3 + e]; pp[u][e] = vp[vv[u] * 3 + e]; }
+        heads(i0 + 4 * 64);                    // (unconditional, from clamped indices: a branch here would put a full wait in front of it)
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (i0 + u * 64 >= i1 || (gg[u][0] == 0.f && gg[u][1] == 0.f && gg[u][2] == 0.f)) continue;
