@@ -1915,8 +1915,19 @@ __device__ __forceinline__ void pen_vertex_out(const PenDev& P, const int b, con
 // wavefronts must arrive -- the callers make the call wave-uniform)
 __device__ __forceinline__ float pen_frame_loss_partial(const PenDev& P, const int b, const int total, const unsigned* s_hasp, const int t256) {
     float s = 0.f;
-    if (total > 0) for (int f = t256; f < P.F; f += 256)
-        if ((s_hasp[f >> 5] >> (f & 31)) & 1u) s += P.tloss[(size_t)b * P.F + f];
+    // (round 5: eight unconditional loads per trip, the bit decides what is added -- a load under `if (bit)` in a loop of 82 trips was a
+    //  dependent round trip for every triangle with pairs a lane met; same order of the sum)
+    if (total > 0) for (int f0 = t256; f0 < P.F; f0 += 256 * 8) {
+        float v[8]; bool on[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {               // (a lane without a pair reads the column's first word: one line for all of them)
+            const int f = f0 + u * 256;
+            on[u] = f < P.F && ((s_hasp[min(f, P.F - 1) >> 5] >> (f & 31)) & 1u);
+            v[u] = P.tloss[(size_t)b * P.F + (on[u] ? f : 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (on[u]) s += v[u];
+    }
     return wave_sum_dpp(s);
 }
 
@@ -1935,7 +1946,7 @@ void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss
     for (int w = threadIdx.x; w < P.hasp_words; w += 256) s_hasp[w] = P.hasp[(size_t)b * P.hasp_words + w];
     __syncthreads();
     if (v < P.V) pen_vertex_out(P, b, v, total, s_hasp, dverts, ap);
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == gridDim.x - 1) {          // (the row's last workgroup: it has the fewest vertices)
         const float s = pen_frame_loss_partial(P, b, total, s_hasp, threadIdx.x);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         __syncthreads();
