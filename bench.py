@@ -655,6 +655,13 @@ def main():
     # --workload pen: the SMPL-X topology, part table and ExPose body the reference tree ships (tests/golden/smplx_topology.npz,
     # synthetic.make_topology_model) -- the mesh fitting.py:437-455 evaluates; --mesh tubes = rounds 2-4's surface-like stand-in
     topo = pen and args.mesh == "topology"
+    if topo and not synthetic.topology_available():
+        # the fixture is a local build product (tools/make_topology.py; SMPL-X licence: not committed): say so, use the tubes
+        if rank == 0:
+            print("bench: tests/golden/smplx_topology.npz is not there (python tools/make_topology.py builds it from the "
+                  "reference tree) -- falling back to --mesh tubes", file=sys.stderr, flush=True)
+        topo = False
+        args.mesh = "tubes"
     model = synthetic.make_topology_model(0) if topo else synthetic.make_synthetic_model(0, surface=pen)
     jm = U.smpl_to_annotation("smplx", use_hands=cfg["use_hands"], use_face=cfg["use_face"],
                               use_face_contour=cfg["use_face_contour"], format=cfg["format"])

@@ -113,6 +113,62 @@ def candidate_pairs(verts, faces, segm=None, parents=None, ign_part_pairs=None, 
     return res[np.lexsort((res[:, 1], res[:, 0]))]
 
 
+def candidate_pairs_sweep(verts, faces, segm=None, parents=None, ign_part_pairs=None, block=2_000_000):
+    """The pairs of candidate_pairs (same array, tested), an order of magnitude faster on a body mesh: sort the boxes by their
+    low corner along the mesh's longest axis; triangle i (sorted) can only overlap the triangles after it whose low corner does
+    not exceed i's high corner -- a contiguous run found by one searchsorted --; the runs are expanded into (i, j) index arrays
+    in blocks and put through the remaining tests at once.  Used where the term is evaluated hundreds of times (the reference-
+    driven fits of tools/make_goldens.py e2e_pen_set); candidate_pairs stays the plain statement."""
+    verts = np.asarray(verts, np.float64)
+    faces = np.asarray(faces, np.int64)
+    tri = verts[faces]
+    lo, hi = tri.min(1), tri.max(1)
+    F = faces.shape[0]
+    ax = int(np.argmax(hi.max(0) - lo.min(0)))
+    order = np.argsort(lo[:, ax], kind="stable")
+    lo_s, hi_s, f_s = lo[order], hi[order], faces[order]
+    end = np.searchsorted(lo_s[:, ax], hi_s[:, ax], side="right")            # columns [i + 1, end_i)
+    cnt = np.maximum(end - np.arange(F) - 1, 0)
+    ign = parse_ign_part_pairs(ign_part_pairs)
+    if segm is not None:
+        sg, pr = np.asarray(segm, np.int64)[order], np.asarray(parents, np.int64)[order]
+        npart = int(max(sg.max(), pr.max())) + 1
+        bad = np.zeros((npart, npart), bool)
+        for a_, b_ in ign:
+            if a_ < npart and b_ < npart:
+                bad[a_, b_] = bad[b_, a_] = True
+    oth = [a for a in range(3) if a != ax]
+    out = []
+    s = 0
+    csum = np.concatenate([[0], np.cumsum(cnt)])
+    while s < F:
+        e = int(np.searchsorted(csum, csum[s] + block, side="right")) - 1
+        e = max(e, s + 1)
+        e = min(e, F)
+        n = cnt[s:e]
+        tot = int(n.sum())
+        if tot:
+            ii = np.repeat(np.arange(s, e), n)
+            jj = np.arange(tot) - np.repeat(csum[s:e] - csum[s], n) + ii + 1
+            keep = np.ones(tot, bool)
+            for a in oth:
+                keep &= (lo_s[ii, a] <= hi_s[jj, a]) & (lo_s[jj, a] <= hi_s[ii, a])
+            ii, jj = ii[keep], jj[keep]
+            if ii.size:
+                share = (f_s[ii][:, :, None] == f_s[jj][:, None, :]).any(axis=(1, 2))
+                k2 = ~share
+                if segm is not None:
+                    sa, sb, pa, pb = sg[ii], sg[jj], pr[ii], pr[jj]
+                    k2 &= ~((sa == sb) | (sa == pb) | (sb == pa)) & ~bad[sa, sb]
+                a_, b_ = order[ii[k2]], order[jj[k2]]
+                out.append(np.stack([np.minimum(a_, b_), np.maximum(a_, b_)], 1))
+        s = e
+    if not out:
+        return np.zeros((0, 2), np.int64)
+    res = np.concatenate(out, 0)
+    return res[np.lexsort((res[:, 1], res[:, 0]))]
+
+
 def _cone_geometry(tri):
     """tri [P,3,3] -> circumcentre o [P,3], radius r [P], unit normal n [P,3]."""
     p0, a, b = tri[:, 0], tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]

@@ -240,18 +240,35 @@ def make_synthetic_parts(model):
 TOPOLOGY_FILE = "smplx_topology.npz"
 
 
-def load_topology(path=None):
-    """The arrays of tests/golden/smplx_topology.npz (tools/make_goldens.py smplx_topology: the SMPL-X face topology of
-    the reference's demo .ply files, `segm` / `parents` of smplifyx/smplx_parts_segm.pkl, ExPose's posed body of demo
-    frame 02) as a dict of int64 / float64 arrays.  path: the .npz, a directory holding it, or None = this repository's
-    fixture (SFX_SMPLX_TOPOLOGY overrides)."""
+def _topology_path(path=None):
     import os
     if path is None:
         path = os.environ.get("SFX_SMPLX_TOPOLOGY") or os.path.join(
             os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
     if os.path.isdir(path):
         path = os.path.join(path, TOPOLOGY_FILE)
-    g = np.load(path)
+    return path
+
+
+def topology_available(path=None):
+    """Is the SMPL-X topology fixture there?  It is built locally from the reference tree's data files
+    (tools/make_topology.py, run by __graft_entry__.build()) and never committed (MPG non-commercial licence)."""
+    import os
+    return os.path.isfile(_topology_path(path))
+
+
+def load_topology(path=None):
+    """The arrays of tests/golden/smplx_topology.npz (tools/make_topology.py: the SMPL-X face topology of the reference's
+    demo .ply files, `segm` / `parents` of smplifyx/smplx_parts_segm.pkl, ExPose's posed body of demo frame 02) as a dict
+    of int64 / float64 arrays.  path: the .npz, a directory holding it, or None = this working tree's copy
+    (SFX_SMPLX_TOPOLOGY overrides).  The file is a LOCAL build product, not part of the repository's history."""
+    path = _topology_path(path)
+    try:
+        g = np.load(path)
+    except FileNotFoundError:
+        raise FileNotFoundError("%s is not there: it is built from the reference tree by `python tools/make_topology.py` "
+                                "(or __graft_entry__.build()) and is not committed (SMPL-X licence); without it use the "
+                                "synthetic tube mesh (make_synthetic_model(surface=True), bench.py --mesh tubes)" % path)
     return dict(faces=g["faces"].astype(np.int64), segm=g["segm"].astype(np.int64), parents=g["parents"].astype(np.int64),
                 vertices=g["vertices"].astype(np.float64), joints=g["joints"].astype(np.float64))
 

@@ -142,8 +142,22 @@ def check_closure(label, stage, loss, lo, grad, go, loss_tol=CLOSURE_LOSS_TOL, g
     return le, ge
 
 
+TERM_LOG = {}
+
+
+def check_bound(label, what, err, bound):
+    """Record and assert one relative error of the interpenetration term (or any other quantity outside check_closure's
+    loss / gradient pair): the session summary prints the observed maximum next to the bound that protects it."""
+    e = TERM_LOG.setdefault((label, what), [0.0, 0, bound])
+    e[0] = max(e[0], float(err)); e[1] += 1
+    assert err <= bound, (label, what, float(err), bound)
+    return err
+
+
 def parity_log_lines():
     out = []
+    for (label, what), (err, n, bound) in sorted(TERM_LOG.items()):
+        out.append("term parity    %-28s %-34s rel err max %.2e (bound %.0e)  [%d checks]" % (label, what, err, bound, n))
     for (label, stage), (le, ge, n, lt, gt) in sorted(PARITY_LOG.items()):
         out.append("closure parity %-28s stage %2d: loss rel err max %.2e (bound %.0e)  gradient rel err max %.2e (bound %.0e)  [%d frames]"
                    % (label, stage, le, lt, ge, gt, n))

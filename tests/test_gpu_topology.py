@@ -1,6 +1,7 @@
 """The interpenetration term on the mesh the reference evaluates it on (fitting.py:437-455, fit_single_frame.py:300-328): the real
 SMPL-X face topology, the real per-face part table (smplifyx/smplx_parts_segm.pkl) and a real body surface (ExPose's result on
-demo frame 02) -- tests/golden/smplx_topology.npz, smplifyx_amd.synthetic.make_topology_model -- with
+demo frame 02) -- tests/golden/smplx_topology.npz (built locally by tools/make_topology.py, not committed),
+smplifyx_amd.synthetic.make_topology_model -- with
 cfg_files/fit_smplx_combined_halpe.yaml VERBATIM: hands + face (K = 136), max_collisions 128, df_cone_height 1e-4, its
 ign_part_pairs.  HIP through the C ABI against oracle/penetration.py: the pair set BIT-EXACT, loss and vertex gradient at the
 bounds of the stand-alone operator tests (tests/test_gpu_penetration.py), the closure's total inside the fitting loop."""
@@ -12,7 +13,10 @@ import helpers as H
 from oracle import penetration as OP
 from smplifyx_amd import engine, synthetic
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not synthetic.topology_available(),
+                                 reason="tests/golden/smplx_topology.npz is a local build product (tools/make_topology.py, "
+                                        "SMPL-X licence: not committed) and is not there")]
 
 
 @pytest.fixture(scope="module")
@@ -26,6 +30,35 @@ def cfg_halpe():
     assert cfg["use_hands"] and cfg["use_face"] and cfg["max_collisions"] == 128 and cfg["df_cone_height"] == 1e-4
     assert cfg["coll_loss_weights"] == [0.0, 0.1, 1.0] and len(cfg["ign_part_pairs"]) == 6
     return cfg
+
+
+# Bounds of the interpenetration term at the cfg's values (sigma 1e-4, real surface), ~10 x the maxima observed on MI355X (round 6;
+# the session summary prints the observed maxima: tests/helpers.check_bound)
+TERM_LOSS_TOL = 2e-4
+TERM_VGRAD_TOL = 3e-3
+TERM_PGRAD_TOL = 3e-3
+TERM_INTOTAL_TOL = 5e-3
+
+
+def _oracle_jt(model, cfg, frames, i, params, gv, dtype=torch.float64):
+    """J^T gv: the gradient, in the reference's variable order, of  sum(vertices(theta) * gv)  at frame i's `params` through
+    the oracle's forward (fp64 autograd) -- the skinning adjoint applied to a given vertex gradient gv [V, 3]."""
+    ff = H.oracle_frame_fit(model, cfg, frames, i, dtype=dtype)
+    bm = ff.bm
+    with torch.no_grad():
+        for k, v in params.items():
+            if k in ("est_tz", "cam_translation"):
+                continue
+            if k == "pose_embedding":
+                ff.pose_embedding.copy_(torch.tensor(v[i:i + 1], dtype=dtype))
+            else:
+                getattr(bm, k).copy_(torch.tensor(v[i:i + 1], dtype=dtype))
+    ps = [p for p in bm.parameters() if p.requires_grad] + [ff.pose_embedding]
+    for p in ps:
+        p.grad = None
+    out = bm(return_verts=True, body_pose=ff._body_pose(), return_full_pose=True)
+    (out.vertices[0] * torch.tensor(np.asarray(gv), dtype=dtype)).sum().backward()
+    return torch.cat([(p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), dtype=dtype)) for p in ps]).numpy()
 
 
 def _unordered(op):
@@ -75,8 +108,8 @@ def test_operator_on_the_real_surface(topo_model, cfg_halpe):
         un, both = _unordered(op)
         assert both and np.array_equal(un, pairs), (b, len(un), len(pairs))           # the pair SET, bit for bit
         assert np.bincount(pairs.reshape(-1)).max() < cfg_halpe["max_collisions"]     # the cap never binds on a body
-        assert abs(loss[b] - lo) <= 2e-4 * abs(lo) + 1e-9, (b, loss[b], lo)
-        assert np.linalg.norm(dv[b] - go) <= 3e-3 * np.linalg.norm(go) + 1e-9, (b, np.linalg.norm(dv[b] - go), np.linalg.norm(go))
+        H.check_bound("topology-operator", "loss", abs(loss[b] - lo) / max(abs(lo), 1e-30), 2e-4)
+        H.check_bound("topology-operator", "vertex gradient", np.linalg.norm(dv[b] - go) / max(np.linalg.norm(go), 1e-30), 3e-3)
         n_pairs.append(len(pairs))
     assert n_pairs[0] > 300 and max(n_pairs) > 500, n_pairs      # (the rest pose's 850 pairs minus what the mean hand pose opens)
     # a mesh's result does not depend on its neighbours in the batch
@@ -235,8 +268,15 @@ def test_closure_on_the_real_surface(topo_model, cfg_halpe):
     for i in range(B):
         lo, go = oracle(i, 0, False)
         H.check_closure("topology-halpe-dense", 0, l0[i], lo, g0[i], go)
+    # the same batch with the collision weights zeroed: what the closure is without the term, on the same device arithmetic
+    cfg0 = dict(cfg); cfg0["coll_loss_weights"] = [0.0] * len(cfg["coll_loss_weights"])
+    fb0 = H.engine_batch_from_frames(dm, cfg0, frames, range(B), lbs_mode="dense")
+    fb0.set_frames(frames["keypoints"], T._jw(cfg, frames), T._cmask(cfg, frames), frames["focal"],
+                   np.tile([frames["W"] * 0.5, frames["H"] * 0.5], (B, 1)), 1000.0 / frames["H"], est_tz=est)
+    fb0.set_params(regression_pose=frames["reg_pose"], **{k: v for k, v in P.items() if k != "est_tz"})
     for stage in (1, 2):
         loss, grad = fb.closure(stage)
+        loss0, grad0 = fb0.closure(stage)
         st = fb.penetration_stats()
         assert np.all(st["entry_overflow"] == 0) and np.all(st["dropped"] == 0) and np.all(st["walks_cut"] == 0), st
         vd = fb.debug_read("verts").reshape(B, -1, 3).astype(np.float64)
@@ -251,9 +291,20 @@ def test_closure_on_the_real_surface(topo_model, cfg_halpe):
             vt = torch.tensor(vd[i], dtype=torch.float64, requires_grad=True)
             lo_v = OP.penetration_loss(vt, faces, pairs, cfg["df_cone_height"])
             lo_v.backward()
-            assert abs(pl[i] - float(lo_v)) <= 2e-4 * float(lo_v), (stage, i, pl[i], float(lo_v))
+            H.check_bound("topology-halpe-closure", "term loss (device vertices)", abs(pl[i] - float(lo_v)) / float(lo_v), TERM_LOSS_TOL)
             gv = vt.grad.numpy()
-            assert np.linalg.norm(pg[i] - gv) <= 3e-3 * np.linalg.norm(gv), (stage, i, np.linalg.norm(pg[i] - gv), np.linalg.norm(gv))
+            H.check_bound("topology-halpe-closure", "term vertex gradient", np.linalg.norm(pg[i] - gv) / np.linalg.norm(gv), TERM_VGRAD_TOL)
+            # the term's gradient in PARAMETER space at the cfg's sigma 1e-4: this closure minus the same closure with the
+            # collision weight zeroed, against J^T of the oracle (fp64, at the device's parameters) applied to the oracle's
+            # vertex gradient on the device's own vertices
+            g_term = grad[i].astype(np.float64) - grad0[i].astype(np.float64)
+            g_ref = _oracle_jt(model, cfg, frames, i, P, float(cfg["coll_loss_weights"][stage]) * gv)
+            assert np.linalg.norm(g_ref) > 1e-3 * np.linalg.norm(grad0[i]), (np.linalg.norm(g_ref), np.linalg.norm(grad0[i]))
+            H.check_bound("topology-halpe-closure", "term parameter gradient", np.linalg.norm(g_term - g_ref) / np.linalg.norm(g_ref),
+                          TERM_PGRAD_TOL)
+            H.check_bound("topology-halpe-closure", "term loss in the closure total",
+                          abs((float(loss[i]) - float(loss0[i])) - float(cfg["coll_loss_weights"][stage]) * float(lo_v)) /
+                          (float(cfg["coll_loss_weights"][stage]) * float(lo_v)), TERM_INTOTAL_TOL)
         i = stage - 1
         lo, go = oracle(i, stage, True)
         lo_np, go_np = oracle(i, stage, False)
@@ -261,7 +312,7 @@ def test_closure_on_the_real_surface(topo_model, cfg_halpe):
         assert pen_part > 0, (pen_part, lo)
         assert abs(loss[i] - lo) <= 5e-3 * pen_part + 2e-5 * abs(lo_np), (stage, loss[i], lo, lo_np)
         assert np.all(np.isfinite(grad)) and np.all(grad[i][13:13 + 63] == 0)
-    fb.close(); dm.close()
+    fb0.close(); fb.close(); dm.close()
 
 
 def test_fit_on_the_real_surface_is_reproducible_and_pool_independent(topo_model, cfg_halpe):

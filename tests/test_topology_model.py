@@ -1,5 +1,5 @@
-"""CPU: the SMPL-X topology fixture (tests/golden/smplx_topology.npz, made by tools/make_goldens.py smplx_topology from the
-reference's demo .ply files, smplifyx/smplx_parts_segm.pkl and ExPose's demo result) and the body model
+"""CPU: the SMPL-X topology fixture (tests/golden/smplx_topology.npz, made LOCALLY by tools/make_topology.py -- never committed,
+SMPL-X licence -- from the reference's demo .ply files, smplifyx/smplx_parts_segm.pkl and ExPose's demo result) and the body model
 smplifyx_amd.synthetic.make_topology_model builds on it -- the mesh the interpenetration term (fitting.py:437-455,
 fit_single_frame.py:300-328) is tested and benchmarked on."""
 import numpy as np
@@ -8,6 +8,8 @@ import torch
 
 from oracle import penetration as OP
 from smplifyx_amd import synthetic
+
+pytestmark = pytest.mark.skipif(not synthetic.topology_available(), reason="smplx_topology.npz not built (tools/make_topology.py)")
 
 IGN = ["9,16", "9,17", "6,16", "6,17", "1,2", "12,22"]          # cfg_files/fit_smplx_combined_halpe.yaml: ign_part_pairs
 

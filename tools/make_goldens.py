@@ -2,7 +2,7 @@
 """Generate tests/golden/*.npz by running the REAL reference (imported from
 /root/reference, this container only) on seeded inputs.  The reference Python never
 ships; only these numeric arrays do.  Re-run: `python tools/make_goldens.py [what ...]`
-with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_full_set, e2e_vposer_set, e2e_side, e2e_bench, gmm_unmerged, e2e_bench_raw_delta, smplx_topology}.
+with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_full_set, e2e_vposer_set, e2e_side, e2e_bench, gmm_unmerged, e2e_bench_raw_delta, smplx_topology, e2e_pen_set}.
 
 The LBS itself has no reference implementation here (external `smplx`, absent): wherever a
 body model is needed the reference drives oracle.body_model.SMPLXRef built from
@@ -29,6 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 warnings.filterwarnings("ignore")
 import ref_import  # noqa: E402
 
+PEN_DEFAULT_FRAMES = "0,1,2,3,4,5,6,7"
 GOLD = os.path.join(ROOT, "tests", "golden")
 os.makedirs(GOLD, exist_ok=True)
 ref = ref_import.import_reference()
@@ -735,42 +736,114 @@ def gen_parser():
     _save("parser", **out)
 
 
-def _read_ply_mesh(path):
-    """(vertices [V,3] float64, faces [F,3] int64) of a binary-little-endian .ply with double vertices and uchar/uint
-    face lists (what Open3D wrote into demo/ExPose_results)."""
-    raw = open(path, "rb").read()
-    i = raw.index(b"end_header\n") + len(b"end_header\n")
-    hdr = raw[:i].decode().splitlines()
-    assert "format binary_little_endian 1.0" in hdr and "property double x" in hdr, hdr
-    nv = int([l for l in hdr if l.startswith("element vertex")][0].split()[-1])
-    nf = int([l for l in hdr if l.startswith("element face")][0].split()[-1])
-    v = np.frombuffer(raw, "<f8", nv * 3, i).reshape(nv, 3)
-    f = np.frombuffer(raw, np.dtype([("n", "u1"), ("idx", "<u4", 3)]), nf, i + nv * 24)
-    assert (f["n"] == 3).all()
-    return v.copy(), f["idx"].astype(np.int64)
+PEN_PRIOR_SEED = 1000            # bench.py --workload pen / tools/pen_collapse_probe.py: RandomState(1000 + rank) camera-prior noise
+
+
+def _pen_frame_inputs(i, model, cfg):
+    """Frame i of the `--workload pen` job: keypoints (oracle forward), regression prior, the synthetic "ExPose" camera prior
+    (true translation + 5 cm noise, row i of RandomState(1000).normal(size=(n, 3)) -- the same row for every n > i)."""
+    import helpers as H
+    from smplifyx_amd import synthetic
+    K = len(H.joint_map_for(cfg))
+    frames = synthetic.make_frames(1, H.oracle_joints_fn(model, cfg), K, start=i, focal=5000.0)
+    noise = np.random.RandomState(PEN_PRIOR_SEED).normal(size=(i + 1, 3))[i]
+    cam_prior_t = (frames["cam_t"][0] + 0.05 * noise).astype(np.float32)
+    return frames, cam_prior_t
+
+
+def _pen_task(task):
+    """One REAL-reference fit of frame i of the configs[4] job -- cfg_files/fit_smplx_combined_halpe.yaml verbatim (hands + face,
+    K = 136, regression prior 'combined', camera prior, interpenetration: max_collisions 128, df_cone_height 1e-4,
+    coll_loss_weights [0, 0.1, 1], the cfg's ign_part_pairs) on synthetic.make_topology_model(0) (the real SMPL-X faces and part
+    table) -- in one precision, `term` on or off.  The reference's fit_single_frame runs as it stands (python -O: the two CUDA
+    asserts at fit_single_frame.py:305-308 are stripped): it imports BVH / DistanceFieldPenetrationLoss / FilterFaces
+    (:301-303 -> oracle/mesh_intersection_cpu.py), reads the part table from `part_segm_fn` (:316-324), and SMPLifyLoss.forward
+    evaluates fitting.py:437-455."""
+    i, tag, term = task
+    import helpers as H
+    from smplifyx_amd import synthetic
+    from scipy.spatial.transform import Rotation as Rot
+    dtype = torch.float32 if tag == "f32" else torch.float64
+    model = synthetic.make_topology_model(0)
+    parts = synthetic.topology_parts()
+    cfg = H.load_cfg("fit_smplx_combined_halpe.yaml", use_cuda=False, interpenetration=bool(term))
+    assert cfg["regression_prior"] == "combined" and cfg["use_camera_prior"] and cfg["max_collisions"] == 128
+    frames, cam_prior_t = _pen_frame_inputs(i, model, cfg)
+    K = frames["keypoints"].shape[1]
+    M = ref_import.install_mesh_intersection(np.asarray(model["f"]), (parts["segm"], parts["parents"], cfg["ign_part_pairs"]))
+    made = {}
+    orig_bvh_init = M.BVH.__init__
+
+    def bvh_init(self, *a, **k):
+        orig_bvh_init(self, *a, **k)
+        made["bvh"] = self
+    M.BVH.__init__ = bvh_init
+    segm_fn = tempfile.mktemp(suffix="_parts.pkl")
+    with open(segm_fn, "wb") as fh:
+        pickle.dump({"segm": np.asarray(parts["segm"]), "parents": np.asarray(parts["parents"])}, fh)
+    bp = Rot.from_euler("XYZ", frames["reg_pose"][0].reshape(21, 3).astype(np.float64)).as_matrix().astype(np.float32)
+    go = Rot.from_euler("XYZ", frames["reg_global"][0].astype(np.float64)[None]).as_matrix().astype(np.float32)
+    # regression_prior 'combined' (fit_single_frame.py:209-236): ExPose's joints [:19] + PIXIE's [19:], ExPose's global orientation
+    # and camera (center, transl: :389-396; focal 5000 leaves transl as it is)
+    expose = {"body_pose": bp, "global_orient": go, "center": np.array([frames["W"] * 0.5, frames["H"] * 0.5]),
+              "transl": cam_prior_t.astype(np.float64).copy()}
+    pixie = {"body_pose": bp, "global_pose": go}
+    c = dict(cfg); c["part_segm_fn"] = segm_fn
+    t0 = __import__("time").time()
+    try:
+        bm = H.oracle_model(model, cfg, dtype)
+        res, losses, evals = _run_reference_fit(bm, c, frames["keypoints"], frames["H"], frames["W"], frames["focal"],
+                                                H.base_joint_weights(cfg, K), dtype, pixie=pixie, expose=expose)
+    finally:
+        M.BVH.__init__ = orig_bvh_init
+        os.remove(segm_fn)
+    out = {"losses": losses, "evals": evals}
+    for k in ("camera_translation", "global_orient", "betas", "body_pose", "left_hand_pose", "right_hand_pose",
+              "jaw_pose", "leye_pose", "reye_pose", "expression"):
+        out[k] = np.asarray(res[k], np.float64)
+    out["finite"] = np.array(all(np.isfinite(v).all() for v in out.values()))
+    bvh = made.get("bvh")
+    out["bvh_calls"] = np.array(bvh.calls if bvh is not None else 0)
+    out["bvh_pairs_cut"] = np.array(bvh.pairs_cut if bvh is not None else 0)
+    out["bvh_max_pairs"] = np.array(bvh.max_pairs if bvh is not None else 0)
+    print("e2e pen frame", i, tag, "term" if term else "no term", losses, evals, "bvh calls %s cut %s max unordered pairs %s" %
+          (out["bvh_calls"], out["bvh_pairs_cut"], out["bvh_max_pairs"]), "%.0f s" % (__import__("time").time() - t0), flush=True)
+    return i, tag, term, frames["keypoints"][0], frames["reg_pose"][0], frames["reg_global"][0], cam_prior_t, out
+
+
+def gen_e2e_pen_set():
+    """BASELINE configs[4] through the REAL reference with the interpenetration term ON (see _pen_task): frames
+    SFX_GOLDEN_PEN_FRAMES (comma list of indices of the `--workload pen` sequence; the default holds the frames the device path
+    collapses on -- tools/pen_collapse_probe.py -- next to ordinary ones), fp32 and fp64 with the term, fp32 without it.
+    Run as  python -O tools/make_goldens.py e2e_pen_set  (-O strips the reference's two CUDA asserts).  Minutes per fit."""
+    import multiprocessing as mp
+    if __debug__:
+        raise SystemExit("e2e_pen_set: run under python -O (fit_single_frame.py:305-308 asserts use_cuda and a CUDA device)")
+    idx = [int(x) for x in os.environ.get("SFX_GOLDEN_PEN_FRAMES", PEN_DEFAULT_FRAMES).split(",") if x.strip()]
+    path = os.path.join(GOLD, "e2e_pen_set.npz")
+    out = {}
+    if os.path.exists(path) and os.environ.get("SFX_GOLDEN_PEN_EXTEND") == "1":           # keep the fits already made
+        g = np.load(path)
+        out = {k: g[k] for k in g.files}
+        have = set(int(x) for x in out.get("frames", []))
+        idx = sorted(have | set(idx))
+    else:
+        have = set()
+    tasks = [(i, tag, term) for i in idx if i not in have for tag, term in (("f32", 1), ("f64", 1), ("f32", 0))]
+    with mp.get_context("fork").Pool(int(os.environ.get("SFX_GOLDEN_WORKERS", "6"))) as pool:
+        results = pool.map(_pen_task, tasks, chunksize=1)
+    for i, tag, term, k_, p_, g_, c_, o in results:
+        out["f%d_keypoints" % i], out["f%d_reg_pose" % i], out["f%d_reg_global" % i], out["f%d_cam_prior_t" % i] = k_, p_, g_, c_
+        for key, v in o.items():
+            out["f%d_%s%s_%s" % (i, tag, "" if term else "_noterm", key)] = v
+    out["frames"] = np.array(idx, np.int64)
+    _save("e2e_pen_set", **out)
 
 
 def gen_smplx_topology():
-    """The mesh the reference's interpenetration term is evaluated on (fitting.py:437-455, fit_single_frame.py:300-328),
-    as far as the reference tree holds it: the SMPL-X face topology [20908, 3] (demo/ExPose_results/*/*.ply -- the four
-    files agree), the per-face body part and parent part of smplifyx/smplx_parts_segm.pkl (`segm`, `parents`; loaded at
-    fit_single_frame.py:317-324), and ONE posed body on that topology: ExPose's vertices [10475, 3] and joints [144, 3]
-    of demo frame 02 (numeric arrays only; MPG non-commercial research licence, LICENSE:1-20).
-    smplifyx_amd.synthetic.make_topology_model builds the benchmark's / tests' body model around these arrays."""
-    root = ref_import.REF_ROOT if hasattr(ref_import, "REF_ROOT") else "/root/reference"
-    demo = os.path.join(root, "demo", "ExPose_results")
-    meshes = [_read_ply_mesh(p) for p in sorted(__import__("glob").glob(os.path.join(demo, "*", "*.ply")))]
-    assert len(meshes) == 4 and all(np.array_equal(m[1], meshes[0][1]) for m in meshes)
-    faces = meshes[0][1]
-    with open(os.path.join(root, "smplifyx", "smplx_parts_segm.pkl"), "rb") as fh:
-        parts = pickle.load(fh, encoding="latin1")
-    segm, parents = np.asarray(parts["segm"], np.int64), np.asarray(parts["parents"], np.int64)
-    assert segm.shape == parents.shape == (len(faces),)
-    z = np.load(os.path.join(demo, "02_cropped.jpg", "02_cropped.jpg_params.npz"), allow_pickle=True)
-    verts, joints = np.asarray(z["vertices"], np.float32), np.asarray(z["joints"], np.float32)
-    assert np.abs(meshes[0][0] - (verts.astype(np.float64) + np.asarray(z["transl"]))).max() < 1e-6     # the .ply = vertices + transl
-    _save("smplx_topology", faces=faces.astype(np.int32), segm=segm.astype(np.int8), parents=parents.astype(np.int8),
-          vertices=verts, joints=joints)
+    """tests/golden/smplx_topology.npz: a LOCAL, uncommitted build product (SMPL-X licence) -- tools/make_topology.py."""
+    import make_topology
+    print("wrote", make_topology.build(force=True))
 
 
 if __name__ == "__main__":
@@ -779,4 +852,4 @@ if __name__ == "__main__":
         {"objective": gen_objective, "lbfgs": gen_lbfgs, "euler": gen_euler, "tables": gen_tables,
          "e2e": gen_e2e, "demo": gen_demo, "e2e_vposer": gen_e2e_vposer, "parser": gen_parser, "eval": gen_eval,
          "gmm": gen_gmm, "e2e_full": gen_e2e_full, "e2e_full_set": gen_e2e_full_set, "e2e_vposer_set": gen_e2e_vposer_set, "e2e_side": gen_e2e_side, "e2e_bench": gen_e2e_bench,
-         "gmm_unmerged": gen_gmm_unmerged, "e2e_bench_raw_delta": gen_e2e_bench_raw_delta, "smplx_topology": gen_smplx_topology}[w]()
+         "gmm_unmerged": gen_gmm_unmerged, "e2e_pen_set": gen_e2e_pen_set, "e2e_bench_raw_delta": gen_e2e_bench_raw_delta, "smplx_topology": gen_smplx_topology}[w]()

@@ -22,6 +22,28 @@ def available():
     return os.path.isdir(os.path.join(REF_ROOT, "smplifyx"))
 
 
+def install_mesh_intersection(faces=None, part_filter=None):
+    """Register oracle/mesh_intersection_cpu.py (CPU stand-ins built on oracle/penetration.py) under the three module names of
+    the external CUDA package the reference imports at fit_single_frame.py:301-303, so that the reference's own interpenetration
+    lines (fit_single_frame.py:300-328, fitting.py:437-455) run here.  faces: the model's faces (the stand-in BVH cannot see
+    vertex ids in a triangles tensor); part_filter: (segm, parents, ign_part_pairs) for assumption A1's order of operations."""
+    if REPO_ROOT not in sys.path:
+        sys.path.insert(0, REPO_ROOT)
+    from oracle import mesh_intersection_cpu as M
+    pkg = types.ModuleType("mesh_intersection")
+    for name in ("bvh_search_tree", "loss", "filter_faces"):
+        mod = types.ModuleType("mesh_intersection." + name)
+        setattr(pkg, name, mod)
+        sys.modules["mesh_intersection." + name] = mod
+    pkg.bvh_search_tree.BVH = M.BVH
+    pkg.loss.DistanceFieldPenetrationLoss = M.DistanceFieldPenetrationLoss
+    pkg.filter_faces.FilterFaces = M.FilterFaces
+    sys.modules["mesh_intersection"] = pkg
+    M.BVH.faces = None if faces is None else __import__("numpy").asarray(faces).astype("int64")
+    M.BVH.part_filter = part_filter
+    return M
+
+
 def import_reference():
     """Returns a namespace with the reference modules:
     fitting, camera, prior, utils, lbfgs_ls, optim_factory, fit_single_frame, data_parser."""
