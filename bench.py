@@ -520,6 +520,78 @@ def reference_parity(model, lbs_mode, raw=True):
     return out
 
 
+def load_pen_golden():
+    """tests/golden/e2e_pen_set.npz (tools/make_goldens.py e2e_pen_set): the REAL reference's fits of frames of the `--workload pen`
+    job WITH the interpenetration term -- fitting.py:437-455 as it stands, over CPU stand-ins for the three objects of the absent
+    mesh_intersection package (oracle/mesh_intersection_cpu.py) -- fp32 and fp64, and fp32 without the term.  Returns a dict of
+    stacked arrays in the golden's frame order, or None when the file is absent."""
+    path = os.path.join(ROOT, "tests", "golden", "e2e_pen_set.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    fr = [int(i) for i in g["frames"]]
+    st = lambda fmt: np.stack([g[fmt % i] for i in fr])
+    out = dict(frames=np.array(fr), keypoints=st("f%d_keypoints"), reg_pose=st("f%d_reg_pose"), reg_global=st("f%d_reg_global"),
+               cam_prior_t=st("f%d_cam_prior_t"), r32=st("f%d_f32_losses"), r64=st("f%d_f64_losses"), r32_noterm=st("f%d_f32_noterm_losses"),
+               e32=st("f%d_f32_evals"), e64=st("f%d_f64_evals"), e32_noterm=st("f%d_f32_noterm_evals"),
+               cut32=st("f%d_f32_bvh_pairs_cut"), cut64=st("f%d_f64_bvh_pairs_cut"),
+               maxpairs32=st("f%d_f32_bvh_max_pairs"), maxpairs64=st("f%d_f64_bvh_max_pairs"))
+    return out
+
+
+def fit_pen_golden(dm, cfg, g, lbs_mode="dense", interpenetration=True):
+    """The golden frames of load_pen_golden() through driver.fit_frames the way `--workload pen` fits its frames."""
+    from smplifyx_amd import driver
+    n, K = g["keypoints"].shape[:2]
+    jw = np.ones(K, np.float32)
+    ign = cfg.get("joints_to_ign")
+    if ign is not None and -1 not in ign:
+        jw[ign] = 0.0
+    c = dict(cfg); c["interpenetration"] = bool(interpenetration)
+    return driver.fit_frames(dm, c, g["keypoints"], jw, 600, 800, 5000.0, reg_pose=g["reg_pose"], reg_global=g["reg_global"],
+                             cam_prior_t=g["cam_prior_t"], cam_prior_center=np.tile(np.array([400.0, 300.0], np.float32), (n, 1)),
+                             lbs_mode=lbs_mode, reuse_entry_eval=True)
+
+
+def reference_parity_pen(dm, cfg, lbs_mode):
+    """configs[4]'s half of "mean reprojection-loss delta vs reference": the golden frames of tests/golden/e2e_pen_set.npz fitted
+    here with the term, per stage against the reference's fp32 fits, the reference's own fp64-vs-fp32 difference beside it; the
+    frames on which the reference's BVH stand-in met a folded mesh (cap of max_collisions partners binding) are named."""
+    g = load_pen_golden()
+    if g is None:
+        return None
+    res = fit_pen_golden(dm, cfg, g, lbs_mode)
+    ours, r32, r64 = res["stage_loss"].astype(np.float64), g["r32"], g["r64"]
+    fin = np.isfinite(ours).all(1) & np.isfinite(r32).all(1) & np.isfinite(r64).all(1)
+    out = parity_stats(ours[fin, -1], r32[fin, -1], r64[fin, -1])
+    rel = lambda a, b: (a - b) / np.abs(b)
+    out.update({
+        "source": "tests/golden/e2e_pen_set.npz: the reference's fit_single_frame WITH the interpenetration term (fitting.py:437-455 over "
+                  "CPU stand-ins for mesh_intersection built on oracle/penetration.py), fp32 / fp64, frames %s of the --workload pen sequence"
+                  % g["frames"].tolist(),
+        "lbs_mode": lbs_mode, "frames_fitted": int(len(fin)), "frames_scored": int(fin.sum()),
+        "non_finite_here": g["frames"][~np.isfinite(ours).all(1)].tolist(),
+        "non_finite_reference_f32": g["frames"][~np.isfinite(r32).all(1)].tolist(),
+        "non_finite_reference_f64": g["frames"][~np.isfinite(r64).all(1)].tolist(),
+        "camera_stage_loss_rel_delta_max": float(np.max(np.abs(rel(ours[fin, 0], r32[fin, 0])))),
+        "per_stage_loss_rel_delta_mean": [float(np.mean(np.abs(rel(ours[fin, k], r32[fin, k])))) for k in range(ours.shape[1])],
+        "per_stage_loss_rel_delta_median": [float(np.median(np.abs(rel(ours[fin, k], r32[fin, k])))) for k in range(ours.shape[1])],
+        "per_stage_loss_rel_delta_signed_median": [float(np.median(rel(ours[fin, k], r32[fin, k]))) for k in range(ours.shape[1])],
+        "reference_f32_vs_f64_per_stage_rel_delta_mean": [float(np.mean(np.abs(rel(r64[fin, k], r32[fin, k])))) for k in range(ours.shape[1])],
+        "reference_f32_vs_f64_per_stage_rel_delta_median": [float(np.median(np.abs(rel(r64[fin, k], r32[fin, k])))) for k in range(ours.shape[1])],
+        "closure_evals_mean": float(res["stage_evals"].sum(1).mean()),
+        "reference_closure_evals_f32_mean": float(g["e32"].sum(1).mean()), "reference_closure_evals_f64_mean": float(g["e64"].sum(1).mean()),
+        "reference_frames_with_a_folded_mesh_f32": g["frames"][g["cut32"] > 0].tolist(),
+        "reference_frames_with_a_folded_mesh_f64": g["frames"][g["cut64"] > 0].tolist(),
+        "frames_flagged_order_dependent_here": g["frames"][np.asarray(res.get("pen_order_dependent", np.zeros(len(fin), bool)), bool)].tolist(),
+        "final_loss": [float(x) for x in ours[:, -1]],
+        "reference_final_loss_f32": [float(x) for x in r32[:, -1]], "reference_final_loss_f64": [float(x) for x in r64[:, -1]],
+        "note": "per stage: camera stage, then the 3 body stages of fit_smplx_combined_halpe.yaml (collision weights 0, 0.1, 1).  A "
+                "'folded mesh' = an evaluation in which some triangle met more than max_collisions = 128 partners (a trial step of the "
+                "line search pushed limbs through each other): the reference path reaches such states as well (DESIGN.md)"})
+    return out
+
+
 def closure_parity(model, workload, lbs_mode):
     """Closure-level parity of THIS build, measured in this run: the HIP closure (C ABI) against fp64 autograd of the
     oracle (checker only) at seeded points of 3 synthetic frames, camera stage and every body stage: observed maximum
@@ -602,7 +674,6 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the side measurement on the min-3-camera-keypoints sequence")
     ap.add_argument("--no-parity", action="store_true", help="skip the fit of the reference's golden frames (profiling passes: "
                     "keeps their launches out of the per-kernel averages)")
-    ap.add_argument("--groups", type=int, default=1, help="independent sub-batches per GPU (host threads/streams)")
     ap.add_argument("--mesh", choices=("topology", "tubes"), default="topology",
                     help="--workload pen: the real SMPL-X topology + part table + ExPose body (default), or the synthetic tubes")
     ap.add_argument("--no-configs3", action="store_true", help="N = 1: skip the extra 1 024-frame fit (configs[3]'s per-GPU job) behind the "
@@ -707,7 +778,7 @@ def main():
                                 reg_pose=None if full else fr["reg_pose"],
                                 reg_global=None if full else fr["reg_global"],
                                 cam_prior_t=cam_t_prior, cam_prior_center=cam_c_prior,
-                                lbs_mode=lbs_mode or args.lbs, reuse_entry_eval=True, groups=args.groups,
+                                lbs_mode=lbs_mode or args.lbs, reuse_entry_eval=True,
                                 slots=args.slots if (lbs_mode or args.lbs) == "dense" else 0)
         tg = time.time()
         rec = sdist.pack_records(res, rank * B)
@@ -842,7 +913,7 @@ def main():
                        "keypoints": "SURVEY 8(d) verbatim: projected model joints + 1 px noise, confidences U(0.3, 1), 10 % of the keypoints "
                                     "dropped (the sequence of rounds 1-2a; `value_min3_camera_keypoints` = the same job when the detector "
                                     "keeps at least 3 of the 4 camera-initialisation keypoints, round 2's headline sequence)",
-                       "frames_per_gpu": B, "lbs_mode": args.lbs, "groups_per_gpu": args.groups,
+                       "frames_per_gpu": B, "lbs_mode": args.lbs,
                        "gemm_columns_per_gpu": (args.slots if (0 < args.slots < B and args.lbs == "dense") else B),
                        "parallelism": "frames sharded, dp%d" % world,
                        # N = 1: configs[3]'s per-GPU job (1 024 frames through the default column pool) fitted behind the headline --
@@ -1080,6 +1151,11 @@ def main():
                 out["reference_parity"] = reference_parity(model, args.lbs, raw=True)
                 if side_min3 is not None:
                     out["min3_camera_keypoints"]["reference_parity"] = reference_parity(model, args.lbs, raw=False)
+            except Exception as e:
+                out["reference_parity"] = {"error": repr(e)}
+        if not args.no_parity and pen and topo and world == 1:
+            try:
+                out["reference_parity"] = reference_parity_pen(dm, cfg, args.lbs)
             except Exception as e:
                 out["reference_parity"] = {"error": repr(e)}
         if not args.no_parity and world == 1:

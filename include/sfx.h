@@ -198,11 +198,6 @@ int  sfx_batch_guess_init(sfx_batch* b, const int32_t* pairs /* [n_pairs][2] */,
  * (-1 = camera stage).  Blocks until done.                                                */
 int  sfx_batch_fit(sfx_batch* b, int32_t first_stage, int32_t last_stage, void* stream);
 
-/* sfx_batch_fit for several batches at once (sub-batches of one workload, dense LBS): their MFMA
- * GEMMs run back to back while every batch's latency-bound optimiser tick overlaps the other
- * batches' GEMMs on its own stream.  Blocks until all are done; results equal sfx_batch_fit's. */
-int  sfx_fit_multi(sfx_batch** batches, int32_t n, int32_t first_stage, int32_t last_stage);
-
 /* ONE optimizer.step(closure) of LBFGS('lbfgsls') for every frame (lbfgs_ls.py:256-445), for
  * callers that drive run_fitting's outer loop themselves.  resume = 0 starts a fresh optimiser
  * (new stage), 1 continues the previous one (history kept).  loss_out [B] (HOST) receives what
@@ -301,11 +296,6 @@ int  sfx_pen_pairs(sfx_pen* h, int32_t mesh, int32_t cap, int32_t* pairs_host, i
  * roofline_pen) divides the first two by the third.                                                                    */
 int  sfx_pen_work_reset(void);
 int  sfx_pen_work_get(int64_t* work_host);
-/* debug: elapsed 100 MHz wall-clock ticks at the end of k_pen_grid's seven steps (triangle boxes,
- * frame box, part boxes, part culling, grid histogram, scan, scatter; [7..9] unused) of the most
- * recent evaluation, then the number of grid entries: HOST [B][11].                               */
-int  sfx_pen_phase_clocks(sfx_pen* h, int32_t B, int32_t* clocks_host);
-
 /* Host side of the fitting loops (dense mode) since the last reset, HOST [4]: seconds the host thread spent enqueueing launches,
  * seconds it spent waiting for a batch's stage flags, wall seconds of the loops, rounds enqueued.  Wall time far above the kernels'
  * time with little waiting = the queue ran dry behind a slow host (bench.py reports this next to the kernels' times).          */
@@ -321,42 +311,12 @@ int  sfx_prof_enable(int32_t on);
 int  sfx_prof_get(const char* name, double* total_ms, int64_t* launches, double* units /* frames processed */);
 void sfx_prof_reset(void);
 
-/* Debug: shader-clock stamps at the phase boundaries of one closure launch (block 0). */
-int  sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out /* [32] */);
-
-/* Debug / A-B measurements: which dense LBS kernel the rounds launch -- 16 = k_lbs_dense16 (16 frames per wavefront: the
- * product kernel; at <= 32 active frames its form with one coordinate per wavefront, k_lbs_dense16c), 17 = k_lbs_dense16 at
- * every size, 32 = k_lbs_dense (32 frames per wavefront).  The same chain of fp32 operations per vertex and frame in all of
- * them, so the same bits.  Process-wide; any other value only queries.  Returns the previous setting.                   */
-int  sfx_debug_lbs_dense_form(int32_t form);
-
-/* Debug / A-B measurements: which form of the interpenetration term handles and batches created FROM NOW ON take -- 0 = the ten
- * general kernels on every column, every step dealt flat over the chip (default); 1 = grid build and pair tests spread over the
- * chip, then ONE workgroup per column from the accepted pairs to the gradient (k_pen_narrow), plus the general kernels on the
- * columns it hands over; 2 = form 1 with every column handed over; 3 = one workgroup per column behind the triangle boxes
- * (k_pen_frame).  Forms 1 and 3 were built in round 5 and measured slower on whole fits (a round lasts as long as its most crowded
- * column); all forms produce the same bits (pair list, loss, gradients: tests/test_gpu_topology.py).  Any other value only queries.
- * Returns the previous setting.  Environment: SFX_PEN_FORM.                                                                    */
-int  sfx_debug_pen_form(int32_t form);
-/* Debug: 100-MHz ticks the workgroups of k_pen_narrow spent in their phases since sfx_pen_work_reset, summed over the column
- * evaluations: HOST [8] = entry, pair list, pair evaluation, triangle sums, vertices + loss, evaluations, their ordered pairs, 0. */
-int  sfx_debug_pen_phase_ticks(int64_t* ticks_host);
-
-/* Experiment (timing only): `rounds` rounds of the dense loop; mode 0 serial (GEMM -> tick), mode 1 GEMM and tick of a
- * round launched together on two streams.  out_ms = elapsed time.  The batch's results are meaningless afterwards.     */
-int  sfx_debug_overlap_test(sfx_batch* b, int32_t rounds, int32_t mode, double* out_ms);
-/* Debug: direction of the device's blocked two-loop recursion for a caller-supplied history (rows of 192 floats, zero
- * padded; `count` pairs pushed in order, the window keeps the last history_size -- <= 0: 100, at most 400) and gradient
+/* Stand-alone operator (the parity tests of LBFGS.step's direction call it): direction of the device's blocked two-loop
+ * recursion for a caller-supplied history (rows of 192 floats, zero padded; `count` pairs pushed in order, the window keeps the last history_size -- <= 0: 100, at most 400) and gradient
  * g[192]; d_out[192].  Host pointers.  Specification: optimizers/lbfgs_ls.py:312-341. */
-int  sfx_debug_two_loop(const float* S, const float* Y, int32_t count, int32_t history_size, const float* g, float* d_out);
+int  sfx_lbfgs_two_loop(const float* S, const float* Y, int32_t count, int32_t history_size, const float* g, float* d_out);
 
-/* Debug: attach (enable>=1) a 64-slot clock buffer to the batch, run any entry point, then read it
- * and detach (enable=0): out[0..18] = closure phase stamps of the last launch, out[32+i] =
- * shader-clock cycles frame 0 spent between optimiser-tick marks i-1 and i, out[63] = ticks.
- * enable = N > 1: the stamps of the dense tick kernel freeze after its N-th launch (default 40),
- * out[24..26] = its start / end of adjoint+tick / end, out[40..56] = phases of its adjoint pass.  */
-int  sfx_debug_clocks(sfx_batch* b, int32_t enable, int64_t* out /* [64] or NULL */);
-/* debug / tests: copy a device buffer of the dense path's most recent evaluation to the host, [B][per frame]:
+/* tests / diagnostics: copy a device buffer of the dense path's most recent evaluation to the host, [B][per frame]:
  * "verts", "vposed", "pen_dverts" (V*3), "pen_dfeat", "feat" (512), "pen_dA", "A" (12*55), "pen_loss" (1).
  * n_out = number of floats the caller's buffer holds (checked).                                          */
 int  sfx_batch_debug_read(sfx_batch* b, const char* name, float* out, int64_t n_out);

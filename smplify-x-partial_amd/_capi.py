@@ -75,18 +75,14 @@ SYMBOLS = {
     "sfx_batch_closure": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, C.c_void_p]),
     "sfx_batch_guess_init": (C.c_int, [C.c_void_p, i32p, C.c_int32, C.c_void_p]),
     "sfx_batch_fit": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
-    "sfx_fit_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32]),
     "sfx_batch_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, C.c_void_p]),
     "sfx_batch_pen_stats": (C.c_int, [C.c_void_p, i32p, i32p]),
     "sfx_batch_get_grad": (C.c_int, [C.c_void_p, C.c_int32, f32p]),
     "sfx_batch_get_stats": (C.c_int, [C.c_void_p, f32p, i32p, i32p]),
-    "sfx_debug_lbs_dense_form": (C.c_int, [C.c_int32]),
-    "sfx_debug_overlap_test": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
-    "sfx_debug_two_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sfx_lbfgs_two_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "sfx_batch_trace": (C.c_int, [C.c_void_p, C.c_int32]),
     "sfx_batch_get_trace": (C.c_int, [C.c_void_p, f32p, i32p]),
     "sfx_batch_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "sfx_debug_phase_clocks": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "sfx_pen_create": (C.c_int, [C.c_int32, C.c_int32, i32p, i32p, i32p, i32p, C.c_int32, C.c_int32, C.c_int32,
                                  C.POINTER(C.c_void_p)]),
     "sfx_pen_destroy": (None, [C.c_void_p]),
@@ -97,13 +93,9 @@ SYMBOLS = {
     "sfx_pen_stats": (C.c_int, [C.c_void_p, C.c_int32, i32p]),
     "sfx_pen_pairs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, i32p, C.POINTER(C.c_int32)]),
     "sfx_batch_pen_pairs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, i32p, C.POINTER(C.c_int32)]),
-    "sfx_pen_phase_clocks": (C.c_int, [C.c_void_p, C.c_int32, i32p]),
     "sfx_batch_pen_flags": (C.c_int, [C.c_void_p, i32p]),
-    "sfx_debug_pen_form": (C.c_int, [C.c_int32]),
-    "sfx_debug_pen_phase_ticks": (C.c_int, [C.POINTER(C.c_int64)]),
     "sfx_pen_work_reset": (C.c_int, []),
     "sfx_pen_work_get": (C.c_int, [C.POINTER(C.c_int64)]),
-    "sfx_debug_clocks": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "sfx_batch_set_gmm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, f32p, f32p]),
     "sfx_batch_set_gmm_form": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, f32p, f32p, f32p]),
     "sfx_batch_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, f32p, C.c_int64]),
@@ -114,6 +106,29 @@ SYMBOLS = {
     "sfx_last_error": (C.c_char_p, []),
     "sfx_version": (C.c_char_p, []),
 }
+
+# what include/sfx_lab.h adds (libsfx_lab.so: csrc/build.sh with SFX_LAB=1; selected with SFX_LIB=<path> in the environment)
+LAB_SYMBOLS = {
+    "sfx_debug_lbs_dense_form": (C.c_int, [C.c_int32]),
+    "sfx_debug_phase_clocks": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
+    "sfx_pen_phase_clocks": (C.c_int, [C.c_void_p, C.c_int32, i32p]),
+    "sfx_debug_pen_form": (C.c_int, [C.c_int32]),
+    "sfx_debug_pen_phase_ticks": (C.c_int, [C.POINTER(C.c_int64)]),
+    "sfx_debug_clocks": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
+}
+_has_lab = False
+
+
+def has_lab():
+    """True when the loaded library is the lab build (A/B forms, phase clocks: include/sfx_lab.h)."""
+    load()
+    return _has_lab
+
+
+def need_lab(what):
+    if not has_lab():
+        raise RuntimeError("%s needs the lab build of the library (include/sfx_lab.h): SFX_LAB=1 bash "
+                           "smplify-x-partial_amd/csrc/build.sh, then SFX_LIB=smplify-x-partial_amd/libsfx_lab.so" % what)
 
 
 def load():
@@ -133,6 +148,13 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    global _has_lab
+    _has_lab = all(hasattr(lib, name) for name in LAB_SYMBOLS)
+    if _has_lab:
+        for name, (res, args) in LAB_SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 

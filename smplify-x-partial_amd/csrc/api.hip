@@ -645,11 +645,6 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
         if (c->n_stages > 0) { sfx_set_error("%d optimisation variables (limit %d): reduce num_pca_comps", body.n, SFX_NVAR_MAX); delete b; return -1; }
         body.n = SFX_NVAR_MAX;
     }
-    D.cfg.hist_dead_lo = D.cfg.hist_dead_hi = 0;
-    if (const char* e = getenv("SFX_HIST_ZEROPAGE")) if (atoi(e) > 0)
-        for (int g = 0; g < body.ngroups; ++g) if (!body.g_has[g]) {
-            D.cfg.hist_dead_lo = (body.g_off[g] + 2) / 3; D.cfg.hist_dead_hi = (body.g_off[g] + body.g_len[g]) / 3;
-            if (atoi(e) == 2) { D.cfg.hist_dead_lo += 25; D.cfg.hist_dead_hi += 25; } }      // (2: LIVE lanes instead -- the fit must change: shows that the switch is wired)
     b->vl_host[0] = cam; b->vl_host[1] = body;
     std::vector<VarList> vls = {cam, body};
     b->vl_dev = b->mem.up(vls);
@@ -718,7 +713,7 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     if (b->slots >= B) b->slots = 0;
     D.opt = b->mem.zeros<char>((size_t)B * sfx_optstate_size());
     D.vec = b->mem.zeros<float>((size_t)B * NVEC * SFX_NVAR_MAX);
-    D.hist = b->mem.zeros<float>(((size_t)B * 2 * (D.cfg.hist_ring + 8) + 16) * SFX_NVAR_MAX);      // (+ 16 rows of zeros nobody writes: hist_dead_lo)
+    D.hist = b->mem.zeros<float>((size_t)B * 2 * (D.cfg.hist_ring + 8) * SFX_NVAR_MAX);
     D.n_active = b->mem.zeros<int>(4);
     D.stage_loss = b->mem.zeros<float>((size_t)B * (1 + SFX_MAX_STAGES));
     D.stage_evals = b->mem.zeros<int>((size_t)B * (1 + SFX_MAX_STAGES));
@@ -853,6 +848,7 @@ extern "C" int sfx_batch_get_params(sfx_batch* b, float* cam_t, float* go, float
     return 0;
 }
 
+#ifdef SFX_LAB       // include/sfx_lab.h
 extern "C" int sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out /* [32] */) {
     if (!b) { sfx_set_error("null batch"); return -1; }
     long long* d = nullptr;
@@ -871,6 +867,7 @@ extern "C" int sfx_debug_phase_clocks(sfx_batch* b, int32_t stage, int64_t* out 
     for (int i = 0; i < 32; ++i) out[i] = h[i];
     return 0;
 }
+#endif
 
 // debug / tests: copy one of the dense path's device buffers of the most recent evaluation to the host.
 // name -> floats per frame (rows are GEMM columns = frames while no compaction is in force):
@@ -908,61 +905,25 @@ extern "C" int sfx_batch_debug_read(sfx_batch* b, const char* name, float* out, 
     return -1;
 }
 
-// debug: the direction the device's blocked two-loop recursion (lbfgs_body.h lb_two_loop) computes from a history of `count`
+// Stand-alone operator: the direction the device's blocked two-loop recursion (lbfgs_body.h lb_two_loop) computes from a history of `count`
 // curvature pairs pushed in order (rows of SFX_NVAR_MAX = 192 floats, zero padded; the window keeps the last history_size,
 // <= 0: 100) and a gradient g: d = -H g with H_diag = y.s / y.y of the last pair (lbfgs_ls.py:312-341).  Host pointers.
-extern "C" int sfx_debug_two_loop(const float* S, const float* Y, int32_t count, int32_t history_size, const float* g, float* d_out) {
-    if (!S || !Y || !g || !d_out || count < 1 || history_size > SFX_HIST_MAX) { sfx_set_error("sfx_debug_two_loop: bad arguments"); return -1; }
+extern "C" int sfx_lbfgs_two_loop(const float* S, const float* Y, int32_t count, int32_t history_size, const float* g, float* d_out) {
+    if (!S || !Y || !g || !d_out || count < 1 || history_size > SFX_HIST_MAX) { sfx_set_error("sfx_lbfgs_two_loop: bad arguments"); return -1; }
     const int rc = debug_two_loop(S, Y, count, history_size > 0 ? history_size : SFX_HIST, g, d_out);
-    if (rc) { sfx_set_error("sfx_debug_two_loop: HIP error"); return -1; }
+    if (rc) { sfx_set_error("sfx_lbfgs_two_loop: HIP error"); return -1; }
     return 0;
 }
 
-// debug: attach (enable=1) / read out and detach (enable=0) the 64-slot clock buffer; while attached,
-// closure launches stamp dbg[0..18] and optimiser ticks of frame 0 accumulate dbg[32..63]
-// Experiment (timing only, results are not meaningful): `rounds` rounds of the dense fit loop with the GEMM on a second
-// stream.  mode 0: serial as in sfx_batch_fit (GEMM -> tick); mode 1: GEMM(i) and tick(i) launched together (what a loop
-// whose loss pass does not wait for the GEMM would cost); out_ms = elapsed wall time of the rounds.
+#ifdef SFX_LAB       // include/sfx_lab.h
 extern "C" int sfx_debug_lbs_dense_form(int32_t form) {
     const int prev = g_lbs_dense_form;
     if (form == 16 || form == 17 || form == 32) g_lbs_dense_form = form;
     return prev;
 }
 
-extern "C" int sfx_debug_overlap_test(sfx_batch* b, int32_t rounds, int32_t mode, double* out_ms) {
-    if (!b || b->D.cfg.lbs_mode != 1) { sfx_set_error("dense batch needed"); return -1; }
-    BatchDev& D = b->D; const DevModel& M = b->m->M;
-    hipStream_t sT, sG; hipEvent_t eT, eG, t0, t1;
-    SFX_CHECK(hipStreamCreateWithFlags(&sT, hipStreamNonBlocking)); SFX_CHECK(hipStreamCreateWithFlags(&sG, hipStreamNonBlocking));
-    SFX_CHECK(hipEventCreateWithFlags(&eT, hipEventDisableTiming)); SFX_CHECK(hipEventCreateWithFlags(&eG, hipEventDisableTiming));
-    SFX_CHECK(hipEventCreate(&t0)); SFX_CHECK(hipEventCreate(&t1));
-    const int ns = D.cfg.n_stages - 1;
-    launch_lbfgs_tick(M, D, b->vl_dev, 0, ns, 1, 0, sT);
-    launch_tick_dense(M, D, b->vl_dev, b->sw_dev, 0, ns, 0, sT);
-    launch_lbs_dense(M, D, sT);
-    SFX_CHECK(hipStreamSynchronize(sT));
-    SFX_CHECK(hipEventRecord(t0, sT));
-    for (int r = 0; r < rounds; ++r) {
-        if (mode == 0) {
-            launch_lbs_dense(M, D, sT);
-            launch_tick_dense(M, D, b->vl_dev, b->sw_dev, 0, ns, 1, sT);
-        } else {
-            SFX_CHECK(hipEventRecord(eT, sT));
-            SFX_CHECK(hipStreamWaitEvent(sG, eT, 0));
-            launch_lbs_dense(M, D, sG);
-            SFX_CHECK(hipEventRecord(eG, sG));
-            launch_tick_dense(M, D, b->vl_dev, b->sw_dev, 0, ns, 1, sT);
-            SFX_CHECK(hipStreamWaitEvent(sT, eG, 0));
-        }
-    }
-    SFX_CHECK(hipEventRecord(t1, sT));
-    SFX_CHECK(hipStreamSynchronize(sT)); SFX_CHECK(hipStreamSynchronize(sG));
-    float ms = 0.f; SFX_CHECK(hipEventElapsedTime(&ms, t0, t1));
-    if (out_ms) *out_ms = ms;
-    hipEventDestroy(eT); hipEventDestroy(eG); hipEventDestroy(t0); hipEventDestroy(t1); hipStreamDestroy(sT); hipStreamDestroy(sG);
-    return 0;
-}
-
+// debug: attach (enable=1) / read out and detach (enable=0) the 64-slot clock buffer; while attached,
+// closure launches stamp dbg[0..18] and optimiser ticks of frame 0 accumulate dbg[32..63]
 extern "C" int sfx_debug_clocks(sfx_batch* b, int32_t enable, int64_t* out /* [64] or NULL */) {
     if (!b) { sfx_set_error("null batch"); return -1; }
     if (enable) {
@@ -980,6 +941,7 @@ extern "C" int sfx_debug_clocks(sfx_batch* b, int32_t enable, int64_t* out /* [6
     if (out) for (int i = 0; i < 64; ++i) out[i] = h[i];
     return 0;
 }
+#endif
 
 extern "C" int sfx_batch_num_vars(sfx_batch* b, int32_t stage) {
     if (!b) return -1;
@@ -1031,7 +993,11 @@ static int eval_penetration(sfx_batch* b, int stage_override, hipStream_t s, boo
     }
     // Fused loop: the step is a captured graph (SFX_PEN_GRAPH=0 switches it off).  The first evaluation of a process runs directly
     // (one-time attribute calls inside), every new column count is captured once on the loop's own stream.
+#ifdef SFX_LAB
     static const bool graph_on = [] { const char* e = getenv("SFX_PEN_GRAPH"); return !e || atoi(e) != 0; }();
+#else
+    constexpr bool graph_on = true;
+#endif
     static bool warmed = false;
     if (want_ready && graph_on && warmed && !b->pen_chunked) {
         auto it = b->pen_graphs.find(D.nact);
@@ -1170,7 +1136,14 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
         // first pose / chain export is one extra launch over the admitted frames only.  Once the queue is dry the
         // columns are compacted whenever a 32-frame MFMA slice has emptied, as before.  Frames are independent and a
         // column's arithmetic does not depend on its index: results equal those of a batch with one column per frame.
-        static const bool dbg_nact = getenv("SFX_DEBUG_NACT") != nullptr;
+#ifdef SFX_LAB       // measurement switches of the lab build (include/sfx_lab.h): diagnostics to stderr, polling cadence
+        static const bool dbg_nact = getenv("SFX_DEBUG_NACT") != nullptr, dbg_host = getenv("SFX_DEBUG_HOST") != nullptr;
+        static const int rpb_env = [] { const char* e = getenv("SFX_POLL_ROUNDS"); return e ? atoi(e) : 0; }();
+        static const int ahead_env = [] { const char* e = getenv("SFX_POLL_AHEAD"); return e ? atoi(e) : 0; }();
+#else
+        constexpr bool dbg_nact = false, dbg_host = false;
+        constexpr int rpb_env = 0, ahead_env = 0;
+#endif
         static long nact_hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // rounds by active GEMM columns: <=32, <=64, ..., <=256, more
         const int pool = b->slots > 0 ? std::min(b->slots, B) : B;
         std::vector<int>& col = b->slot_host;                          // frame -> column, -1 = queued or retired
@@ -1196,10 +1169,8 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
         if (int rc = upload(nullptr)) return rc;
         { ProfScope p("tick", s, D.nrun); launch_tick_dense(M, D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, s); }
         // SFX_DEBUG_HOST=1: how much of the loop's wall time the HOST spends enqueueing (its headroom against a busy box)
-        static const bool dbg_host = getenv("SFX_DEBUG_HOST") != nullptr;
         double host_enq_s = 0.0, host_wait_s = 0.0; long host_batches = 0;
         const double wall0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-        static const int rpb_env = [] { const char* e = getenv("SFX_POLL_ROUNDS"); return e ? atoi(e) : 0; }();
         const int rpb = std::max(1, std::min(64, rpb_env > 0 ? rpb_env : 8));          // rounds per polled batch
         auto rounds = [&](int buf) -> int {
             if (dbg_nact) nact_hist[std::min(8, (D.nact - 1) / 32)] += rpb;
@@ -1216,7 +1187,6 @@ static int run_ticks(sfx_batch* b, int first_stage, int last_stage, int init, in
             SFX_CHECK(hipEventRecord(b->poll_ev[buf], s));
             return 0;
         };
-        static const int ahead_env = [] { const char* e = getenv("SFX_POLL_AHEAD"); return e ? atoi(e) : 0; }();
         const int ahead = std::max(1, std::min(SFX_POLL_BUFS - 1, ahead_env > 0 ? ahead_env : (b->pen ? 1 : 3)));
         long q_head = 0, q_next = 0;       // batches processed / queued
         for (; q_next < ahead; ++q_next) if (int rc = rounds((int)(q_next % SFX_POLL_BUFS))) return rc;
@@ -1345,100 +1315,6 @@ extern "C" int sfx_batch_fit(sfx_batch* b, int32_t first_stage, int32_t last_sta
         sfx_set_error("bad stage range [%d,%d]", first_stage, last_stage); return -1;
     }
     return run_ticks(b, first_stage, last_stage, 1, 0, (hipStream_t)stream);
-}
-
-// Software pipeline over several independent batches (sub-batches of one workload), dense mode:
-// each batch has its own stream; the MFMA GEMMs of the batches are chained by events
-// (GEMM_0 -> GEMM_1 -> ... -> GEMM_0 ...) so they run back to back, while each batch's
-// latency-bound tick kernel (loss/adjoint -> L-BFGS tick -> next pose/chain) runs on its own stream
-// underneath the other batches' GEMMs.  Frames are independent: results equal sfx_batch_fit's.
-extern "C" int sfx_fit_multi(sfx_batch** bs, int32_t n, int32_t first_stage, int32_t last_stage) {
-    if (!bs || n < 1) { sfx_set_error("bad arguments"); return -1; }
-    for (int g = 0; g < n; ++g) {
-        if (!bs[g]) { sfx_set_error("null batch"); return -1; }
-        if (first_stage < -1 || last_stage >= bs[g]->D.cfg.n_stages || last_stage < first_stage) {
-            sfx_set_error("bad stage range [%d,%d]", first_stage, last_stage); return -1; }
-    }
-    bool all_dense = true;
-    for (int g = 0; g < n; ++g) all_dense = all_dense && bs[g]->D.cfg.lbs_mode == 1;
-    if (n == 1 || !all_dense || g_unfused) {
-        for (int g = 0; g < n; ++g) { int rc = run_ticks(bs[g], first_stage, last_stage, 1, 0, 0); if (rc) return rc; }
-        return 0;
-    }
-    std::vector<hipStream_t> st(n);
-    std::vector<hipEvent_t> ev(n);
-    std::vector<int*> hp(n);
-    std::vector<char> done(n, 0);
-    for (int g = 0; g < n; ++g) {
-        SFX_CHECK(hipStreamCreateWithFlags(&st[g], hipStreamNonBlocking));
-        SFX_CHECK(hipEventCreateWithFlags(&ev[g], hipEventDisableTiming));
-        hp[g] = bs[g]->stage_host;
-        if (!hp[g]) { sfx_set_error("pinned buffer missing"); return -2; }
-    }
-    SFX_CHECK(hipDeviceSynchronize());
-    for (int g = 0; g < n; ++g) {
-        sfx_batch* b = bs[g];
-        launch_lbfgs_tick(b->m->M, b->D, b->vl_dev, first_stage, last_stage, 1, 0, st[g]);
-        ProfScope p("tick", st[g]);
-        launch_tick_dense(b->m->M, b->D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, st[g]);
-    }
-    long tick = 0;
-    long max_ticks = 0;
-    for (int g = 0; g < n; ++g) max_ticks = std::max(max_ticks, sfx_fit_tick_bound(bs[g]->D.cfg, first_stage, last_stage));
-    int remaining = n, prev = -1;
-    int rc = 0;
-    while (remaining > 0 && tick < max_ticks && rc == 0) {
-        for (int q = 0; q < 8; ++q, ++tick) {
-            for (int g = 0; g < n; ++g) {
-                if (done[g]) continue;
-                sfx_batch* b = bs[g];
-                if (prev >= 0 && prev != g) hipStreamWaitEvent(st[g], ev[prev], 0);   // GEMMs back to back
-                { ProfScope p("lbs_dense", st[g], b->D.nact); launch_lbs_dense(b->m->M, b->D, st[g]); }
-                if (int rc = eval_penetration(b, -2, st[g], true)) return rc;
-                hipEventRecord(ev[g], st[g]);
-                prev = g;
-                ProfScope p("tick", st[g]);
-                launch_tick_dense(b->m->M, b->D, b->vl_dev, b->sw_dev, first_stage, last_stage, 1, st[g]);
-            }
-        }
-        for (int g = 0; g < n; ++g)
-            if (!done[g]) hipMemcpyAsync(hp[g], bs[g]->D.stage, (size_t)bs[g]->D.cfg.B * sizeof(int), hipMemcpyDeviceToHost, st[g]);
-        for (int g = 0; g < n; ++g) {
-            if (done[g]) continue;
-            sfx_batch* b = bs[g];
-            const int B = b->D.cfg.B;
-            if (hipStreamSynchronize(st[g]) != hipSuccess) { sfx_set_error("stream sync failed"); rc = -2; break; }
-            int nact = 0;
-            for (int i = 0; i < B; ++i) if (hp[g][i] <= last_stage) ++nact;
-            if (nact == 0) { done[g] = 1; --remaining; if (prev == g) prev = -1; continue; }
-            if ((b->D.nact + 31) / 32 != (nact + 31) / 32) {
-                std::vector<int>& sl = b->slot_host;
-                sl.assign(B, 0);
-                int k = 0;
-                for (int i = 0; i < B; ++i) sl[i] = (hp[g][i] <= last_stage) ? k++ : 0;
-                hipMemcpyAsync(b->D.slot, sl.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st[g]);
-                hipStreamSynchronize(st[g]);        // sl is reused: finish the copy before the next remap
-                b->D.nact = nact;
-                ProfScope p("tick", st[g]);
-                launch_tick_dense(b->m->M, b->D, b->vl_dev, b->sw_dev, first_stage, last_stage, 0, st[g]);
-            }
-        }
-    }
-    for (int g = 0; g < n; ++g) {
-        sfx_batch* b = bs[g];
-        const int B = b->D.cfg.B;
-        std::vector<int>& sl = b->slot_host;
-        sl.resize(B);
-        for (int i = 0; i < B; ++i) sl[i] = i;
-        hipMemcpyAsync(b->D.slot, sl.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st[g]);
-        hipStreamSynchronize(st[g]);
-        b->D.nact = B;
-        hipStreamDestroy(st[g]); hipEventDestroy(ev[g]);
-    }
-    SFX_CHECK(hipGetLastError());
-    if (rc) return rc;
-    if (remaining > 0) { sfx_set_error("fit did not finish within %ld ticks", max_ticks); return -4; }
-    return 0;
 }
 
 extern "C" int sfx_batch_step(sfx_batch* b, int32_t stage, int32_t resume, float* loss_out, void* stream) {

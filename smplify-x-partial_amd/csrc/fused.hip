@@ -136,9 +136,13 @@ void launch_tick_dense(const DevModel& M, const BatchDev& D, const VarList* vl_d
     if (grid <= 0) return;
     static const int n_cu = [] { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); return hipGetDeviceProperties(&p, dev) == hipSuccess ? p.multiProcessorCount : 256; }();
     if (sfx_small_closure(M, D)) {
-        // a workgroup per CU: eight wavefronts (FrameLDSSmall8: same bits as four, closure_body.h); SFX_TICK_THREADS=256: the
-        // four-wavefront kernel of round 3 (measurement switch)
+        // a workgroup per CU: eight wavefronts (FrameLDSSmall8: same bits as four, closure_body.h); lab build, SFX_TICK_THREADS=256:
+        // the four-wavefront kernel of round 3 (measurement switch)
+#ifdef SFX_LAB
         static const bool t256 = [] { const char* e = getenv("SFX_TICK_THREADS"); return e && atoi(e) == 256; }();
+#else
+        constexpr bool t256 = false;
+#endif
         if (grid <= n_cu && !t256)
             hipLaunchKernelGGL((k_tick_dense<FrameLDSSmall8, 1>), dim3(grid), dim3(FrameLDSSmall8::kThreads), 0, s, M, D, vl_dev, sw_dev, first_stage, last_stage, has_eval);
         else if (grid <= n_cu)

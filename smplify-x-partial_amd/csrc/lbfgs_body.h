@@ -265,7 +265,7 @@ __device__ __forceinline__ void lb_axpy(LbRow& y, const float a, const LbRow& x)
 template <int DIR>
 __device__ __forceinline__ void lb_load(LbSet& X, const int base, const int n, const int head, const float* hMine,
                                         const float* hAll, const float* tab, const float* ro, const float* s_alp,
-                                        const bool want_al, const int lane, const int R, const char* zrow = nullptr) {
+                                        const bool want_al, const int lane, const int R) {
     const int grp = lane >> 3;
     int p = head + base; p = p >= R ? p - R : p;
     if (DIR < 0 && p < 7) p += R;
@@ -282,7 +282,6 @@ __device__ __forceinline__ void lb_load(LbSet& X, const int base, const int n, c
     if (want_al) X.al = s_alp[ig];
     const char* ra = reinterpret_cast<const char*>(hAll) + (size_t)p * LB_ROWB + 12 * lane;
     const char* rm = reinterpret_cast<const char*>(hMine) + (size_t)p * LB_ROWB + 12 * lane;
-    if (zrow) { ra = zrow; rm = zrow; }          // (a lane whose three elements are dead variables: zeros, from one line every such lane shares)
 #pragma unroll
     for (int c = 0; c < 8; ++c) X.all[c] = lb_ldrow(ra + DIR * c * LB_ROWB);
 #pragma unroll
@@ -337,7 +336,7 @@ __device__ __forceinline__ void lb_push_pair(float* hY, float* hS, OptState* gst
 template <int SETS>
 __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, const OptState* gst, float* s_al,
                                              const int n_, const int head_, const float hd, const Lane3 q_in, const int lane,
-                                             const int R = SFX_HIST, const char* zrow = nullptr) {
+                                             const int R = SFX_HIST) {
     const int n = __builtin_amdgcn_readfirstlane(n_), head = __builtin_amdgcn_readfirstlane(head_);
     float* s_alp = s_al + 8;        // members below index 0 of the last block land in the padding
     const int grp = lane >> 3;
@@ -365,7 +364,7 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
 #pragma unroll
         for (int c = 0; c < 8; ++c) lb_axpy(q, -al[c], X.all[c]);
     };
-#define LB_LD1(X, b_) lb_load<-1>(X, (b_), n, head, hS, hY, gst->syt, gst->ro, s_alp, false, lane, R, zrow)
+#define LB_LD1(X, b_) lb_load<-1>(X, (b_), n, head, hS, hY, gst->syt, gst->ro, s_alp, false, lane, R)
     // The look-ahead loads are UNCONDITIONAL (a block past the end of the window re-reads block 0; it is never used): with
     // `if (i0 >= 16) load` the number of loads in flight at the next dot products depended on a branch, and the compiler then
     // waits for the shorter path's count -- vmcnt(0): every block paid its own memory round trip and the look-ahead bought
@@ -416,7 +415,7 @@ __device__ __forceinline__ Lane3 lb_two_loop(const float* hS, const float* hY, c
 #pragma unroll
         for (int c = 0; c < 8; ++c) lb_axpy(r, cc[c], X.all[c]);
     };
-#define LB_LD2(X, b_) lb_load<1>(X, (b_), n, head, hY, hS, gst->syb, gst->ro, s_alp, true, lane, R, zrow)
+#define LB_LD2(X, b_) lb_load<1>(X, (b_), n, head, hY, hS, gst->syb, gst->ro, s_alp, true, lane, R)
     {
         int i0 = 0, k = 0;
         const int last = max(n - 1, 0);
@@ -680,10 +679,7 @@ __device__ __forceinline__ void lbfgs_tick_wave0(const DevModel& M, const BatchD
                     if (n == 0) {
                         for (int e = 0; e < NE3; ++e) r.v[e] = q.v[e] * hd;
                     } else {
-                        // (measurement, DESIGN 4.5: lanes of the dead body_pose slots read zeros from one shared line)
-                        const char* zrow = (stage >= 0 && lane >= C.hist_dead_lo && lane < C.hist_dead_hi)
-                            ? reinterpret_cast<const char*>(D.hist + ((size_t)C.B * 2 * hrows + 8) * SFX_NVAR_MAX) : nullptr;
-                        r = lb_two_loop<SETS>(hS, hY, gst, s_al, n, s.hist_head, hd, q, lane, R, zrow);
+                        r = lb_two_loop<SETS>(hS, hY, gst, s_al, n, s.hist_head, hd, q, lane, R);
                     }
                 }
                 TMARK(5);

@@ -284,9 +284,11 @@ void launch_pen_adjoint(const DevModel& M, const BatchDev& D, hipStream_t s) {
     const int rw = ftiles >= 3 ? 512 : ADJ_RW_MIN;       // 8 k tiles x ftiles x slices workgroups: keep >= 256 of them
     const int ns = (3 * M.Vpad + 4 * rw - 1) / (4 * rw);
     // (d v_posed = T^T g, the GEMM's operand, was written by k_pen_gather: PenAdjPrep)
-    static const int ki = [] { const char* e = getenv("SFX_ADJ_KI"); return e && atoi(e) == 4 ? 4 : 2; }();      // (4: the 64-k tile of rounds 3-5, A/B switch; same bits)
-    if (ki == 4) hipLaunchKernelGGL(k_lbs_dense_adj<4>, dim3(ns, SFX_KD_PAD / 64, ftiles), dim3(ADJ_T), 0, s, M, D, rw);
-    else hipLaunchKernelGGL(k_lbs_dense_adj<2>, dim3(ns, SFX_KD_PAD / 32, ftiles), dim3(ADJ_T), 0, s, M, D, rw);
+#ifdef SFX_LAB       // SFX_ADJ_KI=4: the 64-k tile of rounds 3-5 (A/B switch of the lab build; same bits)
+    static const int ki = [] { const char* e = getenv("SFX_ADJ_KI"); return e && atoi(e) == 4 ? 4 : 2; }();
+    if (ki == 4) { hipLaunchKernelGGL(k_lbs_dense_adj<4>, dim3(ns, SFX_KD_PAD / 64, ftiles), dim3(ADJ_T), 0, s, M, D, rw); } else
+#endif
+    hipLaunchKernelGGL(k_lbs_dense_adj<2>, dim3(ns, SFX_KD_PAD / 32, ftiles), dim3(ADJ_T), 0, s, M, D, rw);
     const int n_red = ftiles * (SFX_KD_PAD / 4);
     hipLaunchKernelGGL(k_adj_finish, dim3(n_red + D.nact * ((SFX_J + 3) / 4)), dim3(256), 0, s, M, D,
                        rw > ADJ_RW_MIN ? ns : 2 * ns, rw > ADJ_RW_MIN ? 0 : 1, n_red);

@@ -172,8 +172,6 @@ struct BatchCfgDev {
     int hist_cap;                      // LBFGS history_size (<= SFX_HIST_MAX)
     int hist_ring;                     // slots of the history ring: SFX_HIST, or history_size when that is larger (round 5)
     int proj64;                        // projection in fp64 in every stage (cfg float_dtype float64; the camera stage always is)
-    int hist_dead_lo, hist_dead_hi;    // lanes [lo, hi) of the body stage's history rows hold only the dead body_pose slots (0, 0: none /
-                                       // measurement switched off): they read a page of zeros behind the history (lbfgs_body.h lb_load)
 };
 
 // Per-frame data pointers (all device).
@@ -284,7 +282,9 @@ struct PenAdjPrep {
 void launch_pen_adjoint(const DevModel& M, const BatchDev& D, hipStream_t s);
 int sfx_adj_slices(const DevModel& M);
 void launch_lbs_dense(const DevModel& M, const BatchDev& D, hipStream_t s);
-extern int g_lbs_dense_form;          // 16 (k_lbs_dense16, default) | 32 (k_lbs_dense)
+#ifdef SFX_LAB
+extern int g_lbs_dense_form;          // 16 (k_lbs_dense16, default) | 17 (k_lbs_dense16 at every size) | 32 (k_lbs_dense)
+#endif
 void launch_lbfgs_tick(const DevModel& M, const BatchDev& D, const VarList* vl_dev, int first_stage,
                        int last_stage, int init, int step_mode, hipStream_t s);
 size_t sfx_optstate_size();

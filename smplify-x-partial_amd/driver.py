@@ -153,7 +153,7 @@ def predicted_cost(cfg, prep):
 
 def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, reg_global=None,
                cam_prior_t=None, cam_prior_center=None, lbs_mode="dense", reuse_entry_eval=True,
-               want_vertices=False, groups=1, body_pose_prior=None, slots=0, order="auto"):
+               want_vertices=False, body_pose_prior=None, slots=0, order="auto"):
     """Fit B frames.  Arrays are [B, ...]; H, W, focal scalars or [B].  Returns a dict of
     [B, ...] arrays: the reference's result-pkl fields + per-stage losses / evaluation counts.
 
@@ -162,11 +162,7 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
     by pi about y with the lower final loss kept (:527-551,662-667) -- runs on device; frames
     change stage independently.
 
-    groups > 1 splits the frames into that many sub-batches that are pipelined through the GPU
-    (sfx_fit_multi): the MFMA GEMMs of the sub-batches run back to back while each sub-batch's
-    latency-bound optimiser tick hides under the others' GEMMs.  Results are unchanged.
-
-    slots (dense mode, groups == 1): size of the GEMM column pool when there are more frames than that --
+    slots (dense mode): size of the GEMM column pool when there are more frames than that --
     the reference's loop over frames (main.py:207) as continuous batching: frames queue and take over the
     columns of frames that finish.  Results are unchanged.  slots = -1: auto_slots(B).
     order (pooled runs only): "auto" = the queue is ordered by predicted_cost, longest first (a straggler admitted last holds
@@ -176,7 +172,7 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
     if slots is not None and slots < 0:
         slots = auto_slots(B_all) if lbs_mode == "dense" else 0
     perm = None
-    if lbs_mode == "dense" and groups == 1 and 0 < slots < B_all and order == "auto":
+    if lbs_mode == "dense" and 0 < slots < B_all and order == "auto":
         cost = predicted_cost(cfg, prepare_frames(cfg, keypoints, joint_weights))
         perm = np.argsort(-cost, kind="stable")
         if np.array_equal(perm, np.arange(B_all)):
@@ -193,32 +189,12 @@ def fit_frames(dm, cfg, keypoints, joint_weights, H, W, focal, reg_pose=None, re
             joint_weights = jw_a[perm]
         H, W, focal, reg_pose, reg_global = pm(H), pm(W), pm(focal), pm(reg_pose), pm(reg_global)
         cam_prior_t, cam_prior_center = pm(cam_prior_t), pm(cam_prior_center)
-    groups = max(1, min(int(groups), B_all // 32)) if lbs_mode == "dense" else 1
-    cuts = [(B_all * g) // groups for g in range(groups + 1)]
-    jw_all = np.asarray(joint_weights)
-    jw_per_frame = jw_all.ndim == 2 and jw_all.shape[0] == B_all and B_all > 1
-
-    def per(a, lo, hi):
-        if a is None:
-            return None
-        a = np.asarray(a)
-        return a[lo:hi] if a.ndim > 0 and a.shape[0] == B_all and B_all > 1 else a
-    made = []
-    for g in range(groups):
-        lo, hi = cuts[g], cuts[g + 1]
-        made.append(_make_batch(dm, cfg, np.asarray(keypoints)[lo:hi], jw_all[lo:hi] if jw_per_frame else jw_all,
-                                per(H, lo, hi), per(W, lo, hi), per(focal, lo, hi), per(reg_pose, lo, hi),
-                                per(reg_global, lo, hi), per(cam_prior_t, lo, hi), per(cam_prior_center, lo, hi),
-                                lbs_mode, reuse_entry_eval, body_pose_prior, slots if groups == 1 else 0))
-    fbs = [m[0] for m in made]
+    fb, prep = _make_batch(dm, cfg, np.asarray(keypoints), np.asarray(joint_weights), H, W, focal, reg_pose, reg_global,
+                           cam_prior_t, cam_prior_center, lbs_mode, reuse_entry_eval, body_pose_prior, slots)
     pen_on = bool(cfg.get("interpenetration", False))
     work0 = engine.pen_work_get() if pen_on else None
-    if groups == 1:
-        fbs[0].fit(first_stage=-1, last_stage=fbs[0].n_stages - 1)
-    else:
-        engine.fit_multi(fbs, first_stage=-1, last_stage=fbs[0].n_stages - 1)
-    parts = [_collect(fb, prep, want_vertices) for fb, prep in made]
-    res = {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}
+    fb.fit(first_stage=-1, last_stage=fb.n_stages - 1)
+    res = _collect(fb, prep, want_vertices)
     if pen_on:      # diagnostics of the interpenetration term over this fit (device counters, engine.pen_work_get; per-frame flags)
         w1 = engine.pen_work_get()
         cut, over = w1["walks_cut"] - work0["walks_cut"], w1["lists_overflowed"] - work0["lists_overflowed"]

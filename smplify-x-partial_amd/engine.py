@@ -424,13 +424,6 @@ class FrameBatch(object):
             pass
 
 
-def fit_multi(batches, first_stage=-1, last_stage=None):
-    """sfx_fit_multi: pipeline several FrameBatches (same configuration) through the GPU."""
-    last = batches[0].n_stages - 1 if last_stage is None else last_stage
-    arr = (C.c_void_p * len(batches))(*[b._h for b in batches])
-    capi.check(capi.load().sfx_fit_multi(arr, len(batches), first_stage, last))
-
-
 def prof_enable(on=True, every=1):
     """HIP-event timing of the named kernel launches; `every` = N times only every N-th launch of
     each name (an event pair costs two queue packets per launch)."""
@@ -474,12 +467,14 @@ def pen_work_get():
 def pen_form(form=-1):
     """Debug / A-B: which form of the interpenetration term Penetration handles and FrameBatches created from now on take
     (sfx_debug_pen_form: 0 = the ten general kernels, the default; 1 = one workgroup per column behind the pair tests; 2 = form 1
-    handing every column over; 3 = one workgroup per column behind the triangle boxes).  Returns the previous setting; any other argument only queries."""
+    handing every column over).  LAB build only (include/sfx_lab.h).  Returns the previous setting; any other argument only queries."""
+    capi.need_lab("pen_form")
     return int(capi.load().sfx_debug_pen_form(int(form)))
 
 
 def pen_phase_ticks():
     """Debug: mean microseconds a column evaluation spent in the phases of k_pen_narrow since pen_work_reset()."""
+    capi.need_lab("pen_phase_ticks")
     w = (C.c_int64 * 8)()
     capi.check(capi.load().sfx_debug_pen_phase_ticks(w))
     n = max(int(w[5]), 1)
@@ -576,7 +571,8 @@ class Penetration(object):
         return _read_pairs(lambda cap, buf, n: self._lib.sfx_pen_pairs(self._h, int(mesh), cap, buf, n))
 
     def phase_clocks(self, B):
-        """Debug: microseconds at the end of the broad phase's ten steps, grid entries (see sfx_pen_phase_clocks)."""
+        """Debug (LAB build): microseconds at the end of the broad phase's ten steps, grid entries (see sfx_pen_phase_clocks)."""
+        capi.need_lab("phase_clocks")
         out = np.zeros((B, 11), np.int32)
         capi.check(self._lib.sfx_pen_phase_clocks(self._h, int(B), capi.iptr(out)))
         res = out / 100.0

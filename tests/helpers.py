@@ -7,6 +7,24 @@ import torch
 from smplifyx_amd import cmd_parser, synthetic, utils as U
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def has_lab():
+    """Is the library under test the LAB build (include/sfx_lab.h: A/B forms, environment switches, phase clocks)?  The product
+    library (libsfx.so) has none of them; tools/run_gpu_suite.sh runs the suite once on each."""
+    from smplifyx_amd import _capi
+    try:
+        return _capi.has_lab()
+    except Exception:
+        return False
+
+
+def requires_lab():
+    import pytest
+    return pytest.mark.skipif(not has_lab(), reason="needs the lab build (SFX_LAB=1 csrc/build.sh; SFX_LIB=.../libsfx_lab.so; "
+                                                    "tools/run_gpu_suite.sh)")
+
+
 CFG_DIR = os.path.join(ROOT, "cfg_files")
 
 

@@ -37,6 +37,7 @@ def test_dense_path_is_batch_composition_independent(synth_model, cfg_body, B):
     assert np.array_equal(out[0][3]["stage_evals"][-1], out[1][3]["stage_evals"][-1])
 
 
+@H.requires_lab()
 def test_kernel_shapes_of_the_dense_loop_give_the_same_bits():
     """Round 4 added launch shapes to both kernels of the dense loop, each chosen by the number of active frames: k_lbs_dense16<W>
     with W = 3 / 4 / 5 wavefronts per workgroup, k_tick_dense on eight wavefronts (<= 256 frames) or four.  A frame's fit must not
@@ -77,6 +78,7 @@ print(json.dumps({"sha": h.hexdigest(), "evals": int(np.asarray(st["stage_evals"
         assert o == outs["default"], (name, outs)
 
 
+@H.requires_lab()
 def test_the_two_dense_kernels_are_interchangeable_bit_for_bit(synth_model, cfg_body):
     """k_lbs_dense16 (16 frames per wavefront, the product kernel) and k_lbs_dense (32 per wavefront, kept for A/B
     measurements) put every (vertex, frame) through the same chain of fp32 operations: all vertices of a 100-frame launch
@@ -109,6 +111,7 @@ def test_the_two_dense_kernels_are_interchangeable_bit_for_bit(synth_model, cfg_
     assert np.array_equal(out[0][4], out[1][4])
 
 
+@H.requires_lab()
 @pytest.mark.parametrize("n", [1, 9, 16, 17, 32])
 def test_the_few_frames_dense_kernel_is_interchangeable_bit_for_bit(synth_model, cfg_body, n):
     """k_lbs_dense16c (round 5: at <= 32 active frames the three coordinates of a 16-frame slice go to three wavefronts -- the

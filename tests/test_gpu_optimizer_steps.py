@@ -320,7 +320,7 @@ def test_blocked_two_loop_matches_the_sequential_recursion(count):
     g = np.zeros(W, np.float32); g[:N] = rng.standard_normal(N)
     d = np.zeros(W, np.float32)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    _capi.check(_capi.load().sfx_debug_two_loop(p(S), p(Y), count, 0, p(g), p(d)))
+    _capi.check(_capi.load().sfx_lbfgs_two_loop(p(S), p(Y), count, 0, p(g), p(d)))
     w = slice(max(0, count - 100), count)
     ref = _two_loop_fp64(S[w, :N].astype(np.float64), Y[w, :N].astype(np.float64), g[:N])
     assert np.all(d[N:] == 0)
@@ -346,7 +346,7 @@ def test_blocked_two_loop_with_a_history_size_other_than_100(count, history):
     d = np.zeros(W, np.float32)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     lib = _capi.load()
-    _capi.check(lib.sfx_debug_two_loop(p(S), p(Y), count, history, p(g), p(d)))
+    _capi.check(lib.sfx_lbfgs_two_loop(p(S), p(Y), count, history, p(g), p(d)))
     w = slice(max(0, count - history), count)
     ref = _two_loop_fp64(S[w, :N].astype(np.float64), Y[w, :N].astype(np.float64), g[:N])
     assert np.all(d[N:] == 0)
@@ -356,7 +356,7 @@ def test_blocked_two_loop_with_a_history_size_other_than_100(count, history):
     if count > history and history != 100:      # ... and it is not the 100-pair window's direction
         ref100 = _two_loop_fp64(S[max(0, count - 100):, :N].astype(np.float64), Y[max(0, count - 100):, :N].astype(np.float64), g[:N])
         assert np.abs(d[:N] - ref100).max() / np.abs(ref).max() > 50 * err
-    assert lib.sfx_debug_two_loop(p(S), p(Y), count, 401, p(g), p(d)) != 0      # beyond the LDS array of the alphas: refused, loudly
+    assert lib.sfx_lbfgs_two_loop(p(S), p(Y), count, 401, p(g), p(d)) != 0      # beyond the LDS array of the alphas: refused, loudly
 
 
 def test_first_body_stage_with_history_size_150(synth_model, cfg_body):

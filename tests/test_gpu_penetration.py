@@ -6,6 +6,9 @@ import torch
 
 import helpers as H
 from oracle import penetration as OP
+
+# bounds of the stand-alone operator: ~10 x the maxima observed on MI355X in round 6 (loss 2.1e-7, vertex gradient 5.1e-5 over 29 checks;
+# the session summary prints them: helpers.check_bound)
 from smplifyx_amd import engine
 
 pytestmark = pytest.mark.gpu
@@ -66,8 +69,8 @@ def test_two_spheres_loss_and_gradient(sigma, outside):
         lo, go, pairs = OP.penetration(v32, faces, segm, parents, None, sigma=sigma, penalize_outside=outside)
         assert st["pairs"][b] == 2 * len(pairs), (b, st["pairs"][b], len(pairs))
         assert len(pairs) > 50
-        H.check_bound("operator", "loss", abs(loss[b] - lo) / max(abs(lo), 1e-30), 2e-4)
-        H.check_bound("operator", "vertex gradient", np.linalg.norm(dv[b] - go) / max(np.linalg.norm(go), 1e-30), 2e-3)
+        H.check_bound("operator", "loss", abs(loss[b] - lo) / max(abs(lo), 1e-30), 5e-6)
+        H.check_bound("operator", "vertex gradient", np.linalg.norm(dv[b] - go) / max(np.linalg.norm(go), 1e-30), 6e-4)
 
 
 @pytest.mark.parametrize("sigma,outside", [(0.5, True), (0.5, False), (1e-4, True)])
@@ -92,8 +95,8 @@ def test_point2plane_loss_and_gradient(sigma, outside):
         v32 = vb[b].astype(np.float32).astype(np.float64)
         lo, go, pairs = OP.penetration(v32, faces, segm, parents, None, sigma=sigma, penalize_outside=outside, point2plane=True)
         assert st["pairs"][b] == 2 * len(pairs) and len(pairs) > 50
-        H.check_bound("operator", "loss", abs(loss[b] - lo) / max(abs(lo), 1e-30), 2e-4)
-        H.check_bound("operator", "vertex gradient", np.linalg.norm(dv[b] - go) / max(np.linalg.norm(go), 1e-30), 2e-3)
+        H.check_bound("operator", "loss", abs(loss[b] - lo) / max(abs(lo), 1e-30), 5e-6)
+        H.check_bound("operator", "vertex gradient", np.linalg.norm(dv[b] - go) / max(np.linalg.norm(go), 1e-30), 6e-4)
         assert 0 < loss[b] < 0.98 * l0[b], (loss[b], l0[b])               # (n_f . n_g)^2 < 1 on most pairs of two spheres
         # not the default gradient rescaled: the normals carry gradient of their own
         cosang = float((dv[b] * d0[b]).sum() / (np.linalg.norm(dv[b]) * np.linalg.norm(d0[b])))
@@ -155,8 +158,8 @@ def test_max_collisions_cap_keeps_the_lowest_ids():
             assert st["pairs"][i] == len(opairs) and st["dropped"][i] == n_cut, (st, len(opairs), n_cut)
             res.append((float(loss[i]), dv[i].cpu().numpy()))
         assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])          # batch composition
-        H.check_bound("operator", "loss", abs(res[0][0] - float(lo)) / max(abs(float(lo)), 1e-30), 2e-4)
-        H.check_bound("operator", "vertex gradient", np.linalg.norm(res[0][1] - go) / max(np.linalg.norm(go), 1e-30), 2e-3)
+        H.check_bound("operator", "loss", abs(res[0][0] - float(lo)) / max(abs(float(lo)), 1e-30), 5e-6)
+        H.check_bound("operator", "vertex gradient", np.linalg.norm(res[0][1] - go) / max(np.linalg.norm(go), 1e-30), 6e-4)
 
 
 def test_lists_beyond_twice_the_cap_are_derived_from_the_grid_again():
@@ -189,8 +192,8 @@ def test_lists_beyond_twice_the_cap_are_derived_from_the_grid_again():
             res.append((float(loss[i]), dv[i].cpu().numpy()))
         for r in res[1:]:
             assert res[0][0] == r[0] and np.array_equal(res[0][1], r[1])               # batch composition, run to run
-        H.check_bound("operator", "loss", abs(res[0][0] - float(lo)) / max(abs(float(lo)), 1e-30), 2e-4)
-        H.check_bound("operator", "vertex gradient", np.linalg.norm(res[0][1] - go) / max(np.linalg.norm(go), 1e-30), 2e-3)
+        H.check_bound("operator", "loss", abs(res[0][0] - float(lo)) / max(abs(float(lo)), 1e-30), 5e-6)
+        H.check_bound("operator", "vertex gradient", np.linalg.norm(res[0][1] - go) / max(np.linalg.norm(go), 1e-30), 6e-4)
 
 
 def test_max_collisions_cap_is_reported():
@@ -366,9 +369,9 @@ def test_interpenetration_at_the_cfg_values(synth_model):
             vt = torch.tensor(vd[i], dtype=torch.float64, requires_grad=True)
             lo_v = OP.penetration_loss_ordered(vt, faces, opairs, 1e-4)
             lo_v.backward()
-            H.check_bound("operator", "loss", abs(pl[i] - float(lo_v)) / max(abs(float(lo_v)), 1e-30), 2e-4)
+            H.check_bound("operator", "loss", abs(pl[i] - float(lo_v)) / max(abs(float(lo_v)), 1e-30), 5e-6)
             gv = vt.grad.numpy()
-            H.check_bound("operator", "vertex gradient", np.linalg.norm(pg[i] - gv) / max(np.linalg.norm(gv), 1e-30), 3e-3)
+            H.check_bound("operator", "vertex gradient", np.linalg.norm(pg[i] - gv) / max(np.linalg.norm(gv), 1e-30), 6e-4)
         i = stage - 1
         lo, go = oracle(i, stage, True)
         lo_np, go_np = oracle(i, stage, False)
@@ -544,6 +547,7 @@ def test_pooled_batch_with_interpenetration():
     assert (out["all"][2]["pairs"] > 0).sum() > B // 2          # the tubes of neighbouring bones run through each other: the term was evaluated
 
 
+@H.requires_lab()
 def test_chunked_pair_tests_equal_the_unchunked_walk(tmp_path):
     """k_pen_walk / k_pen_walk2 (round 4: a block's walk through its bucket in chunks of 64 steps, the chunks beyond the first as
     one flat list over all meshes) against the walk that runs every bucket to its end on the block's own wavefront

@@ -34,10 +34,11 @@ def cfg_halpe():
 
 # Bounds of the interpenetration term at the cfg's values (sigma 1e-4, real surface), ~10 x the maxima observed on MI355X (round 6;
 # the session summary prints the observed maxima: tests/helpers.check_bound)
-TERM_LOSS_TOL = 2e-4
-TERM_VGRAD_TOL = 3e-3
-TERM_PGRAD_TOL = 3e-3
-TERM_INTOTAL_TOL = 5e-3
+# observed (gpurun, round 6): loss 1.8e-7, vertex gradient 5.8e-5, parameter gradient 2.1e-4, the term inside the total 6.6e-5
+TERM_LOSS_TOL = 2e-5
+TERM_VGRAD_TOL = 1e-3
+TERM_PGRAD_TOL = 2e-3
+TERM_INTOTAL_TOL = 7e-4
 
 
 def _oracle_jt(model, cfg, frames, i, params, gv, dtype=torch.float64):
@@ -108,8 +109,8 @@ def test_operator_on_the_real_surface(topo_model, cfg_halpe):
         un, both = _unordered(op)
         assert both and np.array_equal(un, pairs), (b, len(un), len(pairs))           # the pair SET, bit for bit
         assert np.bincount(pairs.reshape(-1)).max() < cfg_halpe["max_collisions"]     # the cap never binds on a body
-        H.check_bound("topology-operator", "loss", abs(loss[b] - lo) / max(abs(lo), 1e-30), 2e-4)
-        H.check_bound("topology-operator", "vertex gradient", np.linalg.norm(dv[b] - go) / max(np.linalg.norm(go), 1e-30), 3e-3)
+        H.check_bound("topology-operator", "loss", abs(loss[b] - lo) / max(abs(lo), 1e-30), 2e-5)         # observed 1.9e-6
+        H.check_bound("topology-operator", "vertex gradient", np.linalg.norm(dv[b] - go) / max(np.linalg.norm(go), 1e-30), 1.5e-3)      # observed 1.2e-4
         n_pairs.append(len(pairs))
     assert n_pairs[0] > 300 and max(n_pairs) > 500, n_pairs      # (the rest pose's 850 pairs minus what the mean hand pose opens)
     # a mesh's result does not depend on its neighbours in the batch
@@ -118,11 +119,13 @@ def test_operator_on_the_real_surface(topo_model, cfg_halpe):
     pen.close()
 
 
+@H.requires_lab()
 def test_the_three_forms_of_the_term_give_the_same_bits(topo_model, cfg_halpe):
-    """Round 5: one workgroup per column behind the accepted pairs (k_pen_narrow, form 1, the default) against the ten general
-    kernels of rounds 2-4 (form 0), against form 1 handing every column to them (form 2) and against one workgroup per column
-    behind the triangle boxes (k_pen_frame, form 3): pair list, statistics, loss and every vertex' gradient bit for bit -- on posed bodies, with a cap that binds (max_collisions 4:
-    cut lists, pairs only one side kept), and with point2plane."""
+    """LAB build: the product's form of the step (form 0: the general kernels on every column) against one workgroup per column
+    behind the accepted pairs (k_pen_narrow, form 1) and against form 1 handing every column to the general kernels (form 2): pair
+    list, statistics, loss and every vertex' gradient bit for bit -- on posed bodies, with a cap that binds (max_collisions 4: cut
+    lists, pairs only one side kept), and with point2plane.  (Round 5's form 3, one workgroup per column behind the triangle boxes,
+    passed the same test until it was deleted in round 6.)"""
     parts = synthetic.topology_parts()
     faces = np.asarray(topo_model["f"]).astype(np.int64)
     B = 5
@@ -132,7 +135,7 @@ def test_the_three_forms_of_the_term_give_the_same_bits(topo_model, cfg_halpe):
     try:
         for cap, p2p in ((128, False), (4, False), (128, True)):
             res = {}
-            for form in (0, 1, 2, 3):
+            for form in (0, 1, 2):
                 engine.pen_form(form)
                 pen = engine.Penetration(vb.shape[1], faces, parts["segm"], parts["parents"], cfg_halpe["ign_part_pairs"],
                                          max_collisions=cap, max_batch=B)
@@ -143,7 +146,7 @@ def test_the_three_forms_of_the_term_give_the_same_bits(topo_model, cfg_halpe):
                 pen.close()
             if cap == 4:
                 assert res[1][3]["dropped"].min() > 0               # the cap binds on every body
-            for form in (1, 2, 3):
+            for form in (1, 2):
                 assert np.array_equal(res[form][0], res[0][0]), (cap, p2p, form, res[form][0], res[0][0])
                 assert np.array_equal(res[form][1], res[0][1]), (cap, p2p, form)
                 for b in range(B):
@@ -158,7 +161,7 @@ def test_the_three_forms_of_the_term_give_the_same_bits(topo_model, cfg_halpe):
         assert (n_un > 700).any() and (n_un <= 700).any(), n_un
         os.environ["SFX_PEN_FAST_PAIRS"] = "700"
         try:
-            for form in (1, 3):
+            for form in (1,):
                 engine.pen_form(form)
                 pen = engine.Penetration(vb.shape[1], faces, parts["segm"], parts["parents"], cfg_halpe["ign_part_pairs"], max_collisions=128, max_batch=B)
                 for _ in range(2):
@@ -299,7 +302,8 @@ def test_closure_on_the_real_surface(topo_model, cfg_halpe):
             # vertex gradient on the device's own vertices
             g_term = grad[i].astype(np.float64) - grad0[i].astype(np.float64)
             g_ref = _oracle_jt(model, cfg, frames, i, P, float(cfg["coll_loss_weights"][stage]) * gv)
-            assert np.linalg.norm(g_ref) > 1e-3 * np.linalg.norm(grad0[i]), (np.linalg.norm(g_ref), np.linalg.norm(grad0[i]))
+            # (the difference of two fp32 gradients carries ~1e-7 of the plain gradient's length: it must not drown the term's)
+            assert np.linalg.norm(g_ref) > 1e-4 * np.linalg.norm(grad0[i]), (stage, i, np.linalg.norm(g_ref), np.linalg.norm(grad0[i]))
             H.check_bound("topology-halpe-closure", "term parameter gradient", np.linalg.norm(g_term - g_ref) / np.linalg.norm(g_ref),
                           TERM_PGRAD_TOL)
             H.check_bound("topology-halpe-closure", "term loss in the closure total",
@@ -344,33 +348,31 @@ def test_fit_on_the_real_surface_is_reproducible_and_pool_independent(topo_model
     r2, w2 = fit(5)
     assert np.all(np.isfinite(r0["stage_loss"])) and w0["columns"] > 0 and w0["pairs"] > 0, w0
     assert w0["walks_cut"] == 0, w0          # (lists beyond 2 x max_collisions occur in trial steps of the line search: derived from the grid again, exact)
-    # the other forms of the term (one workgroup per column behind the pair tests) fit the same bits
-    prev = engine.pen_form(1)
-    try:
-        dm_old = T._dm(model, cfg)
-        dm_old.set_parts(parts["segm"], parts["parents"], cfg["ign_part_pairs"])
-        keep, dm = dm, dm_old
-        r3, w3 = fit(0)
-        dm = keep
-        dm_old.close()
-    finally:
-        engine.pen_form(prev)
-    for k in r0:
-        assert np.array_equal(np.asarray(r0[k]), np.asarray(r3[k])), ("form 1", k)
-    assert (w3["pairs"], w3["columns"], w3["entries"]) == (w0["pairs"], w0["columns"], w0["entries"]), (w0, w3)
-    # round 5's two ways of launching the same kernels: a grid row per column of the call instead of rows that loop over the list of
-    # columns carrying the term (SFX_PEN_ROWS_OFF), and the columns in two shares on two streams (SFX_PEN_BRANCHES=2; read when
-    # the batch's operator is created) -- a column's numbers depend on neither
-    import os
-    for var, val in (("SFX_PEN_ROWS_OFF", "1"), ("SFX_PEN_BRANCHES", "2")):
-        os.environ[var] = val
+    if H.has_lab():
+        # LAB build: the other form of the term (one workgroup per column behind the pair tests) fits the same bits
+        prev = engine.pen_form(1)
+        try:
+            dm_old = T._dm(model, cfg)
+            dm_old.set_parts(parts["segm"], parts["parents"], cfg["ign_part_pairs"])
+            keep, dm = dm, dm_old
+            r3, w3 = fit(0)
+            dm = keep
+            dm_old.close()
+        finally:
+            engine.pen_form(prev)
+        for k in r0:
+            assert np.array_equal(np.asarray(r0[k]), np.asarray(r3[k])), ("form 1", k)
+        assert (w3["pairs"], w3["columns"], w3["entries"]) == (w0["pairs"], w0["columns"], w0["entries"]), (w0, w3)
+        # ... and so does a grid row per column of the call instead of rows that loop over the list of columns carrying the term
+        import os
+        os.environ["SFX_PEN_ROWS_OFF"] = "1"
         try:
             r4, w4 = fit(0)
         finally:
-            del os.environ[var]
+            del os.environ["SFX_PEN_ROWS_OFF"]
         for k in r0:
-            assert np.array_equal(np.asarray(r0[k]), np.asarray(r4[k])), (var, k)
-        assert (w4["pairs"], w4["columns"], w4["entries"]) == (w0["pairs"], w0["columns"], w0["entries"]), (var, w0, w4)
+            assert np.array_equal(np.asarray(r0[k]), np.asarray(r4[k])), ("SFX_PEN_ROWS_OFF", k)
+        assert (w4["pairs"], w4["columns"], w4["entries"]) == (w0["pairs"], w0["columns"], w0["entries"]), (w0, w4)
     assert {"stage_loss", "stage_evals", "betas", "global_orient", "body_pose", "left_hand_pose"} <= set(r0)
     for k in r0:
         assert np.array_equal(np.asarray(r0[k]), np.asarray(r1[k])), k

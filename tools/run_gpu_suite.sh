@@ -1,6 +1,13 @@
-# the whole GPU suite, then the default bench line and the configs[3] single-GPU job (the two-workgroups-per-CU tick kernel)
-cd $GRAFT_REPO_ROOT
-python -m pytest tests -x -q -m gpu 2>&1 | tail -4
-python bench.py --steps 10 --warmup 2 > gpurun_out/s_default.json 2> gpurun_out/s_default.err
-python -c "
-import json; d=json.load(open('gpurun_out/s_default.json')); print('default', d['value'], d['roofline_tick']['avg_launch_us'], d['roofline']['avg_launch_us'], d['config'].get('configs3_single_gpu_frames_per_s'))"
+#!/bin/bash
+# The GPU suite on BOTH builds of the library (GPU box):
+#   1. product  libsfx.so      -- what ships; the tests of interchangeable forms / environment switches skip
+#   2. lab      libsfx_lab.so  -- the same source with -DSFX_LAB (include/sfx_lab.h): those tests run, everything else runs again
+# usage: tools/run_gpu_suite.sh [pytest args]      (both libraries must have been built: python __graft_entry__.py)
+set -u
+cd "$(dirname "$0")/.."
+echo "== product build (libsfx.so)"
+python -m pytest tests -m gpu -q "$@"; rc1=$?
+echo "== lab build (libsfx_lab.so)"
+SFX_LIB="$PWD/smplify-x-partial_amd/libsfx_lab.so" python -m pytest tests -m gpu -q "$@"; rc2=$?
+echo "product rc=$rc1 lab rc=$rc2"
+exit $(( rc1 != 0 || rc2 != 0 ))
