@@ -130,6 +130,7 @@ extern "C" int sfx_pen_pairs(sfx_pen* h, int32_t mesh, int32_t cap, int32_t* pai
 int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sigma, int32_t penalize_outside,
                         float* loss_dev, float* dverts_dev, const int* want_dev, const PenAdjPrep* prep, int* over_dev, void* stream);
 int sfx_pen_capacity(const sfx_pen* h);          // meshes per call the handle's buffers hold (collide.hip)
+void sfx_pen_note_batch(sfx_pen* h, int B);      // meshes of the evaluation a replayed graph performs
 int sfx_pen_stats_from(const int* stats_dev, int n, int32_t* stats_host);
 int sfx_pen_stats_stride(void);
 const int* sfx_pen_stats_dev(const sfx_pen* h);
@@ -1016,6 +1017,7 @@ static int eval_penetration(sfx_batch* b, int stage_override, hipStream_t s, boo
             if (ei != hipSuccess) { sfx_set_error("hipGraphInstantiate failed"); return -2; }
             it = b->pen_graphs.emplace(D.nact, exec).first;
         }
+        sfx_pen_note_batch(b->pen, D.nact);
         SFX_CHECK(hipGraphLaunch(it->second, s));
         return 0;
     }

@@ -191,6 +191,7 @@ extern "C" int sfx_pen_work_get(int64_t* out /* [6] */) {
 struct sfx_pen {
     PenDev P{};
     int Bmax = 0;
+    int last_B = 0;              // meshes of the most recent evaluation: what sfx_pen_pairs / sfx_pen_stats may be asked about
     int form = 0;                // (lab build: sfx_debug_pen_form; the product has one form)
     std::vector<void*> mem;
     template <typename T> T* up(const std::vector<T>& h) {
@@ -293,8 +294,8 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
 #ifdef SFX_LAB
     { const char* e = getenv("SFX_PEN_FAST_PAIRS"); if (e && atoi(e) > 0) P.pf_cap = std::min(P.pf_cap, atoi(e)); }      // (measurement switch: columns with more pairs go to the general kernels)
 #endif
-    P.fast_ok = ((unsigned long long)F * (unsigned long long)F < (1ull << 32)) && (2 * ((F + 31) / 32) + (V + 31) / 32 + V <= PEN_GRID_INTS) &&
-                (size_t)2 * PEN_FP <= (size_t)P.pair_cap ? 1 : 0;
+    P.pf_cap = std::max(1, std::min(P.pf_cap, P.pair_cap / 2));      // (a mesh's pair list holds both orders of every pair the one-workgroup form accepts: small meshes too)
+    P.fast_ok = ((unsigned long long)F * (unsigned long long)F < (1ull << 32)) && (2 * ((F + 31) / 32) + (V + 31) / 32 + V <= PEN_GRID_INTS) ? 1 : 0;
     if (!P.heavy || !P.hlist || !P.nheavy || !P.pcnt || !P.wl || !P.nw || !P.rb || !P.nrb || !P.lq || !P.nlq) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.cells || !P.gridp || !P.tgrad || !P.tloss || !P.tcount || !P.pbox || !P.gpart || !P.aabb || !P.entries) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
     if (!P.stats || !P.pout || !P.plist || !P.pown || !P.poff || !P.partners || !P.pavail || !P.ptotal || !P.ovq || !P.ovn || !P.callno || !P.ovm) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
@@ -303,6 +304,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
 }
 
 int sfx_pen_capacity(const sfx_pen* h) { return h ? h->Bmax : 0; }
+void sfx_pen_note_batch(sfx_pen* h, int B) { if (h) h->last_B = B; }      // (a replayed graph of the step: api.hip eval_penetration)
 
 extern "C" int sfx_pen_set_point2plane(sfx_pen* h, int32_t on) {
     if (!h) { sfx_set_error("null handle"); return -1; }
@@ -391,6 +393,7 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
     if (B < 1 || B > h->Bmax) { sfx_set_error("batch %d exceeds the capacity %d given to sfx_pen_create", B, h->Bmax); return -1; }
     if (!(sigma > 0.f)) { sfx_set_error("df_cone_height must be positive"); return -1; }
     hipStream_t s = (hipStream_t)stream;
+    h->last_B = B;
     return pen_eval_cols(h, h->P, B, verts_dev, sigma, penalize_outside, loss_dev, dverts_dev, want_dev, prep, over_dev, s);
 }
 
@@ -444,7 +447,8 @@ extern "C" int sfx_pen_eval_pairs(sfx_pen* h, int32_t B, const float* verts_dev,
     if (!h || !verts_dev || !loss_dev || !dverts_dev || (n_pairs > 0 && !pairs_dev)) { sfx_set_error("null argument"); return -1; }
     if (B < 1 || B > h->Bmax) { sfx_set_error("batch %d exceeds the capacity %d given to sfx_pen_create", B, h->Bmax); return -1; }
     if (!(sigma > 0.f) || n_pairs < 0) { sfx_set_error("bad arguments"); return -1; }
-    if (!h->P.fast_ok) { sfx_set_error("mesh too large for the stand-alone pair evaluation (one workgroup sorts a mesh's pairs in LDS)"); return -1; }
+    if (!h->P.fast_ok) { sfx_set_error("mesh too large for the stand-alone pair evaluation (one workgroup holds a mesh's bit sets and vertex list in LDS: V + F / 16 <= %d; F < 65536)", PEN_GRID_INTS); return -1; }
+    h->last_B = B;
     hipStream_t s = (hipStream_t)stream;
     const size_t narrow_lds = (size_t)(2 * PEN_FP + 2 * h->P.hasp_words + (h->P.V + 31) / 32 + h->P.V) * sizeof(int);
     if (hipFuncSetAttribute((const void*)k_pen_narrow<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
@@ -486,6 +490,7 @@ const int* sfx_pen_stats_dev(const sfx_pen* h) { return h ? h->P.stats : nullptr
 // loss in the reference (fitting.py:445-450) -- here both orders of every pair.
 extern "C" int sfx_pen_pairs(sfx_pen* h, int32_t mesh, int32_t cap, int32_t* pairs_host, int32_t* n_out) {
     if (!h || !n_out || mesh < 0 || mesh >= h->Bmax || cap < 0 || (cap > 0 && !pairs_host)) { sfx_set_error("bad arguments"); return -1; }
+    if (mesh >= h->last_B) { sfx_set_error("mesh %d was not part of the most recent evaluation (%d meshes): its pair list is stale", mesh, h->last_B); return -1; }
     if (hipDeviceSynchronize() != hipSuccess) { sfx_set_error("device error"); return -4; }
     int tot = 0;
     if (hipMemcpy(&tot, h->P.ptotal + mesh, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { sfx_set_error("device error"); return -4; }

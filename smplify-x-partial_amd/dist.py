@@ -39,6 +39,19 @@ def shard_range(n_frames, rank, world):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def shard_by_cost(cost, rank, world):
+    """Frame indices of `rank` when the frames KNOWN to be long (driver.predicted_cost: side views are fitted twice, frames with
+    an under-determined camera take 2-3 x the evaluations) are dealt round-robin instead of landing on one GPU with their
+    contiguous block: frames in order of predicted cost (longest first, stable), dealt to the ranks back and forth (0 .. world-1,
+    world-1 .. 0, ...) so that the rank that got the longest frame of a pass gets the shortest of the next.  Sizes differ by at
+    most one; returned ascending, so a rank still walks its frames in input order."""
+    order = np.argsort(-np.asarray(cost, np.float64), kind="stable")
+    pos = np.arange(len(order))
+    q = pos % (2 * world)
+    owner = np.where(q < world, q, 2 * world - 1 - q)
+    return np.sort(order[owner == rank])
+
+
 def pack_records(res, first_frame, fields=None):
     """dict of [B,.] arrays (driver.fit_frames) -> float64 [B, record length]."""
     fields = record_fields(res) if fields is None else fields

@@ -12,7 +12,7 @@ schedule of all of them runs on the GPU at once -- and the same files are writte
     <output_folder>/images/<fn>/<person:03d>/                  (created, as in the reference)
 
 With torch.distributed initialised (one process per GPU), rank r takes the frames
-dist.shard_range gives it; there is no collective in the data path (each rank writes its own
+dist.shard_by_cost gives it (known stragglers dealt round-robin); there is no collective in the data path (each rank writes its own
 result files).
 """
 import os
@@ -133,8 +133,12 @@ def main(**args):
             img_name = data["img_path"].split("images")[-1].split(".")[0].lstrip("/\\")
             items.append(dict(fn=data["fn"], person=person_id, H=H_, W=W_, img_name=img_name,
                               keypoints=keypoints[person_id], gender=input_gender))
-    lo, hi = sdist.shard_range(len(items), rank, world)
-    items = items[lo:hi]
+    if world > 1 and items:
+        # this rank's share: the frames known to be long before the fit (driver.predicted_cost) are dealt round-robin over the
+        # ranks -- a contiguous block (dist.shard_range) can hand one GPU all the side views of a sequence
+        kp_all = np.stack([it["keypoints"] for it in items]).astype(np.float32)
+        cost = driver.predicted_cost(args, driver.prepare_frames(args, kp_all, joint_weights))
+        items = [items[i] for i in sdist.shard_by_cost(cost, rank, world)]
     groups = {}
     for it in items:
         groups.setdefault((it["gender"], it["H"], it["W"]), []).append(it)

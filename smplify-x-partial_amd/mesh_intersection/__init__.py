@@ -9,3 +9,4 @@ they do what the package's modules do, on the same device operator, so that fitt
 FilterFaces(collision_idxs) -> filtered tensor, DistanceFieldPenetrationLoss(triangles, collision_idxs) -> loss [B],
 differentiable with respect to the triangles."""
 from . import bvh_search_tree, filter_faces, loss  # noqa: F401
+from ._operator import set_faces  # noqa: F401

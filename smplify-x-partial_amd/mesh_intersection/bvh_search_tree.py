@@ -12,9 +12,11 @@ class BVH(nn.Module):
     of triangles (boxes overlap, no shared vertex; each unordered pair once, lower id first, sorted), -1 where empty.  A triangle
     with more than max_collisions partners keeps its lowest ids (oracle/penetration.py assumption A1)."""
 
-    def __init__(self, max_collisions=8):
+    def __init__(self, max_collisions=8, faces=None):
         super().__init__()
         self.max_collisions = int(max_collisions)
+        if faces is not None:                       # (not an argument of the package: spares the topology recovery)
+            _operator.set_faces(faces)
 
     def forward(self, triangles):
         op, verts = _operator.operator_for(triangles, self.max_collisions)

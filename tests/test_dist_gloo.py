@@ -40,6 +40,14 @@ def test_shard_and_gather_world2(tmp_path):
     n = 7                                   # ragged: 4 + 3
     assert [sd.shard_range(n, r, 2) for r in range(2)] == [(0, 4), (4, 7)]
     assert [sd.shard_range(8192, r, 8) for r in range(8)][3] == (3072, 4096)
+    # the cost-ordered deal: every frame to exactly one rank, sizes within one, the long frames spread evenly
+    cost = np.ones(37); cost[[3, 4, 5, 6, 30, 31]] = 2.5; cost[[10, 11]] = 5.0
+    shares = [sd.shard_by_cost(cost, r, 4) for r in range(4)]
+    assert sorted(np.concatenate(shares).tolist()) == list(range(37))
+    assert max(len(s_) for s_ in shares) - min(len(s_) for s_ in shares) <= 1 and all(np.all(np.diff(s_) > 0) for s_ in shares)
+    loads = [cost[s_].sum() for s_ in shares]
+    contiguous = [cost[slice(*sd.shard_range(37, r, 4))].sum() for r in range(4)]
+    assert max(loads) < max(contiguous) and max(loads) - min(loads) < max(contiguous) - min(contiguous), (loads, contiguous)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker, args=(2, port, n, str(tmp_path)), nprocs=2, join=True)
     want = sd.pack_records(_fake_fit(0, n), 0)
