@@ -120,10 +120,10 @@ struct PenDev {
     int* ovm;                  // [1 + B] meshes of this evaluation whose overflow queue k_pen_rank has to drain: count (k_pen_g1 -> 0), ids (k_pen_list)
     int* over;                 // [B] or NULL (set per call): 1 = this evaluation of the mesh kept partners by ARRIVAL order somewhere (a list beyond
                                //     2 x max_collisions, a cut walk): its numbers are not reproducible run to run
-    // round 5: the per-frame kernel (k_pen_frame) and the columns it hands to the general kernels
+    // the one-workgroup-per-mesh path (k_pen_narrow: stand-alone pair evaluation; lab forms 1 / 2) and the columns it hands to the general kernels
     int* heavy;                // [B] 1 = this evaluation of the column goes through the general kernels (crowded grid / too many pairs for one workgroup's LDS)
     int* hlist;                // [B] the heavy columns of this evaluation, any order
-    int* nheavy;               // [1] their number (k_pen_g1 -> 0, k_pen_frame appends)
+    int* nheavy;               // [1] their number (k_pen_g1 -> 0, k_pen_narrow appends)
     float* wbox;               // [B][n_clus][6] boxes of the clusters of 64 consecutive triangles (k_pen_g1: one DPP reduction per wavefront)
     const unsigned long long* cpm;   // [n_clus] parts present in a cluster, one bit each (static)
     int n_clus;                // (F + 63) / 64
@@ -142,7 +142,7 @@ struct PenDev {
 };
 
 // Which columns a kernel of the general path works on.  hlist == NULL (the ten-kernel form, SFX / sfx_debug_pen_form 0): column
-// blockIdx.y of the call, masked by `want`.  hlist != NULL (round 5): the compact list of columns k_pen_frame has handed over
+// blockIdx.y of the call, masked by `want`.  hlist != NULL (round 5): the compact list of columns k_pen_narrow has handed over (lab forms 1 / 2)
 // ("heavy": a crowded grid or more pairs than one workgroup's LDS sorts), *nheavy of them -- the grid's rows loop over the list,
 // and a launch that finds it empty (nearly every one) ends after one load.
 struct PenSel { const int* want; const int* hlist; const int* nheavy; const int* heavy; };
@@ -280,13 +280,7 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
     h->form = g_pen_form;
 #endif
     P.n_clus = (F + 63) / 64;
-    {
-        std::vector<unsigned long long> cpm(P.n_clus, 0ull);
-        for (int f = 0; f < F; ++f) cpm[f >> 6] |= 1ull << sg[f];
-        P.cpm = h->up(cpm);
-        P.wbox = h->zeros<float>(B * P.n_clus * 6);
-        if (!P.cpm || !P.wbox) { sfx_set_error("out of device memory"); for (void* p : h->mem) hipFree(p); delete h; return -2; }
-    }
+    P.cpm = nullptr; P.wbox = nullptr;        // (cluster boxes: only round 5's k_pen_frame read them)
     P.heavy = h->zeros<int>(B); P.hlist = h->zeros<int>(B); P.nheavy = h->zeros<int>(1); P.pcnt = h->zeros<int>(B);
     P.wl = h->zeros<int>(B); P.nw = h->zeros<int>(1); P.rb = h->zeros<int>((size_t)B * P.n_clus); P.nrb = h->zeros<int>(B); P.lq = h->zeros<int>((size_t)B * F); P.nlq = h->zeros<int>(B);
     P.pbuf = reinterpret_cast<int2*>(P.partners);         // (the partner lists are unused on the fast path)

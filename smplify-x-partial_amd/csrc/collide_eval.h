@@ -19,7 +19,7 @@
 // gains the path through both unit normals.  A lane (f, g) owns d / d (vertices of f): its own cone's terms (1) and the terms
 // of g's cone at its vertices (2) both depend on n_f through c.
 // One ordered pair (f receives g): the loss this lane owns and its gradient with respect to f's nine coordinates -> v[0..8], v[9].
-// Shared by k_pen_eval and k_pen_frame; this file is compiled with -ffp-contract=off, so the two instances perform the same
+// Shared by k_pen_eval and pen_narrow; this file is compiled with -ffp-contract=off, so the two instances perform the same
 // fp32 operations in the same order whatever surrounds them (a fused multiply-add chosen in one context and not in the other
 // would make the two forms of the term differ in the last bit).
 template <bool P2P>
@@ -162,7 +162,7 @@ void k_pen_eval(PenDev P, const float* __restrict__ verts, float sigma, int pena
 // a range adds the (1 + range / 64) chunk sums in ascending order.
 // (Round 4 tried these sums inside k_pen_gather, per incident corner: one launch fewer, but every corner then walks two
 //  dependent loads and its chunk loop on the lane's own chain -- 75 us against 36 + 11 for the two kernels.  Kept apart.)
-// the sums of one triangle's pair range [i, i + n) from the run sums k_pen_eval / k_pen_frame left per 64-pair chunk of the list
+// the sums of one triangle's pair range [i, i + n) from the run sums k_pen_eval / pen_narrow left per 64-pair chunk of the list
 __device__ __forceinline__ void pen_face_sum(const float* __restrict__ po, const int pair_cap, const int i, const int n, float* __restrict__ tg /* [9] */,
                                              float* __restrict__ tl) {
     float acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -199,7 +199,7 @@ void k_pen_facesum(PenDev P, PenSel sel) {
 // triangles in index order (independent of where a pair sits in the list).  When the caller is a fitting batch the lane
 // that has formed g(v) goes on to d v_posed = T^T g, the operand of the adjoint GEMM (a launch of its own, k_adj_prep,
 // until round 4).
-// g(v) of one vertex and what follows from it (shared by k_pen_gather, every vertex, and k_pen_frame, the vertices of triangles
+// g(v) of one vertex and what follows from it (shared by k_pen_gather, every vertex, and pen_narrow, the vertices of triangles
 // that have pairs -- the others' rows are zeroed by k_pen_g1).  s_hasp: the frame's "triangle has pairs" bits in LDS.
 __device__ __forceinline__ void pen_vertex_out(const PenDev& P, const int b, const int v, const int total, const unsigned* s_hasp,
                                                float* __restrict__ dverts, const PenAdjPrep& ap) {
@@ -304,36 +304,22 @@ void k_pen_gather(PenDev P, float* __restrict__ dverts, float* __restrict__ loss
 }
 
 // =============================================================================================
-// Round 5: the whole term of ONE column behind the triangle boxes in one workgroup.
-//
-// On the mesh the reference evaluates (the SMPL-X topology with smplx_parts_segm.pkl; tests/golden/smplx_topology.npz) the part
-// boxes turn away 88 % of the triangles before the grid, ~2 500 survivors make ~6 200 grid entries and ~1 700 ordered pairs per
-// evaluation: two orders of magnitude below what the ten general kernels above are dimensioned for, each of which paid a launch,
-// a pass over all F triangles or V vertices, and its own round trips (k_pen_g2 41 us, k_pen_g3 25, k_pen_walk 29 + 20,
-// k_pen_list 17, k_pen_rank 60, k_pen_eval 12, k_pen_facesum 8, k_pen_gather 28 = 240 us per round of the halpe cfg's fit).
-// k_pen_frame does the same steps for a column with the column's data in LDS:
-//   A  part culling + one (triangle, cell) record per cell of a survivor's box     (k_pen_g2: coalesced pass over the F boxes)
-//   B  counting sort of the records into the hashed grid                           (k_pen_g3, unchanged: 2 x 64 KB of LDS)
-//   C  pair tests, a block of 64 entries per wavefront, 16 wavefronts              (k_pen_walk's chunk walk; bucket ends from LDS)
-//      accepted pairs -> one list of the frame (global scratch; the per-triangle partner lists are not used)
+// One workgroup per mesh from the accepted pairs to the outputs (pen_narrow / k_pen_narrow) -- the stand-alone pair evaluation
+// (sfx_pen_eval_pairs: DistanceFieldPenetrationLoss on pairs the caller supplies) and, in the lab build, forms 1 / 2 of the fitting
+// loop's step.  On the mesh the reference evaluates, the part boxes turn away 88 % of the triangles before the grid, ~2 500 survivors
+// make ~2 000 grid entries and ~1 700 ordered pairs per evaluation, which one workgroup holds in LDS:
 //   D  both orders of every pair as 32-bit keys f * F + g, bitonic sort in LDS, rank within a triangle's run: the max_collisions
-//      LOWEST partners are kept -> the frame's pair list, triangles ascending, partners ascending   (k_pen_list + k_pen_rank)
+//      LOWEST partners are kept -> the mesh's pair list, triangles ascending, partners ascending   (k_pen_list + k_pen_rank)
 //   E  pair evaluation per 64-aligned chunk of that list (pen_pair_eval, pen_run_sums: the general kernels' functions)
 //   F  per-triangle sums (pen_face_sum)
-//   G  gradient of the vertices of triangles that have pairs (pen_vertex_out) -- the other rows were zeroed by k_pen_g1 --,
-//      d v_posed = T^T g, the frame's loss (pen_frame_loss_partial)
-// Every number is formed by the same fp32 operations in the same order as in the ten-kernel form (sfx_debug_pen_form(0)): the
-// pair list is canonical, the sums are defined on it; tests/test_gpu_topology.py, tests/test_gpu_penetration.py compare bit for bit.
-// A column that does not fit -- more than PEN_FE grid entries, a bucket beyond PEN_FB entries (a limb pushed through another by a
-// trial step of the line search), more than PEN_FP pairs -- is handed to the general kernels ("heavy": P.heavy / P.hlist), which
-// run on the compact list of such columns and end after one load when it is empty.
-#define PEN_FE 16384            // grid entries of a column on the fast path
-#define PEN_FB 256              // longest bucket on the fast path (chunks 0..3 of a block's walk)
+//   G  gradient of the vertices of triangles that have pairs (pen_vertex_out), d v_posed = T^T g, the mesh's loss
+// Every number is formed by the same fp32 operations in the same order as in the general kernels: the pair list is canonical, the
+// sums are defined on it (tests/test_gpu_topology.py, tests/test_gpu_penetration.py compare bit for bit on the lab build).  A mesh
+// with more than PEN_FP pairs does not fit (P.heavy / P.hlist: the lab forms hand it to the general kernels, the stand-alone
+// evaluation reports it).  (Round 5's k_pen_frame -- the grid build and the pair tests in the same workgroup, phases A-C -- lost to
+// the flat kernels on whole fits, 145 against 332 frames/s, and was deleted in round 6: LAB_NOTES.md.)
 #define PEN_FP 8192             // unordered pairs on the fast path: 2 x PEN_FP sort keys = 64 KB of LDS
 #define PEN_FW 16               // wavefronts of the workgroup
-#ifndef PEN_AU
-#define PEN_AU 1               // (4 faulted with a memory access error on the device -- not understood; 2 ran and changed nothing)
-#endif
 
 __device__ __forceinline__ int pen_block_excl_scan_max(const int v, int* wmax /* [PEN_T / 64] */) {      // exclusive prefix MAX over the block's lanes (values >= -1)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -351,7 +337,7 @@ __device__ __forceinline__ int pen_block_excl_scan_max(const int v, int* wmax /*
 
 // Phases D-G of the per-column work: from the column's accepted pairs (P.pbuf, any order) to the pair list, the pair evaluation,
 // the per-triangle sums, the gradient of the vertices that have one, d v_posed and the frame's loss -- one workgroup of PEN_T lanes,
-// everything between the pair buffer and the outputs in LDS.  Shared by k_pen_narrow (round 5's default form) and k_pen_frame.
+// everything between the pair buffer and the outputs in LDS.  Used by k_pen_narrow.
 struct PenNarrowLds { unsigned* keys /* [2 PEN_FP] */; unsigned* bits /* [2 hasp_words + (V + 31) / 32 + V] */; int* slice /* [PEN_T] */; float* red /* [PEN_T / 64] */; int* dead; };
 template <bool P2P, class MARK>
 __device__ __forceinline__ void pen_narrow(const PenDev& P, const int b, const int npairs, const PenNarrowLds L, const float* __restrict__ verts,
@@ -503,7 +489,7 @@ __device__ __forceinline__ void pen_narrow(const PenDev& P, const int b, const i
 
 // Round 5's default form: the grid build and the pair tests stay spread over the chip (k_pen_g1 / g2 / g3, k_pen_walk / walk2 --
 // the tests are matrix-free ALU work, ~50 instructions per candidate and 10^4-10^5 candidates per column: one compute unit
-// needs 70-150 us for a column's, measured in k_pen_frame), the accepted pairs land in one list per column, and ONE workgroup per
+// needs 70-150 us for a column's, measured in round 5's k_pen_frame), the accepted pairs land in one list per column, and ONE workgroup per
 // column does everything behind them (pen_narrow) -- what k_pen_list, k_pen_rank, k_pen_eval, k_pen_facesum and k_pen_gather did
 // with a pass over all F triangles or V vertices and a launch each.  A column with more pairs than the LDS sort holds (2 x PEN_FP
 // keys) is handed to those kernels (P.heavy / P.hlist), which redo its pair tests into the partner lists.
@@ -518,7 +504,7 @@ void k_pen_narrow(PenDev P, const float* __restrict__ verts, const float sigma, 
     const int b = blockIdx.x, t = threadIdx.x;
     int* st = P.stats + b * PEN_STATS;
     const long long t_start = wall_clock64();
-    int n_mark = 3;                             // (stats[7..10]: the stamps of phases D-G, as in k_pen_frame)
+    int n_mark = 3;                             // (stats[7..10]: the stamps of phases D-G)
     auto mark = [&]() { if (t == 0) st[4 + n_mark] = (int)(wall_clock64() - t_start); ++n_mark; };
     const int wanted = want ? want[b] : 1, npairs = P.pcnt[b], overflow = st[2], cut = st[13];
     if (t == 0) { P.heavy[b] = 0; P.wqn[b] = 0; s_dead = 0; }      // (the chunk queue is consumed: the general kernels start from an empty one)

@@ -29,7 +29,7 @@ __device__ __forceinline__ bool pen_gw_map(const int nb, int& b, int& w) {
 __device__ __forceinline__ int pen_bucket(int x, int y, int z) {
     return (int)(((unsigned)x * 73856093u ^ (unsigned)y * 19349663u ^ (unsigned)z * 83492791u) & (PEN_CELLS - 1)); }
 
-// zero_dverts / zero_G (round 5, with k_pen_frame): the per-frame kernel writes the gradient of the vertices that HAVE one (a few
+// zero_dverts / zero_G (lab forms 1 / 2, k_pen_narrow): the per-column kernel writes the gradient of the vertices that HAVE one (a few
 // hundred of 10 475 on a body); the other rows of d loss / d vertices and of the adjoint GEMM's operand are zeroed here, by the
 // launch that has eight workgroups per column and nothing else to write but the boxes.
 #ifndef PEN_G1_OCC
@@ -107,7 +107,7 @@ void k_pen_g1(PenDev P, const float* __restrict__ verts, const int* __restrict__
             if (valid) ext_sum += fmaxf(fmaxf(c[0] - a[0], c[1] - a[1]), c[2] - a[2]);
             // part boxes: consecutive triangles mostly belong to one part -- a complete wavefront of one part reduces its 64
             // boxes on DPP and one lane updates the part's box.  The wavefront's own box -- a cluster of 64 consecutive triangles --
-            // is kept as well (round 5): k_pen_frame culls whole clusters against the part boxes before it looks at a triangle.
+            // was kept as well in round 5 (k_pen_frame culled whole clusters against the part boxes; P.wbox is NULL since round 6).
             const int s0 = __builtin_amdgcn_readfirstlane(seg[u]);
             const bool one_part = __ballot(!valid || seg[u] == s0) == ~0ull;
 #pragma unroll

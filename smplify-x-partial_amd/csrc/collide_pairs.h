@@ -333,7 +333,7 @@ void k_pen_walk2(PenDev P, int B, PenSel sel, int to_pbuf) {
     extern __shared__ int s_pref[];             // [B + 1] exclusive prefix of the meshes' queued chunks
     __shared__ int s_scan[256];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    if (sel.hlist && *sel.nheavy == 0) return;          // (only heavy columns queue chunks: k_pen_frame leaves the others' queues empty)
+    if (sel.hlist && *sel.nheavy == 0) return;          // (only heavy columns queue chunks: k_pen_narrow leaves the others' queues empty)
     if (t < 64) s_mask[t] = P.skipmask[t];
     const int n_items = pen_prefix(B, s_pref, s_scan, [&](int b_) { return min(P.wqn[b_], P.wq_cap); });
     PenWalkCtx W;
