@@ -1135,7 +1135,7 @@ def main():
                                    "lists_rederived_per_launch": pen_work["lists_overflowed"] / n_scopes_all,
                                    "walks_cut": pen_work["walks_cut"],
                                    "note": "twelve dependent kernels per round, one captured graph; bound by wavefront slots x dependent "
-                                           "round trips, not by bytes (DESIGN 4.6: two chains side by side take what one takes); E and P "
+                                           "round trips, not by bytes (LAB_NOTES §4.6: two chains side by side take what one takes); E and P "
                                            "are device counts over the timed region; per-kernel times and counters: profiles/r05_pen_*"}
             if pmc_ok:
                 tr = sum(v.get("hbm_read_bytes_per_launch", 0.0) + v.get("hbm_write_bytes_per_launch", 0.0) for k, v in pj.items()

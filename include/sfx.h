@@ -144,7 +144,7 @@ typedef struct sfx_batch_cfg {
                                        follows it (max_iter * 5 / 4, lbfgs_ls.py:203)                              */
     int32_t high_precision;         /* cfg float_dtype: float64 (main.py:99-105): besides the keypoint forward (always fp64) the
                                        projection up to the pixel residual is carried in fp64 in every stage -- gradient noise
-                                       0.13 x torch fp32's, the fits behave like the reference's float64 run;
+                                       0.13 x torch fp32's, the fits behave like the reference's float64 run (LAB_NOTES.md §3.1);
                                        parameters, reverse sweep and optimiser stay fp32                          */
     int32_t point2plane;            /* DistanceFieldPenetrationLoss(point2plane=True) (cmd_parser.py:239): see
                                        sfx_pen_set_point2plane                                                     */

@@ -146,7 +146,7 @@ struct sfx_model {
 };
 
 // The fused dense loop keeps `ahead` batches of 8 rounds queued beyond the one whose stage flags the host is waiting for: the
-// GPU only idles when the host thread stays away for longer than that much queued work.  Measured in round 4:
+// GPU only idles when the host thread stays away for longer than that much queued work.  Measured in round 4 (LAB_NOTES §4.6):
 // the host's own enqueueing is 4-7 % of the loop (7 us per round of 2 launches, 43 us per round of 13), so a captured graph
 // would save nothing on a quiet host; on a host whose 16 cores carry 32 spinning processes EVERY workload halves (body 509 ->
 // 239, interpenetration 349 -> 182 frames/s: the polling thread waits milliseconds for a time slice), and a deeper queue buys

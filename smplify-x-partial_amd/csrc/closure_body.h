@@ -26,7 +26,7 @@
 
 // Precision of the keypoint forward (rotations, rest joints, kinematic chain, keypoint skinning: fwd_t) and of the
 // projection up to the pixel residual (proj_t); see "forward precision" in closure_body.  Measured on the 64 + 64
-// reference fits of the benchmark configuration (evaluations per frame / signed mean final-loss
+// reference fits of the benchmark configuration (LAB_NOTES.md §3.1; evaluations per frame / signed mean final-loss
 // difference to the reference's fp32 run; the reference: 2 362 in fp32, 4 098 and -2.1 % in fp64):
 //   fwd fp64, proj fp64 : 3 221 / -1.7 %   gradient noise 0.13 x torch fp32's: keeps working where the reference stalls
 //   fwd fp64, proj fp32 : 2 482 / -0.4 %   <- built: never noisier than the reference, closest to it in loss and in work

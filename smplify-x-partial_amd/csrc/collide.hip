@@ -8,7 +8,7 @@
 // and its gradient with respect to the vertices.  Algorithm and formulas: oracle/penetration.py
 // (the package's source is absent: parity unpinned).
 //
-// MI355X design (not the package's LBVH; DESIGN.md 4.6 has the table):
+// MI355X design (not the package's LBVH; LAB_NOTES.md §4.6 has the table):
 //   k_pen_g1 / g2 / g3   triangle AABBs (8 x 1024 lanes per frame) -> bounding box per body part: a triangle
 //                 whose box meets the box of no part it may collide with is dropped, the survivors are
 //                 compacted (8 x 1024) -> they enter a uniform grid (cell = twice the mean triangle extent,

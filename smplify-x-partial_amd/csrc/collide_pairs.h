@@ -301,7 +301,7 @@ void k_pen_walk(PenDev P, PenSel sel, int to_pbuf, int flatB) {
     if (flatB > 0) {
         // (round 5) ONE flat list of the blocks over all columns of the call, a block per wavefront: a body's grid has ~30 blocks of 64
         // entries, and 128 workgroups per column -- sized for a mesh that has collapsed into itself -- sent 120 of them through two
-        // loads and out again, each holding a wavefront slot
+        // loads and out again, each holding a wavefront slot (LAB_NOTES §4.6)
         const int n_items = pen_prefix(flatB, s_wpref, s_wscan, [&](int b_) {
             return pen_sel_on(sel, b_) ? (P.cells[(size_t)b_ * (PEN_CELLS + 1) + PEN_CELLS] + 63) >> 6 : 0; });
         int b_prev = -1;
@@ -799,7 +799,7 @@ void k_pen_rank(PenDev P, PenSel sel, int cap_pad, int flatB) {
     // (round 5) ONE flat list of the blocks that HAVE pairs over all columns of the call (k_pen_list leaves them per column: P.rb /
     // P.nrb), a block per wavefront: a body's ~400 triangles with partners sit in ~30 of its 327 blocks, and a grid of 64
     // workgroups per column sent nine wavefronts in ten through three loads and out again, each holding a wavefront slot that
-    // a busy one was waiting for (the step is bound by slots x round trips)
+    // a busy one was waiting for (LAB_NOTES §4.6: the step is bound by slots x round trips)
     int* s_pref = s_sort + 4 * tcap;
     const int n_items = pen_prefix(flatB, s_pref, s_scan, [&](int b_) { return pen_sel_on(sel, b_) && P.ptotal[b_] > 0 ? P.nrb[b_] + P.nlq[b_] : 0; });
     const int n_rankers = ((int)gridDim.x - PEN_RANK_HELPERS) * 4;

@@ -175,7 +175,7 @@ void k_lbs_dense(DevModel M, BatchDev D) {
 // DIAGNOSTIC build only (tools/build_variant.sh mf32 lbs_dense -DMF32 -DNO_T): the K loop of the blend-shape GEMM on
 // v_mfma_f32_32x32x2_f32 -- wavefront tile 32 vertices x 32 frames, 3 x 16 accumulator registers, per K step of two rows
 // 1 A read + 3 B reads for 3 MFMAs -- against the same loop of k_lbs_dense built with -DNO_T (no skinning epilogue, a
-// checksum store).  Measured and rejected: DESIGN.md 4.5.  A operand staged k-major ([k][frame], +1 pad) so that the 32
+// checksum store).  Measured and rejected: LAB_NOTES.md §4.5.  A operand staged k-major ([k][frame], +1 pad) so that the 32
 // frames of an operand fetch hit 32 banks.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define VB2 32

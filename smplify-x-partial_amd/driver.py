@@ -135,7 +135,7 @@ POOL_COLUMNS = 512          # GEMM columns of the pool a job larger than this is
 def auto_slots(n_frames):
     """Default size of the column pool: jobs of up to POOL_COLUMNS frames are resident (one column per frame), larger ones queue
     through POOL_COLUMNS columns -- the columns a straggler would leave idle at the end of a resident run are refilled
-    (1 024 frames of the benchmark's generator: 710 frames/s resident, 830-840 through 512 columns)."""
+    (1 024 frames of the benchmark's generator: 710 frames/s resident, 830-840 through 512 columns, LAB_NOTES §4.4)."""
     return 0 if n_frames <= POOL_COLUMNS else POOL_COLUMNS
 
 

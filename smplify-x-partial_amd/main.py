@@ -91,7 +91,7 @@ def main(**args):
     if args.get("float_dtype", "float32") == "float64":
         warnings.warn("float_dtype: float64 selects the engine's high-precision mode (keypoint forward AND projection in fp64; "
                       "parameters, reverse sweep and optimiser stay fp32): the fits behave like the reference's float64 run "
-                      "(DESIGN.md 3.1), they are not an end-to-end float64 evaluation")
+                      "(LAB_NOTES.md §3.1), they are not an end-to-end float64 evaluation")
     if args.get("use_cuda", True) and not torch.cuda.is_available():
         print("CUDA is not available, exiting!")
         sys.exit(-1)

@@ -268,7 +268,7 @@ def test_full_model_fit_matches_reference(gpu, synth_model, name, yaml_, mode):
     """Hands + face + contour (K = 135 / 136 keypoints, every prior term of SMPLifyLoss active, hand / face
     joint weights of the schedule) with a regression prior, coco25 and halpe formats, against the REAL
     reference's fit_single_frame (tests/golden/e2e_full.npz, fp32 and fp64 runs): camera stage 1e-4, body
-    stages within the reference's own fp32 / fp64 spread as everywhere else."""
+    stages within the reference's own fp32 / fp64 spread as everywhere else (LAB_NOTES.md §3)."""
     from smplifyx_amd import driver
     g = _golden("e2e_full")
     cfg = H.load_cfg(yaml_, interpenetration=False)

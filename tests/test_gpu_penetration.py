@@ -293,7 +293,7 @@ def test_closure_with_interpenetration_matches_oracle(synth_model, point2plane):
         lo, go = oracle(i, stage, True)
         lo_np, _ = oracle(i, stage, False)
         assert lo - lo_np > 1e-3 * lo                                  # the term matters in this pose
-        # (looser than the keypoint terms' 1e-5 / 1e-4: the cone field amplifies the 1e-7 m between two fp32 skinnings)
+        # (looser than the keypoint terms' 1e-5 / 1e-4: the cone field amplifies the 1e-7 m between two fp32 skinnings, LAB_NOTES §4.6)
         H.check_closure("pen-body-dense", stage, loss[i], lo, grad[i], go, loss_tol=1e-4, grad_tol=2e-3)
         assert np.all(grad[i][13:13 + 63] == 0)                        # dead body_pose parameter
     fb.close()
@@ -522,7 +522,7 @@ def test_pooled_batch_with_interpenetration():
     res_pool = driver.fit_frames(dm, cfg, frames["keypoints"], jw, 600, 800, 5000.0, slots=slots, **kw)
     res_all = driver.fit_frames(dm, cfg, frames["keypoints"], jw, 600, 800, 5000.0, **kw)
     res_again = driver.fit_frames(dm, cfg, frames["keypoints"], jw, 600, 800, 5000.0, **kw)
-    # A triangle that meets more than 2 x max_collisions partners in some trial pose keeps the ones that ARRIVE first:
+    # A triangle that meets more than 2 x max_collisions partners in some trial pose keeps the ones that ARRIVE first (LAB_NOTES §4.6):
     # such a frame is not reproducible run to run, whatever the batch, and the engine says which ones they are
     # (result key 'pen_order_dependent', sticky per frame over the fit).  Every other frame must come out of the pool, and out
     # of a second resident run, with the same bits.

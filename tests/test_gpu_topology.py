@@ -227,7 +227,7 @@ def test_the_reference_lines_run_on_the_stand_alone_modules(topo_model, cfg_halp
 
 def test_closure_on_the_real_surface(topo_model, cfg_halpe):
     """The halpe cfg verbatim inside the fitting closure (dense path): per stage with a collision weight, on the device's OWN
-    vertices (read back; DESIGN 4.6: at sigma 1e-4 the field amplifies the 1e-7 m between two fp32 skinnings) -- pair set
+    vertices (read back; LAB_NOTES §4.6: at sigma 1e-4 the field amplifies the 1e-7 m between two fp32 skinnings) -- pair set
     bit-exact, term's loss 2e-4, vertex gradient 3e-3 against the oracle in fp64 -- and the closure's total against the
     oracle's own end-to-end evaluation to the accuracy the term has."""
     import test_gpu_parity as T

@@ -154,7 +154,7 @@ def test_closure_with_mixture_prior_matches_oracle(g, synth_model):
 def test_fit_with_mixture_prior_matches_reference_fit(g, synth_model, mode):
     """driver.fit_frames with body_prior_type 'gmm' (no regression prior: the body pose starts from the
     mixture's mean) against the reference's fit_single_frame, tolerances from the reference's own
-    fp32 / fp64 difference as everywhere else."""
+    fp32 / fp64 difference as everywhere else (LAB_NOTES.md §3)."""
     import test_gpu_parity as T
     from smplifyx_amd import driver, prior
     cfg = _cfg()
