@@ -590,3 +590,28 @@ print(json.dumps({"loss": [float(x).hex() for x in loss.cpu().numpy()], "pairs":
     a, b = outs["chunked"], outs["unchunked"]
     assert a["pairs"][0] > 3000 and a["pairs"][1] < a["pairs"][0] and a["dropped"] == [0, 0, 0] and a["cut"] == [0, 0, 0], a
     assert a == b, (a, b)
+
+
+def test_operator_matches_the_reference_lines_golden():
+    """The device operator against numbers the REFERENCE's own lines produced: tests/golden/objective_pen.npz holds
+    SMPLifyLoss.forward's total with the collision weight at 0 and at 0.1 (fitting.py:437-455 over the CPU stand-ins of the absent
+    package) and d total / d vertices; their difference is 0.1 x the term on that mesh."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "objective_pen.npz"))
+    verts, faces = g["verts"].astype(np.float32), g["faces"].astype(np.int64)
+    ref_loss = (float(g["w01_total"]) - float(g["w0_total"])) / 0.1
+    ref_grad = g["w01_d_vertices"][0] / 0.1
+    pen = engine.Penetration(len(verts), faces, g["w01_segm"].astype(np.int64), g["parents"].astype(np.int64), ["0,1"],
+                             max_collisions=128, max_batch=1)
+    loss, dv = pen.eval(torch.tensor(verts[None], device="cuda"), 0.01)
+    st = pen.stats(1)
+    assert st["dropped"][0] == 0 and st["pairs"][0] > 200
+    # (the golden's vertices are fp64; the device rounds them to fp32: 1e-7 relative on the coordinates, amplified by 1 / sigma = 100)
+    H.check_bound("operator-vs-reference-lines", "loss", abs(float(loss[0]) - ref_loss) / ref_loss, 2e-4)
+    H.check_bound("operator-vs-reference-lines", "vertex gradient",
+                  np.linalg.norm(dv[0].cpu().numpy() - ref_grad) / np.linalg.norm(ref_grad), 2e-3)
+    # nothing between parts that never collide: one part for every triangle
+    pen1 = engine.Penetration(len(verts), faces, np.zeros(len(faces), np.int64), g["parents"].astype(np.int64), None, max_collisions=128, max_batch=1)
+    l1, d1 = pen1.eval(torch.tensor(verts[None], device="cuda"), 0.01)
+    assert float(l1[0]) == 0.0 and float(d1.abs().sum()) == 0.0 and np.abs(g["nopairs_d_vertices"]).sum() == 0
+    pen.close(); pen1.close()

@@ -87,3 +87,49 @@ def test_bvh_stand_in_caps_like_the_oracle_fit():
     loss = M.DistanceFieldPenetrationLoss(sigma=0.01)(tri, idx[None])[0]
     ref = OP.penetration_loss_ordered(torch.tensor(verts), faces, op, 0.01)
     assert abs(float(loss) - float(ref)) <= 1e-12 * float(ref)
+
+
+@pytest.mark.parametrize("tag", ["w0", "w01", "nopairs"])
+def test_objective_with_the_term_matches_the_reference_lines(tag):
+    """tests/golden/objective_pen.npz: the REAL fitting.SMPLifyLoss.forward with interpenetration=True (fitting.py:437-455 over the
+    stand-ins) -- the oracle's objective + oracle.fit_frame.FrameFit.penetration_term on the same inputs gives the same total and
+    the same gradients, with the collision weight at 0 (gate closed: the term is not evaluated, `bvh_calls` 0 in the golden), at 0.1,
+    and when the part filter leaves no pair (branch not taken: `pen_calls` 0)."""
+    import os
+    import types
+    from collections import namedtuple
+    from oracle import objective as obj
+    from oracle.fit_frame import FrameFit
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "objective_pen.npz"))
+    assert int(g["w0_bvh_calls"]) == 0 and int(g["w01_bvh_calls"]) == 1 and int(g["w01_pen_calls"]) == 1
+    assert int(g["nopairs_bvh_calls"]) == 1 and int(g["nopairs_pen_calls"]) == 0
+    T = lambda k: torch.tensor(g[k], dtype=torch.float64, requires_grad=True)
+    joints, full_pose, betas, emb = T("joints"), T("full_pose"), T("betas"), T("emb")
+    vertices = torch.tensor(g["verts"][None], dtype=torch.float64, requires_grad=True)
+    cam_t = torch.tensor([[0.05, 0.1, 20.0]], dtype=torch.float64, requires_grad=True)
+    f = torch.full([1], 5000.0, dtype=torch.float64)
+    proj = obj.project(joints, torch.eye(3, dtype=torch.float64)[None], cam_t, f, f, torch.tensor([[400.0, 300.0]], dtype=torch.float64))
+    MO = namedtuple("MO", ["full_pose", "betas", "body_pose", "left_hand_pose", "right_hand_pose", "expression", "jaw_pose"])
+    cw = float(g[tag + "_coll_loss_weight"])
+    w = {k: torch.tensor(v, dtype=torch.float64) for k, v in dict(
+        data_weight=1000 / 600, body_pose_weight=300.0, shape_weight=50.0, bending_prior_weight=3.17 * 300.0, coll_loss_weight=cw).items()}
+    terms = obj.smplify_terms(MO(full_pose, betas, emb, None, None, None, None), proj, torch.tensor(g["gt"]), torch.tensor(g["conf"]),
+                              torch.tensor(g["jw"]), w, emb, use_vposer=False, regression_pose=torch.tensor(g["reg"]), stage=1,
+                              num_stages=3, use_joints_conf=True, use_hands=False, use_face=False, rho=100)
+    ign = None if tag == "nopairs" else ["0,1"]
+    fake = types.SimpleNamespace(pen=dict(faces=g["faces"].astype(np.int64), segm=g[tag + "_segm"], parents=g["parents"], ign=ign),
+                                 cfg=dict(max_collisions=128, df_cone_height=0.01, penalize_outside=True, point2plane=False))
+    pen = FrameFit.penetration_term(fake, vertices, w)
+    total = terms["total"] if pen is None else terms["total"] + pen
+    assert (pen is None) == (tag == "w0")
+    ref_total = float(g[tag + "_total"])
+    assert abs(total.item() - ref_total) <= 1e-12 * abs(ref_total)
+    if tag == "w01":      # the term itself, not only the total it is 1e-5 of
+        ref_pen = ref_total - float(g["w0_total"])
+        assert ref_pen > 100 and abs(float(pen) - ref_pen) <= 1e-8 * ref_pen
+    total.backward()
+    for name, t in (("joints", joints), ("full_pose", full_pose), ("betas", betas), ("emb", emb), ("cam_t", cam_t), ("vertices", vertices)):
+        got = t.grad.numpy() if t.grad is not None else np.zeros(tuple(t.shape))
+        refg = g[tag + "_d_" + name]
+        assert np.allclose(got, refg, rtol=1e-9, atol=1e-12 * max(1.0, np.abs(refg).max())), (tag, name)
+    assert (np.abs(g[tag + "_d_vertices"]).sum() > 0) == (tag == "w01")

@@ -2,7 +2,7 @@
 """Generate tests/golden/*.npz by running the REAL reference (imported from
 /root/reference, this container only) on seeded inputs.  The reference Python never
 ships; only these numeric arrays do.  Re-run: `python tools/make_goldens.py [what ...]`
-with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_full_set, e2e_vposer_set, e2e_side, e2e_bench, gmm_unmerged, e2e_bench_raw_delta, smplx_topology, e2e_pen_set}.
+with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_full_set, e2e_vposer_set, e2e_side, e2e_bench, gmm_unmerged, e2e_bench_raw_delta, smplx_topology, e2e_pen_set, objective_pen}.
 
 The LBS itself has no reference implementation here (external `smplx`, absent): wherever a
 body model is needed the reference drives oracle.body_model.SMPLXRef built from
@@ -864,6 +864,68 @@ def gen_e2e_pen_set():
     _save("e2e_pen_set", **out)
 
 
+def gen_objective_pen():
+    """fitting.py:437-455 at closure level: the REAL SMPLifyLoss.forward with interpenetration=True over the CPU stand-ins for the
+    three mesh_intersection objects (oracle/mesh_intersection_cpu.py), fp64, on a small triangle soup (its own data: no licensed
+    array) -- total and every gradient incl. d total / d vertices -- for the cases the lines distinguish: collision weight 0 (the
+    `coll_loss_weight.item() > 0` gate: the term is not evaluated), 0.1 with colliding pairs, and 0.1 on a mesh whose candidate
+    pairs the part filter removes entirely (the `collision_idxs.ge(0).sum() > 0` branch).  tests/test_oracle_standins.py holds the
+    oracle's objective + penetration term to these numbers."""
+    from collections import namedtuple
+    rng = np.random.RandomState(7)
+    F, K = 300, 25
+    c = 0.6 * rng.rand(F, 3)
+    verts0 = (c[:, None, :] + 0.08 * rng.randn(F, 3, 3)).reshape(-1, 3) + [0, 0, 9.0]
+    faces = np.arange(F * 3).reshape(F, 3)
+    segm = rng.randint(0, 3, F)
+    parents = np.where(segm == 2, 1, -1)
+    out = dict(faces=faces, segm=segm, parents=parents, verts=verts0)
+    MO = namedtuple("MO", ["joints", "full_pose", "betas", "body_pose", "left_hand_pose", "right_hand_pose",
+                           "expression", "jaw_pose", "vertices"])
+    M = ref_import.install_mesh_intersection(faces, None)          # (the package's order: BVH caps, FilterFaces filters; cap 128 never binds here)
+    mk = lambda *s_: torch.tensor(rng.normal(size=s_), dtype=torch.float64, requires_grad=True)
+    joints = torch.tensor(rng.normal(size=(1, K, 3)) * 0.4 + [0, 0, 9.0], dtype=torch.float64, requires_grad=True)
+    full_pose, betas, emb = mk(1, 165), mk(1, 10), mk(1, 63)
+    reg = torch.tensor(rng.normal(size=(1, 63)), dtype=torch.float64)
+    gt = torch.tensor(rng.normal(size=(1, K, 2)) * 60 + [400, 300], dtype=torch.float64)
+    conf = torch.tensor(rng.uniform(size=(1, K)), dtype=torch.float64)
+    jw = torch.tensor((rng.uniform(size=(1, K)) > 0.2).astype(np.float64))
+    out.update(joints=joints.detach().numpy(), full_pose=full_pose.detach().numpy(), betas=betas.detach().numpy(),
+               emb=emb.detach().numpy(), reg=reg.numpy(), gt=gt.numpy(), conf=conf.numpy(), jw=jw.numpy())
+    pri = lambda t: ref.prior.create_prior(prior_type=t, dtype=torch.float64)
+    for tag, cw, all_one_part in (("w0", 0.0, False), ("w01", 0.1, False), ("nopairs", 0.1, True)):
+        sg = np.zeros(F, np.int64) if all_one_part else segm
+        cam = ref.camera.create_camera(focal_length_x=5000.0, focal_length_y=5000.0, dtype=torch.float64,
+                                       center=torch.tensor([[400.0, 300.0]], dtype=torch.float64))
+        with torch.no_grad():
+            cam.translation[:] = torch.tensor([[0.05, 0.1, 20.0]], dtype=torch.float64)
+        search_tree = M.BVH(max_collisions=128)
+        pen_distance = M.DistanceFieldPenetrationLoss(sigma=0.01, point2plane=False, vectorized=True, penalize_outside=True)
+        filt = M.FilterFaces(faces_segm=sg, faces_parents=parents, ign_part_pairs=["0,1"] if not all_one_part else None)
+        loss = ref.fitting.create_loss("smplify", rho=100, use_joints_conf=True, use_face=False, use_hands=False,
+                                       body_pose_prior=pri("l2"), shape_prior=pri("l2"), angle_prior=pri("angle"),
+                                       interpenetration=True, search_tree=search_tree, pen_distance=pen_distance,
+                                       tri_filtering_module=filt, dtype=torch.float64, regression_pose=reg, num_stages=3)
+        W = dict(data_weight=1000 / 600, body_pose_weight=300.0, shape_weight=50.0, bending_prior_weight=3.17 * 300.0,
+                 coll_loss_weight=cw)
+        loss.reset_loss_weights(W)
+        for t in (joints, full_pose, betas, emb):
+            t.grad = None
+        vertices = torch.tensor(verts0[None], dtype=torch.float64, requires_grad=True)
+        mo = MO(joints, full_pose, betas, emb, None, None, None, None, vertices)
+        total = loss(mo, camera=cam, gt_joints=gt, joints_conf=conf, body_model_faces=torch.tensor(faces.reshape(-1)),
+                     joint_weights=jw, stage=1, use_vposer=False, pose_embedding=emb)
+        total.backward()
+        g = lambda t: (t.grad.numpy().copy() if t.grad is not None else np.zeros(tuple(t.shape)))
+        out.update({tag + "_" + k: v for k, v in dict(
+            total=np.array(total.item()), coll_loss_weight=np.array(cw), segm=sg, bvh_calls=np.array(search_tree.calls),
+            pen_calls=np.array(pen_distance.calls), d_joints=g(joints), d_full_pose=g(full_pose), d_betas=g(betas), d_emb=g(emb),
+            d_vertices=g(vertices), d_cam_t=cam.translation.grad.numpy().copy()).items()})
+        print("objective_pen", tag, total.item(), "bvh calls", search_tree.calls, "pen calls", pen_distance.calls,
+              "|d verts|", np.abs(g(vertices)).sum())
+    _save("objective_pen", **out)
+
+
 def gen_smplx_topology():
     """tests/golden/smplx_topology.npz: a LOCAL, uncommitted build product (SMPL-X licence) -- tools/make_topology.py."""
     import make_topology
@@ -876,4 +938,4 @@ if __name__ == "__main__":
         {"objective": gen_objective, "lbfgs": gen_lbfgs, "euler": gen_euler, "tables": gen_tables,
          "e2e": gen_e2e, "demo": gen_demo, "e2e_vposer": gen_e2e_vposer, "parser": gen_parser, "eval": gen_eval,
          "gmm": gen_gmm, "e2e_full": gen_e2e_full, "e2e_full_set": gen_e2e_full_set, "e2e_vposer_set": gen_e2e_vposer_set, "e2e_side": gen_e2e_side, "e2e_bench": gen_e2e_bench,
-         "gmm_unmerged": gen_gmm_unmerged, "e2e_pen_set": gen_e2e_pen_set, "e2e_bench_raw_delta": gen_e2e_bench_raw_delta, "smplx_topology": gen_smplx_topology}[w]()
+         "gmm_unmerged": gen_gmm_unmerged, "e2e_pen_set": gen_e2e_pen_set, "objective_pen": gen_objective_pen, "e2e_bench_raw_delta": gen_e2e_bench_raw_delta, "smplx_topology": gen_smplx_topology}[w]()
