@@ -1131,12 +1131,12 @@ def main():
                                    "grid_entries_per_column": E_, "pairs_per_column": P_,
                                    "share_of_step": max(ms_p - 1e-3 * pair_us * n_p, 0.0) * args.prof_every / (1e3 * dt),
                                    "bytes_per_launch": by_col * want_per_launch,
-                                   "launches_per_round": 12,
+                                   "launches_per_round": int(driver.last_pen_launches),
                                    "lists_rederived_per_launch": pen_work["lists_overflowed"] / n_scopes_all,
                                    "walks_cut": pen_work["walks_cut"],
-                                   "note": "twelve dependent kernels per round, one captured graph; bound by wavefront slots x dependent "
+                                   "note": "dependent kernels of one round (launches_per_round: counted on the captured graph); bound by wavefront slots x dependent "
                                            "round trips, not by bytes (LAB_NOTES §4.6: two chains side by side take what one takes); E and P "
-                                           "are device counts over the timed region; per-kernel times and counters: profiles/r05_pen_*"}
+                                           "are device counts over the timed region; per-kernel times and counters: profiles/r06_pen_*"}
             if pmc_ok:
                 tr = sum(v.get("hbm_read_bytes_per_launch", 0.0) + v.get("hbm_write_bytes_per_launch", 0.0) for k, v in pj.items()
                          if isinstance(v, dict) and k.startswith(("k_pen_", "k_adj_", "k_lbs_dense_adj")))

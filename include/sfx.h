@@ -219,6 +219,9 @@ int  sfx_batch_pen_stats(sfx_batch* b, int32_t* stats_host /* [B][4] */, int32_t
  * such case since round 4: its kept partners -- the lowest ids -- are derived from the grid again; with max_collisions > 1024,
  * or in a mesh with more than 4096 such triangles -- one that has collapsed onto itself -- it still is.)                                                                                                              */
 int  sfx_batch_pen_flags(sfx_batch* b, int32_t* flags_host);
+/* Kernel launches of ONE interpenetration step of the fitting loop (broad phase ... adjoint), counted on the graph the batch
+ * captured for it most recently; 0 before the first fit with the term (measurement: bench.py roofline_pen.launches_per_round). */
+int  sfx_batch_pen_launches(sfx_batch* b);
 /* sfx_pen_pairs for GEMM column `column` of the batch's most recent evaluation (resident batches only). */
 int  sfx_batch_pen_pairs(sfx_batch* b, int32_t column, int32_t cap, int32_t* pairs_host, int32_t* n_out);
 

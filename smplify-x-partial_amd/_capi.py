@@ -94,6 +94,7 @@ SYMBOLS = {
     "sfx_pen_pairs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, i32p, C.POINTER(C.c_int32)]),
     "sfx_batch_pen_pairs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, i32p, C.POINTER(C.c_int32)]),
     "sfx_batch_pen_flags": (C.c_int, [C.c_void_p, i32p]),
+    "sfx_batch_pen_launches": (C.c_int, [C.c_void_p]),
     "sfx_pen_work_reset": (C.c_int, []),
     "sfx_pen_work_get": (C.c_int, [C.POINTER(C.c_int64)]),
     "sfx_batch_set_gmm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, f32p, f32p, f32p]),

@@ -131,6 +131,7 @@ int sfx_pen_eval_masked(sfx_pen* h, int32_t B, const float* verts_dev, float sig
                         float* loss_dev, float* dverts_dev, const int* want_dev, const PenAdjPrep* prep, int* over_dev, void* stream);
 int sfx_pen_capacity(const sfx_pen* h);          // meshes per call the handle's buffers hold (collide.hip)
 void sfx_pen_note_batch(sfx_pen* h, int B);      // meshes of the evaluation a replayed graph performs
+void sfx_pen_reuse(sfx_pen* h);                  // a handle taken from a model's idle slot: per-process settings of the lab build re-read
 int sfx_pen_stats_from(const int* stats_dev, int n, int32_t* stats_host);
 int sfx_pen_stats_stride(void);
 const int* sfx_pen_stats_dev(const sfx_pen* h);
@@ -143,6 +144,15 @@ struct sfx_model {
     std::vector<int> meta_host = std::vector<int>(SFX_META_N, 0);
     sfx_batch* fwd = nullptr;     // lazily created batch behind sfx_lbs_forward
     int fwd_B = 0;
+    // The collision buffers of the interpenetration term (~45 MB per GEMM column: 11.5 GB for 256 columns) outlive the batch that
+    // used them: a job is a sequence of batches on one model (driver.fit_frames per (gender, H, W) group, bench.py per step), and
+    // returning 11 GB to the driver and asking for them again cost 10 ms on some boxes and 450 ms per batch on others (round 6:
+    // `outside_loop_ms_per_step` of the --workload pen line, 402 against 239 frames/s for the same kernels).  ONE idle handle is
+    // kept per model; it is reused when it holds at least the columns asked for, at the same max_collisions and part table.
+    sfx_pen* pen_idle = nullptr;
+    int pen_idle_cols = 0, pen_idle_cap = 0, pen_idle_gen = -1;
+    int parts_gen = 0;            // bumped by sfx_model_set_parts: handles made for another part table are not reused
+    std::mutex pen_mu;
 };
 
 // The fused dense loop keeps `ahead` batches of 8 rounds queued beyond the one whose stage flags the host is waiting for: the
@@ -173,9 +183,11 @@ struct sfx_batch {
     int K = 0;
     sfx_pen* pen = nullptr;       // interpenetration operator (cfg.interpenetration)
     float pen_sigma = 0.f; int pen_outside = 1;
+    int pen_cols = 0, pen_cap = 0, pen_gen = -1;       // what b->pen was made for (returned to the model's idle slot on destroy)
     // the interpenetration step of a round of the fused loop as ONE captured graph per column count (twelve kernels; the count
     // only changes when the columns are compacted -- a handful of times per fit): one API call per round instead of twelve
     std::map<int, hipGraphExec_t> pen_graphs;
+    int pen_graph_nodes = 0;       // kernel nodes of the most recently captured interpenetration step (sfx_batch_pen_launches)
     hipStream_t cap_stream = nullptr;   // capture happens on a stream of its own (the caller's may be the legacy NULL stream, which cannot capture)
     int* pen_stats_all = nullptr; // [B][stride] diagnostics of a CHUNKED evaluation (stand-alone call on a pooled batch), else unused
     bool pen_chunked = false;     // the most recent evaluation was chunked: sfx_batch_pen_stats reads pen_stats_all
@@ -528,6 +540,7 @@ extern "C" void sfx_batch_destroy(sfx_batch* b);
 extern "C" void sfx_model_destroy(sfx_model* m) {
     if (!m) return;
     if (m->fwd) sfx_batch_destroy(m->fwd);
+    if (m->pen_idle) sfx_pen_destroy(m->pen_idle);
     m->mem.free_all();
     delete m;
 }
@@ -535,6 +548,7 @@ extern "C" void sfx_model_destroy(sfx_model* m) {
 extern "C" int sfx_model_set_parts(sfx_model* m, const int32_t* segm, const int32_t* parents, const int32_t* ign_pairs,
                                    int32_t n_ign) {
     if (!m) { sfx_set_error("null argument"); return -1; }
+    { std::lock_guard<std::mutex> lk(m->pen_mu); ++m->parts_gen; if (m->pen_idle) { sfx_pen_destroy(m->pen_idle); m->pen_idle = nullptr; } }
     if (!segm && !parents) {        // no FilterFaces module (fit_single_frame.py:316 without part_segm_fn): no pair is filtered by part
         m->segm_host.clear(); m->parents_host.clear(); m->ign_host.clear();
         return 0;
@@ -686,10 +700,23 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
         // collision buffers (partner lists, grid entries, pair list: ~45 MB per mesh at max_collisions 128) are indexed by
         // GEMM column, not by frame: a job that runs B frames through a pool of `slots` columns holds `slots` of them
         const int pen_cols = (c->slots > 0 && c->slots < B && c->lbs_mode == 1) ? std::min(B, ((c->slots + 31) / 32) * 32) : B;
-        int rc = sfx_pen_create(m->M.V, F, m->faces_host.data(), parts ? m->segm_host.data() : nullptr,
-                                parts ? m->parents_host.data() : nullptr, m->ign_host.empty() ? nullptr : m->ign_host.data(),
-                                (int)(m->ign_host.size() / 2), std::max(1, c->max_collisions), pen_cols, &b->pen);
-        if (rc) { b->mem.free_all(); delete b; return rc; }
+        const int pen_cap = std::max(1, c->max_collisions);
+        {
+            std::lock_guard<std::mutex> lk(m->pen_mu);
+            if (m->pen_idle && m->pen_idle_cols >= pen_cols && m->pen_idle_cap == pen_cap && m->pen_idle_gen == m->parts_gen) {
+                b->pen = m->pen_idle; b->pen_cols = m->pen_idle_cols;
+                m->pen_idle = nullptr;
+                sfx_pen_reuse(b->pen);
+            } else if (m->pen_idle) { sfx_pen_destroy(m->pen_idle); m->pen_idle = nullptr; }      // too small / another table: make room first
+        }
+        if (!b->pen) {
+            int rc = sfx_pen_create(m->M.V, F, m->faces_host.data(), parts ? m->segm_host.data() : nullptr,
+                                    parts ? m->parents_host.data() : nullptr, m->ign_host.empty() ? nullptr : m->ign_host.data(),
+                                    (int)(m->ign_host.size() / 2), pen_cap, pen_cols, &b->pen);
+            if (rc) { b->mem.free_all(); delete b; return rc; }
+            b->pen_cols = pen_cols;
+        }
+        b->pen_cap = pen_cap; b->pen_gen = m->parts_gen;
         b->pen_sigma = c->df_cone_height; b->pen_outside = c->penalize_outside ? 1 : 0;
         (void)sfx_pen_set_point2plane(b->pen, c->point2plane);
         D.pen_loss = b->mem.zeros<float>(B);
@@ -744,7 +771,16 @@ extern "C" void sfx_batch_destroy(sfx_batch* b) {
     for (auto& kv : b->pen_graphs) hipGraphExecDestroy(kv.second);
     b->pen_graphs.clear();
     if (b->cap_stream) hipStreamDestroy(b->cap_stream);
-    if (b->pen) sfx_pen_destroy(b->pen);
+    if (b->pen) {          // the collision buffers go back to the model's idle slot (see sfx_model)
+        sfx_model* m = b->m;
+        (void)hipDeviceSynchronize();
+        std::lock_guard<std::mutex> lk(m->pen_mu);
+        if (b->pen_gen == m->parts_gen && (!m->pen_idle || m->pen_idle_cols <= b->pen_cols)) {
+            if (m->pen_idle) sfx_pen_destroy(m->pen_idle);
+            m->pen_idle = b->pen; m->pen_idle_cols = b->pen_cols; m->pen_idle_cap = b->pen_cap; m->pen_idle_gen = b->pen_gen;
+        } else sfx_pen_destroy(b->pen);
+        b->pen = nullptr;
+    }
     if (b->D.trace) hipFree(b->D.trace);
     if (b->D.trace_n) hipFree(b->D.trace_n);
     b->mem.free_all();
@@ -1012,6 +1048,16 @@ static int eval_penetration(sfx_batch* b, int stage_override, hipStream_t s, boo
             launch_pen_adjoint(M, D, cs);
             const hipError_t ec = hipStreamEndCapture(cs, &graph);
             if (rc || ec != hipSuccess || !graph) { if (graph) hipGraphDestroy(graph); (void)hipGetLastError(); sfx_set_error("capture of the interpenetration step failed"); return rc ? rc : -2; }
+            {   // what one round launches for the term: counted on the captured graph, not written down
+                size_t nn = 0;
+                if (hipGraphGetNodes(graph, nullptr, &nn) == hipSuccess) {
+                    std::vector<hipGraphNode_t> nodes(nn);
+                    int nk = 0;
+                    if (nn && hipGraphGetNodes(graph, nodes.data(), &nn) == hipSuccess)
+                        for (size_t i = 0; i < nn; ++i) { hipGraphNodeType ty; if (hipGraphNodeGetType(nodes[i], &ty) == hipSuccess && ty == hipGraphNodeTypeKernel) ++nk; }
+                    b->pen_graph_nodes = nk;
+                }
+            }
             const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
             hipGraphDestroy(graph);
             if (ei != hipSuccess) { sfx_set_error("hipGraphInstantiate failed"); return -2; }
@@ -1402,6 +1448,11 @@ extern "C" int sfx_batch_pen_pairs(sfx_batch* b, int32_t column, int32_t cap, in
     if (!b->pen) { sfx_set_error("batch was created without interpenetration"); return -1; }
     if (b->pen_chunked) { sfx_set_error("the pair lists of a pooled batch's stand-alone evaluation are overwritten chunk by chunk"); return -1; }
     return sfx_pen_pairs(b->pen, column, cap, pairs_host, n_out);
+}
+
+extern "C" int sfx_batch_pen_launches(sfx_batch* b) {
+    if (!b) { sfx_set_error("null argument"); return -1; }
+    return b->pen_graph_nodes;
 }
 
 extern "C" int sfx_batch_pen_flags(sfx_batch* b, int32_t* flags_host /* [B] */) {

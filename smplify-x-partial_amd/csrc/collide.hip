@@ -298,6 +298,13 @@ extern "C" int sfx_pen_create(int32_t V, int32_t F, const int32_t* faces, const 
 }
 
 int sfx_pen_capacity(const sfx_pen* h) { return h ? h->Bmax : 0; }
+void sfx_pen_reuse(sfx_pen* h) {      // (api.hip: a handle taken from a model's idle slot by a new batch)
+    if (!h) return;
+    h->last_B = 0;
+#ifdef SFX_LAB
+    h->form = g_pen_form;
+#endif
+}
 void sfx_pen_note_batch(sfx_pen* h, int B) { if (h) h->last_B = B; }      // (a replayed graph of the step: api.hip eval_penetration)
 
 extern "C" int sfx_pen_set_point2plane(sfx_pen* h, int32_t on) {

@@ -122,6 +122,8 @@ def _collect(fb, prep, want_vertices):
     out["final_loss"] = out["stage_loss"][:, -1].copy()
     if fb.cfg.get("interpenetration", False):
         out["pen_order_dependent"] = fb.penetration_flags()      # frames whose collision partners depended on arrival order somewhere
+        global last_pen_launches
+        last_pen_launches = fb.penetration_launches()            # kernel launches of one step of the term (counted on the captured graph)
     if want_vertices:
         v, j = fb.forward()
         out["vertices"], out["joints"] = v.cpu().numpy(), j.cpu().numpy()
@@ -129,6 +131,7 @@ def _collect(fb, prep, want_vertices):
     return out
 
 
+last_pen_launches = 0        # of the most recent fit with the interpenetration term (bench.py roofline_pen)
 POOL_COLUMNS = 512          # GEMM columns of the pool a job larger than this is run through by default (slots=-1)
 
 

@@ -371,6 +371,10 @@ class FrameBatch(object):
         capi.check(self._lib.sfx_batch_pen_flags(self._h, capi.iptr(fl)))
         return fl != 0
 
+    def penetration_launches(self):
+        """Kernel launches of one interpenetration step of the fitting loop, counted on the captured graph (0 before a fit)."""
+        return int(self._lib.sfx_batch_pen_launches(self._h))
+
     def last_grad(self, stage):
         """Gradient [B,N] of the most recent closure evaluation (what var.grad holds after step())."""
         grad = np.zeros((self.B, self.num_vars(stage)), np.float32)
