@@ -533,7 +533,11 @@ def load_pen_golden():
     st = lambda fmt: np.stack([g[fmt % i] for i in fr])
     out = dict(frames=np.array(fr), keypoints=st("f%d_keypoints"), reg_pose=st("f%d_reg_pose"), reg_global=st("f%d_reg_global"),
                cam_prior_t=st("f%d_cam_prior_t"), r32=st("f%d_f32_losses"), r64=st("f%d_f64_losses"), r32_noterm=st("f%d_f32_noterm_losses"),
-               e32=st("f%d_f32_evals"), e64=st("f%d_f64_evals"), e32_noterm=st("f%d_f32_noterm_evals"),
+               e32=np.array([g["f%d_f32_evals_all" % i].sum() for i in fr]), e64=np.array([g["f%d_f64_evals_all" % i].sum() for i in fr]),
+               e32_noterm=np.array([g["f%d_f32_noterm_evals_all" % i].sum() for i in fr]),
+               n_orient=np.array([2 if len(g["f%d_f32_losses_all" % i]) == 7 else 1 for i in fr]),
+               kept32=st("f%d_f32_kept_orientation"), kept64=st("f%d_f64_kept_orientation"),
+               finite32=st("f%d_f32_finite"), finite64=st("f%d_f64_finite"),
                cut32=st("f%d_f32_bvh_pairs_cut"), cut64=st("f%d_f64_bvh_pairs_cut"),
                maxpairs32=st("f%d_f32_bvh_max_pairs"), maxpairs64=st("f%d_f64_bvh_max_pairs"))
     return out
@@ -571,8 +575,8 @@ def reference_parity_pen(dm, cfg, lbs_mode):
                   % g["frames"].tolist(),
         "lbs_mode": lbs_mode, "frames_fitted": int(len(fin)), "frames_scored": int(fin.sum()),
         "non_finite_here": g["frames"][~np.isfinite(ours).all(1)].tolist(),
-        "non_finite_reference_f32": g["frames"][~np.isfinite(r32).all(1)].tolist(),
-        "non_finite_reference_f64": g["frames"][~np.isfinite(r64).all(1)].tolist(),
+        "non_finite_reference_f32": g["frames"][~np.isfinite(r32).all(1) | ~g["finite32"].astype(bool)].tolist(),
+        "non_finite_reference_f64": g["frames"][~np.isfinite(r64).all(1) | ~g["finite64"].astype(bool)].tolist(),
         "camera_stage_loss_rel_delta_max": float(np.max(np.abs(rel(ours[fin, 0], r32[fin, 0])))),
         "per_stage_loss_rel_delta_mean": [float(np.mean(np.abs(rel(ours[fin, k], r32[fin, k])))) for k in range(ours.shape[1])],
         "per_stage_loss_rel_delta_median": [float(np.median(np.abs(rel(ours[fin, k], r32[fin, k])))) for k in range(ours.shape[1])],
@@ -580,7 +584,7 @@ def reference_parity_pen(dm, cfg, lbs_mode):
         "reference_f32_vs_f64_per_stage_rel_delta_mean": [float(np.mean(np.abs(rel(r64[fin, k], r32[fin, k])))) for k in range(ours.shape[1])],
         "reference_f32_vs_f64_per_stage_rel_delta_median": [float(np.median(np.abs(rel(r64[fin, k], r32[fin, k])))) for k in range(ours.shape[1])],
         "closure_evals_mean": float(res["stage_evals"].sum(1).mean()),
-        "reference_closure_evals_f32_mean": float(g["e32"].sum(1).mean()), "reference_closure_evals_f64_mean": float(g["e64"].sum(1).mean()),
+        "reference_closure_evals_f32_mean": float(g["e32"].mean()), "reference_closure_evals_f64_mean": float(g["e64"].mean()),
         "reference_frames_with_a_folded_mesh_f32": g["frames"][g["cut32"] > 0].tolist(),
         "reference_frames_with_a_folded_mesh_f64": g["frames"][g["cut64"] > 0].tolist(),
         "frames_flagged_order_dependent_here": g["frames"][np.asarray(res.get("pen_order_dependent", np.zeros(len(fin), bool)), bool)].tolist(),
