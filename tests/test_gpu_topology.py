@@ -379,3 +379,62 @@ def test_fit_on_the_real_surface_is_reproducible_and_pool_independent(topo_model
         assert np.array_equal(np.asarray(r0[k]), np.asarray(r2[k])), k
     assert not np.any(r0.get("pen_order_dependent", np.zeros(B, bool)))
     dm.close()
+
+
+def test_pen_set_matches_reference(topo_model, cfg_halpe):
+    """configs[4] end to end against the REAL reference WITH the interpenetration term (tests/golden/e2e_pen_set.npz:
+    fit_single_frame under `python -O`, fitting.py:437-455 evaluated over CPU stand-ins for the absent mesh_intersection package;
+    16 frames of the `--workload pen` sequence incl. the six on which the device meets a folded mesh; fp32 and fp64 with the term,
+    fp32 without).  The reference against itself (mean |fp64 - fp32| over the set): camera stage 1e-6, body stage 1 (collision weight
+    0) 0.25 %, stage 2 (weight 0.1) 1.6 %, stage 3 (weight 1, face keypoints on the contour's lookup table) 34 % with a median of
+    8 % -- the last stage is a lottery in the reference too (frame 0: 28 730 in fp32, 69 565 in fp64).  Required, on the frames
+    that end finite here and in the reference: camera stage 2e-4 per frame; stages 1 and 2 signed mean within +- max(the
+    reference's own mean |difference|, 3e-3 / 5e-3) and mean |difference| within twice that; stage 3 on medians (|median| within the
+    reference's own median |difference|, median |difference| within 1.5 x it); the term's effect on the stage-2 loss (with /
+    without the term, same device arithmetic) distributed like the reference's; at most one frame non-finite (the reference: its
+    fp64 fit of frame 192 ends with non-finite parameters); evaluation counts between the reference's fp32 and fp64 runs."""
+    import bench as BB
+    import test_gpu_parity as T
+    g = BB.load_pen_golden()
+    if g is None:
+        pytest.skip("tests/golden/e2e_pen_set.npz absent")
+    cfg = BB.build_cfg("pen")
+    assert cfg["max_collisions"] == cfg_halpe["max_collisions"] == 128 and cfg["coll_loss_weights"] == [0.0, 0.1, 1.0]
+    parts = synthetic.topology_parts()
+    dm = T._dm(topo_model, cfg)
+    dm.set_parts(parts["segm"], parts["parents"], cfg["ign_part_pairs"])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)          # (the cut-walk warning: expected on the folded frames)
+        res = BB.fit_pen_golden(dm, cfg, g)
+        res0 = BB.fit_pen_golden(dm, cfg, g, interpenetration=False)
+    ours, ours0 = res["stage_loss"].astype(np.float64), res0["stage_loss"].astype(np.float64)
+    r32, r64, r0 = g["r32"], g["r64"], g["r32_noterm"]
+    n = len(g["frames"])
+    assert n >= 16 and list(res["n_orient"]) == list(g["n_orient"])
+    rel = lambda a, b: (a - b) / np.abs(b)
+    assert np.abs(rel(ours[:, 0], r32[:, 0])).max() < 2e-4, rel(ours[:, 0], r32[:, 0])
+    bad = ~np.isfinite(ours).all(1)
+    assert bad.sum() <= 1, g["frames"][bad]
+    assert np.isfinite(ours0).all()                                # without the term nothing diverges
+    ok = ~bad & np.isfinite(r32).all(1) & np.isfinite(r64).all(1)
+    d, y = rel(ours[ok], r32[ok]), rel(r64[ok], r32[ok])
+    for k, floor in ((1, 3e-3), (2, 5e-3)):
+        yard = max(np.abs(y[:, k]).mean(), floor)
+        H.check_bound("pen-set", "stage %d signed mean / yard" % k, abs(d[:, k].mean()) / yard, 1.0)
+        H.check_bound("pen-set", "stage %d mean |difference| / yard" % k, np.abs(d[:, k]).mean() / yard, 2.0)
+    H.check_bound("pen-set", "stage 3 |median| / reference's median |difference|", abs(np.median(d[:, 3])) / np.median(np.abs(y[:, 3])), 1.0)
+    H.check_bound("pen-set", "stage 3 median |difference| / reference's", np.median(np.abs(d[:, 3])) / np.median(np.abs(y[:, 3])), 1.5)
+    # what the term does to the stage-2 loss: here (with / without on the device) and in the reference (fp32 with / without)
+    eff, eff_ref = rel(ours[ok, 2], ours0[ok, 2]), rel(r32[ok, 2], r0[ok, 2])
+    assert (eff > 0).sum() >= ok.sum() - 1 and (eff_ref > 0).sum() >= ok.sum() - 1, (eff, eff_ref)
+    H.check_bound("pen-set", "term's stage-2 effect, |log(median here / median reference)|",
+                  abs(np.log(np.median(eff) / np.median(eff_ref))), np.log(2.0))
+    ev = res["stage_evals"].sum(1).mean()
+    assert 0.7 * g["e32"].mean() <= ev <= 1.1 * g["e64"].mean(), (ev, g["e32"].mean(), g["e64"].mean())
+    # the frames on which the reference's BVH stand-in met a folded mesh (cap binding) are the side views' flipped orientation: the
+    # device flags a cut bucket walk on a subset of the same frames
+    folded_ref = set(g["frames"][(g["cut32"] > 0) | (g["cut64"] > 0)].tolist())
+    flagged = set(g["frames"][np.asarray(res["pen_order_dependent"], bool)].tolist())
+    assert len(flagged - folded_ref) <= 1, (flagged, folded_ref)
+    dm.close()
