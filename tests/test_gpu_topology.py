@@ -438,3 +438,42 @@ def test_pen_set_matches_reference(topo_model, cfg_halpe):
     flagged = set(g["frames"][np.asarray(res["pen_order_dependent"], bool)].tolist())
     assert len(flagged - folded_ref) <= 1, (flagged, folded_ref)
     dm.close()
+
+
+def test_collision_buffers_are_reused_only_for_the_same_part_table(topo_model, cfg_halpe):
+    """Round 6: the collision buffers of a batch go back to the model when the batch is closed and serve the next batch (11 GB of
+    hipFree / hipMalloc per 256-column batch otherwise).  A batch created after `set_parts` with ANOTHER table must not get the old
+    handle: the pair set of the same body follows the table -- with the cfg's ign_part_pairs, without them, with them again -- and
+    equals the oracle's each time; a batch with another max_collisions gets its own cap."""
+    import test_gpu_parity as T
+    model, cfg = topo_model, cfg_halpe
+    parts = synthetic.topology_parts()
+    faces = np.asarray(model["f"]).astype(np.int64)
+    dm = T._dm(model, cfg)
+    K = len(H.joint_map_for(cfg))
+    frames = synthetic.make_frames(1, H.oracle_joints_fn(model, cfg), K, focal=5000.0)
+
+    def pairs_with(ign, c=cfg):
+        dm.set_parts(parts["segm"], parts["parents"], ign)
+        fb = H.engine_batch_from_frames(dm, c, frames, [0], lbs_mode="dense")
+        fb.set_params(regression_pose=frames["reg_pose"], global_orient=frames["reg_global"], pose_embedding=frames["reg_pose"],
+                      cam_translation=frames["cam_t"])
+        fb.closure(2)
+        vd = fb.debug_read("verts").reshape(1, -1, 3).astype(np.float64)[0]
+        un, both = _unordered(fb.penetration_pairs(0))
+        st = fb.penetration_stats()
+        fb.close()
+        want = OP.candidate_pairs_sweep(vd, faces, parts["segm"], parts["parents"], ign)
+        assert both and np.array_equal(un, want), (ign, len(un), len(want))
+        return len(un), int(st["dropped"][0])
+    a, _ = pairs_with(cfg["ign_part_pairs"])
+    b, _ = pairs_with(None)
+    c, _ = pairs_with(cfg["ign_part_pairs"])
+    assert a == c and b > a > 100, (a, b, c)
+    c4 = dict(cfg); c4["max_collisions"] = 4
+    dm.set_parts(parts["segm"], parts["parents"], cfg["ign_part_pairs"])
+    fb = H.engine_batch_from_frames(dm, c4, frames, [0], lbs_mode="dense")
+    fb.set_params(regression_pose=frames["reg_pose"], global_orient=frames["reg_global"], pose_embedding=frames["reg_pose"], cam_translation=frames["cam_t"])
+    fb.closure(2)
+    assert fb.penetration_stats()["dropped"][0] > 0            # the cap of 4 binds: not the 128-partner handle of the batches before
+    fb.close(); dm.close()
