@@ -338,3 +338,24 @@ def test_penetration_gradient_finite_differences_and_invariants():
         mine = np.sort(op[op[:, 0] == t, 1])
         allp = np.sort(np.concatenate([pairs[pairs[:, 0] == t, 1], pairs[pairs[:, 1] == t, 0]]))
         assert len(mine) <= cap and set(mine) <= set(allp[:cap])
+
+
+def test_cubic_interpolation_overflow_matches_reference():
+    """tests/golden/cubic_overflow.npz: the reference's _cubic_interpolate (lbfgs_ls.py:11-36) with Python-float function values and
+    0-d TENSOR directional derivatives where a trial point evaluates to 1e19 ... 3e29 (what a unit step along a direction blown up
+    by the interpenetration term produces: tools/pen_nan_probe.py).  In fp32 `d1 ** 2` overflows and NaN comes back through
+    min(max(...)); in fp64 the same inputs give a finite step.  The specification machine's dual-typed scalars reproduce both --
+    the device's NaN on such a fit is the reference's own arithmetic, not a difference from it."""
+    from oracle import lbfgs_machine as LM
+    g = gold("cubic_overflow")
+    for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        old = LM.Sc.dt
+        LM.Sc.dt = dt
+        try:
+            for row, want in zip(g["rows"], g[tag]):
+                x1, f1, g1, x2, f2, g2 = (float(v) for v in row)
+                got = LM.cubic_interpolate(LM.P(x1), LM.P(f1), LM.T(g1), LM.P(x2), LM.P(f2), LM.T(g2)).v
+                assert (np.isnan(got) and np.isnan(want)) or got == dt(want) or abs(float(got) - want) <= 1e-6 * abs(want), (tag, row, got, want)
+        finally:
+            LM.Sc.dt = old
+    assert np.isnan(g["f32"][:3]).all() and np.isfinite(g["f64"]).all()

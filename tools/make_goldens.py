@@ -2,7 +2,7 @@
 """Generate tests/golden/*.npz by running the REAL reference (imported from
 /root/reference, this container only) on seeded inputs.  The reference Python never
 ships; only these numeric arrays do.  Re-run: `python tools/make_goldens.py [what ...]`
-with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_full_set, e2e_vposer_set, e2e_side, e2e_bench, gmm_unmerged, e2e_bench_raw_delta, smplx_topology, e2e_pen_set, objective_pen}.
+with what in {objective, lbfgs, euler, tables, e2e, demo, e2e_vposer, parser, eval, gmm, e2e_full, e2e_full_set, e2e_vposer_set, e2e_side, e2e_bench, gmm_unmerged, e2e_bench_raw_delta, smplx_topology, e2e_pen_set, objective_pen, cubic_overflow}.
 
 The LBS itself has no reference implementation here (external `smplx`, absent): wherever a
 body model is needed the reference drives oracle.body_model.SMPLXRef built from
@@ -926,6 +926,28 @@ def gen_objective_pen():
     _save("objective_pen", **out)
 
 
+def gen_cubic_overflow():
+    """_cubic_interpolate (lbfgs_ls.py:11-36) where a trial point of the line search evaluates to ~1e29 (a unit step along an L-BFGS
+    direction blown up by the interpenetration term: tools/pen_nan_probe.py, frame 92 of the configs[4] job): function values are
+    Python floats, directional derivatives 0-d tensors of the model's dtype, so `d1 ** 2` overflows in fp32 and the result is NaN,
+    which min(max(...)) passes on; in fp64 it is finite.  Rows: x1, f1, g1, x2, f2, g2 -> t in fp32 and fp64."""
+    rows = np.array([[0.0, 9.093459e4, -7.7e4, 1.0, 2.782107e29, 5.0e29],
+                     [0.0, 9.093459e4, -7.7e4, 1.0, 2.782107e29, 5.564215e29],
+                     [0.0, 1.0e5, -1.0e3, 1.0, 1.0e19, 1.0e19],          # just below the overflow of d1 ** 2 in fp32
+                     [0.0, 1.0e5, -1.0e3, 1.0, 1.0e20, 3.0e20],          # just above
+                     [0.0, 1.0e5, -1.0e3, 2.0, 3.0e5, 4.0e5],            # an ordinary bracket
+                     [1.0, 5.0, -2.0, 0.25, 4.0, 1.0]])
+    out = {"rows": rows}
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        r = []
+        for x1, f1, g1, x2, f2, g2 in rows:
+            v = ref.lbfgs_ls._cubic_interpolate(float(x1), float(f1), torch.tensor(g1, dtype=dt), float(x2), float(f2), torch.tensor(g2, dtype=dt))
+            r.append(float(v))
+        out[tag] = np.array(r, np.float64)
+        print("cubic", tag, out[tag])
+    _save("cubic_overflow", **out)
+
+
 def gen_smplx_topology():
     """tests/golden/smplx_topology.npz: a LOCAL, uncommitted build product (SMPL-X licence) -- tools/make_topology.py."""
     import make_topology
@@ -938,4 +960,4 @@ if __name__ == "__main__":
         {"objective": gen_objective, "lbfgs": gen_lbfgs, "euler": gen_euler, "tables": gen_tables,
          "e2e": gen_e2e, "demo": gen_demo, "e2e_vposer": gen_e2e_vposer, "parser": gen_parser, "eval": gen_eval,
          "gmm": gen_gmm, "e2e_full": gen_e2e_full, "e2e_full_set": gen_e2e_full_set, "e2e_vposer_set": gen_e2e_vposer_set, "e2e_side": gen_e2e_side, "e2e_bench": gen_e2e_bench,
-         "gmm_unmerged": gen_gmm_unmerged, "e2e_pen_set": gen_e2e_pen_set, "objective_pen": gen_objective_pen, "e2e_bench_raw_delta": gen_e2e_bench_raw_delta, "smplx_topology": gen_smplx_topology}[w]()
+         "gmm_unmerged": gen_gmm_unmerged, "e2e_pen_set": gen_e2e_pen_set, "objective_pen": gen_objective_pen, "cubic_overflow": gen_cubic_overflow, "e2e_bench_raw_delta": gen_e2e_bench_raw_delta, "smplx_topology": gen_smplx_topology}[w]()
