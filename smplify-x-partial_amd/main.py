@@ -70,6 +70,18 @@ def _camera_prior(regression_prior, focal_length, pixie, expose, pare):
     raise ValueError("unknown regression prior %r" % regression_prior)
 
 
+def rank_share(items, cfg, joint_weights, rank, world):
+    """This rank's frames of a multi-GPU job: the frames known to be long before the fit (driver.predicted_cost: side views,
+    under-determined cameras) are dealt over the ranks back and forth (dist.shard_by_cost) -- a contiguous block
+    (dist.shard_range) can hand one GPU all the side views of a sequence.  Every frame goes to exactly one rank; a rank walks
+    its frames in input order."""
+    if world <= 1 or not items:
+        return items
+    kp_all = np.stack([it["keypoints"] for it in items]).astype(np.float32)
+    cost = driver.predicted_cost(cfg, driver.prepare_frames(cfg, kp_all, joint_weights))
+    return [items[i] for i in sdist.shard_by_cost(cost, rank, world)]
+
+
 def main(**args):
     output_folder = osp.expandvars(args.pop("output_folder"))
     rank, world = (torch.distributed.get_rank(), torch.distributed.get_world_size()) \
@@ -133,12 +145,7 @@ def main(**args):
             img_name = data["img_path"].split("images")[-1].split(".")[0].lstrip("/\\")
             items.append(dict(fn=data["fn"], person=person_id, H=H_, W=W_, img_name=img_name,
                               keypoints=keypoints[person_id], gender=input_gender))
-    if world > 1 and items:
-        # this rank's share: the frames known to be long before the fit (driver.predicted_cost) are dealt round-robin over the
-        # ranks -- a contiguous block (dist.shard_range) can hand one GPU all the side views of a sequence
-        kp_all = np.stack([it["keypoints"] for it in items]).astype(np.float32)
-        cost = driver.predicted_cost(args, driver.prepare_frames(args, kp_all, joint_weights))
-        items = [items[i] for i in sdist.shard_by_cost(cost, rank, world)]
+    items = rank_share(items, args, joint_weights, rank, world)
     groups = {}
     for it in items:
         groups.setdefault((it["gender"], it["H"], it["W"]), []).append(it)

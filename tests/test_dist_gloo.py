@@ -57,3 +57,26 @@ def test_shard_and_gather_world2(tmp_path):
         assert np.array_equal(got, want)
     u = sd.unpack_records(want)
     assert np.array_equal(u["frame"][:, 0], np.arange(n)) and u["body_pose"].shape == (n, 63)
+
+
+def test_main_deals_the_long_frames_over_the_ranks():
+    """main.rank_share: every frame to exactly one rank, input order kept within a rank, and the side views (fitted twice) of a
+    sequence that holds them in one stretch spread over the ranks instead of landing on one."""
+    from smplifyx_amd import main as M
+    cfg = dict(format="coco25", confidence_threshold=0.2, init_joints_idxs=[9, 12, 2, 5], side_view_thsh=25.0,
+               left_shoulder_idx=2, right_shoulder_idx=5)
+    rng = np.random.RandomState(0)
+    items = []
+    for i in range(40):
+        kp = np.concatenate([rng.uniform(100, 500, size=(25, 2)), rng.uniform(0.5, 1.0, size=(25, 1))], 1).astype(np.float32)
+        if 8 <= i < 16:
+            kp[5, :2] = kp[2, :2] + 3.0                    # shoulders 3 px apart: a side view
+        items.append(dict(fn="f%02d" % i, keypoints=kp))
+    jw = np.ones(25, np.float32)
+    shares = [M.rank_share(items, cfg, jw, r, 4) for r in range(4)]
+    names = [[it["fn"] for it in s_] for s_ in shares]
+    assert sorted(sum(names, [])) == sorted(it["fn"] for it in items)
+    assert all(n == sorted(n) for n in names) and max(map(len, names)) - min(map(len, names)) <= 1
+    side = [sum(1 for n in s_ if 8 <= int(n[1:]) < 16) for s_ in names]
+    assert side == [2, 2, 2, 2], side                      # (contiguous blocks of ten: [2, 6, 0, 0])
+    assert M.rank_share(items, cfg, jw, 0, 1) is items
