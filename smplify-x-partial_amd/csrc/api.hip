@@ -689,7 +689,6 @@ extern "C" int sfx_batch_create(sfx_model* m, const sfx_batch_cfg* c, const sfx_
     D.f = b->mem.zeros<float>(B);
     D.g = b->mem.zeros<float>((size_t)B * SFX_NVAR_MAX);
     D.bodypose = b->mem.zeros<float>((size_t)B * 63);
-    D.vp_dbody = c->use_vposer ? b->mem.zeros<float>((size_t)B * 64) : nullptr;
     D.featR = b->mem.zeros<float>((size_t)SFX_KD_PAD * D.Bpad);
     D.AT = b->mem.zeros<float>((size_t)12 * SFX_JPAD * D.Bpad);
     D.verts = b->mem.zeros<float>((size_t)B * m->M.V * 3);

@@ -371,13 +371,8 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     const float* bodypose = S.x + L.emb;
     if constexpr (HAS_VP) {
         if (C.use_vposer && !reuse) {          // body_pose = vposer.decode(pose_embedding) (fitting.py:236-238)
-            if (args.vp_split) {               // decoded by k_vp_forward over all frames (fused.hip): activations and pose are in D.fwd
-                if (t < 64) S.V.body[t] = fwd[FWD_PREFIX + 96 + 2 * VP_H + 128 + t];
-                __syncthreads();
-            } else {
-                vposer_forward<CT>(S.V, M, S.x + L.emb, S.T);
-                if (t < 63) D.bodypose[(size_t)b * 63 + t] = S.V.body[t];
-            }
+            vposer_forward<CT>(S.V, M, S.x + L.emb, S.T);
+            if (t < 63) D.bodypose[(size_t)b * 63 + t] = S.V.body[t];
         }
         if (C.use_vposer) bodypose = S.V.body;
     }
@@ -536,7 +531,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
                 float* ex = fwd + FWD_PREFIX;
                 if (t < SFX_NHAND) { ex[t] = S.lh45[t]; ex[SFX_NHAND + t] = S.rh45[t]; }
                 if (t == 64) ex[2 * SFX_NHAND] = __int_as_float(S.lut_row);
-                if constexpr (HAS_VP) if (C.use_vposer && !args.vp_split) {      // (split form: k_vp_forward has written them there)
+                if constexpr (HAS_VP) if (C.use_vposer) {
                     float* vx = ex + 96;
                     for (int i = t; i < VP_H; i += CT) { vx[i] = S.V.h1[i]; vx[VP_H + i] = S.V.h2[i]; }
                     if (t < 128) vx[2 * VP_H + t] = S.V.o[t];
@@ -1111,10 +1106,7 @@ __device__ __forceinline__ void closure_body(LDS& S, const DevModel& M, const Ba
     }
     __syncthreads();
     MARK(15);
-    if constexpr (HAS_VP) if (C.use_vposer) {
-        if (args.vp_split) { if (t < 64) D.vp_dbody[(size_t)b * 64 + t] = t < 63 ? S.dpose[3 + t] : 0.f; }      // k_vp_backward adds d latent to D.g
-        else vposer_backward<CT>(S.V, M, &S.dpose[3], &S.gc[L.emb], S.T);   // d body_pose -> d latent
-    }
+    if constexpr (HAS_VP) if (C.use_vposer) vposer_backward<CT>(S.V, M, &S.dpose[3], &S.gc[L.emb], S.T);   // d body_pose -> d latent
     const VarList& vl = vls[cam_stage ? 0 : 1];
     float* gout = D.g + (size_t)b * SFX_NVAR_MAX;
     for (int i = t; i < vl.n; i += CT) { const float gv = S.gc[vl.idx[i]]; gout[i] = gv; if (gflat) gflat[i] = gv; }

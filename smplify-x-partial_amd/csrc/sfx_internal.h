@@ -191,7 +191,6 @@ struct BatchDev {
     float* f;          // [B] loss at Xt
     float* g;          // [B][NVAR_MAX] flat gradient at Xt
     float* bodypose;   // [B][63] decoded body pose (VPoser) scratch
-    float* vp_dbody;   // [B][64] d loss / d body_pose of the most recent evaluation (split form of the tick: k_vp_backward's input)
     // dense path
     float* featR;      // [Bpad][KD_PAD]: one 2-KiB row of blend-shape coefficients per GEMM column (frame)
     float* AT;         // [12][JPAD][Bpad]
@@ -262,9 +261,6 @@ struct ClosureArgs {
     int keep_tables;        // 1: S.meta / S.fd are still valid from the previous evaluation of this workgroup
     int reuse_fwd;          // 1: forward state of this trial point was saved by the export pass
     const float* x_lds;     // the trial point in the workgroup's LDS (k_tick_dense: left there by the optimiser tick); NULL: read X / Xt
-    int vp_split;           // 1: the VPoser products of this evaluation run in kernels of their own over all frames (fused.hip: the
-                            //    split form of the tick): an export pass takes the decoded body pose from D.fwd, an adjoint pass leaves
-                            //    d body_pose in D.vp_dbody instead of walking the decoder back
 };
 // the 47-KB closure variant serves models whose keypoints need at most SFX_SMALL_ITEMS vertex rows
 // when the VPoser decoder is not in the loop

@@ -410,40 +410,6 @@ def test_vposer_set_matches_reference(gpu, synth_model, mode):
     assert np.median(np.abs(d[:, 5])) <= 1.5 * np.median(np.abs(y[:, 5])), (np.median(np.abs(d[:, 5])), np.median(np.abs(y[:, 5])))
 
 
-def test_split_form_of_the_vposer_tick_gives_the_fused_kernels_bits(gpu, synth_model):
-    """EXPERIMENT (round 6, reverted by the next commit): the split form of the tick (csrc/fused.hip k_vp_forward / k_vp_backward)
-    against the fused kernel -- the 16 golden frames of e2e_vposer_set alone (fused) and inside a 224-frame batch (split until fewer
-    than 200 frames run); in the lab build also with the form forced / never taken: bit for bit."""
-    import os
-    from smplifyx_amd import synthetic, driver
-    g = _golden("e2e_vposer_set")
-    cfg = H.load_cfg("fit_smplx_smplifyx.yaml")
-    dm = _dm(synth_model, cfg, vposer=synthetic.make_synthetic_vposer(0))
-    n = 16
-    kp = g["keypoints"][:n]
-    jw = H.base_joint_weights(cfg, kp.shape[1])
-
-    def fit(k):
-        big = np.concatenate([kp] * (k // n + 1))[:k].copy()
-        for r in range(1, k // n + 1):
-            big[r * n:(r + 1) * n, :, :2] += 0.11 * r
-        return driver.fit_frames(dm, cfg, big, jw, 600, 800, 5000.0, lbs_mode="dense")
-    keys = ("stage_loss", "stage_evals", "pose_embedding", "betas", "global_orient", "cam_translation", "left_hand_pose", "expression")
-    a = fit(n)
-    b = fit(224)
-    for k_ in keys:
-        assert np.array_equal(np.asarray(a[k_]), np.asarray(b[k_])[:n], equal_nan=True), k_
-    if H.has_lab():
-        for val in ("1", "1000000"):
-            os.environ["SFX_TICK_SPLIT"] = val
-            try:
-                c = fit(n)
-            finally:
-                del os.environ["SFX_TICK_SPLIT"]
-            for k_ in keys:
-                assert np.array_equal(np.asarray(a[k_]), np.asarray(c[k_]), equal_nan=True), (val, k_)
-
-
 def test_continuous_batching_matches_resident_batch(gpu, synth_model):
     """Dense mode with a column pool smaller than the job (cfg.slots: frames queue and take over the columns of
     frames that finish) gives every frame the result it has when all frames are resident -- bit for bit: frames are
